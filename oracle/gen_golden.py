@@ -1,0 +1,216 @@
+"""Generate tests/golden/*.npz by IMPORTING the reference (build container only).
+
+TEST INFRASTRUCTURE.  Run:  python -m oracle.gen_golden
+Needs /root/reference; the produced fixtures are data only (inputs + the
+reference's outputs) and travel to the GPU box, the reference does not.
+
+Fixtures:
+  fill_gridmap_native.npz   EnvBatch.getGlobalMap sequences (env.py:267-374): random walk,
+                            all-zero depth first step, negative coords, arbitrary headings
+  nav_reduced.npz           forward('navigation') (vilmodel.py:782-918), reduced config
+                            (1/1/1 layers, FFN 64, vocab 2000), B=3 ragged N; all outputs +
+                            the grid_encoder input/mask captured by a forward pre-hook
+  nav_reduced_obj.npz       same with obj_feat_size=768 (og_head + vp_obj_masks)
+  nav_full_b2.npz           full-size config (9/2/4 layers, 161 M params), B=2, t=3;
+                            inputs regenerated from seeds -> only outputs stored
+  text_pano_reduced.npz     forward('language') / forward('panorama') reduced config
+Weights are never stored: both sides regenerate them with ref_harness.det_tensor.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_harness as R
+from . import gridmap_oracle as G
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gridmm_amd import synthetic as S  # noqa: E402  (input generators only)
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+REDUCED = dict(num_l_layers=1, num_pano_layers=1, num_x_layers=1, intermediate_size=64, vocab_size=2000)
+
+
+def _versions():
+    import transformers
+    return json.dumps({"numpy": np.__version__, "torch": torch.__version__,
+                       "transformers": transformers.__version__})
+
+
+def _full_depth(depth_s):
+    """Embed sampled (12,49) depth into a (36,128,128,1) map at the reference's sample indices."""
+    full = np.zeros((36, 128, 128, 1), np.uint16)
+    idx = G.NATIVE.sample_index()
+    for v in range(12):
+        full[12 + v][np.ix_(idx, idx)] = depth_s[v].reshape(7, 7, 1)
+    return full
+
+
+def gen_fill_gridmap():
+    rs = np.random.RandomState(1234)
+    episodes = []
+    # A: random walk, 4 steps;  B: all-zero depth first step;  C: far-negative coords + odd headings
+    for name, steps in (("A", 4), ("B", 3), ("C", 4), ("D", 1)):
+        obs = S.make_observations(rs, S.NATIVE, steps, feat_scale=1.0)
+        if name == "B":
+            obs[0]["depth"][:] = 0
+        if name == "C":
+            for o in obs:
+                o["x"] -= 137.25
+                o["y"] -= 61.125
+                o["heading"] = float(rs.uniform(-7, 7))
+        if name == "D":
+            obs[0]["depth"][:, ::2] = 0
+        episodes.append(obs)
+    depth_db, clip_db, info = {}, {}, {}
+    for e, obs in enumerate(episodes):
+        for t, o in enumerate(obs):
+            key = "s%d_v%d" % (e, t)
+            depth_db[key] = _full_depth(o["depth"])
+            clip = np.zeros((12, 50, 768), np.float16)
+            clip[:, 1:] = o["feats"].reshape(12, 49, 768)
+            clip_db[key] = clip
+            info[key] = {"x": o["x"], "y": o["y"]}
+    env = R.RefGridEnv(len(episodes), depth_db, clip_db, info)
+    out = {"versions": _versions(), "n_episodes": len(episodes)}
+    for e, obs in enumerate(episodes):
+        out["e%d_steps" % e] = len(obs)
+        for t, o in enumerate(obs):
+            sem, gmap, pos = env.step(e, "s%d" % e, "v%d" % t, o["heading"])
+            assert sem.shape[0] == 588 * (t + 1)
+            assert np.array_equal(sem[-588:], o["feats"])
+            p = "e%d_t%d_" % (e, t)
+            out[p + "depth"] = o["depth"]
+            out[p + "pose"] = np.array([o["x"], o["y"], o["heading"]], np.float64)
+            out[p + "grid_map"] = gmap.astype(np.int16)
+            out[p + "pos_fts"] = pos.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "fill_gridmap_native.npz"), **out)
+    print("fill_gridmap_native: ok")
+
+
+def _nav_inputs(seed, B, Ns, L, G_, V1, n_cand, n_visited, with_obj=False, feat_scale=0.35):
+    rs = np.random.RandomState(seed)
+    batch = S.make_nav_batch(rs, B, L=L, G=G_, n_visited=n_visited, V1=V1, n_cand=n_cand,
+                             min_len=max(2, L // 3), with_obj=with_obj)
+    grid_fts, grid_map, pos = [], [], []
+    for b in range(B):
+        n = Ns[b]
+        grid_fts.append(torch.from_numpy((rs.standard_normal((n, 768)) * feat_scale).astype(np.float16)))
+        gm = rs.randint(-1, 196, size=n).astype(np.float64)
+        if b == 1:  # sparse occupancy: few cells -> exercises the compaction-mask quirk
+            gm = rs.choice([-1, 3, 17, 18, 95, 96, 150, 195], size=n).astype(np.float64)
+        grid_map.append(torch.from_numpy(gm))
+        pos.append(torch.from_numpy(G.gridmap_pos_fts(np.float32(rs.uniform(2, 9)))))
+    batch["grid_fts"], batch["grid_map"] = grid_fts, grid_map
+    batch["gridmap_pos_fts"] = torch.stack(pos, 0)
+    return batch
+
+
+def _pack_batch(out, batch):
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            out["in_" + k] = v.numpy()
+        elif k in ("grid_fts", "grid_map"):
+            for b, t in enumerate(v):
+                out["in_%s_%d" % (k, b)] = t.numpy()
+        elif k in ("gmap_vpids", "vp_cand_vpids"):
+            out["in_" + k] = json.dumps(v)
+
+
+def _run_nav(model, batch):
+    cap = {}
+
+    def hook(mod, args, kwargs):
+        cap["map_embeds"] = args[0].detach().clone()
+        cap["kpm"] = kwargs["src_key_padding_mask"].detach().clone()
+
+    h = model.grid_encoder.register_forward_pre_hook(hook, with_kwargs=True)
+    with torch.no_grad():
+        outs = model("navigation", batch)
+    h.remove()
+    return outs, cap
+
+
+def gen_nav_reduced(with_obj):
+    torch.set_num_threads(1)
+    over = dict(REDUCED)
+    if with_obj:
+        over["obj_feat_size"] = 768
+    model = R.build_ref_model(seed=7, **over)
+    batch = _nav_inputs(seed=99 + int(with_obj), B=3, Ns=[230, 170, 96], L=12, G_=7, V1=9, n_cand=3,
+                        n_visited=2, with_obj=with_obj)
+    outs, cap = _run_nav(model, batch)
+    out = {"versions": _versions(), "weight_seed": 7, "cfg": json.dumps(over),
+           "param_names": json.dumps([k for k in model.state_dict()]),
+           "param_shapes": json.dumps([list(v.shape) for v in model.state_dict().values()])}
+    _pack_batch(out, batch)
+    for k, v in outs.items():
+        if v is not None:
+            out["out_" + k] = v.numpy()
+    C = cap["map_embeds"].shape[1] - batch["gmap_masks"].shape[1]
+    out["cap_grid_map_embeds"] = cap["map_embeds"][:, :C].numpy()
+    out["cap_grid_masks"] = cap["kpm"][:, :C].logical_not().numpy()
+    name = "nav_reduced_obj.npz" if with_obj else "nav_reduced.npz"
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "ok  Cmax=%d" % C, {k: tuple(v.shape) for k, v in outs.items() if v is not None})
+
+
+def full_b2_inputs():
+    """Inputs of nav_full_b2 (regenerated identically by the tests from these seeds)."""
+    return _nav_inputs(seed=4242, B=2, Ns=[1764, 1176], L=40, G_=12, V1=37, n_cand=4, n_visited=4)
+
+
+def gen_nav_full():
+    torch.set_num_threads(4)
+    model = R.build_ref_model(seed=3)
+    batch = full_b2_inputs()
+    outs, cap = _run_nav(model, batch)
+    out = {"versions": _versions(), "weight_seed": 3, "cfg": json.dumps({}),
+           "param_names": json.dumps([k for k in model.state_dict()]),
+           "param_shapes": json.dumps([list(v.shape) for v in model.state_dict().values()])}
+    for k, v in outs.items():
+        if v is not None:
+            out["out_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "nav_full_b2.npz"), **out)
+    print("nav_full_b2 ok", {k: float(v[torch.isfinite(v)].abs().max()) for k, v in outs.items() if v is not None})
+
+
+def gen_text_pano():
+    torch.set_num_threads(1)
+    model = R.build_ref_model(seed=7, **REDUCED)
+    rs = np.random.RandomState(5)
+    B, L = 3, 14
+    lens = np.array([14, 9, 5])
+    txt_ids = rs.randint(1, 2000, size=(B, L)).astype(np.int64) * (np.arange(L)[None] < lens[:, None])
+    txt_masks = np.arange(L)[None] < lens[:, None]
+    view = rs.standard_normal((B, 36, 768)).astype(np.float32)
+    loc = rs.uniform(-1, 1, size=(B, 36, 7)).astype(np.float32)
+    nav_types = (rs.rand(B, 36) < 0.15).astype(np.int64)
+    view_lens = np.array([36, 36, 36], np.int64)
+    with torch.no_grad():
+        txt = model("language", {"txt_ids": torch.from_numpy(txt_ids), "txt_masks": torch.from_numpy(txt_masks)})
+        pano, pmask = model("panorama", {
+            "view_img_fts": torch.from_numpy(view), "obj_img_fts": None, "loc_fts": torch.from_numpy(loc),
+            "nav_types": torch.from_numpy(nav_types), "view_lens": torch.from_numpy(view_lens), "obj_lens": None})
+    np.savez_compressed(
+        os.path.join(OUT, "text_pano_reduced.npz"), versions=_versions(), weight_seed=7, cfg=json.dumps(REDUCED),
+        param_names=json.dumps([k for k in model.state_dict()]),
+        param_shapes=json.dumps([list(v.shape) for v in model.state_dict().values()]),
+        in_txt_ids=txt_ids, in_txt_masks=txt_masks, in_view_img_fts=view, in_loc_fts=loc,
+        in_nav_types=nav_types, in_view_lens=view_lens, out_txt_embeds=txt.numpy(),
+        out_pano_embeds=pano.numpy(), out_pano_masks=pmask.numpy())
+    print("text_pano_reduced ok")
+
+
+if __name__ == "__main__":
+    assert R.reference_available(), "needs /root/reference"
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano"]
+    if "fill" in which: gen_fill_gridmap()
+    if "nav" in which: gen_nav_reduced(False)
+    if "navobj" in which: gen_nav_reduced(True)
+    if "textpano" in which: gen_text_pano()
+    if "full" in which: gen_nav_full()
