@@ -1,0 +1,323 @@
+// Instruction-relevance grid aggregation: ONE pass over the fp16 feature slab.
+//
+//   w_j    = max_l <x_j, text_l>            all L text columns, padded tokens included
+//                                           (map_nav_src/models/vilmodel.py:798)
+//   out[c] = sum_{j in cell c} softmax_j(w_j) x_j      (vilmodel.py:801-807; grid_proj is
+//            applied to the 196 reduced vectors afterwards: W sum_j a_j x_j + b, sum_j a_j = 1)
+//
+// Work decomposition: the points of an episode arrive sorted by cell (gridmm_grid_bin's `perm`);
+// a workgroup owns a contiguous, cell-aligned chunk of that order, so no cross-workgroup merge
+// is needed and every slab row is read from HBM exactly once (1 KB contiguous per row at
+// D = 512).  Per 32-point tile:
+//   1. rows -> LDS (row-major, 16-B chunk index XOR (row & 15): conflict-free ds_read_b128)
+//   2. relevance on MFMA f16 16x16x32: wave t owns text columns [16t, 16t+16) for the whole
+//      launch, their fp16 hi+lo fragments (22 significant bits ~ fp32) live in registers;
+//      A fragments come from the LDS tile; per-point max over columns by DPP shuffles, then
+//      across waves through LDS
+//   3. online-softmax accumulation (fp32) of the LDS-resident rows into the running cell vector
+//      held in registers (2 feature dims per thread); flush on cell change.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+constexpr int TILE = 32;
+constexpr float NEG_BIG = -3.0e38f;
+
+__global__ void text_fragments_kernel(const float* __restrict__ text, _Float16* __restrict__ frag, int B,
+                                      int L, int D, int Lt) {
+  // frag[b][plane][ct][ks][lane][e]
+  const int KS = D / 32;
+  const size_t per_b = (size_t)2 * Lt * KS * 64 * 8;
+  const size_t total = (size_t)B * Lt * KS * 64 * 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i;
+    const int e = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int ks = r % KS; r /= KS;
+    const int ct = r % Lt; r /= Lt;
+    const int b = (int)r;
+    const int col = ct * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + e;
+    const float x = col < L ? text[((size_t)b * L + col) * D + k] : 0.f;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    const size_t o = (((size_t)ct * KS + ks) * 64 + lane) * 8 + e;
+    frag[b * per_b + o] = h;
+    frag[b * per_b + (size_t)Lt * KS * 64 * 8 + o] = l;
+  }
+}
+
+// chunk boundaries in CELL index space: chunk k of episode b covers cells [cb[k], cb[k+1])
+__global__ void build_chunks_kernel(const int32_t* __restrict__ cell_start, int32_t* __restrict__ chunks,
+                                    int n_chunks) {
+  const int b = blockIdx.x;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  int32_t* cb = chunks + (size_t)b * (n_chunks + 1);
+  const int valid = cs[GRIDMM_CELLS];
+  const int target = (valid + n_chunks - 1) / n_chunks;
+  for (int k = threadIdx.x; k <= n_chunks; k += blockDim.x) {
+    int c;
+    if (k == 0) c = 0;
+    else if (k == n_chunks) c = GRIDMM_CELLS;
+    else {
+      const long want = (long)k * target;
+      c = GRIDMM_CELLS;
+      for (int q = 0; q <= GRIDMM_CELLS; ++q)
+        if (cs[q] >= want) { c = q; break; }
+    }
+    cb[k] = c;
+  }
+}
+
+// RESIDENT: wave t keeps text column tile t in registers (Lt <= 8 waves, <= 256 VGPRs).
+// !RESIDENT (L > 128): 8 waves, each loops over column tiles t, t+8, ... and re-streams the
+// fragments from L2 per tile -- correct for any L <= 256, slower.
+template <int KS, bool RESIDENT>  // D = 32 * KS
+__global__ __launch_bounds__(512) void grid_aggregate_kernel(
+    const _Float16* __restrict__ slab, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ cell_start, const _Float16* __restrict__ text_frag,
+    float* __restrict__ cells, uint8_t* __restrict__ occ, float* __restrict__ relevance,
+    const int32_t* __restrict__ chunks, int cap, int L, int Lt, int n_chunks) {
+  constexpr int D = 32 * KS;
+  constexpr int NCH = D / 8;                 // 16-B chunks per row
+  constexpr int NACC = (D / 2 + 255) / 256;  // feature-dim pairs per thread (block >= 256 threads)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  _Float16* s_tile = reinterpret_cast<_Float16*>(smem);                       // [TILE][D]
+  float* s_wmax = reinterpret_cast<float*>(smem + (size_t)TILE * D * 2);      // [Lt][TILE]
+  float* s_w = s_wmax + (size_t)Lt * TILE;                                    // [TILE]
+  float* s_e = s_w + TILE;                                                    // [TILE]
+  int* s_cell = reinterpret_cast<int*>(s_e + TILE);                           // [TILE]
+  int* s_src = s_cell + TILE;                                                 // [TILE]
+  float* s_state = reinterpret_cast<float*>(s_src + TILE);                    // [0]=scale_run [1]=m_run
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int nwaves = nthreads >> 6;
+  const int b = blockIdx.y, k = blockIdx.x;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  const int c_lo = chunks[(size_t)b * (n_chunks + 1) + k], c_hi = chunks[(size_t)b * (n_chunks + 1) + k + 1];
+  if (c_lo >= c_hi) return;
+  const int p_lo = cs[c_lo], p_hi = cs[c_hi];
+  float* cells_b = cells + (size_t)b * GRIDMM_CELLS * D;
+  uint8_t* occ_b = occ + (size_t)b * GRIDMM_CELLS;
+
+  // empty cells of this chunk: zero vector, occ = 0 (vilmodel.py:803-807)
+  for (int c = c_lo + wave; c < c_hi; c += nwaves) {
+    if (cs[c + 1] == cs[c]) {
+      for (int d = lane; d < D / 4; d += 64)
+        reinterpret_cast<float4*>(cells_b + (size_t)c * D)[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane == 0) occ_b[c] = 0;
+    }
+  }
+  if (p_lo >= p_hi) return;
+
+  // this wave's text columns, register-resident for the whole chunk
+  const size_t plane = (size_t)Lt * KS * 64 * 8;
+  const _Float16* tf_b = text_frag + (size_t)b * 2 * plane + (size_t)lane * 8;
+  f16x8_t thi[RESIDENT ? KS : 1], tlo[RESIDENT ? KS : 1];
+  if (RESIDENT && wave < Lt) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      thi[RESIDENT ? ks : 0] = *reinterpret_cast<const f16x8_t*>(tf_b + ((size_t)wave * KS + ks) * 64 * 8);
+      tlo[RESIDENT ? ks : 0] = *reinterpret_cast<const f16x8_t*>(tf_b + plane + ((size_t)wave * KS + ks) * 64 * 8);
+    }
+  }
+
+  const _Float16* slab_b = slab + (size_t)b * cap * D;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+
+  int cur = -1;            // cell being accumulated
+  float m_run = NEG_BIG, s_run = 0.f;
+  float v0[NACC], v1[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) v0[a] = v1[a] = 0.f;
+
+  auto flush = [&]() {
+    if (cur < 0) return;
+    const float inv = 1.0f / s_run;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int dp = tid + a * nthreads;
+      if (dp < D / 2) reinterpret_cast<float2*>(cells_b + (size_t)cur * D)[dp] = make_float2(v0[a] * inv, v1[a] * inv);
+    }
+    if (tid == 0) occ_b[cur] = 1;
+  };
+
+  for (int p0 = p_lo; p0 < p_hi; p0 += TILE) {
+    const int npt = min(TILE, p_hi - p0);
+    // ---- 1. stage rows
+    if (tid < TILE) {
+      int src = -1, cell = -1;
+      if (tid < npt) {
+        src = perm_b[p0 + tid];
+        // cell of sorted position p0+tid: the last c with cs[c] <= p (binary search over 197 starts)
+        int lo = c_lo, hi = c_hi;  // invariant cs[lo] <= p < cs[hi]
+        const int p = p0 + tid;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (cs[mid] <= p) lo = mid; else hi = mid;
+        }
+        cell = lo;
+      }
+      s_src[tid] = src;
+      s_cell[tid] = cell;
+    }
+    __syncthreads();
+    for (int r = wave; r < TILE; r += nwaves) {
+      const int src = s_src[r];
+      for (int c = lane; c < NCH; c += 64) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (src >= 0) v = reinterpret_cast<const uint4*>(slab_b + (size_t)src * D)[c];
+        reinterpret_cast<uint4*>(s_tile + (size_t)r * D)[c ^ (r & 15)] = v;
+      }
+    }
+    __syncthreads();
+    // ---- 2. relevance on the matrix pipe
+    for (int ct = wave; ct < Lt; ct += nwaves) {
+      const int i = lane & 15, g = lane >> 4;
+      const bool two = npt > 16;
+      f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        f16x8_t bh, bl;
+        if (RESIDENT) {
+          bh = thi[RESIDENT ? ks : 0];
+          bl = tlo[RESIDENT ? ks : 0];
+        } else {
+          bh = *reinterpret_cast<const f16x8_t*>(tf_b + ((size_t)ct * KS + ks) * 64 * 8);
+          bl = *reinterpret_cast<const f16x8_t*>(tf_b + plane + ((size_t)ct * KS + ks) * 64 * 8);
+        }
+        const int ch = ks * 4 + g;
+        const f16x8_t a0 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)i * D)[ch ^ i];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, acc0, 0, 0, 0);
+        if (two) {
+          const f16x8_t a1 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(16 + i) * D)[ch ^ i];
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc1, 0, 0, 0);
+        }
+      }
+      const bool colv = (ct * 16 + i) < L;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x0 = colv ? acc0[r] : NEG_BIG, x1 = colv ? acc1[r] : NEG_BIG;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          x0 = fmaxf(x0, __shfl_xor(x0, o, 64));
+          x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
+        }
+        if (i == 0) {
+          s_wmax[ct * TILE + g * 4 + r] = x0;
+          s_wmax[ct * TILE + 16 + g * 4 + r] = x1;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < TILE) {
+      float w = NEG_BIG;
+      for (int t = 0; t < Lt; ++t) w = fmaxf(w, s_wmax[t * TILE + tid]);
+      s_w[tid] = w;
+      if (relevance && tid < npt) relevance[(size_t)b * cap + s_src[tid]] = w;
+    }
+    __syncthreads();
+    // ---- 3a. per-point softmax numerators against the (running / in-tile) cell maximum
+    if (tid < TILE) {
+      float e = 0.f;
+      if (tid < npt) {
+        const int c = s_cell[tid];
+        float m = (c == cur) ? m_run : NEG_BIG;
+        for (int r = 0; r < npt; ++r)
+          if (s_cell[r] == c) m = fmaxf(m, s_w[r]);
+        e = expf(s_w[tid] - m);
+        if (tid == 0) s_state[0] = (c == cur) ? expf(m_run - m) : 1.0f;  // rescale of the running cell
+        if (tid == npt - 1) s_state[1] = m;                                // maximum of the last cell
+      }
+      s_e[tid] = e;
+    }
+    __syncthreads();
+    // ---- 3b. accumulate rows (all threads; 2 feature dims per thread per NACC slot)
+    {
+      const float sc = s_state[0];
+      if (cur >= 0 && s_cell[0] == cur) {
+        s_run *= sc;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) { v0[a] *= sc; v1[a] *= sc; }
+      }
+      for (int r = 0; r < npt; ++r) {
+        const int c = s_cell[r];
+        if (c != cur) {
+          flush();
+          cur = c; s_run = 0.f;
+#pragma unroll
+          for (int a = 0; a < NACC; ++a) v0[a] = v1[a] = 0.f;
+        }
+        const float e = s_e[r];
+        s_run += e;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          const int dp = tid + a * nthreads;
+          if (dp < D / 2) {
+            const int ch = (dp >> 2) ^ (r & 15);
+            const f16x2_t h = *reinterpret_cast<const f16x2_t*>(s_tile + (size_t)r * D + ch * 8 + (dp & 3) * 2);
+            v0[a] += e * (float)h[0];
+            v1[a] += e * (float)h[1];
+          }
+        }
+      }
+      m_run = s_state[1];
+    }
+    __syncthreads();
+  }
+  flush();
+}
+
+}  // namespace
+
+extern "C" int gridmm_text_fragments(const float* text, void* frag, int B, int L, int D,
+                                     gridmm_stream_t stream) {
+  if (B <= 0 || L <= 0 || D <= 0 || D % 32) return GRIDMM_EINVAL;
+  const int Lt = (L + 15) / 16;
+  const size_t total = (size_t)B * Lt * (D / 32) * 64 * 8;
+  unsigned grid = (unsigned)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(text_fragments_kernel, dim3(grid), dim3(256), 0, as_stream(stream), text,
+                     (_Float16*)frag, B, L, D, Lt);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                     const void* text_frag, float* cells, uint8_t* occ, float* relevance,
+                                     int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
+                                     gridmm_stream_t stream) {
+  if (B <= 0 || cap <= 0 || L <= 0 || n_chunks <= 0 || n_chunks > GRIDMM_CELLS) return GRIDMM_EINVAL;
+  const int Lt = (L + 15) / 16;
+  if (Lt > 16) return GRIDMM_EINVAL;  // L <= 256 (reference: max_instr_len 200)
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(build_chunks_kernel, dim3(B), dim3(64), 0, st, cell_start, chunks, n_chunks);
+  const bool resident = Lt <= 8;
+  const int nwaves = resident ? (Lt < 4 ? 4 : Lt) : 8;
+  dim3 grid(n_chunks, B), block(nwaves * 64);
+  const size_t lds = (size_t)TILE * D * 2 + ((size_t)Lt * TILE + 2 * TILE) * sizeof(float) +
+                     2 * TILE * sizeof(int) + 4 * sizeof(float);
+#define GRIDMM_AGG(KS)                                                                              \
+  do {                                                                                              \
+    if (resident)                                                                                   \
+      hipLaunchKernelGGL((grid_aggregate_kernel<KS, true>), grid, block, lds, st,                   \
+                         (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag, cells, \
+                         occ, relevance, chunks, cap, L, Lt, n_chunks);                             \
+    else                                                                                            \
+      hipLaunchKernelGGL((grid_aggregate_kernel<KS, false>), grid, block, lds, st,                  \
+                         (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag, cells, \
+                         occ, relevance, chunks, cap, L, Lt, n_chunks);                             \
+  } while (0)
+  switch (D) {
+    case 256: GRIDMM_AGG(8); break;
+    case 512: GRIDMM_AGG(16); break;
+    case 768: GRIDMM_AGG(24); break;
+    default: return GRIDMM_EINVAL;
+  }
+#undef GRIDMM_AGG
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}

@@ -1,0 +1,46 @@
+// Shared device helpers for the gfx950 kernels of libgridmm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gridmm.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+
+#define GRIDMM_CHECK_LAUNCH()                                   \
+  do {                                                          \
+    if (hipGetLastError() != hipSuccess) return GRIDMM_ELAUNCH; \
+  } while (0)
+
+static inline hipStream_t as_stream(gridmm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// fp32 -> bf16 bits, round-to-nearest-even (inputs are finite on this path).
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
+  unsigned int u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+
+// 64-lane wave reductions (wave = 64 on CDNA).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,144 @@
+"""Device-resident grid memory: the HIP-backed mirror of the reference's per-episode map state.
+
+Reference (relative to /root/reference):
+  state lists                     map_nav_src/r2r/env.py:141-151 (global_semantic, global_position_x/y,
+                                  global_mask, max/min_x/y, heading, global_map)
+  EnvBatch.getGlobalMap           map_nav_src/r2r/env.py:267-374
+  EnvBatch.get_gridmap_pos_fts    map_nav_src/r2r/env.py:242-265
+  H2D of the whole history/step   map_nav_src/r2r/agent.py:168  (O(t^2) PCIe bytes) -- removed here:
+                                  the slab and the point history stay in HBM, only pose/heading
+                                  (a few floats per episode) cross PCIe each step.
+
+Layout in HBM for B episodes, capacity `cap = max_steps * pts_per_obs` points each:
+  slab       (B, cap, D)  fp16   CLIP patch tokens, appended per step (never re-copied)
+  hist_x/y   (B, cap)     fp32   world XY of every point
+  hist_valid (B, cap)     uint8  depth != 0
+  cell_id    (B, cap)     int16  current egocentric cell (x*14+y) or -1       -> `grid_map`
+  perm       (B, cap)     int32  point indices sorted by (cell, index)
+  cell_start (B, 198)     int32  per-cell ranges of perm
+  bbox (B,4), half_len (B,), pos_fts (B,196,5)
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .synthetic import GridGeometry, NATIVE  # noqa: F401  (geometry description only)
+
+
+class GridMemoryBatch:
+    def __init__(self, batch_size, geom=NATIVE, max_steps=15, device="cuda"):
+        self.B, self.geom, self.max_steps = batch_size, geom, max_steps
+        self.device = torch.device(device)
+        self.n_new = geom.pts_per_obs
+        self.cap = max_steps * self.n_new
+        B, cap, dev = batch_size, self.cap, self.device
+        self.slab = torch.zeros(B, cap, geom.feat_dim, dtype=torch.float16, device=dev)
+        self.hist_x = torch.zeros(B, cap, dtype=torch.float32, device=dev)
+        self.hist_y = torch.zeros(B, cap, dtype=torch.float32, device=dev)
+        self.hist_valid = torch.zeros(B, cap, dtype=torch.uint8, device=dev)
+        self.cell_id = torch.full((B, cap), -1, dtype=torch.int16, device=dev)
+        self.perm = torch.zeros(B, cap, dtype=torch.int32, device=dev)
+        self.cell_start = torch.zeros(B, 198, dtype=torch.int32, device=dev)
+        self.bbox = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        self.half_len = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.pos_fts = torch.zeros(B, 196, 5, dtype=torch.float32, device=dev)
+        self.n_pts = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.n_pts_host = np.zeros(B, np.int64)
+        # host-side constants, rounded exactly as NumPy rounds them in env.py:118, 290
+        P = geom.patches
+        base = np.array([(2 * c + 1 - P) / P for c in range(P)] * P, np.float32)
+        self.x_off = torch.from_numpy(base * np.float32(geom.tan_half_fov)).to(dev)
+        ang = [v * math.pi / (geom.n_views / 2) for v in range(geom.n_views)]
+        self.view_cos = torch.tensor([np.float32(math.cos(a)) for a in ang], dtype=torch.float32, device=dev)
+        self.view_sin = torch.tensor([np.float32(math.sin(a)) for a in ang], dtype=torch.float32, device=dev)
+        self.reset()
+
+    def reset(self):
+        """EnvBatch.newEpisodes (env.py:178-194)."""
+        self.bbox[:] = torch.tensor([-10000.0, 10000.0, -10000.0, 10000.0], device=self.device)
+        self.n_pts.zero_()
+        self.n_pts_host[:] = 0
+        self.cell_id.fill_(-1)
+
+    def step(self, depth, feats, poses, headings, active=None):
+        """Append one observation per episode and re-bin the whole history (getGlobalMap for all i).
+
+        depth  (B, n_views*ppv) uint16  sampled patch-centre depth (host or device)
+        feats  (B, n_views*ppv, D) fp16 patch tokens (host or device), or None when the producer has
+               already written them in place into `next_slot()` (zero-copy append)
+        poses  B x (x, y) python floats (viewpoint_info, env.py:286); headings B python floats
+        active optional B bools: inactive episodes are left untouched
+        """
+        B, dev, n_new = self.B, self.device, self.n_new
+        act_host = np.ones(B, bool) if active is None else np.asarray(active, bool)
+        if (self.n_pts_host[act_host] + n_new > self.cap).any():
+            raise ValueError("grid memory capacity exceeded (max_steps=%d)" % self.max_steps)
+        depth = torch.as_tensor(depth).to(dev, non_blocking=True)
+        if depth.dtype != torch.uint16:
+            depth = depth.to(torch.int32).to(torch.uint16)
+        depth = depth.reshape(B, n_new).contiguous()
+        if feats is not None:
+            feats = torch.as_tensor(feats).to(dev, non_blocking=True).reshape(B, n_new, self.geom.feat_dim)
+        pose32 = np.array([[np.float32(p[0]), np.float32(p[1])] for p in poses], np.float32)
+        head_cs = np.array([[np.float32(math.cos(-h)), np.float32(math.sin(-h))] for h in headings], np.float32)
+        pose_d = torch.from_numpy(pose32).to(dev)
+        head_d = torch.from_numpy(head_cs).to(dev)
+        act_d = None if active is None else torch.from_numpy(act_host.astype(np.uint8)).to(dev)
+
+        lock = act_host.all() and (self.n_pts_host == self.n_pts_host[0]).all()
+        if feats is None:
+            pass  # zero-copy append: the producer already wrote the tokens into next_slot()
+        elif lock:
+            n0 = int(self.n_pts_host[0])
+            self.slab[:, n0:n0 + n_new].copy_(feats)
+        else:
+            for b in np.nonzero(act_host)[0]:
+                n0 = int(self.n_pts_host[b])
+                self.slab[b, n0:n0 + n_new].copy_(feats[b])
+        ops.grid_project(depth, self.x_off, self.view_cos, self.view_sin, pose_d, self.n_pts, self.hist_x,
+                         self.hist_y, self.hist_valid, self.bbox, self.half_len, self.pos_fts, act_d,
+                         self.geom.n_views, self.geom.patches ** 2, self.geom.depth_div)
+        self.n_pts_host[act_host] += n_new
+        self.n_pts.copy_(torch.from_numpy(self.n_pts_host.astype(np.int32)))
+        ops.grid_bin(self.hist_x, self.hist_y, self.hist_valid, self.n_pts, pose_d, head_d, self.half_len,
+                     self.cell_id, self.perm, self.cell_start)
+        return self.pos_fts
+
+    def next_slot(self):
+        """(B, n_new, D) view of the slab where the next observation's tokens go (lock-step batches)."""
+        n0 = int(self.n_pts_host[0])
+        assert (self.n_pts_host == n0).all(), "next_slot() needs lock-step episodes"
+        return self.slab[:, n0:n0 + self.n_new]
+
+    # ---- the reference's observation form (env.py:610-612), for drop-in callers and tests
+    def grid_fts(self, b):
+        return self.slab[b, :int(self.n_pts_host[b])]
+
+    def grid_map(self, b):
+        return self.cell_id[b, :int(self.n_pts_host[b])].to(torch.float64)
+
+    def as_reference_obs(self):
+        return ([self.grid_fts(b) for b in range(self.B)], [self.grid_map(b) for b in range(self.B)],
+                self.pos_fts)
+
+
+def pack_reference_lists(grid_fts, grid_map):
+    """List form (agent.py:168: per-episode (N_b, D) fp16 + (N_b,) float64 ids) -> packed slab + sorted lists."""
+    B = len(grid_fts)
+    dev = grid_fts[0].device
+    D = grid_fts[0].shape[1]
+    n = [int(t.shape[0]) for t in grid_fts]
+    cap = max(max(n), 1)
+    slab = torch.zeros(B, cap, D, dtype=torch.float16, device=dev)
+    ids = torch.full((B, cap), -1, dtype=torch.int16, device=dev)
+    for b in range(B):
+        if n[b]:
+            slab[b, :n[b]].copy_(grid_fts[b].to(torch.float16))
+            ids[b, :n[b]].copy_(grid_map[b].to(torch.int16))
+    n_pts = torch.tensor(n, dtype=torch.int32, device=dev)
+    perm = torch.empty(B, cap, dtype=torch.int32, device=dev)
+    cell_start = torch.empty(B, 198, dtype=torch.int32, device=dev)
+    ops.grid_sort_ids(ids, n_pts, perm, cell_start)
+    return slab, perm, cell_start

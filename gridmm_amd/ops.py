@@ -1,0 +1,301 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/gridmm.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all
+arithmetic on the hot path happens inside libgridmm_hip.so.  Every wrapper
+raises if a tensor is not on the GPU - there is no fallback.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+N_CELLS = 196
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing (bench.py roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream == the stream passed to the C-ABI)."""
+
+    def __init__(self):
+        self.records = []  # (name, work, start_event, end_event)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, name, work, start):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.records.append((name, work, start, e))
+
+    def summary(self):
+        """name -> dict(calls, ms, work) after a device synchronize."""
+        out = {}
+        for name, work, s, e in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "work": 0.0})
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["work"] += work
+        return out
+
+
+TIMER = None  # set to a KernelTimer() to time launches
+
+
+def _timed(name, work, fn):
+    if TIMER is None:
+        return fn()
+    s = TIMER.begin()
+    r = fn()
+    TIMER.end(name, work, s)
+    return r
+
+
+def _p(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise _lib.GridmmLibraryError("gridmm ops need GPU tensors (got %s); no CPU fallback exists" % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _rows2d(t):
+    """View (..., H) with contiguous last dim as (M, H) + row stride; requires a uniform row stride."""
+    if t.stride(-1) != 1:
+        raise ValueError("last dim must be contiguous")
+    if t.dim() == 1:
+        return 1, t.shape[0], t.shape[0]
+    H = t.shape[-1]
+    rs = t.stride(-2)
+    M = 1
+    for d in range(t.dim() - 1):
+        M *= t.shape[d]
+    # leading dims must fold onto a single stride
+    exp = rs
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise ValueError("tensor rows are not uniformly strided: %s %s" % (tuple(t.shape), t.stride()))
+        exp *= t.shape[d]
+    return M, H, rs
+
+
+class PackedLinear:
+    """bf16 hi/lo planes of a Linear weight (N, K) zero-padded to Kp = roundup(K, 32), plus fp32 bias."""
+
+    __slots__ = ("hi", "lo", "bias", "N", "K", "Kp")
+
+    def __init__(self, weight, bias=None):
+        lib = _lib.load()
+        w = weight.detach().to(torch.float32).contiguous()
+        self.N, self.K = w.shape
+        self.Kp = (self.K + 31) // 32 * 32
+        self.hi = torch.empty(self.N, self.Kp, dtype=torch.bfloat16, device=w.device)
+        self.lo = torch.empty_like(self.hi)
+        _lib.check(lib.gridmm_split_weight(_p(w), _p(self.hi), _p(self.lo), self.N, self.K, self.Kp, _stream()),
+                   "gridmm_split_weight")
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+
+
+def _is_uniform(t):
+    try:
+        _rows2d(t)
+        return True
+    except ValueError:
+        return False
+
+
+def uniform_rows(t):
+    """Return t if its rows fold onto one stride, else a packed copy (device-side gridmm_copy_rows)."""
+    if _is_uniform(t):
+        return t
+    if t.dim() == 3 and t.stride(2) == 1 and t.dtype == torch.float32 and t.shape[2] % 4 == 0:
+        out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+        return copy_rows(t, out, 0)
+    return t.contiguous()
+
+
+def linear(x, pw, act=ACT_NONE, residual=None, out=None):
+    """out = act(x @ W^T + b) (+ residual).  x: (..., K) fp32, rows uniformly strided."""
+    lib = _lib.load()
+    x = uniform_rows(x)
+    if residual is not None:
+        residual = uniform_rows(residual)
+    M, K, lda = _rows2d(x)
+    if K != pw.K or x.dtype != torch.float32:
+        raise ValueError("linear: bad input %s for weight (%d,%d)" % (tuple(x.shape), pw.N, pw.K))
+    if out is None:
+        out = torch.empty(*x.shape[:-1], pw.N, dtype=torch.float32, device=x.device)
+    Mo, No, ldc = _rows2d(out)
+    assert Mo == M and No == pw.N
+    ldr = 0
+    if residual is not None:
+        Mr, Nr, ldr = _rows2d(residual)
+        assert Mr == M and Nr == pw.N
+    _timed("linear", 2.0 * M * pw.N * K, lambda: _lib.check(
+        lib.gridmm_linear(_p(x), lda, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual), ldr,
+                          _p(out), ldc, M, pw.N, K, act, _stream()), "gridmm_linear"))
+    return out
+
+
+def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=None, out=None):
+    """out = LN(x (+ residual)) * gamma + beta (+ add1) (+ table[idx])."""
+    lib = _lib.load()
+    x = uniform_rows(x)
+    residual = None if residual is None else uniform_rows(residual)
+    add1 = None if add1 is None else uniform_rows(add1)
+    M, H, ldx = _rows2d(x)
+    final = None
+    if out is not None and not _is_uniform(out):
+        final, out = out, None
+    if out is None:
+        out = torch.empty(*x.shape, dtype=torch.float32, device=x.device)
+    _, _, ldy = _rows2d(out)
+    ldr = ld1 = 0
+    if residual is not None:
+        _, _, ldr = _rows2d(residual)
+    if add1 is not None:
+        _, _, ld1 = _rows2d(add1)
+    if idx is not None:
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        assert idx.numel() == M
+    _lib.check(lib.gridmm_layernorm(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(beta), float(eps), _p(out), ldy,
+                                    _p(add1), ld1, _p(table), _p(idx), M, H, _stream()), "gridmm_layernorm")
+    if final is not None:
+        copy_rows(out, final, 0)
+        return final
+    return out
+
+
+def attention(q, k, v, kmask, out=None, heads=12, scale=None):
+    """q (B,Sq,H*64) / k,v (B,Sk,H*64) possibly strided views into fused QKV buffers; kmask (B,Sk) uint8/bool."""
+    lib = _lib.load()
+    B, Sq, HD = q.shape
+    Sk = k.shape[1]
+    assert HD == heads * 64 and k.shape[2] == HD and v.shape[2] == HD
+    for t in (q, k, v):
+        assert t.stride(2) == 1 and t.dtype == torch.float32
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    if out is None:
+        out = torch.empty(B, Sq, HD, dtype=torch.float32, device=q.device)
+    if kmask is not None:
+        if kmask.dtype == torch.bool:
+            kmask = kmask.view(torch.uint8)
+        assert kmask.shape == (B, Sk) and kmask.stride(1) == 1
+    _timed("attention", 4.0 * B * Sq * Sk * HD, lambda: _lib.check(lib.gridmm_attention(
+        _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+        _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), out.stride(0), out.stride(1),
+        B, heads, Sq, Sk, float(scale), _stream()), "gridmm_attention"))
+    return out
+
+
+def ln_dot(x, gamma, beta, eps, w, b0, out=None):
+    lib = _lib.load()
+    x = uniform_rows(x)
+    M, H, ldx = _rows2d(x)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], dtype=torch.float32, device=x.device)
+    _lib.check(lib.gridmm_ln_dot(_p(x), ldx, _p(gamma), _p(beta), float(eps), _p(w), _p(b0), _p(out), M, H,
+                                 _stream()), "gridmm_ln_dot")
+    return out
+
+
+def copy_rows(src, dst, dst_row0=0):
+    """dst[:, dst_row0:dst_row0+rows] = src   for (B, rows, H) fp32 tensors (row-contiguous)."""
+    lib = _lib.load()
+    B, rows, H = src.shape
+    assert dst.shape[0] == B and dst.shape[2] == H and src.stride(2) == 1 and dst.stride(2) == 1
+    d = dst[:, dst_row0:dst_row0 + rows]
+    _lib.check(lib.gridmm_copy_rows(_p(src), src.stride(0), src.stride(1), _p(d), d.stride(0), d.stride(1),
+                                    B, rows, H, _stream()), "gridmm_copy_rows")
+    return dst
+
+
+def cells_compact(proj, pos_emb, occ, out, mask):
+    """Compact cells into rows [0,196) of out (B,S_pad,H) / mask (B,S_pad); returns (n_cells, cmax) int32 tensors."""
+    lib = _lib.load()
+    B, S_pad, H = out.shape
+    n_cells = torch.empty(B, dtype=torch.int32, device=out.device)
+    cmax = torch.empty(1, dtype=torch.int32, device=out.device)
+    assert out.is_contiguous() and mask.is_contiguous() and mask.shape == (B, S_pad)
+    _lib.check(lib.gridmm_cells_compact(_p(proj), _p(pos_emb), _p(occ), _p(out), _p(mask), _p(n_cells), _p(cmax),
+                                        B, H, S_pad, _stream()), "gridmm_cells_compact")
+    return n_cells, cmax
+
+
+def fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, cand_of_node,
+                cand_visited):
+    lib = _lib.load()
+    B, G = g_raw.shape
+    V = l_raw.shape[1]
+    dev = g_raw.device
+    outs = [torch.empty(B, G, device=dev), torch.empty(B, V, device=dev), torch.empty(B, G, device=dev),
+            torch.empty(B, G, device=dev)]
+    _lib.check(lib.gridmm_fuse_logits(_p(g_raw), _p(l_raw), _p(grid_raw), _p(fuse_raw), _p(gmap_masks),
+                                      _p(gmap_visited), _p(vp_nav_masks), _p(cand_of_node), _p(cand_visited),
+                                      _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, G, V, _stream()),
+               "gridmm_fuse_logits")
+    return outs  # global, local, grid, fused
+
+
+def grid_project(depth, x_off, view_cos, view_sin, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len,
+                 pos_fts, active, n_views, ppv, depth_div):
+    lib = _lib.load()
+    B, cap = hist_x.shape
+    _lib.check(lib.gridmm_grid_project(_p(depth), _p(x_off), _p(view_cos), _p(view_sin), _p(pose), _p(n_old),
+                                       _p(hist_x), _p(hist_y), _p(hist_valid), _p(bbox), _p(half_len), _p(pos_fts),
+                                       _p(active), B, n_views, ppv, cap, float(depth_div), _stream()),
+               "gridmm_grid_project")
+
+
+def grid_bin(hist_x, hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start):
+    lib = _lib.load()
+    B, cap = hist_x.shape
+    _lib.check(lib.gridmm_grid_bin(_p(hist_x), _p(hist_y), _p(hist_valid), _p(n_pts), _p(pose), _p(head_cs),
+                                   _p(half_len), _p(cell_id), _p(perm), _p(cell_start), B, cap, _stream()),
+               "gridmm_grid_bin")
+
+
+def grid_sort_ids(cell_id, n_pts, perm, cell_start):
+    lib = _lib.load()
+    B, cap = cell_id.shape
+    _lib.check(lib.gridmm_grid_sort_ids(_p(cell_id), _p(n_pts), _p(perm), _p(cell_start), B, cap, _stream()),
+               "gridmm_grid_sort_ids")
+
+
+def text_fragments(text_fts):
+    """(B, L, D) fp32 -> MFMA B-fragment planes (fp16 hi|lo)."""
+    lib = _lib.load()
+    B, L, D = text_fts.shape
+    Lt = (L + 15) // 16
+    frag = torch.empty(B, 2, Lt, D // 32, 64, 8, dtype=torch.float16, device=text_fts.device)
+    _lib.check(lib.gridmm_text_fragments(_p(text_fts.contiguous()), _p(frag), B, L, D, _stream()),
+               "gridmm_text_fragments")
+    return frag
+
+
+def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_relevance=False):
+    """slab (B,cap,D) fp16 -> cells (B,196,D) fp32, occ (B,196) uint8 [, relevance (B,cap) fp32]."""
+    lib = _lib.load()
+    B, cap, D = slab.shape
+    assert slab.dtype == torch.float16 and slab.is_contiguous()
+    if n_chunks is None:
+        n_chunks = max(1, min(N_CELLS, -(-512 // B)))
+    dev = slab.device
+    cells = torch.empty(B, N_CELLS, D, dtype=torch.float32, device=dev)
+    occ = torch.empty(B, N_CELLS, dtype=torch.uint8, device=dev)
+    rel = torch.zeros(B, cap, dtype=torch.float32, device=dev) if want_relevance else None
+    chunks = torch.empty(B, n_chunks + 1, dtype=torch.int32, device=dev)
+    _timed("grid_aggregate", 0.0, lambda: _lib.check(
+        lib.gridmm_grid_aggregate(_p(slab), _p(perm), _p(cell_start), _p(text_frag), _p(cells), _p(occ),
+                                  _p(rel), _p(chunks), B, cap, D, L, n_chunks, _stream()),
+        "gridmm_grid_aggregate"))
+    return (cells, occ, rel) if want_relevance else (cells, occ)

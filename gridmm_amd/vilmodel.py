@@ -1,0 +1,464 @@
+"""GlocalTextPathNavCMT on hand-written HIP kernels -- the drop-in for the reference's model path.
+
+Keeps the reference's public surface (relative to /root/reference/map_nav_src/models):
+  GlocalTextPathNavCMT.forward(mode, batch)        vilmodel.py:920-939   modes 'language' | 'panorama' | 'navigation'
+  module tree / state_dict keys                     vilmodel.py:676-710   (reference checkpoints load unchanged)
+  forward_navigation_per_step                       vilmodel.py:782-918   -> HIP: aggregation, encoders, logit fusion
+The nn.Module tree below only HOLDS parameters under the reference's names; all arithmetic of the
+three modes runs in libgridmm_hip.so through gridmm_amd.ops.  There is no PyTorch fallback: on a
+box without the library or without a GPU, forward() raises.
+
+Additions over the reference API (optional, used by bench / the agent loop):
+  batch['grid_memory'] = GridMemoryBatch   device-resident slab + per-cell point lists instead of the
+                                           python lists grid_fts / grid_map (which are still accepted)
+  slab feature dim D_in != 768             text_proj: Linear(768, D_in), grid_proj: Linear(D_in, 768)
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import ops
+from .grid_memory import GridMemoryBatch, pack_reference_lists
+
+N_CELLS = 196
+
+
+def default_config(**over):
+    """bert-base defaults + map_nav_src/models/vlnbert_init.py:38-56."""
+    cfg = dict(
+        hidden_size=768, num_attention_heads=12, intermediate_size=3072, vocab_size=30522,
+        max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu",
+        hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+        max_action_steps=100, image_feat_size=768, angle_feat_size=4, obj_feat_size=0, obj_loc_size=3,
+        num_l_layers=9, num_pano_layers=2, num_x_layers=4, graph_sprels=True, glocal_fuse=True,
+        fix_lang_embedding=False, fix_pano_embedding=False, fix_local_branch=False, update_lang_bert=True,
+        output_attentions=True, pred_head_dropout_prob=0.1, use_lang2visn_attn=False,
+        grid_feat_size=768,  # D_in of the slab (reference: hard-coded 768, vilmodel.py:702-703)
+    )
+    cfg.update(over)
+    return SimpleNamespace(**cfg)
+
+
+def _get(cfg, name, default=None):
+    return getattr(cfg, name, default)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names == reference state_dict keys)
+# ------------------------------------------------------------------------------------------------
+class BertSelfAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.query = nn.Linear(c.hidden_size, c.hidden_size)
+        self.key = nn.Linear(c.hidden_size, c.hidden_size)
+        self.value = nn.Linear(c.hidden_size, c.hidden_size)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self = BertSelfAttention(c)
+        self.output = BertSelfOutput(c)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.intermediate_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attention = BertAttention(c)
+        self.intermediate = BertIntermediate(c)
+        self.output = BertOutput(c)
+
+
+class BertXAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.att = BertSelfAttention(c)  # BertOutAttention has the same parameters (query/key/value)
+        self.output = BertSelfOutput(c)
+
+
+class GraphLXRTXLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        if _get(c, "use_lang2visn_attn", False):
+            self.lang_self_att = BertAttention(c)
+            self.lang_inter = BertIntermediate(c)
+            self.lang_output = BertOutput(c)
+        self.visn_self_att = BertAttention(c)
+        self.visn_inter = BertIntermediate(c)
+        self.visn_output = BertOutput(c)
+        self.visual_attention = BertXAttention(c)
+
+
+class CrossmodalEncoder(nn.Module):
+    def __init__(self, c, num_layers):
+        super().__init__()
+        self.x_layers = nn.ModuleList([GraphLXRTXLayer(c) for _ in range(num_layers)])
+
+
+class MultiheadAttentionParams(nn.Module):
+    """Same parameter names as nn.MultiheadAttention (in_proj_weight/in_proj_bias/out_proj.*)."""
+
+    def __init__(self, h):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * h, h))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * h))
+        self.out_proj = nn.Linear(h, h)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class PreLNLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self_attn = MultiheadAttentionParams(c.hidden_size)
+        self.linear1 = nn.Linear(c.hidden_size, c.intermediate_size)
+        self.linear2 = nn.Linear(c.intermediate_size, c.hidden_size)
+        self.norm1 = nn.LayerNorm(c.hidden_size)  # eps 1e-5 (transformer.py:146-147)
+        self.norm2 = nn.LayerNorm(c.hidden_size)
+
+
+class PreLNEncoder(nn.Module):
+    """create_transformer_encoder(config, n, norm=True)  (ops.py:11-23)."""
+
+    def __init__(self, c, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([PreLNLayer(c) for _ in range(num_layers)])
+        self.norm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
+        self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class LanguageEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(c) for _ in range(c.num_l_layers)])
+
+
+class ImageEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.img_linear = nn.Linear(c.image_feat_size, c.hidden_size)
+        self.img_layer_norm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+        self.loc_linear = nn.Linear(c.angle_feat_size + 3, c.hidden_size)
+        self.loc_layer_norm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+        if c.obj_feat_size > 0 and c.obj_feat_size != c.image_feat_size:
+            self.obj_linear = nn.Linear(c.obj_feat_size, c.hidden_size)
+            self.obj_layer_norm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+        else:
+            self.obj_linear = self.obj_layer_norm = None
+        self.nav_type_embedding = nn.Embedding(3, c.hidden_size)
+        self.layer_norm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+        self.pano_encoder = PreLNEncoder(c, c.num_pano_layers) if c.num_pano_layers > 0 else None
+
+
+class LocalVPEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.vp_pos_embeddings = nn.Sequential(
+            nn.Linear(c.angle_feat_size * 2 + 6, c.hidden_size), nn.LayerNorm(c.hidden_size, eps=1e-12))
+        self.encoder = CrossmodalEncoder(c, c.num_x_layers)
+
+
+class GlobalMapEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.gmap_pos_embeddings = nn.Sequential(
+            nn.Linear(c.angle_feat_size + 3, c.hidden_size), nn.LayerNorm(c.hidden_size, eps=1e-12))
+        self.gmap_step_embeddings = nn.Embedding(c.max_action_steps, c.hidden_size)
+        self.sprel_linear = nn.Linear(1, 1) if c.graph_sprels else None  # unused on this path (vilmodel.py:577-590)
+
+
+class ClsPrediction(nn.Module):
+    def __init__(self, hidden_size, input_size=None):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(input_size or hidden_size, hidden_size), nn.ReLU(),
+                                 nn.LayerNorm(hidden_size, eps=1e-12), nn.Linear(hidden_size, 1))
+
+
+# ------------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------------
+class GlocalTextPathNavCMT(nn.Module):
+    def __init__(self, config=None):
+        super().__init__()
+        c = self.config = config if config is not None else default_config()
+        H = c.hidden_size
+        self.embeddings = BertEmbeddings(c)
+        self.lang_encoder = LanguageEncoder(c)
+        self.img_embeddings = ImageEmbeddings(c)
+        self.local_encoder = LocalVPEncoder(c)
+        self.global_encoder = GlobalMapEncoder(c)
+        self.global_sap_head = ClsPrediction(H)
+        self.local_sap_head = ClsPrediction(H)
+        self.grid_sap_head = ClsPrediction(H)
+        self.grid_encoder = PreLNEncoder(c, 1)
+        self.grid_txt_encoder = CrossmodalEncoder(c, 1)  # num_x_layers forced to 1 (vilmodel.py:694)
+        self.grid_pos_embeddings = nn.Sequential(nn.Linear(5, H), nn.LayerNorm(H, eps=1e-12))
+        d_in = _get(c, "grid_feat_size", 768)
+        self.text_proj = nn.Linear(H, d_in)
+        self.grid_proj = nn.Linear(d_in, H)
+        self.sap_fuse_linear = ClsPrediction(H, input_size=H * 2) if c.glocal_fuse else None
+        if c.obj_feat_size > 0:
+            self.og_head = ClsPrediction(H)
+        self.heads = c.num_attention_heads
+        self._packed = {}
+        for m in self.modules():  # BERT-style init (BertPreTrainedModel.init_weights)
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                nn.init.normal_(m.weight, std=0.02)
+                if isinstance(m, nn.Linear) and m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    # ---- packed (bf16 hi/lo) weights, rebuilt when a parameter changes -------------------------
+    def _pack(self, key, weights, biases):
+        ver = tuple((w.data_ptr(), w._version) for w in weights) + tuple((b.data_ptr(), b._version) for b in biases)
+        ent = self._packed.get(key)
+        if ent is None or ent[0] != ver:
+            w = weights[0] if len(weights) == 1 else torch.cat([x.detach() for x in weights], 0)
+            b = biases[0] if len(biases) == 1 else torch.cat([x.detach() for x in biases], 0)
+            ent = (ver, ops.PackedLinear(w, b))
+            self._packed[key] = ent
+        return ent[1]
+
+    def _lin(self, mod, key):
+        return self._pack(key, [mod.weight], [mod.bias])
+
+    def _qkv(self, att, key, which="qkv"):
+        mods = {"qkv": [att.query, att.key, att.value], "kv": [att.key, att.value], "q": [att.query]}[which]
+        return self._pack(key + "." + which, [m.weight for m in mods], [m.bias for m in mods])
+
+    # ---- building blocks ----------------------------------------------------------------------
+    def _ln(self, mod, x, residual=None, **kw):
+        return ops.layernorm(x, mod.weight, mod.bias, mod.eps, residual=residual, **kw)
+
+    def _self_attention(self, att, key, x, kmask):
+        """BertAttention (vilmodel.py:172-182): LN(dense(attn(x)) + x)."""
+        H = x.shape[-1]
+        qkv = ops.linear(x, self._qkv(att.self, key))
+        ctx = ops.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask, heads=self.heads)
+        return self._ln(att.output.LayerNorm, ops.linear(ctx, self._lin(att.output.dense, key + ".o")), residual=x)
+
+    def _cross_attention(self, xatt, key, x, ctx, ctx_mask, kv=None):
+        """BertXAttention (vilmodel.py:370-379)."""
+        H = x.shape[-1]
+        q = ops.linear(x, self._qkv(xatt.att, key, "q"))
+        if kv is None:
+            kv = ops.linear(ctx, self._qkv(xatt.att, key, "kv"))
+        c = ops.attention(q, kv[..., :H], kv[..., H:2 * H], ctx_mask, heads=self.heads)
+        return self._ln(xatt.output.LayerNorm, ops.linear(c, self._lin(xatt.output.dense, key + ".o")), residual=x)
+
+    def _ffn(self, inter, out, key, x):
+        h = ops.linear(x, self._lin(inter.dense, key + ".i"), act=ops.ACT_GELU)
+        return self._ln(out.LayerNorm, ops.linear(h, self._lin(out.dense, key + ".f")), residual=x)
+
+    def _bert_layer(self, layer, key, x, kmask):
+        a = self._self_attention(layer.attention, key + ".att", x, kmask)
+        return self._ffn(layer.intermediate, layer.output, key, a)
+
+    def _x_layer(self, layer, key, lang, lang_mask, visn, visn_mask):
+        """GraphLXRTXLayer.forward with graph_sprels=None (vilmodel.py:399-414)."""
+        a = self._cross_attention(layer.visual_attention, key + ".x", visn, lang, lang_mask)
+        a = self._self_attention(layer.visn_self_att, key + ".s", a, visn_mask)
+        return self._ffn(layer.visn_inter, layer.visn_output, key, a)
+
+    def _pre_ln_encoder(self, enc, key, x, kmask):
+        """TransformerEncoder, normalize_before=True (transformer.py:170-182), final LN eps 1e-12."""
+        H = x.shape[-1]
+        for i, layer in enumerate(enc.layers):
+            k = "%s.%d" % (key, i)
+            h = self._ln(layer.norm1, x)
+            qkv = ops.linear(h, self._pack(k + ".in", [layer.self_attn.in_proj_weight], [layer.self_attn.in_proj_bias]))
+            ctx = ops.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask, heads=self.heads)
+            x = ops.linear(ctx, self._lin(layer.self_attn.out_proj, k + ".o"), residual=x)
+            h = self._ln(layer.norm2, x)
+            f = ops.linear(h, self._lin(layer.linear1, k + ".1"), act=ops.ACT_GELU)
+            x = ops.linear(f, self._lin(layer.linear2, k + ".2"), residual=x)
+        return self._ln(enc.norm, x)
+
+    def _cls(self, head, key, x):
+        """ClsPrediction (vilmodel.py:663-674): Linear -> ReLU -> LN -> Linear(H,1)."""
+        h = ops.linear(x, self._lin(head.net[0], key), act=ops.ACT_RELU)
+        return ops.ln_dot(h, head.net[2].weight, head.net[2].bias, head.net[2].eps, head.net[3].weight.view(-1),
+                          head.net[3].bias)
+
+    @staticmethod
+    def _u8(m):
+        return (m if m.dtype == torch.uint8 else m.to(torch.uint8)).contiguous()
+
+    # ---- modes --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_text(self, txt_ids, txt_masks):
+        """vilmodel.py:730-734."""
+        e = self.embeddings
+        L = txt_ids.shape[1]
+        pos = torch.arange(L, device=txt_ids.device).unsqueeze(0).expand_as(txt_ids)
+        x = e.word_embeddings.weight[txt_ids]                     # gathers = data movement
+        pt = (e.position_embeddings.weight[pos] + e.token_type_embeddings.weight[0]).contiguous()
+        x = self._ln(e.LayerNorm, x.contiguous(), residual=pt)
+        m = self._u8(txt_masks)
+        for i, layer in enumerate(self.lang_encoder.layer):
+            x = self._bert_layer(layer, "lang.%d" % i, x, m)
+        return x
+
+    @torch.no_grad()
+    def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
+        """vilmodel.py:736-780 (view-only branch on HIP; objects are concatenated by the caller form)."""
+        ie = self.img_embeddings
+        if obj_img_fts is not None:
+            raise NotImplementedError("object panorama tokens (REVERIE/SOON) are outside this round's scope")
+        x = self._ln(ie.img_layer_norm, ops.linear(view_img_fts.float().contiguous(), self._lin(ie.img_linear, "img")))
+        extra = (ie.nav_type_embedding.weight[nav_types] + self.embeddings.token_type_embeddings.weight[1]).contiguous()
+        y = self._ln(ie.loc_layer_norm, ops.linear(loc_fts.float().contiguous(), self._lin(ie.loc_linear, "loc")),
+                     add1=extra)
+        x = self._ln(ie.layer_norm, x, residual=y)
+        lens = view_lens
+        masks = torch.arange(int(lens.max()), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
+        if ie.pano_encoder is not None:
+            x = self._pre_ln_encoder(ie.pano_encoder, "pano", x, self._u8(masks))
+        return x, masks
+
+    @staticmethod
+    def _fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V):
+        """Integer form of the vpid-keyed python loops (vilmodel.py:884-899); host side."""
+        B = len(gmap_vpids)
+        vis = gmap_visited_masks.detach().cpu().numpy() if torch.is_tensor(gmap_visited_masks) else gmap_visited_masks
+        cand_of_node = torch.full((B, G), -2, dtype=torch.int32)
+        cand_visited = torch.zeros(B, V, dtype=torch.uint8)
+        for i in range(B):
+            visited = set(vp for vp, m in zip(gmap_vpids[i], vis[i]) if m)
+            tmp = {}
+            for j, cv in enumerate(vp_cand_vpids[i]):
+                if j > 0:
+                    if cv in visited:
+                        cand_visited[i, j] = 1
+                    else:
+                        tmp[cv] = j
+            for j, vp in enumerate(gmap_vpids[i]):
+                if j > 0 and vp not in visited:
+                    cand_of_node[i, j] = tmp.get(vp, -1)
+        return cand_of_node, cand_visited
+
+    @torch.no_grad()
+    def forward_navigation_per_step(
+            self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
+            gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
+            vp_nav_masks, vp_obj_masks, vp_cand_vpids, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None):
+        """vilmodel.py:782-918 on HIP kernels.  Same arguments, same output dict."""
+        dev = txt_embeds.device
+        B, L, H = txt_embeds.shape
+        G, V = gmap_masks.shape[1], vp_masks.shape[1]
+        txt_embeds = txt_embeds.float().contiguous()
+        txt_m, gmap_m, vp_m = self._u8(txt_masks), self._u8(gmap_masks), self._u8(vp_masks)
+
+        # ---- grid memory -> 196 instruction-weighted cell vectors (vilmodel.py:793-807)
+        text_fts = ops.linear(txt_embeds, self._lin(self.text_proj, "text_proj"))
+        frag = ops.text_fragments(text_fts)
+        if grid_memory is not None:
+            slab, perm, cell_start = grid_memory.slab, grid_memory.perm, grid_memory.cell_start
+            if gridmap_pos_fts is None:
+                gridmap_pos_fts = grid_memory.pos_fts
+        else:
+            slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
+        cells, occ = ops.grid_aggregate(slab, perm, cell_start, frag, L)
+        proj = ops.linear(cells, self._lin(self.grid_proj, "grid_proj"))
+        gp = self.grid_pos_embeddings
+        pos_emb = self._ln(gp[1], ops.linear(gridmap_pos_fts.float().contiguous(), self._lin(gp[0], "grid_pos")))
+
+        # ---- [cells | gmap nodes] sequence, padded to 196 + G (vilmodel.py:813-837)
+        S = N_CELLS + G
+        map_embeds = torch.empty(B, S, H, dtype=torch.float32, device=dev)
+        map_masks = torch.empty(B, S, dtype=torch.uint8, device=dev)
+        ops.cells_compact(proj, pos_emb, occ, map_embeds, map_masks)
+        map_masks[:, N_CELLS:] = gmap_m
+        ge = self.global_encoder
+        self._ln(ge.gmap_pos_embeddings[1],
+                 ops.linear(gmap_pos_fts.float().contiguous(), self._lin(ge.gmap_pos_embeddings[0], "gmap_pos")),
+                 add1=gmap_img_embeds.float().contiguous(), table=ge.gmap_step_embeddings.weight,
+                 idx=gmap_step_ids, out=map_embeds[:, N_CELLS:])
+        q = torch.empty(B, G + V, H, dtype=torch.float32, device=dev)
+        le = self.local_encoder
+        self._ln(le.vp_pos_embeddings[1],
+                 ops.linear(vp_pos_fts.float().contiguous(), self._lin(le.vp_pos_embeddings[0], "vp_pos")),
+                 add1=vp_img_embeds.float().contiguous(), out=q[:, G:])
+
+        # ---- grid encoder + grid/text cross-modal layer (vilmodel.py:840-841)
+        map_embeds = self._pre_ln_encoder(self.grid_encoder, "grid_enc", map_embeds, map_masks)
+        for i, layer in enumerate(self.grid_txt_encoder.x_layers):
+            map_embeds = self._x_layer(layer, "grid_txt.%d" % i, txt_embeds, txt_m, map_embeds, map_masks)
+
+        # ---- local encoder over q = [gmap | vp], kv = [map | txt] (vilmodel.py:843-856)
+        kv = torch.empty(B, S + L, H, dtype=torch.float32, device=dev)
+        ops.copy_rows(map_embeds, kv, 0)
+        ops.copy_rows(txt_embeds, kv, S)
+        kv_masks = torch.cat([map_masks, txt_m], 1)
+        ops.copy_rows(map_embeds[:, N_CELLS:], q, 0)
+        q_masks = torch.cat([gmap_m, vp_m], 1)
+        for i, layer in enumerate(le.encoder.x_layers):
+            q = self._x_layer(layer, "local.%d" % i, kv, kv_masks, q, q_masks)
+        gmap_embeds, vp_embeds = q[:, :G], q[:, G:]
+
+        # ---- heads + fusion (vilmodel.py:859-907)
+        fuse_raw = None
+        if self.sap_fuse_linear is not None:
+            fuse_raw = self._cls(self.sap_fuse_linear, "fuse", torch.cat([gmap_embeds[:, 0], vp_embeds[:, 0]], 1))
+        g_raw = self._cls(self.global_sap_head, "ghead", gmap_embeds)
+        grid_raw = self._cls(self.grid_sap_head, "gridhead", map_embeds[:, N_CELLS:])
+        l_raw = self._cls(self.local_sap_head, "lhead", vp_embeds)
+        cand_of_node, cand_visited = self._fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V)
+        global_logits, local_logits, grid_logits, fused_logits = ops.fuse_logits(
+            g_raw, l_raw, grid_raw, fuse_raw, gmap_m, self._u8(gmap_visited_masks), self._u8(vp_nav_masks),
+            cand_of_node.to(dev), cand_visited.to(dev))
+        obj_logits = None
+        if vp_obj_masks is not None:
+            obj_logits = self._cls(self.og_head, "oghead", vp_embeds)
+            obj_logits.masked_fill_(vp_obj_masks.logical_not(), -float("inf"))
+        return {
+            "gmap_embeds": gmap_embeds, "vp_embeds": vp_embeds, "global_logits": global_logits,
+            "local_logits": local_logits, "fused_logits": fused_logits, "obj_logits": obj_logits,
+            "grid_logits": grid_logits,
+        }
+
+    def forward(self, mode, batch, **kwargs):
+        """vilmodel.py:920-939."""
+        if mode == "language":
+            return self.forward_text(batch["txt_ids"], batch["txt_masks"])
+        elif mode == "panorama":
+            return self.forward_panorama_per_step(
+                batch["view_img_fts"], batch.get("obj_img_fts"), batch["loc_fts"], batch["nav_types"],
+                batch["view_lens"], batch.get("obj_lens"))
+        elif mode == "navigation":
+            return self.forward_navigation_per_step(
+                batch["txt_embeds"], batch["txt_masks"], batch["gmap_img_embeds"], batch["gmap_step_ids"],
+                batch["gmap_pos_fts"], batch["gmap_masks"], batch.get("gmap_pair_dists"),
+                batch["gmap_visited_masks"], batch["gmap_vpids"], batch["vp_img_embeds"], batch["vp_pos_fts"],
+                batch["vp_masks"], batch["vp_nav_masks"], batch.get("vp_obj_masks"), batch["vp_cand_vpids"],
+                batch.get("grid_fts"), batch.get("grid_map"), batch.get("gridmap_pos_fts"),
+                grid_memory=batch.get("grid_memory"))
+        raise NotImplementedError("wrong mode: %s" % mode)

@@ -1,0 +1,186 @@
+/*
+ * gridmm.h — C-ABI of libgridmm_hip.so: hand-written HIP/CDNA4 (gfx950) kernels for the
+ * GridMM grid-memory forward path.
+ *
+ * The reference (MrZihan/GridMM) is 100 % Python: there is no FFI to mirror.  Each entry
+ * point below replaces the stock-op sequence cited next to it (paths relative to the
+ * reference tree).  Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless a
+ *     parameter is marked [host];
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
+ *   - no allocation inside: outputs / workspaces are caller-provided;
+ *   - returns 0 on success, a negative GRIDMM_E* code otherwise (never throws);
+ *   - re-entrant, no global state.
+ */
+#ifndef GRIDMM_H
+#define GRIDMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRIDMM_OK 0
+#define GRIDMM_EINVAL (-1)   /* bad shape / unsupported size */
+#define GRIDMM_ELAUNCH (-2)  /* hipGetLastError() != hipSuccess after launch */
+
+#define GRIDMM_GRID 14
+#define GRIDMM_CELLS 196
+
+typedef void* gridmm_stream_t;
+
+/* ABI version of this header (bumped on any signature change). */
+int gridmm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Grid memory ("fill_gridmap")
+ * ---------------------------------------------------------------------------------------- */
+
+/* Back-project ONE new observation per episode into world XY and append it to the
+ * device-resident point history; update the running bounding box; derive the map scale and
+ * the 196 cell-centre position features.
+ * Replaces: get_rel_position  map_nav_src/r2r/env.py:115-121,
+ *           EnvBatch.getGlobalMap :289-294 (projection), :312-331 (bbox, half_len),
+ *           EnvBatch.get_gridmap_pos_fts :242-265.
+ * Arithmetic is fp32 in the reference's operation order without FMA contraction (bit-exact XY).
+ *   depth      [B][n_pts] uint16, sampled patch-centre depth, view-major (n_pts = n_views*ppv)
+ *   x_off      [ppv] f32   lateral offsets * tan(fov/2)           (host computes, env.py:118)
+ *   view_cos/sin [n_views] f32, cos/sin of the python-double view angle rounded to f32
+ *   pose       [B][2] f32  (x, y) of the current viewpoint rounded to f32
+ *   n_old      [B] int32   points already in the history of each episode
+ *   hist_x/y   [B][cap] f32, hist_valid [B][cap] uint8: history (new points written at n_old[b])
+ *   bbox       [B][4] f32  running (max_x, min_x, max_y, min_y); init (-10000,10000,-10000,10000)
+ *   half_len   [B] f32 out; pos_fts [B][196][5] f32 out
+ *   active     [B] uint8 or NULL: episodes with 0 are skipped entirely
+ */
+int gridmm_grid_project(const uint16_t* depth, const float* x_off, const float* view_cos,
+                        const float* view_sin, const float* pose, const int32_t* n_old,
+                        float* hist_x, float* hist_y, uint8_t* hist_valid, float* bbox,
+                        float* half_len, float* pos_fts, const uint8_t* active,
+                        int B, int n_views, int ppv, int cap, float depth_div,
+                        gridmm_stream_t stream);
+
+/* Re-bin the WHOLE history of every episode into the current egocentric 14x14 frame and
+ * build the per-cell point lists (stable counting sort by cell id).
+ * Replaces: EnvBatch.getGlobalMap map_nav_src/r2r/env.py:337-369 (rotate, scale, truncate,
+ *           clamp, 196-iteration mask loop).   Cell ids are bit-exact with the reference.
+ *   n_pts      [B] int32   points in each history (after the append)
+ *   head_cs    [B][2] f32  cos/sin of (-heading) rounded to f32 (host)
+ *   cell_id    [B][cap] int16 out: x*14+y, or -1 for invalid depth
+ *   perm       [B][cap] int32 out: point indices sorted by (cell, index); invalid points last
+ *   cell_start [B][198] int32 out: perm range of cell c is [cell_start[c], cell_start[c+1]);
+ *              cell_start[196] = #valid points, cell_start[197] = n_pts
+ */
+int gridmm_grid_bin(const float* hist_x, const float* hist_y, const uint8_t* hist_valid,
+                    const int32_t* n_pts, const float* pose, const float* head_cs,
+                    const float* half_len, int16_t* cell_id, int32_t* perm, int32_t* cell_start,
+                    int B, int cap, gridmm_stream_t stream);
+
+/* Same counting sort for caller-provided cell ids (the reference's `grid_map` list form,
+ * map_nav_src/r2r/agent.py:168): ids are int16 in {-1, 0..195}. */
+int gridmm_grid_sort_ids(const int16_t* cell_id, const int32_t* n_pts, int32_t* perm,
+                         int32_t* cell_start, int B, int cap, gridmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Instruction-relevance grid aggregation
+ * ---------------------------------------------------------------------------------------- */
+
+/* Split text_fts = text_proj(txt_embeds) (fp32) into fp16 hi + lo planes laid out as MFMA
+ * B-fragments.   text [B][L][D] f32 -> frag [B][2][Lt][D/32][64][8] fp16, Lt = ceil(L/16). */
+int gridmm_text_fragments(const float* text, void* frag, int B, int L, int D,
+                          gridmm_stream_t stream);
+
+/* One pass over the fp16 slab: per point relevance w_j = max_l <x_j, text_l> (all L columns,
+ * padded tokens included, vilmodel.py:798) on MFMA f16 tiles, then per cell
+ * out[c] = sum_j softmax_j(w_j) x_j  (online softmax, fp32) and occ[c] = cell non-empty.
+ * Replaces: map_nav_src/models/vilmodel.py:797-807 (the 196*B python loop).  grid_proj is
+ * applied AFTER the reduction (W (sum_j a_j x_j) + b, since sum_j a_j = 1).
+ *   slab       [B][cap][D] fp16      perm/cell_start as produced by gridmm_grid_bin
+ *   cells      [B][196][D] f32 out (zeros for empty cells); occ [B][196] uint8 out
+ *   relevance  [B][cap] f32 out or NULL (w_j, for tests)
+ *   chunks     [B][n_chunks+1] int32 workspace (cell-aligned work partition, device-built)
+ */
+int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                          const void* text_frag, float* cells, uint8_t* occ, float* relevance,
+                          int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
+                          gridmm_stream_t stream);
+
+/* Compact non-empty cells to the front (cell order), add the position embedding, build the
+ * key mask exactly as vilmodel.py:813-823 does (including its in-place view quirk).
+ *   proj [B][196][H] f32 = grid_proj(cells)+bias; pos_emb [B][196][H] f32
+ *   out  rows [0,196) of a [B][S_pad][H] buffer (row stride H, batch stride S_pad*H)
+ *   mask rows [0,196) of a [B][S_pad] uint8 buffer;  n_cells [B] int32 out; cmax [1] int32 out
+ */
+int gridmm_cells_compact(const float* proj, const float* pos_emb, const uint8_t* occ, float* out,
+                         uint8_t* mask, int32_t* n_cells, int32_t* cmax, int B, int H, int S_pad,
+                         gridmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder building blocks (QKV / FFN GEMMs on MFMA bf16, fp32 everywhere else)
+ * ---------------------------------------------------------------------------------------- */
+
+/* W [N][K] f32 -> bf16 hi / lo planes [N][Kp], Kp = roundup(K,32), zero padded. */
+int gridmm_split_weight(const float* W, void* hi, void* lo, int N, int K, int Kp,
+                        gridmm_stream_t stream);
+
+#define GRIDMM_ACT_NONE 0
+#define GRIDMM_ACT_GELU 1  /* exact erf gelu (vilmodel.py:47-53, transformer.py:472) */
+#define GRIDMM_ACT_RELU 2
+
+/* C[M][N] = act(A[M][K] * W^T + bias) (+ residual), fp32 in / fp32 out, the contraction on
+ * MFMA bf16 16x16x32 tiles as a 3-term split (a_hi w_hi + a_lo w_hi + a_hi w_lo, fp32
+ * accumulate): ~2^-16 relative, inside the 1e-3 logit tolerance where plain bf16 is not.
+ * Replaces every nn.Linear on the path (vilmodel.py:124-126, 165, 187, 201, 345-347, ...;
+ * transformer.py in_proj/out_proj/linear1/linear2).
+ *   lda/ldc/ldr in elements; residual may be NULL; bias may be NULL. */
+int gridmm_linear(const float* A, int lda, const void* W_hi, const void* W_lo, int Kp,
+                  const float* bias, const float* residual, int ldr, float* C, int ldc,
+                  int M, int N, int K, int act, gridmm_stream_t stream);
+
+/* Y = LayerNorm(X (+ R)) * gamma + beta, row-wise over H, fp32 two-pass statistics.
+ * Optionally Y += add1 (+ table[idx[row]]).   Replaces BertLayerNorm / nn.LayerNorm uses. */
+int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr, const float* gamma,
+                     const float* beta, float eps, float* Y, int ldy, const float* add1, int ld1,
+                     const float* table, const int64_t* idx, int M, int H, gridmm_stream_t stream);
+
+/* Multi-head attention core, head_dim 64, fp32 (MFMA f32 16x16x4), online softmax.
+ * O[b][i][h*64+d] = sum_j softmax_j(scale * <Q[b,i,h], K[b,j,h]>  over keys with kmask=1) V[b,j,h,d]
+ * Masked keys contribute exactly 0 (both mask conventions of the reference, vilmodel.py:136,
+ * 354 (-10000 additive) and transformer.py:176 (key_padding_mask), give 0 in fp32).
+ *   Q/K/V element (b,i,h,d) at ptr[b*bs + i*rs + h*64 + d]  (strides in elements)
+ *   kmask [B][Sk] uint8 (row stride mask_bs) */
+int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
+                     const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs,
+                     float* O, int64_t o_bs, int o_rs, int B, int heads, int Sq, int Sk,
+                     float scale, gridmm_stream_t stream);
+
+/* out[m] = <LayerNorm(X[m]) * gamma + beta, w> + b0      (tail of ClsPrediction,
+ * vilmodel.py:663-674: Linear -> ReLU -> LN -> Linear(H,1)). */
+int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const float* beta, float eps,
+                  const float* w, const float* b0, float* out, int M, int H,
+                  gridmm_stream_t stream);
+
+/* Logit masking + global/local fusion (vilmodel.py:859-907) with integer index maps.
+ *   g_raw [B][G], l_raw [B][V], grid_raw [B][G] f32: head outputs; fuse_raw [B] f32 (pre-sigmoid) or NULL (0.5)
+ *   gmap_masks, gmap_visited [B][G] uint8; vp_nav_masks [B][V] uint8
+ *   cand_of_node [B][G] int32: j>0 unvisited node -> index k of the same vpid among the
+ *       candidates, or -1 (add the sum of visited candidates' local logits); host-built from
+ *       the python vpid lists.   cand_visited [B][V] uint8: candidate k>0 is a visited node.
+ *   outputs global/grid/fused [B][G], local [B][V] f32 (-inf where masked) */
+int gridmm_fuse_logits(const float* g_raw, const float* l_raw, const float* grid_raw,
+                       const float* fuse_raw, const uint8_t* gmap_masks,
+                       const uint8_t* gmap_visited, const uint8_t* vp_nav_masks,
+                       const int32_t* cand_of_node, const uint8_t* cand_visited,
+                       float* global_logits, float* local_logits, float* grid_logits,
+                       float* fused_logits, int B, int G, int V, gridmm_stream_t stream);
+
+/* Strided row copy / gather used to assemble [cells | gmap | txt] sequences without torch.cat:
+ * dst[b][dst_row0 + i][:] = src[b][i][:] for i < rows.  H floats per row. */
+int gridmm_copy_rows(const float* src, int64_t src_bs, int src_rs, float* dst, int64_t dst_bs,
+                     int dst_rs, int B, int rows, int H, gridmm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIDMM_H */

@@ -1,0 +1,150 @@
+"""GPU: aggregation + full forward('navigation') / ('language') / ('panorama') on HIP vs the reference's
+golden vectors and vs the oracle.  Tolerance: 1e-3 on logits (north star); we assert 2e-4."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_state_dict, golden_nav_batch
+from oracle import navcmt_oracle as O
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 2e-4      # north star: 1e-3
+EMBED_TOL = 5e-4
+
+
+def _model(fx, dev="cuda"):
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    cfg = default_config(**json.loads(str(fx["cfg"])))
+    m = GlocalTextPathNavCMT(cfg).to(dev).eval()
+    sd = golden_state_dict(fx)
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    return m, sd
+
+
+def _cmp(a, b, tol):
+    a = a.detach().float().cpu().numpy()
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    inf = ~np.isfinite(b)
+    assert np.array_equal(~np.isfinite(a), inf), "mask (-inf) placement differs"
+    err = float(np.abs(a[~inf] - b[~inf]).max()) if (~inf).any() else 0.0
+    assert err <= tol, err
+    return err
+
+
+def _to_dev(batch):
+    from gridmm_amd.synthetic import batch_to
+    return batch_to(batch, "cuda")
+
+
+@pytest.mark.parametrize("name", ["nav_reduced.npz", "nav_reduced_obj.npz"])
+def test_navigation_matches_reference_golden(name):
+    fx = load_golden(name)
+    model, _ = _model(fx)
+    batch = _to_dev(golden_nav_batch(fx))
+    outs = model("navigation", batch)
+    for k in ("global_logits", "local_logits", "fused_logits", "grid_logits"):
+        _cmp(outs[k], fx["out_" + k], LOGIT_TOL)
+    _cmp(outs["gmap_embeds"], fx["out_gmap_embeds"], EMBED_TOL)
+    _cmp(outs["vp_embeds"], fx["out_vp_embeds"], EMBED_TOL)
+    if "out_obj_logits" in fx.files:
+        _cmp(outs["obj_logits"], fx["out_obj_logits"], LOGIT_TOL)
+    else:
+        assert outs["obj_logits"] is None
+
+
+def test_aggregation_stage_matches_reference_capture():
+    """Cell vectors + compaction mask (vilmodel.py:793-823) incl. the mask quirk, vs the reference's
+    grid_encoder input captured by a forward pre-hook."""
+    from gridmm_amd import ops
+    from gridmm_amd.grid_memory import pack_reference_lists
+    fx = load_golden("nav_reduced.npz")
+    model, sd = _model(fx)
+    batch = _to_dev(golden_nav_batch(fx))
+    B, L, H = batch["txt_embeds"].shape
+    text_fts = ops.linear(batch["txt_embeds"], model._lin(model.text_proj, "text_proj"))
+    slab, perm, cs = pack_reference_lists(batch["grid_fts"], batch["grid_map"])
+    cells, occ, rel = ops.grid_aggregate(slab, perm, cs, ops.text_fragments(text_fts), L, want_relevance=True)
+    # oracle for the un-projected stage
+    cpu = golden_nav_batch(fx)
+    with torch.no_grad():
+        tf = O.linear(sd, "text_proj", cpu["txt_embeds"])
+        for b in range(B):
+            x = cpu["grid_fts"][b].float()
+            w = (x @ tf[b].t()).max(-1).values
+            n = x.shape[0]
+            valid = cpu["grid_map"][b] >= 0
+            got = rel[b, :n].cpu()
+            assert (got[valid] - w[valid]).abs().max() < 2e-5 * max(1.0, w.abs().max().item())
+            for c in range(196):
+                sel = cpu["grid_map"][b] == c
+                assert bool(occ[b, c]) == bool(sel.any())
+                if sel.any():
+                    ref = (torch.softmax(w[sel], 0)[:, None] * x[sel]).sum(0)
+                    assert (cells[b, c].cpu() - ref).abs().max() < 2e-5
+                else:
+                    assert (cells[b, c] == 0).all()
+    proj = ops.linear(cells, model._lin(model.grid_proj, "grid_proj"))
+    gp = model.grid_pos_embeddings
+    pos_emb = model._ln(gp[1], ops.linear(batch["gridmap_pos_fts"], model._lin(gp[0], "grid_pos")))
+    out = torch.zeros(B, 196 + 2, H, device="cuda")
+    mask = torch.zeros(B, 196 + 2, dtype=torch.uint8, device="cuda")
+    n_cells, cmax = ops.cells_compact(proj, pos_emb, occ, out, mask)
+    C = fx["cap_grid_masks"].shape[1]
+    assert int(cmax) == C
+    assert np.array_equal(mask[:, :C].cpu().numpy().astype(bool), fx["cap_grid_masks"])
+    assert (mask[:, C:196] == 0).all()
+    assert np.abs(out[:, :C].cpu().numpy() - fx["cap_grid_map_embeds"]).max() < 5e-5
+
+
+def test_text_and_panorama_modes_match_reference_golden():
+    fx = load_golden("text_pano_reduced.npz")
+    model, _ = _model(fx)
+    d = lambda k: torch.from_numpy(fx[k]).cuda()
+    txt = model("language", {"txt_ids": d("in_txt_ids"), "txt_masks": d("in_txt_masks")})
+    valid = fx["in_txt_masks"]
+    err = np.abs(txt.cpu().numpy() - fx["out_txt_embeds"])[valid].max()
+    assert err < EMBED_TOL, err
+    pano, pm = model("panorama", {"view_img_fts": d("in_view_img_fts"), "obj_img_fts": None, "loc_fts": d("in_loc_fts"),
+                                  "nav_types": d("in_nav_types"), "view_lens": d("in_view_lens"), "obj_lens": None})
+    assert np.array_equal(pm.cpu().numpy(), fx["out_pano_masks"])
+    _cmp(pano, fx["out_pano_embeds"], EMBED_TOL)
+
+
+def test_full_size_navigation_matches_reference_golden():
+    """161 M-parameter config, B=2, N=1764/1176 points, L=40; inputs regenerated from seeds."""
+    from oracle import gen_golden
+    fx = load_golden("nav_full_b2.npz")
+    model, _ = _model(fx)
+    batch = _to_dev(gen_golden.full_b2_inputs())
+    outs = model("navigation", batch)
+    for k in ("global_logits", "local_logits", "fused_logits", "grid_logits"):
+        _cmp(outs[k], fx["out_" + k], LOGIT_TOL)
+    _cmp(outs["gmap_embeds"], fx["out_gmap_embeds"], EMBED_TOL)
+    _cmp(outs["vp_embeds"], fx["out_vp_embeds"], EMBED_TOL)
+
+
+def test_grid_memory_handle_equals_list_form():
+    """batch['grid_memory'] (device-resident, HIP-binned) == the reference's list form of the same memory."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    fx = load_golden("nav_reduced.npz")
+    model, _ = _model(fx)
+    batch = _to_dev(golden_nav_batch(fx))
+    B = 3
+    rs = np.random.RandomState(5)
+    mem = GridMemoryBatch(B, S.NATIVE, max_steps=2)
+    for t in range(2):
+        eps = [S.make_observations(rs, S.NATIVE, 1, feat_scale=0.35)[0] for _ in range(B)]
+        mem.step(np.stack([e["depth"].reshape(-1) for e in eps]), np.stack([e["feats"] for e in eps]),
+                 [(e["x"], e["y"]) for e in eps], [e["heading"] for e in eps])
+    fts, gmaps, pos = mem.as_reference_obs()
+    b1 = dict(batch, grid_fts=fts, grid_map=gmaps, gridmap_pos_fts=pos)
+    b2 = dict(batch, grid_fts=None, grid_map=None, gridmap_pos_fts=None, grid_memory=mem)
+    o1, o2 = model("navigation", b1), model("navigation", b2)
+    for k in ("fused_logits", "grid_logits", "gmap_embeds"):
+        a, b = o1[k], o2[k]
+        f = torch.isfinite(a)
+        assert torch.equal(f, torch.isfinite(b)) and (a[f] - b[f]).abs().max() < 1e-5
