@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""bench.py -- nav steps/s of the GridMM grid-memory hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic episodes, inputs resident in HBM:
+    fill_gridmap (project the new 36x196 observation, re-bin the memory, build per-cell lists)
+  + GlocalTextPathNavCMT.forward('navigation')  (aggregation, grid/cross-modal encoders, logit fusion)
+Workload = BASELINE.json configs[1]: B=32 episodes per GPU, slab 36 views x 196 patches x 512-D (N=7056
+points, memory depth t=1), L=80 instruction tokens, G=20 map nodes, 36 views + stop, full-size model
+(161 M-parameter architecture with text_proj/grid_proj at D_in=512), random-init weights, synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Episodes are independent: ranks shard the episode batch, no collective on the step path ("weak" scaling,
+B per GPU fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "nav steps/sec (whole node), R2R batch=32, 36x196x512 grid, 1/2/4/8 MI355X"
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="episodes per GPU")
+    ap.add_argument("--shape", default="baseline", choices=["baseline", "native"])
+    ap.add_argument("--mem-steps", type=int, default=1, help="observations in each episode's memory (t)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-torch-gpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build_workload(args, dev):
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+
+    geom = S.BASELINE if args.shape == "baseline" else S.NATIVE
+    torch.manual_seed(0)
+    model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim)).eval()
+    # BERT-style random init leaves LayerNorm at (1, 0); fine for timing
+    model.to(dev)
+    rs = np.random.RandomState(int(os.environ.get("RANK", "0")))
+    B, t = args.batch, args.mem_steps
+    batch = S.batch_to(S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, min_len=30), dev)
+    mem = GridMemoryBatch(B, geom, max_steps=t, device=dev)
+    eps = [S.make_observations(rs, geom, t) for _ in range(B)]
+    depth = [torch.from_numpy(np.stack([e[k]["depth"].reshape(-1) for e in eps])).to(dev) for k in range(t)]
+    # tokens are written into the slab once, before timing (zero-copy append: producer-owned slot)
+    for k in range(t):
+        mem.slab[:, k * geom.pts_per_obs:(k + 1) * geom.pts_per_obs].copy_(
+            torch.from_numpy(np.stack([e[k]["feats"] for e in eps])))
+    poses = [[(e[k]["x"], e[k]["y"]) for e in eps] for k in range(t)]
+    heads = [[e[k]["heading"] for e in eps] for k in range(t)]
+    batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
+
+    def step():
+        mem.reset()
+        for k in range(t):                      # t = 1 for the headline config
+            mem.step(depth[k], None, poses[k], heads[k])
+        return model("navigation", batch)
+
+    return model, batch, mem, eps, step, geom
+
+
+def time_steps(step, steps, warmup, dist):
+    for _ in range(warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def roofline_leg(step, args, geom, L=80):
+    """Per-kernel HIP-event timing over a few instrumented steps (events on the launch stream)."""
+    from gridmm_amd import ops
+    n = max(3, min(args.steps, 10))
+    ops.TIMER = ops.KernelTimer()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    summ = ops.TIMER.summary()
+    ops.TIMER = None
+    kern = {k: {"calls_per_step": v["calls"] / n, "ms_per_step": v["ms"] / n, "avg_us": 1e3 * v["ms"] / v["calls"]}
+            for k, v in summ.items()}
+    B, N, D = args.batch, geom.pts_per_obs * args.mem_steps, geom.feat_dim
+    out = {"kernels": kern}
+    if "linear" in summ:
+        tf = summ["linear"]["work"] / (summ["linear"]["ms"] * 1e-3) / 1e12
+        out["linear"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_BF16_PEAK_TF, "traffic": None,
+                         "note": "algorithmic 2MNK flops of all GEMM launches / their summed HIP-event time; the "
+                                 "3-term bf16 split issues 3x these flops on the matrix pipe"}
+    if "grid_aggregate" in summ:
+        # algorithmic bytes per launch: slab + perm + text fragments (hi+lo) + cell vectors out
+        byts = B * (N * D * 2 + N * 4 + 2 * L * D * 2 + 196 * D * 4 + 196)
+        gbs = byts / (summ["grid_aggregate"]["ms"] / summ["grid_aggregate"]["calls"] * 1e-3) / 1e9
+        out["grid_aggregate"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": byts}
+    dom = max(("linear", "grid_aggregate", "attention"), key=lambda k: summ.get(k, {"ms": 0})["ms"])
+    out["dominant"] = dom
+    return out
+
+
+def cpu_baseline(model, eps, batch, args, geom):
+    """The oracle (NumPy + torch-CPU port of the reference algorithm, incl. its 196-cell loop) timed on this
+    host on a bounded sample of the same workload."""
+    from oracle import navcmt_oracle as O, gridmap_oracle as G
+    og = G.BASELINE if args.shape == "baseline" else G.NATIVE
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    keys = ("txt_embeds", "txt_masks", "gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_masks",
+            "gmap_visited_masks", "vp_img_embeds", "vp_pos_fts", "vp_masks", "vp_nav_masks")
+
+    def run(b0, b1):
+        refs = []
+        for b in range(b0, b1):
+            mem = G.GridMemory(og)
+            for o in eps[b]:
+                r = mem.step(o["depth"], o["feats"], o["x"], o["y"], o["heading"])
+            refs.append(r)
+        cb = {k: batch[k][b0:b1].cpu() for k in keys}
+        cb.update(gmap_vpids=batch["gmap_vpids"][b0:b1], vp_cand_vpids=batch["vp_cand_vpids"][b0:b1],
+                  vp_obj_masks=None, gmap_pair_dists=None,
+                  grid_fts=[torch.from_numpy(r[0]) for r in refs], grid_map=[torch.from_numpy(r[1]) for r in refs],
+                  gridmap_pos_fts=torch.from_numpy(np.stack([r[2] for r in refs])))
+        with torch.no_grad():
+            O.forward_navigation(sd, cb)
+
+    best = None
+    ncpu = os.cpu_count() or 1
+    for k in sorted(set([1, min(8, ncpu)])):
+        torch.set_num_threads(k)
+        t0 = time.perf_counter()
+        run(0, 1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (k, dt)
+    k = best[0]
+    torch.set_num_threads(k)
+    done, t0 = 0, time.perf_counter()
+    chunk = 2
+    while time.perf_counter() - t0 < args.cpu_seconds and done + chunk <= len(eps):
+        run(done, done + chunk)
+        done += chunk
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "steps/s", "cores": k, "kind": "port",
+            "sample": "%d episode-steps of the same workload (N=%d points x %d-D, L=80, full-size model), "
+                      "oracle/navcmt_oracle.py + oracle/gridmap_oracle.py on %d torch thread(s), %.1f s"
+                      % (done, geom.pts_per_obs * args.mem_steps, geom.feat_dim, k, dt)}
+
+
+def torch_gpu_baseline(model, batch, mem, args):
+    """The reference-style PyTorch path on this GPU: the op-for-op oracle (196-cell python loop and all) run with
+    stock torch ops on cuda -- the '>= 5x' comparator of the north star.  Bounded: 1 warm-up + 2 timed calls."""
+    from oracle import navcmt_oracle as O
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    fts, gmaps, pos = mem.as_reference_obs()
+    b = dict(batch, grid_fts=fts, grid_map=gmaps, gridmap_pos_fts=pos, grid_memory=None)
+    with torch.no_grad():
+        O.forward_navigation(sd, b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            O.forward_navigation(sd, b)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": args.batch / dt, "unit": "steps/s", "kind": "port-on-gpu",
+            "sample": "forward('navigation') only (grid map prebuilt), B=%d, fp32 stock torch ops, %.3f s/call"
+                      % (args.batch, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL ("nccl" backend on ROCm)
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    model, batch, mem, eps, step, geom = build_workload(args, dev)
+    dt = time_steps(step, args.steps, args.warmup, dist)
+    n_gpus = world
+    value = n_gpus * args.batch * args.steps / dt
+
+    out = {
+        "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "R2R fine-tune batch=%d/GPU, %d views x %d patches x %dD, 14x14 grid, memory depth "
+                               "t=%d (N=%d points), L=80, G=20, V=37, full-size GlocalTextPathNavCMT (random init): "
+                               "fill_gridmap + forward('navigation')"
+                               % (args.batch, geom.n_views, geom.patches ** 2, geom.feat_dim, args.mem_steps,
+                                  geom.pts_per_obs * args.mem_steps),
+                   "global_batch": args.batch * n_gpus, "parallelism": "dp%d (episode sharding, no step-path collective)" % n_gpus,
+                   "gemm": "MFMA bf16 16x16x32, 3-term split (hi*hi+lo*hi+hi*lo), fp32 accumulate",
+                   "attention": "MFMA f32 16x16x4 (exact fp32)", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
+    }
+    if rank == 0 and not args.no_roofline:
+        rl = roofline_leg(step, args, geom)
+        dom = rl["dominant"]
+        out["roofline"] = dict(rl.get(dom, {}), kernel=dom)
+        for k in ("linear", "grid_aggregate"):
+            if k != dom and k in rl:
+                out["roofline_" + k] = rl[k]
+        out["kernels"] = rl["kernels"]
+    if rank == 0 and n_gpus == 1:
+        if not args.no_torch_gpu_baseline:
+            out["torch_gpu_baseline"] = torch_gpu_baseline(model, batch, mem, args)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, eps, batch, args, geom)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -280,7 +280,7 @@ extern "C" int gridmm_text_fragments(const float* text, void* frag, int B, int L
   const size_t total = (size_t)B * Lt * (D / 32) * 64 * 8;
   unsigned grid = (unsigned)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(text_fragments_kernel, dim3(grid), dim3(256), 0, as_stream(stream), text,
+  GRIDMM_LAUNCH(text_fragments_kernel, dim3(grid), dim3(256), 0, as_stream(stream), text,
                      (_Float16*)frag, B, L, D, Lt);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
@@ -294,7 +294,7 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
   const int Lt = (L + 15) / 16;
   if (Lt > 16) return GRIDMM_EINVAL;  // L <= 256 (reference: max_instr_len 200)
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(build_chunks_kernel, dim3(B), dim3(64), 0, st, cell_start, chunks, n_chunks);
+  GRIDMM_LAUNCH(build_chunks_kernel, dim3(B), dim3(64), 0, st, cell_start, chunks, n_chunks);
   const bool resident = Lt <= 8;
   const int nwaves = resident ? (Lt < 4 ? 4 : Lt) : 8;
   dim3 grid(n_chunks, B), block(nwaves * 64);
@@ -303,11 +303,11 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
 #define GRIDMM_AGG(KS)                                                                              \
   do {                                                                                              \
     if (resident)                                                                                   \
-      hipLaunchKernelGGL((grid_aggregate_kernel<KS, true>), grid, block, lds, st,                   \
+      GRIDMM_LAUNCH((grid_aggregate_kernel<KS, true>), grid, block, lds, st,                   \
                          (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag, cells, \
                          occ, relevance, chunks, cap, L, Lt, n_chunks);                             \
     else                                                                                            \
-      hipLaunchKernelGGL((grid_aggregate_kernel<KS, false>), grid, block, lds, st,                  \
+      GRIDMM_LAUNCH((grid_aggregate_kernel<KS, false>), grid, block, lds, st,                  \
                          (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag, cells, \
                          occ, relevance, chunks, cap, L, Lt, n_chunks);                             \
   } while (0)

@@ -131,7 +131,7 @@ extern "C" int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const fl
   if ((q_rs | k_rs | v_rs | o_rs) & 3) return GRIDMM_EINVAL;
   if ((q_bs | k_bs | v_bs | o_bs) & 3) return GRIDMM_EINVAL;
   dim3 grid((Sq + 63) / 64, heads, B), block(256);
-  hipLaunchKernelGGL(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
+  GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
                      v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, Sq, Sk, scale);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;

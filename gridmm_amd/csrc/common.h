@@ -16,6 +16,14 @@ typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
     if (hipGetLastError() != hipSuccess) return GRIDMM_ELAUNCH; \
   } while (0)
 
+// torch (and anything else in the process) can leave a benign sticky error (e.g. hipErrorNotReady from an
+// event query) in the per-thread last-error slot: clear it before the launch we are about to check.
+#define GRIDMM_LAUNCH(...)            \
+  do {                                \
+    (void)hipGetLastError();          \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 static inline hipStream_t as_stream(gridmm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // fp32 -> bf16 bits, round-to-nearest-even (inputs are finite on this path).

@@ -211,7 +211,7 @@ extern "C" int gridmm_grid_project(const uint16_t* depth, const float* x_off, co
                                    int n_views, int ppv, int cap, float depth_div,
                                    gridmm_stream_t stream) {
   if (B <= 0 || n_views <= 0 || ppv <= 0 || cap < n_views * ppv) return GRIDMM_EINVAL;
-  hipLaunchKernelGGL(grid_project_kernel, dim3(B), dim3(256), 0, as_stream(stream), depth, x_off, view_cos,
+  GRIDMM_LAUNCH(grid_project_kernel, dim3(B), dim3(256), 0, as_stream(stream), depth, x_off, view_cos,
                      view_sin, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len, pos_fts, active,
                      n_views, ppv, cap, depth_div);
   GRIDMM_CHECK_LAUNCH();
@@ -223,7 +223,7 @@ extern "C" int gridmm_grid_bin(const float* hist_x, const float* hist_y, const u
                                const float* half_len, int16_t* cell_id, int32_t* perm,
                                int32_t* cell_start, int B, int cap, gridmm_stream_t stream) {
   if (B <= 0 || cap <= 0) return GRIDMM_EINVAL;
-  hipLaunchKernelGGL((grid_bin_sort_kernel<true>), dim3(B), dim3(1024), 0, as_stream(stream), hist_x,
+  GRIDMM_LAUNCH((grid_bin_sort_kernel<true>), dim3(B), dim3(1024), 0, as_stream(stream), hist_x,
                      hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start, cap);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
@@ -232,7 +232,7 @@ extern "C" int gridmm_grid_bin(const float* hist_x, const float* hist_y, const u
 extern "C" int gridmm_grid_sort_ids(const int16_t* cell_id, const int32_t* n_pts, int32_t* perm,
                                     int32_t* cell_start, int B, int cap, gridmm_stream_t stream) {
   if (B <= 0 || cap <= 0) return GRIDMM_EINVAL;
-  hipLaunchKernelGGL((grid_bin_sort_kernel<false>), dim3(B), dim3(1024), 0, as_stream(stream), nullptr,
+  GRIDMM_LAUNCH((grid_bin_sort_kernel<false>), dim3(B), dim3(1024), 0, as_stream(stream), nullptr,
                      nullptr, nullptr, n_pts, nullptr, nullptr, nullptr, const_cast<int16_t*>(cell_id), perm,
                      cell_start, cap);
   GRIDMM_CHECK_LAUNCH();

