@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="episodes per GPU")
     ap.add_argument("--shape", default="baseline", choices=["baseline", "native"])
     ap.add_argument("--mem-steps", type=int, default=1, help="observations in each episode's memory (t)")
+    ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -63,22 +64,37 @@ def build_workload(args, dev):
     batch = S.batch_to(S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, min_len=30), dev)
     mem = GridMemoryBatch(B, geom, max_steps=t, device=dev)
     eps = [S.make_observations(rs, geom, t) for _ in range(B)]
+    n_new = geom.pts_per_obs
     depth = [torch.from_numpy(np.stack([e[k]["depth"].reshape(-1) for e in eps])).to(dev) for k in range(t)]
     # tokens are written into the slab once, before timing (zero-copy append: producer-owned slot)
     for k in range(t):
-        mem.slab[:, k * geom.pts_per_obs:(k + 1) * geom.pts_per_obs].copy_(
-            torch.from_numpy(np.stack([e[k]["feats"] for e in eps])))
+        mem.slab[:, k * n_new:(k + 1) * n_new].copy_(torch.from_numpy(np.stack([e[k]["feats"] for e in eps])))
     poses = [[(e[k]["x"], e[k]["y"]) for e in eps] for k in range(t)]
     heads = [[e[k]["heading"] for e in eps] for k in range(t)]
+    for k in range(t - 1):                      # history prefix (t-1 observations), built once
+        mem.step(depth[k], None, poses[k], heads[k])
+    restore = (mem.n_pts.clone(), mem.bbox.clone())
+    n_host0 = mem.n_pts_host.copy()
     batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
+    batch["fusion_maps"] = model.fusion_maps(batch, dev)
 
-    def step():
-        mem.reset()
-        for k in range(t):                      # t = 1 for the headline config
-            mem.step(depth[k], None, poses[k], heads[k])
+    def eager_step():
+        mem.n_pts.copy_(restore[0])
+        mem.bbox.copy_(restore[1])
+        mem.n_pts_host[:] = n_host0
+        mem.step(depth[t - 1], None, poses[t - 1], heads[t - 1])   # project the new observation + re-bin all
         return model("navigation", batch)
 
-    return model, batch, mem, eps, step, geom
+    step = eager_step
+    if not args.eager:
+        from gridmm_amd.graph import GraphedNavStep
+        eager_step()                            # packs the weights, fills the allocator
+        g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore)
+        mem.n_pts_host[:] = n_host0 + n_new
+
+        def step():
+            return g(poses[t - 1], heads[t - 1])
+    return model, batch, mem, eps, step, eager_step, geom
 
 
 def time_steps(step, steps, warmup, dist):
@@ -214,7 +230,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
-    model, batch, mem, eps, step, geom = build_workload(args, dev)
+    model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev)
     dt = time_steps(step, args.steps, args.warmup, dist)
     n_gpus = world
     value = n_gpus * args.batch * args.steps / dt
@@ -229,11 +245,12 @@ def main():
                                % (args.batch, geom.n_views, geom.patches ** 2, geom.feat_dim, args.mem_steps,
                                   geom.pts_per_obs * args.mem_steps),
                    "global_batch": args.batch * n_gpus, "parallelism": "dp%d (episode sharding, no step-path collective)" % n_gpus,
+                   "launch": "eager" if args.eager else "hipGraph replay (pose/heading H2D outside the graph)",
                    "gemm": "MFMA bf16 16x16x32, 3-term split (hi*hi+lo*hi+hi*lo), fp32 accumulate",
                    "attention": "MFMA f32 16x16x4 (exact fp32)", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
     }
     if rank == 0 and not args.no_roofline:
-        rl = roofline_leg(step, args, geom)
+        rl = roofline_leg(eager_step, args, geom)   # per-launch HIP events need eager launches
         dom = rl["dominant"]
         out["roofline"] = dict(rl.get(dom, {}), kernel=dom)
         for k in ("linear", "grid_aggregate"):

@@ -6,6 +6,12 @@ PyTorch fallback behind these entry points.
 import ctypes
 import os
 
+# ORDER MATTERS: PyTorch-ROCm bundles its own libamdhip64.so.7.  It must be in the process before
+# libgridmm_hip.so is dlopen'ed so that the library's DT_NEEDED libamdhip64.so.7 resolves (by SONAME) to the
+# SAME HIP runtime that owns torch's streams and allocations; loading ours first binds /opt/rocm's copy and
+# every launch on a torch stream then fails with hipErrorNoDevice.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
 ABI_VERSION = 1
@@ -23,9 +29,11 @@ SIGNATURES = {
     "gridmm_cells_compact": [_vp] * 7 + [_i, _i, _i, _vp],
     "gridmm_split_weight": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_linear": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    "gridmm_layernorm": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
+    "gridmm_layernorm": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gridmm_split_rows": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "gridmm_linear_planes": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gridmm_attention": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
-                         _i, _i, _i, _i, _f, _vp],
+                         _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "gridmm_ln_dot": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_fuse_logits": [_vp] * 13 + [_i, _i, _i, _vp],
     "gridmm_copy_rows": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp],
@@ -61,4 +69,5 @@ def load():
 
 def check(status, what):
     if status != 0:
-        raise GridmmLibraryError("%s failed with status %d" % (what, status))
+        detail = " (hipError_t %d)" % (-1000 - status) if status <= -1000 else ""
+        raise GridmmLibraryError("%s failed with status %d%s" % (what, status, detail))

@@ -19,7 +19,8 @@ constexpr float NEG_BIG = -1.0e30f;
 __global__ __launch_bounds__(256) void attention_kernel(
     const float* __restrict__ Q, int64_t q_bs, int q_rs, const float* __restrict__ K, int64_t k_bs,
     int k_rs, const float* __restrict__ V, int64_t v_bs, int v_rs, const uint8_t* __restrict__ kmask,
-    int mask_bs, float* __restrict__ O, int64_t o_bs, int o_rs, int Sq, int Sk, float scale) {
+    int mask_bs, float* __restrict__ O, int64_t o_bs, int o_rs, unsigned short* __restrict__ Ohi,
+    unsigned short* __restrict__ Olo, int64_t p_bs, int p_rs, int Sq, int Sk, float scale) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 16;
   if (q0 >= Sq) return;
@@ -115,8 +116,19 @@ __global__ __launch_bounds__(256) void attention_kernel(
     const float a = __shfl(inv, 4 * g + r, 64);
     const int q = q0 + 4 * g + r;
     if (q < Sq) {
-      float4 v = make_float4(o[0][r] * a, o[1][r] * a, o[2][r] * a, o[3][r] * a);
-      *reinterpret_cast<float4*>(O + b * o_bs + (size_t)q * o_rs + h * 64 + 4 * j) = v;
+      const float x[4] = {o[0][r] * a, o[1][r] * a, o[2][r] * a, o[3][r] * a};
+      if (O) *reinterpret_cast<float4*>(O + b * o_bs + (size_t)q * o_rs + h * 64 + 4 * j) = make_float4(x[0], x[1], x[2], x[3]);
+      if (Ohi) {
+        u16x4_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned short hh = f32_to_bf16_rne(x[e]);
+          hi[e] = hh;
+          lo[e] = f32_to_bf16_rne(x[e] - bf16_bits_to_f32(hh));
+        }
+        *reinterpret_cast<u16x4_t*>(Ohi + b * p_bs + (size_t)q * p_rs + h * 64 + 4 * j) = hi;
+        *reinterpret_cast<u16x4_t*>(Olo + b * p_bs + (size_t)q * p_rs + h * 64 + 4 * j) = lo;
+      }
     }
   }
 }
@@ -125,14 +137,17 @@ __global__ __launch_bounds__(256) void attention_kernel(
 
 extern "C" int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs,
                                 int k_rs, const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask,
-                                int mask_bs, float* O, int64_t o_bs, int o_rs, int B, int heads, int Sq,
-                                int Sk, float scale, gridmm_stream_t stream) {
+                                int mask_bs, float* O, int64_t o_bs, int o_rs, void* O_hi, void* O_lo,
+                                int64_t p_bs, int p_rs, int B, int heads, int Sq, int Sk, float scale,
+                                gridmm_stream_t stream) {
   if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0) return GRIDMM_EINVAL;
+  if ((!O && !O_hi) || (O_hi && (!O_lo || (p_rs & 3) || (p_bs & 3)))) return GRIDMM_EINVAL;
   if ((q_rs | k_rs | v_rs | o_rs) & 3) return GRIDMM_EINVAL;
   if ((q_bs | k_bs | v_bs | o_bs) & 3) return GRIDMM_EINVAL;
   dim3 grid((Sq + 63) / 64, heads, B), block(256);
   GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
-                     v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, Sq, Sk, scale);
+                     v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs,
+                     p_rs, Sq, Sk, scale);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -13,7 +13,8 @@ typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 
 #define GRIDMM_CHECK_LAUNCH()                                   \
   do {                                                          \
-    if (hipGetLastError() != hipSuccess) return GRIDMM_ELAUNCH; \
+    hipError_t e_ = hipGetLastError();                          \
+    if (e_ != hipSuccess) return -1000 - (int)e_;               \
   } while (0)
 
 // torch (and anything else in the process) can leave a benign sticky error (e.g. hipErrorNotReady from an

@@ -27,7 +27,7 @@ __device__ __forceinline__ int trunc_x86(float v) {
 __global__ __launch_bounds__(256) void grid_project_kernel(
     const uint16_t* __restrict__ depth, const float* __restrict__ x_off,
     const float* __restrict__ view_cos, const float* __restrict__ view_sin,
-    const float* __restrict__ pose, const int32_t* __restrict__ n_old, float* __restrict__ hist_x,
+    const float* __restrict__ pose, int32_t* __restrict__ n_old, float* __restrict__ hist_x,
     float* __restrict__ hist_y, uint8_t* __restrict__ hist_valid, float* __restrict__ bbox,
     float* __restrict__ half_len, float* __restrict__ pos_fts, const uint8_t* __restrict__ active,
     int n_views, int ppv, int cap, float depth_div) {
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void grid_project_kernel(
     s_half = hl;
   }
   __syncthreads();
+  if (tid == 0) n_old[b] = base + n_new;  // the history now holds the new observation (every read of n_old is above)
   // env.py:242-265 -- row i*14+j <-> cell (x=i, y=j)
   if (tid < GRIDMM_CELLS) {
     const float hl = s_half;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(1024) void grid_bin_sort_kernel(
 }  // namespace
 
 extern "C" int gridmm_grid_project(const uint16_t* depth, const float* x_off, const float* view_cos,
-                                   const float* view_sin, const float* pose, const int32_t* n_old,
+                                   const float* view_sin, const float* pose, int32_t* n_old,
                                    float* hist_x, float* hist_y, uint8_t* hist_valid, float* bbox,
                                    float* half_len, float* pos_fts, const uint8_t* active, int B,
                                    int n_views, int ppv, int cap, float depth_div,

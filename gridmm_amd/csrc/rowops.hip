@@ -13,7 +13,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ R, int ldr,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float* __restrict__ Y, int ldy, const float* __restrict__ add1, int ld1,
-    const float* __restrict__ table, const int64_t* __restrict__ idx, int M, int H) {
+    const float* __restrict__ table, const int64_t* __restrict__ idx, unsigned short* __restrict__ Yhi,
+    unsigned short* __restrict__ Ylo, int ldp, int M, int H) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -65,7 +66,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
         const float4 a = reinterpret_cast<const float4*>(trow)[c];
         y.x += a.x; y.y += a.y; y.z += a.z; y.w += a.w;
       }
-      reinterpret_cast<float4*>(Y + (size_t)row * ldy)[c] = y;
+      if (Y) reinterpret_cast<float4*>(Y + (size_t)row * ldy)[c] = y;
+      if (Yhi) {
+        const float x[4] = {y.x, y.y, y.z, y.w};
+        u16x4_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned short h = f32_to_bf16_rne(x[e]);
+          hi[e] = h;
+          lo[e] = f32_to_bf16_rne(x[e] - bf16_bits_to_f32(h));
+        }
+        reinterpret_cast<u16x4_t*>(Yhi + (size_t)row * ldp)[c] = hi;
+        reinterpret_cast<u16x4_t*>(Ylo + (size_t)row * ldp)[c] = lo;
+      }
     }
   }
 }
@@ -265,15 +278,17 @@ __global__ void fuse_logits_kernel(const float* __restrict__ g_raw, const float*
 
 extern "C" int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr, const float* gamma,
                                 const float* beta, float eps, float* Y, int ldy, const float* add1,
-                                int ld1, const float* table, const int64_t* idx, int M, int H,
-                                gridmm_stream_t stream) {
-  if (M <= 0 || H <= 0 || H % 4 || H > MAX_H || ldx % 4 || ldy % 4 || (R && ldr % 4) || (add1 && ld1 % 4))
+                                int ld1, const float* table, const int64_t* idx, void* Y_hi, void* Y_lo,
+                                int ldp, int M, int H, gridmm_stream_t stream) {
+  if (M <= 0 || H <= 0 || H % 4 || H > MAX_H || ldx % 4 || (Y && ldy % 4) || (R && ldr % 4) || (add1 && ld1 % 4))
     return GRIDMM_EINVAL;
+  if ((!Y && !Y_hi) || (Y_hi && (!Y_lo || ldp % 4))) return GRIDMM_EINVAL;
+  unsigned short *Yhi = (unsigned short*)Y_hi, *Ylo = (unsigned short*)Y_lo;
   dim3 grid((M + 3) / 4), block(256);
   const int nv = (H / 4 + 63) / 64;
 #define GRIDMM_LN(NV)                                                                              \
   GRIDMM_LAUNCH((layernorm_kernel<NV>), grid, block, 0, as_stream(stream), X, ldx, R, ldr, gamma, \
-                     beta, eps, Y, ldy, add1, ld1, table, idx, M, H)
+                     beta, eps, Y, ldy, add1, ld1, table, idx, Yhi, Ylo, ldp, M, H)
   if (nv == 1) GRIDMM_LN(1); else if (nv == 2) GRIDMM_LN(2); else if (nv == 3) GRIDMM_LN(3); else GRIDMM_LN(4);
 #undef GRIDMM_LN
   GRIDMM_CHECK_LAUNCH();

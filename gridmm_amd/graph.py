@@ -1,0 +1,52 @@
+"""hipGraph replay of one navigation step (fill_gridmap + forward('navigation')).
+
+The step is ~130 short kernels; launched eagerly from Python it is host-bound (launch gaps ~20 % of
+the step).  Everything on the device side is graph-capturable by construction: the C-ABI only enqueues
+kernels on the caller's stream, the point counters live on the device, and the per-step host inputs
+(pose, heading: a few floats per episode) go through static pinned->device buffers OUTSIDE the graph.
+torch.cuda.CUDAGraph is a hipGraph on ROCm; capture sees the C-ABI launches because they are issued on
+torch's current (capturing) stream.
+
+Shapes are static per graph (B, L, G, V, memory depth): an agent loop would keep one graph per shape
+bucket; bench.py uses one.
+"""
+import torch
+
+
+class GraphedNavStep:
+    def __init__(self, model, mem, batch, depth, restore=None, warmup=2):
+        """depth: (B, n_pts) uint16 device tensor of the observation appended by each step.
+        restore: optional (n_pts0, bbox0) device tensors copied back before each step, so that every replay
+        appends to the same history prefix (benchmarks at a fixed memory depth t)."""
+        self.model, self.mem, self.batch, self.depth = model, mem, dict(batch), depth
+        self.restore = restore
+        dev = mem.device
+        if self.batch.get("fusion_maps") is None:
+            self.batch["fusion_maps"] = model.fusion_maps(batch, dev)
+        self.batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
+        self.graph = None
+        self.outs = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):             # warm-up on a side stream: weight packing, allocator pools
+            for _ in range(warmup):
+                self._device_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outs = self._device_step()
+
+    def _device_step(self):
+        mem = self.mem
+        if self.restore is not None:
+            mem.n_pts.copy_(self.restore[0])
+            mem.bbox.copy_(self.restore[1])
+        mem.project_and_bin(self.depth)
+        return self.model("navigation", self.batch)
+
+    def __call__(self, poses, headings):
+        """poses/headings for the (single) appended observation; returns the static output dict."""
+        self.mem.set_pose(poses, headings)
+        self.graph.replay()
+        return self.outs

@@ -46,6 +46,16 @@ class GridMemoryBatch:
         self.pos_fts = torch.zeros(B, 196, 5, dtype=torch.float32, device=dev)
         self.n_pts = torch.zeros(B, dtype=torch.int32, device=dev)
         self.n_pts_host = np.zeros(B, np.int64)
+        # static per-step inputs (pinned host -> device): the only bytes that cross PCIe each step
+        self._pose_host = torch.zeros(B, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(B, 2)
+        self._head_host = torch.zeros(B, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(B, 2)
+        self._act_host = torch.ones(B, dtype=torch.uint8).pin_memory() if dev.type == "cuda" else torch.ones(B, dtype=torch.uint8)
+        self.pose_d = torch.zeros(B, 2, dtype=torch.float32, device=dev)
+        self.head_d = torch.zeros(B, 2, dtype=torch.float32, device=dev)
+        self.act_d = torch.ones(B, dtype=torch.uint8, device=dev)
+        self._active = None
+        self._h2d_done = None
+        self._bbox_init = torch.tensor([-10000.0, 10000.0, -10000.0, 10000.0], device=dev).repeat(B, 1)
         # host-side constants, rounded exactly as NumPy rounds them in env.py:118, 290
         P = geom.patches
         base = np.array([(2 * c + 1 - P) / P for c in range(P)] * P, np.float32)
@@ -56,11 +66,44 @@ class GridMemoryBatch:
         self.reset()
 
     def reset(self):
-        """EnvBatch.newEpisodes (env.py:178-194)."""
-        self.bbox[:] = torch.tensor([-10000.0, 10000.0, -10000.0, 10000.0], device=self.device)
+        """EnvBatch.newEpisodes (env.py:178-194).  Device-only work (graph-capturable)."""
+        self.bbox.copy_(self._bbox_init)
         self.n_pts.zero_()
         self.n_pts_host[:] = 0
         self.cell_id.fill_(-1)
+
+    # ---- host half of a step: a few floats per episode into static (pinned -> device) buffers
+    def set_pose(self, poses, headings, active=None):
+        """poses: B x (x, y) python floats (viewpoint_info, env.py:286); headings: B python floats.
+        Rounded to fp32 on the host exactly as NumPy does (env.py:118-120, 344-348)."""
+        if self._h2d_done is not None:
+            self._h2d_done.synchronize()          # the previous step's async H2D has consumed the pinned buffers
+        p = self._pose_host.numpy()
+        h = self._head_host.numpy()
+        for b in range(self.B):
+            p[b, 0], p[b, 1] = np.float32(poses[b][0]), np.float32(poses[b][1])
+            h[b, 0], h[b, 1] = np.float32(math.cos(-headings[b])), np.float32(math.sin(-headings[b]))
+        self.pose_d.copy_(self._pose_host, non_blocking=True)
+        self.head_d.copy_(self._head_host, non_blocking=True)
+        if active is None:
+            self._active = None
+        else:
+            self._act_host.copy_(torch.from_numpy(np.asarray(active, bool).astype(np.uint8)))
+            self.act_d.copy_(self._act_host, non_blocking=True)
+            self._active = np.asarray(active, bool)
+        if self.device.type == "cuda":
+            self._h2d_done = torch.cuda.Event()
+            self._h2d_done.record()
+
+    # ---- device half: kernel launches only (replayable from a hipGraph)
+    def project_and_bin(self, depth):
+        """depth (B, n_views*ppv) uint16 on the device.  Uses the pose/heading set by set_pose()."""
+        ops.grid_project(depth, self.x_off, self.view_cos, self.view_sin, self.pose_d, self.n_pts, self.hist_x,
+                         self.hist_y, self.hist_valid, self.bbox, self.half_len, self.pos_fts,
+                         None if self._active is None else self.act_d,
+                         self.geom.n_views, self.geom.patches ** 2, self.geom.depth_div)
+        ops.grid_bin(self.hist_x, self.hist_y, self.hist_valid, self.n_pts, self.pose_d, self.head_d, self.half_len,
+                     self.cell_id, self.perm, self.cell_start)
 
     def step(self, depth, feats, poses, headings, active=None):
         """Append one observation per episode and re-bin the whole history (getGlobalMap for all i).
@@ -68,7 +111,7 @@ class GridMemoryBatch:
         depth  (B, n_views*ppv) uint16  sampled patch-centre depth (host or device)
         feats  (B, n_views*ppv, D) fp16 patch tokens (host or device), or None when the producer has
                already written them in place into `next_slot()` (zero-copy append)
-        poses  B x (x, y) python floats (viewpoint_info, env.py:286); headings B python floats
+        poses  B x (x, y) python floats; headings B python floats
         active optional B bools: inactive episodes are left untouched
         """
         B, dev, n_new = self.B, self.device, self.n_new
@@ -81,29 +124,16 @@ class GridMemoryBatch:
         depth = depth.reshape(B, n_new).contiguous()
         if feats is not None:
             feats = torch.as_tensor(feats).to(dev, non_blocking=True).reshape(B, n_new, self.geom.feat_dim)
-        pose32 = np.array([[np.float32(p[0]), np.float32(p[1])] for p in poses], np.float32)
-        head_cs = np.array([[np.float32(math.cos(-h)), np.float32(math.sin(-h))] for h in headings], np.float32)
-        pose_d = torch.from_numpy(pose32).to(dev)
-        head_d = torch.from_numpy(head_cs).to(dev)
-        act_d = None if active is None else torch.from_numpy(act_host.astype(np.uint8)).to(dev)
-
-        lock = act_host.all() and (self.n_pts_host == self.n_pts_host[0]).all()
-        if feats is None:
-            pass  # zero-copy append: the producer already wrote the tokens into next_slot()
-        elif lock:
-            n0 = int(self.n_pts_host[0])
-            self.slab[:, n0:n0 + n_new].copy_(feats)
-        else:
-            for b in np.nonzero(act_host)[0]:
-                n0 = int(self.n_pts_host[b])
-                self.slab[b, n0:n0 + n_new].copy_(feats[b])
-        ops.grid_project(depth, self.x_off, self.view_cos, self.view_sin, pose_d, self.n_pts, self.hist_x,
-                         self.hist_y, self.hist_valid, self.bbox, self.half_len, self.pos_fts, act_d,
-                         self.geom.n_views, self.geom.patches ** 2, self.geom.depth_div)
-        self.n_pts_host[act_host] += n_new
-        self.n_pts.copy_(torch.from_numpy(self.n_pts_host.astype(np.int32)))
-        ops.grid_bin(self.hist_x, self.hist_y, self.hist_valid, self.n_pts, pose_d, head_d, self.half_len,
-                     self.cell_id, self.perm, self.cell_start)
+            if act_host.all() and (self.n_pts_host == self.n_pts_host[0]).all():
+                n0 = int(self.n_pts_host[0])
+                self.slab[:, n0:n0 + n_new].copy_(feats)
+            else:
+                for b in np.nonzero(act_host)[0]:
+                    n0 = int(self.n_pts_host[b])
+                    self.slab[b, n0:n0 + n_new].copy_(feats[b])
+        self.set_pose(poses, headings, active)
+        self.project_and_bin(depth)
+        self.n_pts_host[act_host] += n_new            # host mirror of the device-side counter
         return self.pos_fts
 
     def next_slot(self):

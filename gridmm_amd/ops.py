@@ -122,32 +122,92 @@ def uniform_rows(t):
     return t.contiguous()
 
 
-def linear(x, pw, act=ACT_NONE, residual=None, out=None):
-    """out = act(x @ W^T + b) (+ residual).  x: (..., K) fp32, rows uniformly strided."""
+class Act:
+    """An activation in up to two device representations: fp32 (residual / LayerNorm / attention
+    input) and bf16 hi/lo planes (A operand of the next MFMA GEMM, written by the producer kernel)."""
+
+    __slots__ = ("f32", "hi", "lo")
+
+    def __init__(self, f32=None, hi=None, lo=None):
+        self.f32, self.hi, self.lo = f32, hi, lo
+
+    @property
+    def shape(self):
+        return (self.f32 if self.f32 is not None else self.hi).shape
+
+    @property
+    def device(self):
+        return (self.f32 if self.f32 is not None else self.hi).device
+
+
+def _planes_like(shape, device):
+    hi = torch.empty(tuple(shape), dtype=torch.bfloat16, device=device)
+    return hi, torch.empty_like(hi)
+
+
+def split_rows(x):
+    """fp32 (..., K) -> Act with bf16 hi/lo planes (K % 8 == 0)."""
     lib = _lib.load()
     x = uniform_rows(x)
+    M, K, ldx = _rows2d(x)
+    assert K % 8 == 0
+    hi, lo = _planes_like(x.shape, x.device)
+    _timed("split_rows", 0.0, lambda: _lib.check(
+        lib.gridmm_split_rows(_p(x), ldx, _p(hi), _p(lo), K, M, K, _stream()), "gridmm_split_rows"))
+    return Act(x, hi, lo)
+
+
+def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_planes=False):
+    """act(x @ W^T + b) (+ residual) -> Act.  x: Act or fp32 tensor (..., K).
+
+    K % 32 == 0 (every hidden-size GEMM): gridmm_linear_planes -- A as bf16 planes (taken from the
+    producer, or split here for external fp32 inputs), LDS-DMA pipeline.  Otherwise (K = 5 / 7 / 14
+    position features): gridmm_linear with the split done in the kernel.
+    """
+    lib = _lib.load()
+    a = x if isinstance(x, Act) else Act(x)
+    shape = a.shape
+    K = shape[-1]
+    if K != pw.K:
+        raise ValueError("linear: bad input %s for weight (%d,%d)" % (tuple(shape), pw.N, pw.K))
     if residual is not None:
         residual = uniform_rows(residual)
-    M, K, lda = _rows2d(x)
-    if K != pw.K or x.dtype != torch.float32:
-        raise ValueError("linear: bad input %s for weight (%d,%d)" % (tuple(x.shape), pw.N, pw.K))
-    if out is None:
-        out = torch.empty(*x.shape[:-1], pw.N, dtype=torch.float32, device=x.device)
-    Mo, No, ldc = _rows2d(out)
-    assert Mo == M and No == pw.N
-    ldr = 0
-    if residual is not None:
-        Mr, Nr, ldr = _rows2d(residual)
-        assert Mr == M and Nr == pw.N
-    _timed("linear", 2.0 * M * pw.N * K, lambda: _lib.check(
-        lib.gridmm_linear(_p(x), lda, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual), ldr,
-                          _p(out), ldc, M, pw.N, K, act, _stream()), "gridmm_linear"))
-    return out
+    oshape = tuple(shape[:-1]) + (pw.N,)
+    dev = a.device
+    if (K % 32 == 0) and (pw.N % 4 == 0):
+        if a.hi is None or not _is_uniform(a.hi):
+            a = split_rows(a.f32)
+        M, _, lda = _rows2d(a.hi)
+        c = out if out is not None else (torch.empty(oshape, dtype=torch.float32, device=dev) if want_f32 else None)
+        hi = lo = None
+        if want_planes:
+            hi, lo = _planes_like(oshape, dev)
+        ldc = _rows2d(c)[2] if c is not None else 0
+        ldr = _rows2d(residual)[2] if residual is not None else 0
+        _timed("linear", 2.0 * M * pw.N * K, lambda: _lib.check(
+            lib.gridmm_linear_planes(_p(a.hi), _p(a.lo), lda, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual),
+                                     ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream()),
+            "gridmm_linear_planes"))
+        return Act(c, hi, lo)
+    xf = uniform_rows(a.f32)
+    M, _, lda = _rows2d(xf)
+    if xf.dtype != torch.float32:
+        raise ValueError("linear: fp32 input expected")
+    c = out if out is not None else torch.empty(oshape, dtype=torch.float32, device=dev)
+    ldc = _rows2d(c)[2]
+    ldr = _rows2d(residual)[2] if residual is not None else 0
+    _timed("linear_small", 2.0 * M * pw.N * K, lambda: _lib.check(
+        lib.gridmm_linear(_p(xf), lda, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual), ldr,
+                          _p(c), ldc, M, pw.N, K, act, _stream()), "gridmm_linear"))
+    return split_rows(c) if want_planes else Act(c)
 
 
-def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=None, out=None):
-    """out = LN(x (+ residual)) * gamma + beta (+ add1) (+ table[idx])."""
+def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=None, out=None,
+              want_f32=True, want_planes=False):
+    """LN(x (+ residual)) * gamma + beta (+ add1) (+ table[idx]) -> Act (fp32 and/or bf16 planes)."""
     lib = _lib.load()
+    if isinstance(x, Act):
+        x = x.f32
     x = uniform_rows(x)
     residual = None if residual is None else uniform_rows(residual)
     add1 = None if add1 is None else uniform_rows(add1)
@@ -155,9 +215,12 @@ def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=Non
     final = None
     if out is not None and not _is_uniform(out):
         final, out = out, None
-    if out is None:
+    if out is None and (want_f32 or final is not None):
         out = torch.empty(*x.shape, dtype=torch.float32, device=x.device)
-    _, _, ldy = _rows2d(out)
+    ldy = _rows2d(out)[2] if out is not None else 0
+    hi = lo = None
+    if want_planes:
+        hi, lo = _planes_like(x.shape, x.device)
     ldr = ld1 = 0
     if residual is not None:
         _, _, ldr = _rows2d(residual)
@@ -166,16 +229,19 @@ def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=Non
     if idx is not None:
         idx = idx.reshape(-1).to(torch.int64).contiguous()
         assert idx.numel() == M
-    _lib.check(lib.gridmm_layernorm(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(beta), float(eps), _p(out), ldy,
-                                    _p(add1), ld1, _p(table), _p(idx), M, H, _stream()), "gridmm_layernorm")
+    _timed("layernorm", 0.0, lambda: _lib.check(
+        lib.gridmm_layernorm(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(beta), float(eps), _p(out), ldy,
+                             _p(add1), ld1, _p(table), _p(idx), _p(hi), _p(lo), H, M, H, _stream()),
+        "gridmm_layernorm"))
     if final is not None:
         copy_rows(out, final, 0)
-        return final
-    return out
+        out = final
+    return Act(out, hi, lo)
 
 
-def attention(q, k, v, kmask, out=None, heads=12, scale=None):
-    """q (B,Sq,H*64) / k,v (B,Sk,H*64) possibly strided views into fused QKV buffers; kmask (B,Sk) uint8/bool."""
+def attention(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True):
+    """q (B,Sq,H*64) / k,v (B,Sk,H*64) fp32, possibly strided views into fused QKV buffers; kmask (B,Sk)
+    uint8/bool.  Returns an Act (bf16 planes for the output projection by default)."""
     lib = _lib.load()
     B, Sq, HD = q.shape
     Sk = k.shape[1]
@@ -184,21 +250,25 @@ def attention(q, k, v, kmask, out=None, heads=12, scale=None):
         assert t.stride(2) == 1 and t.dtype == torch.float32
     if scale is None:
         scale = 1.0 / math.sqrt(64.0)
-    if out is None:
-        out = torch.empty(B, Sq, HD, dtype=torch.float32, device=q.device)
+    out = torch.empty(B, Sq, HD, dtype=torch.float32, device=q.device) if want_f32 else None
+    hi = lo = None
+    if want_planes:
+        hi, lo = _planes_like((B, Sq, HD), q.device)
     if kmask is not None:
         if kmask.dtype == torch.bool:
             kmask = kmask.view(torch.uint8)
         assert kmask.shape == (B, Sk) and kmask.stride(1) == 1
     _timed("attention", 4.0 * B * Sq * Sk * HD, lambda: _lib.check(lib.gridmm_attention(
         _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
-        _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), out.stride(0), out.stride(1),
+        _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * HD, HD, _p(hi), _p(lo), Sq * HD, HD,
         B, heads, Sq, Sk, float(scale), _stream()), "gridmm_attention"))
-    return out
+    return Act(out, hi, lo)
 
 
 def ln_dot(x, gamma, beta, eps, w, b0, out=None):
     lib = _lib.load()
+    if isinstance(x, Act):
+        x = x.f32
     x = uniform_rows(x)
     M, H, ldx = _rows2d(x)
     if out is None:
@@ -211,6 +281,9 @@ def ln_dot(x, gamma, beta, eps, w, b0, out=None):
 def copy_rows(src, dst, dst_row0=0):
     """dst[:, dst_row0:dst_row0+rows] = src   for (B, rows, H) fp32 tensors (row-contiguous)."""
     lib = _lib.load()
+    if src.dtype == torch.bfloat16:   # bf16 planes move as packed words
+        assert dst.dtype == torch.bfloat16 and src.shape[2] % 8 == 0 and src.stride(1) % 2 == 0
+        src, dst = src.view(torch.float32), dst.view(torch.float32)
     B, rows, H = src.shape
     assert dst.shape[0] == B and dst.shape[2] == H and src.stride(2) == 1 and dst.stride(2) == 1
     d = dst[:, dst_row0:dst_row0 + rows]

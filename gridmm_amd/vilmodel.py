@@ -254,53 +254,61 @@ class GlocalTextPathNavCMT(nn.Module):
         mods = {"qkv": [att.query, att.key, att.value], "kv": [att.key, att.value], "q": [att.query]}[which]
         return self._pack(key + "." + which, [m.weight for m in mods], [m.bias for m in mods])
 
-    # ---- building blocks ----------------------------------------------------------------------
+    # ---- building blocks (activations travel as ops.Act: fp32 and/or bf16 hi/lo planes) ---------
     def _ln(self, mod, x, residual=None, **kw):
         return ops.layernorm(x, mod.weight, mod.bias, mod.eps, residual=residual, **kw)
 
+    def _attend(self, qkv_q, k, v, kmask):
+        return ops.attention(qkv_q, k, v, kmask, heads=self.heads)   # -> planes for the output projection
+
     def _self_attention(self, att, key, x, kmask):
-        """BertAttention (vilmodel.py:172-182): LN(dense(attn(x)) + x)."""
+        """BertAttention (vilmodel.py:172-182): LN(dense(attn(x)) + x).  x: Act(f32 + planes)."""
         H = x.shape[-1]
-        qkv = ops.linear(x, self._qkv(att.self, key))
-        ctx = ops.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask, heads=self.heads)
-        return self._ln(att.output.LayerNorm, ops.linear(ctx, self._lin(att.output.dense, key + ".o")), residual=x)
+        qkv = ops.linear(x, self._qkv(att.self, key)).f32
+        ctx = self._attend(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask)
+        h = ops.linear(ctx, self._lin(att.output.dense, key + ".o"), residual=x.f32)
+        return self._ln(att.output.LayerNorm, h, want_planes=True)
 
     def _cross_attention(self, xatt, key, x, ctx, ctx_mask, kv=None):
-        """BertXAttention (vilmodel.py:370-379)."""
+        """BertXAttention (vilmodel.py:370-379).  kv: precomputed (B,Sk,>=2H) fp32 view [K | V]."""
         H = x.shape[-1]
-        q = ops.linear(x, self._qkv(xatt.att, key, "q"))
+        q = ops.linear(x, self._qkv(xatt.att, key, "q")).f32
         if kv is None:
-            kv = ops.linear(ctx, self._qkv(xatt.att, key, "kv"))
-        c = ops.attention(q, kv[..., :H], kv[..., H:2 * H], ctx_mask, heads=self.heads)
-        return self._ln(xatt.output.LayerNorm, ops.linear(c, self._lin(xatt.output.dense, key + ".o")), residual=x)
+            kv = ops.linear(ctx, self._qkv(xatt.att, key, "kv")).f32
+        c = self._attend(q, kv[..., :H], kv[..., H:2 * H], ctx_mask)
+        h = ops.linear(c, self._lin(xatt.output.dense, key + ".o"), residual=x.f32)
+        return self._ln(xatt.output.LayerNorm, h, want_planes=True)
 
     def _ffn(self, inter, out, key, x):
-        h = ops.linear(x, self._lin(inter.dense, key + ".i"), act=ops.ACT_GELU)
-        return self._ln(out.LayerNorm, ops.linear(h, self._lin(out.dense, key + ".f")), residual=x)
+        h = ops.linear(x, self._lin(inter.dense, key + ".i"), act=ops.ACT_GELU, want_f32=False, want_planes=True)
+        o = ops.linear(h, self._lin(out.dense, key + ".f"), residual=x.f32)
+        return self._ln(out.LayerNorm, o, want_planes=True)
 
     def _bert_layer(self, layer, key, x, kmask):
         a = self._self_attention(layer.attention, key + ".att", x, kmask)
         return self._ffn(layer.intermediate, layer.output, key, a)
 
-    def _x_layer(self, layer, key, lang, lang_mask, visn, visn_mask):
+    def _x_layer(self, layer, key, lang, lang_mask, visn, visn_mask, kv=None):
         """GraphLXRTXLayer.forward with graph_sprels=None (vilmodel.py:399-414)."""
-        a = self._cross_attention(layer.visual_attention, key + ".x", visn, lang, lang_mask)
+        a = self._cross_attention(layer.visual_attention, key + ".x", visn, lang, lang_mask, kv=kv)
         a = self._self_attention(layer.visn_self_att, key + ".s", a, visn_mask)
         return self._ffn(layer.visn_inter, layer.visn_output, key, a)
 
     def _pre_ln_encoder(self, enc, key, x, kmask):
-        """TransformerEncoder, normalize_before=True (transformer.py:170-182), final LN eps 1e-12."""
+        """TransformerEncoder, normalize_before=True (transformer.py:170-182), final LN eps 1e-12.
+        x: fp32 tensor (the residual stream); returns Act(f32 + planes)."""
         H = x.shape[-1]
         for i, layer in enumerate(enc.layers):
             k = "%s.%d" % (key, i)
-            h = self._ln(layer.norm1, x)
-            qkv = ops.linear(h, self._pack(k + ".in", [layer.self_attn.in_proj_weight], [layer.self_attn.in_proj_bias]))
-            ctx = ops.attention(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask, heads=self.heads)
-            x = ops.linear(ctx, self._lin(layer.self_attn.out_proj, k + ".o"), residual=x)
-            h = self._ln(layer.norm2, x)
-            f = ops.linear(h, self._lin(layer.linear1, k + ".1"), act=ops.ACT_GELU)
-            x = ops.linear(f, self._lin(layer.linear2, k + ".2"), residual=x)
-        return self._ln(enc.norm, x)
+            h = self._ln(layer.norm1, x, want_f32=False, want_planes=True)
+            qkv = ops.linear(h, self._pack(k + ".in", [layer.self_attn.in_proj_weight],
+                                           [layer.self_attn.in_proj_bias])).f32
+            ctx = self._attend(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask)
+            x = ops.linear(ctx, self._lin(layer.self_attn.out_proj, k + ".o"), residual=x).f32
+            h = self._ln(layer.norm2, x, want_f32=False, want_planes=True)
+            f = ops.linear(h, self._lin(layer.linear1, k + ".1"), act=ops.ACT_GELU, want_f32=False, want_planes=True)
+            x = ops.linear(f, self._lin(layer.linear2, k + ".2"), residual=x).f32
+        return self._ln(enc.norm, x, want_planes=True)
 
     def _cls(self, head, key, x):
         """ClsPrediction (vilmodel.py:663-674): Linear -> ReLU -> LN -> Linear(H,1)."""
@@ -321,11 +329,11 @@ class GlocalTextPathNavCMT(nn.Module):
         pos = torch.arange(L, device=txt_ids.device).unsqueeze(0).expand_as(txt_ids)
         x = e.word_embeddings.weight[txt_ids]                     # gathers = data movement
         pt = (e.position_embeddings.weight[pos] + e.token_type_embeddings.weight[0]).contiguous()
-        x = self._ln(e.LayerNorm, x.contiguous(), residual=pt)
+        x = self._ln(e.LayerNorm, x.contiguous(), residual=pt, want_planes=True)
         m = self._u8(txt_masks)
         for i, layer in enumerate(self.lang_encoder.layer):
             x = self._bert_layer(layer, "lang.%d" % i, x, m)
-        return x
+        return x.f32
 
     @torch.no_grad()
     def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
@@ -337,11 +345,11 @@ class GlocalTextPathNavCMT(nn.Module):
         extra = (ie.nav_type_embedding.weight[nav_types] + self.embeddings.token_type_embeddings.weight[1]).contiguous()
         y = self._ln(ie.loc_layer_norm, ops.linear(loc_fts.float().contiguous(), self._lin(ie.loc_linear, "loc")),
                      add1=extra)
-        x = self._ln(ie.layer_norm, x, residual=y)
+        x = self._ln(ie.layer_norm, x, residual=y.f32).f32
         lens = view_lens
         masks = torch.arange(int(lens.max()), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
         if ie.pano_encoder is not None:
-            x = self._pre_ln_encoder(ie.pano_encoder, "pano", x, self._u8(masks))
+            x = self._pre_ln_encoder(ie.pano_encoder, "pano", x, self._u8(masks)).f32
         return x, masks
 
     @staticmethod
@@ -365,11 +373,18 @@ class GlocalTextPathNavCMT(nn.Module):
                     cand_of_node[i, j] = tmp.get(vp, -1)
         return cand_of_node, cand_visited
 
+    def fusion_maps(self, batch, device):
+        """Device tensors for batch['fusion_maps'] (integer form of the vpid-keyed fusion loops)."""
+        G, V = batch["gmap_masks"].shape[1], batch["vp_masks"].shape[1]
+        a, b = self._fusion_index_maps(batch["gmap_vpids"], batch["gmap_visited_masks"], batch["vp_cand_vpids"], G, V)
+        return a.to(device), b.to(device)
+
     @torch.no_grad()
     def forward_navigation_per_step(
             self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
             gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
-            vp_nav_masks, vp_obj_masks, vp_cand_vpids, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None):
+            vp_nav_masks, vp_obj_masks, vp_cand_vpids, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None,
+            fusion_maps=None):
         """vilmodel.py:782-918 on HIP kernels.  Same arguments, same output dict."""
         dev = txt_embeds.device
         B, L, H = txt_embeds.shape
@@ -378,7 +393,8 @@ class GlocalTextPathNavCMT(nn.Module):
         txt_m, gmap_m, vp_m = self._u8(txt_masks), self._u8(gmap_masks), self._u8(vp_masks)
 
         # ---- grid memory -> 196 instruction-weighted cell vectors (vilmodel.py:793-807)
-        text_fts = ops.linear(txt_embeds, self._lin(self.text_proj, "text_proj"))
+        txt = ops.split_rows(txt_embeds)                       # fp32 + bf16 planes of the instruction tokens
+        text_fts = ops.linear(txt, self._lin(self.text_proj, "text_proj")).f32
         frag = ops.text_fragments(text_fts)
         if grid_memory is not None:
             slab, perm, cell_start = grid_memory.slab, grid_memory.perm, grid_memory.cell_start
@@ -387,9 +403,9 @@ class GlocalTextPathNavCMT(nn.Module):
         else:
             slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
         cells, occ = ops.grid_aggregate(slab, perm, cell_start, frag, L)
-        proj = ops.linear(cells, self._lin(self.grid_proj, "grid_proj"))
+        proj = ops.linear(cells, self._lin(self.grid_proj, "grid_proj")).f32
         gp = self.grid_pos_embeddings
-        pos_emb = self._ln(gp[1], ops.linear(gridmap_pos_fts.float().contiguous(), self._lin(gp[0], "grid_pos")))
+        pos_emb = self._ln(gp[1], ops.linear(gridmap_pos_fts.float().contiguous(), self._lin(gp[0], "grid_pos"))).f32
 
         # ---- [cells | gmap nodes] sequence, padded to 196 + G (vilmodel.py:813-837)
         S = N_CELLS + G
@@ -409,19 +425,32 @@ class GlocalTextPathNavCMT(nn.Module):
                  add1=vp_img_embeds.float().contiguous(), out=q[:, G:])
 
         # ---- grid encoder + grid/text cross-modal layer (vilmodel.py:840-841)
-        map_embeds = self._pre_ln_encoder(self.grid_encoder, "grid_enc", map_embeds, map_masks)
+        mp = self._pre_ln_encoder(self.grid_encoder, "grid_enc", map_embeds, map_masks)
         for i, layer in enumerate(self.grid_txt_encoder.x_layers):
-            map_embeds = self._x_layer(layer, "grid_txt.%d" % i, txt_embeds, txt_m, map_embeds, map_masks)
+            mp = self._x_layer(layer, "grid_txt.%d" % i, txt, txt_m, mp, map_masks)
+        map_embeds = mp.f32
 
-        # ---- local encoder over q = [gmap | vp], kv = [map | txt] (vilmodel.py:843-856)
-        kv = torch.empty(B, S + L, H, dtype=torch.float32, device=dev)
-        ops.copy_rows(map_embeds, kv, 0)
-        ops.copy_rows(txt_embeds, kv, S)
+        # ---- local encoder over q = [gmap | vp], kv = [map | txt] (vilmodel.py:843-856).  The context is the
+        # same for all layers, so the K/V projections of every layer run as ONE GEMM (N = layers * 2H).
+        kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
+        for src, dst in ((mp.hi, kv.hi), (mp.lo, kv.lo)):
+            ops.copy_rows(src, dst, 0)
+        for src, dst in ((txt.hi, kv.hi), (txt.lo, kv.lo)):
+            ops.copy_rows(src, dst, S)
         kv_masks = torch.cat([map_masks, txt_m], 1)
+        xl = le.encoder.x_layers
+        kv_all = ops.linear(kv, self._pack("local.kv_all",
+                                           [w for l in xl for w in (l.visual_attention.att.key.weight,
+                                                                    l.visual_attention.att.value.weight)],
+                                           [b for l in xl for b in (l.visual_attention.att.key.bias,
+                                                                    l.visual_attention.att.value.bias)])).f32
         ops.copy_rows(map_embeds[:, N_CELLS:], q, 0)
+        qa = ops.split_rows(q)
         q_masks = torch.cat([gmap_m, vp_m], 1)
-        for i, layer in enumerate(le.encoder.x_layers):
-            q = self._x_layer(layer, "local.%d" % i, kv, kv_masks, q, q_masks)
+        for i, layer in enumerate(xl):
+            qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks,
+                               kv=kv_all[..., 2 * H * i:2 * H * (i + 1)])
+        q = qa.f32
         gmap_embeds, vp_embeds = q[:, :G], q[:, G:]
 
         # ---- heads + fusion (vilmodel.py:859-907)
@@ -431,10 +460,12 @@ class GlocalTextPathNavCMT(nn.Module):
         g_raw = self._cls(self.global_sap_head, "ghead", gmap_embeds)
         grid_raw = self._cls(self.grid_sap_head, "gridhead", map_embeds[:, N_CELLS:])
         l_raw = self._cls(self.local_sap_head, "lhead", vp_embeds)
-        cand_of_node, cand_visited = self._fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V)
+        if fusion_maps is None:   # host-built from the python vpid lists; pass precomputed device tensors to avoid
+            cand_of_node, cand_visited = self._fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V)
+            fusion_maps = (cand_of_node.to(dev), cand_visited.to(dev))   # the H2D (needed under graph capture)
         global_logits, local_logits, grid_logits, fused_logits = ops.fuse_logits(
             g_raw, l_raw, grid_raw, fuse_raw, gmap_m, self._u8(gmap_visited_masks), self._u8(vp_nav_masks),
-            cand_of_node.to(dev), cand_visited.to(dev))
+            fusion_maps[0], fusion_maps[1])
         obj_logits = None
         if vp_obj_masks is not None:
             obj_logits = self._cls(self.og_head, "oghead", vp_embeds)
@@ -460,5 +491,5 @@ class GlocalTextPathNavCMT(nn.Module):
                 batch["gmap_visited_masks"], batch["gmap_vpids"], batch["vp_img_embeds"], batch["vp_pos_fts"],
                 batch["vp_masks"], batch["vp_nav_masks"], batch.get("vp_obj_masks"), batch["vp_cand_vpids"],
                 batch.get("grid_fts"), batch.get("grid_map"), batch.get("gridmap_pos_fts"),
-                grid_memory=batch.get("grid_memory"))
+                grid_memory=batch.get("grid_memory"), fusion_maps=batch.get("fusion_maps"))
         raise NotImplementedError("wrong mode: %s" % mode)

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRIDMM_OK 0
 #define GRIDMM_EINVAL (-1)   /* bad shape / unsupported size */
-#define GRIDMM_ELAUNCH (-2)  /* hipGetLastError() != hipSuccess after launch */
+#define GRIDMM_ELAUNCH (-1000) /* launch failed: status = -1000 - hipError_t */
 
 #define GRIDMM_GRID 14
 #define GRIDMM_CELLS 196
@@ -48,14 +48,15 @@ int gridmm_abi_version(void);
  *   x_off      [ppv] f32   lateral offsets * tan(fov/2)           (host computes, env.py:118)
  *   view_cos/sin [n_views] f32, cos/sin of the python-double view angle rounded to f32
  *   pose       [B][2] f32  (x, y) of the current viewpoint rounded to f32
- *   n_old      [B] int32   points already in the history of each episode
+ *   n_pts      [B] int32   in: points already in the history of each episode; out: += n_views*ppv
+ *                          (kept on the device so that a whole step can be replayed from a hipGraph)
  *   hist_x/y   [B][cap] f32, hist_valid [B][cap] uint8: history (new points written at n_old[b])
  *   bbox       [B][4] f32  running (max_x, min_x, max_y, min_y); init (-10000,10000,-10000,10000)
  *   half_len   [B] f32 out; pos_fts [B][196][5] f32 out
  *   active     [B] uint8 or NULL: episodes with 0 are skipped entirely
  */
 int gridmm_grid_project(const uint16_t* depth, const float* x_off, const float* view_cos,
-                        const float* view_sin, const float* pose, const int32_t* n_old,
+                        const float* view_sin, const float* pose, int32_t* n_pts,
                         float* hist_x, float* hist_y, uint8_t* hist_valid, float* bbox,
                         float* half_len, float* pos_fts, const uint8_t* active,
                         int B, int n_views, int ppv, int cap, float depth_div,
@@ -142,7 +143,21 @@ int gridmm_linear(const float* A, int lda, const void* W_hi, const void* W_lo, i
  * Optionally Y += add1 (+ table[idx[row]]).   Replaces BertLayerNorm / nn.LayerNorm uses. */
 int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr, const float* gamma,
                      const float* beta, float eps, float* Y, int ldy, const float* add1, int ld1,
-                     const float* table, const int64_t* idx, int M, int H, gridmm_stream_t stream);
+                     const float* table, const int64_t* idx, void* Y_hi, void* Y_lo, int ldp,
+                     int M, int H, gridmm_stream_t stream);
+/* (Y may be NULL when only the bf16 hi/lo planes Y_hi/Y_lo [M][ldp] -- the next GEMM's A operand -- are wanted) */
+
+/* fp32 rows -> bf16 hi/lo planes [M][ldp], zero padded to ldp (ldp % 8 == 0). */
+int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, int ldp, int M, int K,
+                      gridmm_stream_t stream);
+
+/* gridmm_linear with BOTH operands as pre-split bf16 planes (the hot-path GEMM: LDS-DMA tile pipeline,
+ * no conversion in the loop).  K % 32 == 0, lda % 8 == 0, N % 4 == 0.  Output as fp32 (C) and/or as
+ * bf16 hi/lo planes (C_hi/C_lo, row stride ldp) for the next GEMM. */
+int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
+                         int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                         void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
+                         gridmm_stream_t stream);
 
 /* Multi-head attention core, head_dim 64, fp32 (MFMA f32 16x16x4), online softmax.
  * O[b][i][h*64+d] = sum_j softmax_j(scale * <Q[b,i,h], K[b,j,h]>  over keys with kmask=1) V[b,j,h,d]
@@ -152,8 +167,9 @@ int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr, const flo
  *   kmask [B][Sk] uint8 (row stride mask_bs) */
 int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
                      const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs,
-                     float* O, int64_t o_bs, int o_rs, int B, int heads, int Sq, int Sk,
-                     float scale, gridmm_stream_t stream);
+                     float* O, int64_t o_bs, int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs,
+                     int B, int heads, int Sq, int Sk, float scale, gridmm_stream_t stream);
+/* (O may be NULL when only the bf16 hi/lo planes O_hi/O_lo, strides p_bs/p_rs in elements, are wanted) */
 
 /* out[m] = <LayerNorm(X[m]) * gamma + beta, w> + b0      (tail of ClsPrediction,
  * vilmodel.py:663-674: Linear -> ReLU -> LN -> Linear(H,1)). */

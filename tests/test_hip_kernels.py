@@ -32,7 +32,8 @@ def test_linear_bf16x3_matches_fp32(dev, M, N, K, act):
     b = (torch.randn(N, generator=g) * 0.1).to(dev)
     r = torch.randn(M, N, generator=g).to(dev) if act != 1 else None
     pw = ops.PackedLinear(w, b)
-    y = ops.linear(x, pw, act=act, residual=r)
+    out = ops.linear(x, pw, act=act, residual=r, want_planes=(N % 8 == 0))
+    y = out.f32
     ref = x.double() @ w.double().t() + b.double()
     if act == 1:
         ref = ref * 0.5 * (1 + torch.erf(ref / math.sqrt(2)))
@@ -45,6 +46,10 @@ def test_linear_bf16x3_matches_fp32(dev, M, N, K, act):
     assert err <= 4e-5 * scale + 1e-6, (err, scale)     # ~2^-16 relative to the absolute-value product
     # and clearly better than a single bf16 term would be
     assert err <= 2e-4 * max(1.0, ref.abs().max().item())
+    # the bf16 hi/lo planes emitted for the next GEMM reproduce the fp32 result to ~2^-16
+    if out.hi is not None:
+        rec = out.hi.float() + out.lo.float()
+        assert (rec - y).abs().max().item() <= 2.0 ** -15 * max(1e-3, y.abs().max().item())
 
 
 def test_linear_strided_input_and_output(dev):
@@ -52,7 +57,7 @@ def test_linear_strided_input_and_output(dev):
     x = torch.randn(4, 50, 1024, device=dev)[..., :768]        # row stride 1024
     w = torch.randn(96, 768, device=dev) * 0.05
     pw = ops.PackedLinear(w, None)
-    y = ops.linear(x, pw)
+    y = ops.linear(x, pw).f32
     assert torch.allclose(y, x @ w.t(), atol=2e-4, rtol=1e-4)
 
 
@@ -64,16 +69,19 @@ def test_layernorm_variants(dev, M, H):
     table = torch.randn(11, H, device=dev)
     idx = torch.randint(0, 11, (M,), device=dev)
     for eps in (1e-12, 1e-5):
-        y = ops.layernorm(x, g, b, eps)
+        y = ops.layernorm(x, g, b, eps).f32
         assert torch.allclose(y, F.layer_norm(x, (H,), g, b, eps), atol=2e-5, rtol=1e-5)
-        y = ops.layernorm(x, g, b, eps, residual=r, add1=a, table=table, idx=idx)
+        ya = ops.layernorm(x, g, b, eps, residual=r, add1=a, table=table, idx=idx, want_planes=(H % 8 == 0))
+        y = ya.f32
         ref = F.layer_norm(x + r, (H,), g, b, eps) + a + table[idx]
         assert torch.allclose(y, ref, atol=3e-5, rtol=1e-5)
+        if ya.hi is not None:
+            assert ((ya.hi.float() + ya.lo.float()) - y).abs().max() <= 2.0 ** -15 * y.abs().max()
     w, b0 = torch.randn(H, device=dev), torch.randn(1, device=dev)
     d = ops.ln_dot(x, g, b, 1e-12, w, b0)
     ref = F.layer_norm(x, (H,), g, b, 1e-12) @ w + b0
     assert torch.allclose(d, ref, atol=2e-4, rtol=1e-5)
-    z = ops.layernorm(torch.zeros(3, H, device=dev), g, b, 1e-5)      # zero rows -> beta, no NaN
+    z = ops.layernorm(torch.zeros(3, H, device=dev), g, b, 1e-5).f32      # zero rows -> beta, no NaN
     assert torch.allclose(z, b.expand(3, H))
 
 
@@ -91,7 +99,9 @@ def test_attention_matches_fp32_softmax(dev, B, Sq, Sk):
     if not mask[-1].any():
         mask[-1, -1] = True
     mask = mask.to(dev)
-    o = ops.attention(q, k, v, mask)
+    oa = ops.attention(q, k, v, mask, want_f32=True, want_planes=True)
+    o = oa.f32
+    assert ((oa.hi.float() + oa.lo.float()) - o).abs().max() <= 2.0 ** -15 * o.abs().max()
     def heads(t):
         return t.reshape(B, -1, Hh, 64).permute(0, 2, 1, 3).double()
     s = heads(q) @ heads(k).transpose(-1, -2) / 8.0

@@ -64,7 +64,7 @@ def test_aggregation_stage_matches_reference_capture():
     model, sd = _model(fx)
     batch = _to_dev(golden_nav_batch(fx))
     B, L, H = batch["txt_embeds"].shape
-    text_fts = ops.linear(batch["txt_embeds"], model._lin(model.text_proj, "text_proj"))
+    text_fts = ops.linear(batch["txt_embeds"], model._lin(model.text_proj, "text_proj")).f32
     slab, perm, cs = pack_reference_lists(batch["grid_fts"], batch["grid_map"])
     cells, occ, rel = ops.grid_aggregate(slab, perm, cs, ops.text_fragments(text_fts), L, want_relevance=True)
     # oracle for the un-projected stage
@@ -86,9 +86,9 @@ def test_aggregation_stage_matches_reference_capture():
                     assert (cells[b, c].cpu() - ref).abs().max() < 1e-4   # bf16x3 text_proj noise enters through softmax(w)
                 else:
                     assert (cells[b, c] == 0).all()
-    proj = ops.linear(cells, model._lin(model.grid_proj, "grid_proj"))
+    proj = ops.linear(cells, model._lin(model.grid_proj, "grid_proj")).f32
     gp = model.grid_pos_embeddings
-    pos_emb = model._ln(gp[1], ops.linear(batch["gridmap_pos_fts"], model._lin(gp[0], "grid_pos")))
+    pos_emb = model._ln(gp[1], ops.linear(batch["gridmap_pos_fts"], model._lin(gp[0], "grid_pos"))).f32
     out = torch.zeros(B, 196 + 2, H, device="cuda")
     mask = torch.zeros(B, 196 + 2, dtype=torch.uint8, device="cuda")
     n_cells, cmax = ops.cells_compact(proj, pos_emb, occ, out, mask)
