@@ -32,6 +32,7 @@ SIGNATURES = {
     "gridmm_layernorm": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_split_rows": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_linear_planes": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gridmm_linear_planes_cfg": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gridmm_attention": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
                          _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "gridmm_ln_dot": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],

@@ -73,7 +73,25 @@ __global__ void build_chunks_kernel(const int32_t* __restrict__ cell_start, int3
 // RESIDENT: wave t keeps text column tile t in registers (Lt <= 8 waves, <= 256 VGPRs).
 // !RESIDENT (L > 128): 8 waves, each loops over column tiles t, t+8, ... and re-streams the
 // fragments from L2 per tile -- correct for any L <= 256, slower.
-template <int KS, bool RESIDENT>  // D = 32 * KS
+//
+// Pipeline: an R-slot LDS ring of 32-point tiles filled by LDS-DMA (one 1-KiB global_load_lds per
+// 512-D row, XOR swizzle on the per-lane SOURCE chunk; row ids come from SCALAR loads of `perm`, so no
+// vector-memory load ever queues behind the DMA bursts).  Tile t+R-1 is issued right after the barrier
+// that retires tile t-1; a COUNTED s_waitcnt vmcnt keeps R-2 younger tiles (64-96 KB per CU) in flight
+// across every barrier -- that is what it takes to cover the HBM latency of a 1-KiB-row gather.
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void wait_vm_dyn(int n) {  // n = (R-2) * rows-per-wave: a handful of values
+  switch (n) {
+    case 8: wait_vm<8>(); break;    case 10: wait_vm<10>(); break;  case 12: wait_vm<12>(); break;
+    case 14: wait_vm<14>(); break;  case 16: wait_vm<16>(); break;  case 4: wait_vm<4>(); break;
+    case 5: wait_vm<5>(); break;    case 6: wait_vm<6>(); break;    case 7: wait_vm<7>(); break;
+    default: wait_vm<0>(); break;
+  }
+}
+
+template <int KS, bool RESIDENT, int R>  // D = 32 * KS, R ring slots
 __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     const _Float16* __restrict__ slab, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ cell_start, const _Float16* __restrict__ text_frag,
@@ -83,15 +101,16 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
   constexpr int NCH = D / 8;                 // 16-B chunks per row
   constexpr int NACC = (D / 2 + 255) / 256;  // feature-dim pairs per thread (block >= 256 threads)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  _Float16* s_tile = reinterpret_cast<_Float16*>(smem);                       // [TILE][D]
-  float* s_wmax = reinterpret_cast<float*>(smem + (size_t)TILE * D * 2);      // [Lt][TILE]
-  float* s_w = s_wmax + (size_t)Lt * TILE;                                    // [TILE]
-  float* s_e = s_w + TILE;                                                    // [TILE]
-  int* s_cell = reinterpret_cast<int*>(s_e + TILE);                           // [TILE]
-  int* s_src = s_cell + TILE;                                                 // [TILE]
-  float* s_state = reinterpret_cast<float*>(s_src + TILE);                    // [0]=scale_run [1]=m_run
+  _Float16* s_tiles = reinterpret_cast<_Float16*>(smem);                       // [R][TILE][D]
+  float* s_wmax = reinterpret_cast<float*>(smem + (size_t)R * TILE * D * 2);   // [Lt][TILE]
+  float* s_w = s_wmax + (size_t)Lt * TILE;                                     // [TILE]
+  float* s_e = s_w + TILE;                                                     // [TILE]
+  int* s_cell = reinterpret_cast<int*>(s_e + TILE);                            // [TILE]
+  float* s_state = reinterpret_cast<float*>(s_cell + TILE);                    // [0]=scale [1]=m_run [2]=heads
+  int* s_cs = reinterpret_cast<int*>(s_state + 4);                             // [198] cell_start of this episode
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nwaves = nthreads >> 6;
   const int b = blockIdx.y, k = blockIdx.x;
   const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
@@ -110,6 +129,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     }
   }
   if (p_lo >= p_hi) return;
+  for (int i = tid; i < GRIDMM_CELLS + 2; i += nthreads) s_cs[i] = cs[i];  // binary searches run on LDS
 
   // this wave's text columns, register-resident for the whole chunk
   const size_t plane = (size_t)Lt * KS * 64 * 8;
@@ -143,40 +163,67 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     if (tid == 0) occ_b[cur] = 1;
   };
 
-  for (int p0 = p_lo; p0 < p_hi; p0 += TILE) {
+  const int ntiles = (p_hi - p_lo + TILE - 1) / TILE;
+  const int RW = (TILE + nwaves - 1) / nwaves;  // DMA instructions per wave per tile (x NCH/64), constant
+  constexpr int IPR = (NCH + 63) / 64;           // DMA instructions per row
+  // LDS-DMA of tile t: wave w moves rows w, w+nwaves, ... (always RW of them: short waves / short tiles
+  // repeat a valid row, so the in-order vmcnt bookkeeping is the same for every wave and tile).
+  // Position c of row r holds global chunk c ^ (r & 15).
+  auto dma_tile = [&](int t) {
+    _Float16* dst = s_tiles + (size_t)(t % R) * TILE * D;
+    const int p0 = p_lo + t * TILE;
+    for (int j = 0; j < RW; ++j) {
+      int r = wave + j * nwaves;
+      if (r >= TILE) r = wave;
+      int p = p0 + r;
+      if (p >= p_hi) p = p_hi - 1;
+      const int src = __builtin_amdgcn_readfirstlane(perm_b[p]);   // wave-uniform address -> scalar load
+      const _Float16* row = slab_b + (size_t)src * D;
+#pragma unroll
+      for (int c0 = 0; c0 < NCH; c0 += 64) {
+        const int c = c0 + lane;
+        if (c < NCH)   // D = 768: the second 1-KiB piece of a row is half masked (still one vmcnt event)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(row + (size_t)(c ^ (r & 15)) * 8),
+              (__attribute__((address_space(3))) void*)(dst + (size_t)r * D + (size_t)c0 * 8), 16, 0, 0);
+      }
+    }
+  };
+  auto lds_barrier = [&]() {  // LDS-visibility barrier that leaves the DMA (vmcnt) in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  __syncthreads();                                  // s_cs visible
+  for (int t = 0; t < R - 1 && t < ntiles; ++t) dma_tile(t);
+  const int keep = (R - 2) * RW * IPR;              // DMA instructions allowed to stay in flight
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int p0 = p_lo + t * TILE;
     const int npt = min(TILE, p_hi - p0);
-    // ---- 1. stage rows
-    if (tid < TILE) {
-      int src = -1, cell = -1;
-      if (tid < npt) {
-        src = perm_b[p0 + tid];
-        // cell of sorted position p0+tid: the last c with cs[c] <= p (binary search over 197 starts)
-        int lo = c_lo, hi = c_hi;  // invariant cs[lo] <= p < cs[hi]
-        const int p = p0 + tid;
+    const _Float16* s_tile = s_tiles + (size_t)(t % R) * TILE * D;
+    // ---- 1. retire tile t (counted wait: the R-2 younger tiles stay in flight), publish it, issue tile t+R-1
+    if (t + R - 2 < ntiles) wait_vm_dyn(keep); else wait_vm<0>();
+    lds_barrier();
+    if (t + R - 1 < ntiles) dma_tile(t + R - 1);    // its slot held tile t-1: free since the barrier above
+    if (tid < TILE) {                               // cell of each point of this tile (binary search on LDS)
+      int cell = -1;
+      const int p = p0 + tid;
+      if (p < p_hi) {
+        int lo = c_lo, hi = c_hi;  // invariant cs[lo] <= p < cs[hi]; the last c with cs[c] <= p owns p
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
-          if (cs[mid] <= p) lo = mid; else hi = mid;
+          if (s_cs[mid] <= p) lo = mid; else hi = mid;
         }
         cell = lo;
       }
-      s_src[tid] = src;
       s_cell[tid] = cell;
     }
-    __syncthreads();
-    for (int r = wave; r < TILE; r += nwaves) {
-      const int src = s_src[r];
-      for (int c = lane; c < NCH; c += 64) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (src >= 0) v = reinterpret_cast<const uint4*>(slab_b + (size_t)src * D)[c];
-        reinterpret_cast<uint4*>(s_tile + (size_t)r * D)[c ^ (r & 15)] = v;
-      }
-    }
-    __syncthreads();
     // ---- 2. relevance on the matrix pipe
     for (int ct = wave; ct < Lt; ct += nwaves) {
       const int i = lane & 15, g = lane >> 4;
       const bool two = npt > 16;
-      f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         f16x8_t bh, bl;
@@ -190,17 +237,17 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
         const int ch = ks * 4 + g;
         const f16x8_t a0 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)i * D)[ch ^ i];
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, acc0, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, acc2, 0, 0, 0);
         if (two) {
           const f16x8_t a1 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(16 + i) * D)[ch ^ i];
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc1, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc3, 0, 0, 0);
         }
       }
       const bool colv = (ct * 16 + i) < L;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x0 = colv ? acc0[r] : NEG_BIG, x1 = colv ? acc1[r] : NEG_BIG;
+        float x0 = colv ? acc0[r] + acc2[r] : NEG_BIG, x1 = colv ? acc1[r] + acc3[r] : NEG_BIG;
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
           x0 = fmaxf(x0, __shfl_xor(x0, o, 64));
@@ -212,61 +259,99 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
         }
       }
     }
-    __syncthreads();
-    if (tid < TILE) {
+    lds_barrier();
+    // ---- 3a. (wave 0) per-point relevance; points are sorted by cell, so a cell is a contiguous run of lanes:
+    //          segmented max by shuffles, softmax numerators against the (running / in-tile) cell maximum
+    if (wave == 0) {
       float w = NEG_BIG;
-      for (int t = 0; t < Lt; ++t) w = fmaxf(w, s_wmax[t * TILE + tid]);
-      s_w[tid] = w;
-      if (relevance && tid < npt) relevance[(size_t)b * cap + s_src[tid]] = w;
-    }
-    __syncthreads();
-    // ---- 3a. per-point softmax numerators against the (running / in-tile) cell maximum
-    if (tid < TILE) {
-      float e = 0.f;
-      if (tid < npt) {
-        const int c = s_cell[tid];
-        float m = (c == cur) ? m_run : NEG_BIG;
-        for (int r = 0; r < npt; ++r)
-          if (s_cell[r] == c) m = fmaxf(m, s_w[r]);
-        e = expf(s_w[tid] - m);
-        if (tid == 0) s_state[0] = (c == cur) ? expf(m_run - m) : 1.0f;  // rescale of the running cell
-        if (tid == npt - 1) s_state[1] = m;                                // maximum of the last cell
+      if (lane < TILE)
+        for (int q = 0; q < Lt; ++q) w = fmaxf(w, s_wmax[q * TILE + lane]);
+      if (relevance && lane < npt) relevance[(size_t)b * cap + perm_b[p0 + lane]] = w;   // tests only
+      const int c = (lane < npt) ? s_cell[lane] : -2 - lane;   // unique sentinel: never joins a run
+      if (lane >= npt) w = NEG_BIG;
+      float pre = w, suf = w;
+#pragma unroll
+      for (int o = 1; o < TILE; o <<= 1) {
+        const float pu = __shfl_up(pre, o, 64), sd = __shfl_down(suf, o, 64);
+        const int cu = __shfl_up(c, o, 64), cd = __shfl_down(c, o, 64);
+        if (lane >= o && cu == c) pre = fmaxf(pre, pu);
+        if (lane + o < 64 && cd == c) suf = fmaxf(suf, sd);
       }
-      s_e[tid] = e;
+      float m = fmaxf(pre, suf);
+      if (c == cur) m = fmaxf(m, m_run);                       // the run continuing from the previous tile
+      const int cprev = __shfl_up(c, 1, 64);
+      const bool head = (lane < npt) && (lane == 0 || cprev != c);
+      const unsigned long long heads = __ballot(head);
+      if (lane < TILE) s_e[lane] = (lane < npt) ? expf(w - m) : 0.f;
+      if (lane == 0) {
+        s_state[0] = (c == cur) ? expf(m_run - m) : 1.0f;      // rescale of the running cell
+        reinterpret_cast<unsigned int*>(s_state)[2] = (unsigned int)heads;
+      }
+      if (lane == npt - 1) s_state[1] = m;                      // maximum of the last cell
     }
-    __syncthreads();
-    // ---- 3b. accumulate rows (all threads; 2 feature dims per thread per NACC slot)
+    lds_barrier();
+    // ---- 3b. accumulate rows, one contiguous run (cell) at a time; 2 feature dims per thread per NACC slot
     {
       const float sc = s_state[0];
+      unsigned int heads = reinterpret_cast<const unsigned int*>(s_state)[2];
       if (cur >= 0 && s_cell[0] == cur) {
         s_run *= sc;
 #pragma unroll
         for (int a = 0; a < NACC; ++a) { v0[a] *= sc; v1[a] *= sc; }
       }
-      for (int r = 0; r < npt; ++r) {
-        const int c = s_cell[r];
+      while (heads) {
+        const int r0 = __builtin_ctz(heads);
+        heads &= heads - 1;
+        const int r1 = heads ? __builtin_ctz(heads) : npt;
+        const int c = s_cell[r0];
         if (c != cur) {
           flush();
           cur = c; s_run = 0.f;
 #pragma unroll
           for (int a = 0; a < NACC; ++a) v0[a] = v1[a] = 0.f;
         }
-        const float e = s_e[r];
-        s_run += e;
+        int r = r0;
+        for (; r + 4 <= r1; r += 4) {          // 4 independent LDS reads in flight per slot
+          float e[4];
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) {
-          const int dp = tid + a * nthreads;
-          if (dp < D / 2) {
-            const int ch = (dp >> 2) ^ (r & 15);
-            const f16x2_t h = *reinterpret_cast<const f16x2_t*>(s_tile + (size_t)r * D + ch * 8 + (dp & 3) * 2);
-            v0[a] += e * (float)h[0];
-            v1[a] += e * (float)h[1];
+          for (int u = 0; u < 4; ++u) e[u] = s_e[r + u];
+#pragma unroll
+          for (int a = 0; a < NACC; ++a) {
+            const int dp = tid + a * nthreads;
+            if (dp < D / 2) {
+              f16x2_t h[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int ch = (dp >> 2) ^ ((r + u) & 15);
+                h[u] = *reinterpret_cast<const f16x2_t*>(s_tile + (size_t)(r + u) * D + ch * 8 + (dp & 3) * 2);
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                v0[a] += e[u] * (float)h[u][0];
+                v1[a] += e[u] * (float)h[u][1];
+              }
+            }
+          }
+          s_run += (e[0] + e[1]) + (e[2] + e[3]);
+        }
+        for (; r < r1; ++r) {
+          const float e = s_e[r];
+          s_run += e;
+#pragma unroll
+          for (int a = 0; a < NACC; ++a) {
+            const int dp = tid + a * nthreads;
+            if (dp < D / 2) {
+              const int ch = (dp >> 2) ^ (r & 15);
+              const f16x2_t h = *reinterpret_cast<const f16x2_t*>(s_tile + (size_t)r * D + ch * 8 + (dp & 3) * 2);
+              v0[a] += e * (float)h[0];
+              v1[a] += e * (float)h[1];
+            }
           }
         }
       }
       m_run = s_state[1];
     }
-    __syncthreads();
+    // (the barrier at the top of the next iteration separates this tile's readers from the next writers)
   }
   flush();
 }
@@ -298,18 +383,22 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
   const bool resident = Lt <= 8;
   const int nwaves = resident ? (Lt < 4 ? 4 : Lt) : 8;
   dim3 grid(n_chunks, B), block(nwaves * 64);
-  const size_t lds = (size_t)TILE * D * 2 + ((size_t)Lt * TILE + 2 * TILE) * sizeof(float) +
-                     2 * TILE * sizeof(int) + 4 * sizeof(float);
-#define GRIDMM_AGG(KS)                                                                              \
-  do {                                                                                              \
-    if (resident)                                                                                   \
-      GRIDMM_LAUNCH((grid_aggregate_kernel<KS, true>), grid, block, lds, st,                   \
-                         (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag, cells, \
-                         occ, relevance, chunks, cap, L, Lt, n_chunks);                             \
-    else                                                                                            \
-      GRIDMM_LAUNCH((grid_aggregate_kernel<KS, false>), grid, block, lds, st,                  \
-                         (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag, cells, \
-                         occ, relevance, chunks, cap, L, Lt, n_chunks);                             \
+  const int R = D <= 512 ? 4 : 3;  // ring slots: 4 x 32 KB (D=512) / 3 x 48 KB (D=768)
+  const size_t lds = (size_t)R * TILE * D * 2 + ((size_t)Lt * TILE + 2 * TILE) * sizeof(float) +
+                     TILE * sizeof(int) + 4 * sizeof(float) + 200 * sizeof(int);
+#define GRIDMM_AGG_ONE(KS, RES)                                                                                   \
+  do {                                                                                                            \
+    auto kern = grid_aggregate_kernel<KS, RES, (KS <= 16 ? 4 : 3)>;                                               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                            (int)lds) != hipSuccess)                                                              \
+      return GRIDMM_EINVAL;                                                                                       \
+    GRIDMM_LAUNCH(kern, grid, block, lds, st, (const _Float16*)slab, perm, cell_start,                            \
+                  (const _Float16*)text_frag, cells, occ, relevance, chunks, cap, L, Lt, n_chunks);               \
+  } while (0)
+#define GRIDMM_AGG(KS)                 \
+  do {                                 \
+    if (resident) GRIDMM_AGG_ONE(KS, true); \
+    else GRIDMM_AGG_ONE(KS, false);    \
   } while (0)
   switch (D) {
     case 256: GRIDMM_AGG(8); break;
@@ -318,6 +407,7 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
     default: return GRIDMM_EINVAL;
   }
 #undef GRIDMM_AGG
+#undef GRIDMM_AGG_ONE
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -44,23 +44,32 @@ __global__ __launch_bounds__(256) void attention_kernel(
   const float* Vb = V + b * v_bs + h * 64 + 4 * j;
   const uint8_t* mb = kmask ? kmask + (size_t)b * mask_bs : nullptr;
 
-  for (int key0 = 0; key0 < Sk; key0 += 16) {
-    // skip fully masked key tiles (wave-uniform)
-    bool any_valid = true;
-    if (mb) {
-      const int kk = key0 + j;
-      any_valid = __any((kk < Sk) && mb[kk]);
-    }
-    if (!any_valid) continue;
-
+  // K/V fragments of one 16-key tile; the next tile is fetched while the current one is in the matrix pipe
+  auto load_kv = [&](int key0, float4 (&kf)[4], float4 (&vf)[4]) {
     const float* krow = Kb + (size_t)min(key0 + j, Sk - 1) * k_rs;
-    float4 kf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const float4*>(krow + 16 * s);
-    float4 vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       vf[s] = *reinterpret_cast<const float4*>(Vb + (size_t)min(key0 + 4 * g + s, Sk - 1) * v_rs);
+  };
+  auto tile_valid = [&](int key0) -> bool {   // wave-uniform: any unmasked key in the tile
+    if (key0 >= Sk) return false;
+    if (!mb) return true;
+    const int kk = key0 + j;
+    return __any((kk < Sk) && mb[kk]);
+  };
+  auto next_valid = [&](int key0) -> int {    // first tile start >= key0 with an unmasked key (or >= Sk)
+    while (key0 < Sk && !tile_valid(key0)) key0 += 16;
+    return key0;
+  };
+
+  float4 kf[4], vf[4], kn[4], vn[4];
+  int key0 = next_valid(0);
+  if (key0 < Sk) load_kv(key0, kf, vf);
+  while (key0 < Sk) {
+    const int key1 = next_valid(key0 + 16);
+    if (key1 < Sk) load_kv(key1, kn, vn);      // prefetch (register double buffer)
 
     f32x4_t st = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -108,6 +117,9 @@ __global__ __launch_bounds__(256) void attention_kernel(
       o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[s], vf[s].z, o[2], 0, 0, 0);
       o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[s], vf[s].w, o[3], 0, 0, 0);
     }
+    key0 = key1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = kn[s]; vf[s] = vn[s]; }
   }
 
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;

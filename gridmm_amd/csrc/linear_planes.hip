@@ -14,33 +14,68 @@
 
 namespace {
 
-constexpr int BK = 32;
-
-__device__ __forceinline__ int swz(int row) { return ((row >> 3) & 1) << 1; }
+// LDS image of a plane tile: row-major [row][BK] bf16; the 16-B chunk index is XOR-swizzled so that every
+// ds_read_b128 lane group (16 rows x one k-chunk) hits 16 distinct bank slots:
+//   BK = 32 (64-B rows, 4 chunks):  chunk ^= ((row >> 3) & 1) << 1
+//   BK = 64 (128-B rows, 8 chunks): chunk ^= (row >> 1) & 7      (full 128-B lines per DMA row)
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+  return BK == 32 ? (((row >> 3) & 1) << 1) : ((row >> 1) & 7);
+}
 
 __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int ACT>
-__global__ __launch_bounds__(256) void linear_planes_kernel(
+// BM x BN block tile, WM x WN per wave (16x16x32 MFMA tiles), NS-stage LDS ring filled by LDS-DMA.
+// One raw s_barrier per k-step; the DMA of stage kt+NS-1 is issued right after the barrier that retires
+// stage kt-1, and only a COUNTED s_waitcnt vmcnt keeps the younger stages in flight across barriers.
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
     const float* __restrict__ bias, const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc,
     unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo, int ldp, int M, int N, int K) {
-  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int STAGE = (2 * BM + 2 * BN) * BK;          // u16 elements per stage: Ahi|Alo|Whi|Wlo
-  constexpr int PIECES = (2 * BM + 2 * BN) / 16;         // 1-KiB DMA pieces per stage
-  constexpr int PPW = PIECES / 4;                        // per wave
-  static_assert(PIECES % 4 == 0, "tile must split evenly over 4 waves");
-  constexpr int EPI = (BM / 2) * (BN / 2);               // floats per wave in the epilogue transpose
-  constexpr int LDS_U16 = (2 * STAGE * 2 > 4 * EPI * 4 ? 2 * STAGE : 4 * EPI * 2);
+  constexpr int RPP = 512 / BK;                          // rows per 1-KiB DMA piece
+  constexpr int CPR = BK / 8;                            // 16-B chunks per row
+  constexpr int PIECES = (2 * BM + 2 * BN) / RPP;        // 1-KiB DMA pieces per stage
+  static_assert(PIECES % NW == 0, "tile must split evenly over the waves");
+  constexpr int PPW = PIECES / NW;
+  constexpr int ER = WM < 64 ? WM : 64;                  // rows per epilogue pass (LDS budget)
+  constexpr int EPI = ER * WN;                           // floats per wave in the epilogue transpose
+  constexpr int LDS_U16 = (NS * STAGE * 2 > NW * EPI * 4 ? NS * STAGE : NW * EPI * 2);
   __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_U16];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+  // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (each XCD has its own 4 MB L2): give every XCD a
+  // CONTIGUOUS chunk of a strip-major tile list (strips of 8 column tiles, row-major inside), so the
+  // workgroups resident on one XCD at a time cover a compact ~8x8 block of tiles and share their A / W
+  // rows through that L2 instead of re-fetching them from the Infinity Cache (measured on this chip:
+  // L2-resident LDS-DMA streams at ~27 TB/s, L2-missing strided rows at ~12 TB/s; tools/l2_to_lds_bw.hip).
+  int ty, tx;
+  {
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN, T = tm * tn;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, q = T >> 3, rem = T & 7;
+    const int t = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;   // bijective for any T
+    constexpr int W = 8;
+    const int nfs = tn / W, full = nfs * tm * W;
+    if (t < full) {
+      const int strip = t / (tm * W), r = t - strip * tm * W;
+      ty = r / W;
+      tx = strip * W + r % W;
+    } else {
+      const int w = tn - nfs * W, r = t - full;
+      ty = r / w;
+      tx = nfs * W + r % w;
+    }
+  }
+  const int bm = ty * BM, bn = tx * BN;
 
   // DMA plan of this wave: piece p covers 16 rows of one plane
   const unsigned short* src[PPW];
@@ -49,12 +84,12 @@ __global__ __launch_bounds__(256) void linear_planes_kernel(
   for (int i = 0; i < PPW; ++i) {
     const int p = wave * PPW + i;
     int plane, r0;
-    if (p < BM / 16) { plane = 0; r0 = p * 16; }
-    else if (p < 2 * BM / 16) { plane = 1; r0 = (p - BM / 16) * 16; }
-    else if (p < (2 * BM + BN) / 16) { plane = 2; r0 = (p - 2 * BM / 16) * 16; }
-    else { plane = 3; r0 = (p - (2 * BM + BN) / 16) * 16; }
-    const int row = r0 + (lane >> 2);
-    const int chunk = (lane & 3) ^ swz(row);
+    if (p < BM / RPP) { plane = 0; r0 = p * RPP; }
+    else if (p < 2 * BM / RPP) { plane = 1; r0 = (p - BM / RPP) * RPP; }
+    else if (p < (2 * BM + BN) / RPP) { plane = 2; r0 = (p - 2 * BM / RPP) * RPP; }
+    else { plane = 3; r0 = (p - (2 * BM + BN) / RPP) * RPP; }
+    const int row = r0 + lane / CPR;
+    const int chunk = (lane % CPR) ^ swz<BK>(row);
     if (plane < 2) {
       const int m = min(bm + row, M - 1);
       src[i] = (plane == 0 ? Ahi : Alo) + (size_t)m * lda + chunk * 8;
@@ -74,53 +109,58 @@ __global__ __launch_bounds__(256) void linear_planes_kernel(
 
   const int nk = K / BK;
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) dma16(src[i], smem + dst[i]);
-  __syncthreads();  // (waits vmcnt(0): stage 0 landed)
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + s * BK, smem + s * STAGE + dst[i]);
+    }
 
   const int frow = lane & 15, fchunk = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
-    const unsigned short* cur = smem + (kt & 1) * STAGE;
-    if (kt + 1 < nk) {
-      unsigned short* nxt = smem + ((kt + 1) & 1) * STAGE;
-#pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + 1) * BK, nxt + dst[i]);
+    // retire stage kt: everything except the (NS-2) younger stages must have landed
+    if (NS >= 3 && kt + NS - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+    __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; buffer (kt-1)%NS is free
+    if (kt + NS - 1 < nk) {
+      unsigned short* nxt = smem + ((kt + NS - 1) % NS) * STAGE;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row = wr * (BM / 2) + i * 16 + frow;
-      const int off = row * BK + (fchunk ^ swz(row)) * 8;
-      ah[i] = *reinterpret_cast<const bf16x8_t*>(cur + off);
-      al[i] = *reinterpret_cast<const bf16x8_t*>(cur + BM * BK + off);
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * BK, nxt + dst[i]);
     }
+    const unsigned short* cur = smem + (kt % NS) * STAGE;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int row = wc * (BN / 2) + j * 16 + frow;
-      const int off = 2 * BM * BK + row * BK + (fchunk ^ swz(row)) * 8;
-      bh[j] = *reinterpret_cast<const bf16x8_t*>(cur + off);
-      bl[j] = *reinterpret_cast<const bf16x8_t*>(cur + BN * BK + off);
-    }
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        const int row = wr * WM + i * 16 + frow;
+        const int off = row * BK + ((ks * 4 + fchunk) ^ swz<BK>(row)) * 8;
+        ah[i] = *reinterpret_cast<const bf16x8_t*>(cur + off);
+        al[i] = *reinterpret_cast<const bf16x8_t*>(cur + BM * BK + off);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        const int row = wc * WN + j * 16 + frow;
+        const int off = 2 * BM * BK + row * BK + ((ks * 4 + fchunk) ^ swz<BK>(row)) * 8;
+        bh[j] = *reinterpret_cast<const bf16x8_t*>(cur + off);
+        bl[j] = *reinterpret_cast<const bf16x8_t*>(cur + BN * BK + off);
       }
-    __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading `cur`
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
   }
+  __syncthreads();  // all waves are done with the last stage before LDS is reused by the epilogue
 
   // ---- epilogue: per-wave transpose through LDS, then row-wise 128-bit accesses
-  constexpr int WM = BM / 2, WN = BN / 2;  // wave sub-tile
   float* ep = reinterpret_cast<float*>(smem) + wave * EPI;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ep[(i * 16 + (lane >> 4) * 4 + r) * WN + j * 16 + (lane & 15)] = acc[i][j][r];
-  __builtin_amdgcn_wave_barrier();
   constexpr int F4_PER_ROW = WN / 4;                // float4 per sub-tile row
   constexpr int ROWS_PER_IT = 64 / F4_PER_ROW;
   const int c4 = lane % F4_PER_ROW, rr = lane / F4_PER_ROW;
@@ -128,32 +168,44 @@ __global__ __launch_bounds__(256) void linear_planes_kernel(
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias && n0 < N) bv = *reinterpret_cast<const float4*>(bias + n0);  // N % 4 == 0
 #pragma unroll
-  for (int it = 0; it < WM / ROWS_PER_IT; ++it) {
-    const int row = it * ROWS_PER_IT + rr;
-    const int m = bm + wr * WM + row;
-    float4 v = *reinterpret_cast<const float4*>(ep + row * WN + c4 * 4);
-    if (m < M && n0 < N) {
-      float x[4] = {v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w};
+  for (int h = 0; h < WM / ER; ++h) {
+    if (h) __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
-        if (ACT == GRIDMM_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
-      }
-      if (R) {
-        const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
-        x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w;
-      }
-      if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
-      if (Chi) {
-        u16x4_t hi, lo;
+    for (int i = 0; i < ER / 16; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[(i * 16 + (lane >> 4) * 4 + r) * WN + j * 16 + (lane & 15)] = acc[h * (ER / 16) + i][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < ER / ROWS_PER_IT; ++it) {
+      const int row = it * ROWS_PER_IT + rr;
+      const int m = bm + wr * WM + h * ER + row;
+      float4 v = *reinterpret_cast<const float4*>(ep + row * WN + c4 * 4);
+      if (m < M && n0 < N) {
+        float x[4] = {v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const unsigned short h = f32_to_bf16_rne(x[e]);
-          hi[e] = h;
-          lo[e] = f32_to_bf16_rne(x[e] - bf16_bits_to_f32(h));
+          if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
+          if (ACT == GRIDMM_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
         }
-        *reinterpret_cast<u16x4_t*>(Chi + (size_t)m * ldp + n0) = hi;
-        *reinterpret_cast<u16x4_t*>(Clo + (size_t)m * ldp + n0) = lo;
+        if (R) {
+          const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
+          x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w;
+        }
+        if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
+        if (Chi) {
+          u16x4_t hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned short hh = f32_to_bf16_rne(x[e]);
+            hi[e] = hh;
+            lo[e] = f32_to_bf16_rne(x[e] - bf16_bits_to_f32(hh));
+          }
+          *reinterpret_cast<u16x4_t*>(Chi + (size_t)m * ldp + n0) = hi;
+          *reinterpret_cast<u16x4_t*>(Clo + (size_t)m * ldp + n0) = lo;
+        }
       }
     }
   }
@@ -180,14 +232,14 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM, int WN, int NS, int BK>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st) {
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(256);
-#define GRIDMM_LP(ACT)                                                                                   \
-  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, ACT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, Kp, bias, \
-                R, ldr, C, ldc, Chi, Clo, ldp, M, N, K)
+  dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM)), block((BM / WM) * (BN / WN) * 64);
+#define GRIDMM_LP(ACT)                                                                                        \
+  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
+                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
   else GRIDMM_LP(GRIDMM_ACT_RELU);
@@ -210,19 +262,66 @@ extern "C" int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, in
   return GRIDMM_OK;
 }
 
-extern "C" int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
-                                    const void* W_lo, int Kp, const float* bias, const float* residual, int ldr,
-                                    float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N, int K,
-                                    int act, gridmm_stream_t stream) {
+// Tile selection (cfg 0): estimated time = ceil(workgroups / (256 CUs * resident workgroups per CU)) rounds,
+// each costing BM*BN*occ / quality, with the relative per-tile throughputs measured on MI355X by
+// tools/bench_gemm.py (profiles/gemm_tiles_r1.txt): larger tiles re-use more of each LDS-DMA'd byte, small
+// ones fill the 256 CUs when M*N is small.
+static int pick_cfg(int M, int N, int K) {
+  struct Cand { int cfg, bm, bn, occ; float q; bool k64; };
+  static const Cand cands[] = {
+      {7, 256, 256, 1, 1.00f, false}, {3, 256, 128, 1, 0.95f, false}, {1, 128, 128, 2, 0.88f, false},
+      {2, 128, 128, 1, 0.87f, true},  {8, 64, 64, 2, 0.75f, true},    {4, 64, 64, 5, 0.60f, false}};
+  int best = 4;
+  float best_t = 1e30f;
+  for (const Cand& c : cands) {
+    if (c.k64 && (K % 64)) continue;
+    const long wgs = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+    const long rounds = (wgs + 256L * c.occ - 1) / (256L * c.occ);
+    const float t = (float)rounds * c.occ * c.bm * c.bn / c.q;
+    if (t < best_t) { best_t = t; best = c.cfg; }
+  }
+  return best;
+}
+
+// cfg: 0 = auto; tuning configs 1..6 (tools/bench_gemm.py):
+//   1: 128x128 NS=2   2: 128x128 NS=3   3: 256x128 (8 waves) NS=2   4: 64x64 NS=2   5: 64x64 NS=3   6: 128x64 NS=3
+extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
+                                        const void* W_lo, int Kp, const float* bias, const float* residual,
+                                        int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N,
+                                        int K, int act, int cfg, gridmm_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || act < 0 || act > 2)
     return GRIDMM_EINVAL;
+  if (K % 64 && (cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 13)) return GRIDMM_EINVAL;
   if ((C && ldc % 4) || (residual && ldr % 4) || (C_hi && (ldp % 4 || !C_lo)) || (!C && !C_hi)) return GRIDMM_EINVAL;
   const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
   const unsigned short *wh = (const unsigned short*)W_hi, *wl = (const unsigned short*)W_lo;
   unsigned short *ch = (unsigned short*)C_hi, *cl = (unsigned short*)C_lo;
   hipStream_t st = as_stream(stream);
-  const long wg128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (wg128 >= 200)
-    return launch<128, 128>(ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st);
-  return launch<64, 64>(ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st);
+  if (cfg == 0) cfg = pick_cfg(M, N, K);
+#define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st
+  switch (cfg) {
+    case 1: return launch<128, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
+    case 2: return launch<128, 128, 64, 32, 2, 64>(GRIDMM_ARGS);
+    case 3: return launch<256, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
+    case 4: return launch<64, 64, 32, 32, 2, 32>(GRIDMM_ARGS);
+    case 5: return launch<128, 128, 64, 64, 2, 64>(GRIDMM_ARGS);
+    case 6: return launch<128, 64, 64, 32, 2, 32>(GRIDMM_ARGS);
+    case 7: return launch<256, 256, 128, 64, 2, 32>(GRIDMM_ARGS);
+    case 8: return launch<64, 64, 32, 32, 2, 64>(GRIDMM_ARGS);
+    case 9: return launch<128, 64, 32, 32, 2, 64>(GRIDMM_ARGS);
+    case 10: return launch<64, 64, 32, 32, 4, 64>(GRIDMM_ARGS);
+    case 11: return launch<64, 64, 32, 32, 3, 64>(GRIDMM_ARGS);
+    case 12: return launch<128, 128, 64, 32, 3, 32>(GRIDMM_ARGS);
+    case 13: return launch<128, 64, 32, 32, 3, 64>(GRIDMM_ARGS);
+    default: return GRIDMM_EINVAL;
+  }
+#undef GRIDMM_ARGS
+}
+
+extern "C" int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
+                                    const void* W_lo, int Kp, const float* bias, const float* residual, int ldr,
+                                    float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N, int K,
+                                    int act, gridmm_stream_t stream) {
+  return gridmm_linear_planes_cfg(A_hi, A_lo, lda, W_hi, W_lo, Kp, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M,
+                                  N, K, act, 0, stream);
 }

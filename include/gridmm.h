@@ -159,6 +159,12 @@ int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void
                          void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
                          gridmm_stream_t stream);
 
+/* Same with an explicit tile configuration (tuning / benchmarking; cfg 0 = the heuristic above). */
+int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
+                             int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                             void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act, int cfg,
+                             gridmm_stream_t stream);
+
 /* Multi-head attention core, head_dim 64, fp32 (MFMA f32 16x16x4), online softmax.
  * O[b][i][h*64+d] = sum_j softmax_j(scale * <Q[b,i,h], K[b,j,h]>  over keys with kmask=1) V[b,j,h,d]
  * Masked keys contribute exactly 0 (both mask conventions of the reference, vilmodel.py:136,
