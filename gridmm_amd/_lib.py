@@ -35,6 +35,9 @@ SIGNATURES = {
     "gridmm_linear_planes_cfg": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gridmm_attention": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
                          _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
+    "gridmm_transpose_v": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_attention_planes": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i,
+                                _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "gridmm_ln_dot": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_fuse_logits": [_vp] * 13 + [_i, _i, _i, _vp],
     "gridmm_copy_rows": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp],

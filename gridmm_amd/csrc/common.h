@@ -37,6 +37,19 @@ __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }
 
+// two fp32 -> packed bf16x2 (lo half = a, hi half = b), round-to-nearest-even, ONE VALU instruction on gfx950
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b) {
+  unsigned int r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// hi/lo bf16 split of two floats: hi = rne(x), lo = rne(x - hi); returns packed pairs
+__device__ __forceinline__ void split2_bf16(float a, float b, unsigned int& hi, unsigned int& lo) {
+  hi = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  lo = cvt_pk_bf16(ra, rb);
+}
+
 // 64-lane wave reductions (wave = 64 on CDNA).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

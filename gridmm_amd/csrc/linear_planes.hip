@@ -269,8 +269,12 @@ extern "C" int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, in
 static int pick_cfg(int M, int N, int K) {
   struct Cand { int cfg, bm, bn, occ; float q; bool k64; };
   static const Cand cands[] = {
-      {7, 256, 256, 1, 1.00f, false}, {3, 256, 128, 1, 0.95f, false}, {1, 128, 128, 2, 0.88f, false},
-      {2, 128, 128, 1, 0.87f, true},  {8, 64, 64, 2, 0.75f, true},    {4, 64, 64, 5, 0.60f, false}};
+      {7, 256, 256, 1, 1.30f, false},  // 8 waves, 128x64 per wave: most reuse per LDS-DMA byte
+      {16, 256, 128, 1, 1.00f, false}, // 16 waves
+      {15, 128, 128, 2, 1.10f, false}, // 16 waves x 2 workgroups = full 32-wave occupancy
+      {2, 128, 128, 1, 0.87f, true},   // 8 waves, BK = 64
+      {8, 64, 64, 2, 0.75f, true},     // small M*N: fills the 256 CUs
+      {4, 64, 64, 5, 0.60f, false}};
   int best = 4;
   float best_t = 1e30f;
   for (const Cand& c : cands) {
@@ -313,6 +317,9 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
     case 11: return launch<64, 64, 32, 32, 3, 64>(GRIDMM_ARGS);
     case 12: return launch<128, 128, 64, 32, 3, 32>(GRIDMM_ARGS);
     case 13: return launch<128, 64, 32, 32, 3, 64>(GRIDMM_ARGS);
+    case 14: return launch<128, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
+    case 15: return launch<128, 128, 32, 32, 2, 32>(GRIDMM_ARGS);
+    case 16: return launch<256, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
     default: return GRIDMM_EINVAL;
   }
 #undef GRIDMM_ARGS

@@ -199,13 +199,13 @@ __global__ __launch_bounds__(256) void cells_compact_kernel(
       for (int w = 1; w < 4; ++w) cmax = s_wmax[w] > cmax ? s_wmax[w] : cmax;
       s_tail = n + tail;
       s_cmax = cmax;
-      n_cells[b] = n;
-      if (b == 0) cmax_out[0] = cmax;
+      if (blockIdx.y == 0) n_cells[b] = n;
+      if (b == 0 && blockIdx.y == 0) cmax_out[0] = cmax;
     }
   }
   __syncthreads();
   const int n = s_n, lim = s_tail, cmax = s_cmax;
-  for (int p = tid; p < GRIDMM_CELLS; p += blockDim.x) {
+  for (int p = tid; p < GRIDMM_CELLS && blockIdx.y == 0; p += blockDim.x) {
     uint8_t m;
     if (p < n) m = 1;
     else if (p < lim) m = occ[b * GRIDMM_CELLS + p] ? 1 : 0;
@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256) void cells_compact_kernel(
   }
   const int nv = H >> 2;
   float* ob = out + (size_t)b * S_pad * H;
-  for (int i = tid; i < GRIDMM_CELLS * nv; i += blockDim.x) {
+  // blockIdx.y splits the 196 output rows into 14 slices (the row copy is the only real work)
+  const int p_lo = blockIdx.y * GRIDMM_GRID, p_hi = p_lo + GRIDMM_GRID;
+  for (int i = p_lo * nv + tid; i < p_hi * nv; i += blockDim.x) {
     const int p = i / nv, c = i % nv;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p < n) {
@@ -327,7 +329,7 @@ extern "C" int gridmm_cells_compact(const float* proj, const float* pos_emb, con
                                     uint8_t* mask, int32_t* n_cells, int32_t* cmax, int B, int H, int S_pad,
                                     gridmm_stream_t stream) {
   if (B <= 0 || H <= 0 || H % 4 || S_pad < GRIDMM_CELLS) return GRIDMM_EINVAL;
-  GRIDMM_LAUNCH(cells_compact_kernel, dim3(B), dim3(256), 0, as_stream(stream), proj, pos_emb, occ,
+  GRIDMM_LAUNCH(cells_compact_kernel, dim3(B, GRIDMM_GRID), dim3(256), 0, as_stream(stream), proj, pos_emb, occ,
                      out, mask, n_cells, cmax, B, H, S_pad);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;

@@ -258,24 +258,29 @@ class GlocalTextPathNavCMT(nn.Module):
     def _ln(self, mod, x, residual=None, **kw):
         return ops.layernorm(x, mod.weight, mod.bias, mod.eps, residual=residual, **kw)
 
-    def _attend(self, qkv_q, k, v, kmask):
-        return ops.attention(qkv_q, k, v, kmask, heads=self.heads)   # -> planes for the output projection
+    def _attend(self, q, k, v, kmask):
+        """q/k/v: ops.Act holding bf16 planes (B,S,n*H) + column offsets (act, col0) -> bf16x3 attention."""
+        def sl(t):
+            a, c0 = t
+            H = self.config.hidden_size
+            return a.hi[..., c0:c0 + H], a.lo[..., c0:c0 + H]
+        return ops.attention_planes(sl(q), sl(k), sl(v), kmask, heads=self.heads)   # -> planes for the out-proj
 
     def _self_attention(self, att, key, x, kmask):
         """BertAttention (vilmodel.py:172-182): LN(dense(attn(x)) + x).  x: Act(f32 + planes)."""
         H = x.shape[-1]
-        qkv = ops.linear(x, self._qkv(att.self, key)).f32
-        ctx = self._attend(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask)
+        qkv = ops.linear(x, self._qkv(att.self, key), want_f32=False, want_planes=True)
+        ctx = self._attend((qkv, 0), (qkv, H), (qkv, 2 * H), kmask)
         h = ops.linear(ctx, self._lin(att.output.dense, key + ".o"), residual=x.f32)
         return self._ln(att.output.LayerNorm, h, want_planes=True)
 
     def _cross_attention(self, xatt, key, x, ctx, ctx_mask, kv=None):
-        """BertXAttention (vilmodel.py:370-379).  kv: precomputed (B,Sk,>=2H) fp32 view [K | V]."""
+        """BertXAttention (vilmodel.py:370-379).  kv: optional precomputed (Act planes (B,Sk,n*2H), col0)."""
         H = x.shape[-1]
-        q = ops.linear(x, self._qkv(xatt.att, key, "q")).f32
+        q = ops.linear(x, self._qkv(xatt.att, key, "q"), want_f32=False, want_planes=True)
         if kv is None:
-            kv = ops.linear(ctx, self._qkv(xatt.att, key, "kv")).f32
-        c = self._attend(q, kv[..., :H], kv[..., H:2 * H], ctx_mask)
+            kv = (ops.linear(ctx, self._qkv(xatt.att, key, "kv"), want_f32=False, want_planes=True), 0)
+        c = self._attend((q, 0), (kv[0], kv[1]), (kv[0], kv[1] + H), ctx_mask)
         h = ops.linear(c, self._lin(xatt.output.dense, key + ".o"), residual=x.f32)
         return self._ln(xatt.output.LayerNorm, h, want_planes=True)
 
@@ -302,8 +307,8 @@ class GlocalTextPathNavCMT(nn.Module):
             k = "%s.%d" % (key, i)
             h = self._ln(layer.norm1, x, want_f32=False, want_planes=True)
             qkv = ops.linear(h, self._pack(k + ".in", [layer.self_attn.in_proj_weight],
-                                           [layer.self_attn.in_proj_bias])).f32
-            ctx = self._attend(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], kmask)
+                                           [layer.self_attn.in_proj_bias]), want_f32=False, want_planes=True)
+            ctx = self._attend((qkv, 0), (qkv, H), (qkv, 2 * H), kmask)
             x = ops.linear(ctx, self._lin(layer.self_attn.out_proj, k + ".o"), residual=x).f32
             h = self._ln(layer.norm2, x, want_f32=False, want_planes=True)
             f = ops.linear(h, self._lin(layer.linear1, k + ".1"), act=ops.ACT_GELU, want_f32=False, want_planes=True)
@@ -318,6 +323,8 @@ class GlocalTextPathNavCMT(nn.Module):
 
     @staticmethod
     def _u8(m):
+        if m.dtype == torch.bool:
+            return m.contiguous().view(torch.uint8)      # same bytes, no copy kernel
         return (m if m.dtype == torch.uint8 else m.to(torch.uint8)).contiguous()
 
     # ---- modes --------------------------------------------------------------------------------
@@ -443,13 +450,13 @@ class GlocalTextPathNavCMT(nn.Module):
                                            [w for l in xl for w in (l.visual_attention.att.key.weight,
                                                                     l.visual_attention.att.value.weight)],
                                            [b for l in xl for b in (l.visual_attention.att.key.bias,
-                                                                    l.visual_attention.att.value.bias)])).f32
+                                                                    l.visual_attention.att.value.bias)]),
+                            want_f32=False, want_planes=True)
         ops.copy_rows(map_embeds[:, N_CELLS:], q, 0)
         qa = ops.split_rows(q)
         q_masks = torch.cat([gmap_m, vp_m], 1)
         for i, layer in enumerate(xl):
-            qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks,
-                               kv=kv_all[..., 2 * H * i:2 * H * (i + 1)])
+            qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks, kv=(kv_all, 2 * H * i))
         q = qa.f32
         gmap_embeds, vp_embeds = q[:, :G], q[:, G:]
 

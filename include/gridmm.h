@@ -177,6 +177,17 @@ int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const float* K, int
                      int B, int heads, int Sq, int Sk, float scale, gridmm_stream_t stream);
 /* (O may be NULL when only the bf16 hi/lo planes O_hi/O_lo, strides p_bs/p_rs in elements, are wanted) */
 
+/* bf16x3 variant (the one on the hot path): Q and K as the bf16 hi/lo planes the QKV GEMM emits, V as
+ * per-head RE-TILED planes VT[b][h][key tile of 32][d][32 slots] (Skp = roundup(Sk, 32) keys, zero padded;
+ * slot 8g+e <-> key 4g+e for e<4, 16+4g+(e-4) otherwise) built by gridmm_transpose_v.  Both matmuls run on MFMA bf16 16x16x32 with the 3-term split, softmax in fp32. */
+int gridmm_transpose_v(const void* V_hi, const void* V_lo, int64_t v_bs, int v_rs, void* T_hi, void* T_lo,
+                       int B, int heads, int Sk, int Skp, gridmm_stream_t stream);
+int gridmm_attention_planes(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                            const void* K_lo, int64_t k_bs, int k_rs, const void* T_hi, const void* T_lo, int Skp,
+                            const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs, int o_rs, void* O_hi,
+                            void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq, int Sk, float scale,
+                            gridmm_stream_t stream);
+
 /* out[m] = <LayerNorm(X[m]) * gamma + beta, w> + b0      (tail of ClsPrediction,
  * vilmodel.py:663-674: Linear -> ReLU -> LN -> Linear(H,1)). */
 int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const float* beta, float eps,

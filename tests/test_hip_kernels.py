@@ -143,3 +143,32 @@ def test_copy_rows_and_cells_compact_quirk(dev):
     src = torch.randn(B, G, H, device=dev)
     ops.copy_rows(src, out, 196)
     assert torch.equal(out[:, 196:], src)
+
+
+@pytest.mark.parametrize("B,Sq,Sk", [(2, 16, 32), (3, 57, 296), (2, 216, 216), (1, 5, 37), (2, 216, 80)])
+def test_attention_bf16x3_planes_matches_fp32_softmax(dev, B, Sq, Sk):
+    """The hot-path attention (MFMA bf16 3-term split, V transposed per head) vs an fp64 softmax reference."""
+    ops = _ops()
+    Hh = 12
+    g = torch.Generator().manual_seed(B * 3 + Sq + Sk)
+    qkv = torch.randn(B, max(Sq, Sk), 3 * 768, generator=g).to(dev)
+    a = ops.split_rows(qkv)
+    lens = torch.randint(1, Sk + 1, (B,), generator=g)
+    lens[0] = Sk
+    mask = (torch.arange(Sk)[None] < lens[:, None])
+    mask[-1, 0] = False
+    if not mask[-1].any():
+        mask[-1, -1] = True
+    mask = mask.to(dev)
+    sl = lambda c0, n: (a.hi[:, :n, c0:c0 + 768], a.lo[:, :n, c0:c0 + 768])
+    out = ops.attention_planes(sl(0, Sq), sl(768, Sk), sl(1536, Sk), mask, want_f32=True, want_planes=True)
+    o = out.f32
+    def heads(t):
+        return t.reshape(B, -1, Hh, 64).permute(0, 2, 1, 3).double()
+    q, k, v = qkv[:, :Sq, :768], qkv[:, :Sk, 768:1536], qkv[:, :Sk, 1536:]
+    s = heads(q) @ heads(k).transpose(-1, -2) / 8.0
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ heads(v)).permute(0, 2, 1, 3).reshape(B, Sq, 768)
+    err = (o.double() - ref).abs().max().item()
+    assert err < 2e-4, err          # ~2^-16 relative on scores of magnitude ~10 (N(0,1) q.k over 64 dims)
+    assert ((out.hi.float() + out.lo.float()) - o).abs().max() <= 2.0 ** -15 * o.abs().max()
