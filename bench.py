@@ -110,11 +110,8 @@ def time_steps(step, steps, warmup, dist):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    from gridmm_amd.dist import max_over_ranks
+    return max_over_ranks(dt)          # the slowest rank defines the step time (identity at N=1)
 
 
 def roofline_leg(step, args, geom, L=80):
