@@ -31,7 +31,7 @@ __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short
 // BM x BN block tile, WM x WN per wave (16x16x32 MFMA tiles), NS-stage LDS ring filled by LDS-DMA.
 // One raw s_barrier per k-step; the DMA of stage kt+NS-1 is issued right after the barrier that retires
 // stage kt-1, and only a COUNTED s_waitcnt vmcnt keeps the younger stages in flight across barriers.
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
@@ -124,7 +124,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; buffer (kt-1)%NS is free
-    if (kt + NS - 1 < nk) {
+    if (ABLATE != 2 && kt + NS - 1 < nk) {
       unsigned short* nxt = smem + ((kt + NS - 1) % NS) * STAGE;
 #pragma unroll
       for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * BK, nxt + dst[i]);
@@ -146,6 +146,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
         const int off = 2 * BM * BK + row * BK + ((ks * 4 + fchunk) ^ swz<BK>(row)) * 8;
         bh[j] = *reinterpret_cast<const bf16x8_t*>(cur + off);
         bl[j] = *reinterpret_cast<const bf16x8_t*>(cur + BN * BK + off);
+      }
+      if (ABLATE == 1) {   // keep the fragment reads alive without the matrix work
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -232,13 +239,13 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int BK>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st) {
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM)), block((BM / WM) * (BN / WN) * 64);
 #define GRIDMM_LP(ACT)                                                                                        \
-  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
+  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
                 Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
@@ -295,7 +302,7 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
                                         int K, int act, int cfg, gridmm_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || act < 0 || act > 2)
     return GRIDMM_EINVAL;
-  if (K % 64 && (cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 13)) return GRIDMM_EINVAL;
+  if (K % 64 && (cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 13 || cfg == 108 || cfg == 208)) return GRIDMM_EINVAL;
   if ((C && ldc % 4) || (residual && ldr % 4) || (C_hi && (ldp % 4 || !C_lo)) || (!C && !C_hi)) return GRIDMM_EINVAL;
   const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
   const unsigned short *wh = (const unsigned short*)W_hi, *wl = (const unsigned short*)W_lo;
@@ -320,6 +327,13 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
     case 14: return launch<128, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
     case 15: return launch<128, 128, 32, 32, 2, 32>(GRIDMM_ARGS);
     case 16: return launch<256, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
+    // ablations (tools/bench_gemm.py): 1xx = no MFMA (DMA + LDS reads only), 2xx = no DMA after the prologue
+    case 108: return launch<64, 64, 32, 32, 2, 64, 1>(GRIDMM_ARGS);
+    case 208: return launch<64, 64, 32, 32, 2, 64, 2>(GRIDMM_ARGS);
+    case 115: return launch<128, 128, 32, 32, 2, 32, 1>(GRIDMM_ARGS);
+    case 215: return launch<128, 128, 32, 32, 2, 32, 2>(GRIDMM_ARGS);
+    case 107: return launch<256, 256, 128, 64, 2, 32, 1>(GRIDMM_ARGS);
+    case 207: return launch<256, 256, 128, 64, 2, 32, 2>(GRIDMM_ARGS);
     default: return GRIDMM_EINVAL;
   }
 #undef GRIDMM_ARGS

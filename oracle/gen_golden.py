@@ -205,10 +205,61 @@ def gen_text_pano():
     print("text_pano_reduced ok")
 
 
+ROLLOUT = dict(batch_size=3, n_scans=2, n_episodes=3, seed=11, max_action_len=6)
+
+
+def make_rollout_agent(vln_bert, device="cpu", grid_memory=None):
+    """The scripted synthetic episodes of rollout_reduced.npz (shared by the generator and the tests)."""
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.sim_env import SyntheticNavEnv
+    from .adapters import OracleGridMemory
+    r = ROLLOUT
+    mem = grid_memory if grid_memory is not None else OracleGridMemory(r["batch_size"])
+    env = SyntheticNavEnv(r["batch_size"], mem, n_scans=r["n_scans"], n_episodes=r["n_episodes"], seed=r["seed"])
+    agent = GMapNavAgent(default_args(max_action_len=r["max_action_len"]), env, vln_bert, device=device)
+    agent.feedback = "argmax"
+    agent.trace = []
+    return agent
+
+
+def gen_rollout():
+    """GMapNavAgent.rollout (agent.py:268-451) driven with the REFERENCE model: per-step logits + actions."""
+    import collections
+    torch.set_num_threads(1)
+    model = R.build_ref_model(seed=7, **REDUCED)
+
+    def ref_bert(mode, batch):
+        with torch.no_grad():
+            return model(mode, collections.defaultdict(lambda: None, batch))
+
+    agent = make_rollout_agent(ref_bert)
+    traj = agent.rollout()
+    out = {"versions": _versions(), "weight_seed": 7, "cfg": json.dumps(REDUCED),
+           "param_names": json.dumps([k for k in model.state_dict()]),
+           "param_shapes": json.dumps([list(v.shape) for v in model.state_dict().values()]),
+           "n_steps": len(agent.trace), "traj": json.dumps([t["path"] for t in traj])}
+    margin = 1e9
+    for st in agent.trace:
+        t = st["t"]
+        fl = st["nav_outs"]["fused_logits"]
+        out["t%d_fused" % t] = fl.numpy()
+        out["t%d_local" % t] = st["nav_outs"]["local_logits"].numpy()
+        out["t%d_global" % t] = st["nav_outs"]["global_logits"].numpy()
+        out["t%d_grid" % t] = st["nav_outs"]["grid_logits"].numpy()
+        out["t%d_a" % t] = st["a_t"]
+        out["t%d_ended" % t] = st["ended"]
+        top2 = torch.topk(torch.nan_to_num(fl, neginf=-1e9), 2, dim=1).values
+        margin = min(margin, float((top2[:, 0] - top2[:, 1])[~torch.from_numpy(st["ended"])].min()) if (~st["ended"]).any() else margin)
+    assert margin > 2e-3, "argmax margin %.2e too small for a robust action fixture; change ROLLOUT seed" % margin
+    np.savez_compressed(os.path.join(OUT, "rollout_reduced.npz"), **out)
+    print("rollout_reduced ok: steps=%d min argmax margin=%.3e paths=%s" % (len(agent.trace), margin, out["traj"][:120]))
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout"]
+    if "rollout" in which: gen_rollout()
     if "fill" in which: gen_fill_gridmap()
     if "nav" in which: gen_nav_reduced(False)
     if "navobj" in which: gen_nav_reduced(True)
