@@ -24,13 +24,16 @@ __device__ __forceinline__ int trunc_x86(float v) {
 // ---------------------------------------------------------------------------------------------
 // project: one workgroup per episode
 // ---------------------------------------------------------------------------------------------
+constexpr int FLAG_VLNCE = 1;  // VLN-CE twin: gy = -ry + y; map_x = -(tx cos + ty sin); (x, Z, y) cell features
+
+template <bool DEPTH_F32>
 __global__ __launch_bounds__(256) void grid_project_kernel(
-    const uint16_t* __restrict__ depth, const float* __restrict__ x_off,
-    const float* __restrict__ view_cos, const float* __restrict__ view_sin,
+    const void* __restrict__ depth_, const float* __restrict__ x_off,
+    const float* __restrict__ view_cos, const float* __restrict__ view_sin, int view_stride,
     const float* __restrict__ pose, int32_t* __restrict__ n_old, float* __restrict__ hist_x,
     float* __restrict__ hist_y, uint8_t* __restrict__ hist_valid, float* __restrict__ bbox,
     float* __restrict__ half_len, float* __restrict__ pos_fts, const uint8_t* __restrict__ active,
-    int n_views, int ppv, int cap, float depth_div) {
+    int n_views, int ppv, int cap, float depth_div, int flags, float max_dist) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (active && !active[b]) return;
   const int n_new = n_views * ppv, base = n_old[b];
@@ -38,17 +41,26 @@ __global__ __launch_bounds__(256) void grid_project_kernel(
   float mxx = -__builtin_inff(), mnx = __builtin_inff(), mxy = -__builtin_inff(), mny = __builtin_inff();
   for (int i = tid; i < n_new; i += 256) {
     const int v = i / ppv, p = i - v * ppv;
-    const uint16_t d = depth[(size_t)b * n_new + i];
-    const float dy = (float)d / depth_div;       // env.py:116
+    float dy;
+    bool ok;
+    if (DEPTH_F32) {   // VLN-CE: habitat depth in metres, used as is (Policy_ViewSelection_GridMap.py:634)
+      dy = reinterpret_cast<const float*>(depth_)[(size_t)b * n_new + i];
+      ok = dy != 0.f;
+    } else {
+      const uint16_t d = reinterpret_cast<const uint16_t*>(depth_)[(size_t)b * n_new + i];
+      dy = (float)d / depth_div;                 // env.py:116
+      ok = d != 0;
+    }
     const float dx = dy * x_off[p];              // env.py:118
-    const float c = view_cos[v], s = view_sin[v];
+    const float c = view_cos[b * view_stride + v], s = view_sin[b * view_stride + v];
     const float t0 = dx * c, t1 = dy * s, t2 = dy * c, t3 = dx * s;
     const float gx = (t0 + t1) + px;             // env.py:119, 291
-    const float gy = (t2 - t3) + py;             // env.py:120, 292
+    const float ry = t2 - t3;
+    const float gy = (flags & FLAG_VLNCE) ? (-ry) + py : ry + py;   // env.py:120, 292 / VLN-CE :739
     const size_t o = (size_t)b * cap + base + i;
     hist_x[o] = gx;
     hist_y[o] = gy;
-    hist_valid[o] = d != 0;
+    hist_valid[o] = ok;
     mxx = fmaxf(mxx, gx); mnx = fminf(mnx, gx);
     mxy = fmaxf(mxy, gy); mny = fminf(mny, gy);
   }
@@ -85,16 +97,30 @@ __global__ __launch_bounds__(256) void grid_project_kernel(
     const int i = tid / GRIDMM_GRID, j = tid - i * GRIDMM_GRID;
     const float bx = ((float)i * cell_len - hl) + cell_len / 2.0f;
     const float by = ((float)j * cell_len - hl) + cell_len / 2.0f;
-    float dist = sqrtf(bx * bx + by * by);
-    dist = dist >= 1e-8f ? dist : 1e-8f;
-    float hd = asinf(bx / dist);
-    if (by < 0.f) hd = 3.14159265358979323846f - hd;
     float* o = pos_fts + ((size_t)b * GRIDMM_CELLS + tid) * 5;
-    o[0] = sinf(hd);
-    o[1] = cosf(hd);
-    o[2] = 0.f;
-    o[3] = 1.f;
-    o[4] = dist / 30.0f;
+    if (flags & FLAG_VLNCE) {
+      // vlnce_baselines/models/utils.py:125-144 reads points as (x, Z, y): the cell's j coordinate is an elevation
+      if (bx == 0.f && by == 0.f) {
+        o[0] = 0.f; o[1] = 1.f; o[2] = 0.f; o[3] = 1.f; o[4] = 0.f;
+      } else {
+        float xy = sqrtf(bx * bx);
+        xy = xy >= 1e-8f ? xy : 1e-8f;
+        float xyz = sqrtf(bx * bx + by * by);
+        xyz = xyz >= 1e-8f ? xyz : 1e-8f;
+        const float hd = asinf(bx / xy), el = asinf(by / xyz);
+        o[0] = sinf(hd); o[1] = cosf(hd); o[2] = sinf(el); o[3] = cosf(el); o[4] = xyz / max_dist;
+      }
+    } else {
+      float dist = sqrtf(bx * bx + by * by);
+      dist = dist >= 1e-8f ? dist : 1e-8f;
+      float hd = asinf(bx / dist);
+      if (by < 0.f) hd = 3.14159265358979323846f - hd;
+      o[0] = sinf(hd);
+      o[1] = cosf(hd);
+      o[2] = 0.f;
+      o[3] = 1.f;
+      o[4] = dist / max_dist;
+    }
   }
 }
 
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(1024) void grid_bin_sort_kernel(
     const uint8_t* __restrict__ hist_valid, const int32_t* __restrict__ n_pts,
     const float* __restrict__ pose, const float* __restrict__ head_cs,
     const float* __restrict__ half_len, int16_t* __restrict__ cell_id, int32_t* __restrict__ perm,
-    int32_t* __restrict__ cell_start, int cap) {
+    int32_t* __restrict__ cell_start, int cap, int flags) {
   __shared__ int s_cur[SORT_WAVES][NBIN];
   __shared__ int s_start[NBIN + 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,7 +161,8 @@ __global__ __launch_bounds__(1024) void grid_bin_sort_kernel(
       const size_t o = (size_t)b * cap + i;
       const float tx = hist_x[o] - px, ty = hist_y[o] - py;                  // env.py:344-345
       const float a0 = tx * c, a1 = ty * s, a2 = ty * c, a3 = tx * s;
-      const float mx = a0 + a1, my = a2 - a3;                                 // env.py:347-348
+      const float sx = a0 + a1, my = a2 - a3;                                 // env.py:347-348
+      const float mx = (flags & FLAG_VLNCE) ? -sx : sx;                       // VLN-CE :797
       int cx = trunc_x86(((mx + hl) / two_h) * 13.0f);                        // env.py:349
       int cy = trunc_x86(((my + hl) / two_h) * 13.0f);                        // env.py:351
       cx = cx < 0 ? 0 : (cx > 13 ? 13 : cx);                                  // env.py:353-357
@@ -205,16 +232,22 @@ __global__ __launch_bounds__(1024) void grid_bin_sort_kernel(
 
 }  // namespace
 
-extern "C" int gridmm_grid_project(const uint16_t* depth, const float* x_off, const float* view_cos,
-                                   const float* view_sin, const float* pose, int32_t* n_old,
+extern "C" int gridmm_grid_project(const void* depth, int depth_f32, const float* x_off, const float* view_cos,
+                                   const float* view_sin, int view_stride, const float* pose, int32_t* n_old,
                                    float* hist_x, float* hist_y, uint8_t* hist_valid, float* bbox,
                                    float* half_len, float* pos_fts, const uint8_t* active, int B,
-                                   int n_views, int ppv, int cap, float depth_div,
+                                   int n_views, int ppv, int cap, float depth_div, int flags, float max_dist,
                                    gridmm_stream_t stream) {
-  if (B <= 0 || n_views <= 0 || ppv <= 0 || cap < n_views * ppv) return GRIDMM_EINVAL;
-  GRIDMM_LAUNCH(grid_project_kernel, dim3(B), dim3(256), 0, as_stream(stream), depth, x_off, view_cos,
-                     view_sin, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len, pos_fts, active,
-                     n_views, ppv, cap, depth_div);
+  if (B <= 0 || n_views <= 0 || ppv <= 0 || cap < n_views * ppv || (view_stride != 0 && view_stride != n_views))
+    return GRIDMM_EINVAL;
+  if (depth_f32)
+    GRIDMM_LAUNCH(grid_project_kernel<true>, dim3(B), dim3(256), 0, as_stream(stream), depth, x_off, view_cos,
+                  view_sin, view_stride, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len, pos_fts, active,
+                  n_views, ppv, cap, depth_div, flags, max_dist);
+  else
+    GRIDMM_LAUNCH(grid_project_kernel<false>, dim3(B), dim3(256), 0, as_stream(stream), depth, x_off, view_cos,
+                  view_sin, view_stride, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len, pos_fts, active,
+                  n_views, ppv, cap, depth_div, flags, max_dist);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -222,10 +255,10 @@ extern "C" int gridmm_grid_project(const uint16_t* depth, const float* x_off, co
 extern "C" int gridmm_grid_bin(const float* hist_x, const float* hist_y, const uint8_t* hist_valid,
                                const int32_t* n_pts, const float* pose, const float* head_cs,
                                const float* half_len, int16_t* cell_id, int32_t* perm,
-                               int32_t* cell_start, int B, int cap, gridmm_stream_t stream) {
+                               int32_t* cell_start, int B, int cap, int flags, gridmm_stream_t stream) {
   if (B <= 0 || cap <= 0) return GRIDMM_EINVAL;
   GRIDMM_LAUNCH((grid_bin_sort_kernel<true>), dim3(B), dim3(1024), 0, as_stream(stream), hist_x,
-                     hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start, cap);
+                hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start, cap, flags);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -234,8 +267,8 @@ extern "C" int gridmm_grid_sort_ids(const int16_t* cell_id, const int32_t* n_pts
                                     int32_t* cell_start, int B, int cap, gridmm_stream_t stream) {
   if (B <= 0 || cap <= 0) return GRIDMM_EINVAL;
   GRIDMM_LAUNCH((grid_bin_sort_kernel<false>), dim3(B), dim3(1024), 0, as_stream(stream), nullptr,
-                     nullptr, nullptr, n_pts, nullptr, nullptr, nullptr, const_cast<int16_t*>(cell_id), perm,
-                     cell_start, cap);
+                nullptr, nullptr, n_pts, nullptr, nullptr, nullptr, const_cast<int16_t*>(cell_id), perm,
+                cell_start, cap, 0);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -60,9 +60,18 @@ class GridMemoryBatch:
         P = geom.patches
         base = np.array([(2 * c + 1 - P) / P for c in range(P)] * P, np.float32)
         self.x_off = torch.from_numpy(base * np.float32(geom.tan_half_fov)).to(dev)
-        ang = [v * math.pi / (geom.n_views / 2) for v in range(geom.n_views)]
-        self.view_cos = torch.tensor([np.float32(math.cos(a)) for a in ang], dtype=torch.float32, device=dev)
-        self.view_sin = torch.tensor([np.float32(math.sin(a)) for a in ang], dtype=torch.float32, device=dev)
+        self._view_ang = [v * math.pi / (geom.n_views / 2) for v in range(geom.n_views)]
+        self.flags = ops.FLAG_VLNCE if geom.vlnce else 0
+        if geom.vlnce:   # per-episode view tables: angle = v*pi/6 - heading (Policy_ViewSelection_GridMap.py:734)
+            pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
+            self._vcos_host = pin(torch.zeros(B, geom.n_views, dtype=torch.float32))
+            self._vsin_host = pin(torch.zeros(B, geom.n_views, dtype=torch.float32))
+            self.view_cos = torch.zeros(B, geom.n_views, dtype=torch.float32, device=dev)
+            self.view_sin = torch.zeros(B, geom.n_views, dtype=torch.float32, device=dev)
+        else:
+            ang = self._view_ang
+            self.view_cos = torch.tensor([np.float32(math.cos(a)) for a in ang], dtype=torch.float32, device=dev)
+            self.view_sin = torch.tensor([np.float32(math.sin(a)) for a in ang], dtype=torch.float32, device=dev)
         self.reset()
 
     def reset(self):
@@ -82,9 +91,17 @@ class GridMemoryBatch:
         h = self._head_host.numpy()
         for b in range(self.B):
             p[b, 0], p[b, 1] = np.float32(poses[b][0]), np.float32(poses[b][1])
-            h[b, 0], h[b, 1] = np.float32(math.cos(-headings[b])), np.float32(math.sin(-headings[b]))
+            a = (-headings[b] + math.pi) if self.geom.vlnce else -headings[b]       # env.py:337 / VLN-CE :785
+            h[b, 0], h[b, 1] = np.float32(math.cos(a)), np.float32(math.sin(a))
         self.pose_d.copy_(self._pose_host, non_blocking=True)
         self.head_d.copy_(self._head_host, non_blocking=True)
+        if self.geom.vlnce:
+            vc, vs = self._vcos_host.numpy(), self._vsin_host.numpy()
+            for b in range(self.B):
+                for v, a0 in enumerate(self._view_ang):
+                    vc[b, v], vs[b, v] = np.float32(math.cos(a0 - headings[b])), np.float32(math.sin(a0 - headings[b]))
+            self.view_cos.copy_(self._vcos_host, non_blocking=True)
+            self.view_sin.copy_(self._vsin_host, non_blocking=True)
         if active is None:
             self._active = None
         else:
@@ -101,9 +118,10 @@ class GridMemoryBatch:
         ops.grid_project(depth, self.x_off, self.view_cos, self.view_sin, self.pose_d, self.n_pts, self.hist_x,
                          self.hist_y, self.hist_valid, self.bbox, self.half_len, self.pos_fts,
                          None if self._active is None else self.act_d,
-                         self.geom.n_views, self.geom.patches ** 2, self.geom.depth_div)
+                         self.geom.n_views, self.geom.patches ** 2, self.geom.depth_div, self.flags,
+                         self.geom.max_dist)
         ops.grid_bin(self.hist_x, self.hist_y, self.hist_valid, self.n_pts, self.pose_d, self.head_d, self.half_len,
-                     self.cell_id, self.perm, self.cell_start)
+                     self.cell_id, self.perm, self.cell_start, self.flags)
 
     def step(self, depth, feats, poses, headings, active=None):
         """Append one observation per episode and re-bin the whole history (getGlobalMap for all i).
@@ -119,7 +137,9 @@ class GridMemoryBatch:
         if (self.n_pts_host[act_host] + n_new > self.cap).any():
             raise ValueError("grid memory capacity exceeded (max_steps=%d)" % self.max_steps)
         depth = torch.as_tensor(depth).to(dev, non_blocking=True)
-        if depth.dtype != torch.uint16:
+        if self.geom.vlnce:
+            depth = depth.to(torch.float32)                     # habitat depth, metres
+        elif depth.dtype != torch.uint16:
             depth = depth.to(torch.int32).to(torch.uint16)
         depth = depth.reshape(B, n_new).contiguous()
         if feats is not None:

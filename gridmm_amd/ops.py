@@ -356,22 +356,27 @@ def fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_n
     return outs  # global, local, grid, fused
 
 
+FLAG_VLNCE = 1
+
+
 def grid_project(depth, x_off, view_cos, view_sin, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len,
-                 pos_fts, active, n_views, ppv, depth_div):
+                 pos_fts, active, n_views, ppv, depth_div, flags=0, max_dist=30.0):
     lib = _lib.load()
     B, cap = hist_x.shape
-    _lib.check(lib.gridmm_grid_project(_p(depth), _p(x_off), _p(view_cos), _p(view_sin), _p(pose), _p(n_old),
-                                       _p(hist_x), _p(hist_y), _p(hist_valid), _p(bbox), _p(half_len), _p(pos_fts),
-                                       _p(active), B, n_views, ppv, cap, float(depth_div), _stream()),
-               "gridmm_grid_project")
+    depth_f32 = int(depth.dtype == torch.float32)
+    view_stride = n_views if view_cos.dim() == 2 else 0       # per-episode view tables (VLN-CE) or shared
+    _lib.check(lib.gridmm_grid_project(_p(depth), depth_f32, _p(x_off), _p(view_cos), _p(view_sin), view_stride,
+                                       _p(pose), _p(n_old), _p(hist_x), _p(hist_y), _p(hist_valid), _p(bbox),
+                                       _p(half_len), _p(pos_fts), _p(active), B, n_views, ppv, cap, float(depth_div),
+                                       int(flags), float(max_dist), _stream()), "gridmm_grid_project")
 
 
-def grid_bin(hist_x, hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start):
+def grid_bin(hist_x, hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start, flags=0):
     lib = _lib.load()
     B, cap = hist_x.shape
     _lib.check(lib.gridmm_grid_bin(_p(hist_x), _p(hist_y), _p(hist_valid), _p(n_pts), _p(pose), _p(head_cs),
-                                   _p(half_len), _p(cell_id), _p(perm), _p(cell_start), B, cap, _stream()),
-               "gridmm_grid_bin")
+                                   _p(half_len), _p(cell_id), _p(perm), _p(cell_start), B, cap, int(flags),
+                                   _stream()), "gridmm_grid_bin")
 
 
 def grid_sort_ids(cell_id, n_pts, perm, cell_start):

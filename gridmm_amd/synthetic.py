@@ -19,9 +19,12 @@ class GridGeometry:
     """Shape of one observation slab (native 12x7x7x768; BASELINE 36x14x14x512)."""
 
     def __init__(self, n_views=12, patches=7, feat_dim=768, depth_div=4000.0,
-                 tan_half_fov=math.tan(math.pi / 6)):
+                 tan_half_fov=math.tan(math.pi / 6), vlnce=False, max_dist=30.0):
         self.n_views, self.patches, self.feat_dim = n_views, patches, feat_dim
         self.depth_div, self.tan_half_fov = depth_div, tan_half_fov
+        # VLN-CE twin (Policy_ViewSelection_GridMap.py:632-641, 689-825): float32 depth in metres, view angles
+        # relative to the heading, mirrored y, rotation by pi, MAX_DIST 25 / 40
+        self.vlnce, self.max_dist = vlnce, max_dist
 
     @property
     def pts_per_obs(self):
@@ -30,6 +33,8 @@ class GridGeometry:
 
 NATIVE = GridGeometry()
 BASELINE = GridGeometry(36, 14, 512)
+VLNCE_R2R = GridGeometry(depth_div=1.0, tan_half_fov=math.tan(math.pi / 4.), vlnce=True, max_dist=25.0)
+VLNCE_RXR = GridGeometry(depth_div=1.0, tan_half_fov=math.tan(math.pi * 79. / 360.), vlnce=True, max_dist=40.0)
 
 
 def make_observations(rs, geom, steps, feat_scale=1.0, zero_frac=0.1):

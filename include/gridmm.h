@@ -54,12 +54,17 @@ int gridmm_abi_version(void);
  *   bbox       [B][4] f32  running (max_x, min_x, max_y, min_y); init (-10000,10000,-10000,10000)
  *   half_len   [B] f32 out; pos_fts [B][196][5] f32 out
  *   active     [B] uint8 or NULL: episodes with 0 are skipped entirely
+ * VLN-CE twin (VLN_CE/vlnce_baselines/models/Policy_ViewSelection_GridMap.py:632-641, 689-825), flags bit 0:
+ *   depth_f32 = 1: depth is float32 metres used as is; view_stride = n_views: per-episode view_cos/sin
+ *   [B][n_views] of (v*pi/6 - heading); gy = -ry + y; cell features through the (x, Z, y) reading of
+ *   vlnce_baselines/models/utils.py:125-144; max_dist 25 (R2R-CE) / 40 (RxR-CE) instead of 30.
  */
-int gridmm_grid_project(const uint16_t* depth, const float* x_off, const float* view_cos,
-                        const float* view_sin, const float* pose, int32_t* n_pts,
+#define GRIDMM_FLAG_VLNCE 1
+int gridmm_grid_project(const void* depth, int depth_f32, const float* x_off, const float* view_cos,
+                        const float* view_sin, int view_stride, const float* pose, int32_t* n_pts,
                         float* hist_x, float* hist_y, uint8_t* hist_valid, float* bbox,
                         float* half_len, float* pos_fts, const uint8_t* active,
-                        int B, int n_views, int ppv, int cap, float depth_div,
+                        int B, int n_views, int ppv, int cap, float depth_div, int flags, float max_dist,
                         gridmm_stream_t stream);
 
 /* Re-bin the WHOLE history of every episode into the current egocentric 14x14 frame and
@@ -76,7 +81,8 @@ int gridmm_grid_project(const uint16_t* depth, const float* x_off, const float* 
 int gridmm_grid_bin(const float* hist_x, const float* hist_y, const uint8_t* hist_valid,
                     const int32_t* n_pts, const float* pose, const float* head_cs,
                     const float* half_len, int16_t* cell_id, int32_t* perm, int32_t* cell_start,
-                    int B, int cap, gridmm_stream_t stream);
+                    int B, int cap, int flags, gridmm_stream_t stream);
+/* (flags bit 0 = GRIDMM_FLAG_VLNCE: head_cs = cos/sin(-heading + pi) and map_x = -(tx cos + ty sin)) */
 
 /* Same counting sort for caller-provided cell ids (the reference's `grid_map` list form,
  * map_nav_src/r2r/agent.py:168): ids are int16 in {-1, 0..195}. */

@@ -205,6 +205,34 @@ def gen_text_pano():
     print("text_pano_reduced ok")
 
 
+def gen_fill_gridmap_vlnce():
+    """VLN-CE twin: GridMap.getGlobalMap (Policy_ViewSelection_GridMap.py:689-825), R2R-CE and RxR-CE constants."""
+    out = {"versions": _versions()}
+    idx = G.VLNCE_R2R.sample_index()
+    for name, geom, md in (("r2r", G.VLNCE_R2R, 25), ("rxr", G.VLNCE_RXR, 40)):
+        rs = np.random.RandomState(77 if name == "r2r" else 78)
+        env = R.RefVlnceGridEnv(1, name.replace("r2r", "R2R").replace("rxr", "RxR"), md)
+        T = 4
+        out[name + "_steps"] = T
+        for t in range(T):
+            ds = rs.uniform(0.0, 6.0, size=(12, 49)).astype(np.float32)
+            ds[rs.rand(12, 49) < (1.0 if (name == "rxr" and t == 0) else 0.12)] = 0.0   # RxR ep: all-invalid first step
+            full = np.zeros((12, 256, 256), np.float32)
+            for v in range(12):
+                full[v][np.ix_(idx, idx)] = ds[v].reshape(7, 7)
+            ft = np.zeros((12, 50, 768), np.float16)
+            pos = {"x": float(rs.uniform(-8, 8)), "y": float(rs.uniform(-8, 8))}
+            h = float(rs.uniform(-6.5, 6.5))
+            fts, gmap, pf = env.step(0, pos, h, full, ft)
+            p = "%s_t%d_" % (name, t)
+            out[p + "depth"] = ds
+            out[p + "pose"] = np.array([pos["x"], pos["y"], h], np.float64)
+            out[p + "grid_map"] = gmap.astype(np.int16)
+            out[p + "pos_fts"] = pf.astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "fill_gridmap_vlnce.npz"), **out)
+    print("fill_gridmap_vlnce: ok")
+
+
 ROLLOUT = dict(batch_size=3, n_scans=2, n_episodes=3, seed=11, max_action_len=6)
 
 
@@ -258,8 +286,9 @@ def gen_rollout():
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce"]
     if "rollout" in which: gen_rollout()
+    if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
     if "nav" in which: gen_nav_reduced(False)
     if "navobj" in which: gen_nav_reduced(True)

@@ -43,6 +43,11 @@ class GridGeometry:
     depth_w: int = 128
     depth_div: float = 4000.0  # env.py:116
     tan_half_fov: float = math.tan(math.pi / 6)  # env.py:118
+    sample_offset: int = -1    # -1: stride // 2 (env.py:279: 9 + 18k); VLN-CE uses 19 + 36k
+    max_dist: float = MAX_DIST
+    # VLN-CE twin (VLN_CE/vlnce_baselines/models/Policy_ViewSelection_GridMap.py:632-641, 689-825):
+    vlnce: bool = False        # depth float32 metres (no /4000); view angle = v*pi/6 - heading; gy = -ry + y;
+    #                            re-binning angle = -heading + pi and map_x = -(tx cos + ty sin)
 
     @property
     def pts_per_view(self):
@@ -54,7 +59,8 @@ class GridGeometry:
 
     def sample_index(self):
         stride = self.depth_w // self.patches
-        return np.array([stride // 2 + k * stride for k in range(self.patches)])
+        off = stride // 2 if self.sample_offset < 0 else self.sample_offset
+        return np.array([off + k * stride for k in range(self.patches)])
 
     def x_offsets(self):
         """f32 vector of per-patch lateral offsets * tan(fov/2)   (env.py:118)."""
@@ -69,6 +75,10 @@ class GridGeometry:
 
 NATIVE = GridGeometry()
 BASELINE = GridGeometry(n_views=36, patches=14, feat_dim=512)
+VLNCE_R2R = GridGeometry(depth_w=256, depth_div=1.0, tan_half_fov=math.tan(math.pi / 4.), sample_offset=19,
+                         max_dist=25.0, vlnce=True)
+VLNCE_RXR = GridGeometry(depth_w=256, depth_div=1.0, tan_half_fov=math.tan(math.pi * 79. / 360.), sample_offset=19,
+                         max_dist=40.0, vlnce=True)
 
 
 def sample_depth(depth_full, geom=NATIVE, horizon_slice=None):
@@ -84,8 +94,10 @@ def sample_depth(depth_full, geom=NATIVE, horizon_slice=None):
 
 
 def rel_position(depth_row, angle, geom=NATIVE):
-    """env.py:115-121 for one view.  depth_row: (P*P,) uint16; angle: python double."""
-    depth_y = depth_row.astype(np.float32) / np.float32(geom.depth_div)
+    """env.py:115-121 for one view.  depth_row: (P*P,) uint16 (float32 metres for VLN-CE); angle: python double."""
+    depth_y = depth_row.astype(np.float32)
+    if not geom.vlnce:
+        depth_y = depth_y / np.float32(geom.depth_div)
     depth_x = depth_y * geom.x_offsets()
     c = np.float32(math.cos(angle))
     s = np.float32(math.sin(angle))
@@ -94,8 +106,8 @@ def rel_position(depth_row, angle, geom=NATIVE):
     return rel_x, rel_y
 
 
-def project_observation(depth_s, pos_x, pos_y, geom=NATIVE):
-    """World XY of one observation's points (env.py:289-294, 306-307).
+def project_observation(depth_s, pos_x, pos_y, geom=NATIVE, heading=0.0):
+    """World XY of one observation's points (env.py:289-294, 306-307; VLN-CE :733-741).
 
     depth_s: (n_views, P*P) uint16 sampled depth.  Returns gx, gy (n_pts,) f32 and
     valid (n_pts,) bool (depth != 0, env.py:283-285).
@@ -103,9 +115,14 @@ def project_observation(depth_s, pos_x, pos_y, geom=NATIVE):
     gx, gy = [], []
     px, py = np.float32(pos_x), np.float32(pos_y)
     for v, a in enumerate(geom.view_angles()):
-        rx, ry = rel_position(depth_s[v], a, geom)
-        gx.append(rx + px)
-        gy.append(ry + py)
+        if geom.vlnce:
+            rx, ry = rel_position(depth_s[v], a - heading, geom)     # ix*math.pi/6 - self.headings[i]
+            gx.append(rx + px)
+            gy.append(-ry + py)                                      # global_y = -rel_y + position["y"]
+        else:
+            rx, ry = rel_position(depth_s[v], a, geom)
+            gx.append(rx + px)
+            gy.append(ry + py)
     return np.concatenate(gx), np.concatenate(gy), (depth_s.reshape(-1) != 0)
 
 
@@ -118,7 +135,7 @@ def trunc_i32(x):
     return out
 
 
-def gridmap_pos_fts(half_len):
+def gridmap_pos_fts(half_len, max_dist=MAX_DIST):
     """env.py:242-265 (+ :60-77, :52-58).  half_len: np.float32 scalar.  -> (196,5) f32.
 
     The reference computes cell centres with `half_len` as np.float32 and python
@@ -143,12 +160,41 @@ def gridmap_pos_fts(half_len):
             e = np.arcsin(dz / xyz)
             e -= 0.
             ang.append([h, e])
-            dist.append([xyz / MAX_DIST])
+            dist.append([xyz / max_dist])
     ang = np.array(ang).astype(np.float32)
     dist = np.array(dist).astype(np.float32)
     fts = np.vstack([np.sin(ang[:, 0]), np.cos(ang[:, 0]), np.sin(ang[:, 1]), np.cos(ang[:, 1])])
     fts = fts.transpose().astype(np.float32)
     return np.concatenate([fts, dist], 1)
+
+
+def gridmap_pos_fts_vlnce(half_len, max_dist):
+    """VLN-CE twin: Policy_ViewSelection_GridMap.py:661-687 with vlnce_baselines/models/utils.py:125-144,
+    whose calculate_vp_rel_pos_fts reads its points as (x, Z, y): the grid's second coordinate lands in the
+    ELEVATION (dz = b[1]) and the "y" used for the heading is the constant 0 -- so heading = +-pi/2 and the
+    cell's j coordinate only shows up in sin/cos(elevation).  Copied as is, not fixed."""
+    half_len = np.float32(half_len)
+    cell_len = half_len * 2 / GRID
+    ang, dist = [], []
+    for i in range(GRID):
+        for j in range(GRID):
+            bx = i * cell_len - half_len + cell_len / 2.
+            bz = j * cell_len - half_len + cell_len / 2.
+            dx, dz, dy = bx - 0., bz - 0., 0. - 0.
+            if dx == dz == dy == 0:
+                ang.append([0, 0]); dist.append([0 / max_dist]); continue
+            xy = max(np.sqrt(dx ** 2 + dy ** 2), 1e-8)
+            xyz = max(np.sqrt(dx ** 2 + dy ** 2 + dz ** 2), 1e-8)
+            h = np.arcsin(dx / xy)
+            h -= 0.
+            e = np.arcsin(dz / xyz)
+            e -= 0.
+            ang.append([h, e])
+            dist.append([xyz / max_dist])
+    ang = np.array(ang).astype(np.float32)
+    dist = np.array(dist).astype(np.float32)
+    fts = np.vstack([np.sin(ang[:, 0]), np.cos(ang[:, 0]), np.sin(ang[:, 1]), np.cos(ang[:, 1])])
+    return np.concatenate([fts.transpose().astype(np.float32), dist], 1)
 
 
 class GridMemory:
@@ -167,7 +213,7 @@ class GridMemory:
         half_len f32.
         """
         g = self.geom
-        gx, gy, valid = project_observation(depth_s, pos_x, pos_y, g)
+        gx, gy, valid = project_observation(depth_s, pos_x, pos_y, g, heading)
         self.hist_x.append(gx)
         self.hist_y.append(gy)
         self.hist_valid.append(valid)
@@ -181,9 +227,10 @@ class GridMemory:
 
         half_len = self.half_len(pos_x, pos_y)
         cell = self.bin_points(np.concatenate(self.hist_x), np.concatenate(self.hist_y),
-                               np.concatenate(self.hist_valid), pos_x, pos_y, heading, half_len)
+                               np.concatenate(self.hist_valid), pos_x, pos_y, heading, half_len, g.vlnce)
         grid_map = cell.astype(np.float64)
-        return (np.concatenate(self.hist_fts, 0), grid_map, gridmap_pos_fts(half_len), half_len)
+        pf = gridmap_pos_fts_vlnce(half_len, g.max_dist) if g.vlnce else gridmap_pos_fts(half_len, g.max_dist)
+        return (np.concatenate(self.hist_fts, 0), grid_map, pf, half_len)
 
     def half_len(self, pos_x, pos_y):
         """env.py:322-331: python float (op) np.float32 -> float32."""
@@ -196,14 +243,16 @@ class GridMemory:
         return np.float32(np.float32(h * np.float32(2)) / np.float32(3))
 
     @staticmethod
-    def bin_points(hx, hy, valid, pos_x, pos_y, heading, half_len):
-        """env.py:337-369.  -> int32 cell ids, -1 for invalid depth."""
-        angle = -heading
+    def bin_points(hx, hy, valid, pos_x, pos_y, heading, half_len, vlnce=False):
+        """env.py:337-369 (VLN-CE: Policy_ViewSelection_GridMap.py:785-817).  -> int32 cell ids, -1 = invalid."""
+        angle = (-heading + math.pi) if vlnce else -heading
         c = np.float32(math.cos(angle))
         s = np.float32(math.sin(angle))
         tx = hx - np.float32(pos_x)
         ty = hy - np.float32(pos_y)
         mx = tx * c + ty * s
+        if vlnce:
+            mx = -mx
         my = ty * c - tx * s
         two_h = np.float32(2) * half_len
         with np.errstate(divide="ignore", invalid="ignore"):

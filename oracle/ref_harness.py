@@ -241,3 +241,103 @@ class RefGridEnv:
         eb.global_map[i] = gmap
         eb.max_x[i], eb.min_x[i], eb.max_y[i], eb.min_y[i] = mx, mnx, my, mny
         return np.asarray(sem), np.array(gmap, copy=True), np.asarray(pos_fts)
+
+
+# --------------------------------------------------------------------------- VLN-CE twin (row a12)
+class _Anything:
+    """Permissive stand-in for habitat / gym / timm / torchvision symbols: attribute access, calling,
+    decorating and even sub-classing all succeed (harness-side only; nothing numeric goes through it)."""
+
+    def __init__(self, name="stub"):
+        self.__name__ = name
+
+    def __getattr__(self, k):
+        if k.startswith("__") and k.endswith("__"):
+            raise AttributeError(k)
+        return _Anything(k)
+
+    def __call__(self, *a, **kw):
+        if len(a) == 1 and isinstance(a[0], type) and not kw:
+            return a[0]          # used as a class decorator
+        return _Anything("call")
+
+    def __mro_entries__(self, bases):
+        return (object,)
+
+    def __iter__(self):
+        return iter(())
+
+
+class _AnyModule(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__") and k.endswith("__"):
+            raise AttributeError(k)
+        return _Anything(k)
+
+
+_VLNCE = None
+
+
+def import_vlnce_policy():
+    """Import VLN_CE/vlnce_baselines/models/Policy_ViewSelection_GridMap.py with stand-ins for every
+    simulator / vision dependency; only its pure NumPy methods (getGlobalMap, get_rel_position,
+    get_gridmap_pos_fts: :632-825) are ever called."""
+    global _VLNCE
+    if _VLNCE is not None:
+        return _VLNCE
+    import importlib.util
+    root = os.path.join(REF_ROOT, "VLN_CE")
+    for name in ("gym", "habitat", "habitat_baselines", "habitat_baselines.common",
+                 "habitat_baselines.common.baseline_registry", "habitat_baselines.rl", "habitat_baselines.rl.models",
+                 "habitat_baselines.rl.models.rnn_state_encoder", "habitat_baselines.rl.ppo",
+                 "habitat_baselines.rl.ppo.policy", "timm", "timm.data", "timm.data.transforms_factory",
+                 "torchvision", "torchvision.transforms", "cv2", "imutils", "waypoint_prediction",
+                 "waypoint_prediction.utils", "vlnce_baselines.models.gridmap", "vlnce_baselines.models.gridmap.vlnbert_init",
+                 "vlnce_baselines.common", "vlnce_baselines.common.aux_losses", "vlnce_baselines.models.encoders",
+                 "vlnce_baselines.models.encoders.instruction_encoder", "vlnce_baselines.models.encoders.resnet_encoders",
+                 "vlnce_baselines.models.policy"):
+        if name not in sys.modules:
+            sys.modules[name] = _AnyModule(name)
+    for pkg, sub in (("vlnce_baselines", "vlnce_baselines"), ("vlnce_baselines.models", "vlnce_baselines/models")):
+        if pkg not in sys.modules or isinstance(sys.modules[pkg], _AnyModule):
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(root, sub)]
+            sys.modules[pkg] = m
+    spec = importlib.util.spec_from_file_location(
+        "vlnce_baselines.models.Policy_ViewSelection_GridMap",
+        os.path.join(root, "vlnce_baselines", "models", "Policy_ViewSelection_GridMap.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _VLNCE = mod
+    return mod
+
+
+class RefVlnceGridEnv:
+    """Drives the reference VLN-CE GridMap.getGlobalMap (Policy_ViewSelection_GridMap.py:689-825)."""
+
+    def __init__(self, batch_size, dataset="R2R", max_dist=25):
+        mod = import_vlnce_policy()
+        mod.DATASET, mod.MAX_DIST = dataset, max_dist
+        g = object.__new__(mod.GridMap)
+        g.global_fts = [[] for _ in range(batch_size)]
+        g.global_position_x = [[] for _ in range(batch_size)]
+        g.global_position_y = [[] for _ in range(batch_size)]
+        g.global_mask = [[] for _ in range(batch_size)]
+        g.global_map_index = [[] for _ in range(batch_size)]
+        g.max_x = [-10000 for _ in range(batch_size)]
+        g.min_x = [10000 for _ in range(batch_size)]
+        g.max_y = [-10000 for _ in range(batch_size)]
+        g.min_y = [10000 for _ in range(batch_size)]
+        g.headings = [0 for _ in range(batch_size)]
+        self.g = g
+
+    def step(self, i, position, heading, depth_full, grid_ft):
+        """depth_full (12,256,256) float32 metres; grid_ft (12,50,768)."""
+        g = self.g
+        g.headings[i] = heading
+        (fts, gx, gy, gm, gmap, mx, mnx, my, mny, pos) = g.getGlobalMap(i, position, heading, depth_full, grid_ft, None)
+        g.global_fts[i] = np.asarray(fts).view(_HistArray)
+        g.global_position_x[i], g.global_position_y[i], g.global_mask[i] = gx, gy, gm
+        g.global_map_index[i] = gmap
+        g.max_x[i], g.min_x[i], g.max_y[i], g.min_y[i] = mx, mnx, my, mny
+        return np.asarray(fts), np.array(gmap, copy=True), np.asarray(pos)

@@ -102,3 +102,18 @@ def test_rebinning_is_idempotent_and_permutation_complete():
     assert torch.equal(ids0, mem.cell_id) and torch.equal(perm0, mem.perm)
     for b in range(B):
         assert torch.equal(torch.sort(mem.perm[b, :n].long())[0], torch.arange(n, device="cuda"))
+
+
+def test_vlnce_twin_cell_ids_bit_exact_vs_reference_golden():
+    from gridmm_amd import synthetic as S
+    fx = load_golden("fill_gridmap_vlnce.npz")
+    for name, geom in (("r2r", S.VLNCE_R2R), ("rxr", S.VLNCE_RXR)):
+        T = int(fx[name + "_steps"])
+        mem = _mem(1, geom, T)
+        for t in range(T):
+            p = "%s_t%d_" % (name, t)
+            x, y, h = [float(v) for v in fx[p + "pose"]]
+            mem.step(fx[p + "depth"].reshape(1, -1), np.zeros((1, 588, 768), np.float16), [(x, y)], [h])
+            n = 588 * (t + 1)
+            assert np.array_equal(mem.cell_id[0, :n].cpu().numpy(), fx[p + "grid_map"]), (name, t)
+            assert np.allclose(mem.pos_fts[0].cpu().numpy(), fx[p + "pos_fts"], atol=2e-6), (name, t)

@@ -85,3 +85,18 @@ def test_oracle_vs_live_reference(has_reference):
         ds = G.sample_depth(depth_db["s_v%d" % t], horizon_slice=slice(12, 24))
         f, gm, pf, _ = mem.step(ds, clip_db["s_v%d" % t][:, 1:], info["s_v%d" % t]["x"], info["s_v%d" % t]["y"], h)
         assert np.array_equal(f, sem) and np.array_equal(gm, gmap) and np.array_equal(pf, pos)
+
+
+def test_vlnce_twin_bit_exact_vs_reference_golden():
+    """VLN-CE getGlobalMap (Policy_ViewSelection_GridMap.py:689-825): metres, view angle - heading, mirrored y,
+    rotation by pi, and the (x, Z, y) position-feature quirk of vlnce_baselines/models/utils.py:125-144."""
+    fx = load_golden("fill_gridmap_vlnce.npz")
+    for name, geom in (("r2r", G.VLNCE_R2R), ("rxr", G.VLNCE_RXR)):
+        mem = G.GridMemory(geom)
+        for t in range(int(fx[name + "_steps"])):
+            p = "%s_t%d_" % (name, t)
+            x, y, h = [float(v) for v in fx[p + "pose"]]
+            f, gm, pos, hl = mem.step(fx[p + "depth"], np.zeros((588, 768), np.float16), x, y, h)
+            assert np.array_equal(gm.astype(np.int16), fx[p + "grid_map"]), (name, t)
+            assert np.array_equal(pos, fx[p + "pos_fts"]), (name, t)
+    assert (fx["rxr_t0_grid_map"] == -1).all()
