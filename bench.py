@@ -182,8 +182,9 @@ def cpu_baseline(model, eps, batch, args, geom):
     torch.set_num_threads(k)
     done, t0 = 0, time.perf_counter()
     chunk = 2
-    while time.perf_counter() - t0 < args.cpu_seconds and done + chunk <= len(eps):
-        run(done, done + chunk)
+    while time.perf_counter() - t0 < args.cpu_seconds:      # ~10-30 s of CPU work; wraps around the episode batch
+        b0 = done % (len(eps) - chunk + 1)
+        run(b0, b0 + chunk)
         done += chunk
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "steps/s", "cores": k, "kind": "port",
