@@ -1,0 +1,283 @@
+"""Differentiable wrappers over the HIP kernels (training: SURVEY.md §8 rows a11 / a13 / a14).
+
+The reference trains through torch autograd over nn.Linear / LayerNorm / softmax attention / GELU
+(fine-tune: map_nav_src/r2r/agent_base.py:164-211; pre-train: pretrain_src/train_r2r.py:231-327).  Here
+every one of those ops is a torch.autograd.Function whose forward AND backward are HIP kernels of
+libgridmm_hip.so; torch only records the graph and moves/gathers/concatenates tensors.
+
+  linear      y = x W^T + b            fwd / dX: MFMA bf16x3 tile GEMM (gridmm_linear_planes)
+                                       dW = dY^T X: the same GEMM over transposed planes (gridmm_transpose_split),
+                                       db: column sums from the same transpose pass
+  layer_norm  LN(x (+ r)) g + b        gridmm_layernorm / gridmm_layernorm_bwd
+  gelu, relu                           gridmm_activation
+  attention   softmax(QK^T s + m) V    gridmm_attention_train / gridmm_attention_bwd (exact-fp32 MFMA)
+  grid_aggregate                       gridmm_grid_aggregate / gridmm_grid_aggregate_bwd (grad w.r.t. text_fts)
+
+There is no CPU / eager fallback: the functions raise on non-GPU tensors (ops._p).
+"""
+import math
+
+import torch
+
+from . import _lib, ops
+from .ops import _p, _rows2d, _stream
+
+
+# ------------------------------------------------------------------------------------------------
+# packed-weight cache: bf16 hi/lo planes of W (forward) and W^T (dX), rebuilt when the parameter changes
+# ------------------------------------------------------------------------------------------------
+class _WeightCache:
+    def __init__(self):
+        self._ent = {}
+
+    def get(self, w, transposed):
+        key = (w.data_ptr(), transposed)
+        ver = (w._version, tuple(w.shape))
+        ent = self._ent.get(key)
+        if ent is None or ent[0] != ver:
+            src = w.detach().float()
+            ent = (ver, ops.PackedLinear(src.t().contiguous() if transposed else src.contiguous(), None))
+            self._ent[key] = ent
+        return ent[1]
+
+    def clear(self):
+        self._ent.clear()
+
+
+WEIGHTS = _WeightCache()
+
+
+def _as2d(x):
+    x = ops.uniform_rows(x)
+    M, K, ld = _rows2d(x)
+    return x, M, K, ld
+
+
+def _gemm(a2d, pw, bias=None, residual=None):
+    """(M,K) fp32 @ packed (N,K)^T -> (M,N) fp32 through ops.linear (planes kernel when shapes allow)."""
+    pw.bias = bias
+    try:
+        return ops.linear(a2d, pw, residual=residual).f32
+    finally:
+        pw.bias = None
+
+
+def transpose_split(x2d, want_colsum=False):
+    """fp32 (M,C) -> bf16 hi/lo planes (C,Mp) with Mp = roundup(M,32), optional column sums (C,)."""
+    lib = _lib.load()
+    x2d, M, C, ld = _as2d(x2d)
+    Mp = (M + 31) // 32 * 32
+    hi = torch.empty(C, Mp, dtype=torch.bfloat16, device=x2d.device)
+    lo = torch.empty_like(hi)
+    cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum else None
+    _lib.check(lib.gridmm_transpose_split(_p(x2d), ld, _p(hi), _p(lo), _p(cs), M, C, Mp, _stream()),
+               "gridmm_transpose_split")
+    return hi, lo, cs, Mp
+
+
+def _gemm_tn(dy2d, x2d, want_colsum):
+    """dW (N,K) = dY^T X and db = colsum(dY), contraction over the M rows."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    yh, yl, db, Mp = transpose_split(dy2d, want_colsum)
+    xh, xl, _, _ = transpose_split(x2d)
+    pw = ops.PackedLinear.__new__(ops.PackedLinear)
+    pw.hi, pw.lo, pw.bias, pw.N, pw.K, pw.Kp = xh, xl, None, K, Mp, Mp
+    if K % 4 == 0:
+        dw = ops.linear(ops.Act(None, yh, yl), pw).f32
+    else:   # K = 5 / 7 / 14 position-feature layers: fp32-A kernel (any N); A = dY^T zero-padded to Mp columns
+        a = torch.zeros(N, Mp, dtype=torch.float32, device=dy2d.device)
+        a[:, :M] = dy2d.t()
+        dw = ops.linear(a, pw).f32
+    return dw, db
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        K = x.shape[-1]
+        x2 = x.float().contiguous().view(-1, K)
+        r2 = None if residual is None else residual.float().contiguous().view(-1, weight.shape[0])
+        y = _gemm(x2, WEIGHTS.get(weight, False), None if bias is None else bias.detach().float(), r2)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        N, K = weight.shape
+        dy2 = dy.contiguous().view(-1, N)
+        xm = x2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm(dy2, WEIGHTS.get(weight, True)).view(*dy.shape[:-1], K)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = _gemm_tn(dy2, xm, ctx.has_bias)
+            dw = dw.to(weight.dtype)
+        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None)
+
+
+def linear(x, weight, bias=None, residual=None):
+    """x (..., K) @ weight (N, K)^T + bias (+ residual)."""
+    return _Linear.apply(x, weight, bias, residual)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps):
+        x2 = ops.uniform_rows(x.float())
+        r2 = None if residual is None else ops.uniform_rows(residual.float())
+        y = ops.layernorm(x2, gamma.detach(), beta.detach(), eps, residual=r2).f32
+        ctx.save_for_backward(x2, r2, gamma)
+        ctx.eps, ctx.has_res = eps, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, r2, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, H, ldx = _rows2d(x2)
+        dx = torch.empty(x2.shape, dtype=torch.float32, device=dy.device)
+        dg = torch.empty(H, dtype=torch.float32, device=dy.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty((M + 3) // 4 * 2 * H, dtype=torch.float32, device=dy.device)
+        _lib.check(lib.gridmm_layernorm_bwd(_p(x2), ldx, _p(r2), _rows2d(r2)[2] if r2 is not None else 0,
+                                            _p(gamma.detach()), float(ctx.eps), _p(dy), H, _p(dx), H, _p(dg), _p(db),
+                                            _p(ws), M, H, _stream()), "gridmm_layernorm_bwd")
+        return dx, (dx if ctx.has_res else None), dg, db, None
+
+
+def layer_norm(x, mod, residual=None):
+    """mod: nn.LayerNorm-like (weight, bias, eps).  LN(x (+ residual))."""
+    return _LayerNorm.apply(x, residual, mod.weight, mod.bias, mod.eps)
+
+
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        lib = _lib.load()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(lib.gridmm_activation(_p(x), None, _p(y), x.numel(), mode, _stream()), "gridmm_activation")
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(lib.gridmm_activation(_p(x), _p(dy), _p(dx), x.numel(), ctx.mode + 1, _stream()),
+                   "gridmm_activation")
+        return dx, None
+
+
+def gelu(x):
+    return _Activation.apply(x, 0)
+
+
+def relu(x):
+    return _Activation.apply(x, 2)
+
+
+class _Attention(torch.autograd.Function):
+    """q_src (B,Sq,nq*H) with q at column q_col; kv_src (B,Sk,nk*H) with k at k_col, v at v_col (fused projection
+    outputs are consumed in place through strides).  Returns (B,Sq,H)."""
+
+    @staticmethod
+    def forward(ctx, q_src, kv_src, kmask, cols, heads):
+        lib = _lib.load()
+        H = heads * 64
+        same = kv_src is None
+        if same:
+            kv_src = q_src
+        q_src, kv_src = q_src.contiguous(), kv_src.contiguous()
+        qc, kc, vc = cols
+        B, Sq = q_src.shape[:2]
+        Sk = kv_src.shape[1]
+        q, k, v = q_src[..., qc:qc + H], kv_src[..., kc:kc + H], kv_src[..., vc:vc + H]
+        if kmask is not None:
+            kmask = kmask.contiguous()
+            kmask = kmask.view(torch.uint8) if kmask.dtype == torch.bool else kmask.to(torch.uint8)
+        Sqp = (Sq + 15) // 16 * 16
+        out = torch.empty(B, Sq, H, dtype=torch.float32, device=q_src.device)
+        lse = torch.empty(B, heads, Sqp, dtype=torch.float32, device=q_src.device)
+        scale = 1.0 / math.sqrt(64.0)
+        _lib.check(lib.gridmm_attention_train(
+            _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+            _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(lse), Sqp, B, heads, Sq, Sk,
+            scale, _stream()), "gridmm_attention_train")
+        ctx.save_for_backward(q_src, kv_src, kmask, out, lse)
+        ctx.cols, ctx.heads, ctx.same, ctx.scale = cols, heads, same, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q_src, kv_src, kmask, out, lse = ctx.saved_tensors
+        heads, H = ctx.heads, ctx.heads * 64
+        qc, kc, vc = ctx.cols
+        B, Sq = q_src.shape[:2]
+        Sk = kv_src.shape[1]
+        Sqp = lse.shape[2]
+        dout = dout.contiguous()
+        dq_src = torch.zeros_like(q_src)
+        dkv_src = dq_src if ctx.same else torch.zeros_like(kv_src)
+        delta = torch.empty_like(lse)
+        q, k, v = q_src[..., qc:qc + H], kv_src[..., kc:kc + H], kv_src[..., vc:vc + H]
+        dq, dk, dv = dq_src[..., qc:qc + H], dkv_src[..., kc:kc + H], dkv_src[..., vc:vc + H]
+        _lib.check(lib.gridmm_attention_bwd(
+            _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+            _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(dout), Sq * H, H, _p(lse),
+            _p(delta), _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0), dk.stride(1), _p(dv), dv.stride(0),
+            dv.stride(1), B, heads, Sq, Sk, Sqp, ctx.scale, _stream()), "gridmm_attention_bwd")
+        return dq_src, (None if ctx.same else dkv_src), None, None, None
+
+
+def self_attention(qkv, kmask, heads):
+    """qkv (B,S,3H) = fused [q | k | v] projection."""
+    H = heads * 64
+    return _Attention.apply(qkv, None, kmask, (0, H, 2 * H), heads)
+
+
+def cross_attention(q, kv, kmask, heads, kv_col=0):
+    """q (B,Sq,H); kv (B,Sk,n*2H) with [k | v] of this layer at column kv_col."""
+    H = heads * 64
+    return _Attention.apply(q, kv, kmask, (0, kv_col, kv_col + H), heads)
+
+
+class _GridAggregate(torch.autograd.Function):
+    """cells (B,196,D) = per-cell softmax(max_l <x_j, text_l>)-weighted sum of the fp16 slab rows."""
+
+    @staticmethod
+    def forward(ctx, text_fts, slab, perm, cell_start):
+        text_fts = text_fts.contiguous()
+        B, L, D = text_fts.shape
+        frag = ops.text_fragments(text_fts)
+        cells, occ, rel = ops.grid_aggregate(slab, perm, cell_start, frag, L, want_relevance=True)
+        ctx.save_for_backward(text_fts, slab, perm, cell_start, rel)
+        ctx.mark_non_differentiable(occ)
+        return cells, occ
+
+    @staticmethod
+    def backward(ctx, dcells, _docc):
+        lib = _lib.load()
+        text_fts, slab, perm, cell_start, rel = ctx.saved_tensors
+        B, L, D = text_fts.shape
+        cap = slab.shape[1]
+        dcells = dcells.contiguous()
+        dtext = torch.empty_like(text_fts)
+        da = torch.empty(B, cap, dtype=torch.float32, device=slab.device)
+        am = torch.empty(B, cap, dtype=torch.int32, device=slab.device)
+        _lib.check(lib.gridmm_grid_aggregate_bwd(_p(slab), _p(perm), _p(cell_start), _p(rel), _p(text_fts),
+                                                 _p(dcells), _p(dtext), _p(da), _p(am), B, cap, D, L, _stream()),
+                   "gridmm_grid_aggregate_bwd")
+        return dtext, None, None, None
+
+
+def grid_aggregate(text_fts, slab, perm, cell_start):
+    return _GridAggregate.apply(text_fts, slab, perm, cell_start)

@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void attention_kernel(
     const float* __restrict__ Q, int64_t q_bs, int q_rs, const float* __restrict__ K, int64_t k_bs,
     int k_rs, const float* __restrict__ V, int64_t v_bs, int v_rs, const uint8_t* __restrict__ kmask,
     int mask_bs, float* __restrict__ O, int64_t o_bs, int o_rs, unsigned short* __restrict__ Ohi,
-    unsigned short* __restrict__ Olo, int64_t p_bs, int p_rs, int Sq, int Sk, float scale) {
+    unsigned short* __restrict__ Olo, int64_t p_bs, int p_rs, int Sq, int Sk, float scale,
+    float* __restrict__ lse, int Sqp) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 16;
   if (q0 >= Sq) return;
@@ -123,6 +124,10 @@ __global__ __launch_bounds__(256) void attention_kernel(
   }
 
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  // training: log-sum-exp of the scaled scores per query (+BIG for a fully masked row, so that the
+  // backward's exp(s - lse) is exactly 0 there)
+  if (lse && g == 0 && q0 + j < Sqp)
+    lse[((size_t)b * gridDim.y + h) * Sqp + q0 + j] = l_run > 0.f ? m_run + logf(l_run) : -NEG_BIG;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float a = __shfl(inv, 4 * g + r, 64);
@@ -159,7 +164,22 @@ extern "C" int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const fl
   dim3 grid((Sq + 63) / 64, heads, B), block(256);
   GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
                      v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs,
-                     p_rs, Sq, Sk, scale);
+                     p_rs, Sq, Sk, scale, (float*)nullptr, 0);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs,
+                                      int k_rs, const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask,
+                                      int mask_bs, float* O, int64_t o_bs, int o_rs, float* lse, int Sqp, int B,
+                                      int heads, int Sq, int Sk, float scale, gridmm_stream_t stream) {
+  if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || !O || !lse || Sqp < Sq || Sqp % 16) return GRIDMM_EINVAL;
+  if ((q_rs | k_rs | v_rs | o_rs) & 3) return GRIDMM_EINVAL;
+  if ((q_bs | k_bs | v_bs | o_bs) & 3) return GRIDMM_EINVAL;
+  dim3 grid((Sq + 63) / 64, heads, B), block(256);
+  GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
+                     v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)nullptr, (unsigned short*)nullptr,
+                     (int64_t)0, 0, Sq, Sk, scale, lse, Sqp);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -25,6 +25,8 @@ typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
     hipLaunchKernelGGL(__VA_ARGS__);  \
   } while (0)
 
+constexpr int MAX_H_BWD = 1024;   // widest row the LayerNorm backward stages in LDS
+
 static inline hipStream_t as_stream(gridmm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // fp32 -> bf16 bits, round-to-nearest-even (inputs are finite on this path).

@@ -219,6 +219,55 @@ int gridmm_fuse_logits(const float* g_raw, const float* l_raw, const float* grid
 int gridmm_copy_rows(const float* src, int64_t src_bs, int src_rs, float* dst, int64_t dst_bs,
                      int dst_rs, int B, int rows, int H, gridmm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training (backward) entry points -- SURVEY.md §8 rows a11 / a13 / a14: the fine-tune loop
+ * (map_nav_src/r2r/agent_base.py:164-211, loss.backward at :199) and the pre-training loop
+ * (pretrain_src/train_r2r.py:231-327) back-propagate through the same encoders; in the reference
+ * that is torch autograd over nn.Linear / LayerNorm / softmax attention / GELU.
+ * ---------------------------------------------------------------------------------------- */
+
+/* X fp32 [M][C] (row stride ldx) -> transposed bf16 hi/lo planes T [C][Mp] (Mp % 32 == 0, zero padded),
+ * plus colsum[C] = sum_m X[m][c] (NULL to skip).  With gridmm_linear_planes (C = A B^T) this gives
+ *   dW [N][K] = dY^T X:  A = T(dY) [N][Mp], B = T(X) [K][Mp];   db = colsum(dY)
+ * (backward of nn.Linear, e.g. vilmodel.py:84-86,128,144). */
+int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, int M, int C, int Mp,
+                           gridmm_stream_t stream);
+
+/* Backward of y = LayerNorm(X (+ R)) * gamma + beta (BertLayerNorm / nn.LayerNorm, vilmodel.py:33,131,147).
+ *   dX [M][H] (same gradient flows to R); dgamma, dbeta [H]; workspace >= ceil(M/4) * 2 * H floats. */
+int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int ldr, const float* gamma, float eps,
+                         const float* dY, int ldy, float* dX, int lddx, float* dgamma, float* dbeta,
+                         float* workspace, int M, int H, gridmm_stream_t stream);
+
+/* Elementwise activations for training.  mode 0: out = gelu(X) (erf form, vilmodel.py:37-43);
+ * 1: out = dY * gelu'(X); 2: out = relu(X); 3: out = dY * (X > 0).  n % 4 == 0, contiguous. */
+int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, int mode, gridmm_stream_t stream);
+
+/* gridmm_attention that also returns lse [B][heads][Sqp] (Sqp = roundup(Sq,16)): log-sum-exp of the scaled,
+ * masked scores per query -- the only statistic the backward needs. */
+int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
+                           const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
+                           int64_t o_bs, int o_rs, float* lse, int Sqp, int B, int heads, int Sq, int Sk,
+                           float scale, gridmm_stream_t stream);
+
+/* Backward of the attention core: dQ, dK, dV from dO (fp32, exact-fp32 MFMA; masked keys get zero gradient).
+ * delta [B][heads][Sqp] is a workspace (sum_d dO*O per query). */
+int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
+                         const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, const float* O,
+                         int64_t o_bs, int o_rs, const float* dO, int64_t do_bs, int do_rs, const float* lse,
+                         float* delta, float* dQ, int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs, int dk_rs,
+                         float* dV, int64_t dv_bs, int dv_rs, int B, int heads, int Sq, int Sk, int Sqp, float scale,
+                         gridmm_stream_t stream);
+
+/* Backward of gridmm_grid_aggregate w.r.t. text = text_proj(txt_embeds) (vilmodel.py:795-807; the gradient
+ * reaches text_proj and the language encoder through the max / softmax weights):
+ *   relevance [B][cap] as written by the forward, text [B][L][D] f32, dcells [B][196][D] f32 (gradient of the
+ *   reduced cell vectors, i.e. after grid_proj's own backward) -> dtext [B][L][D] f32.
+ *   da_ws [B][cap] f32 and amax_ws [B][cap] int32 are workspaces. */
+int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                              const float* relevance, const float* text, const float* dcells, float* dtext,
+                              float* da_ws, int32_t* amax_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
