@@ -16,6 +16,7 @@ libgridmm_hip.so; torch only records the graph and moves/gathers/concatenates te
 There is no CPU / eager fallback: the functions raise on non-GPU tensors (ops._p).
 """
 import math
+import weakref
 
 import torch
 
@@ -27,18 +28,36 @@ from .ops import _p, _rows2d, _stream
 # packed-weight cache: bf16 hi/lo planes of W (forward) and W^T (dX), rebuilt when the parameter changes
 # ------------------------------------------------------------------------------------------------
 class _WeightCache:
-    def __init__(self):
-        self._ent = {}
+    """bf16 hi/lo planes of W (forward GEMM) and W^T (dX GEMM) per nn.Parameter, keyed by the parameter OBJECT
+    (weak) and its version counter, so optimizer steps / load_state_dict re-pack.  Temporaries (torch.cat of q|k|v
+    weights) are never cached: the caching allocator recycles their addresses."""
 
-    def get(self, w, transposed):
-        key = (w.data_ptr(), transposed)
-        ver = (w._version, tuple(w.shape))
-        ent = self._ent.get(key)
-        if ent is None or ent[0] != ver:
-            src = w.detach().float()
-            ent = (ver, ops.PackedLinear(src.t().contiguous() if transposed else src.contiguous(), None))
-            self._ent[key] = ent
-        return ent[1]
+    def __init__(self):
+        self._ent = {}   # id(param) -> (weakref to param, entry); the weakref's callback drops the entry
+
+    @staticmethod
+    def _pack(w, transposed):
+        src = w.detach().float()
+        return ops.PackedLinear(src.t().contiguous() if transposed else src.contiguous(), None)
+
+    def getter(self, w):
+        """-> get(transposed) returning the PackedLinear of w or w^T."""
+        if not isinstance(w, torch.nn.Parameter):
+            return lambda transposed: self._pack(w, transposed)
+        ver = (w._version, w.data_ptr(), tuple(w.shape))
+        key = id(w)
+        slot = self._ent.get(key)
+        if slot is None or slot[0]() is not w or slot[1]["ver"] != ver:
+            ent = {"ver": ver}
+            self._ent[key] = (weakref.ref(w, lambda _r, key=key: self._ent.pop(key, None)), ent)
+        else:
+            ent = slot[1]
+
+        def get(transposed, ent=ent, w=w):
+            if transposed not in ent:
+                ent[transposed] = self._pack(w, transposed)
+            return ent[transposed]
+        return get
 
     def clear(self):
         self._ent.clear()
@@ -94,11 +113,12 @@ def _gemm_tn(dy2d, x2d, want_colsum):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual):
+    def forward(ctx, x, weight, bias, residual, packs):
         K = x.shape[-1]
+        ctx.packs = packs
         x2 = x.float().contiguous().view(-1, K)
         r2 = None if residual is None else residual.float().contiguous().view(-1, weight.shape[0])
-        y = _gemm(x2, WEIGHTS.get(weight, False), None if bias is None else bias.detach().float(), r2)
+        y = _gemm(x2, packs(False), None if bias is None else bias.detach().float(), r2)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         return y.view(*x.shape[:-1], weight.shape[0])
@@ -111,16 +131,16 @@ class _Linear(torch.autograd.Function):
         xm = x2
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _gemm(dy2, WEIGHTS.get(weight, True)).view(*dy.shape[:-1], K)
+            dx = _gemm(dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _gemm_tn(dy2, xm, ctx.has_bias)
             dw = dw.to(weight.dtype)
-        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None)
+        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None), None
 
 
 def linear(x, weight, bias=None, residual=None):
     """x (..., K) @ weight (N, K)^T + bias (+ residual)."""
-    return _Linear.apply(x, weight, bias, residual)
+    return _Linear.apply(x, weight, bias, residual, WEIGHTS.getter(weight))
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -19,7 +19,7 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
-from . import ops
+from . import ops, vilmodel_train
 from .grid_memory import GridMemoryBatch, pack_reference_lists
 
 N_CELLS = 196
@@ -229,12 +229,21 @@ class GlocalTextPathNavCMT(nn.Module):
         if c.obj_feat_size > 0:
             self.og_head = ClsPrediction(H)
         self.heads = c.num_attention_heads
+        self.differentiable = None
         self._packed = {}
         for m in self.modules():  # BERT-style init (BertPreTrainedModel.init_weights)
             if isinstance(m, (nn.Linear, nn.Embedding)):
                 nn.init.normal_(m.weight, std=0.02)
                 if isinstance(m, nn.Linear) and m.bias is not None:
                     nn.init.zeros_(m.bias)
+
+    def _differentiable(self):
+        """Which forward runs: the autograd-recording one (vilmodel_train.py) when gradients are enabled and the
+        module is in train() mode -- or when `self.differentiable = True` forces it (gradient tests in eval mode);
+        otherwise the inference path (bf16x3 attention, fused epilogues, hipGraph-capturable)."""
+        if not torch.is_grad_enabled():
+            return False
+        return self.training if self.differentiable is None else bool(self.differentiable)
 
     # ---- packed (bf16 hi/lo) weights, rebuilt when a parameter changes -------------------------
     def _pack(self, key, weights, biases):
@@ -328,9 +337,14 @@ class GlocalTextPathNavCMT(nn.Module):
         return (m if m.dtype == torch.uint8 else m.to(torch.uint8)).contiguous()
 
     # ---- modes --------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward_text(self, txt_ids, txt_masks):
-        """vilmodel.py:730-734."""
+        """vilmodel.py:730-734.  With grad enabled: the differentiable path (vilmodel_train.py)."""
+        if self._differentiable():
+            return vilmodel_train.forward_text(self, txt_ids, txt_masks)
+        return self._forward_text_infer(txt_ids, txt_masks)
+
+    @torch.no_grad()
+    def _forward_text_infer(self, txt_ids, txt_masks):
         e = self.embeddings
         L = txt_ids.shape[1]
         pos = torch.arange(L, device=txt_ids.device).unsqueeze(0).expand_as(txt_ids)
@@ -342,9 +356,15 @@ class GlocalTextPathNavCMT(nn.Module):
             x = self._bert_layer(layer, "lang.%d" % i, x, m)
         return x.f32
 
-    @torch.no_grad()
     def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
         """vilmodel.py:736-780 (view-only branch on HIP; objects are concatenated by the caller form)."""
+        if self._differentiable():
+            return vilmodel_train.forward_panorama(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens,
+                                                   obj_lens)
+        return self._forward_panorama_infer(view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens)
+
+    @torch.no_grad()
+    def _forward_panorama_infer(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
         ie = self.img_embeddings
         if obj_img_fts is not None:
             raise NotImplementedError("object panorama tokens (REVERIE/SOON) are outside this round's scope")
@@ -386,13 +406,19 @@ class GlocalTextPathNavCMT(nn.Module):
         a, b = self._fusion_index_maps(batch["gmap_vpids"], batch["gmap_visited_masks"], batch["vp_cand_vpids"], G, V)
         return a.to(device), b.to(device)
 
+    def forward_navigation_per_step(self, *args, **kwargs):
+        """vilmodel.py:782-918 on HIP kernels.  Same arguments, same output dict.  With grad enabled (fine-tune /
+        pre-training) the differentiable path of vilmodel_train.py runs; under torch.no_grad() the inference path."""
+        if self._differentiable():
+            return vilmodel_train.forward_navigation(self, *args, **kwargs)
+        return self._forward_navigation_infer(*args, **kwargs)
+
     @torch.no_grad()
-    def forward_navigation_per_step(
+    def _forward_navigation_infer(
             self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
             gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
             vp_nav_masks, vp_obj_masks, vp_cand_vpids, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None,
             fusion_maps=None):
-        """vilmodel.py:782-918 on HIP kernels.  Same arguments, same output dict."""
         dev = txt_embeds.device
         B, L, H = txt_embeds.shape
         G, V = gmap_masks.shape[1], vp_masks.shape[1]
