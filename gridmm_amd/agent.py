@@ -27,7 +27,10 @@ from .graph_utils import GraphMap
 def default_args(**over):
     """The subset of r2r/parser.py the loop reads."""
     a = dict(max_action_len=15, ignoreid=-100, image_feat_size=768, angle_feat_size=4, fusion="dynamic",
-             enc_full_graph=True, act_visited_nodes=False, expl_max_ratio=0.6, detailed_output=False)
+             enc_full_graph=True, act_visited_nodes=False, expl_max_ratio=0.6, detailed_output=False,
+             # training (r2r/parser.py): DAgger by default in scripts/run_r2r.sh
+             train_alg="dagger", ml_weight=0.2, expl_sample=False, lr=1e-5, optim="adamW", feat_dropout=0.4,
+             dropout=0.5)
     a.update(over)
     return SimpleNamespace(**a)
 
@@ -269,6 +272,16 @@ class GMapNavAgent:
                 c = torch.distributions.Categorical(nav_probs)
                 self.logs["entropy"].append(c.entropy().sum().item())
                 a_t = c.sample().detach()
+            elif self.feedback == "expl_sample":        # agent.py:385-395
+                a_t = nav_probs.max(1)[1].detach()
+                rand_explores = np.random.rand(B) > self.args.expl_max_ratio
+                if self.args.fusion == "local":
+                    cpu_nav_masks = nav_inputs["vp_nav_masks"].cpu().numpy()
+                else:
+                    cpu_nav_masks = (nav_inputs["gmap_masks"] & nav_inputs["gmap_visited_masks"].logical_not()).cpu().numpy()
+                for i in range(B):
+                    if rand_explores[i]:
+                        a_t[i] = int(np.random.choice(np.arange(len(cpu_nav_masks[i]))[cpu_nav_masks[i]]))
             else:
                 raise ValueError("Invalid feedback option: %s" % self.feedback)
 
@@ -312,5 +325,70 @@ class GMapNavAgent:
         if train_ml is not None:
             ml_loss = ml_loss * train_ml / B
             self.loss = self.loss + ml_loss
-            self.logs["IL_loss"].append(float(ml_loss))
+            self.logs["IL_loss"].append(float(ml_loss.detach()) if torch.is_tensor(ml_loss) else float(ml_loss))
         return traj
+
+    # ---- Seq2SeqAgent.test / .train (agent_base.py:150-211) ---------------------------------------
+    def test(self, feedback="argmax", iters=None):
+        """Evaluate once on each instruction of the environment (BaseAgent.test, agent_base.py:49-77)."""
+        self.feedback = feedback
+        self._set_mode(False)
+        self.env.reset_epoch()
+        self.results, looped = {}, False
+        with torch.no_grad():
+            while not looped and (iters is None or iters > 0):
+                for traj in self.rollout():
+                    if traj["instr_id"] in self.results:
+                        looped = True
+                    else:
+                        self.results[traj["instr_id"]] = traj
+                if iters is not None:
+                    iters -= 1
+        return [{"instr_id": k, "trajectory": v["path"]} for k, v in self.results.items()]
+
+    def _set_mode(self, training):
+        m = self.vln_bert
+        if hasattr(m, "train"):
+            m.train(training)
+        mem = getattr(self.env, "grid_memory", None)
+        if mem is not None and hasattr(mem, "keep_for_backward"):
+            mem.keep_for_backward = bool(training)
+
+    def make_optimizer(self):
+        """agent_base.py:122-139: one optimizer over all vln_bert parameters at args.lr."""
+        opt = {"rms": torch.optim.RMSprop, "adam": torch.optim.Adam, "adamW": torch.optim.AdamW,
+               "sgd": torch.optim.SGD}[self.args.optim]
+        self.vln_bert_optimizer = opt(self.vln_bert.parameters(), lr=self.args.lr)
+        from .dist import GradientReducer
+        self.grad_reducer = GradientReducer(self.vln_bert.parameters())
+        return self.vln_bert_optimizer
+
+    def train(self, n_iters, feedback="teacher"):
+        """agent_base.py:164-211: per iteration zero_grad -> rollout(s) accumulate self.loss -> backward ->
+        [all-reduce(mean) of the gradients across ranks, the DDP step] -> clip_grad_norm 40 -> optimizer step."""
+        if not hasattr(self, "vln_bert_optimizer"):
+            self.make_optimizer()
+        self.feedback = feedback
+        self._set_mode(True)
+        self.losses = []
+        for _ in range(n_iters):
+            self.vln_bert_optimizer.zero_grad()
+            self.loss = 0
+            if self.args.train_alg == "imitation":
+                self.feedback = "teacher"
+                self.rollout(train_ml=1.0)
+            elif self.args.train_alg == "dagger":
+                if self.args.ml_weight != 0:
+                    self.feedback = "teacher"
+                    self.rollout(train_ml=self.args.ml_weight)
+                self.feedback = "expl_sample" if self.args.expl_sample else "sample"
+                self.rollout(train_ml=1)
+            else:
+                raise NotImplementedError("train_alg %r (the A2C branch, train_rl=True, is not used by the released "
+                                          "GridMM scripts)" % self.args.train_alg)
+            self.loss.backward()
+            self.grad_reducer.reduce()
+            torch.nn.utils.clip_grad_norm_(self.vln_bert.parameters(), 40.0)
+            self.vln_bert_optimizer.step()
+            self.losses.append(float(self.loss.detach()))
+        return self.losses

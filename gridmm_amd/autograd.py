@@ -279,14 +279,20 @@ class _GridAggregate(torch.autograd.Function):
         B, L, D = text_fts.shape
         frag = ops.text_fragments(text_fts)
         cells, occ, rel = ops.grid_aggregate(slab, perm, cell_start, frag, L, want_relevance=True)
-        ctx.save_for_backward(text_fts, slab, perm, cell_start, rel)
+        # The grid memory re-bins its whole history in place every step: keep THIS step's point order.  The slab
+        # is append-only within a rollout (rows this step's perm refers to are never rewritten; a training rollout
+        # gets a fresh slab, GridMemoryBatch.reset), so it is referenced, not copied -- and kept out of
+        # save_for_backward, whose version check would trip on the later in-place appends.
+        ctx.save_for_backward(text_fts, perm.clone(), cell_start.clone(), rel)
+        ctx.slab = slab
         ctx.mark_non_differentiable(occ)
         return cells, occ
 
     @staticmethod
     def backward(ctx, dcells, _docc):
         lib = _lib.load()
-        text_fts, slab, perm, cell_start, rel = ctx.saved_tensors
+        text_fts, perm, cell_start, rel = ctx.saved_tensors
+        slab = ctx.slab
         B, L, D = text_fts.shape
         cap = slab.shape[1]
         dcells = dcells.contiguous()

@@ -46,6 +46,7 @@ class GridMemoryBatch:
         self.pos_fts = torch.zeros(B, 196, 5, dtype=torch.float32, device=dev)
         self.n_pts = torch.zeros(B, dtype=torch.int32, device=dev)
         self.n_pts_host = np.zeros(B, np.int64)
+        self.keep_for_backward = False
         # static per-step inputs (pinned host -> device): the only bytes that cross PCIe each step
         self._pose_host = torch.zeros(B, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(B, 2)
         self._head_host = torch.zeros(B, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(B, 2)
@@ -75,7 +76,12 @@ class GridMemoryBatch:
         self.reset()
 
     def reset(self):
-        """EnvBatch.newEpisodes (env.py:178-194).  Device-only work (graph-capturable)."""
+        """EnvBatch.newEpisodes (env.py:178-194).  Device-only work (graph-capturable).
+
+        With `self.keep_for_backward` set (training rollouts), the feature slab of the finished rollout stays
+        untouched -- autograd nodes of that rollout still read it in backward -- and a fresh one is allocated."""
+        if self.keep_for_backward:
+            self.slab = torch.zeros_like(self.slab)
         self.bbox.copy_(self._bbox_init)
         self.n_pts.zero_()
         self.n_pts_host[:] = 0

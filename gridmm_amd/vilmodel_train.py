@@ -142,7 +142,7 @@ def grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memo
     if grid_memory is not None:
         slab, perm, cell_start = grid_memory.slab, grid_memory.perm, grid_memory.cell_start
         if gridmap_pos_fts is None:
-            gridmap_pos_fts = grid_memory.pos_fts
+            gridmap_pos_fts = grid_memory.pos_fts.clone()    # the buffer is overwritten by the next step
     else:
         slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
     cells, occ = ag.grid_aggregate(text_fts, slab, perm, cell_start)

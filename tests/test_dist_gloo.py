@@ -55,3 +55,73 @@ def test_single_process_degrades_gracefully():
     assert D.shard_indices(5) == [0, 1, 2, 3, 4]
     assert D.all_gather_objects({"a": 1}) == [{"a": 1}]
     assert D.max_over_ranks(0.25) == 0.25
+
+
+# ---- training exchange: GradientReducer == DDP(find_unused_parameters=True) semantics ------------------------
+class _Tiny(torch.nn.Module):
+    """Two heads; which one is used depends on the sample ('task'), like the task-mixed pre-training step."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.body = torch.nn.Linear(6, 5)
+        self.head_a = torch.nn.Linear(5, 3)
+        self.head_b = torch.nn.Linear(5, 3)
+        self.never = torch.nn.Linear(5, 1)            # unused on every rank -> grad must stay None
+        for p in self.parameters():
+            p.data = torch.randn(p.shape, generator=g) * 0.3
+
+    def forward(self, x, task):
+        h = torch.tanh(self.body(x))
+        return (self.head_a if task == "a" else self.head_b)(h)
+
+
+def _tiny_loss(model, x, y, task):
+    return torch.nn.functional.cross_entropy(model(x, task), y, reduction="mean")
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gridmm_amd import dist as D
+    torch.manual_seed(100 + rank)
+    model = _Tiny()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)                               # deliberately different; broadcast must fix it
+    D.broadcast_parameters(model.parameters())
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    _tiny_loss(model, xs, ys, "a" if rank == 0 else "b").backward()      # rank 0 never touches head_b and v.v.
+    D.GradientReducer(model.parameters(), bucket_mb=1e-4).reduce()        # tiny buckets: exercise several
+    out = {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_matches_single_process_mean_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process: mean over ranks of the per-rank mean losses
+    model = _Tiny()
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+    (0.5 * (_tiny_loss(model, x[:4], y[:4], "a") + _tiny_loss(model, x[4:], y[4:], "b"))).backward()
+    for k, p in model.named_parameters():
+        for r in range(world):
+            got = outs[r][k]
+            if p.grad is None:
+                assert got is None, k                      # same set of grad-less parameters
+            else:
+                assert got is not None and torch.allclose(got, p.grad, atol=1e-6), k
