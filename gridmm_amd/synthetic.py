@@ -124,3 +124,137 @@ def batch_to(batch, device):
         else:
             out[k] = v
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# pre-training batches (pretrain_src/data/tasks.py collates)
+# ------------------------------------------------------------------------------------------------
+def make_pretrain_batch(rs, B, task, max_steps=3, L=24, vocab=2000, H=768, image_prob_size=50, n_pts=(200, 588),
+                        feat_scale=0.35, views=(36, 33)):
+    """One collated batch with the keys / dtypes of mlm_collate / mrc_collate / sap_collate (tasks.py:104-141,
+    229-275, 334-377) for R2R (no object tokens).  Episodes are random but self-consistent: every global-map node is
+    either a visited viewpoint or a candidate seen from one, the last step's candidates define the local branch.
+
+    CPU tensors + python lists; `grid_fts` is a list of (N_b, 768) fp16, `grid_map` a list of (N_b,) int64.
+    """
+    txt_ids, txt_labels, txt_lens = [], [], []
+    view, loc, types, step_lens, view_lens = [], [], [], [], []
+    traj_vpids, traj_cand_vpids, gmap_vpids = [], [], []
+    gmap_step_ids, gmap_visited, gmap_pos, gmap_dists = [], [], [], []
+    vp_pos, grid_fts, grid_map, gpos = [], [], [], []
+    g_labels, l_labels, mrc_masks, mrc_probs = [], [], [], []
+    for b in range(B):
+        n_tok = int(rs.randint(8, L - 1))
+        ids = [101] + rs.randint(1000, vocab, size=n_tok).tolist() + [102]
+        lab = [-1] * len(ids)
+        if task == "mlm":                                        # random_word (data/common.py): 15 % masked
+            for k in range(1, len(ids) - 1):
+                if rs.rand() < 0.15:
+                    lab[k], ids[k] = ids[k], 103
+            if all(x == -1 for x in lab):
+                lab[1], ids[1] = ids[1], 103
+        txt_ids.append(torch.tensor(ids, dtype=torch.int32))
+        txt_labels.append(torch.tensor(lab, dtype=torch.int32))
+        txt_lens.append(len(ids))
+
+        T = int(rs.randint(1, max_steps + 1))
+        path = ["b%d_v%d" % (b, t) for t in range(T)]
+        cands_per_step, seen = [], []
+        for t in range(T):
+            n_c = int(rs.randint(2, 5))
+            c = ["b%d_v%d_c%d" % (b, t, j) for j in range(n_c)]
+            if t + 1 < T:
+                c[int(rs.randint(n_c))] = path[t + 1]            # the next viewpoint is one of the candidates
+            if t > 0:
+                c[0 if c[0] != (path[t + 1] if t + 1 < T else None) else 1] = path[t - 1]   # and the way back
+            cands_per_step.append(c)
+            V = int(views[rs.randint(len(views))])
+            view.append(torch.from_numpy(rs.standard_normal((V, H)).astype(np.float32)))
+            loc.append(torch.from_numpy(rs.uniform(-1, 1, size=(V, 7)).astype(np.float32)))
+            types.append(torch.tensor([1] * n_c + [0] * (V - n_c), dtype=torch.int32))
+            view_lens.append(V)
+            for x in c:
+                if x not in seen:
+                    seen.append(x)
+        step_lens.append(np.int32(T))
+        traj_vpids.append(path)
+        traj_cand_vpids.append(cands_per_step)
+        nodes = path + [x for x in seen if x not in path]
+        gmap_vpids.append([None] + nodes)
+        G = len(nodes) + 1
+        visited = [False] + [x in path for x in nodes]
+        gmap_visited.append(torch.tensor(visited))
+        gmap_step_ids.append(torch.tensor([0] + [path.index(x) + 1 if x in path else 0 for x in nodes], dtype=torch.int32))
+        gmap_pos.append(torch.from_numpy(rs.uniform(-1, 1, size=(G, 7)).astype(np.float32)))
+        gmap_dists.append(torch.from_numpy(rs.uniform(0, 1, size=(G, G)).astype(np.float32)))
+        Vl = view_lens[-1] + 1
+        p = rs.uniform(-1, 1, size=(Vl, 14)).astype(np.float32)
+        p[len(cands_per_step[-1]) + 1:, 7:] = 0
+        vp_pos.append(torch.from_numpy(p))
+        N = int(rs.randint(n_pts[0], n_pts[1] + 1))
+        grid_fts.append(torch.from_numpy((rs.standard_normal((N, H)) * feat_scale).astype(np.float16)))
+        m = rs.randint(-1, 196, size=N).astype(np.int64)
+        m[:40] = rs.randint(0, 3, size=40)
+        grid_map.append(torch.from_numpy(m))
+        gpos.append(torch.from_numpy(rs.uniform(-1, 1, size=(196, 5)).astype(np.float32)))
+        # action labels (dataset.py get_act_labels): 0 = stop, else index of the next node / candidate
+        unvisited = [j for j in range(1, G) if not visited[j]]
+        stop = rs.rand() < 0.3
+        gl = 0 if stop else int(unvisited[rs.randint(len(unvisited))])
+        node = gmap_vpids[-1][gl]
+        ll = 0 if stop else (cands_per_step[-1].index(node) + 1 if node in cands_per_step[-1] else -100)
+        if ll == -100:                                           # label must be a current candidate for the local CE
+            ll = int(rs.randint(1, len(cands_per_step[-1]) + 1))
+            gl = gmap_vpids[-1].index(cands_per_step[-1][ll - 1])
+            if visited[gl]:
+                gl, ll = 0, 0
+        g_labels.append(gl)
+        l_labels.append(ll)
+        mm = rs.rand(view_lens[-1]) < 0.15
+        if not mm.any():
+            mm[rs.randint(view_lens[-1])] = True
+        mrc_masks.append(torch.from_numpy(mm))
+        pr = rs.standard_normal((view_lens[-1], image_prob_size)).astype(np.float32)
+        mrc_probs.append(torch.softmax(torch.from_numpy(pr), -1))
+        if task == "mrc":                                        # _mask_img_feat: masked views are zeroed
+            view[-1] = view[-1].masked_fill(mrc_masks[-1].unsqueeze(-1), 0)
+
+    pad = torch.nn.utils.rnn.pad_sequence
+
+    def pad_t(ts):
+        n = max(t.shape[0] for t in ts)
+        out = torch.zeros((len(ts), n) + tuple(ts[0].shape[1:]), dtype=ts[0].dtype)
+        for i, t in enumerate(ts):
+            out[i, :t.shape[0]] = t
+        return out
+    Gm = max(len(x) for x in gmap_vpids)
+    dists = torch.zeros(B, Gm, Gm)
+    for i, d in enumerate(gmap_dists):
+        dists[i, :d.shape[0], :d.shape[1]] = d
+    batch = {
+        "txt_ids": pad(txt_ids, batch_first=True, padding_value=0).to(torch.int32),
+        "txt_lens": torch.tensor(txt_lens, dtype=torch.int32),
+        "traj_step_lens": step_lens,
+        "traj_vp_view_lens": torch.tensor(view_lens, dtype=torch.int32),
+        "traj_view_img_fts": pad_t(view), "traj_loc_fts": pad_t(loc),
+        "traj_nav_types": pad(types, batch_first=True, padding_value=0).to(torch.int32),
+        "traj_vpids": traj_vpids, "traj_cand_vpids": traj_cand_vpids,
+        "gmap_vpids": gmap_vpids,
+        "gmap_lens": torch.tensor([len(x) for x in gmap_vpids], dtype=torch.int32),
+        "gmap_step_ids": pad(gmap_step_ids, batch_first=True, padding_value=0).to(torch.int32),
+        "gmap_visited_masks": pad(gmap_visited, batch_first=True, padding_value=False),
+        "gmap_pos_fts": pad_t(gmap_pos), "gmap_pair_dists": dists,
+        "vp_lens": torch.tensor([x.shape[0] for x in vp_pos], dtype=torch.int32),
+        "vp_pos_fts": pad_t(vp_pos),
+        "grid_fts": grid_fts, "grid_map": grid_map, "gridmap_pos_fts": torch.stack(gpos, 0),
+        "target_patch_id": torch.zeros(B, dtype=torch.int32),
+    }
+    if task == "mlm":
+        batch["txt_labels"] = pad(txt_labels, batch_first=True, padding_value=-1).to(torch.int32)
+    if task == "sap":
+        batch["global_act_labels"] = torch.tensor(g_labels, dtype=torch.int32)
+        batch["local_act_labels"] = torch.tensor(l_labels, dtype=torch.int32)
+    if task == "mrc":
+        batch["vp_view_mrc_masks"] = pad(mrc_masks, batch_first=True, padding_value=False)
+        batch["vp_view_probs"] = pad_t(mrc_probs)
+    return batch

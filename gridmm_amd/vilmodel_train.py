@@ -133,7 +133,8 @@ def forward_panorama(model, view_img_fts, obj_img_fts, loc_fts, nav_types, view_
     return x, masks
 
 
-def grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None, proj_weight=None):
+def grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None, proj_weight=None,
+               proj_bias=None):
     """:793-823 -> compacted cell tokens (B,196,H) (zeros past each episode's occupied count) and their mask with
     the reference's view quirk (:817-821), both padded to 196."""
     B, L, H = txt_embeds.shape
@@ -147,7 +148,7 @@ def grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memo
         slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
     cells, occ = ag.grid_aggregate(text_fts, slab, perm, cell_start)
     w = model.grid_proj.weight if proj_weight is None else proj_weight
-    proj = ag.linear(cells, w, model.grid_proj.bias)                 # grid_proj after the reduction (sum a_j = 1)
+    proj = ag.linear(cells, w, model.grid_proj.bias if proj_bias is None else proj_bias)                 # grid_proj after the reduction (sum a_j = 1)
     gp = model.grid_pos_embeddings
     pos = ag.layer_norm(ag.linear(gridmap_pos_fts.float(), gp[0].weight, gp[0].bias), gp[1])
     x = proj + pos

@@ -283,10 +283,56 @@ def gen_rollout():
     print("rollout_reduced ok: steps=%d min argmax margin=%.3e paths=%s" % (len(agent.trace), margin, out["traj"][:120]))
 
 
+PRETRAIN_SEEDS = {"mlm": 11, "mrc": 12, "sap": 13}
+GRAD_SAMPLES = 48
+
+
+def pretrain_batch(task):
+    """The batches of pretrain_reduced.npz, regenerated identically by the tests (inputs are not stored)."""
+    return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS[task]), 3, task)
+
+
+def grad_sample_index(name, numel):
+    """Seeded positions at which a parameter's gradient is recorded."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return rs.randint(0, numel, size=min(GRAD_SAMPLES, numel))
+
+
+def gen_pretrain():
+    """GlocalTextPathCMTPreTraining.forward(batch, task) (pretrain_cmt.py:71-321) in train-step form
+    (train_r2r.py:245-262): per-sample loss vectors, then loss.mean().backward(): per-parameter gradient norm,
+    seeded samples of every gradient, and the set of parameters that received none."""
+    torch.set_num_threads(1)
+    model = R.build_ref_pretrain_model(seed=9).train()     # dropout probs are 0 in the reduced config
+    out = {"versions": _versions(), "weight_seed": 9, "cfg": json.dumps(R.PRETRAIN_REDUCED),
+           "param_names": json.dumps([k for k, _ in model.named_parameters()]),
+           "param_dtypes": json.dumps({k: str(v.dtype) for k, v in model.state_dict().items()})}
+    for task in ("mlm", "mrc", "sap"):
+        batch = pretrain_batch(task)
+        model.zero_grad()
+        loss = model(batch, task=task, compute_loss=True)
+        out["loss_" + task] = loss.detach().float().numpy()
+        loss.mean().backward()
+        names, norms, samples = [], [], []
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.detach().float().reshape(-1)
+            names.append(k)
+            norms.append(float(g.norm()))
+            samples.append(g[torch.from_numpy(grad_sample_index(k, g.numel()))].numpy())
+        out["grad_names_" + task] = json.dumps(names)
+        out["grad_norms_" + task] = np.array(norms, np.float32)
+        out["grad_samples_" + task] = np.concatenate(samples).astype(np.float32)
+        print(task, "loss", out["loss_" + task], "params with grad", len(names))
+    np.savez_compressed(os.path.join(OUT, "pretrain_reduced.npz"), **out)
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain"]
     if "rollout" in which: gen_rollout()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
@@ -294,3 +340,4 @@ if __name__ == "__main__":
     if "navobj" in which: gen_nav_reduced(True)
     if "textpano" in which: gen_text_pano()
     if "full" in which: gen_nav_full()
+    if "pretrain" in which: gen_pretrain()

@@ -161,6 +161,45 @@ def build_ref_model(seed=0, **cfg_over):
     return m
 
 
+# --------------------------------------------------------------------------- pre-training twin
+REF_PRETRAIN = os.path.join(REF_ROOT, "pretrain_src")
+_PRE = None
+
+
+def import_pretrain():
+    """Import pretrain_src/model/{pretrain_cmt,vilmodel}.py (package name `model`)."""
+    global _PRE
+    if _PRE is not None:
+        return _PRE
+    install_shims()
+    if REF_PRETRAIN not in sys.path:
+        sys.path.insert(0, REF_PRETRAIN)
+    from model import pretrain_cmt, vilmodel as pvil  # noqa: the reference's modules
+
+    pvil.BertPreTrainedModel.init_weights = lambda self: None
+    # transformers 5.x has no _tie_or_clone_weights: tie by hand after construction (pretrain_cmt.py:66-69)
+    pretrain_cmt.GlocalTextPathCMTPreTraining.tie_weights = lambda self: None
+    _PRE = pretrain_cmt
+    return pretrain_cmt
+
+
+PRETRAIN_REDUCED = dict(num_l_layers=1, num_pano_layers=1, num_x_layers=2, intermediate_size=64, vocab_size=2000,
+                        use_lang2visn_attn=True, pretrain_tasks=["mlm", "mrc", "sap"], image_prob_size=50,
+                        obj_prob_size=0, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+
+def build_ref_pretrain_model(seed=0, **cfg_over):
+    """GlocalTextPathCMTPreTraining (pretrain_cmt.py:38-69) with deterministic weights, MLM decoder tied."""
+    pre = import_pretrain()
+    cfg = make_config(**dict(PRETRAIN_REDUCED, **cfg_over))
+    m = pre.GlocalTextPathCMTPreTraining(cfg)
+    sd = det_state_dict(m, seed)
+    sd["mlm_head.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    m.load_state_dict(sd)
+    m.mlm_head.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight
+    return m
+
+
 # --------------------------------------------------------------------------- env driver
 class _HistArray(np.ndarray):
     """ndarray whose `== []` is a scalar False (numpy-2 fix for env.py:298)."""

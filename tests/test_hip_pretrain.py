@@ -1,0 +1,82 @@
+"""GPU: the pre-training twin (gridmm_amd.pretrain_cmt) against vectors captured from the imported reference
+(pretrain_src/model/pretrain_cmt.py; oracle/gen_golden.py gen_pretrain): per-sample loss vectors of mlm / mrc / sap,
+and -- after loss.mean().backward() as train_r2r.py:245-262 does -- every parameter's gradient norm, 48 seeded
+samples of every gradient, and the set of parameters without a gradient.
+
+Tolerances: the reference computes grid_proj + the per-cell reduction in fp16 (vilmodel.py:693-703), this build in
+fp32 -> losses agree to 2e-3 relative, gradients to 2e-2 of the tensor's largest sampled entry / norm.
+
+mrc: RegionClassification holds a ReLU (pretrain_cmt.py:15-18) and one of its 7680 pre-activations in this fixture sits
+within 1e-4 of zero: perturbing the REFERENCE's own weights by 1e-4 relative moves its mrc gradients by 2-8 %
+(image_classifier.net.0.weight 7.8 %, measured with oracle/ref_harness in the build container) while mlm / sap move by
+< 1e-3.  The fp16-vs-fp32 difference above is of that size, so for mrc the elementwise bound is 1e-1 and the binding
+check is the cosine between all sampled gradient entries (> 0.999).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import gen_golden
+from oracle.ref_harness import det_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(fx):
+    from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from gridmm_amd.vilmodel import default_config
+    cfg = default_config(**json.loads(str(fx["cfg"])))
+    m = GlocalTextPathCMTPreTraining(cfg)
+    dt = json.loads(str(fx["param_dtypes"]))
+    sd = {}
+    for k, v in m.state_dict().items():
+        assert k in dt, k
+        sd[k] = det_tensor(k, v.shape, int(fx["weight_seed"])).to(v.dtype)
+    assert sorted(sd) == sorted(dt), set(sd) ^ set(dt)                       # same state_dict keys as the reference
+    for k in sd:
+        assert str(sd[k].dtype) == dt[k], (k, sd[k].dtype, dt[k])
+    sd["mlm_head.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    m.load_state_dict(sd)
+    assert [k for k, _ in m.named_parameters()] == json.loads(str(fx["param_names"]))
+    return m.cuda().train()          # dropout probabilities are 0 in the reduced config
+
+
+@pytest.mark.parametrize("task", ["mlm", "mrc", "sap"])
+def test_pretrain_losses_and_gradients_match_reference(task):
+    from gridmm_amd.synthetic import batch_to
+    fx = load_golden("pretrain_reduced.npz")
+    model = _model(fx)
+    batch = batch_to(gen_golden.pretrain_batch(task), "cuda")
+    loss = model(batch, task=task, compute_loss=True)
+    want = fx["loss_" + task]
+    got = loss.detach().cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-3 * max(1.0, np.abs(want).max()), (got, want)
+
+    loss.mean().backward()
+    names = json.loads(str(fx["grad_names_" + task]))
+    params = dict(model.named_parameters())
+    with_grad = [k for k, p in params.items() if p.grad is not None]
+    assert sorted(with_grad) == sorted(names), set(with_grad) ^ set(names)     # same grad-less parameters
+    norms, samples = fx["grad_norms_" + task], fx["grad_samples_" + task]
+    scale = float(norms.max())
+    o, errs, got_all, ref_all = 0, [], [], []
+    for k, n_ref in zip(names, norms):
+        g = params[k].grad.detach().float().reshape(-1).cpu()
+        idx = gen_golden.grad_sample_index(k, g.numel())
+        ref = samples[o:o + len(idx)]
+        o += len(idx)
+        got_all.append(g[torch.from_numpy(idx)].numpy())
+        ref_all.append(ref)
+        denom = max(float(np.abs(ref).max()), 1e-3 * scale / np.sqrt(max(g.numel(), 1)), 1e-12)
+        e = float(np.abs(g[torch.from_numpy(idx)].numpy() - ref).max()) / denom
+        en = abs(float(g.norm()) - float(n_ref)) / max(float(n_ref), 1e-3 * scale)
+        errs += [(e, k), (en, k + " [norm]")]
+    errs.sort(reverse=True)
+    assert errs[0][0] < (1e-1 if task == "mrc" else 2e-2), errs[:12]
+    a, b = np.concatenate(got_all).astype(np.float64), np.concatenate(ref_all).astype(np.float64)
+    cos = float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+    assert cos > 0.999, cos
