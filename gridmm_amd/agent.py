@@ -356,9 +356,13 @@ class GMapNavAgent:
 
     def make_optimizer(self):
         """agent_base.py:122-139: one optimizer over all vln_bert parameters at args.lr."""
-        opt = {"rms": torch.optim.RMSprop, "adam": torch.optim.Adam, "adamW": torch.optim.AdamW,
-               "sgd": torch.optim.SGD}[self.args.optim]
-        self.vln_bert_optimizer = opt(self.vln_bert.parameters(), lr=self.args.lr)
+        if self.args.optim == "adamW":        # scripts/run_r2r.sh; torch.optim.AdamW semantics on the fused HIP step
+            from .optim import AdamW
+            self.vln_bert_optimizer = AdamW(list(self.vln_bert.parameters()), lr=self.args.lr, betas=(0.9, 0.999),
+                                            eps=1e-8, weight_decay=0.01, decay_first=True)
+        else:
+            opt = {"rms": torch.optim.RMSprop, "adam": torch.optim.Adam, "sgd": torch.optim.SGD}[self.args.optim]
+            self.vln_bert_optimizer = opt(self.vln_bert.parameters(), lr=self.args.lr)
         from .dist import GradientReducer
         self.grad_reducer = GradientReducer(self.vln_bert.parameters())
         return self.vln_bert_optimizer
@@ -388,7 +392,10 @@ class GMapNavAgent:
                                           "GridMM scripts)" % self.args.train_alg)
             self.loss.backward()
             self.grad_reducer.reduce()
-            torch.nn.utils.clip_grad_norm_(self.vln_bert.parameters(), 40.0)
-            self.vln_bert_optimizer.step()
+            if self.args.optim == "adamW":
+                self.vln_bert_optimizer.step(max_grad_norm=40.0)          # clip_grad_norm_(40) fused into the step
+            else:
+                torch.nn.utils.clip_grad_norm_(self.vln_bert.parameters(), 40.0)
+                self.vln_bert_optimizer.step()
             self.losses.append(float(self.loss.detach()))
         return self.losses

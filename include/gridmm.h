@@ -268,6 +268,18 @@ int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32
                               const float* relevance, const float* text, const float* dcells, float* dtext,
                               float* da_ws, int32_t* amax_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
 
+/* Optimizer step: gradient-norm clipping + AdamW without a host round trip.
+ * gridmm_grad_sumsq adds sum(g^2) of one gradient tensor into *acc (zero it first; call once per tensor).
+ * gridmm_adamw_step updates one parameter tensor in place; with sumsq != NULL the gradient is first scaled by
+ * min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (torch.nn.utils.clip_grad_norm_).  step_size = lr * sqrt(1-b2^t)/(1-b1^t)
+ * is computed by the caller.  decay_first = 0: pretrain_src/optim/adamw.py:56-112 (decay after the update);
+ * decay_first = 1: torch.optim.AdamW order (fine-tune, agent_base.py:131).  dtype 0 = fp32, 1 = fp16 (the
+ * reference's fp16 grid_proj keeps fp16 optimizer state). */
+int gridmm_grad_sumsq(const void* g, int64_t n, int dtype, float* acc, gridmm_stream_t stream);
+int gridmm_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, int dtype, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float step_size, int decay_first,
+                      const float* sumsq, float max_norm, gridmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,3 +125,28 @@ def test_gradient_reducer_matches_single_process_mean_world2():
                 assert got is None, k                      # same set of grad-less parameters
             else:
                 assert got is not None and torch.allclose(got, p.grad, atol=1e-6), k
+
+
+def _task_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gridmm_amd.pretrain_loop import TaskSampler
+    s = TaskSampler(("mlm", "mrc", "sap"), (1, 1, 1), device="cpu", seed=100 + rank)   # different local seeds
+    q.put((rank, [s.next_task() for _ in range(12)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_task_sampler_all_ranks_train_the_same_task_world2():
+    """data/loader.py:50-58: rank 0's multinomial draw is broadcast (the 1-int exchange of every step)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_task_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert outs[0] == outs[1] and len(set(outs[0])) > 1
