@@ -140,6 +140,17 @@ def roofline_leg(step, args, geom, L=80):
         gbs = byts / (summ["grid_aggregate"]["ms"] / summ["grid_aggregate"]["calls"] * 1e-3) / 1e9
         out["grid_aggregate"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": byts}
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_traffic.sh:
+    # FETCH_SIZE and WRITE_SIZE in separate runs, (2*FETCH + WRITE) * 1024 with the gfx950 read-side correction)
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_hbm_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        c = t.get("config", {})
+        if (int(c.get("batch", -1)), c.get("shape"), int(c.get("mem_steps", -1))) == (args.batch, args.shape, args.mem_steps):
+            for k in ("linear", "grid_aggregate"):
+                if k in out and k in t["kernels"]:
+                    out[k]["traffic"] = t["kernels"][k]["hbm_bytes_per_launch"]
+                    out[k]["traffic_source"] = "profiles/r1_hbm_traffic.json"
     dom = max(("linear", "grid_aggregate", "attention"), key=lambda k: summ.get(k, {"ms": 0})["ms"])
     out["dominant"] = dom
     return out
