@@ -420,6 +420,21 @@ class GlocalTextPathNavCMT(nn.Module):
             vp_nav_masks, vp_obj_masks, vp_cand_vpids, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None,
             fusion_maps=None):
         dev = txt_embeds.device
+        G, V = gmap_masks.shape[1], vp_masks.shape[1]
+        gmap_m = self._u8(gmap_masks)
+        gmap_embeds, vp_embeds, map_embeds = self._encode_navigation_infer(
+            txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks, vp_img_embeds, vp_pos_fts,
+            vp_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory)
+        return self._heads_infer(gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, gmap_vpids,
+                                 vp_nav_masks, vp_obj_masks, vp_cand_vpids, fusion_maps, G, V, dev)
+
+    @torch.no_grad()
+    def _encode_navigation_infer(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
+                                 vp_img_embeds, vp_pos_fts, vp_masks, grid_fts, grid_map, gridmap_pos_fts,
+                                 grid_memory=None):
+        """vilmodel.py:788-856: aggregation, grid encoder, grid/text layer, local encoder -> (gmap_embeds (B,G,H),
+        vp_embeds (B,V,H), map_embeds (B,196+G,H)).  Shared with the VLN-CE twin (gridmap/vilmodel.py:710-776)."""
+        dev = txt_embeds.device
         B, L, H = txt_embeds.shape
         G, V = gmap_masks.shape[1], vp_masks.shape[1]
         txt_embeds = txt_embeds.float().contiguous()
@@ -484,9 +499,12 @@ class GlocalTextPathNavCMT(nn.Module):
         for i, layer in enumerate(xl):
             qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks, kv=(kv_all, 2 * H * i))
         q = qa.f32
-        gmap_embeds, vp_embeds = q[:, :G], q[:, G:]
+        return q[:, :G], q[:, G:], map_embeds
 
-        # ---- heads + fusion (vilmodel.py:859-907)
+    @torch.no_grad()
+    def _heads_infer(self, gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, gmap_vpids, vp_nav_masks,
+                     vp_obj_masks, vp_cand_vpids, fusion_maps, G, V, dev):
+        """vilmodel.py:859-907."""
         fuse_raw = None
         if self.sap_fuse_linear is not None:
             fuse_raw = self._cls(self.sap_fuse_linear, "fuse", torch.cat([gmap_embeds[:, 0], vp_embeds[:, 0]], 1))

@@ -181,18 +181,11 @@ def fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited_masks
     return global_logits, local_logits, grid_logits, global_logits + add
 
 
-def forward_navigation(model, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
-                       gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
-                       vp_nav_masks, vp_obj_masks, vp_cand_vpids, grid_fts, grid_map, gridmap_pos_fts,
-                       grid_memory=None, fusion_maps=None):
-    """:782-918."""
-    dev = txt_embeds.device
-    B, L, H = txt_embeds.shape
-    G, V = gmap_masks.shape[1], vp_masks.shape[1]
-    txt_embeds = txt_embeds.float()
-    txt_masks, gmap_masks, vp_masks = txt_masks.bool(), gmap_masks.bool(), vp_masks.bool()
-
-    cells, cell_masks = grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memory)
+def encode_navigation(model, txt_embeds, txt_masks, cells, cell_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts,
+                      gmap_masks, vp_img_embeds, vp_pos_fts, vp_masks):
+    """:826-856 -> (gmap_embeds (B,G,H), vp_embeds (B,V,H), map_embeds (B,196+G,H)); shared with the VLN-CE twin."""
+    H = txt_embeds.shape[-1]
+    G = gmap_masks.shape[1]
     ge, le = model.global_encoder, model.local_encoder
     gmap_embeds = gmap_img_embeds.float() + ge.gmap_step_embeddings(gmap_step_ids) + ag.layer_norm(
         ag.linear(gmap_pos_fts.float(), ge.gmap_pos_embeddings[0].weight, ge.gmap_pos_embeddings[0].bias),
@@ -217,7 +210,22 @@ def forward_navigation(model, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_
     kv_all = _cat_linear(kv_embeds, [m for l in xl for m in (l.visual_attention.att.key, l.visual_attention.att.value)])
     for i, layer in enumerate(xl):
         q = x_layer(model, layer, kv_all, kv_masks, q, q_masks, kv_col=2 * H * i)
-    gmap_out, vp_out = q[:, :G], q[:, G:]
+    return q[:, :G], q[:, G:], map_embeds
+
+
+def forward_navigation(model, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
+                       gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
+                       vp_nav_masks, vp_obj_masks, vp_cand_vpids, grid_fts, grid_map, gridmap_pos_fts,
+                       grid_memory=None, fusion_maps=None):
+    """:782-918."""
+    dev = txt_embeds.device
+    G, V = gmap_masks.shape[1], vp_masks.shape[1]
+    txt_embeds = txt_embeds.float()
+    txt_masks, gmap_masks, vp_masks = txt_masks.bool(), gmap_masks.bool(), vp_masks.bool()
+    cells, cell_masks = grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memory)
+    gmap_out, vp_out, map_embeds = encode_navigation(model, txt_embeds, txt_masks, cells, cell_masks, gmap_img_embeds,
+                                                     gmap_step_ids, gmap_pos_fts, gmap_masks, vp_img_embeds, vp_pos_fts,
+                                                     vp_masks)
 
     fuse_raw = None
     if model.sap_fuse_linear is not None:

@@ -283,6 +283,32 @@ def gen_rollout():
     print("rollout_reduced ok: steps=%d min argmax margin=%.3e paths=%s" % (len(agent.trace), margin, out["traj"][:120]))
 
 
+VLNCE_NAV_CAND_LENS = [4, 3, 4]
+
+
+def vlnce_nav_tuple(batch, cand_lens=VLNCE_NAV_CAND_LENS):
+    """The positional `navigation` batch of the VLN-CE model (gridmap/vilmodel.py:710-713, 815-818) from the dict form."""
+    return (batch["txt_embeds"], batch["txt_masks"], batch["gmap_img_embeds"], batch["gmap_step_ids"],
+            batch["gmap_pos_fts"], batch["gmap_masks"], batch["vp_img_embeds"], batch["vp_pos_fts"], batch["vp_masks"],
+            batch["vp_nav_masks"], batch["grid_fts"], batch["grid_map"], batch["gridmap_pos_fts"], list(cand_lens))
+
+
+def gen_nav_vlnce():
+    """VLN-CE GlocalTextPathNavCMT.forward('navigation', tuple) (gridmap/vilmodel.py:710-800): fused logits only."""
+    torch.set_num_threads(1)
+    model = R.build_ref_vlnce_model(seed=7, **REDUCED)
+    batch = _nav_inputs(seed=321, B=3, Ns=[200, 150, 90], L=12, G_=7, V1=9, n_cand=3, n_visited=2)
+    with torch.no_grad():
+        fused = model("navigation", vlnce_nav_tuple(batch))
+    out = {"versions": _versions(), "weight_seed": 7, "cfg": json.dumps(REDUCED),
+           "param_names": json.dumps([k for k in model.state_dict()]),
+           "cand_lens": np.array(VLNCE_NAV_CAND_LENS)}
+    _pack_batch(out, batch)
+    out["out_fused_logits"] = fused.numpy()
+    np.savez_compressed(os.path.join(OUT, "nav_vlnce_reduced.npz"), **out)
+    print("nav_vlnce_reduced.npz ok", tuple(fused.shape))
+
+
 PRETRAIN_SEEDS = {"mlm": 11, "mrc": 12, "sap": 13}
 GRAD_SAMPLES = 48
 
@@ -332,7 +358,7 @@ def gen_pretrain():
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce"]
     if "rollout" in which: gen_rollout()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
@@ -341,3 +367,4 @@ if __name__ == "__main__":
     if "textpano" in which: gen_text_pano()
     if "full" in which: gen_nav_full()
     if "pretrain" in which: gen_pretrain()
+    if "navvlnce" in which: gen_nav_vlnce()

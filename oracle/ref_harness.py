@@ -351,6 +351,41 @@ def import_vlnce_policy():
     return mod
 
 
+_VLNCE_VIL = None
+
+
+def import_vlnce_vilmodel():
+    """Import VLN_CE/vlnce_baselines/models/gridmap/vilmodel.py as a standalone package (`_ref_vlnce_gridmap`), with
+    `timm` stubbed and the two vision towers (CLIP, ViT: row f4, not on this path) replaced by empty modules."""
+    global _VLNCE_VIL
+    if _VLNCE_VIL is not None:
+        return _VLNCE_VIL
+    import importlib
+    import transformers  # noqa: F401  (must be imported before the timm stand-in exists: it probes find_spec("timm"))
+    from transformers import BertPreTrainedModel  # noqa: F401
+    install_shims()
+    for name in ("timm", "timm.data", "timm.data.transforms_factory"):
+        if name not in sys.modules:
+            sys.modules[name] = _AnyModule(name)
+    pkg = types.ModuleType("_ref_vlnce_gridmap")
+    pkg.__path__ = [os.path.join(REF_ROOT, "VLN_CE", "vlnce_baselines", "models", "gridmap")]
+    sys.modules["_ref_vlnce_gridmap"] = pkg
+    vil = importlib.import_module("_ref_vlnce_gridmap.vilmodel")
+    vil.BertPreTrainedModel.init_weights = lambda self: None
+    vil.CLIP = lambda **kw: torch.nn.Identity()
+    vil.timm = types.SimpleNamespace(create_model=lambda *a, **kw: torch.nn.Identity())
+    _VLNCE_VIL = vil
+    return vil
+
+
+def build_ref_vlnce_model(seed=0, **cfg_over):
+    vil = import_vlnce_vilmodel()
+    cfg = make_config(**cfg_over)
+    m = vil.GlocalTextPathNavCMT(cfg).eval()
+    m.load_state_dict(det_state_dict(m, seed))
+    return m
+
+
 class RefVlnceGridEnv:
     """Drives the reference VLN-CE GridMap.getGlobalMap (Policy_ViewSelection_GridMap.py:689-825)."""
 

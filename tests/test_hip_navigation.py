@@ -148,3 +148,32 @@ def test_grid_memory_handle_equals_list_form():
         a, b = o1[k], o2[k]
         f = torch.isfinite(a)
         assert torch.equal(f, torch.isfinite(b)) and (a[f] - b[f]).abs().max() < 1e-5
+
+
+def _vlnce_model(fx):
+    from gridmm_amd.vilmodel_ce import GlocalTextPathNavCMT, default_config
+    from oracle.ref_harness import det_tensor
+    m = GlocalTextPathNavCMT(default_config(**json.loads(str(fx["cfg"]))))
+    names = json.loads(str(fx["param_names"]))
+    assert sorted(names) == sorted(m.state_dict().keys())            # the VLN-CE module tree (no sprel_linear)
+    m.load_state_dict({k: det_tensor(k, v.shape, int(fx["weight_seed"])) for k, v in m.state_dict().items()})
+    return m.cuda().eval()
+
+
+def test_vlnce_navigation_matches_reference_golden():
+    """VLN-CE twin (gridmap/vilmodel.py:710-800): tuple batch in, fused_logits only out."""
+    from oracle import gen_golden
+    fx = load_golden("nav_vlnce_reduced.npz")
+    model = _vlnce_model(fx)
+    batch = _to_dev(golden_nav_batch(fx))
+    tup = gen_golden.vlnce_nav_tuple(batch, fx["cand_lens"].tolist())
+    with torch.no_grad():
+        fused = model("navigation", tup)
+    _cmp(fused, fx["out_fused_logits"], LOGIT_TOL)
+    model.differentiable = True                                       # the autograd path gives the same logits
+    fused2 = model("navigation", tup)
+    assert fused2.requires_grad
+    _cmp(fused2, fx["out_fused_logits"], LOGIT_TOL)
+    m = torch.isfinite(fused2)
+    fused2[m].sum().backward()
+    assert model.grid_proj.weight.grad is not None and model.grid_sap_head.net[0].weight.grad is None

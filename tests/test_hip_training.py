@@ -168,7 +168,7 @@ def test_one_optimizer_step_changes_logits_and_repacks_weights():
         loss = _nav_loss(model("navigation", batch), {"g": g.cuda(), "l": l.cuda()})
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[2] < losses[0], losses
     with torch.no_grad():                       # the inference path sees the updated weights too
         a = model("navigation", batch)["fused_logits"]
