@@ -251,9 +251,21 @@ __global__ __launch_bounds__(256) void attention_planes_kernel(
   __shared__ float s_m[4][MQ], s_l[4][MQ];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qt0 = (KSPLIT == 4 ? blockIdx.x : blockIdx.x * 4 + wave) * NQ;   // first query tile of this wave
-  if (KSPLIT == 1 && qt0 * 16 >= Sq) return;
   const int h = blockIdx.y, b = blockIdx.z;
   const int j = lane & 15, g = lane >> 4;
+  // Key-validity bits of the whole row, one 32-bit word per 32-key tile (Sk <= 512), built once per wave from
+  // independent byte loads: inside the key loop the mask is ALU work, not 8 dependent global loads per tile.
+  __shared__ unsigned s_mw[4][16];
+  {
+    const uint8_t* mrow = kmask ? kmask + (size_t)b * mask_bs : nullptr;
+    for (int i = 0; i < (Sk + 63) >> 6; ++i) {
+      const int k = i * 64 + lane;
+      const unsigned long long bal = __ballot((k < Sk) && (!mrow || mrow[k]));
+      if (lane == 0) { s_mw[wave][2 * i] = (unsigned)bal; s_mw[wave][2 * i + 1] = (unsigned)(bal >> 32); }
+    }
+  }
+  __syncthreads();
+  if (KSPLIT == 1 && qt0 * 16 >= Sq) return;
 
   // Q^T as the B operand: lane (query j, k-chunk g) holds head dims 32ks + 8g .. +8
   bf16x8_t qh[NQ][2], ql[NQ][2];
@@ -271,36 +283,37 @@ __global__ __launch_bounds__(256) void attention_planes_kernel(
 #pragma unroll
     for (int n = 0; n < 4; ++n) o[t][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
-  const uint8_t* mb = kmask ? kmask + (size_t)b * mask_bs : nullptr;
   const unsigned short* Kbh = Kh + b * k_bs + h * 64 + 8 * g;
   const unsigned short* Kbl = Kl + b * k_bs + h * 64 + 8 * g;
   const size_t tbase = ((size_t)b * heads + h) * (Skp / 32) * 64 * 32 + (size_t)(4 * j) * 32 + 8 * g;
 
-  for (int key0 = (KSPLIT == 4 ? wave * 32 : 0); key0 < Sk; key0 += 32 * KSPLIT) {
-    if (mb) {   // skip 32-key tiles without any valid key (wave-uniform)
-      const int k1 = key0 + j, k2 = key0 + 16 + j;
-      if (!__any(((k1 < Sk) && mb[k1]) || ((k2 < Sk) && mb[k2]))) continue;
-    }
-    bf16x8_t kh[2][2], kl[2][2];
+  // K / V fragments of one 32-key tile.  Two register sets ping-pong: the next (unmasked) tile is fetched while the
+  // current one is in the matrix pipe -- at NQ = 4 the kernel runs one wave per SIMD, so nothing else hides the loads.
+  struct KV { bf16x8_t kh[2][2], kl[2][2], vh[4], vl[4]; };
+  auto load_tile = [&](int key0, KV& t) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const size_t ko = (size_t)min(key0 + 16 * u + j, Sk - 1) * k_rs;
-      kh[u][0] = ld8(Kbh + ko); kh[u][1] = ld8(Kbh + ko + 32);
-      kl[u][0] = ld8(Kbl + ko); kl[u][1] = ld8(Kbl + ko + 32);
+      t.kh[u][0] = ld8(Kbh + ko); t.kh[u][1] = ld8(Kbh + ko + 32);
+      t.kl[u][0] = ld8(Kbl + ko); t.kl[u][1] = ld8(Kbl + ko + 32);
     }
-    bf16x8_t vh[4], vl[4];
     const size_t to = tbase + (size_t)(key0 >> 5) * 64 * 32;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      vh[n] = ld8(Th + to + n * 32);
-      vl[n] = ld8(Tl + to + n * 32);
+      t.vh[n] = ld8(Th + to + n * 32);
+      t.vl[n] = ld8(Tl + to + n * 32);
     }
+  };
+  auto next_tile = [&](int key0) -> int {   // first 32-key tile >= key0 (this wave's stride) with a valid key
+    while (key0 < Sk && s_mw[wave][key0 >> 5] == 0u) key0 += 32 * KSPLIT;
+    return key0;
+  };
+  auto compute_tile = [&](int key0, const KV& kv) {
+    const auto& kh = kv.kh; const auto& kl = kv.kl; const auto& vh = kv.vh; const auto& vl = kv.vl;
     bool valid[8];
+    const unsigned mword = s_mw[wave][key0 >> 5];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int kk = key0 + 16 * (e >> 2) + 4 * g + (e & 3);
-      valid[e] = (kk < Sk) && (!mb || mb[kk]);
-    }
+    for (int e = 0; e < 8; ++e) valid[e] = (mword >> (16 * (e >> 2) + 4 * g + (e & 3))) & 1u;
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       if ((qt0 + t) * 16 >= Sq) continue;          // wave-uniform
@@ -355,6 +368,19 @@ __global__ __launch_bounds__(256) void attention_planes_kernel(
         o[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pah, vh[n], o[t][n], 0, 0, 0);
       }
     }
+  };
+
+  KV ta, tb;
+  int key0 = next_tile(KSPLIT == 4 ? wave * 32 : 0);
+  if (key0 < Sk) load_tile(key0, ta);
+  while (key0 < Sk) {
+    int key1 = next_tile(key0 + 32 * KSPLIT);
+    if (key1 < Sk) load_tile(key1, tb);
+    compute_tile(key0, ta);
+    if (key1 >= Sk) break;
+    key0 = next_tile(key1 + 32 * KSPLIT);
+    if (key0 < Sk) load_tile(key0, ta);
+    compute_tile(key1, tb);
   }
 
   auto store4 = [&](int q, int dcol, const float (&x)[4]) {
@@ -435,7 +461,7 @@ extern "C" int gridmm_attention_planes(const void* Q_hi, const void* Q_lo, int64
                                        int Skp, const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs, int o_rs,
                                        void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq, int Sk,
                                        float scale, gridmm_stream_t stream) {
-  if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || Skp < Sk || Skp % 32) return GRIDMM_EINVAL;
+  if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || Skp < Sk || Skp % 32 || Sk > 512) return GRIDMM_EINVAL;   // mask words: 16 x 32 keys
   if ((q_rs | k_rs) & 7 || (q_bs | k_bs) & 7) return GRIDMM_EINVAL;
   if ((!O && !O_hi) || (O_hi && (!O_lo || (p_rs & 3) || (p_bs & 3))) || (O && ((o_rs & 3) || (o_bs & 3))))
     return GRIDMM_EINVAL;

@@ -327,6 +327,14 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
     case 14: return launch<128, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
     case 15: return launch<128, 128, 32, 32, 2, 32>(GRIDMM_ARGS);
     case 16: return launch<256, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
+    case 17: return launch<64, 64, 32, 32, 4, 32>(GRIDMM_ARGS);
+    case 18: return launch<64, 64, 32, 32, 3, 32>(GRIDMM_ARGS);
+    case 19: return launch<64, 32, 32, 16, 4, 32>(GRIDMM_ARGS);
+    case 20: return launch<64, 64, 16, 32, 4, 32>(GRIDMM_ARGS);
+    case 21: return launch<128, 64, 32, 32, 4, 32>(GRIDMM_ARGS);
+    case 22: return launch<256, 128, 64, 64, 3, 32>(GRIDMM_ARGS);
+    case 23: return launch<256, 128, 64, 32, 3, 32>(GRIDMM_ARGS);
+    case 24: return launch<128, 256, 64, 64, 3, 32>(GRIDMM_ARGS);
     // ablations (tools/bench_gemm.py): 1xx = no MFMA (DMA + LDS reads only), 2xx = no DMA after the prologue
     case 108: return launch<64, 64, 32, 32, 2, 64, 1>(GRIDMM_ARGS);
     case 208: return launch<64, 64, 32, 32, 2, 64, 2>(GRIDMM_ARGS);
