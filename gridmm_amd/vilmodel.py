@@ -366,14 +366,19 @@ class GlocalTextPathNavCMT(nn.Module):
     @torch.no_grad()
     def _forward_panorama_infer(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
         ie = self.img_embeddings
-        if obj_img_fts is not None:
-            raise NotImplementedError("object panorama tokens (REVERIE/SOON) are outside this round's scope")
-        x = self._ln(ie.img_layer_norm, ops.linear(view_img_fts.float().contiguous(), self._lin(ie.img_linear, "img")))
+        x = self._ln(ie.img_layer_norm, ops.linear(view_img_fts.float().contiguous(), self._lin(ie.img_linear, "img"))).f32
+        lens = view_lens
+        if obj_img_fts is not None:     # [views[:view_len] | objects[:obj_len]] per panorama (vilmodel.py:745-764)
+            if ie.obj_linear is None:
+                o = self._ln(ie.img_layer_norm, ops.linear(obj_img_fts.float().contiguous(), self._lin(ie.img_linear, "img")))
+            else:
+                o = self._ln(ie.obj_layer_norm, ops.linear(obj_img_fts.float().contiguous(), self._lin(ie.obj_linear, "obj")))
+            x = vilmodel_train.interleave_view_obj(x, o.f32, view_lens, obj_lens)
+            lens = view_lens + obj_lens
         extra = (ie.nav_type_embedding.weight[nav_types] + self.embeddings.token_type_embeddings.weight[1]).contiguous()
         y = self._ln(ie.loc_layer_norm, ops.linear(loc_fts.float().contiguous(), self._lin(ie.loc_linear, "loc")),
                      add1=extra)
         x = self._ln(ie.layer_norm, x, residual=y.f32).f32
-        lens = view_lens
         masks = torch.arange(int(lens.max()), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
         if ie.pano_encoder is not None:
             x = self._pre_ln_encoder(ie.pano_encoder, "pano", x, self._u8(masks)).f32

@@ -118,16 +118,37 @@ def forward_text(model, txt_ids, txt_masks):
     return x
 
 
+def interleave_view_obj(view_embeds, obj_embeds, view_lens, obj_lens):
+    """pad_tensors_wgrad([cat(view[:vl], obj[:ol])]) (:754-763) as two gathers + a select: token p of panorama b is
+    view p if p < vl_b, object p - vl_b if p < vl_b + ol_b, else zero padding.  Data movement only (differentiable)."""
+    B, Vv, H = view_embeds.shape
+    Vo = obj_embeds.shape[1]
+    vl, ol = view_lens.long().unsqueeze(1), obj_lens.long().unsqueeze(1)
+    P = int((vl + ol).max())
+    p = torch.arange(P, device=view_embeds.device).unsqueeze(0).expand(B, P)
+    from_view, from_obj = p < vl, (p >= vl) & (p < vl + ol)
+    vg = view_embeds.gather(1, p.clamp(max=Vv - 1).unsqueeze(-1).expand(B, P, H))
+    og = obj_embeds.gather(1, (p - vl).clamp(0, max(Vo - 1, 0)).unsqueeze(-1).expand(B, P, H))
+    zero = torch.zeros((), dtype=view_embeds.dtype, device=view_embeds.device)
+    return torch.where(from_view.unsqueeze(-1), vg, torch.where(from_obj.unsqueeze(-1), og, zero)).contiguous()
+
+
 def forward_panorama(model, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
-    """:736-780 (view tokens; object tokens as in the inference path are out of scope)."""
-    if obj_img_fts is not None:
-        raise NotImplementedError("object panorama tokens (REVERIE/SOON) are outside this round's scope")
+    """:736-780."""
     ie = model.img_embeddings
     x = ag.layer_norm(ag.linear(view_img_fts.float(), ie.img_linear.weight, ie.img_linear.bias), ie.img_layer_norm)
+    lens = view_lens
+    if obj_img_fts is not None:
+        if ie.obj_linear is None:
+            o = ag.layer_norm(ag.linear(obj_img_fts.float(), ie.img_linear.weight, ie.img_linear.bias), ie.img_layer_norm)
+        else:
+            o = ag.layer_norm(ag.linear(obj_img_fts.float(), ie.obj_linear.weight, ie.obj_linear.bias), ie.obj_layer_norm)
+        x = interleave_view_obj(x, o, view_lens, obj_lens)
+        lens = view_lens + obj_lens
     y = ag.layer_norm(ag.linear(loc_fts.float(), ie.loc_linear.weight, ie.loc_linear.bias), ie.loc_layer_norm)
     x = x + y + ie.nav_type_embedding(nav_types) + model.embeddings.token_type_embeddings.weight[1]
     x = _drop(model, ag.layer_norm(x, ie.layer_norm))
-    masks = torch.arange(int(view_lens.max()), device=view_lens.device).unsqueeze(0) < view_lens.unsqueeze(1)
+    masks = torch.arange(int(lens.max()), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
     if ie.pano_encoder is not None:
         x = pre_ln_encoder(model, ie.pano_encoder, x, masks)
     return x, masks

@@ -205,6 +205,39 @@ def gen_text_pano():
     print("text_pano_reduced ok")
 
 
+def gen_pano_obj():
+    """forward('panorama') with object tokens (vilmodel.py:745-764), for both embeddings of the objects:
+    obj_feat_size == image_feat_size (shared img_linear, REVERIE) and != (own obj_linear / obj_layer_norm)."""
+    torch.set_num_threads(1)
+    out = {"versions": _versions(), "weight_seed": 7}
+    rs = np.random.RandomState(15)
+    B = 3
+    view_lens, obj_lens = np.array([36, 33, 36], np.int64), np.array([5, 0, 9], np.int64)
+    P = int((view_lens + obj_lens).max())
+    view = rs.standard_normal((B, 36, 768)).astype(np.float32)
+    loc = rs.uniform(-1, 1, size=(B, P, 7)).astype(np.float32)
+    nav_types = np.zeros((B, P), np.int64)
+    for b in range(B):
+        nav_types[b, :3] = 1
+        nav_types[b, view_lens[b]:view_lens[b] + obj_lens[b]] = 2
+    out.update(in_view_img_fts=view, in_loc_fts=loc, in_nav_types=nav_types, in_view_lens=view_lens, in_obj_lens=obj_lens)
+    for tag, osz in (("shared", 768), ("own", 64)):
+        over = dict(REDUCED, obj_feat_size=osz)
+        model = R.build_ref_model(seed=7, **over)
+        obj = rs.standard_normal((B, int(obj_lens.max()), osz)).astype(np.float32)
+        with torch.no_grad():
+            pano, pmask = model("panorama", {
+                "view_img_fts": torch.from_numpy(view), "obj_img_fts": torch.from_numpy(obj),
+                "loc_fts": torch.from_numpy(loc), "nav_types": torch.from_numpy(nav_types),
+                "view_lens": torch.from_numpy(view_lens), "obj_lens": torch.from_numpy(obj_lens)})
+        out["cfg_" + tag] = json.dumps(over)
+        out["in_obj_img_fts_" + tag] = obj
+        out["out_pano_embeds_" + tag] = pano.numpy()
+        out["out_pano_masks_" + tag] = pmask.numpy()
+    np.savez_compressed(os.path.join(OUT, "pano_obj_reduced.npz"), **out)
+    print("pano_obj_reduced ok", pano.shape)
+
+
 def gen_fill_gridmap_vlnce():
     """VLN-CE twin: GridMap.getGlobalMap (Policy_ViewSelection_GridMap.py:689-825), R2R-CE and RxR-CE constants."""
     out = {"versions": _versions()}
@@ -358,7 +391,7 @@ def gen_pretrain():
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj"]
     if "rollout" in which: gen_rollout()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
@@ -368,3 +401,4 @@ if __name__ == "__main__":
     if "full" in which: gen_nav_full()
     if "pretrain" in which: gen_pretrain()
     if "navvlnce" in which: gen_nav_vlnce()
+    if "panoobj" in which: gen_pano_obj()

@@ -177,3 +177,27 @@ def test_vlnce_navigation_matches_reference_golden():
     m = torch.isfinite(fused2)
     fused2[m].sum().backward()
     assert model.grid_proj.weight.grad is not None and model.grid_sap_head.net[0].weight.grad is None
+
+
+@pytest.mark.parametrize("tag", ["shared", "own"])
+def test_panorama_with_object_tokens_matches_reference_golden(tag):
+    """vilmodel.py:745-764: [views | objects] per panorama, objects through img_linear (REVERIE) or obj_linear."""
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    from oracle.ref_harness import det_tensor
+    fx = load_golden("pano_obj_reduced.npz")
+    m = GlocalTextPathNavCMT(default_config(**json.loads(str(fx["cfg_" + tag])))).cuda().eval()
+    m.load_state_dict({k: det_tensor(k, v.shape, int(fx["weight_seed"])) for k, v in m.state_dict().items()})
+    d = lambda k: torch.from_numpy(fx[k]).cuda()
+    batch = {"view_img_fts": d("in_view_img_fts"), "obj_img_fts": d("in_obj_img_fts_" + tag), "loc_fts": d("in_loc_fts"),
+             "nav_types": d("in_nav_types"), "view_lens": d("in_view_lens"), "obj_lens": d("in_obj_lens")}
+    want, wmask = fx["out_pano_embeds_" + tag], fx["out_pano_masks_" + tag]
+    with torch.no_grad():
+        pano, pm = m("panorama", batch)
+    assert np.array_equal(pm.cpu().numpy(), wmask)
+    assert np.abs(pano.cpu().numpy() - want)[wmask].max() < EMBED_TOL
+    m.differentiable = True
+    pano2, pm2 = m("panorama", batch)
+    assert pano2.requires_grad and np.abs(pano2.detach().cpu().numpy() - want)[wmask].max() < EMBED_TOL
+    (pano2 * pm2.unsqueeze(-1)).sum().backward()
+    g = m.img_embeddings.obj_linear.weight.grad if tag == "own" else m.img_embeddings.img_linear.weight.grad
+    assert g is not None and torch.isfinite(g).all()
