@@ -2,7 +2,7 @@
 
 Mirrors (relative to /root/reference/pretrain_src/model):
   GlocalTextPathCMTPreTraining.forward(batch, task, compute_loss)   pretrain_cmt.py:71-129
-      forward_mlm :131-153   forward_mrc :161-213   forward_sap :215-290   (forward_og needs object tokens: out of scope)
+      forward_mlm :131-153   forward_mrc :161-213   forward_sap :215-290   forward_og :292-321
   GlocalTextPathCMT.forward / forward_mlm                            vilmodel.py:668-766 / :767-856
   ImageEmbeddings.forward :483-532, GlobalMapEncoder._aggregate_gmap_features / gmap_input_embedding :569-620,
   LocalVPEncoder.vp_input_embedding :545-560, BertOnlyMLMHead :262-303
@@ -82,6 +82,15 @@ def _seq_masks(lens, max_len=None):
     return torch.arange(max_len, device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
 
 
+def _gather_span(x, start, length, max_len):
+    """pad_tensors_wgrad([x_b[start_b : start_b + length_b]]) -> (B, max_len, H), zero padded (data movement)."""
+    B, S, H = x.shape
+    p = torch.arange(max_len, device=x.device).unsqueeze(0).expand(B, max_len)
+    idx = (start.unsqueeze(1) + p).clamp(max=S - 1)
+    keep = p < length.unsqueeze(1)
+    return x.gather(1, idx.unsqueeze(-1).expand(B, max_len, H)) * keep.unsqueeze(-1), keep
+
+
 class GlocalTextPathCMTPreTraining(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -94,11 +103,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             self.mlm_head = BertOnlyMLMHead(c)
         if "mrc" in tasks:
             self.image_classifier = RegionClassification(H, c.image_prob_size)
-            self.obj_classifier = None
+            self.obj_classifier = (RegionClassification(H, c.obj_prob_size)
+                                   if c.obj_prob_size > 0 and c.obj_prob_size != c.image_prob_size else None)
         if "sap" in tasks:
             self.local_sap_head = V.ClsPrediction(H)
             self.grid_sap_head = V.ClsPrediction(H)
             self.sap_fuse_linear = V.ClsPrediction(H, input_size=H * 2) if c.glocal_fuse else None
+        if "og" in tasks:
+            self.og_head = V.ClsPrediction(H)
         for m in self.modules():
             if isinstance(m, (nn.Linear, nn.Embedding)) and m.weight.dtype == torch.float32:
                 nn.init.normal_(m.weight, std=0.02)
@@ -131,10 +143,13 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                                           proj_bias=b.grid_proj.bias.float())
 
         # trajectory embedding: every step's panorama through the pano encoder (ImageEmbeddings.forward)
-        traj, traj_masks = VT.forward_panorama(b, batch["traj_view_img_fts"], None, batch["traj_loc_fts"],
-                                               batch["traj_nav_types"].long(), batch["traj_vp_view_lens"].long(), None)
+        only_view_lens = batch["traj_vp_view_lens"].long()
+        obj_lens = batch["traj_vp_obj_lens"].long() if batch["traj_obj_img_fts"] is not None else None
+        traj, traj_masks = VT.forward_panorama(b, batch["traj_view_img_fts"], batch["traj_obj_img_fts"],
+                                               batch["traj_loc_fts"], batch["traj_nav_types"].long(), only_view_lens,
+                                               obj_lens)
         step_lens = [int(x) for x in batch["traj_step_lens"]]
-        view_lens = batch["traj_vp_view_lens"].long()
+        view_lens = only_view_lens if obj_lens is None else only_view_lens + obj_lens      # traj_vp_lens (:512-516)
         Vmax, H = traj.shape[1], traj.shape[2]
         B = len(step_lens)
         offs = [0]
@@ -190,7 +205,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             kv = VT._cat_linear(txt_embeds, [xa.att.key, xa.att.value])
             map_embeds = VT.x_layer(b, layer, kv, txt_masks, map_embeds, map_masks)
         return dict(txt_embeds=txt_embeds, txt_masks=txt_masks, map_embeds=map_embeds, map_masks=map_masks,
-                    gmap_masks=gmap_masks, vp_input=vp_input, vp_masks=vp_masks, last=last, view_lens=view_lens)
+                    gmap_masks=gmap_masks, vp_input=vp_input, vp_masks=vp_masks, last=last, view_lens=view_lens,
+                    last_view_lens=only_view_lens[last], last_obj_lens=None if obj_lens is None else obj_lens[last])
 
     def _bert_forward(self, batch):
         """GlocalTextPathCMT.forward (vilmodel.py:668-766) -> gmap_embeds, vp_embeds, gridmap_embeds, front."""
@@ -213,14 +229,14 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     # ---- tasks ---------------------------------------------------------------------------------------------------
     def forward(self, batch, task, compute_loss=True):
         batch = defaultdict(lambda: None, batch)
-        if batch["traj_obj_img_fts"] is not None:
-            raise NotImplementedError("object tokens (REVERIE / SOON pre-training) are outside this round's scope")
         if task.startswith("mlm"):
             return self.forward_mlm(batch, compute_loss)
         if task.startswith("mrc"):
             return self.forward_mrc(batch, compute_loss)
         if task.startswith("sap"):
             return self.forward_sap(batch, compute_loss)
+        if task.startswith("og"):
+            return self.forward_og(batch, compute_loss)
         raise ValueError("invalid task")
 
     def forward_mlm(self, batch, compute_loss=True):
@@ -244,22 +260,45 @@ class GlocalTextPathCMTPreTraining(nn.Module):
             return F.cross_entropy(scores, labels[sel].long(), reduction="none")
         return scores
 
+    @staticmethod
+    def _region_head(head, x):
+        net = head.net
+        return ag.linear(ag.layer_norm(ag.relu(ag.linear(x, net[0].weight, net[0].bias)), net[2]), net[3].weight, net[3].bias)
+
     def forward_mrc(self, batch, compute_loss=True):
-        """pretrain_cmt.py:161-213 (view tokens)."""
+        """pretrain_cmt.py:161-213: soft-label classification of the masked views (and objects) of the last step."""
         _, vp_embeds, _, f = self._bert_forward(batch)
+        B = vp_embeds.shape[0]
+        one = torch.ones(B, dtype=torch.long, device=vp_embeds.device)
         masks = batch["vp_view_mrc_masks"].bool()
-        n = masks.shape[1]
-        view_embeds = vp_embeds[:, 1:n + 1]                                   # [stop] at 0
-        if view_embeds.shape[1] < n:
-            view_embeds = F.pad(view_embeds, (0, 0, 0, n - view_embeds.shape[1]))
-        out = view_embeds[masks]
-        net = self.image_classifier.net
-        h = ag.layer_norm(ag.relu(ag.linear(out, net[0].weight, net[0].bias)), net[2])
-        logits = ag.linear(h, net[3].weight, net[3].bias)
-        targets = batch["vp_view_probs"][masks]
+        view_embeds, _ = _gather_span(vp_embeds, one, f["last_view_lens"], masks.shape[1])      # [stop] at 0
+        view_logits = self._region_head(self.image_classifier, view_embeds[masks])
+        view_targets = batch["vp_view_probs"][masks]
+        obj_logits = obj_targets = None
+        if f["last_obj_lens"] is not None:
+            omasks = batch["vp_obj_mrc_masks"].bool()
+            obj_embeds, _ = _gather_span(vp_embeds, one + f["last_view_lens"], f["last_obj_lens"], omasks.shape[1])
+            head = self.image_classifier if self.obj_classifier is None else self.obj_classifier
+            obj_logits = self._region_head(head, obj_embeds[omasks])
+            obj_targets = batch["vp_obj_probs"][omasks]
+        if not compute_loss:
+            return view_logits, view_targets, obj_logits, obj_targets
+        loss = F.kl_div(F.log_softmax(view_logits, -1), view_targets, reduction="none").sum(1)
+        if obj_logits is not None:
+            loss = torch.cat([loss, F.kl_div(F.log_softmax(obj_logits, -1), obj_targets, reduction="none").sum(1)], 0)
+        return loss
+
+    def forward_og(self, batch, compute_loss=True):
+        """pretrain_cmt.py:292-321: object grounding over the last step's object tokens."""
+        _, vp_embeds, _, f = self._bert_forward(batch)
+        B = vp_embeds.shape[0]
+        one = torch.ones(B, dtype=torch.long, device=vp_embeds.device)
+        max_obj = int(f["last_obj_lens"].max())
+        obj_embeds, obj_masks = _gather_span(vp_embeds, one + f["last_view_lens"], f["last_obj_lens"], max_obj)
+        obj_logits = VT.cls_head(self.og_head, obj_embeds).masked_fill(~obj_masks, -float("inf"))
         if compute_loss:
-            return F.kl_div(F.log_softmax(logits, -1), targets, reduction="none").sum(1)
-        return logits, targets, None, None
+            return F.cross_entropy(obj_logits, batch["obj_labels"].long(), reduction="none")
+        return obj_logits
 
     def forward_sap(self, batch, compute_loss=True):
         """pretrain_cmt.py:215-290."""

@@ -130,7 +130,7 @@ def batch_to(batch, device):
 # pre-training batches (pretrain_src/data/tasks.py collates)
 # ------------------------------------------------------------------------------------------------
 def make_pretrain_batch(rs, B, task, max_steps=3, L=24, vocab=2000, H=768, image_prob_size=50, n_pts=(200, 588),
-                        feat_scale=0.35, views=(36, 33)):
+                        feat_scale=0.35, views=(36, 33), with_obj=False, obj_feat_size=768, obj_prob_size=50):
     """One collated batch with the keys / dtypes of mlm_collate / mrc_collate / sap_collate (tasks.py:104-141,
     229-275, 334-377) for R2R (no object tokens).  Episodes are random but self-consistent: every global-map node is
     either a visited viewpoint or a candidate seen from one, the last step's candidates define the local branch.
@@ -143,6 +143,7 @@ def make_pretrain_batch(rs, B, task, max_steps=3, L=24, vocab=2000, H=768, image
     gmap_step_ids, gmap_visited, gmap_pos, gmap_dists = [], [], [], []
     vp_pos, grid_fts, grid_map, gpos = [], [], [], []
     g_labels, l_labels, mrc_masks, mrc_probs = [], [], [], []
+    objs, obj_lens, obj_labels, obj_mrc_masks, obj_mrc_probs = [], [], [], [], []
     for b in range(B):
         n_tok = int(rs.randint(8, L - 1))
         ids = [101] + rs.randint(1000, vocab, size=n_tok).tolist() + [102]
@@ -169,9 +170,14 @@ def make_pretrain_batch(rs, B, task, max_steps=3, L=24, vocab=2000, H=768, image
                 c[0 if c[0] != (path[t + 1] if t + 1 < T else None) else 1] = path[t - 1]   # and the way back
             cands_per_step.append(c)
             V = int(views[rs.randint(len(views))])
+            n_o = 0
+            if with_obj:        # object tokens follow the views (nav_type 2); the last step always has some
+                n_o = int(rs.randint(1 if t == T - 1 else 0, 7))
+                objs.append(torch.from_numpy(rs.standard_normal((n_o, obj_feat_size)).astype(np.float32)))
+                obj_lens.append(n_o)
             view.append(torch.from_numpy(rs.standard_normal((V, H)).astype(np.float32)))
-            loc.append(torch.from_numpy(rs.uniform(-1, 1, size=(V, 7)).astype(np.float32)))
-            types.append(torch.tensor([1] * n_c + [0] * (V - n_c), dtype=torch.int32))
+            loc.append(torch.from_numpy(rs.uniform(-1, 1, size=(V + n_o, 7)).astype(np.float32)))
+            types.append(torch.tensor([1] * n_c + [0] * (V - n_c) + [2] * n_o, dtype=torch.int32))
             view_lens.append(V)
             for x in c:
                 if x not in seen:
@@ -187,7 +193,7 @@ def make_pretrain_batch(rs, B, task, max_steps=3, L=24, vocab=2000, H=768, image
         gmap_step_ids.append(torch.tensor([0] + [path.index(x) + 1 if x in path else 0 for x in nodes], dtype=torch.int32))
         gmap_pos.append(torch.from_numpy(rs.uniform(-1, 1, size=(G, 7)).astype(np.float32)))
         gmap_dists.append(torch.from_numpy(rs.uniform(0, 1, size=(G, G)).astype(np.float32)))
-        Vl = view_lens[-1] + 1
+        Vl = view_lens[-1] + 1 + (obj_lens[-1] if with_obj else 0)
         p = rs.uniform(-1, 1, size=(Vl, 14)).astype(np.float32)
         p[len(cands_per_step[-1]) + 1:, 7:] = 0
         vp_pos.append(torch.from_numpy(p))
@@ -218,6 +224,17 @@ def make_pretrain_batch(rs, B, task, max_steps=3, L=24, vocab=2000, H=768, image
         mrc_probs.append(torch.softmax(torch.from_numpy(pr), -1))
         if task == "mrc":                                        # _mask_img_feat: masked views are zeroed
             view[-1] = view[-1].masked_fill(mrc_masks[-1].unsqueeze(-1), 0)
+        if with_obj:
+            n_o = obj_lens[-1]
+            obj_labels.append(int(rs.randint(n_o)))
+            om = rs.rand(n_o) < 0.3
+            if not om.any():
+                om[rs.randint(n_o)] = True
+            obj_mrc_masks.append(torch.from_numpy(om))
+            obj_mrc_probs.append(torch.softmax(torch.from_numpy(
+                rs.standard_normal((n_o, obj_prob_size)).astype(np.float32)), -1))
+            if task == "mrc":
+                objs[-1] = objs[-1].masked_fill(obj_mrc_masks[-1].unsqueeze(-1), 0)
 
     pad = torch.nn.utils.rnn.pad_sequence
 
@@ -249,6 +266,14 @@ def make_pretrain_batch(rs, B, task, max_steps=3, L=24, vocab=2000, H=768, image
         "grid_fts": grid_fts, "grid_map": grid_map, "gridmap_pos_fts": torch.stack(gpos, 0),
         "target_patch_id": torch.zeros(B, dtype=torch.int32),
     }
+    if with_obj:
+        batch["traj_obj_img_fts"] = pad_t(objs)
+        batch["traj_vp_obj_lens"] = torch.tensor(obj_lens, dtype=torch.int32)
+        if task == "og":
+            batch["obj_labels"] = torch.tensor(obj_labels, dtype=torch.int32)
+        if task == "mrc":
+            batch["vp_obj_mrc_masks"] = pad(obj_mrc_masks, batch_first=True, padding_value=False)
+            batch["vp_obj_probs"] = pad_t(obj_mrc_probs)
     if task == "mlm":
         batch["txt_labels"] = pad(txt_labels, batch_first=True, padding_value=-1).to(torch.int32)
     if task == "sap":

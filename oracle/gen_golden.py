@@ -346,8 +346,14 @@ PRETRAIN_SEEDS = {"mlm": 11, "mrc": 12, "sap": 13}
 GRAD_SAMPLES = 48
 
 
-def pretrain_batch(task):
-    """The batches of pretrain_reduced.npz, regenerated identically by the tests (inputs are not stored)."""
+PRETRAIN_OBJ = dict(obj_feat_size=768, obj_prob_size=30, pretrain_tasks=["mrc", "sap", "og"])   # REVERIE-style objects
+
+
+def pretrain_batch(task, with_obj=False):
+    """The batches of pretrain_reduced{,_obj}.npz, regenerated identically by the tests (inputs are not stored)."""
+    if with_obj:
+        return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS.get(task, 14) + 100), 3, task, with_obj=True,
+                                     obj_feat_size=PRETRAIN_OBJ["obj_feat_size"], obj_prob_size=PRETRAIN_OBJ["obj_prob_size"])
     return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS[task]), 3, task)
 
 
@@ -358,17 +364,19 @@ def grad_sample_index(name, numel):
     return rs.randint(0, numel, size=min(GRAD_SAMPLES, numel))
 
 
-def gen_pretrain():
+def gen_pretrain(with_obj=False):
     """GlocalTextPathCMTPreTraining.forward(batch, task) (pretrain_cmt.py:71-321) in train-step form
     (train_r2r.py:245-262): per-sample loss vectors, then loss.mean().backward(): per-parameter gradient norm,
-    seeded samples of every gradient, and the set of parameters that received none."""
+    seeded samples of every gradient, and the set of parameters that received none.
+    with_obj: object tokens in every panorama (REVERIE-style), tasks mrc (view + object branches) / sap / og."""
     torch.set_num_threads(1)
-    model = R.build_ref_pretrain_model(seed=9).train()     # dropout probs are 0 in the reduced config
-    out = {"versions": _versions(), "weight_seed": 9, "cfg": json.dumps(R.PRETRAIN_REDUCED),
+    over = dict(PRETRAIN_OBJ) if with_obj else {}
+    model = R.build_ref_pretrain_model(seed=9, **over).train()     # dropout probs are 0 in the reduced config
+    out = {"versions": _versions(), "weight_seed": 9, "cfg": json.dumps(dict(R.PRETRAIN_REDUCED, **over)),
            "param_names": json.dumps([k for k, _ in model.named_parameters()]),
            "param_dtypes": json.dumps({k: str(v.dtype) for k, v in model.state_dict().items()})}
-    for task in ("mlm", "mrc", "sap"):
-        batch = pretrain_batch(task)
+    for task in (("mrc", "sap", "og") if with_obj else ("mlm", "mrc", "sap")):
+        batch = pretrain_batch(task, with_obj)
         model.zero_grad()
         loss = model(batch, task=task, compute_loss=True)
         out["loss_" + task] = loss.detach().float().numpy()
@@ -385,13 +393,13 @@ def gen_pretrain():
         out["grad_norms_" + task] = np.array(norms, np.float32)
         out["grad_samples_" + task] = np.concatenate(samples).astype(np.float32)
         print(task, "loss", out["loss_" + task], "params with grad", len(names))
-    np.savez_compressed(os.path.join(OUT, "pretrain_reduced.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz"), **out)
 
 
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj"]
     if "rollout" in which: gen_rollout()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
@@ -402,3 +410,4 @@ if __name__ == "__main__":
     if "pretrain" in which: gen_pretrain()
     if "navvlnce" in which: gen_nav_vlnce()
     if "panoobj" in which: gen_pano_obj()
+    if "pretrainobj" in which: gen_pretrain(True)

@@ -194,9 +194,11 @@ def build_ref_pretrain_model(seed=0, **cfg_over):
     cfg = make_config(**dict(PRETRAIN_REDUCED, **cfg_over))
     m = pre.GlocalTextPathCMTPreTraining(cfg)
     sd = det_state_dict(m, seed)
-    sd["mlm_head.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    if "mlm" in cfg.pretrain_tasks:
+        sd["mlm_head.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
     m.load_state_dict(sd)
-    m.mlm_head.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight
+    if "mlm" in cfg.pretrain_tasks:
+        m.mlm_head.predictions.decoder.weight = m.bert.embeddings.word_embeddings.weight
     return m
 
 
