@@ -10,7 +10,8 @@ libgridmm_hip.so; torch only records the graph and moves/gathers/concatenates te
                                        db: column sums from the same transpose pass
   layer_norm  LN(x (+ r)) g + b        gridmm_layernorm / gridmm_layernorm_bwd
   gelu, relu                           gridmm_activation
-  attention   softmax(QK^T s + m) V    gridmm_attention_train / gridmm_attention_bwd (exact-fp32 MFMA)
+  attention   softmax(QK^T s + m) V    gridmm_attention_train / gridmm_attention_bwd (exact-fp32 MFMA), optional
+                                       dropout on the probabilities from a counter-based hash (same mask fwd / bwd)
   grid_aggregate                       gridmm_grid_aggregate / gridmm_grid_aggregate_bwd (grad w.r.t. text_fts)
 
 There is no CPU / eager fallback: the functions raise on non-GPU tensors (ops._p).
@@ -209,7 +210,7 @@ class _Attention(torch.autograd.Function):
     outputs are consumed in place through strides).  Returns (B,Sq,H)."""
 
     @staticmethod
-    def forward(ctx, q_src, kv_src, kmask, cols, heads):
+    def forward(ctx, q_src, kv_src, kmask, cols, heads, dropout_p=0.0):
         lib = _lib.load()
         H = heads * 64
         same = kv_src is None
@@ -227,12 +228,16 @@ class _Attention(torch.autograd.Function):
         out = torch.empty(B, Sq, H, dtype=torch.float32, device=q_src.device)
         lse = torch.empty(B, heads, Sqp, dtype=torch.float32, device=q_src.device)
         scale = 1.0 / math.sqrt(64.0)
+        # one 63-bit seed per call from torch's CPU generator (reproducible under torch.manual_seed); the kernels
+        # derive the keep-mask of element (b,h,q,k) from it, forward and backward alike
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dropout_p > 0 else 0
         _lib.check(lib.gridmm_attention_train(
             _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
             _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(lse), Sqp, B, heads, Sq, Sk,
-            scale, _stream()), "gridmm_attention_train")
+            scale, float(dropout_p), seed, _stream()), "gridmm_attention_train")
         ctx.save_for_backward(q_src, kv_src, kmask, out, lse)
         ctx.cols, ctx.heads, ctx.same, ctx.scale = cols, heads, same, scale
+        ctx.dropout_p, ctx.seed = float(dropout_p), seed
         return out
 
     @staticmethod
@@ -254,20 +259,38 @@ class _Attention(torch.autograd.Function):
             _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
             _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(dout), Sq * H, H, _p(lse),
             _p(delta), _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0), dk.stride(1), _p(dv), dv.stride(0),
-            dv.stride(1), B, heads, Sq, Sk, Sqp, ctx.scale, _stream()), "gridmm_attention_bwd")
-        return dq_src, (None if ctx.same else dkv_src), None, None, None
+            dv.stride(1), B, heads, Sq, Sk, Sqp, ctx.scale, ctx.dropout_p, ctx.seed, _stream()), "gridmm_attention_bwd")
+        return dq_src, (None if ctx.same else dkv_src), None, None, None, None
 
 
-def self_attention(qkv, kmask, heads):
-    """qkv (B,S,3H) = fused [q | k | v] projection."""
+def self_attention(qkv, kmask, heads, dropout_p=0.0):
+    """qkv (B,S,3H) = fused [q | k | v] projection.  dropout_p: dropout on the attention probabilities."""
     H = heads * 64
-    return _Attention.apply(qkv, None, kmask, (0, H, 2 * H), heads)
+    return _Attention.apply(qkv, None, kmask, (0, H, 2 * H), heads, dropout_p)
 
 
-def cross_attention(q, kv, kmask, heads, kv_col=0):
+def cross_attention(q, kv, kmask, heads, kv_col=0, dropout_p=0.0):
     """q (B,Sq,H); kv (B,Sk,n*2H) with [k | v] of this layer at column kv_col."""
     H = heads * 64
-    return _Attention.apply(q, kv, kmask, (0, kv_col, kv_col + H), heads)
+    return _Attention.apply(q, kv, kmask, (0, kv_col, kv_col + H), heads, dropout_p)
+
+
+def attention_dropout_mask(seed, B, heads, Sq, Sk, p):
+    """The keep-mask the kernels derive from `seed` (host restatement of csrc/common.h dropout_keep; tests only)."""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFF)
+
+    def h32(x):
+        x = x & M
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x85ebca6b)) & M
+        x ^= x >> np.uint64(13); x = (x * np.uint64(0xc2b2ae35)) & M
+        x ^= x >> np.uint64(16)
+        return x & M
+    idx = np.arange(B * heads * Sq * Sk, dtype=np.uint64) & M
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    x = h32(((idx * np.uint64(0x9E3779B1)) & M) ^ lo) ^ hi
+    u = (h32(x) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).reshape(B, heads, Sq, Sk)
 
 
 class _GridAggregate(torch.autograd.Function):

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void attention_kernel(
     int k_rs, const float* __restrict__ V, int64_t v_bs, int v_rs, const uint8_t* __restrict__ kmask,
     int mask_bs, float* __restrict__ O, int64_t o_bs, int o_rs, unsigned short* __restrict__ Ohi,
     unsigned short* __restrict__ Olo, int64_t p_bs, int p_rs, int Sq, int Sk, float scale,
-    float* __restrict__ lse, int Sqp) {
+    float* __restrict__ lse, int Sqp, float drop_p, unsigned long long seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 16;
   if (q0 >= Sq) return;
@@ -104,6 +104,13 @@ __global__ __launch_bounds__(256) void attention_kernel(
     l_run = l_run * alpha + ps;
     m_run = m_new;
 
+    if (drop_p > 0.f) {   // dropout on the probabilities (vilmodel.py:143): the row sum above stays un-dropped
+      const float keep_scale = 1.0f / (1.0f - drop_p);
+      const unsigned int row = ((unsigned int)(b * gridDim.y + h) * Sq + (q0 + j)) * Sk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        p[r] = dropout_keep(seed, row + key0 + 4 * g + r, drop_p) ? p[r] * keep_scale : 0.f;
+    }
     // rescale the output rows: row (query) 4g+r takes alpha from the lane whose j == 4g+r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -164,7 +171,7 @@ extern "C" int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const fl
   dim3 grid((Sq + 63) / 64, heads, B), block(256);
   GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
                      v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs,
-                     p_rs, Sq, Sk, scale, (float*)nullptr, 0);
+                     p_rs, Sq, Sk, scale, (float*)nullptr, 0, 0.f, 0ull);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -172,14 +179,16 @@ extern "C" int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const fl
 extern "C" int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs,
                                       int k_rs, const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask,
                                       int mask_bs, float* O, int64_t o_bs, int o_rs, float* lse, int Sqp, int B,
-                                      int heads, int Sq, int Sk, float scale, gridmm_stream_t stream) {
+                                      int heads, int Sq, int Sk, float scale, float dropout_p,
+                                      unsigned long long seed, gridmm_stream_t stream) {
   if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || !O || !lse || Sqp < Sq || Sqp % 16) return GRIDMM_EINVAL;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return GRIDMM_EINVAL;
   if ((q_rs | k_rs | v_rs | o_rs) & 3) return GRIDMM_EINVAL;
   if ((q_bs | k_bs | v_bs | o_bs) & 3) return GRIDMM_EINVAL;
   dim3 grid((Sq + 63) / 64, heads, B), block(256);
   GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
                      v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)nullptr, (unsigned short*)nullptr,
-                     (int64_t)0, 0, Sq, Sk, scale, lse, Sqp);
+                     (int64_t)0, 0, Sq, Sk, scale, lse, Sqp, dropout_p, seed);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(
     const float* __restrict__ V, int64_t v_bs, int v_rs, const uint8_t* __restrict__ kmask, int mask_bs,
     const float* __restrict__ dO, int64_t do_bs, int do_rs, const float* __restrict__ lse,
     const float* __restrict__ delta, float* __restrict__ dQ, int64_t dq_bs, int dq_rs, int Sq, int Sk, int Sqp,
-    float scale) {
+    float scale, float drop_p, unsigned long long seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 16;
   if (q0 >= Sq) return;
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(
   const float* Kb = K + b * k_bs + h * 64;
   const float* Vb = V + b * v_bs + h * 64;
   const uint8_t* mb = kmask ? kmask + (size_t)b * mask_bs : nullptr;
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
 
   for (int key0 = 0; key0 < Sk; key0 += 16) {
     if (mb) {
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(
       const int kk = key0 + 4 * g + r;
       const bool valid = (kk < Sk) && (!mb || mb[kk]);
       const float p = valid ? expf(st[r] - lse_j) : 0.f;
-      ds[r] = p * (dpt[r] - delta_j);
+      float dp = dpt[r];
+      if (drop_p > 0.f)   // d/dP of the dropped probabilities: mask / (1 - p); delta = dO.O already includes it
+        dp = dropout_keep(seed, ((unsigned int)(b * heads + h) * Sq + (q0 + j)) * Sk + kk, drop_p) ? dp * keep_scale : 0.f;
+      ds[r] = p * (dp - delta_j);
     }
     // dQ[query][d] += sum_key dS[query][key] K[key][d]: A needs lane (i = query, k = g) -> the lane holding
     // query i's column is (j = i, g) itself, with keys 4g+s as its 4 k-steps.
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(
     const float* __restrict__ V, int64_t v_bs, int v_rs, const uint8_t* __restrict__ kmask, int mask_bs,
     const float* __restrict__ dO, int64_t do_bs, int do_rs, const float* __restrict__ lse,
     const float* __restrict__ delta, float* __restrict__ dK, int64_t dk_bs, int dk_rs, float* __restrict__ dV,
-    int64_t dv_bs, int dv_rs, int Sq, int Sk, int Sqp, float scale) {
+    int64_t dv_bs, int dv_rs, int Sq, int Sk, int Sqp, float scale, float drop_p, unsigned long long seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int key0 = (blockIdx.x * 4 + wave) * 16;
   if (key0 >= Sk) return;
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(
   const float* Qb = Q + b * q_bs + h * 64;
   const float* dOb = dO + b * do_bs + h * 64;
   const size_t st_off = ((size_t)b * heads + h) * Sqp;
+  const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
 
   if (__any(key_valid)) {
     for (int q0 = 0; q0 < Sq; q0 += 16) {
@@ -170,14 +175,19 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(
       const f32x4_t st = mma16(qf, kf);    // S[query 4g+r][key j] (scaled)
       const f32x4_t dp = mma16(dof, vf);   // dP[query 4g+r][key j]
       const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-      float p[4], ds[4];
+      float p[4], ds[4], pd[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool valid = key_valid && (q0 + 4 * g + r < Sq);
         p[r] = valid ? expf(st[r] - ls[r]) : 0.f;
-        ds[r] = p[r] * (dp[r] - dl[r]);
+        float m = 1.0f;
+        if (drop_p > 0.f)
+          m = dropout_keep(seed, ((unsigned int)(b * heads + h) * Sq + (q0 + 4 * g + r)) * Sk + key0 + j, drop_p)
+                  ? keep_scale : 0.f;
+        pd[r] = p[r] * m;                       // dropped probabilities (what multiplied V in the forward)
+        ds[r] = p[r] * (dp[r] * m - dl[r]);
       }
-      mma_acc(av, p, doc);    // dV[key][d] += sum_q P[q][key] dO[q][d]
+      mma_acc(av, pd, doc);   // dV[key][d] += sum_q P~[q][key] dO[q][d]
       mma_acc(ak, ds, qc);    // dK[key][d] += sum_q dS[q][key] Q[q][d]
     }
   }
@@ -200,7 +210,8 @@ extern "C" int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, cons
                                     const float* O, int64_t o_bs, int o_rs, const float* dO, int64_t do_bs,
                                     int do_rs, const float* lse, float* delta, float* dQ, int64_t dq_bs, int dq_rs,
                                     float* dK, int64_t dk_bs, int dk_rs, float* dV, int64_t dv_bs, int dv_rs, int B,
-                                    int heads, int Sq, int Sk, int Sqp, float scale, gridmm_stream_t stream) {
+                                    int heads, int Sq, int Sk, int Sqp, float scale, float dropout_p,
+                                    unsigned long long seed, gridmm_stream_t stream) {
   if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || Sqp < Sq || Sqp % 16) return GRIDMM_EINVAL;
   if ((q_rs | k_rs | v_rs | o_rs | do_rs | dq_rs | dk_rs | dv_rs) & 3) return GRIDMM_EINVAL;
   if ((q_bs | k_bs | v_bs | o_bs | do_bs | dq_bs | dk_bs | dv_bs) & 3) return GRIDMM_EINVAL;
@@ -212,11 +223,11 @@ extern "C" int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, cons
   // the K scale is folded into the S = Q K^T product once: dq kernel scales Q, dkv kernel scales K
   GRIDMM_LAUNCH(attention_bwd_dq_kernel, dim3((Sq + 63) / 64, heads, B), dim3(256), 0, st, Q, q_bs, q_rs, K, k_bs,
                 k_rs, V, v_bs, v_rs, kmask, mask_bs, dO, do_bs, do_rs, lse, delta, dQ, dq_bs, dq_rs, Sq, Sk, Sqp,
-                scale);
+                scale, dropout_p, seed);
   GRIDMM_CHECK_LAUNCH();
   GRIDMM_LAUNCH(attention_bwd_dkv_kernel, dim3((Sk + 63) / 64, heads, B), dim3(256), 0, st, Q, q_bs, q_rs, K, k_bs,
                 k_rs, V, v_bs, v_rs, kmask, mask_bs, dO, do_bs, do_rs, lse, delta, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs,
-                Sq, Sk, Sqp, scale);
+                Sq, Sk, Sqp, scale, dropout_p, seed);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

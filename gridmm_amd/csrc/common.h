@@ -68,3 +68,14 @@ __device__ __forceinline__ float wave_min(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Counter-based dropout for the attention probabilities (training): element (b, h, q, k) is kept iff
+// hash(seed, linear index) >= p.  Stateless, so the forward and both backward kernels regenerate the same mask.
+__host__ __device__ __forceinline__ unsigned int gridmm_hash32(unsigned int x) {   // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned int idx, float p) {
+  const unsigned int x = gridmm_hash32((idx * 0x9E3779B1u) ^ (unsigned int)seed) ^ (unsigned int)(seed >> 32);
+  return (float)(gridmm_hash32(x) >> 8) * (1.0f / 16777216.0f) >= p;
+}

@@ -7,10 +7,10 @@ back-propagate through.  torch here only concatenates, gathers (embedding tables
 
 Reference line numbers are map_nav_src/models/vilmodel.py unless stated.
 
-Dropout: hidden-state dropout (BertSelfOutput/BertOutput/embeddings, the pre-LN layers' dropout1/2/dropout,
-ClsPrediction has none) is applied when module.training; dropout on the attention PROBABILITIES
-(attention_probs_dropout_prob, vilmodel.py:118; transformer.py MultiheadAttention dropout) is not -- the
-attention kernel is fused; see DESIGN.md "training".
+Dropout (module.training only): hidden-state dropout (BertSelfOutput / BertOutput / embeddings, the pre-LN layers'
+dropout1/2/dropout; ClsPrediction has none) through torch's RNG; dropout on the attention PROBABILITIES
+(attention_probs_dropout_prob, vilmodel.py:112,143,334,362; nn.MultiheadAttention(dropout=p), transformer.py:138) inside
+the fused attention kernels from a counter-based hash, so the backward regenerates the forward's mask.
 """
 import torch
 import torch.nn.functional as F
@@ -26,6 +26,11 @@ def _drop(model, x, p=None):
     return F.dropout(x, p, True) if (model.training and p > 0) else x
 
 
+def _attn_p(model):
+    """attention_probs_dropout_prob (vilmodel.py:112,334), active in train() only."""
+    return float(model.config.attention_probs_dropout_prob) if model.training else 0.0
+
+
 def _cat_linear(x, mods, residual=None):
     """One GEMM for several Linear modules sharing the input (fused q|k|v projections)."""
     if len(mods) == 1:
@@ -37,7 +42,7 @@ def self_attention_block(model, att, x, kmask):
     """BertAttention (:172-182): LN(dropout(dense(attn(x))) + x)."""
     s = att.self
     qkv = _cat_linear(x, [s.query, s.key, s.value])
-    ctx = ag.self_attention(qkv, kmask, model.heads)
+    ctx = ag.self_attention(qkv, kmask, model.heads, _attn_p(model))
     h = _drop(model, ag.linear(ctx, att.output.dense.weight, att.output.dense.bias))
     return ag.layer_norm(h, att.output.LayerNorm, residual=x)
 
@@ -45,7 +50,7 @@ def self_attention_block(model, att, x, kmask):
 def cross_attention_block(model, xatt, x, ctx_kv, ctx_mask, kv_col=0):
     """BertXAttention (:370-379); ctx_kv = [k | v] projections of the context (possibly several layers wide)."""
     q = ag.linear(x, xatt.att.query.weight, xatt.att.query.bias)
-    c = ag.cross_attention(q, ctx_kv, ctx_mask, model.heads, kv_col=kv_col)
+    c = ag.cross_attention(q, ctx_kv, ctx_mask, model.heads, kv_col=kv_col, dropout_p=_attn_p(model))
     h = _drop(model, ag.linear(c, xatt.output.dense.weight, xatt.output.dense.bias))
     return ag.layer_norm(h, xatt.output.LayerNorm, residual=x)
 
@@ -83,7 +88,7 @@ def pre_ln_encoder(model, enc, x, kmask):
     for layer in enc.layers:
         h = ag.layer_norm(x, layer.norm1)
         qkv = ag.linear(h, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias)
-        ctx = ag.self_attention(qkv, kmask, model.heads)
+        ctx = ag.self_attention(qkv, kmask, model.heads, p if model.training else 0.0)   # nn.MultiheadAttention(dropout=p)
         x = x + _drop(model, ag.linear(ctx, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias), p)
         h = ag.layer_norm(x, layer.norm2)
         f = _drop(model, ag.gelu(ag.linear(h, layer.linear1.weight, layer.linear1.bias)), p)

@@ -248,7 +248,10 @@ int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, in
 int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
                            const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
                            int64_t o_bs, int o_rs, float* lse, int Sqp, int B, int heads, int Sq, int Sk,
-                           float scale, gridmm_stream_t stream);
+                           float scale, float dropout_p, unsigned long long seed, gridmm_stream_t stream);
+/* dropout_p > 0: dropout on the attention probabilities (vilmodel.py:143,362; transformer.py MultiheadAttention):
+ * element (b,h,q,k) is kept iff a counter-based hash of (seed, ((b*heads+h)*Sq+q)*Sk+k) >= p, survivors scaled by
+ * 1/(1-p); the backward regenerates the mask from the same (dropout_p, seed). */
 
 /* Backward of the attention core: dQ, dK, dV from dO (fp32, exact-fp32 MFMA; masked keys get zero gradient).
  * delta [B][heads][Sqp] is a workspace (sum_d dO*O per query). */
@@ -257,7 +260,7 @@ int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, const float* K,
                          int64_t o_bs, int o_rs, const float* dO, int64_t do_bs, int do_rs, const float* lse,
                          float* delta, float* dQ, int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs, int dk_rs,
                          float* dV, int64_t dv_bs, int dv_rs, int B, int heads, int Sq, int Sk, int Sqp, float scale,
-                         gridmm_stream_t stream);
+                         float dropout_p, unsigned long long seed, gridmm_stream_t stream);
 
 /* Backward of gridmm_grid_aggregate w.r.t. text = text_proj(txt_embeds) (vilmodel.py:795-807; the gradient
  * reaches text_proj and the language encoder through the max / softmax weights):

@@ -19,6 +19,7 @@ def _dev():
 
 
 def _rel(a, b):
+    a, b = a.detach(), b.detach()
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
 
 
@@ -191,3 +192,32 @@ def test_grid_aggregate_backward(B, D, L, n_obs):
     ref.backward(dcells.double())
     assert _rel(cells, ref) < 1e-4
     assert _rel(text.grad, td.grad) < 1e-3, _rel(text.grad, td.grad)
+
+
+def test_attention_probability_dropout_forward_and_backward():
+    """Dropout on softmax(QK^T) (vilmodel.py:143): the kernels' hash mask, restated on the host, applied in a torch
+    reference -> same output and gradients; keep rate ~ 1 - p; p = 0 is the identity."""
+    from gridmm_amd import autograd as ag
+    dev = _dev()
+    B, S, heads, p = 2, 75, 3, 0.25
+    H = heads * 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, S, 3 * H, generator=g).to(dev).requires_grad_()
+    kmask = torch.ones(B, S, dtype=torch.bool, device=dev)
+    kmask[1, 60:] = False
+    dy = torch.randn(B, S, H, generator=g).to(dev)
+    torch.manual_seed(1234)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # what _Attention.forward will draw
+    torch.manual_seed(1234)
+    y = ag.self_attention(qkv, kmask, heads, dropout_p=p)
+    y.backward(dy)
+    keep = torch.from_numpy(ag.attention_dropout_mask(seed, B, heads, S, S, p)).to(dev)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    qd = qkv.detach().double().requires_grad_()
+    q, k, v = (qd[..., i * H:(i + 1) * H].view(B, S, heads, 64).transpose(1, 2) for i in range(3))
+    s = (q @ k.transpose(-1, -2) / 8.0).masked_fill(~kmask[:, None, None, :], -float("inf"))
+    pr = torch.softmax(s, -1) * keep / (1 - p)
+    yd = (pr @ v).transpose(1, 2).reshape(B, S, H)
+    yd.backward(dy.double())
+    assert _rel(y, yd) < 1e-5
+    assert _rel(qkv.grad, qd.grad) < 2e-5
