@@ -31,7 +31,18 @@ __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short
 // BM x BN block tile, WM x WN per wave (16x16x32 MFMA tiles), NS-stage LDS ring filled by LDS-DMA.
 // One raw s_barrier per k-step; the DMA of stage kt+NS-1 is issued right after the barrier that retires
 // stage kt-1, and only a COUNTED s_waitcnt vmcnt keeps the younger stages in flight across barriers.
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0>
+//
+// PP = 1 ("ping-pong", 8 waves, NS = 2, BK = 32): the k-step is cut into 4 barrier-separated intervals
+//   R1 (ds_read: all W fragments + A fragments of the upper half of the wave tile) | M1 (its MFMAs)
+//   R2 (ds_read: A fragments of the lower half)                                     | M2 (its MFMAs)
+// and the upper half of the waves runs ONE interval behind the lower half.  A SIMD hosts waves of both groups, so in every interval
+// exactly one of its two waves is inside an MFMA cluster while the other reads LDS and then parks on the barrier:
+// the matrix pipe never waits for a ds_read or for a barrier bubble (lockstep waves all read, then all contend).
+// The DMA of stage s+1 is issued by every wave at the first interval of step s (the buffer's last readers, the
+// lagging group's R2 of step s-1, finished one barrier earlier) and retired (vmcnt(0)) by every wave before the
+// barrier that ends the 4th interval -- one barrier before the leading group's first read of it, two before the
+// lagging group's -- so a full k-step of MFMA time covers the global->LDS latency.
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
@@ -45,9 +56,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   constexpr int PIECES = (2 * BM + 2 * BN) / RPP;        // 1-KiB DMA pieces per stage
   static_assert(PIECES % NW == 0, "tile must split evenly over the waves");
   constexpr int PPW = PIECES / NW;
-  constexpr int ER = WM < 64 ? WM : 64;                  // rows per epilogue pass (LDS budget)
+  constexpr int ER = (NW > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : 64);   // rows per epilogue pass (LDS budget)
   constexpr int EPI = ER * WN;                           // floats per wave in the epilogue transpose
-  constexpr int LDS_U16 = (NS * STAGE * 2 > NW * EPI * 4 ? NS * STAGE : NW * EPI * 2);
+  constexpr int LDS_U16 = (TR || NS * STAGE * 2 > NW * EPI * 4) ? NS * STAGE : NW * EPI * 2;
   __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_U16];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -116,6 +127,89 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     }
 
   const int frow = lane & 15, fchunk = lane >> 4;
+  if constexpr (PP) {
+    static_assert(!PP || (NS == 2 && BK == 32 && (NW == 8 || NW == 16) && TM % 2 == 0), "ping-pong schedule: 8 / 16 waves, 2 stages, BK 32");
+    constexpr int HM = TM / 2;
+    bf16x8_t ah[HM], al[HM], bh[TN], bl[TN];
+    auto issue = [&](int stage) {
+      unsigned short* nxt = smem + (stage & 1) * STAGE;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + stage * BK, nxt + dst[i]);
+    };
+    auto read_a = [&](const unsigned short* cur, int half) {
+#pragma unroll
+      for (int i = 0; i < HM; ++i) {
+        const int row = wr * WM + (half * HM + i) * 16 + frow;
+        const int off = row * BK + (fchunk ^ swz<BK>(row)) * 8;
+        ah[i] = *reinterpret_cast<const bf16x8_t*>(cur + off);
+        al[i] = *reinterpret_cast<const bf16x8_t*>(cur + BM * BK + off);
+      }
+    };
+    auto read_b = [&](const unsigned short* cur) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wc * WN + j * 16 + frow;
+        const int off = 2 * BM * BK + row * BK + (fchunk ^ swz<BK>(row)) * 8;
+        bh[j] = *reinterpret_cast<const bf16x8_t*>(cur + off);
+        bl[j] = *reinterpret_cast<const bf16x8_t*>(cur + BN * BK + off);
+      }
+    };
+    auto mma_half = [&](int half) {   // 3 passes over the half tile: every accumulator's MFMAs are HM*TN apart
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < HM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[half * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[half * HM + i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < HM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[half * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[half * HM + i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < HM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[half * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[half * HM + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // interval boundary: nothing may be scheduled across it
+#define GRIDMM_IVAL_END()                          \
+  do {                                             \
+    __builtin_amdgcn_sched_barrier(0);             \
+    __builtin_amdgcn_s_barrier();                  \
+    __builtin_amdgcn_sched_barrier(0);             \
+  } while (0)
+#define GRIDMM_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define GRIDMM_DMA_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+    GRIDMM_DMA_DONE();            // stage 0 (issued above)
+    GRIDMM_IVAL_END();            // ... visible to everyone
+    if (wave < NW / 2) {          // leading group: intervals 4s .. 4s+3 of step s
+      for (int s = 0; s < nk; ++s) {
+        const unsigned short* cur = smem + (s & 1) * STAGE;
+        if (s + 1 < nk) issue(s + 1);
+        read_b(cur); read_a(cur, 0); GRIDMM_READS_DONE(); GRIDMM_IVAL_END();
+        mma_half(0); GRIDMM_IVAL_END();
+        read_a(cur, 1); GRIDMM_READS_DONE(); GRIDMM_IVAL_END();
+        mma_half(1); GRIDMM_DMA_DONE(); GRIDMM_IVAL_END();
+      }
+      GRIDMM_IVAL_END();          // the lagging group's last interval
+    } else {                      // lagging group: one interval behind
+      if (1 < nk) issue(1);
+      GRIDMM_IVAL_END();          // interval 0 (idle)
+      for (int s = 0; s < nk; ++s) {
+        const unsigned short* cur = smem + (s & 1) * STAGE;
+        read_b(cur); read_a(cur, 0); GRIDMM_READS_DONE(); GRIDMM_IVAL_END();
+        mma_half(0); GRIDMM_IVAL_END();
+        read_a(cur, 1); GRIDMM_READS_DONE(); GRIDMM_DMA_DONE(); GRIDMM_IVAL_END();
+        if (s + 2 < nk) issue(s + 2);
+        mma_half(1); GRIDMM_IVAL_END();
+      }
+    }
+#undef GRIDMM_IVAL_END
+#undef GRIDMM_READS_DONE
+#undef GRIDMM_DMA_DONE
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     // retire stage kt: everything except the (NS-2) younger stages must have landed
     if (NS >= 3 && kt + NS - 2 < nk) {
@@ -158,11 +252,53 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (TR) {   // C^T tiles: a lane ends with 4 consecutive COLUMNS of one row (direct row-wise stores)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
         }
     }
+  }
+  if constexpr (TR) {
+    // ---- epilogue straight from the accumulators (no LDS pass, no barrier): with the operands swapped the tile is
+    // C^T, i.e. lane (m = lane & 15, g = lane >> 4) holds C[m][4g .. 4g+3] of every 16x16 tile.
+    const int mrow = lane & 15, g4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n0 = bn + wc * WN + j * 16 + g4;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias && n0 < N) bv = *reinterpret_cast<const float4*>(bias + n0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = bm + wr * WM + i * 16 + mrow;
+        if (m < M && n0 < N) {
+          float x[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
+            if (ACT == GRIDMM_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+          }
+          if (R) {
+            const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
+            x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w;
+          }
+          if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
+          if (Chi) {
+            uint2 hi, lo;
+            split2_bf16(x[0], x[1], hi.x, lo.x);
+            split2_bf16(x[2], x[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(Chi + (size_t)m * ldp + n0) = hi;
+            *reinterpret_cast<uint2*>(Clo + (size_t)m * ldp + n0) = lo;
+          }
+        }
+      }
+    }
+    return;
   }
   __syncthreads();  // all waves are done with the last stage before LDS is reused by the epilogue
 
@@ -239,13 +375,13 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st) {
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM)), block((BM / WM) * (BN / WN) * 64);
 #define GRIDMM_LP(ACT)                                                                                        \
-  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
+  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
                 Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
@@ -276,11 +412,11 @@ extern "C" int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, in
 static int pick_cfg(int M, int N, int K) {
   struct Cand { int cfg, bm, bn, occ; float q; bool k64; };
   static const Cand cands[] = {
-      {7, 256, 256, 1, 1.30f, false},  // 8 waves, 128x64 per wave: most reuse per LDS-DMA byte
+      {36, 256, 256, 1, 1.35f, false}, // 16 waves, 64x64 per wave (4 waves / SIMD): 3-8 % over the 8-wave 128x64 form
       {16, 256, 128, 1, 1.00f, false}, // 16 waves
       {15, 128, 128, 2, 1.10f, false}, // 16 waves x 2 workgroups = full 32-wave occupancy
       {2, 128, 128, 1, 0.87f, true},   // 8 waves, BK = 64
-      {8, 64, 64, 2, 0.75f, true},     // small M*N: fills the 256 CUs
+      {43, 64, 64, 2, 0.78f, true},    // small M*N: fills the 256 CUs; epilogue straight from C^T accumulators
       {4, 64, 64, 5, 0.60f, false}};
   int best = 4;
   float best_t = 1e30f;
@@ -335,6 +471,18 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
     case 22: return launch<256, 128, 64, 64, 3, 32>(GRIDMM_ARGS);
     case 23: return launch<256, 128, 64, 32, 3, 32>(GRIDMM_ARGS);
     case 24: return launch<128, 256, 64, 64, 3, 32>(GRIDMM_ARGS);
+    case 30: return launch<256, 256, 128, 64, 2, 32, 0, 1>(GRIDMM_ARGS);   // ping-pong schedules
+    case 31: return launch<256, 128, 64, 64, 2, 32, 0, 1>(GRIDMM_ARGS);
+    case 32: return launch<128, 256, 64, 64, 2, 32, 0, 1>(GRIDMM_ARGS);
+    case 33: return launch<128, 128, 64, 32, 2, 32, 0, 1>(GRIDMM_ARGS);
+    case 34: return launch<256, 256, 64, 64, 2, 32, 0, 1>(GRIDMM_ARGS);    // 16 waves: 2 + 2 per SIMD
+    case 35: return launch<256, 128, 64, 32, 2, 32, 0, 1>(GRIDMM_ARGS);
+    case 36: return launch<256, 256, 64, 64, 2, 32>(GRIDMM_ARGS);          // 16 waves, lockstep (control)
+    case 40: return launch<256, 256, 64, 64, 2, 32, 0, 0, 1>(GRIDMM_ARGS);  // TR = direct epilogue from C^T accumulators
+    case 41: return launch<256, 256, 128, 64, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
+    case 42: return launch<128, 128, 32, 32, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
+    case 43: return launch<64, 64, 32, 32, 2, 64, 0, 0, 1>(GRIDMM_ARGS);
+    case 44: return launch<256, 128, 64, 32, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
     // ablations (tools/bench_gemm.py): 1xx = no MFMA (DMA + LDS reads only), 2xx = no DMA after the prologue
     case 108: return launch<64, 64, 32, 32, 2, 64, 1>(GRIDMM_ARGS);
     case 208: return launch<64, 64, 32, 32, 2, 64, 2>(GRIDMM_ARGS);
