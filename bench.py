@@ -256,7 +256,7 @@ def main():
                    "global_batch": args.batch * n_gpus, "parallelism": "dp%d (episode sharding, no step-path collective)" % n_gpus,
                    "launch": "eager" if args.eager else "hipGraph replay (pose/heading H2D outside the graph)",
                    "gemm": "MFMA bf16 16x16x32, 3-term split (hi*hi+lo*hi+hi*lo), fp32 accumulate",
-                   "attention": "MFMA f32 16x16x4 (exact fp32)", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
+                   "attention": "MFMA bf16 16x16x32, 3-term split, fp32 softmax", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
     }
     if rank == 0 and not args.no_roofline:
         rl = roofline_leg(eager_step, args, geom)   # per-launch HIP events need eager launches
