@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--shape", default="baseline", choices=["baseline", "native"])
     ap.add_argument("--mem-steps", type=int, default=1, help="observations in each episode's memory (t)")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="cut the episode batch into this many groups captured on concurrent streams of one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -86,7 +88,33 @@ def build_workload(args, dev):
         return model("navigation", batch)
 
     step = eager_step
-    if not args.eager:
+    if not args.eager and args.groups > 1:
+        from gridmm_amd.graph import GraphedNavStepGroups
+        eager_step()                            # packs the weights, fills the allocator
+        ng = args.groups
+        assert B % ng == 0
+        per = B // ng
+        groups, gp, gh = [], [], []
+        for gi in range(ng):
+            sl = slice(gi * per, (gi + 1) * per)
+            gm = GridMemoryBatch(per, geom, max_steps=t, device=dev)
+            gm.slab.copy_(mem.slab[sl])
+            for k in range(t - 1):
+                gm.step(depth[k][sl], None, poses[k][sl], heads[k][sl])
+            gb = {k: (v[sl] if (torch.is_tensor(v) and v.shape[:1] == (B,)) or (isinstance(v, list) and len(v) == B) else v)
+                  for k, v in batch.items() if k not in ("grid_memory", "fusion_maps")}
+            gb = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()}
+            groups.append(dict(mem=gm, batch=gb, depth=depth[t - 1][sl].contiguous(),
+                               restore=(gm.n_pts.clone(), gm.bbox.clone())))
+            gp.append(poses[t - 1][sl])
+            gh.append(heads[t - 1][sl])
+        g = GraphedNavStepGroups(model, groups)
+        for gr in groups:
+            gr["mem"].n_pts_host[:] = gr["mem"].n_pts_host + n_new
+
+        def step():
+            return g(gp, gh)
+    elif not args.eager:
         from gridmm_amd.graph import GraphedNavStep
         eager_step()                            # packs the weights, fills the allocator
         g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore)
