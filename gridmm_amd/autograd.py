@@ -82,60 +82,83 @@ def _gemm(a2d, pw, bias=None, residual=None):
         pw.bias = None
 
 
-def transpose_split(x2d, want_colsum=False):
-    """fp32 (M,C) -> bf16 hi/lo planes (C,Mp) with Mp = roundup(M,32), optional column sums (C,)."""
+def transpose_split(x2d, want_colsum=False, want_rows=False):
+    """fp32 (M,C) -> transposed bf16 hi/lo planes (C,Mp), Mp = roundup(M,32) [, column sums (C,)] [, the row-major
+    planes as an ops.Act] -- one pass over x2d."""
     lib = _lib.load()
     x2d, M, C, ld = _as2d(x2d)
     Mp = (M + 31) // 32 * 32
     hi = torch.empty(C, Mp, dtype=torch.bfloat16, device=x2d.device)
     lo = torch.empty_like(hi)
     cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum else None
-    _lib.check(lib.gridmm_transpose_split(_p(x2d), ld, _p(hi), _p(lo), _p(cs), M, C, Mp, _stream()),
+    rows = None
+    if want_rows and C % 8 == 0:
+        rh = torch.empty(M, C, dtype=torch.bfloat16, device=x2d.device)
+        rows = ops.Act(x2d, rh, torch.empty_like(rh))
+    _lib.check(lib.gridmm_transpose_split(_p(x2d), ld, _p(hi), _p(lo), _p(cs), _p(rows.hi if rows else None),
+                                          _p(rows.lo if rows else None), C, M, C, Mp, _stream()),
                "gridmm_transpose_split")
-    return hi, lo, cs, Mp
+    return hi, lo, cs, Mp, rows
 
 
-def _gemm_tn(dy2d, x2d, want_colsum):
-    """dW (N,K) = dY^T X and db = colsum(dY), contraction over the M rows."""
-    M, N = dy2d.shape
-    K = x2d.shape[1]
-    yh, yl, db, Mp = transpose_split(dy2d, want_colsum)
-    xh, xl, _, _ = transpose_split(x2d)
+def _gemm_tn(yt, xt, N, K, M, Mp, dy2d):
+    """dW (N,K) = dY^T X from the transposed planes yt = (hi, lo) of dY and xt of X (contraction over the M rows)."""
     pw = ops.PackedLinear.__new__(ops.PackedLinear)
-    pw.hi, pw.lo, pw.bias, pw.N, pw.K, pw.Kp = xh, xl, None, K, Mp, Mp
+    pw.hi, pw.lo, pw.bias, pw.N, pw.K, pw.Kp = xt[0], xt[1], None, K, Mp, Mp
     if K % 4 == 0:
-        dw = ops.linear(ops.Act(None, yh, yl), pw).f32
-    else:   # K = 5 / 7 / 14 position-feature layers: fp32-A kernel (any N); A = dY^T zero-padded to Mp columns
-        a = torch.zeros(N, Mp, dtype=torch.float32, device=dy2d.device)
-        a[:, :M] = dy2d.t()
-        dw = ops.linear(a, pw).f32
-    return dw, db
+        return ops.linear(ops.Act(None, yt[0], yt[1]), pw).f32
+    # K = 5 / 7 / 14 position-feature layers: fp32-A kernel (any N); A = dY^T zero-padded to Mp columns
+    a = torch.zeros(N, Mp, dtype=torch.float32, device=dy2d.device)
+    a[:, :M] = dy2d.t()
+    return ops.linear(a, pw).f32
 
 
 class _Linear(torch.autograd.Function):
+    """Each activation / gradient is read once per role pair: the forward's input split also emits X^T planes (saved
+    for dW instead of the fp32 input), the backward's dY pass emits row planes (dX GEMM), dY^T planes (dW GEMM) and db."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, residual, packs):
         K = x.shape[-1]
         ctx.packs = packs
         x2 = x.float().contiguous().view(-1, K)
         r2 = None if residual is None else residual.float().contiguous().view(-1, weight.shape[0])
-        y = _gemm(x2, packs(False), None if bias is None else bias.detach().float(), r2)
-        ctx.save_for_backward(x2, weight)
-        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
+        xt = None
+        a = x2
+        if need_w and K % 8 == 0:
+            xh, xl, _, Mp, rows = transpose_split(x2, want_rows=True)
+            xt, a = (xh, xl, Mp), rows
+        y = _gemm(a, packs(False), None if bias is None else bias.detach().float(), r2)
+        if xt is not None:
+            ctx.save_for_backward(xt[0], xt[1], weight)
+            ctx.Mp, ctx.saved_t = xt[2], True
+        else:
+            ctx.save_for_backward(x2, weight)
+            ctx.saved_t = False
+        ctx.has_bias, ctx.has_res, ctx.M = bias is not None, residual is not None, x2.shape[0]
         return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, weight = ctx.saved_tensors
+        weight = ctx.saved_tensors[-1]
         N, K = weight.shape
         dy2 = dy.contiguous().view(-1, N)
-        xm = x2
+        M = ctx.M
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         dx = dw = db = None
+        yh = yl = rows = None
+        if need_w:
+            yh, yl, db, Mp, rows = transpose_split(dy2, want_colsum=ctx.has_bias, want_rows=ctx.needs_input_grad[0])
         if ctx.needs_input_grad[0]:
-            dx = _gemm(dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = _gemm_tn(dy2, xm, ctx.has_bias)
-            dw = dw.to(weight.dtype)
+            dx = _gemm(rows if rows is not None else dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
+        if need_w:
+            if ctx.saved_t:
+                xt = (ctx.saved_tensors[0], ctx.saved_tensors[1])
+            else:
+                xh, xl, _, _, _ = transpose_split(ctx.saved_tensors[0])
+                xt = (xh, xl)
+            dw = _gemm_tn((yh, yl), xt, N, K, M, Mp, dy2).to(weight.dtype)
         return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None), None
 
 

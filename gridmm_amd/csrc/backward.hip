@@ -14,6 +14,8 @@ namespace {
 __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ X, int ldx,
                                                               unsigned short* __restrict__ Th,
                                                               unsigned short* __restrict__ Tl, float* __restrict__ colsum,
+                                                              unsigned short* __restrict__ Rh,
+                                                              unsigned short* __restrict__ Rl, int ldp,
                                                               int M, int C, int Mp) {
   __shared__ float tile[64][65];
   const int c0 = blockIdx.x * 64, m0 = blockIdx.y * 64, tid = threadIdx.x;
@@ -23,6 +25,23 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
     tile[r][c] = (m < M && cc < C) ? X[(size_t)m * ldx + cc] : 0.f;
   }
   __syncthreads();
+  if (Rh) {   // row-major planes of the same tile (the A operand of the dX / forward GEMM): thread -> (row, 16 columns)
+    const int r = tid >> 2, cc = (tid & 3) * 16;
+    if (m0 + r < M) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int c8 = c0 + cc + 8 * half;
+        if (c8 < ldp) {           // ldp % 8 == 0; columns in [C, ldp) are zero (tile zero-fills beyond C)
+          unsigned int hi[4], lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            split2_bf16(tile[r][cc + 8 * half + 2 * e], tile[r][cc + 8 * half + 2 * e + 1], hi[e], lo[e]);
+          *reinterpret_cast<uint4*>(Rh + (size_t)(m0 + r) * ldp + c8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          *reinterpret_cast<uint4*>(Rl + (size_t)(m0 + r) * ldp + c8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+      }
+    }
+  }
   // thread -> (column c = tid / 4, 16 rows starting at 16 * (tid % 4)): 16 consecutive m = 32 B per plane
   const int c = tid >> 2, r0 = (tid & 3) * 16;
   if (c0 + c < C) {
@@ -127,18 +146,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   }
 }
 
-// dgamma[c] = sum_blocks part[blk][0][c], dbeta likewise; one thread per column, fixed order (deterministic)
-__global__ void ln_param_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int nblk, int H) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
+// dgamma[c] = sum_blocks part[blk][0][c], dbeta likewise.  Block = 32 columns x 32 row-lanes: lane r sums blocks
+// r, r+32, ... (coalesced 128-B reads across the 32 columns), then a fixed-order LDS tree -> deterministic.
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int nblk, int H) {
+  __shared__ float s_g[32][33], s_b[32][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float g = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) {
-    g += part[((size_t)k * 2 + 0) * H + c];
-    b += part[((size_t)k * 2 + 1) * H + c];
+  if (c < H)
+    for (int k = ry; k < nblk; k += 32) {
+      g += part[((size_t)k * 2 + 0) * H + c];
+      b += part[((size_t)k * 2 + 1) * H + c];
+    }
+  s_g[ry][cx] = g;
+  s_b[ry][cx] = b;
+  __syncthreads();
+  if (ry == 0 && c < H) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) { sg += s_g[r][cx]; sb += s_b[r][cx]; }
+    dgamma[c] = sg;
+    dbeta[c] = sb;
   }
-  dgamma[c] = g;
-  dbeta[c] = b;
 }
 
 // mode 0: y = gelu_erf(x); mode 1: dx = dy * gelu'(x); mode 2: y = relu(x); mode 3: dx = dy * (x > 0)
@@ -167,14 +198,15 @@ __global__ void act_kernel(const float* __restrict__ X, const float* __restrict_
 
 }  // namespace
 
-extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, int M, int C,
-                                      int Mp, gridmm_stream_t stream) {
+extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, void* R_hi,
+                                      void* R_lo, int ldp, int M, int C, int Mp, gridmm_stream_t stream) {
   if (M <= 0 || C <= 0 || Mp < M || Mp % 32) return GRIDMM_EINVAL;
+  if (R_hi && (!R_lo || ldp < C || ldp % 8)) return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
   if (colsum && hipMemsetAsync(colsum, 0, (size_t)C * sizeof(float), st) != hipSuccess) return GRIDMM_ELAUNCH;
   dim3 grid((C + 63) / 64, (Mp + 63) / 64), block(256);
   GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)T_hi, (unsigned short*)T_lo,
-                colsum, M, C, Mp);
+                colsum, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -193,7 +225,7 @@ extern "C" int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int
   if (nv == 1) GRIDMM_LNB(1); else if (nv == 2) GRIDMM_LNB(2); else if (nv == 3) GRIDMM_LNB(3); else GRIDMM_LNB(4);
 #undef GRIDMM_LNB
   GRIDMM_CHECK_LAUNCH();
-  GRIDMM_LAUNCH(ln_param_reduce_kernel, dim3((H + 255) / 256), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, H);
+  GRIDMM_LAUNCH(ln_param_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, workspace, dgamma, dbeta, nblk, H);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, const T* 
   }
 }
 
-inline unsigned grid_for(size_t n) {
+inline unsigned grid_for(size_t n, size_t cap = 4096) {
   size_t b = (n + 255) / 256;
-  return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
+  return (unsigned)(b > cap ? cap : (b ? b : 1));
 }
 
 }  // namespace
@@ -63,8 +63,8 @@ inline unsigned grid_for(size_t n) {
 extern "C" int gridmm_grad_sumsq(const void* g, int64_t n, int dtype, float* acc, gridmm_stream_t stream) {
   if (n <= 0 || !acc || (dtype != 0 && dtype != 1)) return GRIDMM_EINVAL;
   hipStream_t st_ = as_stream(stream);
-  if (dtype == 0) GRIDMM_LAUNCH((sumsq_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st_, (const float*)g, (size_t)n, acc);
-  else GRIDMM_LAUNCH((sumsq_kernel<_Float16>), dim3(grid_for(n)), dim3(256), 0, st_, (const _Float16*)g, (size_t)n, acc);
+  if (dtype == 0) GRIDMM_LAUNCH((sumsq_kernel<float>), dim3(grid_for(n / 8, 512)), dim3(256), 0, st_, (const float*)g, (size_t)n, acc);   // <= 512 atomics on *acc
+  else GRIDMM_LAUNCH((sumsq_kernel<_Float16>), dim3(grid_for(n / 8, 512)), dim3(256), 0, st_, (const _Float16*)g, (size_t)n, acc);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -230,8 +230,10 @@ int gridmm_copy_rows(const float* src, int64_t src_bs, int src_rs, float* dst, i
  * plus colsum[C] = sum_m X[m][c] (NULL to skip).  With gridmm_linear_planes (C = A B^T) this gives
  *   dW [N][K] = dY^T X:  A = T(dY) [N][Mp], B = T(X) [K][Mp];   db = colsum(dY)
  * (backward of nn.Linear, e.g. vilmodel.py:84-86,128,144). */
-int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, int M, int C, int Mp,
-                           gridmm_stream_t stream);
+int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, void* R_hi, void* R_lo,
+                           int ldp, int M, int C, int Mp, gridmm_stream_t stream);
+/* (R_hi / R_lo, optional: the row-major planes [M][ldp] of the same X from the same pass -- the A operand of the
+ * forward / dX GEMM -- so an activation or a gradient is read ONCE for both of its GEMM roles) */
 
 /* Backward of y = LayerNorm(X (+ R)) * gamma + beta (BertLayerNorm / nn.LayerNorm, vilmodel.py:33,131,147).
  *   dX [M][H] (same gradient flows to R); dgamma, dbeta [H]; workspace >= ceil(M/4) * 2 * H floats. */
