@@ -11,56 +11,73 @@ namespace {
 
 // X fp32 [M][C] (row stride ldx) -> bf16 hi/lo planes [C][Mp] (Mp % 32 == 0, zero padded) and colsum[C]
 // 64 x 64 tiles through LDS; grid (ceil(C/64), ceil(Mp/64)).
+constexpr int TS_TILES = 4;   // 64-row tiles per workgroup (256 rows): 4x fewer column-sum atomics, loads of tile t+1
+                              // are in flight while tile t is split and stored
 __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ X, int ldx,
                                                               unsigned short* __restrict__ Th,
                                                               unsigned short* __restrict__ Tl, float* __restrict__ colsum,
                                                               unsigned short* __restrict__ Rh,
                                                               unsigned short* __restrict__ Rl, int ldp,
                                                               int M, int C, int Mp) {
-  __shared__ float tile[64][65];
-  const int c0 = blockIdx.x * 64, m0 = blockIdx.y * 64, tid = threadIdx.x;
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const int m = m0 + r, cc = c0 + c;
-    tile[r][c] = (m < M && cc < C) ? X[(size_t)m * ldx + cc] : 0.f;
-  }
-  __syncthreads();
-  if (Rh) {   // row-major planes of the same tile (the A operand of the dX / forward GEMM): thread -> (row, 16 columns)
-    const int r = tid >> 2, cc = (tid & 3) * 16;
-    if (m0 + r < M) {
+  __shared__ float tile[2][64][65];
+  const int c0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int lc = tid & 63, lr = tid >> 6;                 // load role: column lc, rows lr, lr+4, ...
+  const int c = tid >> 2, r0 = (tid & 3) * 16;            // transposed-store role: column c, 16 rows from r0
+  const int rr = tid >> 2, rc = (tid & 3) * 16;           // row-store role: row rr, 16 columns from rc
+  float v[16];
+  auto load = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + lr + 4 * i;
+      v[i] = (m < M && c0 + lc < C) ? X[(size_t)m * ldx + c0 + lc] : 0.f;
+    }
+  };
+  float s = 0.f;
+  const int mbase = blockIdx.y * 64 * TS_TILES;
+  load(mbase);
+  for (int t = 0; t < TS_TILES; ++t) {
+    const int m0 = mbase + 64 * t;
+    if (m0 >= Mp) break;
+    float(*tl)[65] = tile[t & 1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tl[lr + 4 * i][lc] = v[i];
+    __syncthreads();                                        // (the other buffer's readers finished one barrier ago)
+    if (t + 1 < TS_TILES && m0 + 64 < Mp) load(m0 + 64);    // next tile's global loads fly over the stores below
+    if (Rh && m0 + rr < M) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const int c8 = c0 + cc + 8 * half;
-        if (c8 < ldp) {           // ldp % 8 == 0; columns in [C, ldp) are zero (tile zero-fills beyond C)
+        const int c8 = c0 + rc + 8 * half;
+        if (c8 < ldp) {           // ldp % 8 == 0; columns in [C, ldp) are zero (the tile zero-fills beyond C)
           unsigned int hi[4], lo[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            split2_bf16(tile[r][cc + 8 * half + 2 * e], tile[r][cc + 8 * half + 2 * e + 1], hi[e], lo[e]);
-          *reinterpret_cast<uint4*>(Rh + (size_t)(m0 + r) * ldp + c8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-          *reinterpret_cast<uint4*>(Rl + (size_t)(m0 + r) * ldp + c8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            split2_bf16(tl[rr][rc + 8 * half + 2 * e], tl[rr][rc + 8 * half + 2 * e + 1], hi[e], lo[e]);
+          *reinterpret_cast<uint4*>(Rh + (size_t)(m0 + rr) * ldp + c8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          *reinterpret_cast<uint4*>(Rl + (size_t)(m0 + rr) * ldp + c8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
       }
     }
-  }
-  // thread -> (column c = tid / 4, 16 rows starting at 16 * (tid % 4)): 16 consecutive m = 32 B per plane
-  const int c = tid >> 2, r0 = (tid & 3) * 16;
-  if (c0 + c < C) {
-    float s = 0.f;
-    unsigned int hi[8], lo[8];
+    if (c0 + c < C) {
+      unsigned int hi[8], lo[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float a = tile[r0 + 2 * e][c], b = tile[r0 + 2 * e + 1][c];
-      s += a + b;
-      split2_bf16(a, b, hi[e], lo[e]);
+      for (int e = 0; e < 8; ++e) {
+        const float a = tl[r0 + 2 * e][c], b = tl[r0 + 2 * e + 1][c];
+        s += a + b;
+        split2_bf16(a, b, hi[e], lo[e]);
+      }
+      if (m0 + r0 < Mp) {
+        const size_t o = (size_t)(c0 + c) * Mp + m0 + r0;
+        uint4* ph = reinterpret_cast<uint4*>(Th + o);
+        uint4* pl = reinterpret_cast<uint4*>(Tl + o);
+        ph[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); ph[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+        pl[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); pl[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+      }
     }
-    if (m0 + r0 < Mp) {
-      const size_t o = (size_t)(c0 + c) * Mp + m0 + r0;
-      uint4* ph = reinterpret_cast<uint4*>(Th + o);
-      uint4* pl = reinterpret_cast<uint4*>(Tl + o);
-      ph[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); ph[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-      pl[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); pl[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-    }
-    if (colsum) atomicAdd(&colsum[c0 + c], s);   // <= Mp/16 partial sums per column
+  }
+  if (colsum) {            // the 4 row-groups of a column sit in adjacent lanes: one atomic per column and workgroup
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((tid & 3) == 0 && c0 + c < C) atomicAdd(&colsum[c0 + c], s);
   }
 }
 
@@ -204,7 +221,7 @@ extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void*
   if (R_hi && (!R_lo || ldp < C || ldp % 8)) return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
   if (colsum && hipMemsetAsync(colsum, 0, (size_t)C * sizeof(float), st) != hipSuccess) return GRIDMM_ELAUNCH;
-  dim3 grid((C + 63) / 64, (Mp + 63) / 64), block(256);
+  dim3 grid((C + 63) / 64, (Mp + 64 * TS_TILES - 1) / (64 * TS_TILES)), block(256);
   GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)T_hi, (unsigned short*)T_lo,
                 colsum, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp);
   GRIDMM_CHECK_LAUNCH();
