@@ -12,6 +12,7 @@ norm stays on the device, so a step issues no host synchronisation.
 import ctypes
 import math
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -46,25 +47,29 @@ class AdamW(torch.optim.Optimizer):
                 if p.grad is not None:
                     yield group, p
 
-    @torch.no_grad()
-    def grad_norm_sq(self):
-        """Device scalar: sum of squares of all gradients (fp32 accumulate)."""
-        lib = _lib.load()
-        acc = None
-        for _, p in self._live():
-            if acc is None:
-                acc = torch.zeros(1, dtype=torch.float32, device=p.device)
-            g = p.grad.contiguous()
-            _lib.check(lib.gridmm_grad_sumsq(_p(g), g.numel(), 0 if g.dtype == torch.float32 else 1, _p(acc), _stream()),
-                       "gridmm_grad_sumsq")
-        return acc
+    # ---- multi-tensor launch tables (fp32 tensors): one record per parameter, rebuilt every step on the host
+    # (gradient tensors are re-allocated by zero_grad) and shipped with ONE small H2D copy
+    _REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
+                     ("lr", "<f4"), ("step_size", "<f4"), ("eps", "<f4"), ("wd", "<f4")])
+    _CHUNK = 16384
+
+    def _tables(self, items, dev):
+        """items: list of (p, g, exp_avg, exp_avg_sq, lr, step_size, eps, wd) for contiguous fp32 tensors."""
+        rec = np.zeros(len(items), self._REC)
+        first = np.zeros(len(items) + 1, np.int32)
+        for i, (p, g, m, v, lr, ss, eps, wd) in enumerate(items):
+            rec[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, ss, eps, wd)
+            first[i + 1] = first[i] + -(-p.numel() // self._CHUNK)
+        blob = np.concatenate([rec.view(np.uint8), first.view(np.uint8)])
+        d = torch.from_numpy(blob).to(dev, non_blocking=True)
+        return d, rec.nbytes, int(first[-1])
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm=None):
         """max_grad_norm: fuse clip_grad_norm_(all parameters of this optimizer, max_grad_norm) into the update.
         Returns the (pre-clip) gradient norm as a device scalar when clipping, else None."""
         lib = _lib.load()
-        sumsq = self.grad_norm_sq() if max_grad_norm is not None else None
+        multi, single = [], []
         for group, p in self._live():
             if p.dtype not in (torch.float32, torch.float16) or not p.is_contiguous():
                 raise ValueError("AdamW: contiguous fp32 / fp16 parameters expected")
@@ -84,12 +89,40 @@ class AdamW(torch.optim.Optimizer):
             g = p.grad.contiguous()
             if g.dtype != p.dtype:
                 g = g.to(p.dtype)
-            _lib.check(lib.gridmm_adamw_step(
-                _p(p), _p(g), _p(state["exp_avg"]), _p(state["exp_avg_sq"]), p.numel(), 0 if p.dtype == torch.float32 else 1,
-                float(group["lr"]), float(b1), float(b2), float(eps), float(group["weight_decay"]),
-                float(step_size), int(bool(group["decay_first"])), _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
-                float(max_grad_norm or 0.0), _stream()), "gridmm_adamw_step")
-            _bump_version(p)
+            item = (p, g, state["exp_avg"], state["exp_avg_sq"], float(group["lr"]), float(step_size), float(eps),
+                    float(group["weight_decay"]), float(b1), float(b2), int(bool(group["decay_first"])))
+            (multi if p.dtype == torch.float32 else single).append(item)
+        if not multi and not single:
+            return None
+        dev = (multi or single)[0][0].device
+        # all fp32 tensors of one (betas, decay order) class go into one launch; the released configs have one class
+        classes = {}
+        for it in multi:
+            classes.setdefault(it[8:], []).append(it[:8])
+        tables = {k: self._tables(v, dev) for k, v in classes.items()}
+        sumsq = None
+        if max_grad_norm is not None:
+            sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+            part = torch.empty(64, dtype=torch.float32, device=dev)
+            tmp = torch.empty(1, dtype=torch.float32, device=dev)
+            for (blob, rec_bytes, n_chunks), items in zip(tables.values(), classes.values()):
+                _lib.check(lib.gridmm_multi_grad_sumsq(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
+                                                       n_chunks, _p(part), _p(tmp), _stream()), "gridmm_multi_grad_sumsq")
+                sumsq += tmp
+            for p, g, *_ in single:
+                _lib.check(lib.gridmm_grad_sumsq(_p(g), g.numel(), 1, _p(sumsq), _stream()), "gridmm_grad_sumsq")
+        for (b1, b2, df), items in classes.items():
+            blob, rec_bytes, n_chunks = tables[(b1, b2, df)]
+            _lib.check(lib.gridmm_multi_adamw_step(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
+                                                   n_chunks, b1, b2, df, _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
+                                                   float(max_grad_norm or 0.0), _stream()), "gridmm_multi_adamw_step")
+        for p, g, m, v, lr, ss, eps, wd, b1, b2, df in single:            # fp16 parameters (the pre-training grid_proj)
+            _lib.check(lib.gridmm_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), 1, lr, b1, b2, eps, wd, ss, df,
+                                             _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
+                                             float(max_grad_norm or 0.0), _stream()), "gridmm_adamw_step")
+        for it in multi + single:
+            _bump_version(it[0])
+        self._keepalive = (tables, multi, single)      # device tables / cast gradients must outlive the async launches
         return None if sumsq is None else sumsq.sqrt()
 
 

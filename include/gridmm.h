@@ -285,6 +285,16 @@ int gridmm_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, int d
                       float beta2, float eps, float weight_decay, float step_size, int decay_first,
                       const float* sumsq, float max_norm, gridmm_stream_t stream);
 
+/* Multi-tensor forms of the two kernels above for fp32 tensors: ONE launch over all parameters.
+ *   desc        device array of n_tensors records {float* p; const float* g; float* m; float* v; int64 n;
+ *               float lr, step_size, eps, weight_decay;}  (56 bytes, natural C layout)
+ *   chunk_first device int32 [n_tensors + 1]: prefix sums of ceil(n / 16384); n_chunks = chunk_first[n_tensors]
+ * gridmm_multi_grad_sumsq: partial64 = 64-float workspace, out = the global sum of squares (device scalar). */
+int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float* partial64,
+                            float* out, gridmm_stream_t stream);
+int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float beta1,
+                            float beta2, int decay_first, const float* sumsq, float max_norm, gridmm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
