@@ -65,6 +65,7 @@ class _WeightCache:
 
 
 WEIGHTS = _WeightCache()
+SPLITK_OFF = bool(int(__import__('os').environ.get('GRIDMM_SPLITK_OFF', '0')))   # A/B switch for tools/bench_train.py
 
 
 def _as2d(x):
@@ -106,6 +107,19 @@ def _gemm_tn(yt, xt, N, K, M, Mp, dy2d):
     pw = ops.PackedLinear.__new__(ops.PackedLinear)
     pw.hi, pw.lo, pw.bias, pw.N, pw.K, pw.Kp = xt[0], xt[1], None, K, Mp, Mp
     if K % 4 == 0:
+        # few output tiles, long contraction: split the M rows over enough workgroups to fill the chip
+        tiles = -(-N // 128) * -(-K // 128)
+        # measured (profiles/README.md, split-K): only the 768x768 outputs gain (70 -> 47 us at 6912 rows, 52 -> 20 us at 1824)
+        splits = max(1, min(8, 288 // tiles, Mp // 256)) if tiles <= 36 else 1
+        if SPLITK_OFF:
+            splits = 1
+        if splits > 1:
+            lib = _lib.load()
+            dw = torch.empty(N, K, dtype=torch.float32, device=dy2d.device)
+            ws = torch.empty(splits, N, K, dtype=torch.float32, device=dy2d.device)
+            _lib.check(lib.gridmm_linear_planes_splitk(_p(yt[0]), _p(yt[1]), Mp, _p(xt[0]), _p(xt[1]), Mp, _p(dw), _p(ws),
+                                                       N, K, Mp, splits, _stream()), "gridmm_linear_planes_splitk")
+            return dw
         return ops.linear(ops.Act(None, yt[0], yt[1]), pw).f32
     # K = 5 / 7 / 14 position-feature layers: fp32-A kernel (any N); A = dY^T zero-padded to Mp columns
     a = torch.zeros(N, Mp, dtype=torch.float32, device=dy2d.device)

@@ -118,7 +118,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / BK;
+  // split-K (gridDim.y > 1, TR kernels only): workgroup (tile, blockIdx.y) contracts k-steps [k0, k0 + nk) and writes
+  // its partial tile to slice blockIdx.y of a workspace (summed by sum_splits_kernel) -- for the weight-gradient
+  // GEMMs, whose output is small (N x K of a Linear) and whose contraction is the whole batch (thousands of rows):
+  // without it only N*K/(BM*BN) workgroups exist, each walking hundreds of k-steps.
+  int nk = K / BK;
+  if (gridDim.y > 1) {
+    const int per = (nk + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per;
+    nk = max(0, min(per, nk - k0));
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) src[i] += (size_t)k0 * BK;
+  }
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) {
@@ -276,6 +286,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = bm + wr * WM + i * 16 + mrow;
+        if (gridDim.y > 1) {            // split-K partial -> its own slice of the workspace (plain stores)
+          if (m < M && n0 < N)
+            *reinterpret_cast<float4*>(C + (size_t)blockIdx.y * M * ldc + (size_t)m * ldc + n0) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          continue;
+        }
         if (m < M && n0 < N) {
           float x[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
 #pragma unroll
@@ -378,8 +394,9 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
 template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
-           unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st) {
-  dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM)), block((BM / WM) * (BN / WN) * 64);
+           unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
+           int ksplit = 1) {
+  dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM), ksplit), block((BM / WM) * (BN / WN) * 64);
 #define GRIDMM_LP(ACT)                                                                                        \
   GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
                 Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K)
@@ -392,6 +409,48 @@ int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const 
 }
 
 }  // namespace
+
+namespace {
+__global__ void sum_splits_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4, int splits) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(ws)[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(ws)[(size_t)s * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+}
+}  // namespace
+
+// C (fp32, M x N, contiguous) = A W^T with the contraction split over `splits` workgroups per tile; the partial
+// tiles go to `workspace` (splits x M x N floats) and are summed in a fixed order (deterministic).
+// For GEMMs with a small output and a long contraction: the weight gradients dW = dY^T X of training.
+extern "C" int gridmm_linear_planes_splitk(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
+                                           const void* W_lo, int Kp, float* C, float* workspace, int M, int N, int K,
+                                           int splits, gridmm_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || !C || !workspace || splits < 2 || splits > 64)
+    return GRIDMM_EINVAL;
+  if ((K / 32) < splits) return GRIDMM_EINVAL;   // every split needs at least one k-step
+  hipStream_t st = as_stream(stream);
+  const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
+  const unsigned short *wh = (const unsigned short*)W_hi, *wl = (const unsigned short*)W_lo;
+  // 128x128 (16 waves) when the tiles x splits still fill the chip, else 64x64
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
+  int rc;
+  if (t128 >= 200)
+    rc = launch<128, 128, 32, 32, 2, 32, 0, 0, 1>(ah, al, lda, wh, wl, Kp, nullptr, nullptr, 0, workspace, N, nullptr, nullptr,
+                                                  0, M, N, K, 0, st, splits);
+  else
+    rc = launch<64, 64, 32, 32, 2, 32, 0, 0, 1>(ah, al, lda, wh, wl, Kp, nullptr, nullptr, 0, workspace, N, nullptr, nullptr, 0,
+                                                M, N, K, 0, st, splits);
+  if (rc != GRIDMM_OK) return rc;
+  const size_t n4 = (size_t)M * N / 4;
+  GRIDMM_LAUNCH(sum_splits_kernel, dim3((unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256)), dim3(256), 0, st,
+                workspace, C, n4, splits);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
 
 extern "C" int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, int ldp, int M, int K,
                                  gridmm_stream_t stream) {

@@ -285,6 +285,14 @@ int gridmm_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, int d
                       float beta2, float eps, float weight_decay, float step_size, int decay_first,
                       const float* sumsq, float max_norm, gridmm_stream_t stream);
 
+/* C (fp32, M x N, contiguous) = A W^T like gridmm_linear_planes, with the contraction split over `splits` (2..64)
+ * workgroups per output tile; partial tiles go to `workspace` (splits * M * N floats) and are summed in a fixed order
+ * (deterministic; no bias / activation / planes).  For the weight-gradient GEMMs dW = dY^T X: small output,
+ * contraction over all rows of the batch. */
+int gridmm_linear_planes_splitk(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
+                                int Kp, float* C, float* workspace, int M, int N, int K, int splits,
+                                gridmm_stream_t stream);
+
 /* Multi-tensor forms of the two kernels above for fp32 tensors: ONE launch over all parameters.
  *   desc        device array of n_tensors records {float* p; const float* g; float* m; float* v; int64 n;
  *               float lr, step_size, eps, weight_decay;}  (56 bytes, natural C layout)
