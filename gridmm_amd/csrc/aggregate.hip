@@ -169,16 +169,29 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
   // LDS-DMA of tile t: wave w moves rows w, w+nwaves, ... (always RW of them: short waves / short tiles
   // repeat a valid row, so the in-order vmcnt bookkeeping is the same for every wave and tile).
   // Position c of row r holds global chunk c ^ (r & 15).
-  auto dma_tile = [&](int t) {
-    _Float16* dst = s_tiles + (size_t)(t % R) * TILE * D;
+  // Row ids: scalar loads (wave-uniform addresses), so nothing joins the in-order vector-memory queue behind the DMA
+  // bursts -- but fetched a whole tile AHEAD of the DMA that consumes them, all RW of a wave back to back: a per-row
+  // load-then-issue chain would put an L2 round trip in front of every DMA instruction.
+  constexpr int RWMAX = 8;                                   // TILE / min(nwaves = 4)
+  auto load_rows = [&](int t, int (&ids)[RWMAX]) {
     const int p0 = p_lo + t * TILE;
-    for (int j = 0; j < RW; ++j) {
+#pragma unroll
+    for (int j = 0; j < RWMAX; ++j) {
       int r = wave + j * nwaves;
       if (r >= TILE) r = wave;
       int p = p0 + r;
       if (p >= p_hi) p = p_hi - 1;
-      const int src = __builtin_amdgcn_readfirstlane(perm_b[p]);   // wave-uniform address -> scalar load
-      const _Float16* row = slab_b + (size_t)src * D;
+      ids[j] = (j < RW) ? __builtin_amdgcn_readfirstlane(perm_b[p]) : 0;
+    }
+  };
+  auto dma_tile = [&](int t, const int (&ids)[RWMAX]) {
+    _Float16* dst = s_tiles + (size_t)(t % R) * TILE * D;
+#pragma unroll
+    for (int j = 0; j < RWMAX; ++j) {
+      if (j >= RW) break;
+      int r = wave + j * nwaves;
+      if (r >= TILE) r = wave;
+      const _Float16* row = slab_b + (size_t)ids[j] * D;
 #pragma unroll
       for (int c0 = 0; c0 < NCH; c0 += 64) {
         const int c = c0 + lane;
@@ -195,8 +208,10 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
   };
 
   __syncthreads();                                  // s_cs visible
-  for (int t = 0; t < R - 1 && t < ntiles; ++t) dma_tile(t);
+  int ids[RWMAX];
+  for (int t = 0; t < R - 1 && t < ntiles; ++t) { load_rows(t, ids); dma_tile(t, ids); }
   const int keep = (R - 2) * RW * IPR;              // DMA instructions allowed to stay in flight
+  if (R - 1 < ntiles) load_rows(R - 1, ids);        // row ids of the next tile to issue
 
   for (int t = 0; t < ntiles; ++t) {
     const int p0 = p_lo + t * TILE;
@@ -205,7 +220,10 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     // ---- 1. retire tile t (counted wait: the R-2 younger tiles stay in flight), publish it, issue tile t+R-1
     if (t + R - 2 < ntiles) wait_vm_dyn(keep); else wait_vm<0>();
     lds_barrier();
-    if (t + R - 1 < ntiles) dma_tile(t + R - 1);    // its slot held tile t-1: free since the barrier above
+    if (t + R - 1 < ntiles) {                       // its slot held tile t-1: free since the barrier above
+      dma_tile(t + R - 1, ids);
+      if (t + R < ntiles) load_rows(t + R, ids);    // lands during this tile's compute
+    }
     if (tid < TILE) {                               // cell of each point of this tile (binary search on LDS)
       int cell = -1;
       const int p = p0 + tid;
@@ -222,41 +240,57 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     // ---- 2. relevance on the matrix pipe
     for (int ct = wave; ct < Lt; ct += nwaves) {
       const int i = lane & 15, g = lane >> 4;
-      const bool two = npt > 16;
       f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+      // Both 16-row halves always (rows past npt hold a repeated valid row, masked below): no branch in the k loop, and
+      // the A fragments of group q+1 (GK k-steps x 2 halves) are read from LDS while group q is in the matrix pipe.
+      constexpr int GK = 4;
+      static_assert(KS % GK == 0, "k-steps per group");
+      const f16x8_t* row0 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)i * D);
+      const f16x8_t* row1 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(16 + i) * D);
+      f16x8_t fa[2][GK], fb[2][GK];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        f16x8_t bh, bl;
-        if (RESIDENT) {
-          bh = thi[RESIDENT ? ks : 0];
-          bl = tlo[RESIDENT ? ks : 0];
-        } else {
-          bh = *reinterpret_cast<const f16x8_t*>(tf_b + ((size_t)ct * KS + ks) * 64 * 8);
-          bl = *reinterpret_cast<const f16x8_t*>(tf_b + plane + ((size_t)ct * KS + ks) * 64 * 8);
+      for (int u = 0; u < GK; ++u) { fa[0][u] = row0[(u * 4 + g) ^ i]; fb[0][u] = row1[(u * 4 + g) ^ i]; }
+#pragma unroll
+      for (int q = 0; q < KS / GK; ++q) {
+        if (q + 1 < KS / GK) {
+#pragma unroll
+          for (int u = 0; u < GK; ++u) {
+            fa[(q + 1) & 1][u] = row0[(((q + 1) * GK + u) * 4 + g) ^ i];
+            fb[(q + 1) & 1][u] = row1[(((q + 1) * GK + u) * 4 + g) ^ i];
+          }
         }
-        const int ch = ks * 4 + g;
-        const f16x8_t a0 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)i * D)[ch ^ i];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl, acc0, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, acc2, 0, 0, 0);
-        if (two) {
-          const f16x8_t a1 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(16 + i) * D)[ch ^ i];
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc1, 0, 0, 0);
-          acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc3, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < GK; ++u) {
+          const int ks = q * GK + u;
+          f16x8_t bh, bl;
+          if (RESIDENT) {
+            bh = thi[RESIDENT ? ks : 0];
+            bl = tlo[RESIDENT ? ks : 0];
+          } else {
+            bh = *reinterpret_cast<const f16x8_t*>(tf_b + ((size_t)ct * KS + ks) * 64 * 8);
+            bl = *reinterpret_cast<const f16x8_t*>(tf_b + plane + ((size_t)ct * KS + ks) * 64 * 8);
+          }
+          // text fragment as the A operand: the tile comes out transposed, lane (point = lane & 15, g) holds text
+          // columns 4g .. 4g+3, so the max over columns is 3 in-register ops + 2 cross-lane steps (was 16 ds_bpermute
+          // round trips per wave and tile with the points along the registers)
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, fa[q & 1][u], acc0, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, fa[q & 1][u], acc2, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, fb[q & 1][u], acc1, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, fb[q & 1][u], acc3, 0, 0, 0);
         }
       }
-      const bool colv = (ct * 16 + i) < L;
+      float x0 = NEG_BIG, x1 = NEG_BIG;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x0 = colv ? acc0[r] + acc2[r] : NEG_BIG, x1 = colv ? acc1[r] + acc3[r] : NEG_BIG;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          x0 = fmaxf(x0, __shfl_xor(x0, o, 64));
-          x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
-        }
-        if (i == 0) {
-          s_wmax[ct * TILE + g * 4 + r] = x0;
-          s_wmax[ct * TILE + 16 + g * 4 + r] = x1;
-        }
+        const bool colv = (ct * 16 + 4 * g + r) < L;
+        x0 = fmaxf(x0, colv ? acc0[r] + acc2[r] : NEG_BIG);
+        x1 = fmaxf(x1, colv ? acc1[r] + acc3[r] : NEG_BIG);
+      }
+      x0 = fmaxf(x0, __shfl_xor(x0, 16, 64)); x1 = fmaxf(x1, __shfl_xor(x1, 16, 64));
+      x0 = fmaxf(x0, __shfl_xor(x0, 32, 64)); x1 = fmaxf(x1, __shfl_xor(x1, 32, 64));
+      if (g == 0) {
+        s_wmax[ct * TILE + i] = x0;
+        s_wmax[ct * TILE + 16 + i] = x1;
       }
     }
     lds_barrier();
