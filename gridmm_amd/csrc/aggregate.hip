@@ -345,6 +345,32 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
           for (int a = 0; a < NACC; ++a) v0[a] = v1[a] = 0.f;
         }
         int r = r0;
+        for (; r + 8 <= r1; r += 8) {          // 8 rows per group: all 16 LDS reads issued before the first FMA
+          float e[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) e[u] = s_e[r + u];
+#pragma unroll
+          for (int a = 0; a < NACC; ++a) {
+            const int dp = tid + a * nthreads;
+            if (dp < D / 2) {
+              f16x2_t h[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int ch = (dp >> 2) ^ ((r + u) & 15);
+                h[u] = *reinterpret_cast<const f16x2_t*>(s_tile + (size_t)(r + u) * D + ch * 8 + (dp & 3) * 2);
+              }
+              float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;      // two accumulation chains per dim
+#pragma unroll
+              for (int u = 0; u < 8; u += 2) {
+                a0 += e[u] * (float)h[u][0];         a1 += e[u] * (float)h[u][1];
+                b0 += e[u + 1] * (float)h[u + 1][0]; b1 += e[u + 1] * (float)h[u + 1][1];
+              }
+              v0[a] += a0 + b0;
+              v1[a] += a1 + b1;
+            }
+          }
+          s_run += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+        }
         for (; r + 4 <= r1; r += 4) {          // 4 independent LDS reads in flight per slot
           float e[4];
 #pragma unroll
