@@ -21,7 +21,7 @@
 namespace {
 
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-constexpr int TILE = 32;
+constexpr int TILE_SMALL = 32, TILE_BIG = 64;   // points per ring slot: 64 when two slots fit the LDS (D <= 512)
 constexpr float NEG_BIG = -3.0e38f;
 
 __global__ void text_fragments_kernel(const float* __restrict__ text, _Float16* __restrict__ frag, int B,
@@ -91,7 +91,7 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {  // n = (R-2) * rows-per-wa
   }
 }
 
-template <int KS, bool RESIDENT, int R>  // D = 32 * KS, R ring slots
+template <int KS, bool RESIDENT, int R, int TILE>  // D = 32 * KS, R ring slots of TILE points
 __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     const _Float16* __restrict__ slab, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ cell_start, const _Float16* __restrict__ text_frag,
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
   // Row ids: scalar loads (wave-uniform addresses), so nothing joins the in-order vector-memory queue behind the DMA
   // bursts -- but fetched a whole tile AHEAD of the DMA that consumes them, all RW of a wave back to back: a per-row
   // load-then-issue chain would put an L2 round trip in front of every DMA instruction.
-  constexpr int RWMAX = 8;                                   // TILE / min(nwaves = 4)
+  constexpr int RWMAX = TILE / 4;                            // TILE / min(nwaves = 4)
   auto load_rows = [&](int t, int (&ids)[RWMAX]) {
     const int p0 = p_lo + t * TILE;
 #pragma unroll
@@ -245,8 +245,10 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
       // the A fragments of group q+1 (GK k-steps x 2 halves) are read from LDS while group q is in the matrix pipe.
       constexpr int GK = 4;
       static_assert(KS % GK == 0, "k-steps per group");
-      const f16x8_t* row0 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)i * D);
-      const f16x8_t* row1 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(16 + i) * D);
+      for (int hp = 0; hp < TILE / 32; ++hp) {   // 32 points (two 16-row MFMA tiles) per pass
+      acc0 = acc1 = acc2 = acc3 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const f16x8_t* row0 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(hp * 32 + i) * D);
+      const f16x8_t* row1 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(hp * 32 + 16 + i) * D);
       f16x8_t fa[2][GK], fb[2][GK];
 #pragma unroll
       for (int u = 0; u < GK; ++u) { fa[0][u] = row0[(u * 4 + g) ^ i]; fb[0][u] = row1[(u * 4 + g) ^ i]; }
@@ -289,8 +291,9 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
       x0 = fmaxf(x0, __shfl_xor(x0, 16, 64)); x1 = fmaxf(x1, __shfl_xor(x1, 16, 64));
       x0 = fmaxf(x0, __shfl_xor(x0, 32, 64)); x1 = fmaxf(x1, __shfl_xor(x1, 32, 64));
       if (g == 0) {
-        s_wmax[ct * TILE + i] = x0;
-        s_wmax[ct * TILE + 16 + i] = x1;
+        s_wmax[ct * TILE + hp * 32 + i] = x0;
+        s_wmax[ct * TILE + hp * 32 + 16 + i] = x1;
+      }
       }
     }
     lds_barrier();
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
       if (lane == 0) {
         s_state[0] = (c == cur) ? expf(m_run - m) : 1.0f;      // rescale of the running cell
         reinterpret_cast<unsigned int*>(s_state)[2] = (unsigned int)heads;
+        reinterpret_cast<unsigned int*>(s_state)[3] = (unsigned int)(heads >> 32);
       }
       if (lane == npt - 1) s_state[1] = m;                      // maximum of the last cell
     }
@@ -327,16 +331,17 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     // ---- 3b. accumulate rows, one contiguous run (cell) at a time; 2 feature dims per thread per NACC slot
     {
       const float sc = s_state[0];
-      unsigned int heads = reinterpret_cast<const unsigned int*>(s_state)[2];
+      unsigned long long heads = (unsigned long long)reinterpret_cast<const unsigned int*>(s_state)[2] |
+                                 ((unsigned long long)reinterpret_cast<const unsigned int*>(s_state)[3] << 32);
       if (cur >= 0 && s_cell[0] == cur) {
         s_run *= sc;
 #pragma unroll
         for (int a = 0; a < NACC; ++a) { v0[a] *= sc; v1[a] *= sc; }
       }
       while (heads) {
-        const int r0 = __builtin_ctz(heads);
+        const int r0 = __builtin_ctzll(heads);
         heads &= heads - 1;
-        const int r1 = heads ? __builtin_ctz(heads) : npt;
+        const int r1 = heads ? __builtin_ctzll(heads) : npt;
         const int c = s_cell[r0];
         if (c != cur) {
           flush();
@@ -443,12 +448,13 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
   const bool resident = Lt <= 8;
   const int nwaves = resident ? (Lt < 4 ? 4 : Lt) : 8;
   dim3 grid(n_chunks, B), block(nwaves * 64);
-  const int R = D <= 512 ? 4 : 3;  // ring slots: 4 x 32 KB (D=512) / 3 x 48 KB (D=768)
+  // ring: 2 x 64 points (D <= 512: 2 x 64 KB) or 3 x 32 points (D = 768: 3 x 48 KB)
+  const int TILE = D <= 512 ? TILE_BIG : TILE_SMALL, R = D <= 512 ? 2 : 3;
   const size_t lds = (size_t)R * TILE * D * 2 + ((size_t)Lt * TILE + 2 * TILE) * sizeof(float) +
                      TILE * sizeof(int) + 4 * sizeof(float) + 200 * sizeof(int);
 #define GRIDMM_AGG_ONE(KS, RES)                                                                                   \
   do {                                                                                                            \
-    auto kern = grid_aggregate_kernel<KS, RES, (KS <= 16 ? 4 : 3)>;                                               \
+    auto kern = grid_aggregate_kernel<KS, RES, (KS <= 16 ? 2 : 3), (KS <= 16 ? TILE_BIG : TILE_SMALL)>;                                               \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                             (int)lds) != hipSuccess)                                                              \
       return GRIDMM_EINVAL;                                                                                       \
