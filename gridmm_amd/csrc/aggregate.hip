@@ -207,6 +207,10 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     __builtin_amdgcn_s_barrier();
   };
 
+  // Retire every ordinary vector load (text fragments, cell_start) HERE, with a waitcnt the compiler can see: otherwise
+  // its scoreboard carries them into the loop and guards the first fragment use of every iteration with
+  // s_waitcnt vmcnt(0) -- which also waits for the LDS-DMA of the NEXT tile, i.e. serialises the stream with the compute.
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                                  // s_cs visible
   int ids[RWMAX];
   for (int t = 0; t < R - 1 && t < ntiles; ++t) { load_rows(t, ids); dma_tile(t, ids); }
