@@ -201,3 +201,26 @@ def test_panorama_with_object_tokens_matches_reference_golden(tag):
     (pano2 * pm2.unsqueeze(-1)).sum().backward()
     g = m.img_embeddings.obj_linear.weight.grad if tag == "own" else m.img_embeddings.img_linear.weight.grad
     assert g is not None and torch.isfinite(g).all()
+
+
+def test_empty_and_degenerate_grid_memories_match_oracle():
+    """Edge cases of the aggregation (vilmodel.py:797-823): an episode whose points are ALL outside the map (no occupied
+    cell: the sequence is the gmap nodes only), one with every point in a single cell, one with a single point, next to
+    a normal one -- logits against the oracle (which follows the reference's loops literally)."""
+    fx = load_golden("nav_reduced.npz")
+    model, sd = _model(fx)
+    cpu = golden_nav_batch(fx)
+    rs = np.random.RandomState(11)
+    B = cpu["txt_embeds"].shape[0]
+    assert B == 3
+    fts = [torch.from_numpy((rs.standard_normal((n, 768)) * 0.35).astype(np.float16)) for n in (64, 200, 1)]
+    maps = [torch.full((64,), -1.0, dtype=torch.float64),          # nothing inside the 14x14 window
+            torch.full((200,), 77.0, dtype=torch.float64),         # one crowded cell
+            torch.tensor([195.0], dtype=torch.float64)]            # a single point in the last cell
+    cpu["grid_fts"], cpu["grid_map"] = fts, maps
+    with torch.no_grad():
+        want = O.forward_navigation(sd, cpu)
+        got = model("navigation", _to_dev(cpu))
+    for k in ("global_logits", "local_logits", "fused_logits", "grid_logits"):
+        _cmp(got[k], want[k].numpy(), LOGIT_TOL)
+    _cmp(got["gmap_embeds"], want["gmap_embeds"].numpy(), EMBED_TOL)
