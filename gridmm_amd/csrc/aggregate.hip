@@ -169,29 +169,23 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
   // LDS-DMA of tile t: wave w moves rows w, w+nwaves, ... (always RW of them: short waves / short tiles
   // repeat a valid row, so the in-order vmcnt bookkeeping is the same for every wave and tile).
   // Position c of row r holds global chunk c ^ (r & 15).
-  // Row ids: scalar loads (wave-uniform addresses), so nothing joins the in-order vector-memory queue behind the DMA
-  // bursts -- but fetched a whole tile AHEAD of the DMA that consumes them, all RW of a wave back to back: a per-row
-  // load-then-issue chain would put an L2 round trip in front of every DMA instruction.
-  constexpr int RWMAX = TILE / 4;                            // TILE / min(nwaves = 4)
-  auto load_rows = [&](int t, int (&ids)[RWMAX]) {
-    const int p0 = p_lo + t * TILE;
-#pragma unroll
-    for (int j = 0; j < RWMAX; ++j) {
-      int r = wave + j * nwaves;
-      if (r >= TILE) r = wave;
-      int p = p0 + r;
-      if (p >= p_hi) p = p_hi - 1;
-      ids[j] = (j < RW) ? __builtin_amdgcn_readfirstlane(perm_b[p]) : 0;
-    }
+  // Row ids of a tile: ONE vector load per wave (lane l <- perm[p0 + l]), issued a whole iteration before the DMA that
+  // consumes it and BEFORE that iteration's DMA batch (so the counted vmcnt at the next loop top, which lets the
+  // younger DMA batches fly, already covers it); each row's address is then a v_readlane away.  Per-row scalar loads
+  // put an L2 round trip (~0.4 us) in front of every one of the ~13 DMA instructions a wave issues per tile: measured
+  // 5 us per tile of pure skeleton time with compute and DMA both ablated.
+  auto load_ids = [&](int t) -> int {
+    int p = p_lo + t * TILE + (lane & (TILE - 1));
+    if (p >= p_hi) p = p_hi - 1;
+    return perm_b[p];
   };
-  auto dma_tile = [&](int t, const int (&ids)[RWMAX]) {
+  auto dma_tile = [&](int t, int idv) {
     _Float16* dst = s_tiles + (size_t)(t % R) * TILE * D;
-#pragma unroll
-    for (int j = 0; j < RWMAX; ++j) {
-      if (j >= RW) break;
+    for (int j = 0; j < RW; ++j) {
       int r = wave + j * nwaves;
       if (r >= TILE) r = wave;
-      const _Float16* row = slab_b + (size_t)ids[j] * D;
+      const int src = __builtin_amdgcn_readlane(idv, r);     // rows past the end repeat the last valid row (load_ids)
+      const _Float16* row = slab_b + (size_t)src * D;
 #pragma unroll
       for (int c0 = 0; c0 < NCH; c0 += 64) {
         const int c = c0 + lane;
@@ -212,10 +206,9 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
   // s_waitcnt vmcnt(0) -- which also waits for the LDS-DMA of the NEXT tile, i.e. serialises the stream with the compute.
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();                                  // s_cs visible
-  int ids[RWMAX];
-  for (int t = 0; t < R - 1 && t < ntiles; ++t) { load_rows(t, ids); dma_tile(t, ids); }
+  for (int t = 0; t < R - 1 && t < ntiles; ++t) dma_tile(t, load_ids(t));
   const int keep = (R - 2) * RW * IPR;              // DMA instructions allowed to stay in flight
-  if (R - 1 < ntiles) load_rows(R - 1, ids);        // row ids of the next tile to issue
+  int idv = (R - 1 < ntiles) ? load_ids(R - 1) : 0; // row ids of the next tile to issue
 
   for (int t = 0; t < ntiles; ++t) {
     const int p0 = p_lo + t * TILE;
@@ -225,8 +218,9 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     if (t + R - 2 < ntiles) wait_vm_dyn(keep); else wait_vm<0>();
     lds_barrier();
     if (t + R - 1 < ntiles) {                       // its slot held tile t-1: free since the barrier above
-      dma_tile(t + R - 1, ids);
-      if (t + R < ntiles) load_rows(t + R, ids);    // lands during this tile's compute
+      const int idn = (t + R < ntiles) ? load_ids(t + R) : 0;   // older than the DMA batch below in the vmcnt queue
+      dma_tile(t + R - 1, idv);
+      idv = idn;
     }
     if (tid < TILE) {                               // cell of each point of this tile (binary search on LDS)
       int cell = -1;
@@ -301,13 +295,19 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
       }
     }
     lds_barrier();
-    // ---- 3a. (wave 0) per-point relevance; points are sorted by cell, so a cell is a contiguous run of lanes:
-    //          segmented max by shuffles, softmax numerators against the (running / in-tile) cell maximum
-    if (wave == 0) {
+    // ---- 3a. per-point relevance and softmax numerators, computed by EVERY wave for itself (lane = point): the
+    //          results stay in registers (broadcast by v_readlane in 3b), so there is no LDS hand-off and no third
+    //          barrier.  Points are sorted by cell: a cell is a contiguous run of lanes -> segmented max by shuffles.
+    float e_lane, m_last, sc;
+    int c_lane;
+    unsigned long long heads;
+    {
       float w = NEG_BIG;
       if (lane < TILE)
         for (int q = 0; q < Lt; ++q) w = fmaxf(w, s_wmax[q * TILE + lane]);
-      if (relevance && lane < npt) relevance[(size_t)b * cap + perm_b[p0 + lane]] = w;   // tests only
+      // by SORTED position (no perm load here: a vector load inside the loop would put every later LDS access of the
+      // iteration behind a compiler-inserted s_waitcnt vmcnt(0), i.e. behind the next tile's DMA)
+      if (relevance && wave == 0 && lane < npt) relevance[(size_t)b * cap + p0 + lane] = w;
       const int c = (lane < npt) ? s_cell[lane] : -2 - lane;   // unique sentinel: never joins a run
       if (lane >= npt) w = NEG_BIG;
       float pre = w, suf = w;
@@ -322,22 +322,20 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
       if (c == cur) m = fmaxf(m, m_run);                       // the run continuing from the previous tile
       const int cprev = __shfl_up(c, 1, 64);
       const bool head = (lane < npt) && (lane == 0 || cprev != c);
-      const unsigned long long heads = __ballot(head);
-      if (lane < TILE) s_e[lane] = (lane < npt) ? expf(w - m) : 0.f;
-      if (lane == 0) {
-        s_state[0] = (c == cur) ? expf(m_run - m) : 1.0f;      // rescale of the running cell
-        reinterpret_cast<unsigned int*>(s_state)[2] = (unsigned int)heads;
-        reinterpret_cast<unsigned int*>(s_state)[3] = (unsigned int)(heads >> 32);
-      }
-      if (lane == npt - 1) s_state[1] = m;                      // maximum of the last cell
+      heads = __ballot(head);
+      e_lane = (lane < npt) ? expf(w - m) : 0.f;
+      c_lane = c;
+      const float m0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+      const int c0 = __builtin_amdgcn_readfirstlane(c);
+      sc = (c0 == cur) ? expf(m_run - m0) : 1.0f;              // rescale of the running cell
+      m_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), npt - 1));
     }
-    lds_barrier();
+    auto e_of = [&](int r) -> float {                          // r is wave-uniform
+      return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_lane), r));
+    };
     // ---- 3b. accumulate rows, one contiguous run (cell) at a time; 2 feature dims per thread per NACC slot
     {
-      const float sc = s_state[0];
-      unsigned long long heads = (unsigned long long)reinterpret_cast<const unsigned int*>(s_state)[2] |
-                                 ((unsigned long long)reinterpret_cast<const unsigned int*>(s_state)[3] << 32);
-      if (cur >= 0 && s_cell[0] == cur) {
+      if (cur >= 0 && __builtin_amdgcn_readfirstlane(c_lane) == cur) {
         s_run *= sc;
 #pragma unroll
         for (int a = 0; a < NACC; ++a) { v0[a] *= sc; v1[a] *= sc; }
@@ -346,7 +344,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
         const int r0 = __builtin_ctzll(heads);
         heads &= heads - 1;
         const int r1 = heads ? __builtin_ctzll(heads) : npt;
-        const int c = s_cell[r0];
+        const int c = __builtin_amdgcn_readlane(c_lane, r0);
         if (c != cur) {
           flush();
           cur = c; s_run = 0.f;
@@ -357,7 +355,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
         for (; r + 8 <= r1; r += 8) {          // 8 rows per group: all 16 LDS reads issued before the first FMA
           float e[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) e[u] = s_e[r + u];
+          for (int u = 0; u < 8; ++u) e[u] = e_of(r + u);
 #pragma unroll
           for (int a = 0; a < NACC; ++a) {
             const int dp = tid + a * nthreads;
@@ -383,7 +381,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
         for (; r + 4 <= r1; r += 4) {          // 4 independent LDS reads in flight per slot
           float e[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) e[u] = s_e[r + u];
+          for (int u = 0; u < 4; ++u) e[u] = e_of(r + u);
 #pragma unroll
           for (int a = 0; a < NACC; ++a) {
             const int dp = tid + a * nthreads;
@@ -404,7 +402,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
           s_run += (e[0] + e[1]) + (e[2] + e[3]);
         }
         for (; r < r1; ++r) {
-          const float e = s_e[r];
+          const float e = e_of(r);
           s_run += e;
 #pragma unroll
           for (int a = 0; a < NACC; ++a) {
@@ -418,7 +416,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
           }
         }
       }
-      m_run = s_state[1];
+      m_run = m_last;
     }
     // (the barrier at the top of the next iteration separates this tile's readers from the next writers)
   }

@@ -365,12 +365,12 @@ __global__ __launch_bounds__(256) void agg_bwd_cells_kernel(
   const float* w = relevance + (size_t)b * cap;
   const float* dab = da + (size_t)b * cap;
   float m = -3.0e38f;
-  for (int p = beg + tid; p < end; p += 256) m = fmaxf(m, w[perm_b[p]]);
+  for (int p = beg + tid; p < end; p += 256) m = fmaxf(m, w[p]);     // relevance is stored by sorted position
   m = block_reduce(m, s_red, true);
   float z = 0.f, sa = 0.f;
   for (int p = beg + tid; p < end; p += 256) {
     const int s = perm_b[p];
-    const float e = expf(w[s] - m);
+    const float e = expf(w[p] - m);
     z += e;
     sa += e * dab[s];
   }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void agg_bwd_cells_kernel(
   sa = block_reduce(sa, s_red, false) / z;
   for (int p = beg + wave; p < end; p += 4) {
     const int s = perm_b[p];
-    const float a = expf(w[s] - m) / z;
+    const float a = expf(w[p] - m) / z;
     const float dw = a * (dab[s] - sa);
     const f16x2_t* xr = reinterpret_cast<const f16x2_t*>(slab + ((size_t)b * cap + s) * D);
     float* dt = dtext + ((size_t)b * L + amax[(size_t)b * cap + s]) * D;

@@ -398,7 +398,8 @@ def text_fragments(text_fts):
 
 
 def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_relevance=False):
-    """slab (B,cap,D) fp16 -> cells (B,196,D) fp32, occ (B,196) uint8 [, relevance (B,cap) fp32]."""
+    """slab (B,cap,D) fp16 -> cells (B,196,D) fp32, occ (B,196) uint8 [, relevance (B,cap) fp32: w of the point at
+    SORTED position p, i.e. of slot perm[b, p]]."""
     lib = _lib.load()
     B, cap, D = slab.shape
     assert slab.dtype == torch.float16 and slab.is_contiguous()

@@ -105,7 +105,7 @@ int gridmm_text_fragments(const float* text, void* frag, int B, int L, int D,
  * applied AFTER the reduction (W (sum_j a_j x_j) + b, since sum_j a_j = 1).
  *   slab       [B][cap][D] fp16      perm/cell_start as produced by gridmm_grid_bin
  *   cells      [B][196][D] f32 out (zeros for empty cells); occ [B][196] uint8 out
- *   relevance  [B][cap] f32 out or NULL (w_j, for tests)
+ *   relevance  [B][cap] f32 out or NULL: w of the point at SORTED position p (slot perm[b][p]); saved for the backward
  *   chunks     [B][n_chunks+1] int32 workspace (cell-aligned work partition, device-built)
  */
 int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
@@ -266,7 +266,7 @@ int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, const float* K,
 
 /* Backward of gridmm_grid_aggregate w.r.t. text = text_proj(txt_embeds) (vilmodel.py:795-807; the gradient
  * reaches text_proj and the language encoder through the max / softmax weights):
- *   relevance [B][cap] as written by the forward, text [B][L][D] f32, dcells [B][196][D] f32 (gradient of the
+ *   relevance [B][cap] as written by the forward (by sorted position), text [B][L][D] f32, dcells [B][196][D] f32 (gradient of the
  *   reduced cell vectors, i.e. after grid_proj's own backward) -> dtext [B][L][D] f32.
  *   da_ws [B][cap] f32 and amax_ws [B][cap] int32 are workspaces. */
 int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32_t* cell_start,

@@ -76,7 +76,9 @@ def test_aggregation_stage_matches_reference_capture():
             w = (x @ tf[b].t()).max(-1).values
             n = x.shape[0]
             valid = cpu["grid_map"][b] >= 0
-            got = rel[b, :n].cpu()
+            n_valid = int(cs[b, 196])                                  # relevance comes back by sorted position
+            got = torch.zeros(n)
+            got[perm[b, :n_valid].long().cpu()] = rel[b, :n_valid].cpu()
             assert (got[valid] - w[valid]).abs().max() < 5e-5 * max(1.0, w.abs().max().item())
             for c in range(196):
                 sel = cpu["grid_map"][b] == c
