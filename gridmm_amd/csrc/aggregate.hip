@@ -134,12 +134,32 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
   // this wave's text columns, register-resident for the whole chunk
   const size_t plane = (size_t)Lt * KS * 64 * 8;
   const _Float16* tf_b = text_frag + (size_t)b * 2 * plane + (size_t)lane * 8;
+  // RESIDENT (8 waves, Lt <= 8 column tiles): which (column tile, 32-point passes) this wave computes.  Waves w and
+  // w + 4 share a SIMD, so column tiles 0..3 go to waves 0..3 and the remaining Lt - 4 tiles are spread over waves
+  // 4..7 -- split by passes when there are fewer tiles than waves -- to level the MFMA work per SIMD (L = 80: 5 tiles
+  // on 5 waves put 4 passes on SIMD 0 and 2 on the others; this assignment gives 3 / 3 / 2 / 2).
+  constexpr int NP = TILE / 32;
+  int my_ct = -1, hp_lo = 0, hp_hi = 0;
+  if (RESIDENT) {
+    if (wave < 4) {
+      if (wave < Lt) { my_ct = wave; hp_hi = NP; }
+    } else {
+      const int extra = Lt - 4, idx = wave - 4;
+      if (extra == 1) {
+        if (idx < NP) { my_ct = 4; hp_lo = idx; hp_hi = idx + 1; }
+      } else if (extra == 2) {
+        if (NP == 2 || (idx & 1) == 0) { my_ct = 4 + (idx >> 1); hp_lo = NP == 2 ? (idx & 1) : 0; hp_hi = hp_lo + 1; }
+      } else if (extra > 2 && idx < extra) {
+        my_ct = 4 + idx; hp_hi = NP;
+      }
+    }
+  }
   f16x8_t thi[RESIDENT ? KS : 1], tlo[RESIDENT ? KS : 1];
-  if (RESIDENT && wave < Lt) {
+  if (RESIDENT && my_ct >= 0) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      thi[RESIDENT ? ks : 0] = *reinterpret_cast<const f16x8_t*>(tf_b + ((size_t)wave * KS + ks) * 64 * 8);
-      tlo[RESIDENT ? ks : 0] = *reinterpret_cast<const f16x8_t*>(tf_b + plane + ((size_t)wave * KS + ks) * 64 * 8);
+      thi[RESIDENT ? ks : 0] = *reinterpret_cast<const f16x8_t*>(tf_b + ((size_t)my_ct * KS + ks) * 64 * 8);
+      tlo[RESIDENT ? ks : 0] = *reinterpret_cast<const f16x8_t*>(tf_b + plane + ((size_t)my_ct * KS + ks) * 64 * 8);
     }
   }
 
@@ -236,14 +256,15 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
       s_cell[tid] = cell;
     }
     // ---- 2. relevance on the matrix pipe
-    for (int ct = wave; ct < Lt; ct += nwaves) {
+    for (int ct = RESIDENT ? my_ct : wave; ct >= 0 && ct < Lt; ct += RESIDENT ? 1024 : nwaves) {
       const int i = lane & 15, g = lane >> 4;
+      const int hp0 = RESIDENT ? hp_lo : 0, hp1 = RESIDENT ? hp_hi : NP;
       f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
       // Both 16-row halves always (rows past npt hold a repeated valid row, masked below): no branch in the k loop, and
       // the A fragments of group q+1 (GK k-steps x 2 halves) are read from LDS while group q is in the matrix pipe.
       constexpr int GK = 4;
       static_assert(KS % GK == 0, "k-steps per group");
-      for (int hp = 0; hp < TILE / 32; ++hp) {   // 32 points (two 16-row MFMA tiles) per pass
+      for (int hp = hp0; hp < hp1; ++hp) {   // 32 points (two 16-row MFMA tiles) per pass
       acc0 = acc1 = acc2 = acc3 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const f16x8_t* row0 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(hp * 32 + i) * D);
       const f16x8_t* row1 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(hp * 32 + 16 + i) * D);
@@ -448,7 +469,7 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
   hipStream_t st = as_stream(stream);
   GRIDMM_LAUNCH(build_chunks_kernel, dim3(B), dim3(64), 0, st, cell_start, chunks, n_chunks);
   const bool resident = Lt <= 8;
-  const int nwaves = resident ? (Lt < 4 ? 4 : Lt) : 8;
+  const int nwaves = 8;   // 2 per SIMD; the relevance work is levelled over them inside the kernel
   dim3 grid(n_chunks, B), block(nwaves * 64);
   // ring: 2 x 64 points (D <= 512: 2 x 64 KB) or 3 x 32 points (D = 768: 3 x 48 KB)
   const int TILE = D <= 512 ? TILE_BIG : TILE_SMALL, R = D <= 512 ? 2 : 3;
