@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
     const int32_t* __restrict__ chunks, int cap, int L, int Lt, int n_chunks) {
   constexpr int D = 32 * KS;
   constexpr int NCH = D / 8;                 // 16-B chunks per row
-  constexpr int NACC = (D / 2 + 255) / 256;  // feature-dim pairs per thread (block >= 256 threads)
+  constexpr int NACC = (D / 2 + 511) / 512;  // feature-dim pairs per thread (the block is always 8 waves = 512 threads)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   _Float16* s_tiles = reinterpret_cast<_Float16*>(smem);                       // [R][TILE][D]
   float* s_wmax = reinterpret_cast<float*>(smem + (size_t)R * TILE * D * 2);   // [Lt][TILE]
@@ -242,10 +242,10 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
       dma_tile(t + R - 1, idv);
       idv = idn;
     }
-    if (tid < TILE) {                               // cell of each point of this tile (binary search on LDS)
-      int cell = -1;
-      const int p = p0 + tid;
-      if (p < p_hi) {
+    if (wave == nwaves - 1) {                       // cell of each point of this tile (binary search on LDS), by the
+      int cell = -1;                                // LAST wave: it has no (or the least) relevance work below, so the
+      const int p = p0 + lane;                      // ~8 dependent LDS round trips delay nobody on the way to the barrier
+      if (lane < TILE && p < p_hi) {
         int lo = c_lo, hi = c_hi;  // invariant cs[lo] <= p < cs[hi]; the last c with cs[c] <= p owns p
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
         }
         cell = lo;
       }
-      s_cell[tid] = cell;
+      if (lane < TILE) s_cell[lane] = cell;
     }
     // ---- 2. relevance on the matrix pipe
     for (int ct = RESIDENT ? my_ct : wave; ct >= 0 && ct < Lt; ct += RESIDENT ? 1024 : nwaves) {
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_kernel(
       f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
       // Both 16-row halves always (rows past npt hold a repeated valid row, masked below): no branch in the k loop, and
       // the A fragments of group q+1 (GK k-steps x 2 halves) are read from LDS while group q is in the matrix pipe.
-      constexpr int GK = 4;
+      constexpr int GK = KS > 16 ? 2 : 4;       // D = 768 keeps 192 VGPRs of text fragments: prefetch shallower
       static_assert(KS % GK == 0, "k-steps per group");
       for (int hp = hp0; hp < hp1; ++hp) {   // 32 points (two 16-row MFMA tiles) per pass
       acc0 = acc1 = acc2 = acc3 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -468,7 +468,7 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
   if (Lt > 16) return GRIDMM_EINVAL;  // L <= 256 (reference: max_instr_len 200)
   hipStream_t st = as_stream(stream);
   GRIDMM_LAUNCH(build_chunks_kernel, dim3(B), dim3(64), 0, st, cell_start, chunks, n_chunks);
-  const bool resident = Lt <= 8;
+  const bool resident = Lt <= 8 && D != 768;   // D = 768: 192 VGPRs of resident fragments spill (180 B/lane); streaming them from L2 measured 172 vs 185 us
   const int nwaves = 8;   // 2 per SIMD; the relevance work is levelled over them inside the kernel
   dim3 grid(n_chunks, B), block(nwaves * 64);
   // ring: 2 x 64 points (D <= 512: 2 x 64 KB) or 3 x 32 points (D = 768: 3 x 48 KB)
