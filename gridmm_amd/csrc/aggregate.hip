@@ -459,6 +459,11 @@ extern "C" int gridmm_text_fragments(const float* text, void* frag, int B, int L
   return GRIDMM_OK;
 }
 
+// aggregate_pipe.hip: the wave-specialised variant (GRIDMM_EINVAL when the shape is outside its range)
+int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
+                               float* cells, uint8_t* occ, float* relevance, const int32_t* chunks, int B, int cap, int D,
+                               int L, int n_chunks, hipStream_t st);
+
 extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
                                      const void* text_frag, float* cells, uint8_t* occ, float* relevance,
                                      int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
@@ -468,6 +473,9 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
   if (Lt > 16) return GRIDMM_EINVAL;  // L <= 256 (reference: max_instr_len 200)
   hipStream_t st = as_stream(stream);
   GRIDMM_LAUNCH(build_chunks_kernel, dim3(B), dim3(64), 0, st, cell_start, chunks, n_chunks);
+  if (gridmm_grid_aggregate_pipe(slab, perm, cell_start, text_frag, cells, occ, relevance, chunks, B, cap, D, L, n_chunks,
+                                 st) == GRIDMM_OK)
+    return GRIDMM_OK;     // D <= 512 and L <= 96: two-stage wave-specialised pipeline; otherwise the generic kernel below
   const bool resident = Lt <= 8 && D != 768;   // D = 768: 192 VGPRs of resident fragments spill (180 B/lane); streaming them from L2 measured 172 vs 185 us
   const int nwaves = 8;   // 2 per SIMD; the relevance work is levelled over them inside the kernel
   dim3 grid(n_chunks, B), block(nwaves * 64);
