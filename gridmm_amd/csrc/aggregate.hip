@@ -48,25 +48,20 @@ __global__ void text_fragments_kernel(const float* __restrict__ text, _Float16* 
   }
 }
 
-// chunk boundaries in CELL index space: chunk k of episode b covers cells [cb[k], cb[k+1])
-__global__ void build_chunks_kernel(const int32_t* __restrict__ cell_start, int32_t* __restrict__ chunks,
-                                    int n_chunks) {
+// chunk boundaries in CELL index space: chunk k of episode b covers cells [cb[k], cb[k+1]); cb[k] = first cell whose
+// start is >= k * ceil(valid / n_chunks) (cell_start is non-decreasing: a count of the entries below the target)
+__global__ __launch_bounds__(256) void build_chunks_kernel(const int32_t* __restrict__ cell_start,
+                                                           int32_t* __restrict__ chunks, int n_chunks) {
   const int b = blockIdx.x;
   const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
   int32_t* cb = chunks + (size_t)b * (n_chunks + 1);
+  const int mine = threadIdx.x <= GRIDMM_CELLS ? cs[threadIdx.x] : 0x7fffffff;
   const int valid = cs[GRIDMM_CELLS];
   const int target = (valid + n_chunks - 1) / n_chunks;
-  for (int k = threadIdx.x; k <= n_chunks; k += blockDim.x) {
-    int c;
-    if (k == 0) c = 0;
-    else if (k == n_chunks) c = GRIDMM_CELLS;
-    else {
-      const long want = (long)k * target;
-      c = GRIDMM_CELLS;
-      for (int q = 0; q <= GRIDMM_CELLS; ++q)
-        if (cs[q] >= want) { c = q; break; }
-    }
-    cb[k] = c;
+  for (int k = 0; k <= n_chunks; ++k) {
+    const long want = (long)k * target;
+    const int below = __syncthreads_count(mine < want);
+    if (threadIdx.x == 0) cb[k] = k == 0 ? 0 : (k == n_chunks ? GRIDMM_CELLS : min(below, GRIDMM_CELLS));
   }
 }
 
@@ -472,10 +467,10 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
   const int Lt = (L + 15) / 16;
   if (Lt > 16) return GRIDMM_EINVAL;  // L <= 256 (reference: max_instr_len 200)
   hipStream_t st = as_stream(stream);
-  GRIDMM_LAUNCH(build_chunks_kernel, dim3(B), dim3(64), 0, st, cell_start, chunks, n_chunks);
   if (gridmm_grid_aggregate_pipe(slab, perm, cell_start, text_frag, cells, occ, relevance, chunks, B, cap, D, L, n_chunks,
                                  st) == GRIDMM_OK)
     return GRIDMM_OK;     // D <= 512 and L <= 96: two-stage wave-specialised pipeline; otherwise the generic kernel below
+  GRIDMM_LAUNCH(build_chunks_kernel, dim3(B), dim3(256), 0, st, cell_start, chunks, n_chunks);
   const bool resident = Lt <= 8 && D != 768;   // D = 768: 192 VGPRs of resident fragments spill (180 B/lane); streaming them from L2 measured 172 vs 185 us
   const int nwaves = 8;   // 2 per SIMD; the relevance work is levelled over them inside the kernel
   dim3 grid(n_chunks, B), block(nwaves * 64);

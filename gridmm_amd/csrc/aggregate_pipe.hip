@@ -32,7 +32,7 @@ __device__ long long g_prof[8][8];
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 constexpr int PT = 32;            // points per tile
-constexpr int RPW = PT / 8;       // rows DMA'd per wave and tile (8 waves)
+constexpr int MAXR = 12;          // rows DMA'd per R-wave and tile, at most (ceil(PT / Lt), Lt >= 3)
 constexpr float NEG_BIG = -3.0e38f;
 constexpr int HB_WORDS = 4096;    // run-head bitmask: 131072 points per workgroup
 constexpr int TAB_BYTES = 320;   // per-B-wave tables: 32 x (f16 hi, f16 lo, u16 run)
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   float* s_wmax = reinterpret_cast<float*>(smem + (size_t)R * PT * D * 2);      // [2][PT][8]: row = point, column = R-wave
   int* s_cs = reinterpret_cast<int*>(s_wmax + 2 * 8 * PT);                      // [200] cell_start of this episode
   unsigned char* s_tab = reinterpret_cast<unsigned char*>(s_cs + 200);          // [8] per-B-wave tables, TAB_BYTES each
-  int* s_ids = reinterpret_cast<int*>(s_tab + 8 * TAB_BYTES);                   // [8 waves][4 tiles][RPW] slab rows to fetch
-  int* s_necell = s_ids + 8 * 4 * RPW;                                          // [200] non-empty cells of this chunk, in order
+  int* s_ids = reinterpret_cast<int*>(s_tab + 8 * TAB_BYTES);                   // [8 waves][4 tiles][MAXR] slab rows to fetch
+  int* s_necell = s_ids + 8 * 4 * MAXR;                                         // [200] non-empty cells of this chunk, in order
   unsigned* s_hbits = reinterpret_cast<unsigned*>(s_necell + 200);              // [ntiles] bit j of word t: a cell starts at
                                                                                 // point 32 t + j of the chunk (run heads)
 
@@ -86,27 +86,37 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef GRIDMM_AGG_PROF
   const long long pt0 = PROF_T();
-  long long p_wait = 0, p_dma = 0, p_work = 0, p_a = 0, pt1 = 0, pt2 = 0, pta = 0, pmk = 0;
+  long long p_wait = 0, p_dma = 0, p_work = 0, p_a = 0, pt2 = 0, pta = 0, pmk = 0;
   long long p_m[6] = {0, 0, 0, 0, 0, 0};
 #endif
   const int b = blockIdx.y, k = blockIdx.x;
   const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
-  const int c_lo = chunks[(size_t)b * (n_chunks + 1) + k], c_hi = chunks[(size_t)b * (n_chunks + 1) + k + 1];
+  // Chunk k of the episode = cells [c_lo, c_hi), cut where the sorted point index crosses k * ceil(valid / n_chunks)
+  // (the same boundaries build_chunks_kernel writes for the generic kernel; computed here, a 15 us serial kernel
+  // less): cell_start is non-decreasing, so a boundary is the count of entries below the target.
+  const int mine = tid < GRIDMM_CELLS + 2 ? cs[tid] : 0x7fffffff;
+  if (tid < GRIDMM_CELLS + 2) s_cs[tid] = mine;
+  const int valid = cs[GRIDMM_CELLS];
+  const long target = (valid + n_chunks - 1) / n_chunks;
+  const bool counted = tid <= GRIDMM_CELLS;
+  const int below_lo = __syncthreads_count(counted && mine < k * target);
+  const int below_hi = __syncthreads_count(counted && mine < (k + 1) * target);
+  const int c_lo = k == 0 ? 0 : min(below_lo, GRIDMM_CELLS);
+  const int c_hi = k + 1 == n_chunks ? GRIDMM_CELLS : min(below_hi, GRIDMM_CELLS);
   if (c_lo >= c_hi) return;
-  const int p_lo = cs[c_lo], p_hi = cs[c_hi];
+  const int p_lo = s_cs[c_lo], p_hi = s_cs[c_hi];
   float* cells_b = cells + (size_t)b * GRIDMM_CELLS * D;
   uint8_t* occ_b = occ + (size_t)b * GRIDMM_CELLS;
 
   // empty cells of this chunk: zero vector, occ = 0 (vilmodel.py:803-807)
   for (int c = c_lo + wave; c < c_hi; c += 8) {
-    if (cs[c + 1] == cs[c]) {
+    if (s_cs[c + 1] == s_cs[c]) {
       for (int d = lane; d < D / 4; d += 64)
         reinterpret_cast<float4*>(cells_b + (size_t)c * D)[d] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (lane == 0) occ_b[c] = 0;
     }
   }
   if (p_lo >= p_hi) return;
-  for (int i = tid; i < GRIDMM_CELLS + 2; i += 512) s_cs[i] = cs[i];
   for (int i = tid; i < 2 * 8 * PT; i += 512) s_wmax[i] = NEG_BIG;      // columns of absent R-waves stay at -inf
   {
     // Points are sorted by cell: the run heads of every tile are known from cell_start alone.  One bit per point (a
@@ -138,42 +148,70 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   const int32_t* perm_b = perm + (size_t)b * cap;
   const int ntiles = (p_hi - p_lo + PT - 1) / PT;
 
-  // Row ids travel by LDS-DMA as well (4 lanes x 4 B per wave and tile, two iterations ahead of their use): a scalar
-  // load here would put ~1200 cycles of memory latency into EVERY lgkmcnt wait of the iteration (SMEM returns out of
-  // order, so LDS waits cannot be counted past it), and a vector load's result register makes the compiler drain the
-  // DMA queue.  In-order vmcnt covers the ids like the tiles.
-  auto load_ids = [&](int t) {                             // rows wave, wave + 8, ... of tile t -> s_ids[wave][t & 3]
-    if (lane < RPW) {
-      int p = p_lo + t * PT + wave + 8 * lane;
+  // The R-waves feed the ring (the B-waves have global stores in flight, which would make a counted vmcnt wait drain
+  // their part of it, and they are the longer leg of an iteration): R-wave w fetches rows w, w + Lt, ... of a tile.
+  // Row ids travel by LDS-DMA as well (one lane x 4 B per row, two iterations ahead of their use): a scalar load here
+  // would put ~1200 cycles of memory latency into EVERY lgkmcnt wait of the iteration (SMEM returns out of order, so
+  // LDS waits cannot be counted past it), and a vector load's result register makes the compiler drain the DMA queue.
+  // In-order vmcnt covers the ids like the tiles.
+  const int my_rows = is_r ? (PT - wave + Lt - 1) / Lt : 0;
+  auto load_ids = [&](int t) {                             // -> s_ids[wave][t & 3][j]
+    if (lane < my_rows) {
+      int p = p_lo + t * PT + wave + Lt * lane;
       if (p >= p_hi) p = p_hi - 1;                         // short tiles repeat the last valid row
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(perm_b + p),
-                                       (__attribute__((address_space(3))) void*)(s_ids + (wave * 4 + (t & 3)) * RPW),
+                                       (__attribute__((address_space(3))) void*)(s_ids + (wave * 4 + (t & 3)) * MAXR),
                                        4, 0, 0);
     }
   };
-  auto dma_tile = [&](int t) {                             // position c of row r holds global chunk c ^ (r & 15)
-    _Float16* dst = s_tiles + (size_t)(t % R) * PT * D;
-    static_assert(RPW == 4, "ids are read as one int4");
+  int ids_s[MAXR];                                         // slab rows of the tile being fetched (wave-uniform)
+  auto dma_prepare = [&](int t) {
+    static_assert(MAXR == 12, "ids are read as three int4");
     // (asm: the compiler's waitcnt pass answers a visible ds_read here with s_waitcnt vmcnt(0), draining the ring)
-    int4 idv;
+    int4 idv[3];
     {
-      const unsigned a = (unsigned)(size_t)(s_ids + (wave * 4 + (t & 3)) * RPW);          // uniform address: broadcast
-      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(idv) : "v"(a) : "memory");
+      const unsigned a = (unsigned)(size_t)(s_ids + (wave * 4 + (t & 3)) * MAXR);         // uniform address: broadcast
+      asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(idv[0]), "=&v"(idv[1]), "=&v"(idv[2]) : "v"(a) : "memory");
     }
-    const int ids[RPW] = {__builtin_amdgcn_readfirstlane(idv.x), __builtin_amdgcn_readfirstlane(idv.y),
-                          __builtin_amdgcn_readfirstlane(idv.z), __builtin_amdgcn_readfirstlane(idv.w)};
+    const int idl[MAXR] = {idv[0].x, idv[0].y, idv[0].z, idv[0].w, idv[1].x, idv[1].y, idv[1].z, idv[1].w,
+                           idv[2].x, idv[2].y, idv[2].z, idv[2].w};
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-      const int r = wave + 8 * j;
-      const _Float16* row = slab_b + (size_t)ids[j] * D;
+    for (int j = 0; j < MAXR; ++j) ids_s[j] = __builtin_amdgcn_readfirstlane(idl[j]);
+  };
+  auto dma_rows = [&](int t, int j0, int j1) {             // position c of row r holds global chunk c ^ (r & 15)
+    _Float16* dst = s_tiles + (size_t)(t % R) * PT * D;
 #pragma unroll
-      for (int c0 = 0; c0 < NCH; c0 += 64) {
-        const int c = c0 + lane;
-        if (c < NCH)
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(row + (size_t)(c ^ (r & 15)) * 8),
-              (__attribute__((address_space(3))) void*)(dst + (size_t)r * D + (size_t)c0 * 8), 16, 0, 0);
+    for (int j = j0; j < j1; ++j) {
+      if (j < my_rows) {
+        const int r = wave + Lt * j;
+        const _Float16* row = slab_b + (size_t)ids_s[j] * D;
+#pragma unroll
+        for (int c0 = 0; c0 < NCH; c0 += 64) {
+          const int c = c0 + lane;
+          if (c < NCH)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(row + (size_t)(c ^ (r & 15)) * 8),
+                (__attribute__((address_space(3))) void*)(dst + (size_t)r * D + (size_t)c0 * 8), 16, 0, 0);
+        }
       }
+    }
+  };
+  auto wait_vm_dyn = [&](int n) {                          // s_waitcnt vmcnt(n), n wave-uniform
+    switch (n) {
+      case 13: wait_vm<13>(); break;
+      case 12: wait_vm<12>(); break;
+      case 11: wait_vm<11>(); break;
+      case 10: wait_vm<10>(); break;
+      case 9: wait_vm<9>(); break;
+      case 8: wait_vm<8>(); break;
+      case 7: wait_vm<7>(); break;
+      case 6: wait_vm<6>(); break;
+      case 5: wait_vm<5>(); break;
+      case 4: wait_vm<4>(); break;
+      case 3: wait_vm<3>(); break;
+      default: wait_vm<0>(); break;
     }
   };
 
@@ -192,51 +230,55 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   _Float16* t_elo = reinterpret_cast<_Float16*>(tab + 64);          // [32] f16 lo
   unsigned short* t_q = reinterpret_cast<unsigned short*>(tab + 128);   // [32] run index of the point
   auto flush_rows = [&](bool doit, int cell) {   // normalise + store + clear the rows of the lanes with doit
-    const float inv = 1.0f / acc_s[0];
+    const float inv = __builtin_amdgcn_rcpf(acc_s[0]);
+    if (doit) {                                  // one exec region for all stores (the block guard is wave-uniform)
+      float* dst = cells_b + (size_t)cell * D + bw * 16 + g * 4;
 #pragma unroll
-    for (int u = 0; u < NBW; ++u) {
-      const int mb = bw + u * nbw;
-      if (doit && mb < NBLK)
-        *reinterpret_cast<float4*>(cells_b + (size_t)cell * D + mb * 16 + g * 4) =
-            make_float4(acc[u][0] * inv, acc[u][1] * inv, acc[u][2] * inv, acc[u][3] * inv);
+      for (int u = 0; u < NBW; ++u)
+        if (bw + u * nbw < NBLK)
+          *reinterpret_cast<float4*>(dst + u * nbw * 16) =
+              make_float4(acc[u][0] * inv, acc[u][1] * inv, acc[u][2] * inv, acc[u][3] * inv);
+      if (g == 0 && bw == 0) occ_b[cell] = 1;
+    }
+#pragma unroll
+    for (int u = 0; u < NBW; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[u][j] = doit ? 0.f : acc[u][j];
-    }
-    if (doit && g == 0 && bw == 0) occ_b[cell] = 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc_s[j] = doit ? 0.f : acc_s[j];
   };
 
-  // Queue discipline (in order): iteration i issues DMA(i + R - 2) then IDS(i + R); its top needs DMA(i) and
-  // IDS(i + R - 2) (both issued at i - 2) and leaves DMA(i + 1), IDS(i + R - 1) in flight.
-  auto prologue = [&]() {
-    __builtin_amdgcn_s_waitcnt(0);              // text fragments / cell_start: retire ordinary loads before the loop
-    for (int t = 0; t < R && t < ntiles; ++t) load_ids(t);
-    wait_vm<0>();
-    __syncthreads();
-    for (int t = 0; t < R - 2 && t < ntiles; ++t) dma_tile(t);
-  };
-
-  auto iter_head = [&](int i) {
+  // Queue discipline of an R-wave (in order): iteration i issues DMA(i + R - 2) then IDS(i + R); its top needs DMA(i)
+  // and IDS(i + R - 2) (both issued at i - 2) and leaves DMA(i + 1), IDS(i + R - 1) in flight.
+  static_assert(R == 4, "wait counts below assume R = 4");
+  auto iter_head_r = [&](int i) {
 #ifdef GRIDMM_AGG_PROF
     pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta;
 #endif
-    // tile i and the ids of tile i + R - 2 must have landed; one tile + one id set stay in flight
-    static_assert(R == 4, "wait counts below assume R = 4");
-    if (i >= 1 && i + R - 1 < ntiles) wait_vm<RPW * IPR + 1>();     // steady state: DMA(i + 1), IDS(i + R - 1) in flight
-    else if (i + 1 < ntiles) wait_vm<RPW * IPR>();                  // first / last iterations: DMA(i + 1) only
+    if (i >= 1 && i + R - 1 < ntiles) wait_vm_dyn(my_rows * IPR + 1);    // steady state: DMA(i + 1), IDS(i + R - 1) in flight
+    else if (i + 1 < ntiles) wait_vm_dyn(my_rows * IPR);                 // first / last iterations: DMA(i + 1) only
     else wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef GRIDMM_AGG_PROF
+    { const long long t = PROF_T(); p_m[4] += t - pt2; }
+#endif
     __builtin_amdgcn_s_barrier();               // tile i and the products of iteration i-1 visible; slot of tile i-2 free
 #ifdef GRIDMM_AGG_PROF
     { const long long t = PROF_T(); p_wait += t - pt2; pt2 = t; }
 #endif
-    if (i + R - 2 < ntiles) {
-      dma_tile(i + R - 2);
-      if (i + R < ntiles) load_ids(i + R);                 // consumed two iterations from now
-    }
+    if (i + R - 2 < ntiles) dma_prepare(i + R - 2);        // its rows are issued between the MFMA groups below
 #ifdef GRIDMM_AGG_PROF
     pta = PROF_T(); p_dma += pta - pt2;
+#endif
+  };
+  auto iter_head_b = [&](int i) {
+#ifdef GRIDMM_AGG_PROF
+    pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta;
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#ifdef GRIDMM_AGG_PROF
+    { const long long t = PROF_T(); p_wait += t - pt2; pta = t; }
 #endif
   };
   // Two loops (same barrier sequence) so that the register allocator never sees the R-waves' text fragments and the
@@ -248,12 +290,13 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
       thi[ks] = *reinterpret_cast<const f16x8_t*>(tf_b + ((size_t)wave * KS + ks) * 64 * 8);
       tlo[ks] = *reinterpret_cast<const f16x8_t*>(tf_b + plane + ((size_t)wave * KS + ks) * 64 * 8);
     }
-    prologue();
-#ifdef GRIDMM_AGG_PROF
-    pt1 = PROF_T();
-#endif
+    __builtin_amdgcn_s_waitcnt(0);              // text fragments: retire ordinary loads before the loop
+    for (int t = 0; t < R && t < ntiles; ++t) load_ids(t);
+    wait_vm<0>();
+    __syncthreads();                            // cell_start, run heads, s_wmax initialised
+    for (int t = 0; t < R - 2 && t < ntiles; ++t) { dma_prepare(t); dma_rows(t, 0, MAXR); }
     for (int i = 0; i <= ntiles; ++i) {
-      iter_head(i);
+      iter_head_r(i);
       // ---- relevance of tile i on the matrix pipe (text fragment = A operand: lane = point, registers = columns)
       if (i < ntiles) {
         const _Float16* s_tile = s_tiles + (size_t)(i % R) * PT * D;
@@ -265,8 +308,11 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
         f16x8_t fa[2][GK], fb[2][GK];
 #pragma unroll
         for (int u = 0; u < GK; ++u) { fa[0][u] = row0[(u * 4 + g) ^ pi]; fb[0][u] = row1[(u * 4 + g) ^ pi]; }
+        const bool fetch = i + R - 2 < ntiles;                    // DMA(i + R - 2): a slice of its rows per MFMA group,
+        constexpr int NQ = KS / GK, RQ = (MAXR + NQ - 1) / NQ;     // so that the address path works under the MFMAs
 #pragma unroll
         for (int q = 0; q < KS / GK; ++q) {
+          if (fetch) dma_rows(i + R - 2, q * RQ, min((q + 1) * RQ, MAXR));
           if (q + 1 < KS / GK) {
 #pragma unroll
             for (int u = 0; u < GK; ++u) {
@@ -283,6 +329,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
             acc3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(thi[ks], fb[q & 1][u], acc3, 0, 0, 0);
           }
         }
+        if (fetch && i + R < ntiles) load_ids(i + R);              // consumed two iterations from now
         float x0 = NEG_BIG, x1 = NEG_BIG;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -300,12 +347,10 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
       }
     }
   } else {
-    prologue();
-#ifdef GRIDMM_AGG_PROF
-    pt1 = PROF_T();
-#endif
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
     for (int i = 0; i <= ntiles; ++i) {
-      iter_head(i);
+      iter_head_b(i);
       // ---- tile i - 1: softmax numerators (every B-wave for itself, lane = point), then accumulation
       if (i >= 1) {
 #ifdef GRIDMM_AGG_PROF
@@ -329,7 +374,6 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
         }
         if (relevance && wave == 7 && lane < npt) relevance[(size_t)b * cap + p0 + lane] = w;   // by sorted position
         if (lane >= npt) w = NEG_BIG;
-        PROF_MARK(0)
         // A cell is a contiguous run of lanes [rs, re]; the run heads of this tile are one word of s_hbits (bit 0 clear:
         // the first run continues the open cell of the previous tile).  The run maximum at every lane = max(segmented
         // prefix max, segmented suffix max): DPP row shifts (a VALU modifier) + two scalar readlanes for the seam between
@@ -361,7 +405,6 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
           if (lane <= 15 && re >= 16) suf = fmaxf(suf, s16);
         }
         float m = fmaxf(pre, suf);
-        PROF_MARK(1)
         const int q_lane = __builtin_popcount(below) - 1;          // run index inside the tile
         if (cont && q_lane == 0) m = fmaxf(m, m_run);              // the run continuing from the previous tile
         const float e_lane = (lane < npt) ? expf(w - m) : 0.f;
@@ -379,10 +422,13 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
           t_elo[idx] = el;
           t_q[idx] = (unsigned short)(lane < npt ? q_lane : 0xFFFF);
         }
-        PROF_MARK(2)
-        if (t > 0 && !cont)                                        // the open cell ended with the previous tile
+        // The open cell ended with the previous tile: its row (slot base) is stored by the flush of this tile's first
+        // pass, unless that pass needs all 16 slots.
+        bool flush_old = t > 0 && !cont;
+        if (flush_old && nruns >= 16) {
           flush_rows(sl == base, lds_ld_b32(s_necell + n_heads - 1));
-        PROF_MARK(3)
+          flush_old = false;
+        }
         const int start = t == 0 ? 0 : (cont ? base : ((base + 1) & 15));
         if (cont) {
           const float sc = expf(m_run - m0);                     // rescale of the running cell
@@ -397,6 +443,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // own table writes (single wave: program order)
+        PROF_MARK(0)
 #ifdef GRIDMM_AGG_PROF
         p_a += PROF_T() - pta;
 #endif
@@ -426,6 +473,12 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
           const f16x8_t bh = __builtin_bit_cast(f16x8_t, bhu), bl = __builtin_bit_cast(f16x8_t, blu);
           acc_s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bh, acc_s, 0, 0, 0);
           acc_s = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, bl, acc_s, 0, 0, 0);
+          PROF_MARK(1)
+          int cell;                                               // cell of this lane's run: needed after the MFMAs
+          asm volatile("ds_read_b32 %0, %1" : "=v"(cell)
+                       : "v"((unsigned)(size_t)(s_necell + (flush_old && sl == base ? n_heads - 1
+                                                                                   : min(kg0 + qs, GRIDMM_CELLS - 1))))
+                       : "memory");
           // transpose reads in groups of GB blocks, one group ahead of the MFMAs that consume them
           constexpr int GB = 4, NG = (NBW + GB - 1) / GB;
           uint2 xr[NBW][2];
@@ -459,9 +512,13 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
             }
           }
           const int nlast = min(nruns, q0 + 16);
-          const bool doit = qs < nlast && qs != nruns - 1;       // every run of this pass but the tile's last (stays open)
-          const int cell = lds_ld_b32(s_necell + min(kg0 + qs, GRIDMM_CELLS - 1));
+          const bool doit = (qs < nlast && qs != nruns - 1) ||   // every run of this pass but the tile's last (stays open)
+                            (flush_old && sl == base);
+          flush_old = false;
+          PROF_MARK(2)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cell)::"memory");
           flush_rows(doit, cell);
+          PROF_MARK(3)
         }
         base = (start + nruns - 1) & 15;
         n_heads += __builtin_popcount(hbu);
@@ -494,10 +551,10 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
   const int Lt = (L + 15) / 16;
   if (D != 512 && D != 256) return GRIDMM_EINVAL;            // D = 768: 192 VGPRs of resident fragments spill
   const int nbw = 8 - Lt;                                    // B-waves; each owns ceil(D / 16 / nbw) 16-dim blocks
-  if (Lt < 1 || nbw < 1 || (D == 512 && nbw < 2)) return GRIDMM_EINVAL;
+  if (Lt < 3 || nbw < 1 || (D == 512 && nbw < 2)) return GRIDMM_EINVAL;   // Lt >= 3: at most MAXR rows per R-wave
   constexpr int R = 4;
   const size_t lds = (size_t)R * PT * D * 2 + 2 * 8 * PT * sizeof(float) + 200 * sizeof(int) +
-                     8 * TAB_BYTES + 8 * 4 * RPW * sizeof(int) + 200 * sizeof(int) + HB_WORDS * sizeof(unsigned);
+                     8 * TAB_BYTES + 8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + HB_WORDS * sizeof(unsigned);
   if ((cap + PT - 1) / PT > HB_WORDS) return GRIDMM_EINVAL;     // head bitmask of a whole episode must fit
   dim3 grid(n_chunks, B), block(512);
 #define GRIDMM_AGGP(KS, NBW)                                                                                         \

@@ -13,6 +13,6 @@ lib = _lib.load()
 buf = (ctypes.c_longlong * 64)()
 lib.gridmm_debug_agg_prof.argtypes = [ctypes.c_void_p]
 print("rc", lib.gridmm_debug_agg_prof(buf))
-print("wave  m0(lds-in) m1(scan) wait dma work 3a m2(exp,tabwrite) m3(flush-old)")
+print("wave 3a tabread+mask wait dma work 3a(old) mfma flush")
 for w in range(8):
     print(w, [buf[w * 8 + j] for j in range(8)])
