@@ -531,7 +531,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   if (blockIdx.x == 3 && blockIdx.y == 5 && lane == 0) {
     const long long te = PROF_T();
     long long* o = g_prof[wave];
-    o[0] = p_m[0]; o[1] = p_m[1]; o[2] = p_wait; o[3] = p_dma; o[4] = p_work + (te - pta); o[5] = p_a; o[6] = p_m[2]; o[7] = p_m[3];
+    o[0] = p_m[0]; o[1] = p_m[1]; o[2] = p_wait; o[3] = p_dma; o[4] = p_work + (te - pta); o[5] = p_a; o[6] = p_m[4]; o[7] = ntiles;
   }
 #endif
 }
