@@ -34,7 +34,6 @@ typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 constexpr int PT = 32;            // points per tile
 constexpr int MAXR = 12;          // rows DMA'd per R-wave and tile, at most (ceil(PT / Lt), Lt >= 3)
 constexpr float NEG_BIG = -3.0e38f;
-constexpr int HB_WORDS = 4096;    // run-head bitmask: 131072 points per workgroup
 constexpr int TAB_BYTES = 320;   // per-B-wave tables: 32 x (f16 hi, f16 lo, u16 run)
 
 template <int N>
@@ -211,6 +210,8 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
       case 5: wait_vm<5>(); break;
       case 4: wait_vm<4>(); break;
       case 3: wait_vm<3>(); break;
+      case 2: wait_vm<2>(); break;
+      case 1: wait_vm<1>(); break;
       default: wait_vm<0>(); break;
     }
   };
@@ -249,14 +250,15 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   };
 
   // Queue discipline of an R-wave (in order): iteration i issues DMA(i + R - 2) then IDS(i + R); its top needs DMA(i)
-  // and IDS(i + R - 2) (both issued at i - 2) and leaves DMA(i + 1), IDS(i + R - 1) in flight.
-  static_assert(R == 4, "wait counts below assume R = 4");
+  // (issued at i - R + 2) and IDS(i + R - 2) (issued at i - 2) and leaves the R - 3 younger tiles and IDS(i + R - 1)
+  // in flight.
+  static_assert(R == 3 || R == 4, "ring of 3 (D = 768) or 4 slots");
   auto iter_head_r = [&](int i) {
 #ifdef GRIDMM_AGG_PROF
     pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta;
 #endif
-    if (i >= 1 && i + R - 1 < ntiles) wait_vm_dyn(my_rows * IPR + 1);    // steady state: DMA(i + 1), IDS(i + R - 1) in flight
-    else if (i + 1 < ntiles) wait_vm_dyn(my_rows * IPR);                 // first / last iterations: DMA(i + 1) only
+    if (i >= 1 && i + R - 1 < ntiles) wait_vm_dyn((R - 3) * my_rows * IPR + 1);   // steady state
+    else if (i + 1 < ntiles) wait_vm_dyn((R - 3) * my_rows * IPR);                // first / last iterations: tiles only
     else wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef GRIDMM_AGG_PROF
@@ -549,17 +551,20 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
                                float* cells, uint8_t* occ, float* relevance, const int32_t* chunks, int B, int cap, int D,
                                int L, int n_chunks, hipStream_t st) {
   const int Lt = (L + 15) / 16;
-  if (D != 512 && D != 256) return GRIDMM_EINVAL;            // D = 768: 192 VGPRs of resident fragments spill
+  // D = 768 (KS = 24) does not fit: 192 VGPRs of resident text fragments + the MFMA working set spill (58 VGPRs at the
+  // 256-register budget of 2 waves per SIMD), and a 3 x 48 KB ring leaves one tile of latency cover.
+  if (D != 512 && D != 256) return GRIDMM_EINVAL;
   const int nbw = 8 - Lt;                                    // B-waves; each owns ceil(D / 16 / nbw) 16-dim blocks
   if (Lt < 3 || nbw < 1 || (D == 512 && nbw < 2)) return GRIDMM_EINVAL;   // Lt >= 3: at most MAXR rows per R-wave
   constexpr int R = 4;
+  const size_t hb_words = (size_t)(cap + PT - 1) / PT;       // run-head bitmask of (at most) a whole episode
   const size_t lds = (size_t)R * PT * D * 2 + 2 * 8 * PT * sizeof(float) + 200 * sizeof(int) +
-                     8 * TAB_BYTES + 8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + HB_WORDS * sizeof(unsigned);
-  if ((cap + PT - 1) / PT > HB_WORDS) return GRIDMM_EINVAL;     // head bitmask of a whole episode must fit
+                     8 * TAB_BYTES + 8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + hb_words * sizeof(unsigned);
+  if (lds > 160 * 1024) return GRIDMM_EINVAL;                // D = 512: up to ~185k points per episode
   dim3 grid(n_chunks, B), block(512);
-#define GRIDMM_AGGP(KS, NBW)                                                                                         \
+#define GRIDMM_AGGP(KS, RR, NBW)                                                                                     \
   do {                                                                                                               \
-    auto kern = grid_aggregate_pipe_kernel<KS, R, NBW>;                                                              \
+    auto kern = grid_aggregate_pipe_kernel<KS, RR, NBW>;                                                             \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,         \
                             (int)lds) != hipSuccess)                                                                 \
       return GRIDMM_EINVAL;                                                                                          \
@@ -567,9 +572,9 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
                   cells, occ, relevance, chunks, cap, L, Lt, n_chunks);                                              \
   } while (0)
   if (D == 512) {
-    if (nbw >= 4) GRIDMM_AGGP(16, 8); else if (nbw == 3) GRIDMM_AGGP(16, 11); else GRIDMM_AGGP(16, 16);
+    if (nbw >= 4) GRIDMM_AGGP(16, 4, 8); else if (nbw == 3) GRIDMM_AGGP(16, 4, 11); else GRIDMM_AGGP(16, 4, 16);
   } else {
-    if (nbw >= 2) GRIDMM_AGGP(8, 8); else GRIDMM_AGGP(8, 16);
+    if (nbw >= 2) GRIDMM_AGGP(8, 4, 8); else GRIDMM_AGGP(8, 4, 16);
   }
 #undef GRIDMM_AGGP
   GRIDMM_CHECK_LAUNCH();

@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/refresh/kt
 cd $R
 S=$(find gpurun_out/refresh/kt -name "*kernel_stats.csv" | head -1); cp $S gpurun_out/refresh/kernel_stats.csv
 T=$(find gpurun_out/refresh/kt -name "*kernel_trace.csv" | head -1)
-python tools/trace_summary.py $T 1 40 > gpurun_out/refresh/trace_by_shape.txt 2>&1
+python tools/trace_summary.py $T auto 40 > gpurun_out/refresh/trace_by_shape.txt 2>&1
 head -5 gpurun_out/refresh/trace_by_shape.txt
 rm -rf gpurun_out/refresh/kt gpurun_out/pmc_r1/fetch gpurun_out/pmc_r1/write
 for t in 5 15; do timeout 300 python bench.py --mem-steps $t --steps 20 --warmup 5 --no-cpu-baseline --no-torch-gpu-baseline > gpurun_out/refresh/bench_t$t.json 2>/dev/null; done
