@@ -142,8 +142,9 @@ class Act:
 
 
 def _planes_like(shape, device):
-    hi = torch.empty(tuple(shape), dtype=torch.bfloat16, device=device)
-    return hi, torch.empty_like(hi)
+    """hi / lo planes as the two halves of ONE allocation: a pair moves with a single copy_rows launch."""
+    buf = torch.empty((2,) + tuple(shape), dtype=torch.bfloat16, device=device)
+    return buf[0], buf[1]
 
 
 def split_rows(x):
@@ -314,6 +315,23 @@ def ln_dot(x, gamma, beta, eps, w, b0, out=None):
     _lib.check(lib.gridmm_ln_dot(_p(x), ldx, _p(gamma), _p(beta), float(eps), _p(w), _p(b0), _p(out), M, H,
                                  _stream()), "gridmm_ln_dot")
     return out
+
+
+def copy_planes(src, dst, dst_row0=0):
+    """dst.hi/lo[:, dst_row0:dst_row0+rows] = src.hi/lo for Act pairs; one launch when both pairs are the halves of one
+    allocation (what _planes_like hands out), else two."""
+    def paired(a):
+        return (a.hi.shape == a.lo.shape and a.hi.stride() == a.lo.stride() and a.hi.is_contiguous()
+                and a.lo.data_ptr() - a.hi.data_ptr() == a.hi.numel() * a.hi.element_size())
+    if paired(src) and paired(dst):
+        B, rows, H = src.hi.shape
+        s2 = torch.as_strided(src.hi, (2 * B, rows, H), src.hi.stride())
+        d2 = torch.as_strided(dst.hi, (2 * B,) + tuple(dst.hi.shape[1:]), dst.hi.stride())
+        copy_rows(s2, d2, dst_row0)
+    else:
+        copy_rows(src.hi, dst.hi, dst_row0)
+        copy_rows(src.lo, dst.lo, dst_row0)
+    return dst
 
 
 def copy_rows(src, dst, dst_row0=0):

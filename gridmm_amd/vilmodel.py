@@ -486,10 +486,8 @@ class GlocalTextPathNavCMT(nn.Module):
         # ---- local encoder over q = [gmap | vp], kv = [map | txt] (vilmodel.py:843-856).  The context is the
         # same for all layers, so the K/V projections of every layer run as ONE GEMM (N = layers * 2H).
         kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
-        for src, dst in ((mp.hi, kv.hi), (mp.lo, kv.lo)):
-            ops.copy_rows(src, dst, 0)
-        for src, dst in ((txt.hi, kv.hi), (txt.lo, kv.lo)):
-            ops.copy_rows(src, dst, S)
+        ops.copy_planes(mp, kv, 0)
+        ops.copy_planes(txt, kv, S)
         kv_masks = torch.cat([map_masks, txt_m], 1)
         xl = le.encoder.x_layers
         kv_all = ops.linear(kv, self._pack("local.kv_all",
