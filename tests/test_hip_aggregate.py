@@ -56,6 +56,8 @@ CASES = [
     (256, 80, "blocks", [3000, 500], None),
     (256, 64, "sparse", [190, 10], 4),
     (768, 80, "blocks", [2000, 300], None),      # D = 768: generic kernel
+    (512, 80, "crowded", [210000], 8),           # run-head bitmask of the episode exceeds LDS: generic kernel
+    (512, 80, "crowded", [150000], 8),           # largest memories the pipelined kernel takes (4700 tiles per workgroup)
 ]
 
 
