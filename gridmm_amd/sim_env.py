@@ -104,18 +104,30 @@ class SyntheticScan:
             path.append(self.vps[i])
         return path
 
-    # ---- per-viewpoint "sensor" data, regenerated from the key (never stored)
+    # ---- per-viewpoint "sensor" data: a pure function of the key, memoised like the reference's in-memory feature
+    #      store (utils/data.py ImageFeaturesDB keeps every viewpoint it has read)
+    def _memo(self, key, make, limit=160):
+        c = self.__dict__.setdefault("_memo_store", {})
+        if key not in c:
+            if len(c) >= limit:
+                c.pop(next(iter(c)))
+            c[key] = make()
+        return c[key]
+
     def view_features(self, vp, dim=768):
-        return _rs("view", vp).standard_normal((36, dim)).astype(np.float32)
+        return self._memo(("view", vp, dim), lambda: _rs("view", vp).standard_normal((36, dim)).astype(np.float32))
 
     def depth(self, vp, geom=NATIVE):
-        rs = _rs("depth", vp)
-        d = rs.randint(0, 20000, size=(geom.n_views, geom.patches ** 2)).astype(np.uint16)
-        d[rs.rand(*d.shape) < 0.1] = 0
-        return d
+        def make():
+            rs = _rs("depth", vp)
+            d = rs.randint(0, 20000, size=(geom.n_views, geom.patches ** 2)).astype(np.uint16)
+            d[rs.rand(*d.shape) < 0.1] = 0
+            return d
+        return self._memo(("depth", vp, geom.n_views, geom.patches), make)
 
     def patch_tokens(self, vp, geom=NATIVE):
-        return (_rs("clip", vp).standard_normal((geom.pts_per_obs, geom.feat_dim)) * 0.35).astype(np.float16)
+        return self._memo(("clip", vp, geom.pts_per_obs, geom.feat_dim), lambda: (
+            _rs("clip", vp).standard_normal((geom.pts_per_obs, geom.feat_dim)) * 0.35).astype(np.float16))
 
 
 class _SimState:
