@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -23,6 +23,7 @@ SIGNATURES = {
     "gridmm_abi_version": [],
     "gridmm_grid_project": [_vp, _i, _vp, _vp, _vp, _i] + [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _f, _vp],
     "gridmm_grid_bin": [_vp] * 10 + [_i, _i, _i, _vp],
+    "gridmm_grid_bin_sliced": [_vp] * 11 + [_i, _i, _i, _i, _vp],
     "gridmm_grid_sort_ids": [_vp] * 4 + [_i, _i, _vp],
     "gridmm_text_fragments": [_vp, _vp, _i, _i, _i, _vp],
     "gridmm_grid_aggregate": [_vp] * 8 + [_i, _i, _i, _i, _i, _vp],

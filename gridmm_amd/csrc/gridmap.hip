@@ -230,6 +230,144 @@ __global__ __launch_bounds__(1024) void grid_bin_sort_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same sort for deep memories (tens of thousands of points per episode), cut into S slices per episode so that
+// S x B workgroups work on it instead of B: histogram | scan | scatter.  Wave w of slice s owns the contiguous
+// sub-slice (16 s + w) of the history, so the order inside a cell is still ascending point index.
+// ws [B][S][16 + 1][NBIN] int32: rows 0..15 = exclusive prefix of the slice's 16 per-wave histograms, row 16 = the
+// slice's total per bin, turned into the slice's absolute base per bin by the scan (S rows per bin: short).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slice_range(int n, int S, int gw, int& lo, int& hi) {
+  const int per_wave = ((n + S * SORT_WAVES * 64 - 1) / (S * SORT_WAVES * 64)) * 64;   // multiple of 64
+  lo = gw * per_wave;
+  hi = min(n, lo + per_wave);
+}
+
+template <bool COMPUTE>
+__global__ __launch_bounds__(1024) void grid_bin_hist_kernel(
+    const float* __restrict__ hist_x, const float* __restrict__ hist_y, const uint8_t* __restrict__ hist_valid,
+    const int32_t* __restrict__ n_pts, const float* __restrict__ pose, const float* __restrict__ head_cs,
+    const float* __restrict__ half_len, int16_t* __restrict__ cell_id, int32_t* __restrict__ ws, int cap, int flags) {
+  __shared__ int s_cur[SORT_WAVES][NBIN];
+  const int sl = blockIdx.x, S = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int lo, hi;
+  slice_range(n_pts[b], S, sl * SORT_WAVES + wave, lo, hi);
+  for (int i = tid; i < SORT_WAVES * NBIN; i += 1024) (&s_cur[0][0])[i] = 0;
+  __syncthreads();
+  float px = 0.f, py = 0.f, c = 0.f, s = 0.f, hl = 0.f, two_h = 0.f;
+  if (COMPUTE) {
+    px = pose[2 * b]; py = pose[2 * b + 1];
+    c = head_cs[2 * b]; s = head_cs[2 * b + 1];
+    hl = half_len[b]; two_h = 2.0f * hl;
+  }
+  int16_t* ids = cell_id + (size_t)b * cap;
+  for (int i = lo + lane; i < hi; i += 64) {
+    int id;
+    if (COMPUTE) {   // the arithmetic of grid_bin_sort_kernel, operation for operation (bit-exact cell ids)
+      const size_t o = (size_t)b * cap + i;
+      const float tx = hist_x[o] - px, ty = hist_y[o] - py;                  // env.py:344-345
+      const float a0 = tx * c, a1 = ty * s, a2 = ty * c, a3 = tx * s;
+      const float sx = a0 + a1, my = a2 - a3;                                 // env.py:347-348
+      const float mx = (flags & FLAG_VLNCE) ? -sx : sx;                       // VLN-CE :797
+      int cx = trunc_x86(((mx + hl) / two_h) * 13.0f);                        // env.py:349
+      int cy = trunc_x86(((my + hl) / two_h) * 13.0f);                        // env.py:351
+      cx = cx < 0 ? 0 : (cx > 13 ? 13 : cx);                                  // env.py:353-357
+      cy = cy < 0 ? 0 : (cy > 13 ? 13 : cy);
+      id = hist_valid[o] ? cx * GRIDMM_GRID + cy : -1;                        // env.py:359-369
+      ids[i] = (int16_t)id;
+    } else {
+      id = ids[i];
+      if (id < -1 || id >= GRIDMM_CELLS) id = -1;
+    }
+    atomicAdd(&s_cur[wave][id < 0 ? GRIDMM_CELLS : id], 1);
+  }
+  __syncthreads();
+  int32_t* out = ws + ((size_t)b * S + sl) * (SORT_WAVES + 1) * NBIN;
+  if (tid < NBIN) {                      // exclusive scan over the 16 sub-slices of this slice (point order)
+    int run = 0;
+    for (int w = 0; w < SORT_WAVES; ++w) {
+      const int v = s_cur[w][tid];
+      out[w * NBIN + tid] = run;
+      run += v;
+    }
+    out[SORT_WAVES * NBIN + tid] = run;
+  }
+}
+
+__global__ __launch_bounds__(256) void grid_bin_scan_kernel(int32_t* __restrict__ ws, int32_t* __restrict__ cell_start,
+                                                            int S) {
+  __shared__ int s_start[NBIN + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int32_t* tot = ws + (size_t)b * S * (SORT_WAVES + 1) * NBIN + SORT_WAVES * NBIN;   // row 16 of slice 0
+  const size_t stride = (size_t)(SORT_WAVES + 1) * NBIN;
+  int mine[64];
+  int run = 0;
+  if (tid < NBIN) {                      // exclusive scan over the slices of a bin
+    for (int r = 0; r < S; ++r) {
+      const int v = tot[r * stride + tid];
+      mine[r] = run;
+      run += v;
+    }
+    s_start[tid] = run;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < NBIN; ++k) {
+      const int v = s_start[k];
+      s_start[k] = acc;
+      acc += v;
+    }
+    s_start[NBIN] = acc;  // == n
+  }
+  __syncthreads();
+  if (tid < NBIN) {
+    const int base = s_start[tid];
+    for (int r = 0; r < S; ++r) tot[r * stride + tid] = base + mine[r];   // absolute base of slice r in this bin
+  }
+  if (tid <= NBIN) cell_start[(size_t)b * (NBIN + 1) + tid] = s_start[tid];
+}
+
+__global__ __launch_bounds__(1024) void grid_bin_scatter_kernel(const int16_t* __restrict__ cell_id,
+                                                                const int32_t* __restrict__ n_pts,
+                                                                const int32_t* __restrict__ ws,
+                                                                int32_t* __restrict__ perm, int cap) {
+  __shared__ int s_cur[SORT_WAVES][NBIN];
+  const int sl = blockIdx.x, S = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int lo, hi;
+  slice_range(n_pts[b], S, sl * SORT_WAVES + wave, lo, hi);
+  const int32_t* in_ws = ws + ((size_t)b * S + sl) * (SORT_WAVES + 1) * NBIN;
+  for (int i = tid; i < SORT_WAVES * NBIN; i += 1024)          // write cursor = slice base of the bin + wave prefix
+    (&s_cur[0][0])[i] = in_ws[i] + in_ws[SORT_WAVES * NBIN + i % NBIN];
+  __syncthreads();
+  const int16_t* ids = cell_id + (size_t)b * cap;
+  int32_t* pm = perm + (size_t)b * cap;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (int i0 = lo; i0 < hi; i0 += 64) {       // stable scatter, 64 points at a time per wave, in point order
+    const int i = i0 + lane;
+    const bool in = i < hi;
+    int id = in ? (int)ids[i] : -2;
+    if (in && (id < 0 || id >= GRIDMM_CELLS)) id = GRIDMM_CELLS;
+    unsigned long long todo = __ballot(in);
+    int rank = 0, cnt = 0;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int lid = __shfl(id, leader, 64);
+      const unsigned long long m = __ballot(in && id == lid);
+      if (in && id == lid) {
+        rank = __popcll(m & lt_mask);
+        cnt = __popcll(m);
+      }
+      todo &= ~m;
+    }
+    if (in) pm[s_cur[wave][id] + rank] = i;
+    __builtin_amdgcn_wave_barrier();
+    if (in && rank == 0) s_cur[wave][id] += cnt;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 extern "C" int gridmm_grid_project(const void* depth, int depth_f32, const float* x_off, const float* view_cos,
@@ -269,6 +407,24 @@ extern "C" int gridmm_grid_sort_ids(const int16_t* cell_id, const int32_t* n_pts
   GRIDMM_LAUNCH((grid_bin_sort_kernel<false>), dim3(B), dim3(1024), 0, as_stream(stream), nullptr,
                 nullptr, nullptr, n_pts, nullptr, nullptr, nullptr, const_cast<int16_t*>(cell_id), perm,
                 cell_start, cap, 0);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_grid_bin_sliced(const float* hist_x, const float* hist_y, const uint8_t* hist_valid,
+                                      const int32_t* n_pts, const float* pose, const float* head_cs,
+                                      const float* half_len, int16_t* cell_id, int32_t* perm, int32_t* cell_start,
+                                      int32_t* workspace, int slices, int B, int cap, int flags,
+                                      gridmm_stream_t stream) {
+  if (B <= 0 || cap <= 0 || slices < 1 || slices > 64) return GRIDMM_EINVAL;
+  if (slices == 1 || !workspace)
+    return gridmm_grid_bin(hist_x, hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start, B,
+                           cap, flags, stream);
+  hipStream_t st = as_stream(stream);
+  GRIDMM_LAUNCH((grid_bin_hist_kernel<true>), dim3(slices, B), dim3(1024), 0, st, hist_x, hist_y, hist_valid, n_pts,
+                pose, head_cs, half_len, cell_id, workspace, cap, flags);
+  GRIDMM_LAUNCH(grid_bin_scan_kernel, dim3(B), dim3(256), 0, st, workspace, cell_start, slices);
+  GRIDMM_LAUNCH(grid_bin_scatter_kernel, dim3(slices, B), dim3(1024), 0, st, cell_id, n_pts, workspace, perm, cap);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

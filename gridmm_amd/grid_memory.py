@@ -19,6 +19,7 @@ Layout in HBM for B episodes, capacity `cap = max_steps * pts_per_obs` points ea
   bbox (B,4), half_len (B,), pos_fts (B,196,5)
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -28,6 +29,8 @@ from .synthetic import GridGeometry, NATIVE  # noqa: F401  (geometry description
 
 
 class GridMemoryBatch:
+    MAX_BIN_SLICES = 16
+
     def __init__(self, batch_size, geom=NATIVE, max_steps=15, device="cuda"):
         self.B, self.geom, self.max_steps = batch_size, geom, max_steps
         self.device = torch.device(device)
@@ -45,6 +48,7 @@ class GridMemoryBatch:
         self.half_len = torch.zeros(B, dtype=torch.float32, device=dev)
         self.pos_fts = torch.zeros(B, 196, 5, dtype=torch.float32, device=dev)
         self.n_pts = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._bin_ws = torch.empty(B, self.MAX_BIN_SLICES * 17, 197, dtype=torch.int32, device=dev)
         self.n_pts_host = np.zeros(B, np.int64)
         self.keep_for_backward = False
         # static per-step inputs (pinned host -> device): the only bytes that cross PCIe each step
@@ -126,8 +130,13 @@ class GridMemoryBatch:
                          None if self._active is None else self.act_d,
                          self.geom.n_views, self.geom.patches ** 2, self.geom.depth_div, self.flags,
                          self.geom.max_dist)
+        # one workgroup per episode for small memories, else 8 / 16 slices of the history on their own workgroups
+        # (tools/bench_bin.py: N = 7056: 33 -> 18 us, N = 105840: 274 -> 46 us).  Host-known depth: the choice is static
+        # inside a captured graph.
+        n_after = int(self.n_pts_host.max()) + self.n_new
+        slices = int(os.environ.get("GRIDMM_BIN_SLICES", 0)) or (1 if n_after < 3000 else 8 if n_after < 60000 else 16)
         ops.grid_bin(self.hist_x, self.hist_y, self.hist_valid, self.n_pts, self.pose_d, self.head_d, self.half_len,
-                     self.cell_id, self.perm, self.cell_start, self.flags)
+                     self.cell_id, self.perm, self.cell_start, self.flags, workspace=self._bin_ws, slices=slices)
 
     def step(self, depth, feats, poses, headings, active=None):
         """Append one observation per episode and re-bin the whole history (getGlobalMap for all i).

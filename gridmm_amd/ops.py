@@ -390,9 +390,17 @@ def grid_project(depth, x_off, view_cos, view_sin, pose, n_old, hist_x, hist_y, 
                                        int(flags), float(max_dist), _stream()), "gridmm_grid_project")
 
 
-def grid_bin(hist_x, hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start, flags=0):
+def grid_bin(hist_x, hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start, flags=0,
+             workspace=None, slices=1):
+    """slices > 1 (+ workspace (B, slices, 17, 197) int32): the multi-workgroup form for deep memories."""
     lib = _lib.load()
     B, cap = hist_x.shape
+    if slices > 1 and workspace is not None:
+        assert workspace.dtype == torch.int32 and workspace.numel() >= B * slices * 17 * 197
+        _lib.check(lib.gridmm_grid_bin_sliced(_p(hist_x), _p(hist_y), _p(hist_valid), _p(n_pts), _p(pose), _p(head_cs),
+                                              _p(half_len), _p(cell_id), _p(perm), _p(cell_start), _p(workspace),
+                                              int(slices), B, cap, int(flags), _stream()), "gridmm_grid_bin_sliced")
+        return
     _lib.check(lib.gridmm_grid_bin(_p(hist_x), _p(hist_y), _p(hist_valid), _p(n_pts), _p(pose), _p(head_cs),
                                    _p(half_len), _p(cell_id), _p(perm), _p(cell_start), B, cap, int(flags),
                                    _stream()), "gridmm_grid_bin")

@@ -89,6 +89,15 @@ int gridmm_grid_bin(const float* hist_x, const float* hist_y, const uint8_t* his
 int gridmm_grid_sort_ids(const int16_t* cell_id, const int32_t* n_pts, int32_t* perm,
                          int32_t* cell_start, int B, int cap, gridmm_stream_t stream);
 
+/* gridmm_grid_bin for deep memories: the same result (bit-exact cell ids, the same stable order), with every episode
+ * cut into `slices` contiguous parts handled by their own workgroups (histogram | scan | scatter; 3 launches).
+ *   workspace  [B][slices][17][197] int32 scratch;  slices = 1 (or workspace NULL) runs gridmm_grid_bin.
+ * Replaces: the same lines as gridmm_grid_bin (map_nav_src/r2r/env.py:337-369). */
+int gridmm_grid_bin_sliced(const float* hist_x, const float* hist_y, const uint8_t* hist_valid,
+                           const int32_t* n_pts, const float* pose, const float* head_cs,
+                           const float* half_len, int16_t* cell_id, int32_t* perm, int32_t* cell_start,
+                           int32_t* workspace, int slices, int B, int cap, int flags, gridmm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Instruction-relevance grid aggregation
  * ---------------------------------------------------------------------------------------- */

@@ -117,3 +117,39 @@ def test_vlnce_twin_cell_ids_bit_exact_vs_reference_golden():
             n = 588 * (t + 1)
             assert np.array_equal(mem.cell_id[0, :n].cpu().numpy(), fx[p + "grid_map"]), (name, t)
             assert np.allclose(mem.pos_fts[0].cpu().numpy(), fx[p + "pos_fts"], atol=2e-6), (name, t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slices", [2, 8, 16])
+def test_sliced_rebin_is_identical_to_the_single_workgroup_sort(slices):
+    """gridmm_grid_bin_sliced (histogram | scan | scatter over `slices` workgroups per episode, used for memories of more
+    than a few thousand points) vs gridmm_grid_bin: same cell ids, same cell_start, same stable order -- on ragged
+    histories (different lengths per episode, one empty, one not a multiple of anything)."""
+    from gridmm_amd import ops
+    B, cap = 5, 40000
+    g = torch.Generator().manual_seed(slices)
+    n = torch.tensor([40000, 12345, 0, 63, 7056], dtype=torch.int32)
+    hx = (torch.rand(B, cap, generator=g) * 30 - 15).cuda()
+    hy = (torch.rand(B, cap, generator=g) * 30 - 15).cuda()
+    hv = (torch.rand(B, cap, generator=g) > 0.1).to(torch.uint8).cuda()
+    pose = (torch.rand(B, 2, generator=g) * 4 - 2).cuda()
+    ang = torch.rand(B, generator=g) * 6.28
+    head = torch.stack([torch.cos(ang), torch.sin(ang)], 1).cuda()
+    half = (torch.rand(B, generator=g) * 10 + 8).cuda()
+    outs = []
+    for S in (1, slices):
+        cid = torch.full((B, cap), -7, dtype=torch.int16, device="cuda")
+        perm = torch.full((B, cap), -1, dtype=torch.int32, device="cuda")
+        cs = torch.zeros(B, 198, dtype=torch.int32, device="cuda")
+        ws = torch.empty(B, S * 17, 197, dtype=torch.int32, device="cuda")
+        ops.grid_bin(hx, hy, hv, n.cuda(), pose, head, half, cid, perm, cs, 0, workspace=ws, slices=S)
+        torch.cuda.synchronize()
+        outs.append((cid.cpu(), perm.cpu(), cs.cpu()))
+    (c0, p0, s0), (c1, p1, s1) = outs
+    assert torch.equal(s0, s1)
+    for b in range(B):
+        k = int(n[b])
+        assert int(s0[b, 197]) == k
+        assert torch.equal(c0[b, :k], c1[b, :k]) and torch.equal(p0[b, :k], p1[b, :k])
+        assert sorted(p1[b, :k].tolist()) == list(range(k))                      # a permutation
+        assert (p1[b, k:] == -1).all() and (c1[b, k:] == -7).all()               # nothing written past the history
