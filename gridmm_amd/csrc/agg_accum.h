@@ -47,7 +47,7 @@ __device__ __forceinline__ void reg_fence(uint2& x0, uint2& x1) { asm volatile("
 
 // One wave's share of the accumulation: the 16-dim blocks bw, bw + nbw, ... (at most NBW of them) of every cell.
 // Every accumulating wave of a workgroup runs tile() on every tile with the same inputs, so their scalars agree.
-template <int D, int NBW>
+template <int D, int NBW, int GB = 4>   // GB: 16-dim blocks per transpose-read group (two groups of registers in flight)
 struct CellAccumulator {
   static constexpr int NBLK = D / 16;
   float* cells_b;                   // [196][D] of this episode
@@ -198,7 +198,7 @@ struct CellAccumulator {
                                                                                : min(kg0 + qs, GRIDMM_CELLS - 1))))
                    : "memory");
       // transpose reads in groups of GB blocks, one group ahead of the MFMAs that consume them
-      constexpr int GB = 4, NG = (NBW + GB - 1) / GB;
+      constexpr int NG = (NBW + GB - 1) / GB;
       uint2 xr[NBW][2];
       auto issue_group = [&](int gi) {
 #pragma unroll
