@@ -171,6 +171,11 @@ class GridMemoryBatch:
         self.n_pts_host[act_host] += n_new            # host mirror of the device-side counter
         return self.pos_fts
 
+    def points_upper_bound(self):
+        """Host-known bound of the points per episode after the step in flight (graph replays append one observation
+        to the restored history without touching the host mirror)."""
+        return min(self.cap, int(self.n_pts_host.max()) + self.n_new)
+
     def next_slot(self):
         """(B, n_new, D) view of the slab where the next observation's tokens go (lock-step batches)."""
         n0 = int(self.n_pts_host[0])

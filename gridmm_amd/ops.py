@@ -424,9 +424,10 @@ def text_fragments(text_fts):
     return frag
 
 
-def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_relevance=False):
+def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_relevance=False, n_points=None):
     """slab (B,cap,D) fp16 -> cells (B,196,D) fp32, occ (B,196) uint8 [, relevance (B,cap) fp32: w of the point at
-    SORTED position p, i.e. of slot perm[b, p]]."""
+    SORTED position p, i.e. of slot perm[b, p]].  n_points: host-known upper bound of the points per episode (defaults to
+    the slab capacity); only steers the chunking."""
     lib = _lib.load()
     B, cap, D = slab.shape
     assert slab.dtype == torch.float16 and slab.is_contiguous()
@@ -434,7 +435,7 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
         n_chunks = max(1, min(N_CELLS, -(-256 // B)))   # one workgroup per CU (256): 155 us vs 180 us with two rounds
         # chunks are cut at cell boundaries: with deep memories (>~4400 points per workgroup) a few crowded cells unbalance
         # them, and finer chunks let the dispatcher level the load (t=15: 1110 -> 990 us; t=5 is best with one round)
-        n_chunks = min(N_CELLS, n_chunks * max(1, min(6, round(cap / n_chunks / 4400))))
+        n_chunks = min(N_CELLS, n_chunks * max(1, min(6, round((n_points or cap) / n_chunks / 4400))))
         if os.environ.get("GRIDMM_AGG_CHUNKS"):
             n_chunks = int(os.environ["GRIDMM_AGG_CHUNKS"])
     dev = slab.device

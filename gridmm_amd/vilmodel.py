@@ -449,13 +449,15 @@ class GlocalTextPathNavCMT(nn.Module):
         txt = ops.split_rows(txt_embeds)                       # fp32 + bf16 planes of the instruction tokens
         text_fts = ops.linear(txt, self._lin(self.text_proj, "text_proj")).f32
         frag = ops.text_fragments(text_fts)
+        n_points = None
         if grid_memory is not None:
             slab, perm, cell_start = grid_memory.slab, grid_memory.perm, grid_memory.cell_start
+            n_points = grid_memory.points_upper_bound()   # the slab is allocated for max_steps observations
             if gridmap_pos_fts is None:
                 gridmap_pos_fts = grid_memory.pos_fts
         else:
             slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
-        cells, occ = ops.grid_aggregate(slab, perm, cell_start, frag, L)
+        cells, occ = ops.grid_aggregate(slab, perm, cell_start, frag, L, n_points=n_points)
         proj = ops.linear(cells, self._lin(self.grid_proj, "grid_proj")).f32
         gp = self.grid_pos_embeddings
         pos_emb = self._ln(gp[1], ops.linear(gridmap_pos_fts.float().contiguous(), self._lin(gp[0], "grid_pos"))).f32
