@@ -459,6 +459,12 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
                                float* cells, uint8_t* occ, float* relevance, const int32_t* chunks, int B, int cap, int D,
                                int L, int n_chunks, hipStream_t st);
 
+// aggregate_rel.hip + aggregate_pipe.hip (PREW): the two-pass D = 768 path (needs the `relevance` buffer as scratch)
+int gridmm_grid_relevance_wide(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
+                               float* relevance, int B, int cap, int D, int L, int n_chunks, hipStream_t st);
+int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int32_t* cell_start, const float* w,
+                               float* cells, uint8_t* occ, int B, int cap, int D, int n_chunks, hipStream_t st);
+
 extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
                                      const void* text_frag, float* cells, uint8_t* occ, float* relevance,
                                      int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
@@ -470,6 +476,12 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
   if (gridmm_grid_aggregate_pipe(slab, perm, cell_start, text_frag, cells, occ, relevance, chunks, B, cap, D, L, n_chunks,
                                  st) == GRIDMM_OK)
     return GRIDMM_OK;     // D <= 512 and L <= 96: two-stage wave-specialised pipeline; otherwise the generic kernel below
+  if (D == 768 && relevance && L <= 80 && (size_t)cap <= 60000 &&
+      gridmm_grid_relevance_wide(slab, perm, cell_start, text_frag, relevance, B, cap, D, L, n_chunks, st) == GRIDMM_OK) {
+    // D = 768, L <= 80: relevance pass (text fragments spread over 8 waves) + accumulation pass on the resident slab
+    const int rc = gridmm_grid_aggregate_prew(slab, perm, cell_start, relevance, cells, occ, B, cap, D, n_chunks, st);
+    if (rc == GRIDMM_OK) return rc;
+  }
   GRIDMM_LAUNCH(build_chunks_kernel, dim3(B), dim3(256), 0, st, cell_start, chunks, n_chunks);
   const bool resident = Lt <= 8 && D != 768;   // D = 768: 192 VGPRs of resident fragments spill (180 B/lane); streaming them from L2 measured 172 vs 185 us
   const int nwaves = 8;   // 2 per SIMD; the relevance work is levelled over them inside the kernel

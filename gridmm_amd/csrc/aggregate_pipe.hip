@@ -32,7 +32,9 @@ __device__ long long g_prof[8][8];
 using namespace gridmm_agg;
 constexpr int MAXR = 12;          // rows DMA'd per R-wave and tile, at most (ceil(PT / Lt), Lt >= 3)
 
-template <int KS, int R, int NBW>   // D = 32 * KS; NBW = 16-dim blocks per B-wave (at least ceil(D / 16 / B-waves))
+// PREW: the relevance of every point is an INPUT (`relevance`, by sorted position; aggregate_rel.hip computed it): the
+// R-waves only feed the ring -- the second pass of the D = 768 path, whose text fragments do not fit one wave.
+template <int KS, int R, int NBW, bool PREW = false>   // D = 32 * KS; NBW = 16-dim blocks per B-wave (at least ceil(D / 16 / B-waves))
 __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
     const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
     const _Float16* __restrict__ text_frag, float* __restrict__ cells, uint8_t* __restrict__ occ,
@@ -47,7 +49,8 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   unsigned char* s_tab = reinterpret_cast<unsigned char*>(s_cs + 200);          // [8] per-B-wave tables, TAB_BYTES each
   int* s_ids = reinterpret_cast<int*>(s_tab + 8 * TAB_BYTES);                   // [8 waves][4 tiles][MAXR] slab rows to fetch
   int* s_necell = s_ids + 8 * 4 * MAXR;                                         // [200] non-empty cells of this chunk, in order
-  unsigned* s_hbits = reinterpret_cast<unsigned*>(s_necell + 200);              // [ntiles] bit j of word t: a cell starts at
+  float* s_w = reinterpret_cast<float*>(s_necell + 200);                        // [8 tiles][PT] relevance tiles (PREW)
+  unsigned* s_hbits = reinterpret_cast<unsigned*>(s_w + 8 * PT);              // [ntiles] bit j of word t: a cell starts at
                                                                                 // point 32 t + j of the chunk (run heads)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -131,7 +134,14 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
                                        (__attribute__((address_space(3))) void*)(s_ids + (wave * 4 + (t & 3)) * MAXR),
                                        4, 0, 0);
     }
+    if (PREW && wave == 0 && lane < PT) {                  // the tile's relevance values travel with its row ids
+      int p = p_lo + t * PT + lane;
+      if (p >= p_hi) p = p_hi - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(relevance + (size_t)b * cap + p),
+                                       (__attribute__((address_space(3))) void*)(s_w + (t & 7) * PT), 4, 0, 0);
+    }
   };
+  const int ids_instrs = (PREW && wave == 0) ? 2 : 1;      // vector-memory instructions of one load_ids()
   int ids_s[MAXR];                                         // slab rows of the tile being fetched (wave-uniform)
   auto dma_prepare = [&](int t) {
     static_assert(MAXR == 12, "ids are read as three int4");
@@ -178,6 +188,19 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
       case 6: wait_vm<6>(); break;
       case 5: wait_vm<5>(); break;
       case 4: wait_vm<4>(); break;
+      case 26: wait_vm<26>(); break;
+      case 25: wait_vm<25>(); break;
+      case 24: wait_vm<24>(); break;
+      case 23: wait_vm<23>(); break;
+      case 22: wait_vm<22>(); break;
+      case 21: wait_vm<21>(); break;
+      case 20: wait_vm<20>(); break;
+      case 19: wait_vm<19>(); break;
+      case 18: wait_vm<18>(); break;
+      case 17: wait_vm<17>(); break;
+      case 16: wait_vm<16>(); break;
+      case 15: wait_vm<15>(); break;
+      case 14: wait_vm<14>(); break;
       case 3: wait_vm<3>(); break;
       case 2: wait_vm<2>(); break;
       case 1: wait_vm<1>(); break;
@@ -198,8 +221,10 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
 #ifdef GRIDMM_AGG_PROF
     pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta;
 #endif
-    if (i >= 1 && i + R - 1 < ntiles) wait_vm_dyn((R - 3) * my_rows * IPR + 1);   // steady state
-    else if (i + 1 < ntiles) wait_vm_dyn((R - 3) * my_rows * IPR);                // first / last iterations: tiles only
+    // (PREW: nobody computes on tile i in iteration i, so the loaders only need tile i - 1 here and keep tile i flying)
+    constexpr int KEEP = PREW ? 1 : R - 3;
+    if (i >= 1 && i + R - 1 < ntiles) wait_vm_dyn(KEEP * my_rows * IPR + ids_instrs);   // steady state
+    else if (PREW ? i < ntiles : i + 1 < ntiles) wait_vm_dyn(KEEP * my_rows * IPR);      // first / last iterations: tiles only
     else wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef GRIDMM_AGG_PROF
@@ -227,6 +252,20 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   // Two loops (same barrier sequence) so that the register allocator never sees the R-waves' text fragments and the
   // B-waves' accumulators live at the same time.
   if (is_r) {
+  if constexpr (PREW) {                         // loader waves of the second pass: ring feed only
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int t = 0; t < R && t < ntiles; ++t) load_ids(t);
+    wait_vm<0>();
+    __syncthreads();
+    for (int t = 0; t < R - 2 && t < ntiles; ++t) { dma_prepare(t); dma_rows(t, 0, MAXR); }
+    for (int i = 0; i <= ntiles; ++i) {
+      iter_head_r(i);
+      if (i + R - 2 < ntiles) {
+        dma_rows(i + R - 2, 0, MAXR);
+        if (i + R < ntiles) load_ids(i + R);
+      }
+    }
+  } else {
     f16x8_t thi[KS], tlo[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -289,6 +328,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
         }
       }
     }
+  }
   } else {
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -306,7 +346,12 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
         const int lp = lane & (PT - 1);                            // lanes >= PT mirror (results unused)
         float w;
         unsigned hb;
-        {
+        if constexpr (PREW) {
+          const unsigned a_w = (unsigned)(size_t)(s_w + (t & 7) * PT + lp);
+          const unsigned a_h = (unsigned)(size_t)(s_hbits + t);
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(w), "=&v"(hb) : "v"(a_w), "v"(a_h) : "memory");
+        } else {
           const unsigned a_w = (unsigned)(size_t)(s_wmax + ((t & 1) * PT + lp) * 8);
           const unsigned a_h = (unsigned)(size_t)(s_hbits + t);
           float4 w0, w1;
@@ -314,8 +359,8 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
                        "s_waitcnt lgkmcnt(0)"
                        : "=&v"(w0), "=&v"(w1), "=&v"(hb) : "v"(a_w), "v"(a_h) : "memory");
           w = fmaxf(fmaxf(fmaxf(w0.x, w0.y), fmaxf(w0.z, w0.w)), fmaxf(fmaxf(w1.x, w1.y), fmaxf(w1.z, w1.w)));
+          if (relevance && wave == 7 && lane < npt) relevance[(size_t)b * cap + p0 + lane] = w;   // by sorted position
         }
-        if (relevance && wave == 7 && lane < npt) relevance[(size_t)b * cap + p0 + lane] = w;   // by sorted position
         cacc.tile(t, npt, w, (unsigned)__builtin_amdgcn_readfirstlane((int)hb), s_tile);
       }
     }
@@ -351,7 +396,8 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
   constexpr int R = 4;
   const size_t hb_words = (size_t)(cap + PT - 1) / PT;       // run-head bitmask of (at most) a whole episode
   const size_t lds = (size_t)R * PT * D * 2 + 2 * 8 * PT * sizeof(float) + 200 * sizeof(int) +
-                     8 * TAB_BYTES + 8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + hb_words * sizeof(unsigned);
+                     8 * TAB_BYTES + 8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + 8 * PT * sizeof(float) +
+                     hb_words * sizeof(unsigned);
   if (lds > 160 * 1024) return GRIDMM_EINVAL;                // D = 512: up to ~185k points per episode
   dim3 grid(n_chunks, B), block(512);
 #define GRIDMM_AGGP(KS, RR, NBW)                                                                                     \
@@ -369,6 +415,28 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
     if (nbw >= 2) GRIDMM_AGGP(8, 4, 8); else GRIDMM_AGGP(8, 4, 16);
   }
 #undef GRIDMM_AGGP
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+// Second pass of the D = 768 path: w (relevance by sorted position, from gridmm_grid_relevance_wide) -> cells / occ.
+// 3 loader waves + 5 accumulating waves, ring of 3 x 48 KB.
+int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int32_t* cell_start, const float* w,
+                               float* cells, uint8_t* occ, int B, int cap, int D, int n_chunks, hipStream_t st) {
+  if (D != 768) return GRIDMM_EINVAL;
+  constexpr int R = 3, LOADERS = 3;
+  const size_t hb_words = (size_t)(cap + PT - 1) / PT;
+  const size_t lds = (size_t)R * PT * D * 2 + 2 * 8 * PT * sizeof(float) + 200 * sizeof(int) + 8 * TAB_BYTES +
+                     8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + 8 * PT * sizeof(float) +
+                     hb_words * sizeof(unsigned);
+  if (lds > 160 * 1024) return GRIDMM_EINVAL;                // up to ~60k points per episode
+  auto kern = grid_aggregate_pipe_kernel<24, R, 10, true>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+      hipSuccess)
+    return GRIDMM_EINVAL;
+  GRIDMM_LAUNCH(kern, dim3(n_chunks, B), dim3(512), lds, st, (const _Float16*)slab, perm, cell_start,
+                (const _Float16*)nullptr, cells, occ, const_cast<float*>(w), (const int32_t*)nullptr, cap, 0, LOADERS,
+                n_chunks);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -441,7 +441,8 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
     dev = slab.device
     cells = torch.empty(B, N_CELLS, D, dtype=torch.float32, device=dev)
     occ = torch.empty(B, N_CELLS, dtype=torch.uint8, device=dev)
-    rel = torch.zeros(B, cap, dtype=torch.float32, device=dev) if want_relevance else None
+    # D = 768: the two-pass path needs the relevance buffer as its intermediate (allocated even when not asked for)
+    rel = torch.zeros(B, cap, dtype=torch.float32, device=dev) if (want_relevance or D == 768) else None
     chunks = torch.empty(B, n_chunks + 1, dtype=torch.int32, device=dev)
     _timed("grid_aggregate", 0.0, lambda: _lib.check(
         lib.gridmm_grid_aggregate(_p(slab), _p(perm), _p(cell_start), _p(text_frag), _p(cells), _p(occ),

@@ -55,7 +55,12 @@ CASES = [
     (512, 120, "blocks", [900, 100], None),      # L > 96: generic kernel
     (256, 80, "blocks", [3000, 500], None),
     (256, 64, "sparse", [190, 10], 4),
-    (768, 80, "blocks", [2000, 300], None),      # D = 768: generic kernel
+    (768, 80, "blocks", [2000, 300], None),      # D = 768, L <= 80: relevance pass + accumulation pass
+    (768, 80, "sparse", [150, 97, 0, 260], None),
+    (768, 80, "crowded", [9000, 1111, 33, 1], 8),
+    (768, 40, "blocks", [2047, 31], 4),          # 3 token tiles: waves 5..7 hold no text
+    (768, 16, "crowded", [700], None),
+    (768, 96, "blocks", [900, 100], None),       # D = 768, L > 80: generic kernel
     (512, 80, "crowded", [210000], 8),           # run-head bitmask of the episode exceeds LDS: generic kernel
     (512, 80, "crowded", [150000], 8),           # largest memories the pipelined kernel takes (4700 tiles per workgroup)
 ]
