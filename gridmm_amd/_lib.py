@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -27,6 +27,7 @@ SIGNATURES = {
     "gridmm_grid_sort_ids": [_vp] * 4 + [_i, _i, _vp],
     "gridmm_text_fragments": [_vp, _vp, _i, _i, _i, _vp],
     "gridmm_grid_aggregate": [_vp] * 8 + [_i, _i, _i, _i, _i, _vp],
+    "gridmm_grid_aggregate_train": [_vp] * 9 + [_i, _i, _i, _i, _i, _vp],
     "gridmm_cells_compact": [_vp] * 7 + [_i, _i, _i, _vp],
     "gridmm_split_weight": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_linear": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
@@ -52,6 +53,7 @@ SIGNATURES = {
                              _vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f,
                              ctypes.c_uint64, _vp],
     "gridmm_grid_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_grid_aggregate_bwd_routed": [_vp] * 9 + [_i, _i, _i, _i, _vp],
     "gridmm_grad_sumsq": [_vp, _i64, _i, _vp, _vp],
     "gridmm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
     "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],

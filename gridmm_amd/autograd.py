@@ -338,7 +338,8 @@ class _GridAggregate(torch.autograd.Function):
         text_fts = text_fts.contiguous()
         B, L, D = text_fts.shape
         frag = ops.text_fragments(text_fts)
-        cells, occ, rel = ops.grid_aggregate(slab, perm, cell_start, frag, L, want_relevance=True)
+        cells, occ, rel, amax = ops.grid_aggregate(slab, perm, cell_start, frag, L, want_relevance=True, want_amax=True)
+        ctx.amax = amax                      # routing of the backward (None: generic kernel, the backward recomputes it)
         # The grid memory re-bins its whole history in place every step: keep THIS step's point order.  The slab
         # is append-only within a rollout (rows this step's perm refers to are never rewritten; a training rollout
         # gets a fresh slab, GridMemoryBatch.reset), so it is referenced, not copied -- and kept out of
@@ -358,6 +359,12 @@ class _GridAggregate(torch.autograd.Function):
         dcells = dcells.contiguous()
         dtext = torch.empty_like(text_fts)
         da = torch.empty(B, cap, dtype=torch.float32, device=slab.device)
+        if ctx.amax is not None:
+            dw = torch.empty(B, cap, dtype=torch.float32, device=slab.device)
+            _lib.check(lib.gridmm_grid_aggregate_bwd_routed(_p(slab), _p(perm), _p(cell_start), _p(rel), _p(ctx.amax),
+                                                            _p(dcells), _p(dtext), _p(da), _p(dw), B, cap, D, L,
+                                                            _stream()), "gridmm_grid_aggregate_bwd_routed")
+            return dtext, None, None, None
         am = torch.empty(B, cap, dtype=torch.int32, device=slab.device)
         _lib.check(lib.gridmm_grid_aggregate_bwd(_p(slab), _p(perm), _p(cell_start), _p(rel), _p(text_fts),
                                                  _p(dcells), _p(dtext), _p(da), _p(am), B, cap, D, L, _stream()),

@@ -456,28 +456,32 @@ extern "C" int gridmm_text_fragments(const float* text, void* frag, int B, int L
 
 // aggregate_pipe.hip: the wave-specialised variant (GRIDMM_EINVAL when the shape is outside its range)
 int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
-                               float* cells, uint8_t* occ, float* relevance, const int32_t* chunks, int B, int cap, int D,
+                               float* cells, uint8_t* occ, float* relevance, int32_t* amax, int B, int cap, int D,
                                int L, int n_chunks, hipStream_t st);
 
 // aggregate_rel.hip + aggregate_pipe.hip (PREW): the two-pass D = 768 path (needs the `relevance` buffer as scratch)
 int gridmm_grid_relevance_wide(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
-                               float* relevance, int B, int cap, int D, int L, int n_chunks, hipStream_t st);
+                               float* relevance, int32_t* amax, int B, int cap, int D, int L, int n_chunks,
+                               hipStream_t st);
 int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int32_t* cell_start, const float* w,
                                float* cells, uint8_t* occ, int B, int cap, int D, int n_chunks, hipStream_t st);
 
-extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
-                                     const void* text_frag, float* cells, uint8_t* occ, float* relevance,
-                                     int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
-                                     gridmm_stream_t stream) {
+// amax (may be NULL): arg-max instruction token of every point, by sorted position -- the routing of the backward.
+// Returns GRIDMM_OK with amax written, 1 when the generic kernel ran (amax untouched), < 0 on error.
+extern "C" int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                           const void* text_frag, float* cells, uint8_t* occ, float* relevance,
+                                           int32_t* amax, int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
+                                           gridmm_stream_t stream) {
   if (B <= 0 || cap <= 0 || L <= 0 || n_chunks <= 0 || n_chunks > GRIDMM_CELLS) return GRIDMM_EINVAL;
   const int Lt = (L + 15) / 16;
   if (Lt > 16) return GRIDMM_EINVAL;  // L <= 256 (reference: max_instr_len 200)
   hipStream_t st = as_stream(stream);
-  if (gridmm_grid_aggregate_pipe(slab, perm, cell_start, text_frag, cells, occ, relevance, chunks, B, cap, D, L, n_chunks,
-                                 st) == GRIDMM_OK)
+  if (gridmm_grid_aggregate_pipe(slab, perm, cell_start, text_frag, cells, occ, relevance, relevance ? amax : nullptr, B,
+                                 cap, D, L, n_chunks, st) == GRIDMM_OK)
     return GRIDMM_OK;     // D <= 512 and L <= 96: two-stage wave-specialised pipeline; otherwise the generic kernel below
-  if (D == 768 && relevance && L <= 80 && (size_t)cap <= 60000 &&
-      gridmm_grid_relevance_wide(slab, perm, cell_start, text_frag, relevance, B, cap, D, L, n_chunks, st) == GRIDMM_OK) {
+  if (D == 768 && relevance && L <= 80 && (size_t)cap <= 45000 &&
+      gridmm_grid_relevance_wide(slab, perm, cell_start, text_frag, relevance, amax, B, cap, D, L, n_chunks, st) ==
+          GRIDMM_OK) {
     // D = 768, L <= 80: relevance pass (text fragments spread over 8 waves) + accumulation pass on the resident slab
     const int rc = gridmm_grid_aggregate_prew(slab, perm, cell_start, relevance, cells, occ, B, cap, D, n_chunks, st);
     if (rc == GRIDMM_OK) return rc;
@@ -513,5 +517,14 @@ extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, cons
 #undef GRIDMM_AGG
 #undef GRIDMM_AGG_ONE
   GRIDMM_CHECK_LAUNCH();
-  return GRIDMM_OK;
+  return amax ? 1 : GRIDMM_OK;
+}
+
+extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                     const void* text_frag, float* cells, uint8_t* occ, float* relevance,
+                                     int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
+                                     gridmm_stream_t stream) {
+  const int rc = gridmm_grid_aggregate_train(slab, perm, cell_start, text_frag, cells, occ, relevance, nullptr, chunks, B,
+                                             cap, D, L, n_chunks, stream);
+  return rc > 0 ? GRIDMM_OK : rc;
 }

@@ -38,7 +38,7 @@ template <int KS, int R, int NBW, bool PREW = false>   // D = 32 * KS; NBW = 16-
 __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
     const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
     const _Float16* __restrict__ text_frag, float* __restrict__ cells, uint8_t* __restrict__ occ,
-    float* __restrict__ relevance, const int32_t* __restrict__ chunks, int cap, int L, int Lt, int n_chunks) {
+    float* __restrict__ relevance, int32_t* __restrict__ amax, int cap, int L, int Lt, int n_chunks) {
   constexpr int D = 32 * KS;
   constexpr int NCH = D / 8;                 // 16-B chunks per row
   constexpr int IPR = (NCH + 63) / 64;       // DMA instructions per row
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   int* s_ids = reinterpret_cast<int*>(s_tab + 8 * TAB_BYTES);                   // [8 waves][4 tiles][MAXR] slab rows to fetch
   int* s_necell = s_ids + 8 * 4 * MAXR;                                         // [200] non-empty cells of this chunk, in order
   float* s_w = reinterpret_cast<float*>(s_necell + 200);                        // [8 tiles][PT] relevance tiles (PREW)
-  unsigned* s_hbits = reinterpret_cast<unsigned*>(s_w + 8 * PT);              // [ntiles] bit j of word t: a cell starts at
+  int* s_warg = reinterpret_cast<int*>(s_w + 8 * PT);                           // [2][PT][8] arg-max token per R-wave (amax)
+  unsigned* s_hbits = reinterpret_cast<unsigned*>(s_warg + 2 * 8 * PT);              // [ntiles] bit j of word t: a cell starts at
                                                                                 // point 32 t + j of the chunk (run heads)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -319,8 +320,32 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
           x0 = fmaxf(x0, colv ? acc0[r] + acc2[r] : NEG_BIG);
           x1 = fmaxf(x1, colv ? acc1[r] + acc3[r] : NEG_BIG);
         }
-        x0 = fmaxf(x0, __shfl_xor(x0, 16, 64)); x1 = fmaxf(x1, __shfl_xor(x1, 16, 64));
-        x0 = fmaxf(x0, __shfl_xor(x0, 32, 64)); x1 = fmaxf(x1, __shfl_xor(x1, 32, 64));
+        if (amax) {   // training: also the arg-max token (first maximum, as torch.max), for the backward's routing
+          int i0 = 0x7fffffff, i1 = 0x7fffffff;
+          x0 = x1 = NEG_BIG;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int tok = wave * 16 + 4 * g + r;
+            const float v0 = tok < L ? acc0[r] + acc2[r] : NEG_BIG, v1 = tok < L ? acc1[r] + acc3[r] : NEG_BIG;
+            if (v0 > x0) { x0 = v0; i0 = tok; }
+            if (v1 > x1) { x1 = v1; i1 = tok; }
+          }
+#pragma unroll
+          for (int m = 16; m <= 32; m <<= 1) {
+            const float y0 = __shfl_xor(x0, m, 64), y1 = __shfl_xor(x1, m, 64);
+            const int j0 = __shfl_xor(i0, m, 64), j1 = __shfl_xor(i1, m, 64);
+            if (y0 > x0 || (y0 == x0 && j0 < i0)) { x0 = y0; i0 = j0; }
+            if (y1 > x1 || (y1 == x1 && j1 < i1)) { x1 = y1; i1 = j1; }
+          }
+          if (g == 0) {
+            int* wa = s_warg + (i & 1) * 8 * PT + wave;
+            wa[pi * 8] = i0;
+            wa[(16 + pi) * 8] = i1;
+          }
+        } else {
+          x0 = fmaxf(x0, __shfl_xor(x0, 16, 64)); x1 = fmaxf(x1, __shfl_xor(x1, 16, 64));
+          x0 = fmaxf(x0, __shfl_xor(x0, 32, 64)); x1 = fmaxf(x1, __shfl_xor(x1, 32, 64));
+        }
         if (g == 0) {
           float* wm = s_wmax + (i & 1) * 8 * PT + wave;
           wm[pi * 8] = x0;
@@ -360,6 +385,20 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
                        : "=&v"(w0), "=&v"(w1), "=&v"(hb) : "v"(a_w), "v"(a_h) : "memory");
           w = fmaxf(fmaxf(fmaxf(w0.x, w0.y), fmaxf(w0.z, w0.w)), fmaxf(fmaxf(w1.x, w1.y), fmaxf(w1.z, w1.w)));
           if (relevance && wave == 7 && lane < npt) relevance[(size_t)b * cap + p0 + lane] = w;   // by sorted position
+          if (amax && wave == 7) {              // arg-max token: first column (R-wave = token tile) that attains w
+            const unsigned a_a = (unsigned)(size_t)(s_warg + ((t & 1) * PT + lp) * 8);
+            int4 g0, g1;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(g0), "=&v"(g1) : "v"(a_a) : "memory");
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const int wa[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            int arg = wa[0];
+            float bestv = wv[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+              if (wv[q] > bestv) { bestv = wv[q]; arg = wa[q]; }
+            if (lane < npt) amax[(size_t)b * cap + p0 + lane] = arg;
+          }
         }
         cacc.tile(t, npt, w, (unsigned)__builtin_amdgcn_readfirstlane((int)hb), s_tile);
       }
@@ -385,7 +424,7 @@ extern "C" int gridmm_debug_agg_prof(long long* out) {      // development aid (
 
 // Returns GRIDMM_EINVAL when the shape is outside this variant's range (the caller then uses the generic kernel).
 int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
-                               float* cells, uint8_t* occ, float* relevance, const int32_t* chunks, int B, int cap, int D,
+                               float* cells, uint8_t* occ, float* relevance, int32_t* amax, int B, int cap, int D,
                                int L, int n_chunks, hipStream_t st) {
   const int Lt = (L + 15) / 16;
   // D = 768 (KS = 24) does not fit: 192 VGPRs of resident text fragments + the MFMA working set spill (58 VGPRs at the
@@ -397,7 +436,7 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
   const size_t hb_words = (size_t)(cap + PT - 1) / PT;       // run-head bitmask of (at most) a whole episode
   const size_t lds = (size_t)R * PT * D * 2 + 2 * 8 * PT * sizeof(float) + 200 * sizeof(int) +
                      8 * TAB_BYTES + 8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + 8 * PT * sizeof(float) +
-                     hb_words * sizeof(unsigned);
+                     2 * 8 * PT * sizeof(int) + hb_words * sizeof(unsigned);
   if (lds > 160 * 1024) return GRIDMM_EINVAL;                // D = 512: up to ~185k points per episode
   dim3 grid(n_chunks, B), block(512);
 #define GRIDMM_AGGP(KS, RR, NBW)                                                                                     \
@@ -407,7 +446,7 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
                             (int)lds) != hipSuccess)                                                                 \
       return GRIDMM_EINVAL;                                                                                          \
     GRIDMM_LAUNCH(kern, grid, block, lds, st, (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag,   \
-                  cells, occ, relevance, chunks, cap, L, Lt, n_chunks);                                              \
+                  cells, occ, relevance, amax, cap, L, Lt, n_chunks);                                                \
   } while (0)
   if (D == 512) {
     if (nbw >= 4) GRIDMM_AGGP(16, 4, 8); else if (nbw == 3) GRIDMM_AGGP(16, 4, 11); else GRIDMM_AGGP(16, 4, 16);
@@ -428,14 +467,14 @@ int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int3
   const size_t hb_words = (size_t)(cap + PT - 1) / PT;
   const size_t lds = (size_t)R * PT * D * 2 + 2 * 8 * PT * sizeof(float) + 200 * sizeof(int) + 8 * TAB_BYTES +
                      8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + 8 * PT * sizeof(float) +
-                     hb_words * sizeof(unsigned);
+                     2 * 8 * PT * sizeof(int) + hb_words * sizeof(unsigned);
   if (lds > 160 * 1024) return GRIDMM_EINVAL;                // up to ~60k points per episode
   auto kern = grid_aggregate_pipe_kernel<24, R, 10, true>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return GRIDMM_EINVAL;
   GRIDMM_LAUNCH(kern, dim3(n_chunks, B), dim3(512), lds, st, (const _Float16*)slab, perm, cell_start,
-                (const _Float16*)nullptr, cells, occ, const_cast<float*>(w), (const int32_t*)nullptr, cap, 0, LOADERS,
+                (const _Float16*)nullptr, cells, occ, const_cast<float*>(w), (int32_t*)nullptr, cap, 0, LOADERS,
                 n_chunks);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;

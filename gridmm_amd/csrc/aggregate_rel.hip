@@ -48,6 +48,18 @@ __device__ __forceinline__ float max_over_rows(float x) {
   asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(z) : "v"((lane ^ 32u) << 2), "v"(x) : "memory");
   return fmaxf(x, z);
 }
+// (value, index) variant: the larger value wins, ties go to the smaller index (torch.max returns the first maximum)
+__device__ __forceinline__ void argmax_over_rows(float& x, int& idx) {
+  const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+  for (unsigned m = 16; m <= 32; m <<= 1) {
+    float y;
+    int j;
+    asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(y), "=&v"(j) : "v"((lane ^ m) << 2), "v"(x), "v"(idx) : "memory");
+    if (y > x || (y == x && j < idx)) { x = y; idx = j; }
+  }
+}
 __device__ __forceinline__ void lds_rmw_add4(const float* p, const f32x4_t& v) {   // exclusive owner of the 4 floats
   f32x4_t o;
   asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)(size_t)p) : "memory");
@@ -65,12 +77,14 @@ constexpr int RW = PT / NDMA;                 // rows fetched per DMA wave and t
 
 __global__ __launch_bounds__(512) void grid_relevance_wide_kernel(
     const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
-    const _Float16* __restrict__ text_frag, float* __restrict__ relevance, int cap, int L, int Lt, int n_chunks) {
+    const _Float16* __restrict__ text_frag, float* __restrict__ relevance, int32_t* __restrict__ amax, int cap, int L,
+    int Lt, int n_chunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   _Float16* s_tiles = reinterpret_cast<_Float16*>(smem);                        // [R][PT][D]
   float* s_part = reinterpret_cast<float*>(smem + (size_t)R * PT * D * 2);      // [PT][PP] relevance partial sums
   float* s_wmax = s_part + PT * PP;                                             // [PT][8] per-token-tile maxima of a point
-  int* s_ids = reinterpret_cast<int*>(s_wmax + PT * 8);                        // [NDMA waves][4 tiles][RW] slab rows
+  int* s_warg = reinterpret_cast<int*>(s_wmax + PT * 8);                        // [PT][8] arg-max token per token tile
+  int* s_ids = s_warg + PT * 8;                        // [NDMA waves][4 tiles][RW] slab rows
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,14 +256,31 @@ __global__ __launch_bounds__(512) void grid_relevance_wide_kernel(
           lds_store4(pa1, o1);
         } else {
           float x0 = NEG_BIG, x1 = NEG_BIG;
+          if (amax) {   // training: also the arg-max token, for the backward's routing
+            int i0 = 0x7fffffff, i1 = 0x7fffffff;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool colv = ct_a * 16 + 4 * g + r < L;
-            x0 = fmaxf(x0, colv ? o0[r] : NEG_BIG);
-            x1 = fmaxf(x1, colv ? o1[r] : NEG_BIG);
+            for (int r = 0; r < 4; ++r) {
+              const int tok = ct_a * 16 + 4 * g + r;
+              const float v0 = tok < L ? o0[r] : NEG_BIG, v1 = tok < L ? o1[r] : NEG_BIG;
+              if (v0 > x0) { x0 = v0; i0 = tok; }
+              if (v1 > x1) { x1 = v1; i1 = tok; }
+            }
+            argmax_over_rows(x0, i0);
+            argmax_over_rows(x1, i1);
+            if (g == 0) {
+              const unsigned aa = (unsigned)(size_t)(s_warg + pi * 8 + ct_a);
+              asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:512" :: "v"(aa), "v"(i0), "v"(i1) : "memory");
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool colv = ct_a * 16 + 4 * g + r < L;
+              x0 = fmaxf(x0, colv ? o0[r] : NEG_BIG);
+              x1 = fmaxf(x1, colv ? o1[r] : NEG_BIG);
+            }
+            x0 = max_over_rows(x0);
+            x1 = max_over_rows(x1);
           }
-          x0 = max_over_rows(x0);
-          x1 = max_over_rows(x1);
           if (g == 0) {
             const unsigned aw = (unsigned)(size_t)(s_wmax + pi * 8 + ct_a);
             asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:512" :: "v"(aw), "v"(x0), "v"(x1) : "memory");
@@ -277,6 +308,19 @@ __global__ __launch_bounds__(512) void grid_relevance_wide_kernel(
                    : "=&v"(w0), "=&v"(w1) : "v"(a_w) : "memory");
       const float w = fmaxf(fmaxf(fmaxf(w0.x, w0.y), fmaxf(w0.z, w0.w)), fmaxf(fmaxf(w1.x, w1.y), fmaxf(w1.z, w1.w)));
       if (lane < npt) relevance[(size_t)b * cap + p0 + lane] = w;   // by sorted position
+      if (amax) {                               // first token tile that attains w
+        int4 g0, g1;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(g0), "=&v"(g1) : "v"((unsigned)(size_t)(s_warg + lp * 8)) : "memory");
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const int wa[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        int arg = wa[0];
+        float bestv = wv[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+          if (wv[q] > bestv) { bestv = wv[q]; arg = wa[q]; }
+        if (lane < npt) amax[(size_t)b * cap + p0 + lane] = arg;
+      }
     }
     RP(4)
   }
@@ -298,17 +342,18 @@ extern "C" int gridmm_debug_rel_prof(long long* out) {      // development aid (
 
 // Returns GRIDMM_EINVAL when the shape is outside this variant's range.
 int gridmm_grid_relevance_wide(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
-                               float* relevance, int B, int cap, int Dd, int L, int n_chunks, hipStream_t st) {
+                               float* relevance, int32_t* amax, int B, int cap, int Dd, int L, int n_chunks,
+                               hipStream_t st) {
   const int Lt = (L + 15) / 16;
   if (Dd != D || Lt < 1 || Lt * KS > 8 * PPW || !relevance) return GRIDMM_EINVAL;   // L <= 80: 240 fragment units over 8 waves
-  const size_t lds = (size_t)R * PT * D * 2 + (size_t)PT * PP * sizeof(float) + PT * 8 * sizeof(float) +
+  const size_t lds = (size_t)R * PT * D * 2 + (size_t)PT * PP * sizeof(float) + 2 * PT * 8 * sizeof(float) +
                      NDMA * 4 * RW * sizeof(int);
   auto kern = grid_relevance_wide_kernel;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
       hipSuccess)
     return GRIDMM_EINVAL;
   GRIDMM_LAUNCH(kern, dim3(n_chunks, B), dim3(512), lds, st, (const _Float16*)slab, perm, cell_start,
-                (const _Float16*)text_frag, relevance, cap, L, Lt, n_chunks);
+                (const _Float16*)text_frag, relevance, amax, cap, L, Lt, n_chunks);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

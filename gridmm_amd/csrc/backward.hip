@@ -393,6 +393,124 @@ __global__ __launch_bounds__(256) void agg_bwd_cells_kernel(
   }
 }
 
+
+// ---- routed variant: the forward already found the arg-max token of every point (amax, by sorted position), so the
+// backward is three streaming passes with no search, no atomics and a deterministic result:
+//   agg_bwd_da_kernel      da_p = <dcells[cell(p)], x_p>                                  (4 sorted points per wave)
+//   agg_bwd_dw_kernel      per (cell, episode): softmax statistics -> dw_p = a_p (da_p - sum_cell a da)
+//   agg_bwd_gather_kernel  per (token, episode): dt[l] = sum over the points routed to l of dw_p x_p
+template <int NV>
+__global__ __launch_bounds__(256) void agg_bwd_da_kernel(
+    const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
+    const float* __restrict__ dcells, float* __restrict__ da, int cap, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  const int valid = cs[GRIDMM_CELLS];
+  const int p0 = (blockIdx.x * 4 + wave) * AGG_P;
+  if (p0 >= valid) return;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+#pragma unroll
+  for (int p = 0; p < AGG_P; ++p) {
+    const int pos = min(p0 + p, valid - 1);
+    int lo = 0, hi = GRIDMM_CELLS;              // cell of sorted position pos: largest c with cs[c] <= pos
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cs[mid] <= pos) lo = mid; else hi = mid;
+    }
+    const f16x2_t* xr = reinterpret_cast<const f16x2_t*>(slab + ((size_t)b * cap + perm_b[pos]) * D);
+    const float2* dc = reinterpret_cast<const float2*>(dcells + ((size_t)b * GRIDMM_CELLS + lo) * D);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (lane + 64 * i < D / 2) {
+        const f16x2_t h = xr[lane + 64 * i];
+        const float2 d = dc[lane + 64 * i];
+        s += (float)h[0] * d.x + (float)h[1] * d.y;
+      }
+    }
+    s = wave_sum(s);
+    if (lane == 0 && p0 + p < valid) da[(size_t)b * cap + pos] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void agg_bwd_dw_kernel(const int32_t* __restrict__ cell_start,
+                                                         const float* __restrict__ relevance,
+                                                         const float* __restrict__ da, float* __restrict__ dw, int cap) {
+  __shared__ float s_red[4];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  const int beg = cs[c], end = cs[c + 1];
+  if (end <= beg) return;
+  const float* w = relevance + (size_t)b * cap;      // everything here is indexed by sorted position
+  const float* dab = da + (size_t)b * cap;
+  float m = -3.0e38f;
+  for (int p = beg + tid; p < end; p += 256) m = fmaxf(m, w[p]);
+  m = block_reduce(m, s_red, true);
+  float z = 0.f, sa = 0.f;
+  for (int p = beg + tid; p < end; p += 256) {
+    const float e = expf(w[p] - m);
+    z += e;
+    sa += e * dab[p];
+  }
+  z = block_reduce(z, s_red, false);
+  sa = block_reduce(sa, s_red, false) / z;
+  for (int p = beg + tid; p < end; p += 256) dw[(size_t)b * cap + p] = expf(w[p] - m) / z * (dab[p] - sa);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void agg_bwd_gather_kernel(
+    const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
+    const int32_t* __restrict__ amax, const float* __restrict__ dw, float* __restrict__ dtext, int cap, int D, int L) {
+  __shared__ float s_acc[3][AGG_MAXV * 128];
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int valid = cell_start[(size_t)b * (GRIDMM_CELLS + 2) + GRIDMM_CELLS];
+  const int32_t* am = amax + (size_t)b * cap;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+  const float* dwb = dw + (size_t)b * cap;
+  float2 acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = make_float2(0.f, 0.f);
+  for (int p0 = wave * 64; p0 < valid; p0 += 256) {      // each wave scans its own 64-point groups, in point order
+    const int p = p0 + lane;
+    unsigned long long hit = __ballot(p < valid && am[p] == l);
+    while (hit) {
+      const int q = p0 + __builtin_ctzll(hit);
+      hit &= hit - 1;
+      const float g = dwb[q];
+      const f16x2_t* xr = reinterpret_cast<const f16x2_t*>(slab + ((size_t)b * cap + perm_b[q]) * D);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < D / 2) {
+          const f16x2_t h = xr[lane + 64 * i];
+          acc[i].x += g * (float)h[0];
+          acc[i].y += g * (float)h[1];
+        }
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < D / 2) reinterpret_cast<float2*>(s_acc[wave - 1])[lane + 64 * i] = acc[i];
+  }
+  __syncthreads();
+  if (wave == 0) {                                         // fixed summation order: deterministic
+    float2* out = reinterpret_cast<float2*>(dtext + ((size_t)b * L + l) * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (lane + 64 * i < D / 2) {
+        float2 r = acc[i];
+        for (int w = 0; w < 3; ++w) {
+          const float2 o = reinterpret_cast<const float2*>(s_acc[w])[lane + 64 * i];
+          r.x += o.x; r.y += o.y;
+        }
+        out[lane + 64 * i] = r;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32_t* cell_start,
@@ -422,5 +540,36 @@ extern "C" int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, 
     default: GRIDMM_AGGB(6); break;
   }
 #undef GRIDMM_AGGB
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                                const float* relevance, const int32_t* amax, const float* dcells,
+                                                float* dtext, float* da_ws, float* dw_ws, int B, int cap, int D, int L,
+                                                gridmm_stream_t stream) {
+  if (B <= 0 || cap <= 0 || L <= 0 || D <= 0 || D % 2 || D > 128 * AGG_MAXV) return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nv = (D + 127) / 128;
+  dim3 gp((cap + 4 * AGG_P - 1) / (4 * AGG_P), B), gc(GRIDMM_CELLS, B), gl(L, B), block(256);
+#define GRIDMM_AGGR(NV)                                                                                          \
+  do {                                                                                                           \
+    GRIDMM_LAUNCH((agg_bwd_da_kernel<NV>), gp, block, 0, st, (const _Float16*)slab, perm, cell_start, dcells,    \
+                  da_ws, cap, D);                                                                                \
+    GRIDMM_CHECK_LAUNCH();                                                                                       \
+    GRIDMM_LAUNCH(agg_bwd_dw_kernel, gc, block, 0, st, cell_start, relevance, da_ws, dw_ws, cap);                \
+    GRIDMM_CHECK_LAUNCH();                                                                                       \
+    GRIDMM_LAUNCH((agg_bwd_gather_kernel<NV>), gl, block, 0, st, (const _Float16*)slab, perm, cell_start, amax,  \
+                  dw_ws, dtext, cap, D, L);                                                                      \
+    GRIDMM_CHECK_LAUNCH();                                                                                       \
+  } while (0)
+  switch (nv) {
+    case 1: GRIDMM_AGGR(1); break;
+    case 2: GRIDMM_AGGR(2); break;
+    case 3: GRIDMM_AGGR(3); break;
+    case 4: GRIDMM_AGGR(4); break;
+    case 5: GRIDMM_AGGR(5); break;
+    default: GRIDMM_AGGR(6); break;
+  }
+#undef GRIDMM_AGGR
   return GRIDMM_OK;
 }

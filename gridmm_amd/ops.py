@@ -424,10 +424,12 @@ def text_fragments(text_fts):
     return frag
 
 
-def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_relevance=False, n_points=None):
+def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_relevance=False, n_points=None,
+                   want_amax=False):
     """slab (B,cap,D) fp16 -> cells (B,196,D) fp32, occ (B,196) uint8 [, relevance (B,cap) fp32: w of the point at
     SORTED position p, i.e. of slot perm[b, p]].  n_points: host-known upper bound of the points per episode (defaults to
-    the slab capacity); only steers the chunking."""
+    the slab capacity); only steers the chunking.  want_amax (training): also returns the arg-max token of every point by
+    sorted position, (B,cap) int32 -- or None when the shape ran on the generic kernel, which does not produce it."""
     lib = _lib.load()
     B, cap, D = slab.shape
     assert slab.dtype == torch.float16 and slab.is_contiguous()
@@ -442,10 +444,17 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
     cells = torch.empty(B, N_CELLS, D, dtype=torch.float32, device=dev)
     occ = torch.empty(B, N_CELLS, dtype=torch.uint8, device=dev)
     # D = 768: the two-pass path needs the relevance buffer as its intermediate (allocated even when not asked for)
-    rel = torch.zeros(B, cap, dtype=torch.float32, device=dev) if (want_relevance or D == 768) else None
+    rel = torch.zeros(B, cap, dtype=torch.float32, device=dev) if (want_relevance or want_amax or D == 768) else None
     chunks = torch.empty(B, n_chunks + 1, dtype=torch.int32, device=dev)
-    _timed("grid_aggregate", 0.0, lambda: _lib.check(
-        lib.gridmm_grid_aggregate(_p(slab), _p(perm), _p(cell_start), _p(text_frag), _p(cells), _p(occ),
-                                  _p(rel), _p(chunks), B, cap, D, L, n_chunks, _stream()),
-        "gridmm_grid_aggregate"))
+    amax = torch.empty(B, cap, dtype=torch.int32, device=dev) if want_amax else None
+    status = []
+
+    def launch():
+        rc = lib.gridmm_grid_aggregate_train(_p(slab), _p(perm), _p(cell_start), _p(text_frag), _p(cells), _p(occ),
+                                             _p(rel), _p(amax), _p(chunks), B, cap, D, L, n_chunks, _stream())
+        status.append(rc)
+        _lib.check(min(rc, 0), "gridmm_grid_aggregate_train")
+    _timed("grid_aggregate", 0.0, launch)
+    if want_amax:
+        return cells, occ, rel, (amax if status[-1] == 0 else None)
     return (cells, occ, rel) if want_relevance else (cells, occ)

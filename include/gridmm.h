@@ -122,6 +122,14 @@ int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* 
                           int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
                           gridmm_stream_t stream);
 
+/* The same with the routing of the backward as a second by-product (fine-tune / pre-training forward):
+ *   amax [B][cap] int32 out: arg-max instruction token of the point at sorted position p (first maximum, as torch.max).
+ * Returns GRIDMM_OK with amax written, 1 when the shape ran on the generic kernel (amax untouched: use
+ * gridmm_grid_aggregate_bwd, which recomputes it), < 0 on error.  Replaces: vilmodel.py:797-807. */
+int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                const void* text_frag, float* cells, uint8_t* occ, float* relevance, int32_t* amax,
+                                int32_t* chunks, int B, int cap, int D, int L, int n_chunks, gridmm_stream_t stream);
+
 /* Compact non-empty cells to the front (cell order), add the position embedding, build the
  * key mask exactly as vilmodel.py:813-823 does (including its in-place view quirk).
  *   proj [B][196][H] f32 = grid_proj(cells)+bias; pos_emb [B][196][H] f32
@@ -281,6 +289,12 @@ int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, const float* K,
 int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32_t* cell_start,
                               const float* relevance, const float* text, const float* dcells, float* dtext,
                               float* da_ws, int32_t* amax_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
+
+/* The same gradient from the forward's routing (gridmm_grid_aggregate_train): three streaming passes, no search, no
+ * atomics, deterministic.  relevance / amax [B][cap] by sorted position; da_ws, dw_ws [B][cap] f32 workspaces. */
+int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                     const float* relevance, const int32_t* amax, const float* dcells, float* dtext,
+                                     float* da_ws, float* dw_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
 
 /* Optimizer step: gradient-norm clipping + AdamW without a host round trip.
  * gridmm_grad_sumsq adds sum(g^2) of one gradient tensor into *acc (zero it first; call once per tensor).
