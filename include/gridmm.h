@@ -115,6 +115,8 @@ int gridmm_text_fragments(const float* text, void* frag, int B, int L, int D,
  *   slab       [B][cap][D] fp16      perm/cell_start as produced by gridmm_grid_bin
  *   cells      [B][196][D] f32 out (zeros for empty cells); occ [B][196] uint8 out
  *   relevance  [B][cap] f32 out or NULL: w of the point at SORTED position p (slot perm[b][p]); saved for the backward
+ *              (D = 768: also the intermediate of the two-pass path -- relevance pass, then accumulation pass; with NULL
+ *              that shape runs on the slower single-kernel fallback)
  *   chunks     [B][n_chunks+1] int32 workspace (cell-aligned work partition, device-built)
  */
 int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
