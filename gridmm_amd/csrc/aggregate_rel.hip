@@ -9,9 +9,8 @@
 // waves, which store / add in turn (two barriers; ds_add_f32 atomics measured ~1000 cycles per instruction).  (Doing
 // the accumulation in the same kernel needs another ~100 VGPRs per wave: measured 91 spills -- hence two passes; the
 // slab of a typical episode is still in the Infinity Cache for the second one.)
-//   barrier A  tile i landed, s_part of tile i - 1 consumed
 //   phase R    every wave: its K-slice of S = T . X^T on the matrix pipe (text fragment = A operand) -> s_part
-//   barrier B  partial sums complete;  wave 7: max over tokens (lane = point, the lane halves split the tokens) -> w;
+//   barrier B  partial sums complete, tile i + 1 landed;  wave 7: max over tokens (lane = point, the lane halves split the tokens) -> w;
 //              waves 0..3: feed the ring (tile i + 2 by LDS-DMA, 8 rows each; no global stores in these waves, so
 //              their counted vmcnt waits are exact)
 // Ring: 3 x 48 KB.  Row ids travel by LDS-DMA two iterations ahead (see aggregate_pipe.hip).
@@ -168,24 +167,17 @@ __global__ __launch_bounds__(512) void grid_relevance_wide_kernel(
     wait_vm<0>();
   }
   __syncthreads();                              // s_part cleared
-  if (is_dma)
+  if (is_dma) {
     for (int t = 0; t < R - 1 && t < ntiles; ++t) { dma_prepare(t); dma_rows(t, 0, RW); }
+    if (ntiles > 1) wait_vm<RW * IPR>(); else wait_vm<0>();     // tile 0 landed (tile 1 may fly)
+  }
+  __syncthreads();
 
   const int pi = lane & 15, g = lane >> 4;
 #ifdef GRIDMM_AGG_PROF
   long long rp[6] = {0, 0, 0, 0, 0, 0}, rpt = RP_T();
 #endif
   for (int i = 0; i < ntiles; ++i) {
-    // ---- barrier A: tile i landed.  Queue of a DMA wave (in order): iteration i issues DMA(i + 2) then IDS(i + 4);
-    // here it needs DMA(i) and IDS(i + 2) (issued at i - 2) and leaves DMA(i + 1), IDS(i + 3) in flight.
-    if (is_dma) {
-      if (i >= 1 && i + 3 < ntiles) wait_vm<RW * IPR + 1>();
-      else if (i + 1 < ntiles) wait_vm<RW * IPR>();
-      else wait_vm<0>();
-    }
-    RP(0)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     RP(1)
     const _Float16* s_tile = s_tiles + (size_t)(i % R) * PT * D;
 
@@ -198,7 +190,8 @@ __global__ __launch_bounds__(512) void grid_relevance_wide_kernel(
       const f16x8_t* row0 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)pi * D);
       const f16x8_t* row1 = reinterpret_cast<const f16x8_t*>(s_tile + (size_t)(16 + pi) * D);
       constexpr int GP = 3;                     // pairs per fragment group, two groups of registers in flight
-      // the ring feed (tile i + 2 into the slot of tile i - 1, free since barrier A) goes out in slices between the
+      // the ring feed (tile i + 2 into the slot of tile i - 1, read for the last time before the
+      // barriers of iteration i - 1) goes out in slices between the
       // MFMA groups
       const bool fetch = is_dma && i + 2 < ntiles;
       if (fetch) dma_prepare(i + 2);
@@ -293,8 +286,17 @@ __global__ __launch_bounds__(512) void grid_relevance_wide_kernel(
       if (seg_a && rank_a == 2) add_turn();
     }
     RP(2)
+    // ---- barrier B: the partial sums of tile i are complete AND tile i + 1 has landed.  Queue of a DMA wave (in order):
+    // iteration i issued DMA(i + 2) then IDS(i + 4) above; it needs DMA(i + 1) and IDS(i + 3) (issued at i - 1) and
+    // leaves this iteration's two in flight.
+    if (is_dma) {
+      if (i + 4 < ntiles) wait_vm<RW * IPR + 1>();
+      else if (i + 2 < ntiles) wait_vm<RW * IPR>();
+      else wait_vm<0>();
+    }
+    RP(0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();               // ---- barrier B: the partial sums of tile i are complete
+    __builtin_amdgcn_s_barrier();
 
     RP(3)
     if (wave == 7) {
