@@ -104,7 +104,8 @@ class GraphMap:
             self.node_embeds[vp][1] += 1
 
     def get_node_embed(self, vp):
-        return self.node_embeds[vp][0] / self.node_embeds[vp][1]
+        e, n = self.node_embeds[vp]
+        return e if n == 1 else e / n          # x / 1 == x exactly: skip the kernel + autograd node (most nodes: one visit)
 
     def get_pos_fts(self, cur_vp, gmap_vpids, cur_heading, cur_elevation, angle_feat_size=4):
         """(len, 7): sin/cos heading, sin/cos elevation, line dist/30, graph dist/30, hops/10 (graph_utils.py:127-151)."""
