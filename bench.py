@@ -259,12 +259,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    share = bool(os.environ.get("GRIDMM_BENCH_SHARE_GPU"))   # test hook: N ranks on one GPU (gloo for the timing collectives)
+    if share:
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist  # RCCL ("nccl" backend on ROCm)
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev)
