@@ -1,22 +1,22 @@
 // Instruction-relevance grid aggregation, wave-specialised two-stage pipeline (the hot variant of aggregate.hip for
-// L <= 80..96 instruction tokens; same math, same outputs, same entry point).
+// D = 256 / 512 and 33 <= L <= 96 instruction tokens; same math, same outputs, same entry point).
 //
 // aggregate.hip runs the three phases of a tile one after the other on all waves (relevance MFMAs | per-point softmax
 // numerators | accumulation), each a latency-bound chain on a few waves: ~10 us per 64 points and CU, 1.7-1.9 TB/s.
 // Here the 8 waves of a workgroup split into
-//   R-waves (one per 16-column text tile, fragments register-resident): relevance of tile i          -> s_wmax[i & 1]
-//   B-waves (the rest):  cell lookup of tile i, then softmax numerators + accumulation of tile i - 1  (s_wmax[(i-1) & 1])
-// The accumulation is a matrix product as well: out^T[dim][slot] = X^T[dim][point] . E[point][slot], where E holds the
-// softmax numerator of a point in the column of its cell's slot (f16 hi + lo, exact to ~2^-22) and X^T comes straight
-// out of the row-major LDS tile through ds_read_b64_tr_b16.  A cell keeps its slot (= MFMA output column, one per
-// lane & 15) from tile to tile, so the open cell's partial sum never moves between lanes; a ones block yields the
-// softmax denominators in the same layout.  16 dims x 32 points x 16 cells per MFMA pair instead of ~6 VALU
-// instructions per point and thread.
+//   R-waves (one per 16-column text tile, fragments register-resident): relevance of tile i -> s_wmax[i & 1]; they also
+//            feed the ring: rows of tile i + 2 by LDS-DMA, issued in slices between the MFMA groups
+//   B-waves (the rest):  softmax numerators + accumulation of tile i - 1 (s_wmax[(i-1) & 1]; agg_accum.h)
 // with ONE barrier per 32-point tile, so a tile costs max(relevance, softmax + accumulation) instead of their sum, and
 // the LDS-DMA of tiles i+1 .. i+R-2 flies over both.  Ring: R slots of 32 points (4 x 32 KB at D <= 512: slot of tile
-// i-1 being accumulated, slot of tile i in the matrix pipe, two tiles in flight; 3 x 48 KB at D = 768).
-// Row ids come from scalar loads issued a whole iteration ahead (nothing but DMA in the vector-memory queue, so the
-// counted s_waitcnt vmcnt is exact and no compiler-inserted vmcnt(0) drains the stream).
+// i-1 being accumulated, slot of tile i in the matrix pipe, two tiles in flight).
+// The accumulation is a matrix product as well (X^T . E through ds_read_b64_tr_b16; agg_accum.h).  The run heads of a
+// tile are one word of a per-chunk bitmask built from cell_start in the prologue, so there is no per-point cell lookup.
+// Row ids travel by LDS-DMA two iterations ahead of their use (a scalar load would put its memory latency into every
+// lgkmcnt wait, a vector load's result register makes the compiler drain the queue): nothing but DMA in the R-waves'
+// vector-memory queue, so the counted s_waitcnt vmcnt is exact; the B-waves' LDS loads are asm (agg_accum.h) because a
+// visible LDS load into a register that a pending global store still names gets an s_waitcnt vmcnt(0) in front.
+// PREW instantiation: second pass of the D = 768 path (see the template comment below).
 #include "agg_accum.h"
 
 namespace {
