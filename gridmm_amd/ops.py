@@ -444,7 +444,10 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
     cells = torch.empty(B, N_CELLS, D, dtype=torch.float32, device=dev)
     occ = torch.empty(B, N_CELLS, dtype=torch.uint8, device=dev)
     # D = 768: the two-pass path needs the relevance buffer as its intermediate (allocated even when not asked for)
-    rel = torch.zeros(B, cap, dtype=torch.float32, device=dev) if (want_relevance or want_amax or D == 768) else None
+    if want_relevance or want_amax:
+        rel = torch.zeros(B, cap, dtype=torch.float32, device=dev)
+    else:                                   # D = 768: scratch of the two-pass path (only valid positions are written / read)
+        rel = torch.empty(B, cap, dtype=torch.float32, device=dev) if D == 768 else None
     chunks = torch.empty(B, n_chunks + 1, dtype=torch.int32, device=dev)
     amax = torch.empty(B, cap, dtype=torch.int32, device=dev) if want_amax else None
     status = []
