@@ -32,21 +32,8 @@ using namespace gridmm_agg;
 __device__ __forceinline__ void lds_store4(const float* p, const f32x4_t& v) {
   asm volatile("ds_write_b128 %0, %1" :: "v"((unsigned)(size_t)p), "v"(v) : "memory");
 }
-__device__ __forceinline__ f32x4_t lds_load4(const float* p) {
-  f32x4_t o;
-  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)(size_t)p) : "memory");
-  return o;
-}
-// max over the four 16-lane rows of a wave (lane & 15 stays).  ds_bpermute through asm: a compiler-visible one is an
-// "LDS load" for the waitcnt pass (see above).
-__device__ __forceinline__ float max_over_rows(float x) {
-  const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-  float y, z;
-  asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(y) : "v"((lane ^ 16u) << 2), "v"(x) : "memory");
-  x = fmaxf(x, y);
-  asm volatile("ds_bpermute_b32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(z) : "v"((lane ^ 32u) << 2), "v"(x) : "memory");
-  return fmaxf(x, z);
-}
+// Cross-row reductions (max over the four 16-lane rows of a wave, lane & 15 stays) use ds_bpermute through asm: a
+// compiler-visible one is an "LDS load" for the waitcnt pass (see above).
 // (value, index) variant: the larger value wins, ties go to the smaller index (torch.max returns the first maximum)
 __device__ __forceinline__ void argmax_over_rows(float& x, int& idx) {
   const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -57,6 +44,22 @@ __device__ __forceinline__ void argmax_over_rows(float& x, int& idx) {
     asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(y), "=&v"(j) : "v"((lane ^ m) << 2), "v"(x), "v"(idx) : "memory");
     if (y > x || (y == x && j < idx)) { x = y; idx = j; }
+  }
+}
+__device__ __forceinline__ void lds_load4x2(const float* p0, const float* p1, f32x4_t& o0, f32x4_t& o1) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(o0), "=&v"(o1) : "v"((unsigned)(size_t)p0), "v"((unsigned)(size_t)p1) : "memory");
+}
+// two values at once: both permutes of a step are in flight together
+__device__ __forceinline__ void max_over_rows2(float& x0, float& x1) {
+  const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+  for (unsigned m = 16; m <= 32; m <<= 1) {
+    float y0, y1;
+    asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(y0), "=&v"(y1) : "v"((lane ^ m) << 2), "v"(x0), "v"(x1) : "memory");
+    x0 = fmaxf(x0, y0);
+    x1 = fmaxf(x1, y1);
   }
 }
 __device__ __forceinline__ void lds_rmw_add4(const float* p, const f32x4_t& v) {   // exclusive owner of the 4 floats
@@ -243,7 +246,10 @@ __global__ __launch_bounds__(512) void grid_relevance_wide_kernel(
       // maximum per point (over the valid tokens) instead of writing them back
       const bool last_a = (KS * ct_a + KS - 1) / PPW == wave;
       auto add_turn = [&]() {
-        const f32x4_t o0 = lds_load4(pa0) + a0, o1 = lds_load4(pa1) + a1;
+        f32x4_t o0, o1;
+        lds_load4x2(pa0, pa1, o0, o1);
+        o0 += a0;
+        o1 += a1;
         if (!last_a) {
           lds_store4(pa0, o0);
           lds_store4(pa1, o1);
@@ -271,8 +277,7 @@ __global__ __launch_bounds__(512) void grid_relevance_wide_kernel(
               x0 = fmaxf(x0, colv ? o0[r] : NEG_BIG);
               x1 = fmaxf(x1, colv ? o1[r] : NEG_BIG);
             }
-            x0 = max_over_rows(x0);
-            x1 = max_over_rows(x1);
+            max_over_rows2(x0, x1);
           }
           if (g == 0) {
             const unsigned aw = (unsigned)(size_t)(s_wmax + pi * 8 + ct_a);
