@@ -62,12 +62,6 @@ __device__ __forceinline__ void max_over_rows2(float& x0, float& x1) {
     x1 = fmaxf(x1, y1);
   }
 }
-__device__ __forceinline__ void lds_rmw_add4(const float* p, const f32x4_t& v) {   // exclusive owner of the 4 floats
-  f32x4_t o;
-  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"((unsigned)(size_t)p) : "memory");
-  o += v;
-  asm volatile("ds_write_b128 %0, %1" :: "v"((unsigned)(size_t)p), "v"(o) : "memory");
-}
 
 constexpr int KS = 24, D = 32 * KS;           // 768
 constexpr int NCH = D / 8, IPR = 2;           // 16-B chunks per row; DMA instructions per row
