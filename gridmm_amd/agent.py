@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .graph_utils import GraphMap
+from .graph_utils import TopoMap
 
 
 def default_args(**over):
@@ -104,11 +104,11 @@ class GMapNavAgent:
         b_vpids, b_lens, b_embeds, b_steps, b_pos, b_visited, b_pair, no_vp_left = [], [], [], [], [], [], [], []
         for i, gmap in enumerate(gmaps):
             visited, unvisited = [], []
-            for k in gmap.node_positions.keys():
+            for k in gmap.nodes():
                 if self.args.act_visited_nodes:
                     (visited if k == obs[i]["viewpoint"] else unvisited).append(k)
                 else:
-                    (visited if gmap.graph.visited(k) else unvisited).append(k)
+                    (visited if gmap.visited(k) else unvisited).append(k)
             no_vp_left.append(len(unvisited) == 0)
             if self.args.enc_full_graph:
                 vpids = [None] + visited + unvisited
@@ -116,14 +116,11 @@ class GMapNavAgent:
             else:
                 vpids = [None] + unvisited
                 vmask = [0] * len(vpids)
-            steps = [gmap.node_step_ids.get(vp, 0) for vp in vpids]
-            emb = [gmap.get_node_embed(vp) for vp in vpids[1:]]
+            steps = [gmap.step_id.get(vp, 0) for vp in vpids]
+            emb = [gmap.embedding(vp) for vp in vpids[1:]]
             emb = torch.stack([torch.zeros_like(emb[0])] + emb, 0)
-            pos = gmap.get_pos_fts(obs[i]["viewpoint"], vpids, obs[i]["heading"], obs[i]["elevation"])
-            pair = np.zeros((len(vpids), len(vpids)), dtype=np.float32)
-            for a in range(1, len(vpids)):
-                for c in range(a + 1, len(vpids)):
-                    pair[a, c] = pair[c, a] = gmap.graph.distance(vpids[a], vpids[c])
+            pos = gmap.pos_features(obs[i]["viewpoint"], vpids, obs[i]["heading"], obs[i]["elevation"])
+            pair = gmap.pair_distances(vpids)
             b_embeds.append(emb)
             b_steps.append(torch.LongTensor(steps))
             b_pos.append(torch.from_numpy(pos))
@@ -157,8 +154,8 @@ class GMapNavAgent:
         vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
         b_pos = []
         for i, gmap in enumerate(gmaps):
-            cand = gmap.get_pos_fts(obs[i]["viewpoint"], cand_vpids[i], obs[i]["heading"], obs[i]["elevation"])
-            start = gmap.get_pos_fts(obs[i]["viewpoint"], [gmap.start_vp], obs[i]["heading"], obs[i]["elevation"])
+            cand = gmap.pos_features(obs[i]["viewpoint"], cand_vpids[i], obs[i]["heading"], obs[i]["elevation"])
+            start = gmap.pos_features(obs[i]["viewpoint"], [gmap.start_vp], obs[i]["heading"], obs[i]["elevation"])
             pos = np.zeros((vp_img.size(1), 14), dtype=np.float32)
             pos[:, :7] = start
             pos[1:len(cand) + 1, 7:] = cand
@@ -193,7 +190,7 @@ class GMapNavAgent:
         for i, ob in enumerate(obs):
             action = a_t[i]
             if action is not None:
-                traj[i]["path"].append(gmaps[i].graph.path(ob["viewpoint"], action))
+                traj[i]["path"].append(gmaps[i].route(ob["viewpoint"], action))
                 prev = traj[i]["path"][-2][-1] if len(traj[i]["path"][-1]) == 1 else traj[i]["path"][-1][-2]
                 viewidx = self.scanvp_cands["%s_%s" % (ob["scan"], prev)][action]
                 self.env.teleport(i, ob["scan"], action, (viewidx % 12) * math.radians(30),
@@ -210,9 +207,9 @@ class GMapNavAgent:
         obs = self.env.reset() if reset else self.env._get_obs()
         self._update_scanvp_cands(obs)
         B = len(obs)
-        gmaps = [GraphMap(ob["viewpoint"]) for ob in obs]
+        gmaps = [TopoMap(ob["viewpoint"]) for ob in obs]
         for i, ob in enumerate(obs):
-            gmaps[i].update_graph(ob)
+            gmaps[i].observe(ob)
         traj = [{"instr_id": ob["instr_id"], "path": [[ob["viewpoint"]]], "details": {}} for ob in obs]
 
         language_inputs = self._language_variable(obs)
@@ -225,17 +222,17 @@ class GMapNavAgent:
         for t in range(self.args.max_action_len):
             for i, gmap in enumerate(gmaps):
                 if not ended[i]:
-                    gmap.node_step_ids[obs[i]["viewpoint"]] = t + 1
+                    gmap.step_id[obs[i]["viewpoint"]] = t + 1
 
             pano_inputs = self._panorama_feature_variable(obs)
             pano_embeds, pano_masks = self.vln_bert("panorama", pano_inputs)
             avg_pano = torch.sum(pano_embeds * pano_masks.unsqueeze(2), 1) / torch.sum(pano_masks, 1, keepdim=True)
             for i, gmap in enumerate(gmaps):
                 if not ended[i]:
-                    gmap.update_node_embed(obs[i]["viewpoint"], avg_pano[i], rewrite=True)
+                    gmap.add_embedding(obs[i]["viewpoint"], avg_pano[i], overwrite=True)
                     for j, cvp in enumerate(pano_inputs["cand_vpids"][i]):
-                        if not gmap.graph.visited(cvp):
-                            gmap.update_node_embed(cvp, pano_embeds[i, j])
+                        if not gmap.visited(cvp):
+                            gmap.add_embedding(cvp, pano_embeds[i, j])
 
             nav_inputs = self._nav_gmap_variable(obs, gmaps)
             nav_inputs.update(self._nav_vp_variable(obs, gmaps, pano_embeds, pano_inputs["cand_vpids"],
@@ -253,7 +250,7 @@ class GMapNavAgent:
             stop_probs = nav_probs[:, 0].detach().cpu().numpy()       # one D2H per step (reference: B .item() calls)
             for i, gmap in enumerate(gmaps):
                 if not ended[i]:
-                    gmap.node_stop_scores[obs[i]["viewpoint"]] = {"stop": float(stop_probs[i])}
+                    gmap.stop_score[obs[i]["viewpoint"]] = {"stop": float(stop_probs[i])}
 
             nav_targets = None
             if train_ml is not None or self.feedback == "teacher":
@@ -307,17 +304,17 @@ class GMapNavAgent:
             for i in range(B):
                 if (not ended[i]) and just_ended[i]:
                     stop_node, stop_score = None, {"stop": -float("inf")}
-                    for k, v in gmaps[i].node_stop_scores.items():
+                    for k, v in gmaps[i].stop_score.items():
                         if v["stop"] > stop_score["stop"]:
                             stop_score, stop_node = v, k
                     if stop_node is not None and obs[i]["viewpoint"] != stop_node:
-                        traj[i]["path"].append(gmaps[i].graph.path(obs[i]["viewpoint"], stop_node))
+                        traj[i]["path"].append(gmaps[i].route(obs[i]["viewpoint"], stop_node))
 
             obs = self.env._get_obs()
             self._update_scanvp_cands(obs)
             for i, ob in enumerate(obs):
                 if not ended[i]:
-                    gmaps[i].update_graph(ob)
+                    gmaps[i].observe(ob)
             ended[:] = np.logical_or(ended, np.array([x is None for x in cpu_a_t]))
             if ended.all():
                 break

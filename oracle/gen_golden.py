@@ -396,11 +396,83 @@ def gen_pretrain(with_obj=False):
     np.savez_compressed(os.path.join(OUT, "pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz"), **out)
 
 
+TOPO = dict(n_nodes=24, n_steps=20, seed=5, max_nodes=24)
+
+
+def topo_walk_inputs():
+    """Scripted walk over a random geometric graph (shared by the generator and tests/test_topo_map.py)."""
+    rs = np.random.RandomState(TOPO["seed"])
+    n = TOPO["n_nodes"]
+    pos = np.concatenate([rs.uniform(-10, 10, (n, 2)), rs.uniform(-1, 1, (n, 1))], 1)
+    d = np.sqrt(((pos[:, None] - pos[None]) ** 2).sum(-1))
+    adj = np.zeros((n, n), dtype=bool)
+    for i in range(n):
+        for j in np.argsort(d[i])[1:4]:
+            adj[i, j] = adj[j, i] = True
+    walk, cur, seen = [], 0, set()
+    for _ in range(TOPO["n_steps"]):
+        walk.append(cur)
+        seen.add(cur)
+        nb = np.nonzero(adj[cur])[0]
+        fresh = [j for j in nb if j not in seen]
+        cur = int((fresh or list(nb))[rs.randint(len(fresh or nb))])
+    return dict(pos=pos, adj=adj, walk=np.array(walk), heading=rs.uniform(0, 2 * np.pi, len(walk)),
+                elevation=rs.uniform(-0.5, 0.5, len(walk)), embeds=rs.randn(len(walk), 5, 8).astype(np.float32))
+
+
+def topo_observation(inp, t):
+    i = int(inp["walk"][t])
+    return {"viewpoint": "vp%02d" % i, "position": tuple(inp["pos"][i]),
+            "candidate": [{"viewpointId": "vp%02d" % j, "position": tuple(inp["pos"][j])}
+                          for j in np.nonzero(inp["adj"][i])[0]]}
+
+
+def gen_topo_map():
+    """map_nav_src/models/graph_utils.py:43-151 (FloydGraph + GraphMap) driven over the scripted walk: after every
+    step the pair distances, hop counts, routes from the current node, visited flags, position features and node
+    embedding means -> tests/golden/topo_map.npz (pins gridmm_amd/graph_utils.TopoMap)."""
+    R.install_shims()
+    if R.REF_NAV not in sys.path:
+        sys.path.insert(0, R.REF_NAV)
+    from models import graph_utils as G       # the reference's module
+    inp = topo_walk_inputs()
+    N, T = TOPO["max_nodes"], len(inp["walk"])
+    gm = G.GraphMap("vp%02d" % inp["walk"][0])
+    out = {"versions": _versions()}
+    out.update({"in_" + k: v for k, v in inp.items()})
+    dist = np.zeros((T, N, N)); hops = np.full((T, N, N), -1, dtype=np.int64); route = np.full((T, N, N), -1, dtype=np.int64)
+    order = np.full((T, N), -1, dtype=np.int64); visited = np.zeros((T, N), dtype=bool)
+    pos_fts = np.zeros((T, N + 1, 7), dtype=np.float32); emb = np.zeros((T, N, 8), dtype=np.float32)
+    for t in range(T):
+        ob = topo_observation(inp, t)
+        gm.update_graph(ob)
+        cur = ob["viewpoint"]
+        gm.update_node_embed(cur, torch.from_numpy(inp["embeds"][t, 0]), rewrite=True)
+        for c, cc in enumerate(ob["candidate"]):
+            if not gm.graph.visited(cc["viewpointId"]):
+                gm.update_node_embed(cc["viewpointId"], torch.from_numpy(inp["embeds"][t, 1 + c]))
+        names = list(gm.node_positions.keys())
+        order[t, :len(names)] = [int(v[2:]) for v in names]
+        for a, va in enumerate(names):
+            visited[t, a] = gm.graph.visited(va)
+            emb[t, a] = gm.get_node_embed(va).numpy()
+            for b, vb in enumerate(names):
+                dist[t, a, b] = gm.graph.distance(va, vb)
+                hops[t, a, b] = len(gm.graph.path(va, vb))
+            r = gm.graph.path(cur, va)
+            route[t, a, :len(r)] = [int(v[2:]) for v in r]
+        pos_fts[t, :len(names) + 1] = gm.get_pos_fts(cur, [None] + names, inp["heading"][t], inp["elevation"][t])
+    out.update(dist=dist, hops=hops, route=route, order=order, visited=visited, pos_fts=pos_fts, emb=emb)
+    np.savez_compressed(os.path.join(OUT, "topo_map.npz"), **out)
+    print("topo_map: ok,", int((order[-1] >= 0).sum()), "nodes after", T, "steps")
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo"]
     if "rollout" in which: gen_rollout()
+    if "topo" in which: gen_topo_map()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
     if "nav" in which: gen_nav_reduced(False)
