@@ -8,7 +8,7 @@ from gridmm_amd import _lib, ops
 SHAPES = [(6912, 2304, 768), (6912, 768, 768), (6912, 3072, 768), (6912, 768, 3072), (9472, 6144, 768),
           (2560, 1536, 768), (1824, 768, 768), (1824, 2304, 768), (1824, 3072, 768), (1824, 768, 3072),
           (2560, 512, 768), (6272, 768, 512)]
-CFGS = {8: "64x64 BK64", 108: "  noMFMA", 208: "  noDMA", 15: "128x128 16w", 115: "  noMFMA", 215: "  noDMA", 7: "256x256", 107: "  noMFMA", 207: "  noDMA", 1001: "128x128", 14: "128x128 8w", 15: "128x128 16w", 16: "256x128 16w", 12: "128x128 8w NS3", 2: "128x128 8w BK64", 3: "256x128", 7: "256x256", 8: "64x64 BK64", 11: "64x64 BK64 NS3", 10: "64x64 BK64 NS4", 13: "128x64 8w BK64 NS3", 17: "64x64 BK32 NS4", 18: "64x64 BK32 NS3", 19: "64x32 NS4", 20: "64x64 8w NS4", 21: "128x64 8w BK32 NS4", 22: "256x128 8w NS3", 23: "256x128 16w NS3", 24: "128x256 8w NS3", 30: "PP 256x256", 31: "PP 256x128", 32: "PP 128x256", 33: "PP 128x128", 34: "PP 256x256 16w", 35: "PP 256x128 16w", 36: "256x256 16w", 40: "TR 256x256 16w", 41: "TR 256x256 8w", 42: "TR 128x128 16w", 43: "TR 64x64 BK64", 44: "TR 256x128 16w"}
+CFGS = {8: "64x64 BK64", 43: "TR 64x64 BK64", 15: "128x128 16w", 36: "256x256 16w", 7: "256x256 8w", 16: "256x128 16w"}
 
 
 def run(cfgs=None):
@@ -45,15 +45,21 @@ def run(cfgs=None):
             err = (c - ref).abs().max().item() / max(1.0, ref.abs().max().item())
             for _ in range(3):
                 call()
+            # device time: 40 calls captured in one hipGraph (eager launches from python are host-bound at ~8 us)
+            n = 40
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n):
+                    call()
+            g.replay()
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            n = 40
-            for _ in range(n):
-                call()
+            g.replay()
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / n
-            line += " %s: %6.1fus %5.0fTF%s |" % (name, us, 2.0 * M * N * K / us / 1e6, "" if (err < 1e-4 or cfg >= 100) else " ERR %.1e" % err)
+            line += "\n      %-20s %6.1fus %5.0fTF%s" % (name, us, 2.0 * M * N * K / us / 1e6, "" if (err < 1e-4 or 100 <= cfg < 300) else " ERR %.1e" % err)
         print(line, flush=True)
 
 
