@@ -304,6 +304,38 @@ def attention_planes(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_
     return Act(out, hi, lo)
 
 
+def attention_rows(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True, cfg=0):
+    """bf16x3 attention straight from row-major planes.  q, k, v: (hi, lo) pairs of bf16 plane views (B,S,H*64) --
+    typically column slices of the fused QKV / KV GEMM outputs; K and V rows are staged in LDS by the kernel (no
+    re-tiling pass).  Returns an Act (planes for the output projection by default)."""
+    lib = _lib.load()
+    qh, ql = q
+    kh, kl = k
+    vh, vl = v
+    B, Sq, HD = qh.shape
+    Sk = kh.shape[1]
+    assert HD == heads * 64 and kh.shape[2] == HD and vh.shape == kh.shape
+    for t in (qh, ql, kh, kl, vh, vl):
+        assert t.dtype == torch.bfloat16 and t.stride(2) == 1
+    assert qh.stride() == ql.stride() and kh.stride() == kl.stride() and vh.stride() == vl.stride()
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    dev = qh.device
+    out = torch.empty(B, Sq, HD, dtype=torch.float32, device=dev) if want_f32 else None
+    hi = lo = None
+    if want_planes:
+        hi, lo = _planes_like((B, Sq, HD), dev)
+    if kmask is not None:
+        if kmask.dtype == torch.bool:
+            kmask = kmask.view(torch.uint8)
+        assert kmask.shape == (B, Sk) and kmask.stride(1) == 1
+    _timed("attention", 4.0 * B * Sq * Sk * HD, lambda: _lib.check(lib.gridmm_attention_rows_cfg(
+        _p(qh), _p(ql), qh.stride(0), qh.stride(1), _p(kh), _p(kl), kh.stride(0), kh.stride(1), _p(vh), _p(vl),
+        vh.stride(0), vh.stride(1), _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * HD, HD,
+        _p(hi), _p(lo), Sq * HD, HD, B, heads, Sq, Sk, float(scale), int(cfg), _stream()), "gridmm_attention_rows"))
+    return Act(out, hi, lo)
+
+
 def ln_dot(x, gamma, beta, eps, w, b0, out=None):
     lib = _lib.load()
     if isinstance(x, Act):

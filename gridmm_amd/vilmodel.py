@@ -273,7 +273,7 @@ class GlocalTextPathNavCMT(nn.Module):
             a, c0 = t
             H = self.config.hidden_size
             return a.hi[..., c0:c0 + H], a.lo[..., c0:c0 + H]
-        return ops.attention_planes(sl(q), sl(k), sl(v), kmask, heads=self.heads)   # -> planes for the out-proj
+        return ops.attention_rows(sl(q), sl(k), sl(v), kmask, heads=self.heads)     # -> planes for the out-proj
 
     def _self_attention(self, att, key, x, kmask):
         """BertAttention (vilmodel.py:172-182): LN(dense(attn(x)) + x).  x: Act(f32 + planes)."""

@@ -213,6 +213,24 @@ int gridmm_attention_planes(const void* Q_hi, const void* Q_lo, int64_t q_bs, in
                             void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq, int Sk, float scale,
                             gridmm_stream_t stream);
 
+/* bf16x3 attention with K AND V taken as the ROW-MAJOR hi/lo planes the QKV / KV GEMMs emit (no re-tiling pass):
+ * a workgroup stages its head's K / V rows once in LDS (LDS-DMA, source-side swizzle) and reads V^T fragments
+ * through the hardware transpose read.  Replaces gridmm_transpose_v + gridmm_attention_planes on the hot path of
+ * BertSelfAttention / BertOutAttention (map_nav_src/models/vilmodel.py:317-379) and of the grid encoder's
+ * nn.MultiheadAttention (map_nav_src/models/transformer.py:176-177).  Strides in elements, rows 16-byte aligned;
+ * Sk <= 512; kmask (B, Sk) bytes, 0 = masked (contributes exactly 0); a fully masked query row yields 0.
+ * _cfg: cfg = 0 picks the launch shape, cfg > 0 forces one (tools/bench_attn2.py). */
+int gridmm_attention_rows(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                          const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo, int64_t v_bs,
+                          int v_rs, const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs, int o_rs, void* O_hi,
+                          void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq, int Sk, float scale,
+                          gridmm_stream_t stream);
+int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                              const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
+                              int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs,
+                              int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq,
+                              int Sk, float scale, int cfg, gridmm_stream_t stream);
+
 /* out[m] = <LayerNorm(X[m]) * gamma + beta, w> + b0      (tail of ClsPrediction,
  * vilmodel.py:663-674: Linear -> ReLU -> LN -> Linear(H,1)). */
 int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const float* beta, float eps,

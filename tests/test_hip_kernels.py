@@ -172,3 +172,48 @@ def test_attention_bf16x3_planes_matches_fp32_softmax(dev, B, Sq, Sk):
     err = (o.double() - ref).abs().max().item()
     assert err < 2e-4, err          # ~2^-16 relative on scores of magnitude ~10 (N(0,1) q.k over 64 dims)
     assert ((out.hi.float() + out.lo.float()) - o).abs().max() <= 2.0 ** -15 * o.abs().max()
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("B,Sq,Sk", [(2, 16, 32), (3, 57, 296), (2, 216, 216), (1, 5, 37), (2, 216, 80), (2, 57, 57), (1, 40, 512)])
+def test_attention_rows_matches_fp32_softmax(dev, B, Sq, Sk, cfg):
+    """gridmm_attention_rows (K / V staged row-major in LDS, transpose reads) vs an fp64 softmax reference: ragged
+    masks, a masked first key, whole 32-key tiles masked out, key counts across the 64 / 128-row chunk boundaries, and
+    separate K / V buffers with different row strides."""
+    ops = _ops()
+    Hh = 12
+    g = torch.Generator().manual_seed(B * 3 + Sq + Sk)
+    qb = torch.randn(B, Sq, 768, generator=g).to(dev)
+    kvb = torch.randn(B, Sk, 4 * 768, generator=g).to(dev)      # [pad | K | pad | V]: strided column slices
+    qa, kva = ops.split_rows(qb), ops.split_rows(kvb)
+    lens = torch.randint(1, Sk + 1, (B,), generator=g)
+    lens[0] = Sk
+    mask = (torch.arange(Sk)[None] < lens[:, None])
+    mask[-1, 0] = False
+    if Sk > 100:
+        mask[0, 32:96] = False          # two fully masked 32-key tiles in the middle
+    if not mask[-1].any():
+        mask[-1, -1] = True
+    mask = mask.to(dev)
+    ksl = (kva.hi[..., 768:1536], kva.lo[..., 768:1536])
+    vsl = (kva.hi[..., 2304:], kva.lo[..., 2304:])
+    out = ops.attention_rows((qa.hi, qa.lo), ksl, vsl, mask, want_f32=True, want_planes=True, cfg=cfg)
+    o = out.f32
+    def heads(t):
+        return t.reshape(B, -1, Hh, 64).permute(0, 2, 1, 3).double()
+    s = heads(qb) @ heads(kvb[..., 768:1536]).transpose(-1, -2) / 8.0
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ heads(kvb[..., 2304:])).permute(0, 2, 1, 3).reshape(B, Sq, 768)
+    err = (o.double() - ref).abs().max().item()
+    assert err < 2e-4, err
+    assert ((out.hi.float() + out.lo.float()) - o).abs().max() <= 2.0 ** -15 * o.abs().max()
+
+
+def test_attention_rows_fully_masked_row_is_zero(dev):
+    ops = _ops()
+    x = ops.split_rows(torch.randn(2, 20, 3 * 768, device=dev))
+    mask = torch.ones(2, 20, dtype=torch.bool, device=dev)
+    mask[1] = False
+    sl = lambda c0: (x.hi[..., c0:c0 + 768], x.lo[..., c0:c0 + 768])
+    out = ops.attention_rows(sl(0), sl(768), sl(1536), mask, want_f32=True)
+    assert torch.isfinite(out.f32).all() and (out.f32[1] == 0).all() and out.f32[0].abs().max() > 0
