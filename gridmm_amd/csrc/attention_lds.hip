@@ -18,7 +18,7 @@
 //     whose probabilities lane (j, g) already holds in its two S^T accumulators, so P^T is the B operand as it is.
 //     Output lane (j, g) holds O[query j][dims 16n+4g .. +3]: the running-max rescale is lane-local (no broadcast)
 //     and the stores are 64/128-bit.
-//   * NQ query tiles per wave share every K / V fragment read.
+//   * NQ query tiles per wave share every K / V fragment read; wave NW of the workgroup only loads (see the chunk ring).
 #include <type_traits>
 
 #include "common.h"
@@ -64,7 +64,7 @@ __device__ unsigned long long g_att_prof[8];
 #endif
 
 template <int NQ, int NW, int KC, int AB = 0>
-__global__ __launch_bounds__(NW * 64) void attention_rows_kernel(
+__global__ __launch_bounds__((NW + 1) * 64) void attention_rows_kernel(
     const unsigned short* __restrict__ Qh, const unsigned short* __restrict__ Ql, int64_t q_bs, int q_rs,
     const unsigned short* __restrict__ Kh, const unsigned short* __restrict__ Kl, int64_t k_bs, int k_rs,
     const unsigned short* __restrict__ Vh, const unsigned short* __restrict__ Vl, int64_t v_bs, int v_rs,
@@ -74,8 +74,6 @@ __global__ __launch_bounds__(NW * 64) void attention_rows_kernel(
   static_assert(KC % 32 == 0 && 2 * 4 * KC * 128 <= 65536, "chunk ring (also the 16-bit ds offset field)");
   constexpr int PLANE = KC * 64;                                  // u16 per plane image
   constexpr int NT = KC / 32;                                     // key tiles per chunk
-  constexpr int PPW = 4 * (KC / 8) / NW;                          // 1-KiB DMA pieces per wave and chunk
-  static_assert(PPW * NW == 4 * (KC / 8), "pieces must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) unsigned short kvbuf[2 * 4 * PLANE];   // 2 x (K hi | K lo | V hi | V lo)
   __shared__ unsigned s_mw[16];                                   // key validity, one word per 32 keys (Sk <= 512)
   const int lane = threadIdx.x & 63;
@@ -103,26 +101,50 @@ __global__ __launch_bounds__(NW * 64) void attention_rows_kernel(
   const unsigned short* Vbh = Vh + b * v_bs + h * 64;
   const unsigned short* Vbl = Vl + b * v_bs + h * 64;
 
-  // ---- chunk ring: two LDS buffers; the DMA of chunk c+1 runs under the math of chunk c.  Every wave issues the
-  // same PPW pieces per chunk (rows past Sk re-read row Sk-1; they are masked), so the waits are plain vmcnt(0).
-  auto stage = [&](int key0c, int buf) {   // piece p = (plane, 8 key rows); lane -> (row r0 + lane / 8, slot lane % 8)
+  // ---- chunk ring: two LDS buffers; wave NW is the LOADER: it copies chunk c+1 (global -> LDS by LDS-DMA) while the
+  // NW math waves work on chunk c -- a wave that issues DMA into a busy memory pipe is blocked at issue for ~200
+  // cycles per 1-KiB piece (tools/att_prof.py), time the math waves do not have.  One s_barrier per chunk hands the
+  // buffers over.  Rows past Sk re-read row Sk-1 (they are masked).
+  auto stage = [&](int key0c, int buf) {   // piece = (plane, 8 key rows); lane -> (row r0 + lane / 8, slot lane % 8)
     if (AB == 1 || AB == 3) return;        // timing ablation: no staging
+    const int lrow = lane >> 3, coff = ((lane & 7) ^ (lrow & 6)) << 3;   // r0 % 8 == 0: the slot swizzle is per lane
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int p = wave * PPW + i;
-      const int plane = p / (KC / 8), r0 = (p % (KC / 8)) << 3;
-      const int row = r0 + (lane >> 3), c = (lane & 7) ^ (row & 6);
-      const int key = min(key0c + row, Sk - 1);
-      const unsigned short* src = plane == 0 ? Kbh + (size_t)key * k_rs : plane == 1 ? Kbl + (size_t)key * k_rs
-                                : plane == 2 ? Vbh + (size_t)key * v_rs : Vbl + (size_t)key * v_rs;
-      dma16(src + c * 8, kvbuf + buf * (4 * PLANE) + plane * PLANE + r0 * 64);
+    for (int r0 = 0; r0 < KC; r0 += 8) {
+      const int key = min(key0c + r0 + lrow, Sk - 1);
+      const size_t ko = (size_t)key * k_rs + coff, vo = (size_t)key * v_rs + coff;
+      unsigned short* d = kvbuf + buf * (4 * PLANE) + r0 * 64;
+      dma16(Kbh + ko, d);
+      dma16(Kbl + ko, d + PLANE);
+      dma16(Vbh + vo, d + 2 * PLANE);
+      dma16(Vbl + vo, d + 3 * PLANE);
     }
   };
 #ifdef GRIDMM_ATT_PROF
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = __builtin_readcyclecounter();
 #endif
-  stage(0, 0);                             // first: the longest latency of the prologue
+  if (wave == NW) {                        // ---------------- loader wave
+    stage(0, 0);
+    {   // validity words from independent byte loads, under the first DMA
+      const uint8_t* mrow = kmask ? kmask + (size_t)b * mask_bs : nullptr;
+      for (int i = 0; i < ((Sk + 63) >> 6); ++i) {
+        const int k = i * 64 + lane;
+        const unsigned long long bal = __ballot((k < Sk) && (!mrow || mrow[k]));
+        if (lane == 0) { s_mw[2 * i] = (unsigned)bal; s_mw[2 * i + 1] = (unsigned)(bal >> 32); }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // chunk 0 and the validity words are visible
+    int lb = 0;
+    for (int key0c = 0; key0c < Sk; key0c += KC, lb ^= 1) {
+      if (key0c + KC < Sk) {
+        stage(key0c + KC, lb ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();        // chunk c+1 landed; the math waves are done with chunk c
+    }
+    return;
+  }
 
   const int qt0 = (blockIdx.x * NW + wave) * NQ;                  // first query tile of this wave
   // Q^T as the B operand of S^T = K Q^T: lane (query j, k-chunk g) holds head dims 32 ks + 8g .. +8.  Query tiles past
@@ -133,14 +155,6 @@ __global__ __launch_bounds__(NW * 64) void attention_rows_kernel(
     const size_t qo = b * q_bs + (size_t)min((qt0 + t) * 16 + j, Sq - 1) * q_rs + h * 64 + 8 * g;
     qh[t][0] = *reinterpret_cast<const bf16x8_t*>(Qh + qo); qh[t][1] = *reinterpret_cast<const bf16x8_t*>(Qh + qo + 32);
     ql[t][0] = *reinterpret_cast<const bf16x8_t*>(Ql + qo); ql[t][1] = *reinterpret_cast<const bf16x8_t*>(Ql + qo + 32);
-  }
-  {   // validity words from independent byte loads
-    const uint8_t* mrow = kmask ? kmask + (size_t)b * mask_bs : nullptr;
-    for (int i = wave; i < ((Sk + 63) >> 6); i += NW) {
-      const int k = i * 64 + lane;
-      const unsigned long long bal = __ballot((k < Sk) && (!mrow || mrow[k]));
-      if (lane == 0) { s_mw[2 * i] = (unsigned)bal; s_mw[2 * i + 1] = (unsigned)(bal >> 32); }
-    }
   }
   f32x4_t o[NQ][4];
   float m_run[NQ], l_run[NQ];
@@ -153,15 +167,16 @@ __global__ __launch_bounds__(NW * 64) void attention_rows_kernel(
 
   int buf = 0;
   GRIDMM_T(0);                                                    // prologue issue
+  __builtin_amdgcn_s_barrier();                                   // chunk 0 and the validity words are visible
+  GRIDMM_T(1);
   for (int key0c = 0; key0c < Sk; key0c += KC, buf ^= 1) {
     const int rows = min(KC, ((Sk - key0c + 31) >> 5) << 5);      // multiple of 32
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the chunk have landed
-    GRIDMM_T(1);                                                  // DMA wait
-    __syncthreads();                                              // ... everyone's; and the other buffer is free
-    GRIDMM_T(2);                                                  // barrier
-    if (key0c + KC < Sk) stage(key0c + KC, buf ^ 1);
-    GRIDMM_T(3);                                                  // DMA issue
-    if (AB == 2 || AB == 3) continue;                             // timing ablation: no math
+    if (key0c) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's LDS reads of the previous chunk are done
+      __builtin_amdgcn_s_barrier();                               // hand-over: next chunk landed, previous buffer free
+      GRIDMM_T(2);
+    }
+    if (AB == 2 || AB == 3) continue;                             // timing ablation: no math (barriers stay)
     const unsigned short* kv = kvbuf + buf * (4 * PLANE);
     unsigned vaddr[4];
 #pragma unroll
@@ -302,6 +317,7 @@ __global__ __launch_bounds__(NW * 64) void attention_rows_kernel(
     GRIDMM_T(6);                                                  // P V tiles (issue)
   }
 
+  __builtin_amdgcn_s_barrier();                                   // pairs with the loader's last hand-over
   // ---- finish from registers: lane (j, g) holds O[query j][16n + 4g .. +3]
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
@@ -351,14 +367,14 @@ extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int
   if ((!O && !O_hi) || (O_hi && (!O_lo || (p_rs & 3) || (p_bs & 3))) || (O && ((o_rs & 3) || (o_bs & 3))))
     return GRIDMM_EINVAL;
   const int nqt = (Sq + 15) / 16;
-  if (cfg == 0) cfg = nqt <= 4 ? 1 : 4;   // tools/bench_attn2.py: 57-query calls 7-20 us with (1, 4, 64); 216-query calls 25-40 us with (2, 8, 64)
+  if (cfg == 0) cfg = nqt <= 4 ? 5 : 3;   // tools/bench_attn2.py: 57-query calls 7-17 us with (1, 4, 32); 216-query calls 27-40 us with (1, 8, 64)
 #define GRIDMM_ATT_ARGS                                                                                             \
   (const unsigned short*)Q_hi, (const unsigned short*)Q_lo, q_bs, q_rs, (const unsigned short*)K_hi,               \
       (const unsigned short*)K_lo, k_bs, k_rs, (const unsigned short*)V_hi, (const unsigned short*)V_lo, v_bs, v_rs, \
       kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs, p_rs, Sq, Sk, scale
 #define GRIDMM_ATTX(NQ, NW, KC, AB)                                                                                     \
   do {                                                                                                              \
-    dim3 grid((nqt + (NQ) * (NW) - 1) / ((NQ) * (NW)), heads, B), block((NW) * 64);                                  \
+    dim3 grid((nqt + (NQ) * (NW) - 1) / ((NQ) * (NW)), heads, B), block(((NW) + 1) * 64);                                  \
     GRIDMM_LAUNCH((attention_rows_kernel<NQ, NW, KC, AB>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS);    \
   } while (0)
 #define GRIDMM_ATT(NQ, NW, KC) GRIDMM_ATTX(NQ, NW, KC, 0)
@@ -366,10 +382,8 @@ extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int
     case 1: GRIDMM_ATT(1, 4, 64); break;
     case 2: GRIDMM_ATT(2, 4, 64); break;
     case 3: GRIDMM_ATT(1, 8, 64); break;
-    case 4: GRIDMM_ATT(2, 8, 64); break;
     case 5: GRIDMM_ATT(1, 4, 32); break;
     case 6: GRIDMM_ATT(2, 4, 32); break;
-    case 7: GRIDMM_ATT(4, 4, 64); break;
     case 11: GRIDMM_ATTX(2, 4, 64, 1); break;   // ablations of cfg 2: no staging / no math
     case 12: GRIDMM_ATTX(2, 4, 64, 2); break;
     case 13: GRIDMM_ATTX(2, 4, 64, 3); break;

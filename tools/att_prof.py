@@ -7,7 +7,7 @@ from gridmm_amd import _lib, ops
 lib = _lib.load(); dev = torch.device("cuda"); B, heads = int(os.environ.get("ATT_B", "32")), 12
 lib.gridmm_debug_att_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 8)()
-names = ["prologue issue", "DMA wait", "barrier", "DMA issue", "S tiles", "softmax", "PV tiles", "epilogue"]
+names = ["prologue (Q loads issue)", "first barrier (chunk 0 + Q)", "hand-over barriers", "-", "S tiles", "softmax", "PV tiles", "epilogue"]
 for (name, Sq, Sk, Wq, Wk) in [("grid self", 216, 216, 2304, 2304), ("grid x text", 216, 80, 768, 1536), ("local x kv", 57, 296, 768, 6144), ("local self", 57, 57, 2304, 2304)]:
     qb = ops.split_rows(torch.randn(B, Sq, Wq, device=dev)); kb = qb if (Wq == Wk and Sq == Sk) else ops.split_rows(torch.randn(B, Sk, Wk, device=dev))
     q = (qb.hi[..., :768], qb.lo[..., :768]); k = (kb.hi[..., Wk - 1536:Wk - 768], kb.lo[..., Wk - 1536:Wk - 768]); v = (kb.hi[..., Wk - 768:], kb.lo[..., Wk - 768:])
@@ -18,7 +18,7 @@ for (name, Sq, Sk, Wq, Wk) in [("grid self", 216, 216, 2304, 2304), ("grid x tex
         n = 5
         for _ in range(n): ops.attention_rows(q, k, v, mask, cfg=cfg)
         torch.cuda.synchronize(); lib.gridmm_debug_att_prof(buf, 1)
-        nq, nw = {1: (1, 4), 2: (2, 4), 3: (1, 8), 4: (2, 8), 5: (1, 4), 6: (2, 4), 7: (4, 4)}[cfg]
+        nq, nw = {1: (1, 4), 2: (2, 4), 3: (1, 8), 5: (1, 4), 6: (2, 4)}[cfg]
         nqt = (Sq + 15) // 16
         waves = B * heads * ((nqt + nq * nw - 1) // (nq * nw)) * nw
         d = n * waves

@@ -43,7 +43,21 @@ for (name, Sq, Sk, Wq, Wk) in [("grid self", 216, 216, 2304, 2304), ("grid x tex
             for _ in range(3): rows(c)()
         torch.cuda.synchronize()
         continue
-    print("%-12s attention_rows cfg 1..7:" % name, " ".join("%5.1f" % gtime(rows(c)) for c in range(1, 8)), "us | cfg 2 without staging %.1f, without math %.1f, neither %.1f" % (gtime(rows(11)), gtime(rows(12)), gtime(rows(13))), flush=True)
+    print("%-12s attention_rows cfg 1,2,3,5,6:" % name, " ".join("%5.1f" % gtime(rows(c)) for c in (1, 2, 3, 5, 6)), "us | cfg 2 without staging %.1f, without math %.1f, neither %.1f" % (gtime(rows(11)), gtime(rows(12)), gtime(rows(13))), flush=True)
     mf = 4.0 * B * Sq * Sk * 768 * 3
     t1, t2 = gtime(tr), gtime(at)
     print("%-12s Sq=%3d Sk=%3d | transpose_v %5.1f us | attention_planes %5.1f us (%.0f TF on the pipe; MFMA floor %.1f us)" % (name, Sq, Sk, t1, t2, mf / t2 / 1e6, mf / 2.5e9), flush=True)
+
+# ---- layout probe: the same work with per-head CONTIGUOUS planes ([B*heads][S][64], heads = 1 per "batch" entry)
+print("per-head contiguous layout (B*12 single-head problems):")
+for (name, Sq, Sk) in [("grid self", 216, 216), ("grid x text", 216, 80), ("local x kv", 57, 296), ("local self", 57, 57)]:
+    Bh = B * heads
+    qa = ops.split_rows(torch.randn(Bh, Sq, 64, device=dev)); ka = ops.split_rows(torch.randn(Bh, Sk, 64, device=dev)); va = ops.split_rows(torch.randn(Bh, Sk, 64, device=dev))
+    mask = torch.ones(Bh, Sk, dtype=torch.uint8, device=dev)
+    hi, lo = ops._planes_like((Bh, Sq, 64), dev)
+    def rows(cfg):
+        def f():
+            assert lib.gridmm_attention_rows_cfg(p(qa.hi), p(qa.lo), Sq * 64, 64, p(ka.hi), p(ka.lo), Sk * 64, 64, p(va.hi), p(va.lo), Sk * 64, 64,
+                p(mask), Sk, None, 0, 0, p(hi), p(lo), Sq * 64, 64, Bh, 1, Sq, Sk, 0.125, cfg, st()) == 0
+        return f
+    print("%-12s attention_rows cfg 1,2,3,5,6:" % name, " ".join("%5.1f" % gtime(rows(c)) for c in (1, 2, 3, 5, 6)), "us | cfg 2 without staging %.1f, without math %.1f, neither %.1f" % (gtime(rows(11)), gtime(rows(12)), gtime(rows(13))), flush=True)
