@@ -8,7 +8,7 @@ from gridmm_amd import _lib, ops
 SHAPES = [(6912, 2304, 768), (6912, 768, 768), (6912, 3072, 768), (6912, 768, 3072), (9472, 6144, 768),
           (2560, 1536, 768), (1824, 768, 768), (1824, 2304, 768), (1824, 3072, 768), (1824, 768, 3072),
           (2560, 512, 768), (6272, 768, 512)]
-CFGS = {8: "64x64 BK64", 43: "TR 64x64 BK64", 15: "128x128 16w", 36: "256x256 16w", 7: "256x256 8w", 16: "256x128 16w"}
+CFGS = {8: "64x64 BK64", 43: "TR 64x64 BK64", 14: "128x128 8w", 15: "128x128 16w", 36: "256x256 16w", 7: "256x256 8w", 16: "256x128 16w"}
 
 
 def run(cfgs=None):
