@@ -47,11 +47,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-depth-legs", action="store_true", help="skip the extra t = 5 / t = 15 timings")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def build_workload(args, dev):
+def build_workload(args, dev, mem_steps=None, device_feats=False):
+    """mem_steps overrides args.mem_steps (the extra t = 5 / 15 legs); device_feats fills the slab with N(0,1) drawn on
+    the GPU instead of the host-generated features (no oracle leg runs on those workloads)."""
     from gridmm_amd import synthetic as S
     from gridmm_amd.grid_memory import GridMemoryBatch
     from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
@@ -62,15 +65,21 @@ def build_workload(args, dev):
     # BERT-style random init leaves LayerNorm at (1, 0); fine for timing
     model.to(dev)
     rs = np.random.RandomState(int(os.environ.get("RANK", "0")))
-    B, t = args.batch, args.mem_steps
-    batch = S.batch_to(S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, min_len=30), dev)
+    B, t = args.batch, (args.mem_steps if mem_steps is None else mem_steps)
+    host_batch = S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, min_len=30)
+    batch = S.batch_to(host_batch, dev)
+    # what a caller has on the host each step for the fused-logit index maps (vilmodel.py:881-899)
+    fusion_src = (host_batch["gmap_vpids"], host_batch["gmap_visited_masks"].numpy(), host_batch["vp_cand_vpids"])
     mem = GridMemoryBatch(B, geom, max_steps=t, device=dev)
-    eps = [S.make_observations(rs, geom, t) for _ in range(B)]
+    eps = [S.make_observations(rs, geom, t, with_feats=not device_feats) for _ in range(B)]
     n_new = geom.pts_per_obs
     depth = [torch.from_numpy(np.stack([e[k]["depth"].reshape(-1) for e in eps])).to(dev) for k in range(t)]
     # tokens are written into the slab once, before timing (zero-copy append: producer-owned slot)
     for k in range(t):
-        mem.slab[:, k * n_new:(k + 1) * n_new].copy_(torch.from_numpy(np.stack([e[k]["feats"] for e in eps])))
+        if device_feats:
+            mem.slab[:, k * n_new:(k + 1) * n_new].copy_(torch.randn(B, n_new, geom.feat_dim, device=dev))
+        else:
+            mem.slab[:, k * n_new:(k + 1) * n_new].copy_(torch.from_numpy(np.stack([e[k]["feats"] for e in eps])))
     poses = [[(e[k]["x"], e[k]["y"]) for e in eps] for k in range(t)]
     heads = [[e[k]["heading"] for e in eps] for k in range(t)]
     for k in range(t - 1):                      # history prefix (t-1 observations), built once
@@ -78,14 +87,15 @@ def build_workload(args, dev):
     restore = (mem.n_pts.clone(), mem.bbox.clone())
     n_host0 = mem.n_pts_host.copy()
     batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
-    batch["fusion_maps"] = model.fusion_maps(batch, dev)
 
     def eager_step():
         mem.n_pts.copy_(restore[0])
         mem.bbox.copy_(restore[1])
         mem.n_pts_host[:] = n_host0
         mem.step(depth[t - 1], None, poses[t - 1], heads[t - 1])   # project the new observation + re-bin all
-        return model("navigation", batch)
+        # the fused-logit index maps are rebuilt from the vpid lists on every call, as in the reference
+        return model("navigation", dict(batch, fusion_maps=model.fusion_maps(
+            dict(batch, gmap_visited_masks=fusion_src[1]), dev)))
 
     step = eager_step
     if not args.eager and args.groups > 1:
@@ -120,8 +130,8 @@ def build_workload(args, dev):
         g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore)
         mem.n_pts_host[:] = n_host0 + n_new
 
-        def step():
-            return g(poses[t - 1], heads[t - 1])
+        def step():   # host half (pose / heading floats, fused-logit index maps) + one graph replay
+            return g(poses[t - 1], heads[t - 1], fusion=fusion_src)
     return model, batch, mem, eps, step, eager_step, geom
 
 
@@ -140,6 +150,39 @@ def time_steps(step, steps, warmup, dist):
     dt = time.perf_counter() - t0
     from gridmm_amd.dist import max_over_ranks
     return max_over_ranks(dt)          # the slowest rank defines the step time (identity at N=1)
+
+
+LOGIT_KEYS = ("global_logits", "local_logits", "grid_logits", "fused_logits")
+
+
+def check_replay(step, eager_step):
+    """What bench.py times is the hipGraph replay: compare its outputs with the same step launched eagerly (same
+    kernels, same order: expected bit-identical) and fail loudly if they differ."""
+    got = {k: v.clone() for k, v in step().items() if k in LOGIT_KEYS}
+    torch.cuda.synchronize()
+    want = eager_step()
+    torch.cuda.synchronize()
+    worst, bitwise = 0.0, True
+    for k in LOGIT_KEYS:
+        a, w = got[k], want[k]
+        f = torch.isfinite(w)
+        if not torch.equal(f, torch.isfinite(a)):
+            raise SystemExit("bench.py: replayed %s has -inf in different places than the eager step" % k)
+        bitwise &= bool(torch.equal(a[f], w[f]))
+        if f.any():
+            worst = max(worst, float((a[f] - w[f]).abs().max()))
+    if worst > 1e-6:
+        raise SystemExit("bench.py: replayed logits differ from the eager step by %.3g" % worst)
+    return {"replay_vs_eager_max_abs": worst, "bit_identical": bitwise}
+
+
+def extra_depth_leg(args, dev, dist, mem_steps, steps):
+    """nav steps/s of this rank at memory depth t = mem_steps (slab filled on the device), same step otherwise."""
+    model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev, mem_steps=mem_steps, device_feats=True)
+    dt = time_steps(step, steps, 2, dist)
+    del model, batch, mem, step, eager_step
+    torch.cuda.empty_cache()
+    return dt / steps
 
 
 def roofline_leg(step, args, geom, L=80):
@@ -277,6 +320,7 @@ def main():
     dt = time_steps(step, args.steps, args.warmup, dist)
     n_gpus = world
     value = n_gpus * args.batch * args.steps / dt
+    check = check_replay(step, eager_step)      # the timed (replayed) step must reproduce the eager launches
 
     out = {
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -288,10 +332,18 @@ def main():
                                % (args.batch, geom.n_views, geom.patches ** 2, geom.feat_dim, args.mem_steps,
                                   geom.pts_per_obs * args.mem_steps),
                    "global_batch": args.batch * n_gpus, "parallelism": "dp%d (episode sharding, no step-path collective)" % n_gpus,
-                   "launch": "eager" if args.eager else "hipGraph replay (pose/heading H2D outside the graph)",
+                   "launch": "eager" if args.eager else "hipGraph replay; per step on the host: pose/heading floats and the fused-logit index maps (H2D into static buffers)",
                    "gemm": "MFMA bf16 16x16x32, 3-term split (hi*hi+lo*hi+hi*lo), fp32 accumulate",
                    "attention": "MFMA bf16 16x16x32, 3-term split, fp32 softmax", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
     }
+    out["replay_check"] = check
+    if not args.no_depth_legs and not args.eager and args.groups == 1 and args.mem_steps == 1:
+        # the memory deepens as an episode proceeds; the headline is t = 1, these are the same step at
+        # t = 5 and t = 15 (re-binning and aggregation walk 5x / 15x the points)
+        for t in (5, 15):
+            sec = extra_depth_leg(args, dev, dist, t, max(5, args.steps // 2))
+            out["t%d" % t] = {"value": n_gpus * args.batch / sec, "unit": "steps/s", "ms_per_step": 1e3 * sec,
+                              "mem_steps": t, "points": geom.pts_per_obs * t}
     if rank == 0 and not args.no_roofline:
         rl = roofline_leg(eager_step, args, geom)   # per-launch HIP events need eager launches
         dom = rl["dominant"]

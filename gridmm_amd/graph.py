@@ -21,8 +21,15 @@ class GraphedNavStep:
         self.model, self.mem, self.batch, self.depth = model, mem, dict(batch), depth
         self.restore = restore
         dev = mem.device
-        if self.batch.get("fusion_maps") is None:
-            self.batch["fusion_maps"] = model.fusion_maps(batch, dev)
+        # fused-logit index maps (integer form of the reference's per-call vpid loops, vilmodel.py:881-899): static device
+        # buffers read by the graph, refreshed from pinned host buffers by refresh_fusion_maps() before a replay
+        fm = self.batch.get("fusion_maps")
+        if fm is None:
+            fm = model.fusion_maps(batch, dev)
+        self._fm_dev = tuple(t.clone() for t in fm)
+        self._fm_host = tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in fm)
+        self._fm_done = None
+        self.batch["fusion_maps"] = self._fm_dev
         self.batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
         self.graph = None
         self.outs = None
@@ -45,9 +52,26 @@ class GraphedNavStep:
         mem.project_and_bin(self.depth)
         return self.model("navigation", self.batch)
 
-    def __call__(self, poses, headings):
-        """poses/headings for the (single) appended observation; returns the static output dict."""
+    def refresh_fusion_maps(self, gmap_vpids, gmap_visited_masks, vp_cand_vpids):
+        """Host half of the logit fusion for THIS step: the vpid-keyed loops the reference runs inside every
+        forward('navigation') (vilmodel.py:881-899), as integer maps copied into the graph's static buffers."""
+        G, V = self._fm_dev[0].shape[1], self._fm_dev[1].shape[1]
+        a, b = self.model._fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V)
+        if self._fm_done is not None:
+            self._fm_done.synchronize()           # the previous step's async H2D has consumed the pinned buffers
+        self._fm_host[0].copy_(a)
+        self._fm_host[1].copy_(b)
+        self._fm_dev[0].copy_(self._fm_host[0], non_blocking=True)
+        self._fm_dev[1].copy_(self._fm_host[1], non_blocking=True)
+        self._fm_done = torch.cuda.Event()
+        self._fm_done.record()
+
+    def __call__(self, poses, headings, fusion=None):
+        """poses/headings for the (single) appended observation; fusion = (gmap_vpids, gmap_visited_masks (host),
+        vp_cand_vpids) rebuilds the fused-logit index maps for this step; returns the static output dict."""
         self.mem.set_pose(poses, headings)
+        if fusion is not None:
+            self.refresh_fusion_maps(*fusion)
         self.graph.replay()
         return self.outs
 

@@ -37,14 +37,15 @@ VLNCE_R2R = GridGeometry(depth_div=1.0, tan_half_fov=math.tan(math.pi / 4.), vln
 VLNCE_RXR = GridGeometry(depth_div=1.0, tan_half_fov=math.tan(math.pi * 79. / 360.), vlnce=True, max_dist=40.0)
 
 
-def make_observations(rs, geom, steps, feat_scale=1.0, zero_frac=0.1):
-    """One episode's observation sequence: list of dicts(depth, feats, x, y, heading)."""
+def make_observations(rs, geom, steps, feat_scale=1.0, zero_frac=0.1, with_feats=True):
+    """One episode's observation sequence: list of dicts(depth, feats, x, y, heading).  with_feats=False leaves
+    feats None (callers that fill the slab on the device) and draws nothing for them."""
     obs = []
     x, y = float(rs.uniform(-5, 5)), float(rs.uniform(-5, 5))
     for _ in range(steps):
         d = rs.randint(0, 20000, size=(geom.n_views, geom.patches ** 2)).astype(np.uint16)
         d[rs.rand(*d.shape) < zero_frac] = 0
-        f = (rs.standard_normal((geom.pts_per_obs, geom.feat_dim)) * feat_scale).astype(np.float16)
+        f = (rs.standard_normal((geom.pts_per_obs, geom.feat_dim)) * feat_scale).astype(np.float16) if with_feats else None
         obs.append(dict(depth=d, feats=f, x=x, y=y, heading=float(rs.randint(0, 12)) * math.pi / 6))
         r, a = rs.uniform(1, 3), rs.uniform(0, 2 * math.pi)
         x, y = float(x + r * math.cos(a)), float(y + r * math.sin(a))
