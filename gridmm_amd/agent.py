@@ -54,6 +54,13 @@ def gen_seq_masks(seq_lens, max_len=None):
 
 class GMapNavAgent:
     def __init__(self, args, env, vln_bert, device="cuda"):
+        """vln_bert: the model the loop calls as vln_bert(mode, batch).  A bare GlocalTextPathNavCMT is wrapped in
+        model.VLNBert so that train() applies the reference's environment feature dropout (models/model.py:19,29-31);
+        a VLNBert, or any other callable (the tests drive the loop with the reference model), is used as given."""
+        from .vilmodel import GlocalTextPathNavCMT
+        if isinstance(vln_bert, GlocalTextPathNavCMT):
+            from .model import VLNBert
+            vln_bert = VLNBert(args, vln_bert=vln_bert)
         self.args, self.env, self.vln_bert = args, env, vln_bert
         self.device = torch.device(device)
         self.scanvp_cands = {}

@@ -346,6 +346,13 @@ class _GridAggregate(torch.autograd.Function):
         # save_for_backward, whose version check would trip on the later in-place appends.
         ctx.save_for_backward(text_fts, perm.clone(), cell_start.clone(), rel)
         ctx.slab = slab
+        # ... which makes "the slab rows are still the ones this step saw" OUR invariant to check: GridMemoryBatch tags
+        # its slab with an epoch that advances whenever the rows are recycled in place (reset() of a memory that is not
+        # kept for backward); backward refuses to run on a recycled slab instead of returning wrong gradients.
+        ctx.epoch_ref = getattr(slab, "_gridmm_epoch", None)
+        ctx.epoch = None if ctx.epoch_ref is None else ctx.epoch_ref[0]
+        if text_fts.requires_grad and ctx.epoch_ref is not None:
+            slab._gridmm_in_graph = True     # reset() then allocates a fresh slab for the next rollout
         ctx.mark_non_differentiable(occ)
         return cells, occ
 
@@ -354,6 +361,9 @@ class _GridAggregate(torch.autograd.Function):
         lib = _lib.load()
         text_fts, perm, cell_start, rel = ctx.saved_tensors
         slab = ctx.slab
+        if ctx.epoch_ref is not None and ctx.epoch_ref[0] != ctx.epoch:
+            raise RuntimeError("grid_aggregate backward: the grid memory's feature slab was recycled (reset()) after this "
+                               "step's forward; set GridMemoryBatch.keep_for_backward = True for training rollouts")
         B, L, D = text_fts.shape
         cap = slab.shape[1]
         dcells = dcells.contiguous()

@@ -39,14 +39,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, const T* 
     const float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
     scale = c < 1.f ? c : 1.f;
   }
+  // rnd(): round to the tensor's dtype.  The reference updates fp16 tensors with one in-place torch op after the other
+  // (clip_grad_norm_'s mul_, then adamw.py:88-109), each computing in fp32 and rounding its result to fp16 -- which is
+  // what makes g*g*(1-b2) below ~6e-8 vanish from the second moment (and the update explode to m/eps) there.  The same
+  // roundings are taken here; for fp32 tensors rnd() is the identity.
+  auto rnd = [](float x) { return (float)(T)x; };
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float gi = ld(g, i) * scale;
+    const float gi = rnd(ld(g, i) * scale);
     float pi = ld(p, i);
-    const float mi = b1 * ld(m, i) + (1.f - b1) * gi;
-    const float vi = b2 * ld(v, i) + (1.f - b2) * gi * gi;
-    if (decay_first && wd > 0.f) pi -= lr * wd * pi;          // torch.optim.AdamW order
-    pi -= step_size * mi / (sqrtf(vi) + eps);
-    if (!decay_first && wd > 0.f) pi -= lr * wd * pi;         // adamw.py:108-109
+    const float mi = rnd(rnd(b1 * ld(m, i)) + (1.f - b1) * gi);
+    const float vi = rnd(rnd(b2 * ld(v, i)) + (1.f - b2) * gi * gi);
+    if (decay_first && wd > 0.f) pi = rnd(pi - lr * wd * pi);          // torch.optim.AdamW order
+    pi = rnd(pi - step_size * (mi / rnd(rnd(sqrtf(vi)) + eps)));
+    if (!decay_first && wd > 0.f) pi = rnd(pi - lr * wd * pi);         // adamw.py:108-109
     st(p, i, pi);
     st(m, i, mi);
     st(v, i, vi);

@@ -31,13 +31,16 @@ from .synthetic import GridGeometry, NATIVE  # noqa: F401  (geometry description
 class GridMemoryBatch:
     MAX_BIN_SLICES = 16
 
-    def __init__(self, batch_size, geom=NATIVE, max_steps=15, device="cuda"):
+    def __init__(self, batch_size, geom=NATIVE, max_steps=16, device="cuda"):
+        """max_steps: observations per episode the slab holds.  A rollout appends max_action_len + 1 of them (one from
+        env.reset(), one after every action incl. the last, r2r/agent.py:268-451): 16 for the default max_action_len = 15."""
         self.B, self.geom, self.max_steps = batch_size, geom, max_steps
         self.device = torch.device(device)
         self.n_new = geom.pts_per_obs
         self.cap = max_steps * self.n_new
         B, cap, dev = batch_size, self.cap, self.device
         self.slab = torch.zeros(B, cap, geom.feat_dim, dtype=torch.float16, device=dev)
+        self.slab._gridmm_epoch = [0]
         self.hist_x = torch.zeros(B, cap, dtype=torch.float32, device=dev)
         self.hist_y = torch.zeros(B, cap, dtype=torch.float32, device=dev)
         self.hist_valid = torch.zeros(B, cap, dtype=torch.uint8, device=dev)
@@ -84,8 +87,11 @@ class GridMemoryBatch:
 
         With `self.keep_for_backward` set (training rollouts), the feature slab of the finished rollout stays
         untouched -- autograd nodes of that rollout still read it in backward -- and a fresh one is allocated."""
-        if self.keep_for_backward:
-            self.slab = torch.zeros_like(self.slab)
+        if self.keep_for_backward or getattr(self.slab, "_gridmm_in_graph", False):
+            self.slab = torch.zeros_like(self.slab)      # a live autograd graph reads the old rows (autograd._GridAggregate)
+            self.slab._gridmm_epoch = [0]
+        else:
+            self.slab._gridmm_epoch[0] += 1               # rows are recycled in place: stale backward passes must fail
         self.bbox.copy_(self._bbox_init)
         self.n_pts.zero_()
         self.n_pts_host[:] = 0

@@ -467,12 +467,76 @@ def gen_topo_map():
     print("topo_map: ok,", int((order[-1] >= 0).sum()), "nodes after", T, "steps")
 
 
+OPTIM = dict(steps=7, learning_rate=3e-3, warmup_steps=3, num_train_steps=9, weight_decay=0.01, betas=(0.9, 0.98),
+             grad_norm=2.0)
+
+
+class OptimToy(torch.nn.Module):
+    """Parameter NAMES matter (optim/misc.py:14: no decay on 'bias', 'LayerNorm.bias', 'LayerNorm.weight')."""
+
+    def __init__(self):
+        super().__init__()
+        self.dense = torch.nn.Linear(24, 16)
+        self.LayerNorm = torch.nn.LayerNorm(16)
+        self.emb = torch.nn.Embedding(10, 16)
+        self.grid_proj = torch.nn.Linear(16, 8, bias=False).half()   # the pre-training twin keeps this one in fp16
+        self.unused = torch.nn.Linear(4, 4)                          # never receives a gradient
+
+
+def optim_toy_grad(name, shape, step):
+    """Deterministic gradients: alternating large / tiny scales so that clipping is active on some steps only, and
+    |g| ~ 2e-4 entries whose squares underflow an fp16 second-moment state."""
+    g = R.det_tensor("g%d.%s" % (step, name), tuple(shape), 1)
+    return g * (6.0 if step % 2 == 0 else 2e-4 if step == 3 else 0.3)
+
+
+def gen_optim():
+    """pretrain_src/optim/adamw.py:56-112 + sched.py:17-30 + misc.py:12-37 driven as train_r2r.py:266-296 does
+    (lr schedule -> clip_grad_norm_ -> step) -> tests/golden/optim_reduced.npz (pins gridmm_amd/optim.py + optim.hip)."""
+    pre = os.path.join(R.REF_ROOT, "pretrain_src")
+    if pre not in sys.path:
+        sys.path.insert(0, pre)
+    from optim.misc import build_optimizer          # the reference's modules
+    from optim.sched import get_lr_sched
+    o = OPTIM
+    opts = R._AttrDict(optim="adamw", learning_rate=o["learning_rate"], betas=list(o["betas"]), weight_decay=o["weight_decay"],
+                       warmup_steps=o["warmup_steps"], num_train_steps=o["num_train_steps"])
+    torch.manual_seed(0)
+    model = OptimToy()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(R.det_tensor("p." + n, tuple(p.shape), 1).to(p.dtype))
+    opt = build_optimizer(model, opts)
+    out = {"versions": _versions(), "cfg": json.dumps(o), "names": json.dumps([n for n, _ in model.named_parameters()]),
+           "decay": json.dumps([[n for n, p in model.named_parameters() if any(p is q for q in g["params"])] for g in opt.param_groups])}
+    for n, p in model.named_parameters():
+        out["init." + n] = p.detach().float().numpy().copy()      # .float() of an fp32 tensor aliases the parameter
+    lrs, norms = [], []
+    for step in range(1, o["steps"] + 1):
+        lr = get_lr_sched(step, opts)
+        for g in opt.param_groups:
+            g["lr"] = lr
+        for n, p in model.named_parameters():
+            if not n.startswith("unused"):
+                p.grad = optim_toy_grad(n, p.shape, step).to(p.dtype)
+        norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), o["grad_norm"])))
+        opt.step()
+        opt.zero_grad()
+        lrs.append(lr)
+        for n, p in model.named_parameters():
+            out["step%d.%s" % (step, n)] = p.detach().float().numpy().copy()
+    out.update(lr=np.array(lrs), grad_norm=np.array(norms))
+    np.savez_compressed(os.path.join(OUT, "optim_reduced.npz"), **out)
+    print("optim: lr", lrs, "norms", [round(x, 4) for x in norms])
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo", "optim"]
     if "rollout" in which: gen_rollout()
     if "topo" in which: gen_topo_map()
+    if "optim" in which: gen_optim()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
     if "nav" in which: gen_nav_reduced(False)

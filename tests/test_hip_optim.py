@@ -101,3 +101,49 @@ def test_pretraining_steps_reduce_loss_and_follow_schedule():
     assert tr.global_step == 18
     assert abs(tr.optimizer.param_groups[0]["lr"] - 5e-5 * (40 - 18) / (40 - 2)) < 1e-12     # warmup_linear
     assert sum(last.values()) < sum(first.values()), (first, last)       # task-mixed steps on three fixed batches
+
+
+def test_optimizer_trajectory_matches_reference_golden():
+    """tests/golden/optim_reduced.npz: the reference's build_optimizer / get_lr_sched / AdamW.step (pretrain_src/optim/
+    misc.py:12-37, sched.py:17-30, adamw.py:56-112) driven as train_r2r.py:266-296 over 7 steps -- decay / no-decay
+    groups by parameter name, warm-up then linear decay, clipping active on some steps only, a parameter without
+    gradients, and an fp16 parameter with fp16 optimizer state (incl. a step whose g^2 underflows fp16)."""
+    from conftest import load_golden
+    from oracle import gen_golden as GG
+    from gridmm_amd.optim import build_optimizer, get_lr_sched
+    from types import SimpleNamespace
+    fx = load_golden("optim_reduced.npz")
+    o = json.loads(str(fx["cfg"]))
+    model = GG.OptimToy().cuda()
+    names = json.loads(str(fx["names"]))
+    assert [n for n, _ in model.named_parameters()] == names
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(fx["init." + n]).to(p.dtype))
+    opts = SimpleNamespace(optim="adamw", learning_rate=o["learning_rate"], betas=o["betas"], weight_decay=o["weight_decay"],
+                           warmup_steps=o["warmup_steps"], num_train_steps=o["num_train_steps"])
+    opt = build_optimizer(model, opts)
+    groups = [[n for n, p in model.named_parameters() if any(p is q for q in g["params"])] for g in opt.param_groups]
+    assert groups == json.loads(str(fx["decay"]))
+    assert [g["weight_decay"] for g in opt.param_groups] == [o["weight_decay"], 0.0]
+    for step in range(1, o["steps"] + 1):
+        lr = get_lr_sched(step, opts)
+        assert abs(lr - float(fx["lr"][step - 1])) < 1e-15
+        for g in opt.param_groups:
+            g["lr"] = lr
+        for n, p in model.named_parameters():
+            if not n.startswith("unused"):
+                p.grad = GG.optim_toy_grad(n, p.shape, step).to(p.dtype).cuda()
+        norm = opt.step(max_grad_norm=o["grad_norm"])
+        opt.zero_grad()
+        want_norm = float(fx["grad_norm"][step - 1])
+        assert abs(float(norm) - want_norm) < 2e-4 * want_norm, (step, float(norm), want_norm)
+        for n, p in model.named_parameters():
+            want = torch.from_numpy(fx["step%d.%s" % (step, n)])
+            got = p.detach().float().cpu()
+            if p.dtype == torch.float16:     # fp16 parameter / state: within two fp16 roundings of the reference
+                assert float((got - want).abs().max()) <= 2.0 ** -9 * float(want.abs().max()), (step, n)
+            else:
+                assert float((got - want).abs().max()) < 2e-6, (step, n, float((got - want).abs().max()))
+    assert all(torch.equal(p.detach().float().cpu(), torch.from_numpy(fx["init." + n]))
+               for n, p in model.named_parameters() if n.startswith("unused"))

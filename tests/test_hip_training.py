@@ -175,3 +175,33 @@ def test_one_optimizer_step_changes_logits_and_repacks_weights():
     b = model("navigation", batch)["fused_logits"]
     m = torch.isfinite(a)
     assert float((a[m] - b.detach()[m]).abs().max()) < 5e-4
+
+
+def test_backward_on_recycled_slab_fails_loudly_and_fresh_slab_is_automatic():
+    """autograd._GridAggregate keeps the slab by reference: a reset() between forward and backward must either hand
+    the next rollout a fresh slab (memory seen by a live graph) or make the stale backward raise -- never silently
+    return gradients computed from overwritten rows."""
+    from gridmm_amd import autograd as A, synthetic as S
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    rs = np.random.RandomState(3)
+    dev = torch.device("cuda")
+    mem = GridMemoryBatch(2, S.NATIVE, max_steps=2, device=dev)
+    eps = [S.make_observations(rs, S.NATIVE, 1, feat_scale=0.35) for _ in range(2)]
+    mem.step(np.stack([e[0]["depth"].reshape(-1) for e in eps]), np.stack([e[0]["feats"] for e in eps]),
+             [(e[0]["x"], e[0]["y"]) for e in eps], [e[0]["heading"] for e in eps])
+    text = torch.randn(2, 20, 768, device=dev, requires_grad=True)
+    cells, _ = A.grid_aggregate(text, mem.slab, mem.perm, mem.cell_start)
+    old = mem.slab
+    mem.reset()                                   # keep_for_backward is False, but the slab is in a live graph
+    assert mem.slab is not old and mem.slab.data_ptr() != old.data_ptr()
+    cells.sum().backward()                        # reads the untouched old slab
+    assert torch.isfinite(text.grad).all() and text.grad.abs().max() > 0
+    # a slab recycled in place behind the graph's back: backward refuses
+    text2 = torch.randn(2, 20, 768, device=dev, requires_grad=True)
+    mem.step(np.stack([e[0]["depth"].reshape(-1) for e in eps]), np.stack([e[0]["feats"] for e in eps]),
+             [(e[0]["x"], e[0]["y"]) for e in eps], [e[0]["heading"] for e in eps])
+    cells2, _ = A.grid_aggregate(text2, mem.slab, mem.perm, mem.cell_start)
+    mem.slab._gridmm_in_graph = False             # as if the forward had run without the tag (e.g. an older caller)
+    mem.reset()
+    with pytest.raises(RuntimeError, match="recycled"):
+        cells2.sum().backward()

@@ -1,0 +1,53 @@
+"""model.VLNBert: the reference's wrapper (map_nav_src/models/model.py:12-39) -- environment feature dropout on the
+'panorama' image features in train() only; other modes pass through untouched."""
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from gridmm_amd.model import VLNBert
+
+
+class _Probe(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.seen = []
+
+    def forward(self, mode, batch):
+        self.seen.append((mode, batch))
+        return mode
+
+
+def test_feature_dropout_only_in_train_mode_and_only_on_panorama():
+    torch.manual_seed(0)
+    m = VLNBert(SimpleNamespace(feat_dropout=0.4), vln_bert=_Probe())
+    x = torch.ones(4, 36, 768)
+    m.eval()
+    m("panorama", {"view_img_fts": x, "obj_img_fts": x.clone()})
+    assert torch.equal(m.vln_bert.seen[-1][1]["view_img_fts"], x)
+    m.train()
+    m("panorama", {"view_img_fts": x, "obj_img_fts": x.clone()})
+    v, o = m.vln_bert.seen[-1][1]["view_img_fts"], m.vln_bert.seen[-1][1]["obj_img_fts"]
+    for t in (v, o):
+        kept = t != 0
+        assert abs(float(kept.float().mean()) - 0.6) < 0.01                  # p = 0.4 dropped
+        assert torch.allclose(t[kept], torch.full_like(t[kept], 1 / 0.6))    # survivors scaled by 1 / (1 - p)
+    assert not torch.equal(v, o)                                             # independent masks
+    m("panorama", {"view_img_fts": x})                                       # no object features: key stays None
+    assert m.vln_bert.seen[-1][1]["obj_img_fts"] is None
+    m("navigation", {"txt_embeds": x})
+    assert torch.equal(m.vln_bert.seen[-1][1]["txt_embeds"], x)
+    assert m.vln_bert.seen[-1][1]["grid_fts"] is None                        # defaultdict(None), as the reference's
+    assert m("language", {"txt_ids": x}) == "language"
+
+
+def test_agent_wraps_a_bare_model():
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    cfg = default_config(num_l_layers=1, num_pano_layers=1, num_x_layers=1, intermediate_size=64, vocab_size=50)
+    core = GlocalTextPathNavCMT(cfg)
+    agent = GMapNavAgent(default_args(), env=None, vln_bert=core, device="cpu")
+    assert isinstance(agent.vln_bert, VLNBert) and agent.vln_bert.vln_bert is core
+    assert all(k.startswith("vln_bert.") for k in agent.vln_bert.state_dict())   # reference checkpoint key prefix
+    probe = _Probe()
+    assert GMapNavAgent(default_args(), env=None, vln_bert=probe, device="cpu").vln_bert is probe
