@@ -63,7 +63,9 @@ class PreTrainer:
         loss = losses.mean()
         if o.gradient_accumulation_steps > 1:
             loss = loss / o.gradient_accumulation_steps
-        loss.backward()
+        last = (self._micro + 1) % o.gradient_accumulation_steps == 0
+        self.reducer.expect(task if o.gradient_accumulation_steps == 1 else None, final=last)
+        loss.backward()                                        # the reducer's hooks launch the exchange from in here
         self._micro += 1
         norm = None
         if self._micro % o.gradient_accumulation_steps == 0:

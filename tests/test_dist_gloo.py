@@ -150,3 +150,61 @@ def test_task_sampler_all_ranks_train_the_same_task_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert outs[0] == outs[1] and len(set(outs[0])) > 1
+
+
+def _overlap_worker(rank, world, port, q):
+    """Several steps with the reducer constructed BEFORE backward (hooks fill the buckets and launch them during
+    backward once the task's used-set is known), alternating tasks, plus one step whose announced key is wrong."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gridmm_amd import dist as D
+    model = _Tiny()
+    red = D.GradientReducer(model.parameters(), bucket_mb=1e-4)          # several buckets
+    g = torch.Generator().manual_seed(11)
+    outs, early = [], []
+    plan = ["a", "b", "a", "b", "a", ("b", "a")]                          # last step: announces b, runs a
+    for step, task in enumerate(plan):
+        announce, run = task if isinstance(task, tuple) else (task, task)
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+        xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+        for p in model.parameters():
+            p.grad = None
+        red.expect(announce)
+        _tiny_loss(model, xs, ys, run).backward()
+        early.append(sum(b["work"] is not None for b in red.buckets))     # buckets launched before reduce()
+        red.reduce()
+        outs.append({k: (None if p.grad is None else p.grad.detach().numpy().copy()) for k, p in model.named_parameters()})
+    q.put((rank, outs, early))        # plain numpy: no shared-memory tensor hand-off at process exit
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_hooks_overlap_and_task_switching_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (o, e) for r, o, e in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _Tiny()
+    g = torch.Generator().manual_seed(11)
+    for step, task in enumerate(["a", "b", "a", "b", "a", "a"]):
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+        for p in model.parameters():
+            p.grad = None
+        (0.5 * (_tiny_loss(model, x[:4], y[:4], task) + _tiny_loss(model, x[4:], y[4:], task))).backward()
+        for k, p in model.named_parameters():
+            for r in range(world):
+                got = res[r][0][step][k]
+                if p.grad is None:
+                    assert got is None, (step, k)
+                else:
+                    assert got is not None and torch.allclose(torch.from_numpy(got), p.grad, atol=1e-6), (step, k)
+    for r in range(world):
+        early = res[r][1]
+        assert early[0] == 0 and early[1] == 0          # first sight of each task: nothing to predict from
+        assert early[2] > 0 and early[3] > 0 and early[4] > 0   # known used-sets: buckets go out during backward
