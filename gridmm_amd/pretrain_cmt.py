@@ -27,7 +27,9 @@ N_CELLS = 196
 
 
 class GlocalTextPathCMT(nn.Module):
-    """Parameter container of the pre-training backbone (vilmodel.py:640-666)."""
+    """The pre-training backbone (pretrain_src/model/vilmodel.py:640-856): parameters under the reference's names and
+    its two entry points forward(...) / forward_mlm(...) with the reference's positional signature; the arithmetic runs
+    on the HIP autograd path (vilmodel_train.py)."""
 
     def __init__(self, c):
         super().__init__()
@@ -45,6 +47,143 @@ class GlocalTextPathCMT(nn.Module):
         self.text_proj = nn.Linear(H, H)
         self.grid_proj = nn.Linear(H, H).to(torch.float16)         # vilmodel.py:664
         self.heads = c.num_attention_heads
+
+    # ---- shared encoder front (vilmodel.py:668-738) ------------------------------------------------------------
+    def _front(self, batch):
+        """-> dict(txt_embeds, txt_masks, map_embeds, map_masks, gmap_masks, vp_input, vp_masks)."""
+        b = self
+        dev = batch["txt_ids"].device
+        txt_masks = _seq_masks(batch["txt_lens"], batch["txt_ids"].shape[1])
+        txt_embeds = VT.forward_text(b, batch["txt_ids"].long(), txt_masks)
+        cells, cell_masks = VT.grid_cells(b, txt_embeds, batch["grid_fts"], batch["grid_map"],
+                                          batch["gridmap_pos_fts"], proj_weight=b.grid_proj.weight.float(),
+                                          proj_bias=b.grid_proj.bias.float())
+
+        # trajectory embedding: every step's panorama through the pano encoder (ImageEmbeddings.forward)
+        only_view_lens = batch["traj_vp_view_lens"].long()
+        obj_lens = batch["traj_vp_obj_lens"].long() if batch["traj_obj_img_fts"] is not None else None
+        traj, traj_masks = VT.forward_panorama(b, batch["traj_view_img_fts"], batch["traj_obj_img_fts"],
+                                               batch["traj_loc_fts"], batch["traj_nav_types"].long(), only_view_lens,
+                                               obj_lens)
+        step_lens = [int(x) for x in batch["traj_step_lens"]]
+        view_lens = only_view_lens if obj_lens is None else only_view_lens + obj_lens      # traj_vp_lens (:512-516)
+        Vmax, H = traj.shape[1], traj.shape[2]
+        B = len(step_lens)
+        offs = [0]
+        for t in step_lens:
+            offs.append(offs[-1] + t)
+
+        # global-map node features: masked means over panorama tokens, as one (B, G-1, T*Vmax) weight matrix built on
+        # the host from the vpid lists (GlobalMapEncoder._aggregate_gmap_features, vilmodel.py:569-604)
+        G = batch["gmap_step_ids"].shape[1]
+        Tmax = max(step_lens)
+        W = torch.zeros(B, G, Tmax * Vmax)
+        vl = view_lens.cpu().tolist()
+        for i in range(B):
+            visited, unvisited = {}, {}
+            for t in range(step_lens[i]):
+                n = vl[offs[i] + t]
+                visited[batch["traj_vpids"][i][t]] = (t, n)
+                for j, vp in enumerate(batch["traj_cand_vpids"][i][t]):
+                    if vp not in visited:
+                        unvisited.setdefault(vp, []).append((t, j))
+            for k, vp in enumerate(batch["gmap_vpids"][i][1:]):
+                if vp in visited:
+                    t, n = visited[vp]
+                    W[i, k + 1, t * Vmax:t * Vmax + n] = 1.0 / n
+                else:
+                    occ = unvisited[vp]
+                    for t, j in occ:
+                        W[i, k + 1, t * Vmax + j] += 1.0 / len(occ)
+        tok = torch.cat([F.pad(traj[offs[i]:offs[i + 1]].reshape(-1, H), (0, 0, 0, (Tmax - step_lens[i]) * Vmax))
+                         .unsqueeze(0) for i in range(B)], 0)
+        gmap_img = torch.bmm(W.to(dev), tok)                               # row 0 ([stop]) stays zero
+        ge, le = b.global_encoder, b.local_encoder
+        gmap_input = gmap_img + ge.gmap_step_embeddings(batch["gmap_step_ids"].long()) + ag.layer_norm(
+            ag.linear(batch["gmap_pos_fts"].float(), ge.gmap_pos_embeddings[0].weight, ge.gmap_pos_embeddings[0].bias),
+            ge.gmap_pos_embeddings[1])
+        gmap_masks = _seq_masks(batch["gmap_lens"], G)
+
+        # local branch input: last step's tokens behind a zero [stop] token (vp_input_embedding, vilmodel.py:545-560)
+        last = torch.tensor([offs[i + 1] - 1 for i in range(B)], device=dev)
+        vp_lens = view_lens[last] + 1
+        max_vp = int(vp_lens.max())
+        vp_img = torch.cat([traj.new_zeros(B, 1, H), traj[last]], 1)[:, :max_vp]
+        vp_input = vp_img + ag.layer_norm(
+            ag.linear(batch["vp_pos_fts"].float(), le.vp_pos_embeddings[0].weight, le.vp_pos_embeddings[0].bias),
+            le.vp_pos_embeddings[1])
+        vp_masks = _seq_masks(vp_lens, max_vp)
+
+        map_embeds = torch.cat([cells, gmap_input], 1)
+        map_masks = torch.cat([cell_masks, gmap_masks], 1)
+        map_embeds = VT.pre_ln_encoder(b, b.grid_encoder, map_embeds, map_masks)
+        for layer in b.grid_txt_encoder.x_layers:
+            xa = layer.visual_attention
+            kv = VT._cat_linear(txt_embeds, [xa.att.key, xa.att.value])
+            map_embeds = VT.x_layer(b, layer, kv, txt_masks, map_embeds, map_masks)
+        return dict(txt_embeds=txt_embeds, txt_masks=txt_masks, map_embeds=map_embeds, map_masks=map_masks,
+                    gmap_masks=gmap_masks, vp_input=vp_input, vp_masks=vp_masks, last=last, view_lens=view_lens,
+                    last_view_lens=only_view_lens[last], last_obj_lens=None if obj_lens is None else obj_lens[last])
+
+    def _encode(self, batch):
+        """GlocalTextPathCMT.forward (vilmodel.py:668-766) -> gmap_embeds, vp_embeds, gridmap_embeds, front."""
+        b = self
+        f = self._front(batch)
+        H = f["map_embeds"].shape[-1]
+        G = f["gmap_masks"].shape[1]
+        gridmap_embeds = f["map_embeds"][:, N_CELLS:]
+        kv_embeds = torch.cat([f["map_embeds"], f["txt_embeds"]], 1)
+        kv_masks = torch.cat([f["map_masks"], f["txt_masks"]], 1)
+        q = torch.cat([gridmap_embeds, f["vp_input"]], 1)
+        q_masks = torch.cat([f["gmap_masks"], f["vp_masks"]], 1)
+        xl = b.local_encoder.encoder.x_layers
+        kv_all = VT._cat_linear(kv_embeds, [m for l in xl for m in (l.visual_attention.att.key,
+                                                                    l.visual_attention.att.value)])
+        for i, layer in enumerate(xl):
+            q = VT.x_layer(b, layer, kv_all, kv_masks, q, q_masks, kv_col=2 * H * i)
+        return q[:, :G], q[:, G:], gridmap_embeds, f
+
+    _ARGS = ("txt_ids", "txt_lens", "traj_view_img_fts", "traj_obj_img_fts", "traj_loc_fts", "traj_nav_types",
+             "traj_step_lens", "traj_vp_view_lens", "traj_vp_obj_lens", "traj_vpids", "traj_cand_vpids", "gmap_lens",
+             "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists", "gmap_vpids", "vp_pos_fts", "grid_fts", "grid_map")
+
+    def forward(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
+                traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids, gmap_lens, gmap_step_ids,
+                gmap_pos_fts, gmap_pair_dists, gmap_vpids, vp_pos_fts, grid_fts, grid_map, target_patch_id=None,
+                gridmap_pos_fts=None, return_gmap_embeds=True):
+        """The reference's positional surface (pretrain_src/model/vilmodel.py:668-766): returns (gmap_embeds,
+        vp_embeds, map_embeds[:, n_cells:]) -- the last one is the [stop | nodes] part of the map sequence BEFORE the
+        local encoder (what sap's grid head reads).  gmap_pair_dists / target_patch_id are accepted and unused, as in
+        the reference."""
+        vals = (txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types, traj_step_lens,
+                traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids, gmap_lens, gmap_step_ids, gmap_pos_fts,
+                gmap_pair_dists, gmap_vpids, vp_pos_fts, grid_fts, grid_map)
+        batch = defaultdict(lambda: None, zip(self._ARGS, vals))
+        batch["gridmap_pos_fts"] = gridmap_pos_fts
+        gmap_embeds, vp_embeds, gridmap_embeds, _ = self._encode(batch)
+        return (gmap_embeds if return_gmap_embeds else None), vp_embeds, gridmap_embeds
+
+    def _mlm_text(self, f):
+        """vilmodel.py:830-856: the text attends to [gmap | vp] through forward_lang2visn of every local layer."""
+        vp_embeds = torch.cat([f["map_embeds"][:, N_CELLS:], f["vp_input"]], 1)
+        vp_masks = torch.cat([f["gmap_masks"], f["vp_masks"]], 1)
+        txt = f["txt_embeds"]
+        for layer in self.local_encoder.encoder.x_layers:
+            txt = VT.lang2visn_layer(self, layer, txt, f["txt_masks"], vp_embeds, vp_masks)
+        return txt
+
+    def forward_mlm(self, txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types,
+                    traj_step_lens, traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids, gmap_lens,
+                    gmap_step_ids, gmap_pos_fts, gmap_pair_dists, gmap_vpids, vp_pos_fts, grid_fts, grid_map,
+                    gridmap_pos_fts):
+        """pretrain_src/model/vilmodel.py:767-856: text embeddings (B, L, H) after the language-to-vision layers."""
+        vals = (txt_ids, txt_lens, traj_view_img_fts, traj_obj_img_fts, traj_loc_fts, traj_nav_types, traj_step_lens,
+                traj_vp_view_lens, traj_vp_obj_lens, traj_vpids, traj_cand_vpids, gmap_lens, gmap_step_ids, gmap_pos_fts,
+                gmap_pair_dists, gmap_vpids, vp_pos_fts, grid_fts, grid_map)
+        batch = defaultdict(lambda: None, zip(self._ARGS, vals))
+        batch["gridmap_pos_fts"] = gridmap_pos_fts
+        return self._mlm_text(self._front(batch))
+
 
 
 class BertPredictionHeadTransform(nn.Module):
@@ -131,100 +270,11 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def heads(self):
         return self.bert.heads
 
-    # ---- shared encoder front (vilmodel.py:668-738) ------------------------------------------------------------
     def _front(self, batch):
-        """-> dict(txt_embeds, txt_masks, map_embeds, map_masks, gmap_masks, vp_input, vp_masks)."""
-        b = self.bert
-        dev = batch["txt_ids"].device
-        txt_masks = _seq_masks(batch["txt_lens"], batch["txt_ids"].shape[1])
-        txt_embeds = VT.forward_text(b, batch["txt_ids"].long(), txt_masks)
-        cells, cell_masks = VT.grid_cells(b, txt_embeds, batch["grid_fts"], batch["grid_map"],
-                                          batch["gridmap_pos_fts"], proj_weight=b.grid_proj.weight.float(),
-                                          proj_bias=b.grid_proj.bias.float())
-
-        # trajectory embedding: every step's panorama through the pano encoder (ImageEmbeddings.forward)
-        only_view_lens = batch["traj_vp_view_lens"].long()
-        obj_lens = batch["traj_vp_obj_lens"].long() if batch["traj_obj_img_fts"] is not None else None
-        traj, traj_masks = VT.forward_panorama(b, batch["traj_view_img_fts"], batch["traj_obj_img_fts"],
-                                               batch["traj_loc_fts"], batch["traj_nav_types"].long(), only_view_lens,
-                                               obj_lens)
-        step_lens = [int(x) for x in batch["traj_step_lens"]]
-        view_lens = only_view_lens if obj_lens is None else only_view_lens + obj_lens      # traj_vp_lens (:512-516)
-        Vmax, H = traj.shape[1], traj.shape[2]
-        B = len(step_lens)
-        offs = [0]
-        for t in step_lens:
-            offs.append(offs[-1] + t)
-
-        # global-map node features: masked means over panorama tokens, as one (B, G-1, T*Vmax) weight matrix built on
-        # the host from the vpid lists (GlobalMapEncoder._aggregate_gmap_features, vilmodel.py:569-604)
-        G = batch["gmap_step_ids"].shape[1]
-        Tmax = max(step_lens)
-        W = torch.zeros(B, G, Tmax * Vmax)
-        vl = view_lens.cpu().tolist()
-        for i in range(B):
-            visited, unvisited = {}, {}
-            for t in range(step_lens[i]):
-                n = vl[offs[i] + t]
-                visited[batch["traj_vpids"][i][t]] = (t, n)
-                for j, vp in enumerate(batch["traj_cand_vpids"][i][t]):
-                    if vp not in visited:
-                        unvisited.setdefault(vp, []).append((t, j))
-            for k, vp in enumerate(batch["gmap_vpids"][i][1:]):
-                if vp in visited:
-                    t, n = visited[vp]
-                    W[i, k + 1, t * Vmax:t * Vmax + n] = 1.0 / n
-                else:
-                    occ = unvisited[vp]
-                    for t, j in occ:
-                        W[i, k + 1, t * Vmax + j] += 1.0 / len(occ)
-        tok = torch.cat([F.pad(traj[offs[i]:offs[i + 1]].reshape(-1, H), (0, 0, 0, (Tmax - step_lens[i]) * Vmax))
-                         .unsqueeze(0) for i in range(B)], 0)
-        gmap_img = torch.bmm(W.to(dev), tok)                               # row 0 ([stop]) stays zero
-        ge, le = b.global_encoder, b.local_encoder
-        gmap_input = gmap_img + ge.gmap_step_embeddings(batch["gmap_step_ids"].long()) + ag.layer_norm(
-            ag.linear(batch["gmap_pos_fts"].float(), ge.gmap_pos_embeddings[0].weight, ge.gmap_pos_embeddings[0].bias),
-            ge.gmap_pos_embeddings[1])
-        gmap_masks = _seq_masks(batch["gmap_lens"], G)
-
-        # local branch input: last step's tokens behind a zero [stop] token (vp_input_embedding, vilmodel.py:545-560)
-        last = torch.tensor([offs[i + 1] - 1 for i in range(B)], device=dev)
-        vp_lens = view_lens[last] + 1
-        max_vp = int(vp_lens.max())
-        vp_img = torch.cat([traj.new_zeros(B, 1, H), traj[last]], 1)[:, :max_vp]
-        vp_input = vp_img + ag.layer_norm(
-            ag.linear(batch["vp_pos_fts"].float(), le.vp_pos_embeddings[0].weight, le.vp_pos_embeddings[0].bias),
-            le.vp_pos_embeddings[1])
-        vp_masks = _seq_masks(vp_lens, max_vp)
-
-        map_embeds = torch.cat([cells, gmap_input], 1)
-        map_masks = torch.cat([cell_masks, gmap_masks], 1)
-        map_embeds = VT.pre_ln_encoder(b, b.grid_encoder, map_embeds, map_masks)
-        for layer in b.grid_txt_encoder.x_layers:
-            xa = layer.visual_attention
-            kv = VT._cat_linear(txt_embeds, [xa.att.key, xa.att.value])
-            map_embeds = VT.x_layer(b, layer, kv, txt_masks, map_embeds, map_masks)
-        return dict(txt_embeds=txt_embeds, txt_masks=txt_masks, map_embeds=map_embeds, map_masks=map_masks,
-                    gmap_masks=gmap_masks, vp_input=vp_input, vp_masks=vp_masks, last=last, view_lens=view_lens,
-                    last_view_lens=only_view_lens[last], last_obj_lens=None if obj_lens is None else obj_lens[last])
+        return self.bert._front(batch)
 
     def _bert_forward(self, batch):
-        """GlocalTextPathCMT.forward (vilmodel.py:668-766) -> gmap_embeds, vp_embeds, gridmap_embeds, front."""
-        b = self.bert
-        f = self._front(batch)
-        H = f["map_embeds"].shape[-1]
-        G = f["gmap_masks"].shape[1]
-        gridmap_embeds = f["map_embeds"][:, N_CELLS:]
-        kv_embeds = torch.cat([f["map_embeds"], f["txt_embeds"]], 1)
-        kv_masks = torch.cat([f["map_masks"], f["txt_masks"]], 1)
-        q = torch.cat([gridmap_embeds, f["vp_input"]], 1)
-        q_masks = torch.cat([f["gmap_masks"], f["vp_masks"]], 1)
-        xl = b.local_encoder.encoder.x_layers
-        kv_all = VT._cat_linear(kv_embeds, [m for l in xl for m in (l.visual_attention.att.key,
-                                                                    l.visual_attention.att.value)])
-        for i, layer in enumerate(xl):
-            q = VT.x_layer(b, layer, kv_all, kv_masks, q, q_masks, kv_col=2 * H * i)
-        return q[:, :G], q[:, G:], gridmap_embeds, f
+        return self.bert._encode(batch)
 
     # ---- tasks ---------------------------------------------------------------------------------------------------
     def forward(self, batch, task, compute_loss=True):
@@ -242,13 +292,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
     def forward_mlm(self, batch, compute_loss=True):
         """pretrain_cmt.py:131-153 + vilmodel.py:767-856: the text attends to [gmap | vp] through
         forward_lang2visn of every local cross-modal layer, then the tied-decoder MLM head on masked tokens."""
-        b = self.bert
-        f = self._front(batch)
-        vp_embeds = torch.cat([f["map_embeds"][:, N_CELLS:], f["vp_input"]], 1)
-        vp_masks = torch.cat([f["gmap_masks"], f["vp_masks"]], 1)
-        txt = f["txt_embeds"]
-        for layer in b.local_encoder.encoder.x_layers:
-            txt = VT.lang2visn_layer(b, layer, txt, f["txt_masks"], vp_embeds, vp_masks)
+        txt = self.bert._mlm_text(self._front(batch))
         labels = batch["txt_labels"]
         sel = labels != -1
         hidden = txt[sel]                                                     # only masked tokens

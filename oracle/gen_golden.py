@@ -530,13 +530,39 @@ def gen_optim():
     print("optim: lr", lrs, "norms", [round(x, 4) for x in norms])
 
 
+BACKBONE_ARGS = ("txt_ids", "txt_lens", "traj_view_img_fts", "traj_obj_img_fts", "traj_loc_fts", "traj_nav_types",
+                 "traj_step_lens", "traj_vp_view_lens", "traj_vp_obj_lens", "traj_vpids", "traj_cand_vpids", "gmap_lens",
+                 "gmap_step_ids", "gmap_pos_fts", "gmap_pair_dists", "gmap_vpids", "vp_pos_fts", "grid_fts", "grid_map")
+
+
+def gen_backbone():
+    """GlocalTextPathCMT.forward(...) / forward_mlm(...) of the imported reference (pretrain_src/model/vilmodel.py:
+    668-856) called POSITIONALLY on the sap / mlm batches of pretrain_reduced.npz -> pretrain_backbone_reduced.npz."""
+    import collections
+    torch.set_num_threads(1)
+    model = R.build_ref_pretrain_model(seed=9).eval()
+    out = {"versions": _versions(), "weight_seed": 9, "cfg": json.dumps(dict(R.PRETRAIN_REDUCED))}
+    with torch.no_grad():
+        b = collections.defaultdict(lambda: None, pretrain_batch("sap"))
+        g, v, m = model.bert(*[b[k] for k in BACKBONE_ARGS], gridmap_pos_fts=b["gridmap_pos_fts"])
+        out.update(sap_gmap_embeds=g.float().numpy(), sap_vp_embeds=v.float().numpy(), sap_gridmap_embeds=m.float().numpy())
+        g2, _, _ = model.bert(*[b[k] for k in BACKBONE_ARGS], gridmap_pos_fts=b["gridmap_pos_fts"], return_gmap_embeds=False)
+        assert g2 is None
+        b = collections.defaultdict(lambda: None, pretrain_batch("mlm"))
+        t = model.bert.forward_mlm(*[b[k] for k in BACKBONE_ARGS], b["gridmap_pos_fts"])
+        out.update(mlm_txt_embeds=t.float().numpy())
+    np.savez_compressed(os.path.join(OUT, "pretrain_backbone_reduced.npz"), **out)
+    print("backbone:", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo", "optim"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo", "optim", "backbone"]
     if "rollout" in which: gen_rollout()
     if "topo" in which: gen_topo_map()
     if "optim" in which: gen_optim()
+    if "backbone" in which: gen_backbone()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
     if "nav" in which: gen_nav_reduced(False)

@@ -82,3 +82,34 @@ def test_pretrain_losses_and_gradients_match_reference(task, with_obj):
     a, b = np.concatenate(got_all).astype(np.float64), np.concatenate(ref_all).astype(np.float64)
     cos = float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
     assert cos > 0.999, cos
+
+
+def test_backbone_positional_surface_matches_reference():
+    """GlocalTextPathCMT.forward(txt_ids, txt_lens, traj_view_img_fts, ..., grid_fts, grid_map, gridmap_pos_fts=...) and
+    forward_mlm(...) with the reference's positional signature (pretrain_src/model/vilmodel.py:668-673, 767-772) against
+    tests/golden/pretrain_backbone_reduced.npz (the imported reference called the same way)."""
+    import collections
+    import inspect
+    from gridmm_amd.pretrain_cmt import GlocalTextPathCMT
+    from gridmm_amd.synthetic import batch_to
+    want_sig = list(gen_golden.BACKBONE_ARGS) + ["target_patch_id", "gridmap_pos_fts", "return_gmap_embeds"]
+    assert list(inspect.signature(GlocalTextPathCMT.forward).parameters)[1:] == want_sig
+    assert list(inspect.signature(GlocalTextPathCMT.forward_mlm).parameters)[1:] == list(gen_golden.BACKBONE_ARGS) + ["gridmap_pos_fts"]
+    fx = load_golden("pretrain_backbone_reduced.npz")
+    model = _model(load_golden("pretrain_reduced.npz")).eval()
+    with torch.no_grad():
+        b = collections.defaultdict(lambda: None, batch_to(gen_golden.pretrain_batch("sap"), "cuda"))
+        args = [b[k] for k in gen_golden.BACKBONE_ARGS]
+        g, v, m = model.bert(*args, gridmap_pos_fts=b["gridmap_pos_fts"])
+        for got, key in ((g, "sap_gmap_embeds"), (v, "sap_vp_embeds"), (m, "sap_gridmap_embeds")):
+            want = torch.from_numpy(fx[key])
+            assert got.shape == want.shape
+            err = float((got.float().cpu() - want).abs().max())
+            assert err < 3e-3 * max(1.0, float(want.abs().max())), (key, err)      # reference: fp16 grid_proj + reduction
+        none_g, v2, _ = model.bert(*args, gridmap_pos_fts=b["gridmap_pos_fts"], return_gmap_embeds=False)
+        assert none_g is None and torch.equal(v2, v)
+        b = collections.defaultdict(lambda: None, batch_to(gen_golden.pretrain_batch("mlm"), "cuda"))
+        t = model.bert.forward_mlm(*[b[k] for k in gen_golden.BACKBONE_ARGS], b["gridmap_pos_fts"])
+        want = torch.from_numpy(fx["mlm_txt_embeds"])
+        assert t.shape == want.shape
+        assert float((t.float().cpu() - want).abs().max()) < 3e-3 * max(1.0, float(want.abs().max()))
