@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -44,6 +44,7 @@ SIGNATURES = {
                               _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "gridmm_attention_rows_cfg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
                                   _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "gridmm_tokens_to_slab": [_vp, _i, _i, _vp, _i64, _i, _i, _vp],
     "gridmm_ln_dot": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_fuse_logits": [_vp] * 13 + [_i, _i, _i, _vp],
     "gridmm_copy_rows": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp],

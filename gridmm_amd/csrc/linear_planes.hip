@@ -298,6 +298,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
           for (int e = 0; e < 4; ++e) {
             if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
             if (ACT == GRIDMM_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+            if (ACT == GRIDMM_ACT_QUICKGELU) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
           }
           if (R) {
             const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
@@ -348,6 +349,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
         for (int e = 0; e < 4; ++e) {
           if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
           if (ACT == GRIDMM_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+          if (ACT == GRIDMM_ACT_QUICKGELU) x[e] = x[e] / (1.0f + __expf(-1.702f * x[e]));
         }
         if (R) {
           const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
@@ -391,7 +393,8 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0>
+// QG: also instantiate the QuickGELU epilogue (only the configurations pick_cfg can choose carry it)
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
@@ -402,7 +405,11 @@ int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const 
                 Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
-  else GRIDMM_LP(GRIDMM_ACT_RELU);
+  else if (act == GRIDMM_ACT_RELU) GRIDMM_LP(GRIDMM_ACT_RELU);
+  else {
+    if constexpr (QG) GRIDMM_LP(GRIDMM_ACT_QUICKGELU);
+    else return GRIDMM_EINVAL;
+  }
 #undef GRIDMM_LP
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
@@ -495,7 +502,7 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
                                         const void* W_lo, int Kp, const float* bias, const float* residual,
                                         int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N,
                                         int K, int act, int cfg, gridmm_stream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || act < 0 || act > 2)
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || act < 0 || act > 3)
     return GRIDMM_EINVAL;
   if (K % 64 && (cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 13 || cfg == 108 || cfg == 208)) return GRIDMM_EINVAL;
   if ((C && ldc % 4) || (residual && ldr % 4) || (C_hi && (ldp % 4 || !C_lo)) || (!C && !C_hi)) return GRIDMM_EINVAL;
@@ -507,9 +514,9 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
 #define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st
   switch (cfg) {
     case 1: return launch<128, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
-    case 2: return launch<128, 128, 64, 32, 2, 64>(GRIDMM_ARGS);
+    case 2: return launch<128, 128, 64, 32, 2, 64, 0, 0, 0, true>(GRIDMM_ARGS);
     case 3: return launch<256, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
-    case 4: return launch<64, 64, 32, 32, 2, 32>(GRIDMM_ARGS);
+    case 4: return launch<64, 64, 32, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
     case 5: return launch<128, 128, 64, 64, 2, 64>(GRIDMM_ARGS);
     case 6: return launch<128, 64, 64, 32, 2, 32>(GRIDMM_ARGS);
     case 7: return launch<256, 256, 128, 64, 2, 32>(GRIDMM_ARGS);
@@ -520,8 +527,8 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
     case 12: return launch<128, 128, 64, 32, 3, 32>(GRIDMM_ARGS);
     case 13: return launch<128, 64, 32, 32, 3, 64>(GRIDMM_ARGS);
     case 14: return launch<128, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
-    case 15: return launch<128, 128, 32, 32, 2, 32>(GRIDMM_ARGS);
-    case 16: return launch<256, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
+    case 15: return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
+    case 16: return launch<256, 128, 64, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
     case 17: return launch<64, 64, 32, 32, 4, 32>(GRIDMM_ARGS);
     case 18: return launch<64, 64, 32, 32, 3, 32>(GRIDMM_ARGS);
     case 19: return launch<64, 32, 32, 16, 4, 32>(GRIDMM_ARGS);
@@ -536,11 +543,11 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
     case 33: return launch<128, 128, 64, 32, 2, 32, 0, 1>(GRIDMM_ARGS);
     case 34: return launch<256, 256, 64, 64, 2, 32, 0, 1>(GRIDMM_ARGS);    // 16 waves: 2 + 2 per SIMD
     case 35: return launch<256, 128, 64, 32, 2, 32, 0, 1>(GRIDMM_ARGS);
-    case 36: return launch<256, 256, 64, 64, 2, 32>(GRIDMM_ARGS);          // 16 waves, lockstep (control)
+    case 36: return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);   // 16 waves, lockstep (control)
     case 40: return launch<256, 256, 64, 64, 2, 32, 0, 0, 1>(GRIDMM_ARGS);  // TR = direct epilogue from C^T accumulators
     case 41: return launch<256, 256, 128, 64, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
     case 42: return launch<128, 128, 32, 32, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
-    case 43: return launch<64, 64, 32, 32, 2, 64, 0, 0, 1>(GRIDMM_ARGS);
+    case 43: return launch<64, 64, 32, 32, 2, 64, 0, 0, 1, true>(GRIDMM_ARGS);
     case 44: return launch<256, 128, 64, 32, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
     // ablations (tools/bench_gemm.py): 1xx = no MFMA (DMA + LDS reads only), 2xx = no DMA after the prologue
     case 108: return launch<64, 64, 32, 32, 2, 64, 1>(GRIDMM_ARGS);

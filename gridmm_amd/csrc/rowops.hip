@@ -348,3 +348,33 @@ extern "C" int gridmm_fuse_logits(const float* g_raw, const float* l_raw, const 
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
+
+// ---- patch tokens of an image encoder -> the grid memory's fp16 slab -------------------------------------------------
+// X: (B * n_views, T, D) fp32 token rows of the vision tower (token 0 = class token, dropped).  Episode b's slot is
+// slab + b * slab_bs: n_views * (T-1) rows of D fp16, view-major -- exactly the order getGlobalMap appends them in
+// (VLN_CE/vlnce_baselines/models/Policy_ViewSelection_GridMap.py:343-357: batch_grid_fts.view(B,12,50,768), [1:] per view).
+namespace {
+__global__ __launch_bounds__(256) void tokens_to_slab_kernel(const float* __restrict__ X, int T, int D,
+                                                             _Float16* __restrict__ slab, int64_t slab_bs, int n_views) {
+  const int b = blockIdx.y;
+  const int rows = n_views * (T - 1), d4 = D / 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * d4; i += gridDim.x * blockDim.x) {
+    const int r = i / d4, c = (i - r * d4) * 4;
+    const int v = r / (T - 1), t = r - v * (T - 1) + 1;
+    const float4 x = *reinterpret_cast<const float4*>(X + ((size_t)(b * n_views + v) * T + t) * D + c);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 h = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
+    *reinterpret_cast<h4*>(slab + b * slab_bs + (size_t)r * D + c) = h;
+  }
+}
+}  // namespace
+
+extern "C" int gridmm_tokens_to_slab(const float* X, int T, int D, void* slab, int64_t slab_bs, int B, int n_views,
+                                     gridmm_stream_t stream) {
+  if (!X || !slab || B <= 0 || n_views <= 0 || T < 2 || D <= 0 || D % 4 || slab_bs % 4) return GRIDMM_EINVAL;
+  const int work = n_views * (T - 1) * (D / 4);
+  GRIDMM_LAUNCH(tokens_to_slab_kernel, dim3((work + 255) / 256 > 256 ? 256 : (work + 255) / 256, B), dim3(256), 0,
+                as_stream(stream), X, T, D, (_Float16*)slab, slab_bs, n_views);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_QUICKGELU = 0, 1, 2, 3
 N_CELLS = 196
 
 
@@ -334,6 +334,19 @@ def attention_rows(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_pl
         vh.stride(0), vh.stride(1), _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * HD, HD,
         _p(hi), _p(lo), Sq * HD, HD, B, heads, Sq, Sk, float(scale), int(cfg), _stream()), "gridmm_attention_rows"))
     return Act(out, hi, lo)
+
+
+def tokens_to_slab(tokens, slot, n_views):
+    """tokens (B * n_views, T, D) fp32 (T = 1 class token + patches) -> slot (B, n_views * (T-1), D) fp16 view of the grid
+    memory's slab (GridMemoryBatch.next_slot()): the patch tokens land where fill_gridmap expects the new observation."""
+    lib = _lib.load()
+    N, T, D = tokens.shape
+    B = N // n_views
+    assert N == B * n_views and tokens.dtype == torch.float32 and tokens.is_contiguous()
+    assert slot.dtype == torch.float16 and slot.shape == (B, n_views * (T - 1), D) and slot.stride(1) == D and slot.stride(2) == 1
+    _lib.check(lib.gridmm_tokens_to_slab(_p(tokens), T, D, _p(slot), slot.stride(0), B, n_views, _stream()),
+               "gridmm_tokens_to_slab")
+    return slot
 
 
 def ln_dot(x, gamma, beta, eps, w, b0, out=None):

@@ -7,7 +7,10 @@ Reference: /root/reference/VLN_CE/vlnce_baselines/models/gridmap/vilmodel.py
       then  fused = global_sap_head(gmap)*w + local_sap_head(vp)*(1-w),  both truncated to max(candidate_lengths) and
       masked by vp_nav_masks -- no visited masks, no vpid-keyed fusion, grid_sap_head unused; returns ONLY fused_logits.
 The reference module also owns a CLIP-B/32 and a ViT-B/16 tower (`clip.*`, `visual_encoder.*`, :627-631) that feed the
-grid / the views on the fly: they are not part of this path, their checkpoint keys are ignored on load.
+grid / the views on the fly.  `clip` -- the producer of the grid memory -- is built here on the HIP
+kernels when the config asks for it (`with_clip_tower=True`; clip_encoder.CLIP, same state_dict keys) and writes its
+patch tokens straight into the memory's next slot (`encode_observation`); `visual_encoder` (the timm ViT-B/16 that makes
+the 768-d VIEW features) is outside §8 and its checkpoint keys are ignored on load.
 The grid memory for this variant is GridMemoryBatch(geom=synthetic.VLNCE_R2R / VLNCE_RXR).
 """
 import torch
@@ -20,10 +23,21 @@ class GlocalTextPathNavCMT(_DiscreteNavCMT):
     def __init__(self, config=None):
         super().__init__(config)
         self.global_encoder.sprel_linear = None            # gridmap/vilmodel.py:575
+        if getattr(self.config, "with_clip_tower", False):
+            from .clip_encoder import CLIP
+            self.clip = CLIP(input_resolution=224, patch_size=32, width=768, layers=12, heads=12)   # :627-629
 
     def load_state_dict(self, sd, strict=True):
-        sd = {k: v for k, v in sd.items() if not k.startswith(("clip.", "visual_encoder."))}
+        drop = ("visual_encoder.",) if hasattr(self, "clip") else ("clip.", "visual_encoder.")
+        sd = {k: v for k, v in sd.items() if not k.startswith(drop)}
         return super().load_state_dict(sd, strict=strict)
+
+    @torch.no_grad()
+    def encode_observation(self, grid_images, grid_memory):
+        """Policy_ViewSelection_GridMap.py:335-357 on the device: the (B * 12, 3, 224, 224) normalised view images go
+        through the CLIP tower and their 49 patch tokens per view are written, fp16, into the memory's next slot --
+        what `grid_memory.step(depth, feats=None, ...)` then projects and bins.  Returns the (B * 12, 50, 768) tokens."""
+        return self.clip.encode_into(grid_images, grid_memory.next_slot(), n_views=grid_memory.geom.n_views)
 
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts,
                                     gmap_masks, vp_img_embeds, vp_pos_fts, vp_masks, vp_nav_masks, grid_fts,

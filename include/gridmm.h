@@ -153,6 +153,7 @@ int gridmm_split_weight(const float* W, void* hi, void* lo, int N, int K, int Kp
 #define GRIDMM_ACT_NONE 0
 #define GRIDMM_ACT_GELU 1  /* exact erf gelu (vilmodel.py:47-53, transformer.py:472) */
 #define GRIDMM_ACT_RELU 2
+#define GRIDMM_ACT_QUICKGELU 3  /* x * sigmoid(1.702 x): CLIP's MLP (VLN_CE/.../gridmap/clip.py:26-28); gridmm_linear_planes only */
 
 /* C[M][N] = act(A[M][K] * W^T + bias) (+ residual), fp32 in / fp32 out, the contraction on
  * MFMA bf16 16x16x32 tiles as a 3-term split (a_hi w_hi + a_lo w_hi + a_hi w_lo, fp32
@@ -230,6 +231,13 @@ int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int64_t q_bs, 
                               int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs,
                               int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq,
                               int Sk, float scale, int cfg, gridmm_stream_t stream);
+
+/* Patch tokens of a vision tower -> grid-memory slab: X (B * n_views, T, D) fp32 token rows, token 0 (class token)
+ * dropped; episode b's slot `slab + b * slab_bs` receives n_views * (T-1) rows of D fp16, view-major.  The device-side
+ * replacement of the GPU -> CPU -> GPU round trip at VLN_CE/vlnce_baselines/models/Policy_ViewSelection_GridMap.py:
+ * 340-357, 496 (CLIP tokens to numpy, per-episode python lists, torch.tensor(...).cuda() again). */
+int gridmm_tokens_to_slab(const float* X, int T, int D, void* slab, int64_t slab_bs, int B, int n_views,
+                          gridmm_stream_t stream);
 
 /* out[m] = <LayerNorm(X[m]) * gamma + beta, w> + b0      (tail of ClsPrediction,
  * vilmodel.py:663-674: Linear -> ReLU -> LN -> Linear(H,1)). */

@@ -555,14 +555,64 @@ def gen_backbone():
     print("backbone:", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
 
+CLIP_CASES = {"reduced": dict(width=128, layers=2, heads=2, n_images=6, seed=21),
+              "full": dict(width=768, layers=12, heads=12, n_images=2, seed=22)}
+
+
+def clip_det_state(model, seed):
+    """Deterministic CLIP weights keyed by state_dict name: LayerNorm gains near 1, everything else small."""
+    sd = {}
+    for k, v in model.state_dict().items():
+        x = R.det_tensor("clip." + k, tuple(v.shape), seed)
+        if ".ln_" in k or k.startswith("visual.ln_"):
+            rs = np.random.RandomState((zlib_crc(k) ^ seed) & 0x7FFFFFFF)
+            x = torch.from_numpy((1.0 + 0.05 * rs.standard_normal(tuple(v.shape))).astype(np.float32)) if k.endswith("weight") \
+                else torch.from_numpy((0.02 * rs.standard_normal(tuple(v.shape))).astype(np.float32))
+        sd[k] = x.to(v.dtype)
+    return sd
+
+
+def zlib_crc(name):
+    import zlib
+    return zlib.crc32(name.encode())
+
+
+def clip_images(case):
+    c = CLIP_CASES[case]
+    return torch.from_numpy(np.random.RandomState(c["seed"]).standard_normal((c["n_images"], 3, 224, 224)).astype(np.float32))
+
+
+def gen_clip():
+    """VLN_CE/vlnce_baselines/models/gridmap/clip.py: CLIP(224, 32, width, layers, heads)(images) -> (N, 50, width) tokens
+    for a reduced tower and for the full ViT-B/32 shape -> tests/golden/clip_tokens.npz (pins gridmm_amd/clip_encoder.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_gridmap_clip", os.path.join(R.REF_ROOT, "VLN_CE", "vlnce_baselines", "models", "gridmap", "clip.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                              # the reference's module
+    out = {"versions": _versions(), "cases": json.dumps(CLIP_CASES)}
+    torch.set_num_threads(8)
+    for case, c in CLIP_CASES.items():
+        torch.manual_seed(0)
+        model = mod.CLIP(input_resolution=224, patch_size=32, width=c["width"], layers=c["layers"], heads=c["heads"]).eval()
+        model.load_state_dict(clip_det_state(model, c["seed"]))
+        with torch.no_grad():
+            tok = model(clip_images(case))
+        out[case + "_tokens"] = tok.numpy()
+        out[case + "_keys"] = json.dumps(list(model.state_dict().keys()))
+        print("clip", case, tuple(tok.shape), "abs max %.3f" % float(tok.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "clip_tokens.npz"), **out)
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo", "optim", "backbone"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo", "optim", "backbone", "clip"]
     if "rollout" in which: gen_rollout()
     if "topo" in which: gen_topo_map()
     if "optim" in which: gen_optim()
     if "backbone" in which: gen_backbone()
+    if "clip" in which: gen_clip()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
     if "nav" in which: gen_nav_reduced(False)
