@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-depth-legs", action="store_true", help="skip the extra t = 5 / t = 15 timings")
+    ap.add_argument("--no-producer-leg", action="store_true", help="skip the VLN-CE step with the CLIP tower in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -183,6 +184,58 @@ def extra_depth_leg(args, dev, dist, mem_steps, steps):
     del model, batch, mem, step, eager_step
     torch.cuda.empty_cache()
     return dt / steps
+
+
+def producer_leg(args, dev, steps=5):
+    """Config 5's shape with the PRODUCER in the timed region: per step the CLIP ViT-B/32 tower encodes the
+    12 view images of every episode (B x 12 x 3 x 224 x 224, already normalised and resident), writes the patch tokens
+    into the grid memory's next slot, then fill_gridmap + forward('navigation') run as usual -- VLN-CE geometry
+    (12 views x 49 patches x 768-D, habitat depth), full-size model + full-size tower, random init, t = 1."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.clip_encoder import CLIP
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    geom, B = S.VLNCE_R2R, args.batch
+    torch.manual_seed(1)
+    model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim)).eval().to(dev)
+    clip = CLIP().eval().to(dev)
+    rs = np.random.RandomState(5)
+    host_batch = S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, min_len=30)
+    batch = S.batch_to(host_batch, dev)
+    mem = GridMemoryBatch(B, geom, max_steps=1, device=dev)
+    eps = [S.make_observations(rs, geom, 1, with_feats=False)[0] for _ in range(B)]
+    depth = torch.from_numpy(np.stack([e["depth"].reshape(-1) for e in eps]).astype(np.float32)).to(dev)
+    poses, heads = [(e["x"], e["y"]) for e in eps], [e["heading"] for e in eps]
+    images = torch.randn(B * geom.n_views, 3, 224, 224, device=dev)
+    batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step():
+        mem.reset()
+        ev[0].record()
+        clip.encode_into(images, mem.next_slot(), n_views=geom.n_views)
+        ev[1].record()
+        mem.step(depth, None, poses, heads)
+        out = model("navigation", dict(batch, fusion_maps=model.fusion_maps(
+            dict(batch, gmap_visited_masks=host_batch["gmap_visited_masks"].numpy()), dev)))
+        ev[2].record()
+        return out
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enc = nav = 0.0
+    for _ in range(steps):
+        step()
+        torch.cuda.synchronize()
+        enc += ev[0].elapsed_time(ev[1])
+        nav += ev[1].elapsed_time(ev[2])
+    dt = (time.perf_counter() - t0) / steps
+    flops = B * geom.n_views * (2.0 * 49 * 3072 * 768 + 12 * 50 * 2.0 * 768 * (2304 + 768 + 3072 + 3072) + 12 * 4.0 * 50 * 50 * 768)
+    return {"value": B / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt, "encoder_ms": enc / steps, "fill_nav_ms": nav / steps,
+            "encoder_tflops_algorithmic": flops / (enc / steps * 1e-3) / 1e12, "launch": "eager",
+            "workload": "B=%d episodes x 12 views: CLIP ViT-B/32 (224 px) -> slab, fill_gridmap (VLN-CE geometry) + "
+                        "forward('navigation'), t=1, full-size model and tower, random init" % B}
 
 
 def roofline_leg(step, args, geom, L=80):
@@ -344,6 +397,8 @@ def main():
             sec = extra_depth_leg(args, dev, dist, t, max(5, args.steps // 2))
             out["t%d" % t] = {"value": n_gpus * args.batch / sec, "unit": "steps/s", "ms_per_step": 1e3 * sec,
                               "mem_steps": t, "points": geom.pts_per_obs * t}
+    if rank == 0 and n_gpus == 1 and not args.no_producer_leg:
+        out["vlnce_with_producer"] = producer_leg(args, dev)
     if rank == 0 and not args.no_roofline:
         rl = roofline_leg(eager_step, args, geom)   # per-launch HIP events need eager launches
         dom = rl["dominant"]
