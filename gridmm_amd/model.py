@@ -22,6 +22,7 @@ class VLNBert(nn.Module):
         self.args = args
         self.vln_bert = vln_bert if vln_bert is not None else GlocalTextPathNavCMT(config or default_config())
         self.feat_dropout = float(getattr(args, "feat_dropout", 0.0))
+        self.train(self.vln_bert.training)          # wrapping an eval() model must not switch the feature dropout on
 
     def drop_env(self, x):
         return F.dropout(x, self.feat_dropout, self.training) if (self.training and self.feat_dropout > 0) else x

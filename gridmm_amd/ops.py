@@ -365,9 +365,9 @@ def ln_dot(x, gamma, beta, eps, w, b0, out=None):
 def copy_planes(src, dst, dst_row0=0):
     """dst.hi/lo[:, dst_row0:dst_row0+rows] = src.hi/lo for Act pairs; one launch when both pairs are the halves of one
     allocation (what _planes_like hands out), else two."""
-    def paired(a):
-        return (a.hi.shape == a.lo.shape and a.hi.stride() == a.lo.stride() and a.hi.is_contiguous()
-                and a.lo.data_ptr() - a.hi.data_ptr() == a.hi.numel() * a.hi.element_size())
+    def paired(a):   # lo sits exactly B batch strides behind hi (also true for row slices of such a pair)
+        return (a.hi.shape == a.lo.shape and a.hi.stride() == a.lo.stride() and a.hi.stride(2) == 1
+                and a.lo.data_ptr() - a.hi.data_ptr() == a.hi.shape[0] * a.hi.stride(0) * a.hi.element_size())
     if paired(src) and paired(dst):
         B, rows, H = src.hi.shape
         s2 = torch.as_strided(src.hi, (2 * B, rows, H), src.hi.stride())

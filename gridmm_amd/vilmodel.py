@@ -504,6 +504,7 @@ class GlocalTextPathNavCMT(nn.Module):
         for i, layer in enumerate(xl):
             qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks, kv=(kv_all, 2 * H * i))
         q = qa.f32
+        self._last_acts = (qa, mp)            # bf16 planes of the same tensors: the heads read them without re-splitting
         return q[:, :G], q[:, G:], map_embeds
 
     @torch.no_grad()
@@ -513,9 +514,24 @@ class GlocalTextPathNavCMT(nn.Module):
         fuse_raw = None
         if self.sap_fuse_linear is not None:
             fuse_raw = self._cls(self.sap_fuse_linear, "fuse", torch.cat([gmap_embeds[:, 0], vp_embeds[:, 0]], 1))
-        g_raw = self._cls(self.global_sap_head, "ghead", gmap_embeds)
-        grid_raw = self._cls(self.grid_sap_head, "gridhead", map_embeds[:, N_CELLS:])
-        l_raw = self._cls(self.local_sap_head, "lhead", vp_embeds)
+        acts, self._last_acts = getattr(self, "_last_acts", None), None
+        if acts is not None and acts[0].hi is not None and acts[0].f32.data_ptr() == gmap_embeds.data_ptr():
+            # global + local heads as ONE GEMM over all G + V query rows (N = 2H, planes straight from the last
+            # LayerNorm), then LayerNorm . w per head on its half of the columns; rows a head does not own are dropped
+            qa, mp = acts
+            H = gmap_embeds.shape[-1]
+            gh, lh = self.global_sap_head.net, self.local_sap_head.net
+            h = ops.linear(qa, self._pack("ghead+lhead", [gh[0].weight, lh[0].weight], [gh[0].bias, lh[0].bias]),
+                           act=ops.ACT_RELU).f32
+            g_raw = ops.ln_dot(h[..., :H], gh[2].weight, gh[2].bias, gh[2].eps, gh[3].weight.view(-1), gh[3].bias)[:, :G].contiguous()
+            l_raw = ops.ln_dot(h[..., H:], lh[2].weight, lh[2].bias, lh[2].eps, lh[3].weight.view(-1), lh[3].bias)[:, G:].contiguous()
+            gp = ops.Act(None, *ops._planes_like((gmap_embeds.shape[0], G, H), dev))
+            ops.copy_planes(ops.Act(None, mp.hi[:, N_CELLS:], mp.lo[:, N_CELLS:]), gp, 0)
+            grid_raw = self._cls(self.grid_sap_head, "gridhead", gp)
+        else:
+            g_raw = self._cls(self.global_sap_head, "ghead", gmap_embeds)
+            grid_raw = self._cls(self.grid_sap_head, "gridhead", map_embeds[:, N_CELLS:])
+            l_raw = self._cls(self.local_sap_head, "lhead", vp_embeds)
         if fusion_maps is None:   # host-built from the python vpid lists; pass precomputed device tensors to avoid
             cand_of_node, cand_visited = self._fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V)
             fusion_maps = (cand_of_node.to(dev), cand_visited.to(dev))   # the H2D (needed under graph capture)

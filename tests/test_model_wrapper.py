@@ -48,6 +48,8 @@ def test_agent_wraps_a_bare_model():
     core = GlocalTextPathNavCMT(cfg)
     agent = GMapNavAgent(default_args(), env=None, vln_bert=core, device="cpu")
     assert isinstance(agent.vln_bert, VLNBert) and agent.vln_bert.vln_bert is core
+    assert agent.vln_bert.training == core.training
+    assert not GMapNavAgent(default_args(), env=None, vln_bert=GlocalTextPathNavCMT(cfg).eval(), device="cpu").vln_bert.training
     assert all(k.startswith("vln_bert.") for k in agent.vln_bert.state_dict())   # reference checkpoint key prefix
     probe = _Probe()
     assert GMapNavAgent(default_args(), env=None, vln_bert=probe, device="cpu").vln_bert is probe

@@ -5,7 +5,7 @@ steps = sys.argv[2] if len(sys.argv) > 2 else '1'
 steps = float(sum('grid_aggregate' in r['Kernel_Name'] for r in rows)) if steps == 'auto' else float(steps)   # auto: 1 aggregate launch per step
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 def short(n):
-    m = re.search(r'(linear_planes_kernel<[^>]*>|linear_kernel<[^>]*>|attention_planes_kernel<\d>|attention_kernel|transpose_v_kernel|grid_aggregate_pipe_kernel|grid_aggregate_kernel|layernorm_kernel<\d>|ln_dot_kernel|copy_rows_kernel|cells_compact_kernel|grid_bin_sort_kernel|grid_project_kernel|split_rows_kernel|fuse_logits|text_fragments|build_chunks|split_weight)', n)
+    m = re.search(r'(linear_planes_kernel<[^>]*>|linear_kernel<[^>]*>|attention_rows_kernel<[^>]*>|attention_planes_kernel<\d>|attention_kernel|tokens_to_slab_kernel|transpose_v_kernel|grid_aggregate_pipe_kernel|grid_aggregate_kernel|layernorm_kernel<\d>|ln_dot_kernel|copy_rows_kernel|cells_compact_kernel|grid_bin_sort_kernel|grid_project_kernel|split_rows_kernel|fuse_logits|text_fragments|build_chunks|split_weight)', n)
     return m.group(1) if m else n[:48]
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
