@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-depth-legs", action="store_true", help="skip the extra t = 5 / t = 15 timings")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the pre-training step timing (train_samples_per_s)")
     ap.add_argument("--no-producer-leg", action="store_true", help="skip the VLN-CE step with the CLIP tower in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -238,6 +239,37 @@ def producer_leg(args, dev, steps=5):
                         "forward('navigation'), t=1, full-size model and tower, random init" % B}
 
 
+def train_leg(args, dev, steps=6):
+    """Secondary: one pre-training step (config 3's per-GPU shape) -- forward + backward + gradient clip + fused AdamW
+    of the full-size GlocalTextPathCMTPreTraining, B = 32, native grid memory of 3-5 observations, tasks cycling
+    mlm / mrc / sap as the task-mixed loop does (pretrain_src/train_r2r.py:231-303).  Eager launches."""
+    from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.synthetic import batch_to, make_pretrain_batch
+    from gridmm_amd.vilmodel import default_config
+    cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=["mlm", "mrc", "sap"], image_prob_size=1000, obj_prob_size=0)
+    torch.manual_seed(0)
+    model = GlocalTextPathCMTPreTraining(cfg).to(dev)
+    tr = PreTrainer(model, default_opts(warmup_steps=100))
+    tasks = ("mlm", "mrc", "sap")
+    batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i), args.batch, t, max_steps=5, L=80, vocab=30000,
+                                               image_prob_size=1000, n_pts=(588 * 3, 588 * 5)), dev)
+               for i, t in enumerate(tasks)}
+    for t in tasks:
+        tr.train_step(batches[t], t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.train_step(batches[tasks[i % 3]], tasks[i % 3])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del tr, model, batches
+    torch.cuda.empty_cache()
+    return {"train_samples_per_s": args.batch / dt, "ms_per_step": 1e3 * dt, "batch": args.batch,
+            "workload": "pre-training step (mlm/mrc/sap cycling), full-size model, native 12x49x768 grid memory t=3..5, "
+                        "fwd + bwd + clip + fused AdamW, eager launches"}
+
+
 def roofline_leg(step, args, geom, L=80):
     """Per-kernel HIP-event timing over a few instrumented steps (events on the launch stream)."""
     from gridmm_amd import ops
@@ -397,6 +429,8 @@ def main():
             sec = extra_depth_leg(args, dev, dist, t, max(5, args.steps // 2))
             out["t%d" % t] = {"value": n_gpus * args.batch / sec, "unit": "steps/s", "ms_per_step": 1e3 * sec,
                               "mem_steps": t, "points": geom.pts_per_obs * t}
+    if rank == 0 and n_gpus == 1 and not args.no_train_leg:
+        out["train"] = train_leg(args, dev)
     if rank == 0 and n_gpus == 1 and not args.no_producer_leg:
         out["vlnce_with_producer"] = producer_leg(args, dev)
     if rank == 0 and not args.no_roofline:

@@ -118,7 +118,7 @@ def test_bench_two_ranks_on_one_gpu_prints_n_gpus_2():
     env = dict(os.environ, GRIDMM_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--batch", "8", "--no-roofline", "--no-depth-legs", "--no-cpu-baseline", "--no-torch-gpu-baseline"]
+           "--batch", "8", "--no-roofline", "--no-depth-legs", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-train-leg", "--no-producer-leg"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
