@@ -298,7 +298,9 @@ def roofline_leg(step, args, geom, L=80):
                                  "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": byts}
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_traffic.sh:
     # FETCH_SIZE and WRITE_SIZE in separate runs, (2*FETCH + WRITE) * 1024 with the gfx950 read-side correction)
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_hbm_traffic.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic.json")))
+    tpath = cands[-1] if cands else ""               # the newest round's PMC passes
     if os.path.exists(tpath):
         t = json.load(open(tpath))
         c = t.get("config", {})
@@ -306,7 +308,7 @@ def roofline_leg(step, args, geom, L=80):
             for k in ("linear", "grid_aggregate"):
                 if k in out and k in t["kernels"]:
                     out[k]["traffic"] = t["kernels"][k]["hbm_bytes_per_launch"]
-                    out[k]["traffic_source"] = "profiles/r1_hbm_traffic.json"
+                    out[k]["traffic_source"] = "profiles/" + os.path.basename(tpath)
     dom = max(("linear", "grid_aggregate", "attention"), key=lambda k: summ.get(k, {"ms": 0})["ms"])
     out["dominant"] = dom
     return out

@@ -15,7 +15,7 @@ import re
 import sys
 
 CLASSES = [("linear", r"linear_planes_kernel|linear_kernel"), ("grid_aggregate", r"grid_aggregate_kernel|grid_aggregate_pipe_kernel"),
-           ("attention", r"attention_planes_kernel|attention_kernel"), ("transpose_v", r"transpose_v_kernel"),
+           ("attention", r"attention_rows_kernel|attention_planes_kernel|attention_kernel"), ("transpose_v", r"transpose_v_kernel"),
            ("layernorm", r"layernorm_kernel"), ("split_rows", r"split_rows_kernel"),
            ("grid_project", r"grid_project_kernel"), ("grid_bin", r"grid_bin_sort_kernel")]
 
