@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -44,6 +44,9 @@ SIGNATURES = {
                               _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "gridmm_attention_rows_cfg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
                                   _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "gridmm_xattn_layer_workspace": [_i, _i, _i, _i],
+    "gridmm_xattn_layer_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp,
+                               ctypes.c_size_t, _i, _i, _i, _i, _vp],
     "gridmm_tokens_to_slab": [_vp, _i, _i, _vp, _i64, _i, _i, _vp],
     "gridmm_ln_dot": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_fuse_logits": [_vp] * 13 + [_i, _i, _i, _vp],
@@ -87,6 +90,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
     v = lib.gridmm_abi_version()
     if v != ABI_VERSION:
         raise GridmmLibraryError("libgridmm_hip.so ABI %d != expected %d (stale build?)" % (v, ABI_VERSION))

@@ -336,6 +336,62 @@ def attention_rows(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_pl
     return Act(out, hi, lo)
 
 
+class _CLinear(ctypes.Structure):
+    _fields_ = [("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("N", ctypes.c_int),
+                ("K", ctypes.c_int), ("Kp", ctypes.c_int)]
+
+
+class _CLn(ctypes.Structure):
+    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float)]
+
+
+class _CXLayer(ctypes.Structure):
+    _fields_ = [(n, _CLinear) for n in ("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o")] + \
+               [(n, _CLn) for n in ("x_ln", "s_ln", "f_ln")]
+
+
+class XLayerWeights:
+    """gridmm_xlayer_t of one cross-modal layer: packed Linears (PackedLinear) and LayerNorm modules; keeps them alive."""
+
+    def __init__(self, xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln):
+        self.keep = (xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln)
+        c = _CXLayer()
+        for name, pw in zip(("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o"), self.keep[:6]):
+            setattr(c, name, _CLinear(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.bias.data_ptr() if pw.bias is not None else None,
+                                      pw.N, pw.K, pw.Kp))
+        for name, ln in zip(("x_ln", "s_ln", "f_ln"), self.keep[6:]):
+            setattr(c, name, _CLn(ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps)))
+        self.c = c
+        self.H, self.I = xq.N, ffn_i.N
+
+
+_XLAYER_WS = {}
+
+
+def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12):
+    """One GraphLXRTXLayer as ONE C call (gridmm_xattn_layer_fwd): x Act (f32 + planes) (B, Sq, H); kv Act planes
+    (B, Sk, n*H) holding the context's K / V projections at columns k_col / v_col.  Returns Act(f32 + planes)."""
+    lib = _lib.load()
+    B, Sq, H = x.f32.shape
+    Sk = kv.hi.shape[1]
+    dev = x.f32.device
+    assert x.f32.is_contiguous() and x.hi.is_contiguous() and kv.hi.stride(2) == 1 and kv.hi.stride() == kv.lo.stride()
+    need = lib.gridmm_xattn_layer_workspace(B, Sq, H, w.I)
+    key = (dev, need)
+    ws = _XLAYER_WS.get(key)
+    if ws is None:
+        ws = _XLAYER_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    y = torch.empty(B, Sq, H, dtype=torch.float32, device=dev)
+    hi, lo = _planes_like((B, Sq, H), dev)
+    cm = ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask
+    sm = self_mask.view(torch.uint8) if self_mask.dtype == torch.bool else self_mask
+    _lib.check(lib.gridmm_xattn_layer_fwd(ctypes.byref(w.c), _p(x.f32), _p(x.hi), _p(x.lo), _p(kv.hi), _p(kv.lo),
+                                          kv.hi.stride(0), kv.hi.stride(1), int(k_col), int(v_col), _p(cm), cm.stride(0),
+                                          _p(sm), sm.stride(0), _p(y), _p(hi), _p(lo), _p(ws), need, B, Sq, Sk, heads,
+                                          _stream()), "gridmm_xattn_layer_fwd")
+    return Act(y, hi, lo)
+
+
 def tokens_to_slab(tokens, slot, n_views):
     """tokens (B * n_views, T, D) fp32 (T = 1 class token + patches) -> slot (B, n_views * (T-1), D) fp16 view of the grid
     memory's slab (GridMemoryBatch.next_slot()): the patch tokens land where fill_gridmap expects the new observation."""

@@ -303,7 +303,23 @@ class GlocalTextPathNavCMT(nn.Module):
         return self._ffn(layer.intermediate, layer.output, key, a)
 
     def _x_layer(self, layer, key, lang, lang_mask, visn, visn_mask, kv=None):
-        """GraphLXRTXLayer.forward with graph_sprels=None (vilmodel.py:399-414)."""
+        """GraphLXRTXLayer.forward with graph_sprels=None (vilmodel.py:399-414).  One C call per layer
+        (gridmm_xattn_layer_fwd) unless per-kernel timing is on (ops.TIMER: the eleven launches are issued one by one)."""
+        if ops.TIMER is None and visn.f32 is not None and visn.hi is not None and visn.f32.is_contiguous():
+            H = visn.shape[-1]
+            if kv is None:
+                kv = (ops.linear(lang, self._qkv(layer.visual_attention.att, key + ".x", "kv"), want_f32=False,
+                                 want_planes=True), 0)
+            sa, ff = layer.visn_self_att, layer
+            pws = (self._qkv(layer.visual_attention.att, key + ".x", "q"), self._lin(layer.visual_attention.output.dense, key + ".x.o"),
+                   self._qkv(sa.self, key + ".s"), self._lin(sa.output.dense, key + ".s.o"),
+                   self._lin(ff.visn_inter.dense, key + ".i"), self._lin(ff.visn_output.dense, key + ".f"))
+            ent = self._packed.get(key + ".xlayer")
+            if ent is None or any(a is not b for a, b in zip(ent[0], pws)):
+                ent = (pws, ops.XLayerWeights(*pws, layer.visual_attention.output.LayerNorm, sa.output.LayerNorm,
+                                              ff.visn_output.LayerNorm))
+                self._packed[key + ".xlayer"] = ent
+            return ops.xattn_layer(ent[1], visn, kv[0], kv[1], kv[1] + H, lang_mask, visn_mask, heads=self.heads)
         a = self._cross_attention(layer.visual_attention, key + ".x", visn, lang, lang_mask, kv=kv)
         a = self._self_attention(layer.visn_self_att, key + ".s", a, visn_mask)
         return self._ffn(layer.visn_inter, layer.visn_output, key, a)

@@ -15,6 +15,7 @@
 #ifndef GRIDMM_H
 #define GRIDMM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -231,6 +232,28 @@ int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int64_t q_bs, 
                               int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs,
                               int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq,
                               int Sk, float scale, int cfg, gridmm_stream_t stream);
+
+/* ---- one cross-modal layer as one call -------------------------------------------------------------------------
+ * GraphLXRTXLayer.forward with graph_sprels = None (map_nav_src/models/vilmodel.py:399-414; pretrain / VLN-CE twins
+ * identical): cross attention of the Sq tokens over a context whose K / V projections the caller has already computed
+ * (KV planes (B, Sk, .), K at column k_col, V at v_col: the local encoder shares one K/V GEMM over its 4 layers,
+ * vilmodel.py:843-853), self attention, feed forward; every block = dense + residual + LayerNorm.  Weights arrive as
+ * the bf16 hi/lo planes of gridmm_split_weight.  All intermediates live in `workspace` (>= gridmm_xattn_layer_workspace
+ * bytes, 256-byte aligned); outputs: Y fp32 (M, H) and/or its bf16 planes.  heads * 64 == H. */
+typedef struct { const void *w_hi, *w_lo; const float* bias; int N, K, Kp; } gridmm_linear_t;   /* nn.Linear(K, N) */
+typedef struct { const float *gamma, *beta; float eps; } gridmm_ln_t;
+typedef struct {
+  gridmm_linear_t xq, xo;        /* visual_attention.att.query, visual_attention.output.dense */
+  gridmm_linear_t sqkv, so;      /* visn_self_att.self.{query|key|value} stacked (3H, H), visn_self_att.output.dense */
+  gridmm_linear_t ffn_i, ffn_o;  /* visn_inter.dense (H -> I, gelu), visn_output.dense (I -> H) */
+  gridmm_ln_t x_ln, s_ln, f_ln;  /* the three output LayerNorms */
+} gridmm_xlayer_t;
+size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I);
+int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
+                           const void* KV_hi, const void* KV_lo, int64_t kv_bs, int kv_rs, int k_col, int v_col,
+                           const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask, int self_mask_bs,
+                           float* Y, void* Y_hi, void* Y_lo, void* workspace, size_t workspace_bytes, int B, int Sq,
+                           int Sk, int heads, gridmm_stream_t stream);
 
 /* Patch tokens of a vision tower -> grid-memory slab: X (B * n_views, T, D) fp32 token rows, token 0 (class token)
  * dropped; episode b's slot `slab + b * slab_bs` receives n_views * (T-1) rows of D fp16, view-major.  The device-side

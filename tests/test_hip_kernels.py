@@ -217,3 +217,32 @@ def test_attention_rows_fully_masked_row_is_zero(dev):
     sl = lambda c0: (x.hi[..., c0:c0 + 768], x.lo[..., c0:c0 + 768])
     out = ops.attention_rows(sl(0), sl(768), sl(1536), mask, want_f32=True)
     assert torch.isfinite(out.f32).all() and (out.f32[1] == 0).all() and out.f32[0].abs().max() > 0
+
+
+def test_xattn_layer_entry_point_equals_the_eleven_calls(dev):
+    """gridmm_xattn_layer_fwd (one C call per GraphLXRTXLayer) against the same layer issued kernel by kernel from
+    Python (ops.TIMER forces that path): bit-identical outputs, for a cross-attention over a separate context with a
+    ragged mask and a shared K/V buffer read at a column offset."""
+    import numpy as np
+    ops = _ops()
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    torch.manual_seed(0)
+    model = GlocalTextPathNavCMT(default_config(num_l_layers=1, num_pano_layers=1, num_x_layers=2, intermediate_size=256,
+                                                vocab_size=100)).eval().to(dev)
+    layer = model.local_encoder.encoder.x_layers[1]
+    B, Sq, Sk, H = 3, 57, 100, 768
+    g = torch.Generator().manual_seed(1)
+    x = ops.split_rows(torch.randn(B, Sq, H, generator=g).to(dev))
+    kv = ops.split_rows(torch.randn(B, Sk, 4 * H, generator=g).to(dev))          # K/V of layer 1 at column 2H
+    cm = (torch.arange(Sk)[None] < torch.tensor([100, 37, 64])[:, None]).to(dev)
+    sm = (torch.arange(Sq)[None] < torch.tensor([57, 57, 40])[:, None]).to(dev)
+    with torch.no_grad():
+        fused = model._x_layer(layer, "t.1", None, model._u8(cm), x, model._u8(sm), kv=(kv, 2 * H))
+        ops.TIMER = ops.KernelTimer()
+        try:
+            split = model._x_layer(layer, "t.1", None, model._u8(cm), x, model._u8(sm), kv=(kv, 2 * H))
+        finally:
+            ops.TIMER = None
+    torch.cuda.synchronize()
+    assert torch.equal(fused.f32, split.f32) and torch.equal(fused.hi, split.hi) and torch.equal(fused.lo, split.lo)
+    assert torch.isfinite(fused.f32).all() and float(fused.f32.abs().max()) > 0.1

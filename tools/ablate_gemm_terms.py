@@ -53,6 +53,7 @@ def patched(x, pw, *a, **kw):
     return orig_linear(x, pw, *a, **kw)
 
 ops.linear = patched
+ops.TIMER = ops.KernelTimer()      # per-kernel mode: the model issues every GEMM through ops.linear (no fused-layer call)
 GROUPS = [("text_proj", r"text_proj"), ("grid_proj (on the 196 reduced cells)", r"grid_proj"),
           ("grid_enc in_proj", r"grid_enc\.0\.in"), ("grid_enc out_proj", r"grid_enc\.0\.o"),
           ("grid_enc linear1 (gelu)", r"grid_enc\.0\.1"), ("grid_enc linear2", r"grid_enc\.0\.2"),
