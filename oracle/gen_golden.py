@@ -604,15 +604,81 @@ def gen_clip():
     np.savez_compressed(os.path.join(OUT, "clip_tokens.npz"), **out)
 
 
+POLICY_CE = dict(B=2, steps=3, L=12, views=12, seed=31, cand_lens=[[4, 3], [3, 5], [4, 4]], N=[300, 200])
+
+
+def policy_ce_inputs():
+    """Scripted 3-step episode pair for GridMap.forward(mode='navigation') (shared by the generator and the test)."""
+    c = POLICY_CE
+    rs = np.random.RandomState(c["seed"])
+    B, V = c["B"], c["views"]
+    inp = {"lang_feats": torch.from_numpy(rs.standard_normal((B, c["L"], 768)).astype(np.float32) * 0.5),
+           "lang_masks": torch.from_numpy(np.arange(c["L"])[None] < np.array([[c["L"]], [c["L"] - 4]])),
+           "start": [tuple(rs.uniform(-3, 3, 3)) for _ in range(B)], "steps": []}
+    pos = [np.array(p) for p in inp["start"]]
+    for t in range(c["steps"]):
+        cl = c["cand_lens"][t]
+        nav_types = np.zeros((B, V), np.int64)
+        for b in range(B):
+            nav_types[b, :cl[b] - 1] = 1
+        st = dict(positions=[tuple(p) for p in pos], headings=[float(rs.uniform(0, 2 * np.pi)) for _ in range(B)],
+                  cand_lens=list(cl), angles=[list(rs.uniform(-np.pi, np.pi, cl[b] - 1)) for b in range(B)],
+                  distances=[list(rs.uniform(0.5, 3.0, cl[b] - 1)) for b in range(B)],
+                  view_img_fts=torch.from_numpy(rs.standard_normal((B, V, 768)).astype(np.float32) * 0.5),
+                  loc_fts=torch.from_numpy(rs.standard_normal((B, V, 7)).astype(np.float32)),
+                  nav_types=torch.from_numpy(nav_types), view_lens=torch.full((B,), V, dtype=torch.long),
+                  grid_fts=[torch.from_numpy((rs.standard_normal((n, 768)) * 0.35).astype(np.float16).astype(np.float32)) for n in c["N"]],
+                  grid_map=[torch.from_numpy(rs.randint(-1, 196, size=n).astype(np.float64)) for n in c["N"]],
+                  gridmap_pos_fts=torch.stack([torch.from_numpy(G.gridmap_pos_fts(np.float32(rs.uniform(2, 9)))) for _ in range(B)]))
+        inp["steps"].append(st)
+        pos = [p + rs.uniform(-1.5, 1.5, 3) * np.array([1, 0.05, 1]) for p in pos]
+    return inp
+
+
+def gen_policy_ce():
+    """VLN_CE/.../Policy_ViewSelection_GridMap.py GridMap.forward(mode='navigation') (:500-625) of the imported
+    reference -- bare object (no habitat __init__), reduced VLN-CE model inside, `.cuda()` neutralised -- driven over
+    three steps with the episode state set from outside as ss_trainer_GridMap.py:236-254 does -> policy_ce_nav.npz."""
+    torch.set_num_threads(1)
+    model = R.build_ref_vlnce_model(seed=7, **REDUCED)        # first: transformers must be imported before torchvision is stubbed
+    mod = R.import_vlnce_policy()
+    mod.DATASET, mod.MAX_DIST, mod.MAX_STEP = "R2R", 25, 20
+    inp = policy_ce_inputs()
+    g = object.__new__(mod.GridMap)
+    g.__dict__["vln_bert"] = model
+    B = POLICY_CE["B"]
+    g.traj_embeds, g.traj_map = [[] for _ in range(B)], [[] for _ in range(B)]
+    g.start_positions = inp["start"]
+    keep = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {"versions": _versions(), "weight_seed": 7, "cfg": json.dumps(REDUCED)}
+    try:
+        with torch.no_grad():
+            for t, st in enumerate(inp["steps"]):
+                g.positions, g.headings, g.action_step = st["positions"], st["headings"], t + 1
+                logits = mod.GridMap.forward(
+                    g, mode="navigation", lang_feats=inp["lang_feats"], lang_masks=inp["lang_masks"], positions=st["positions"],
+                    candidate_lengths=st["cand_lens"], batch_angles=st["angles"], batch_distances=st["distances"],
+                    batch_view_img_fts=st["view_img_fts"], batch_loc_fts=st["loc_fts"], batch_nav_types=st["nav_types"],
+                    batch_view_lens=st["view_lens"], batch_grid_fts=st["grid_fts"], batch_map_index=st["grid_map"],
+                    batch_gridmap_pos_fts=st["gridmap_pos_fts"])
+                out["logits_%d" % t] = logits.numpy()
+                print("policy_ce step", t, tuple(logits.shape))
+    finally:
+        torch.Tensor.cuda = keep
+    np.savez_compressed(os.path.join(OUT, "policy_ce_nav.npz"), **out)
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo", "optim", "backbone", "clip"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo", "optim", "backbone", "clip", "policyce"]
     if "rollout" in which: gen_rollout()
     if "topo" in which: gen_topo_map()
     if "optim" in which: gen_optim()
     if "backbone" in which: gen_backbone()
     if "clip" in which: gen_clip()
+    if "policyce" in which: gen_policy_ce()
     if "vlnce" in which: gen_fill_gridmap_vlnce()
     if "fill" in which: gen_fill_gridmap()
     if "nav" in which: gen_nav_reduced(False)
