@@ -96,8 +96,8 @@ def _grad_worker(rank, world, port, q):
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
     _tiny_loss(model, xs, ys, "a" if rank == 0 else "b").backward()      # rank 0 never touches head_b and v.v.
     D.GradientReducer(model.parameters(), bucket_mb=1e-4).reduce()        # tiny buckets: exercise several
-    out = {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
-    q.put((rank, out))
+    out = {k: (None if p.grad is None else p.grad.detach().numpy().copy()) for k, p in model.named_parameters()}
+    q.put((rank, out))          # plain numpy: no shared-memory tensor hand-off racing the worker's exit
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,7 +124,7 @@ def test_gradient_reducer_matches_single_process_mean_world2():
             if p.grad is None:
                 assert got is None, k                      # same set of grad-less parameters
             else:
-                assert got is not None and torch.allclose(got, p.grad, atol=1e-6), k
+                assert got is not None and torch.allclose(torch.from_numpy(got), p.grad, atol=1e-6), k
 
 
 def _task_worker(rank, world, port, q):
