@@ -103,19 +103,17 @@ class GridMemoryBatch:
         Rounded to fp32 on the host exactly as NumPy does (env.py:118-120, 344-348)."""
         if self._h2d_done is not None:
             self._h2d_done.synchronize()          # the previous step's async H2D has consumed the pinned buffers
-        p = self._pose_host.numpy()
-        h = self._head_host.numpy()
-        for b in range(self.B):
-            p[b, 0], p[b, 1] = np.float32(poses[b][0]), np.float32(poses[b][1])
-            a = (-headings[b] + math.pi) if self.geom.vlnce else -headings[b]       # env.py:337 / VLN-CE :785
-            h[b, 0], h[b, 1] = np.float32(math.cos(a)), np.float32(math.sin(a))
+        # whole-array writes into the pinned buffers; cos / sin stay libm scalars in double (math.cos, as the reference
+        # computes them) and are rounded to fp32 once, exactly like np.float32(math.cos(a))
+        self._pose_host.numpy()[:] = np.asarray([(pz[0], pz[1]) for pz in poses], dtype=np.float64).astype(np.float32)
+        ang = [(-hd + math.pi) if self.geom.vlnce else -hd for hd in headings]       # env.py:337 / VLN-CE :785
+        self._head_host.numpy()[:] = np.array([(math.cos(a), math.sin(a)) for a in ang], dtype=np.float64).astype(np.float32)
         self.pose_d.copy_(self._pose_host, non_blocking=True)
         self.head_d.copy_(self._head_host, non_blocking=True)
         if self.geom.vlnce:
-            vc, vs = self._vcos_host.numpy(), self._vsin_host.numpy()
-            for b in range(self.B):
-                for v, a0 in enumerate(self._view_ang):
-                    vc[b, v], vs[b, v] = np.float32(math.cos(a0 - headings[b])), np.float32(math.sin(a0 - headings[b]))
+            rel = [[a0 - hd for a0 in self._view_ang] for hd in headings]
+            self._vcos_host.numpy()[:] = np.array([[math.cos(a) for a in r] for r in rel], dtype=np.float64).astype(np.float32)
+            self._vsin_host.numpy()[:] = np.array([[math.sin(a) for a in r] for r in rel], dtype=np.float64).astype(np.float32)
             self.view_cos.copy_(self._vcos_host, non_blocking=True)
             self.view_sin.copy_(self._vsin_host, non_blocking=True)
         if active is None:
