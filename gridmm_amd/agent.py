@@ -358,6 +358,46 @@ class GMapNavAgent:
         if mem is not None and hasattr(mem, "keep_for_backward"):
             mem.keep_for_backward = bool(training)
 
+    # ---- checkpoints in the reference's agent format (agent_base.py:213-259) ------------------------------------
+    def _ckpt_parts(self):
+        if not hasattr(self, "critic"):
+            from .model import Critic
+            self.critic = Critic(self.args).to(self.device)
+        if not hasattr(self, "vln_bert_optimizer"):
+            self.make_optimizer()
+        if not hasattr(self, "critic_optimizer"):
+            self.critic_optimizer = torch.optim.AdamW(self.critic.parameters(), lr=self.args.lr)
+        return (("vln_bert", self.vln_bert, self.vln_bert_optimizer), ("critic", self.critic, self.critic_optimizer))
+
+    def save(self, epoch, path):
+        """{'vln_bert': {epoch, state_dict, optimizer}, 'critic': {...}} -- what the reference's Seq2SeqAgent.save writes."""
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({name: {"epoch": epoch + 1, "state_dict": m.state_dict(), "optimizer": o.state_dict()}
+                    for name, m, o in self._ckpt_parts()}, path)
+
+    def load(self, path):
+        """Loads parameters (and, with args.resume_optimizer, the optimizer states) of a checkpoint in that format, written
+        by this agent or by the reference -- a DistributedDataParallel 'module.' prefix on either side is reconciled and
+        keys the model does not have are skipped, as agent_base.py:230-259 does.  Returns the epoch to resume from."""
+        states = torch.load(path, map_location="cpu")
+        for name, model, opt in self._ckpt_parts():
+            have = model.state_dict()
+            given = states[name]["state_dict"]
+            if set(have) != set(given):
+                mine_ddp = next(iter(have)).startswith("module.")
+                theirs_ddp = next(iter(given)).startswith("module.")
+                if theirs_ddp and not mine_ddp:
+                    given = {k[len("module."):] if k.startswith("module.") else k: v for k, v in given.items()}
+                elif mine_ddp and not theirs_ddp:
+                    given = {"module." + k: v for k, v in given.items()}
+                given = {k: v for k, v in given.items() if k in have}
+            have.update(given)
+            model.load_state_dict(have)
+            if getattr(self.args, "resume_optimizer", False):
+                opt.load_state_dict(states[name]["optimizer"])
+        return states["vln_bert"]["epoch"] - 1
+
     def make_optimizer(self):
         """agent_base.py:122-139: one optimizer over all vln_bert parameters at args.lr."""
         if self.args.optim == "adamW":        # scripts/run_r2r.sh; torch.optim.AdamW semantics on the fused HIP step

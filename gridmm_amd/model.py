@@ -39,3 +39,17 @@ class VLNBert(nn.Module):
         if mode == "navigation":
             return self.vln_bert(mode, batch)
         raise NotImplementedError("wrong mode: %s" % mode)
+
+
+class Critic(nn.Module):
+    """The value head of the reference's (vestigial) A2C branch (map_nav_src/models/model.py:43-55): kept so that agent
+    checkpoints -- which store a 'critic' entry beside 'vln_bert' (r2r/agent_base.py:213-228) -- load and save unchanged.
+    No released script trains it (rollout(train_rl=...) is never called with True); plain torch modules, off the hot path."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.state2value = nn.Sequential(nn.Linear(768, 512), nn.ReLU(), nn.Dropout(float(getattr(args, "dropout", 0.5))),
+                                         nn.Linear(512, 1))
+
+    def forward(self, state):
+        return self.state2value(state).squeeze()

@@ -53,3 +53,33 @@ def test_agent_wraps_a_bare_model():
     assert all(k.startswith("vln_bert.") for k in agent.vln_bert.state_dict())   # reference checkpoint key prefix
     probe = _Probe()
     assert GMapNavAgent(default_args(), env=None, vln_bert=probe, device="cpu").vln_bert is probe
+
+
+def test_agent_checkpoint_round_trip_in_the_reference_format(tmp_path):
+    """save() writes {'vln_bert': {epoch, state_dict, optimizer}, 'critic': {...}} (r2r/agent_base.py:213-228); load()
+    restores it, strips a DDP 'module.' prefix, skips keys the model does not have, returns the epoch."""
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    cfg = default_config(num_l_layers=1, num_pano_layers=1, num_x_layers=1, intermediate_size=64, vocab_size=50)
+    agent = GMapNavAgent(default_args(optim="adam"), env=None, vln_bert=GlocalTextPathNavCMT(cfg), device="cpu")
+    path = str(tmp_path / "ckpt" / "latest_dict")
+    agent.save(6, path)
+    st = torch.load(path, map_location="cpu")
+    assert set(st) == {"vln_bert", "critic"} and set(st["vln_bert"]) == {"epoch", "state_dict", "optimizer"}
+    assert st["vln_bert"]["epoch"] == 7 and all(k.startswith("vln_bert.") for k in st["vln_bert"]["state_dict"])
+    assert set(st["critic"]["state_dict"]) == {"state2value.0.weight", "state2value.0.bias", "state2value.3.weight", "state2value.3.bias"}
+    want = {k: v.clone() for k, v in agent.vln_bert.state_dict().items()}
+    with torch.no_grad():
+        for p in agent.vln_bert.parameters():
+            p.add_(1.0)
+    assert agent.load(path) == 6
+    assert all(torch.equal(v, want[k]) for k, v in agent.vln_bert.state_dict().items())
+    # a checkpoint written from a DistributedDataParallel wrapper, with a key this model does not have
+    st["vln_bert"]["state_dict"] = {"module." + k: v for k, v in st["vln_bert"]["state_dict"].items()}
+    st["vln_bert"]["state_dict"]["module.vln_bert.not_here.weight"] = torch.zeros(3)
+    torch.save(st, path)
+    with torch.no_grad():
+        for p in agent.vln_bert.parameters():
+            p.mul_(0.0)
+    assert agent.load(path) == 6
+    assert all(torch.equal(v, want[k]) for k, v in agent.vln_bert.state_dict().items())
