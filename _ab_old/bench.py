@@ -1,0 +1,459 @@
+#!/usr/bin/env python
+"""bench.py -- nav steps/s of the GridMM grid-memory hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic episodes, inputs resident in HBM:
+    fill_gridmap (project the new 36x196 observation, re-bin the memory, build per-cell lists)
+  + GlocalTextPathNavCMT.forward('navigation')  (aggregation, grid/cross-modal encoders, logit fusion)
+Workload = BASELINE.json configs[1]: B=32 episodes per GPU, slab 36 views x 196 patches x 512-D (N=7056
+points, memory depth t=1), L=80 instruction tokens, G=20 map nodes, 36 views + stop, full-size model
+(161 M-parameter architecture with text_proj/grid_proj at D_in=512), random-init weights, synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Episodes are independent: ranks shard the episode batch, no collective on the step path ("weak" scaling,
+B per GPU fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "nav steps/sec (whole node), R2R batch=32, 36x196x512 grid, 1/2/4/8 MI355X"
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="episodes per GPU")
+    ap.add_argument("--shape", default="baseline", choices=["baseline", "native"])
+    ap.add_argument("--mem-steps", type=int, default=1, help="observations in each episode's memory (t)")
+    ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="cut the episode batch into this many groups captured on concurrent streams of one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-torch-gpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-depth-legs", action="store_true", help="skip the extra t = 5 / t = 15 timings")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the pre-training step timing (train_samples_per_s)")
+    ap.add_argument("--no-producer-leg", action="store_true", help="skip the VLN-CE step with the CLIP tower in the timed region")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build_workload(args, dev, mem_steps=None, device_feats=False):
+    """mem_steps overrides args.mem_steps (the extra t = 5 / 15 legs); device_feats fills the slab with N(0,1) drawn on
+    the GPU instead of the host-generated features (no oracle leg runs on those workloads)."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+
+    geom = S.BASELINE if args.shape == "baseline" else S.NATIVE
+    torch.manual_seed(0)
+    model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim)).eval()
+    # BERT-style random init leaves LayerNorm at (1, 0); fine for timing
+    model.to(dev)
+    rs = np.random.RandomState(int(os.environ.get("RANK", "0")))
+    B, t = args.batch, (args.mem_steps if mem_steps is None else mem_steps)
+    host_batch = S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, min_len=30)
+    batch = S.batch_to(host_batch, dev)
+    # what a caller has on the host each step for the fused-logit index maps (vilmodel.py:881-899)
+    fusion_src = (host_batch["gmap_vpids"], host_batch["gmap_visited_masks"].numpy(), host_batch["vp_cand_vpids"])
+    mem = GridMemoryBatch(B, geom, max_steps=t, device=dev)
+    eps = [S.make_observations(rs, geom, t, with_feats=not device_feats) for _ in range(B)]
+    n_new = geom.pts_per_obs
+    depth = [torch.from_numpy(np.stack([e[k]["depth"].reshape(-1) for e in eps])).to(dev) for k in range(t)]
+    # tokens are written into the slab once, before timing (zero-copy append: producer-owned slot)
+    for k in range(t):
+        if device_feats:
+            mem.slab[:, k * n_new:(k + 1) * n_new].copy_(torch.randn(B, n_new, geom.feat_dim, device=dev))
+        else:
+            mem.slab[:, k * n_new:(k + 1) * n_new].copy_(torch.from_numpy(np.stack([e[k]["feats"] for e in eps])))
+    poses = [[(e[k]["x"], e[k]["y"]) for e in eps] for k in range(t)]
+    heads = [[e[k]["heading"] for e in eps] for k in range(t)]
+    for k in range(t - 1):                      # history prefix (t-1 observations), built once
+        mem.step(depth[k], None, poses[k], heads[k])
+    restore = (mem.n_pts.clone(), mem.bbox.clone())
+    n_host0 = mem.n_pts_host.copy()
+    batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
+
+    def eager_step():
+        mem.n_pts.copy_(restore[0])
+        mem.bbox.copy_(restore[1])
+        mem.n_pts_host[:] = n_host0
+        mem.step(depth[t - 1], None, poses[t - 1], heads[t - 1])   # project the new observation + re-bin all
+        # the fused-logit index maps are rebuilt from the vpid lists on every call, as in the reference
+        return model("navigation", dict(batch, fusion_maps=model.fusion_maps(
+            dict(batch, gmap_visited_masks=fusion_src[1]), dev)))
+
+    step = eager_step
+    if not args.eager and args.groups > 1:
+        from gridmm_amd.graph import GraphedNavStepGroups
+        eager_step()                            # packs the weights, fills the allocator
+        ng = args.groups
+        assert B % ng == 0
+        per = B // ng
+        groups, gp, gh = [], [], []
+        for gi in range(ng):
+            sl = slice(gi * per, (gi + 1) * per)
+            gm = GridMemoryBatch(per, geom, max_steps=t, device=dev)
+            gm.slab.copy_(mem.slab[sl])
+            for k in range(t - 1):
+                gm.step(depth[k][sl], None, poses[k][sl], heads[k][sl])
+            gb = {k: (v[sl] if (torch.is_tensor(v) and v.shape[:1] == (B,)) or (isinstance(v, list) and len(v) == B) else v)
+                  for k, v in batch.items() if k not in ("grid_memory", "fusion_maps")}
+            gb = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()}
+            groups.append(dict(mem=gm, batch=gb, depth=depth[t - 1][sl].contiguous(),
+                               restore=(gm.n_pts.clone(), gm.bbox.clone())))
+            gp.append(poses[t - 1][sl])
+            gh.append(heads[t - 1][sl])
+        g = GraphedNavStepGroups(model, groups)
+        for gr in groups:
+            gr["mem"].n_pts_host[:] = gr["mem"].n_pts_host + n_new
+
+        def step():
+            return g(gp, gh)
+    elif not args.eager:
+        from gridmm_amd.graph import GraphedNavStep
+        eager_step()                            # packs the weights, fills the allocator
+        g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore)
+        mem.n_pts_host[:] = n_host0 + n_new
+
+        def step():   # host half (pose / heading floats, fused-logit index maps) + one graph replay
+            return g(poses[t - 1], heads[t - 1], fusion=fusion_src)
+    return model, batch, mem, eps, step, eager_step, geom
+
+
+def time_steps(step, steps, warmup, dist):
+    for _ in range(warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    from gridmm_amd.dist import max_over_ranks
+    return max_over_ranks(dt)          # the slowest rank defines the step time (identity at N=1)
+
+
+LOGIT_KEYS = ("global_logits", "local_logits", "grid_logits", "fused_logits")
+
+
+def check_replay(step, eager_step):
+    """What bench.py times is the hipGraph replay: compare its outputs with the same step launched eagerly (same
+    kernels, same order: expected bit-identical) and fail loudly if they differ."""
+    got = {k: v.clone() for k, v in step().items() if k in LOGIT_KEYS}
+    torch.cuda.synchronize()
+    want = eager_step()
+    torch.cuda.synchronize()
+    worst, bitwise = 0.0, True
+    for k in LOGIT_KEYS:
+        a, w = got[k], want[k]
+        f = torch.isfinite(w)
+        if not torch.equal(f, torch.isfinite(a)):
+            raise SystemExit("bench.py: replayed %s has -inf in different places than the eager step" % k)
+        bitwise &= bool(torch.equal(a[f], w[f]))
+        if f.any():
+            worst = max(worst, float((a[f] - w[f]).abs().max()))
+    if worst > 1e-6:
+        raise SystemExit("bench.py: replayed logits differ from the eager step by %.3g" % worst)
+    return {"replay_vs_eager_max_abs": worst, "bit_identical": bitwise}
+
+
+def extra_depth_leg(args, dev, dist, mem_steps, steps):
+    """nav steps/s of this rank at memory depth t = mem_steps (slab filled on the device), same step otherwise."""
+    model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev, mem_steps=mem_steps, device_feats=True)
+    dt = time_steps(step, steps, 2, dist)
+    del model, batch, mem, step, eager_step
+    torch.cuda.empty_cache()
+    return dt / steps
+
+
+def producer_leg(args, dev, steps=5):
+    """Config 5's shape with the PRODUCER in the timed region: per step the CLIP ViT-B/32 tower encodes the
+    12 view images of every episode (B x 12 x 3 x 224 x 224, already normalised and resident), writes the patch tokens
+    into the grid memory's next slot, then fill_gridmap + forward('navigation') run as usual -- VLN-CE geometry
+    (12 views x 49 patches x 768-D, habitat depth), full-size model + full-size tower, random init, t = 1."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.clip_encoder import CLIP
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    geom, B = S.VLNCE_R2R, args.batch
+    torch.manual_seed(1)
+    model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim)).eval().to(dev)
+    clip = CLIP().eval().to(dev)
+    rs = np.random.RandomState(5)
+    host_batch = S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, min_len=30)
+    batch = S.batch_to(host_batch, dev)
+    mem = GridMemoryBatch(B, geom, max_steps=1, device=dev)
+    eps = [S.make_observations(rs, geom, 1, with_feats=False)[0] for _ in range(B)]
+    depth = torch.from_numpy(np.stack([e["depth"].reshape(-1) for e in eps]).astype(np.float32)).to(dev)
+    poses, heads = [(e["x"], e["y"]) for e in eps], [e["heading"] for e in eps]
+    images = torch.randn(B * geom.n_views, 3, 224, 224, device=dev)
+    batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step():
+        mem.reset()
+        ev[0].record()
+        clip.encode_into(images, mem.next_slot(), n_views=geom.n_views)
+        ev[1].record()
+        mem.step(depth, None, poses, heads)
+        out = model("navigation", dict(batch, fusion_maps=model.fusion_maps(
+            dict(batch, gmap_visited_masks=host_batch["gmap_visited_masks"].numpy()), dev)))
+        ev[2].record()
+        return out
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    enc = nav = 0.0
+    for _ in range(steps):
+        step()
+        torch.cuda.synchronize()
+        enc += ev[0].elapsed_time(ev[1])
+        nav += ev[1].elapsed_time(ev[2])
+    dt = (time.perf_counter() - t0) / steps
+    flops = B * geom.n_views * (2.0 * 49 * 3072 * 768 + 12 * 50 * 2.0 * 768 * (2304 + 768 + 3072 + 3072) + 12 * 4.0 * 50 * 50 * 768)
+    return {"value": B / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt, "encoder_ms": enc / steps, "fill_nav_ms": nav / steps,
+            "encoder_tflops_algorithmic": flops / (enc / steps * 1e-3) / 1e12, "launch": "eager",
+            "workload": "B=%d episodes x 12 views: CLIP ViT-B/32 (224 px) -> slab, fill_gridmap (VLN-CE geometry) + "
+                        "forward('navigation'), t=1, full-size model and tower, random init" % B}
+
+
+def train_leg(args, dev, steps=6):
+    """Secondary: one pre-training step (config 3's per-GPU shape) -- forward + backward + gradient clip + fused AdamW
+    of the full-size GlocalTextPathCMTPreTraining, B = 32, native grid memory of 3-5 observations, tasks cycling
+    mlm / mrc / sap as the task-mixed loop does (pretrain_src/train_r2r.py:231-303).  Eager launches."""
+    from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.synthetic import batch_to, make_pretrain_batch
+    from gridmm_amd.vilmodel import default_config
+    cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=["mlm", "mrc", "sap"], image_prob_size=1000, obj_prob_size=0)
+    torch.manual_seed(0)
+    model = GlocalTextPathCMTPreTraining(cfg).to(dev)
+    tr = PreTrainer(model, default_opts(warmup_steps=100))
+    tasks = ("mlm", "mrc", "sap")
+    batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i), args.batch, t, max_steps=5, L=80, vocab=30000,
+                                               image_prob_size=1000, n_pts=(588 * 3, 588 * 5)), dev)
+               for i, t in enumerate(tasks)}
+    for t in tasks:
+        tr.train_step(batches[t], t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.train_step(batches[tasks[i % 3]], tasks[i % 3])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del tr, model, batches
+    torch.cuda.empty_cache()
+    return {"train_samples_per_s": args.batch / dt, "ms_per_step": 1e3 * dt, "batch": args.batch,
+            "workload": "pre-training step (mlm/mrc/sap cycling), full-size model, native 12x49x768 grid memory t=3..5, "
+                        "fwd + bwd + clip + fused AdamW, eager launches"}
+
+
+def roofline_leg(step, args, geom, L=80):
+    """Per-kernel HIP-event timing over a few instrumented steps (events on the launch stream)."""
+    from gridmm_amd import ops
+    n = max(3, min(args.steps, 10))
+    ops.TIMER = ops.KernelTimer()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    summ = ops.TIMER.summary()
+    ops.TIMER = None
+    kern = {k: {"calls_per_step": v["calls"] / n, "ms_per_step": v["ms"] / n, "avg_us": 1e3 * v["ms"] / v["calls"]}
+            for k, v in summ.items()}
+    B, N, D = args.batch, geom.pts_per_obs * args.mem_steps, geom.feat_dim
+    out = {"kernels": kern}
+    if "linear" in summ:
+        tf = summ["linear"]["work"] / (summ["linear"]["ms"] * 1e-3) / 1e12
+        out["linear"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_BF16_PEAK_TF, "traffic": None,
+                         "note": "algorithmic 2MNK flops of all GEMM launches / their summed HIP-event time; the "
+                                 "3-term bf16 split issues 3x these flops on the matrix pipe"}
+    if "grid_aggregate" in summ:
+        # algorithmic bytes per launch: slab + perm + text fragments (hi+lo) + cell vectors out
+        byts = B * (N * D * 2 + N * 4 + 2 * L * D * 2 + 196 * D * 4 + 196)
+        gbs = byts / (summ["grid_aggregate"]["ms"] / summ["grid_aggregate"]["calls"] * 1e-3) / 1e9
+        out["grid_aggregate"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": byts}
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_traffic.sh:
+    # FETCH_SIZE and WRITE_SIZE in separate runs, (2*FETCH + WRITE) * 1024 with the gfx950 read-side correction)
+    import glob
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic.json")))
+    tpath = cands[-1] if cands else ""               # the newest round's PMC passes
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        c = t.get("config", {})
+        if (int(c.get("batch", -1)), c.get("shape"), int(c.get("mem_steps", -1))) == (args.batch, args.shape, args.mem_steps):
+            for k in ("linear", "grid_aggregate"):
+                if k in out and k in t["kernels"]:
+                    out[k]["traffic"] = t["kernels"][k]["hbm_bytes_per_launch"]
+                    out[k]["traffic_source"] = "profiles/" + os.path.basename(tpath)
+    dom = max(("linear", "grid_aggregate", "attention"), key=lambda k: summ.get(k, {"ms": 0})["ms"])
+    out["dominant"] = dom
+    return out
+
+
+def cpu_baseline(model, eps, batch, args, geom):
+    """The oracle (NumPy + torch-CPU port of the reference algorithm, incl. its 196-cell loop) timed on this
+    host on a bounded sample of the same workload."""
+    from oracle import navcmt_oracle as O, gridmap_oracle as G
+    og = G.BASELINE if args.shape == "baseline" else G.NATIVE
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    keys = ("txt_embeds", "txt_masks", "gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_masks",
+            "gmap_visited_masks", "vp_img_embeds", "vp_pos_fts", "vp_masks", "vp_nav_masks")
+
+    def run(b0, b1):
+        refs = []
+        for b in range(b0, b1):
+            mem = G.GridMemory(og)
+            for o in eps[b]:
+                r = mem.step(o["depth"], o["feats"], o["x"], o["y"], o["heading"])
+            refs.append(r)
+        cb = {k: batch[k][b0:b1].cpu() for k in keys}
+        cb.update(gmap_vpids=batch["gmap_vpids"][b0:b1], vp_cand_vpids=batch["vp_cand_vpids"][b0:b1],
+                  vp_obj_masks=None, gmap_pair_dists=None,
+                  grid_fts=[torch.from_numpy(r[0]) for r in refs], grid_map=[torch.from_numpy(r[1]) for r in refs],
+                  gridmap_pos_fts=torch.from_numpy(np.stack([r[2] for r in refs])))
+        with torch.no_grad():
+            O.forward_navigation(sd, cb)
+
+    best = None
+    ncpu = os.cpu_count() or 1
+    for k in sorted(set([1, min(8, ncpu)])):
+        torch.set_num_threads(k)
+        t0 = time.perf_counter()
+        run(0, 1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (k, dt)
+    k = best[0]
+    torch.set_num_threads(k)
+    done, t0 = 0, time.perf_counter()
+    chunk = 2
+    while time.perf_counter() - t0 < args.cpu_seconds:      # ~10-30 s of CPU work; wraps around the episode batch
+        b0 = done % (len(eps) - chunk + 1)
+        run(b0, b0 + chunk)
+        done += chunk
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "steps/s", "cores": k, "kind": "port",
+            "sample": "%d episode-steps of the same workload (N=%d points x %d-D, L=80, full-size model), "
+                      "oracle/navcmt_oracle.py + oracle/gridmap_oracle.py on %d torch thread(s), %.1f s"
+                      % (done, geom.pts_per_obs * args.mem_steps, geom.feat_dim, k, dt)}
+
+
+def torch_gpu_baseline(model, batch, mem, args):
+    """The reference-style PyTorch path on this GPU: the op-for-op oracle (196-cell python loop and all) run with
+    stock torch ops on cuda -- the '>= 5x' comparator of the north star.  Bounded: 1 warm-up + 2 timed calls."""
+    from oracle import navcmt_oracle as O
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    fts, gmaps, pos = mem.as_reference_obs()
+    b = dict(batch, grid_fts=fts, grid_map=gmaps, gridmap_pos_fts=pos, grid_memory=None)
+    with torch.no_grad():
+        O.forward_navigation(sd, b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            O.forward_navigation(sd, b)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": args.batch / dt, "unit": "steps/s", "kind": "port-on-gpu",
+            "sample": "forward('navigation') only (grid map prebuilt), B=%d, fp32 stock torch ops, %.3f s/call"
+                      % (args.batch, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    share = bool(os.environ.get("GRIDMM_BENCH_SHARE_GPU"))   # test hook: N ranks on one GPU (gloo for the timing collectives)
+    if share:
+        local %= torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # RCCL ("nccl" backend on ROCm)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev)
+    dt = time_steps(step, args.steps, args.warmup, dist)
+    n_gpus = world
+    value = n_gpus * args.batch * args.steps / dt
+    check = check_replay(step, eager_step)      # the timed (replayed) step must reproduce the eager launches
+
+    out = {
+        "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "R2R fine-tune batch=%d/GPU, %d views x %d patches x %dD, 14x14 grid, memory depth "
+                               "t=%d (N=%d points), L=80, G=20, V=37, full-size GlocalTextPathNavCMT (random init): "
+                               "fill_gridmap + forward('navigation')"
+                               % (args.batch, geom.n_views, geom.patches ** 2, geom.feat_dim, args.mem_steps,
+                                  geom.pts_per_obs * args.mem_steps),
+                   "global_batch": args.batch * n_gpus, "parallelism": "dp%d (episode sharding, no step-path collective)" % n_gpus,
+                   "launch": "eager" if args.eager else "hipGraph replay; per step on the host: pose/heading floats and the fused-logit index maps (H2D into static buffers)",
+                   "gemm": "MFMA bf16 16x16x32, 3-term split (hi*hi+lo*hi+hi*lo), fp32 accumulate",
+                   "attention": "MFMA bf16 16x16x32, 3-term split, fp32 softmax", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
+    }
+    out["replay_check"] = check
+    if not args.no_depth_legs and not args.eager and args.groups == 1 and args.mem_steps == 1:
+        # the memory deepens as an episode proceeds; the headline is t = 1, these are the same step at
+        # t = 5 and t = 15 (re-binning and aggregation walk 5x / 15x the points)
+        for t in (5, 15):
+            sec = extra_depth_leg(args, dev, dist, t, max(5, args.steps // 2))
+            out["t%d" % t] = {"value": n_gpus * args.batch / sec, "unit": "steps/s", "ms_per_step": 1e3 * sec,
+                              "mem_steps": t, "points": geom.pts_per_obs * t}
+    if rank == 0 and n_gpus == 1 and not args.no_train_leg:
+        out["train"] = train_leg(args, dev)
+    if rank == 0 and n_gpus == 1 and not args.no_producer_leg:
+        out["vlnce_with_producer"] = producer_leg(args, dev)
+    if rank == 0 and not args.no_roofline:
+        rl = roofline_leg(eager_step, args, geom)   # per-launch HIP events need eager launches
+        dom = rl["dominant"]
+        out["roofline"] = dict(rl.get(dom, {}), kernel=dom)
+        for k in ("linear", "grid_aggregate"):
+            if k != dom and k in rl:
+                out["roofline_" + k] = rl[k]
+        out["kernels"] = rl["kernels"]
+    if rank == 0 and n_gpus == 1:
+        if not args.no_torch_gpu_baseline:
+            out["torch_gpu_baseline"] = torch_gpu_baseline(model, batch, mem, args)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, eps, batch, args, geom)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""ctypes binding of libgridmm_hip.so (C-ABI declared in include/gridmm.h).
+
+The product path FAILS LOUDLY when the library is missing: there is no CPU or
+PyTorch fallback behind these entry points.
+"""
+import ctypes
+import os
+
+# ORDER MATTERS: PyTorch-ROCm bundles its own libamdhip64.so.7.  It must be in the process before
+# libgridmm_hip.so is dlopen'ed so that the library's DT_NEEDED libamdhip64.so.7 resolves (by SONAME) to the
+# SAME HIP runtime that owns torch's streams and allocations; loading ours first binds /opt/rocm's copy and
+# every launch on a torch stream then fails with hipErrorNoDevice.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
+ABI_VERSION = 13
+
+_vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+# name -> argtypes, exactly the prototypes of include/gridmm.h
+SIGNATURES = {
+    "gridmm_abi_version": [],
+    "gridmm_grid_project": [_vp, _i, _vp, _vp, _vp, _i] + [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _f, _vp],
+    "gridmm_grid_bin": [_vp] * 10 + [_i, _i, _i, _vp],
+    "gridmm_grid_bin_sliced": [_vp] * 11 + [_i, _i, _i, _i, _vp],
+    "gridmm_grid_sort_ids": [_vp] * 4 + [_i, _i, _vp],
+    "gridmm_text_fragments": [_vp, _vp, _i, _i, _i, _vp],
+    "gridmm_grid_aggregate": [_vp] * 8 + [_i, _i, _i, _i, _i, _vp],
+    "gridmm_grid_aggregate_train": [_vp] * 9 + [_i, _i, _i, _i, _i, _vp],
+    "gridmm_cells_compact": [_vp] * 7 + [_i, _i, _i, _vp],
+    "gridmm_split_weight": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "gridmm_linear": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "gridmm_layernorm": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gridmm_split_rows": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "gridmm_linear_planes": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gridmm_linear_planes_cfg": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gridmm_attention": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
+                         _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
+    "gridmm_transpose_v": [_vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_attention_planes": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i,
+                                _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
+    "gridmm_attention_rows": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
+                              _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
+    "gridmm_attention_rows_cfg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
+                                  _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "gridmm_xattn_layer_workspace": [_i, _i, _i, _i],
+    "gridmm_xattn_layer_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp,
+                               ctypes.c_size_t, _i, _i, _i, _i, _vp],
+    "gridmm_tokens_to_slab": [_vp, _i, _i, _vp, _i64, _i, _i, _vp],
+    "gridmm_ln_dot": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
+    "gridmm_fuse_logits": [_vp] * 13 + [_i, _i, _i, _vp],
+    "gridmm_copy_rows": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp],
+    # training (backward)
+    "gridmm_transpose_split": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_layernorm_bwd": [_vp, _i, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "gridmm_activation": [_vp, _vp, _vp, _i64, _i, _vp],
+    "gridmm_attention_train": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i,
+                               _i, _i, _i, _i, _f, _f, ctypes.c_uint64, _vp],
+    "gridmm_attention_bwd": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i64, _i,
+                             _vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f,
+                             ctypes.c_uint64, _vp],
+    "gridmm_grid_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_grid_aggregate_bwd_routed": [_vp] * 9 + [_i, _i, _i, _i, _vp],
+    "gridmm_grad_sumsq": [_vp, _i64, _i, _vp, _vp],
+    "gridmm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
+    "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_multi_grad_sumsq": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "gridmm_multi_adamw_step": [_vp, _vp, _i, _i, _f, _f, _i, _vp, _f, _vp],
+}
+
+_lib = None
+
+
+class GridmmLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library (no GPU needed for loading) and bind every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GridmmLibraryError(
+            "libgridmm_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C gridmm_amd/csrc`). There is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
+    v = lib.gridmm_abi_version()
+    if v != ABI_VERSION:
+        raise GridmmLibraryError("libgridmm_hip.so ABI %d != expected %d (stale build?)" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        detail = " (hipError_t %d)" % (-1000 - status) if status <= -1000 else ""
+        raise GridmmLibraryError("%s failed with status %d%s" % (what, status, detail))

@@ -1,0 +1,445 @@
+"""GMapNavAgent: the reference's per-episode navigation loop around forward(mode, batch).
+
+Restates (relative to /root/reference/map_nav_src/r2r):
+  _language_variable          agent.py:36-49      _panorama_feature_variable   agent.py:51-94
+  _nav_gmap_variable          agent.py:96-169     _nav_vp_variable             agent.py:171-205
+  _teacher_action             agent.py:207-236    make_equiv_action            agent.py:238-255
+  rollout                     agent.py:268-451    (criterion: agent_base.py:141, CE sum, ignore -100)
+Same call order and mode strings (language -> [panorama -> graph update -> navigation -> action] x t),
+same `nav_inputs` keys / shapes / dtypes, same stop handling and best-stop-node backtrack.  What changes
+is where the data lives: tensors are built on `device` directly, and when the environment owns a
+device-resident grid memory it is handed to the model as batch['grid_memory'] instead of re-uploading the
+whole point history every step (agent.py:168).
+
+`vln_bert` is any callable (mode, batch) -> outputs with the reference's contract
+(gridmm_amd.vilmodel.GlocalTextPathNavCMT on the GPU; tests also drive it with the CPU oracle).
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .graph_utils import TopoMap
+
+
+def default_args(**over):
+    """The subset of r2r/parser.py the loop reads."""
+    a = dict(max_action_len=15, ignoreid=-100, image_feat_size=768, angle_feat_size=4, fusion="dynamic",
+             enc_full_graph=True, act_visited_nodes=False, expl_max_ratio=0.6, detailed_output=False,
+             # training (r2r/parser.py): DAgger by default in scripts/run_r2r.sh
+             train_alg="dagger", ml_weight=0.2, expl_sample=False, lr=1e-5, optim="adamW", feat_dropout=0.4,
+             dropout=0.5)
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def pad_tensors(tensors, lens=None, pad=0):
+    """utils/ops.py: B x [T, ...] -> (B, Tmax, ...)."""
+    if lens is None:
+        lens = [t.size(0) for t in tensors]
+    max_len = max(lens)
+    out = tensors[0].new_full((len(tensors), max_len) + tuple(tensors[0].shape[1:]), pad)
+    for i, (t, l) in enumerate(zip(tensors, lens)):
+        out[i, :l] = t
+    return out
+
+
+def gen_seq_masks(seq_lens, max_len=None):
+    if max_len is None:
+        max_len = int(max(seq_lens))
+    return torch.arange(max_len, device=seq_lens.device).unsqueeze(0) < seq_lens.unsqueeze(1)
+
+
+class GMapNavAgent:
+    def __init__(self, args, env, vln_bert, device="cuda"):
+        """vln_bert: the model the loop calls as vln_bert(mode, batch).  A bare GlocalTextPathNavCMT is wrapped in
+        model.VLNBert so that train() applies the reference's environment feature dropout (models/model.py:19,29-31);
+        a VLNBert, or any other callable (the tests drive the loop with the reference model), is used as given."""
+        from .vilmodel import GlocalTextPathNavCMT
+        if isinstance(vln_bert, GlocalTextPathNavCMT):
+            from .model import VLNBert
+            vln_bert = VLNBert(args, vln_bert=vln_bert)
+        self.args, self.env, self.vln_bert = args, env, vln_bert
+        self.device = torch.device(device)
+        self.scanvp_cands = {}
+        self.feedback = "argmax"
+        self.loss = 0.0
+        self.logs = {"entropy": [], "IL_loss": []}
+        self.trace = None      # optional list: per-step dict(nav_inputs / nav_outs / a_t) for parity tests
+
+    # ---- collation -----------------------------------------------------------------------------
+    def _language_variable(self, obs):
+        lens = [len(ob["instr_encoding"]) for ob in obs]
+        seq = np.zeros((len(obs), max(lens)), dtype=np.int64)
+        mask = np.zeros((len(obs), max(lens)), dtype=bool)
+        for i, ob in enumerate(obs):
+            seq[i, :lens[i]] = ob["instr_encoding"]
+            mask[i, :lens[i]] = True
+        return {"txt_ids": torch.from_numpy(seq).to(self.device), "txt_masks": torch.from_numpy(mask).to(self.device)}
+
+    def _panorama_feature_variable(self, obs):
+        fs = self.args.image_feat_size
+        b_img, b_loc, b_types, b_lens, b_cands = [], [], [], [], []
+        for ob in obs:
+            img, ang, types, cands, used = [], [], [], [], set()
+            for cc in ob["candidate"]:
+                img.append(cc["feature"][:fs])
+                ang.append(cc["feature"][fs:])
+                types.append(1)
+                cands.append(cc["viewpointId"])
+                used.add(int(cc["pointId"]))
+            img.extend([x[:fs] for k, x in enumerate(ob["feature"]) if k not in used])
+            ang.extend([x[fs:] for k, x in enumerate(ob["feature"]) if k not in used])
+            types.extend([0] * (36 - len(used)))
+            img, ang = np.stack(img, 0), np.stack(ang, 0)
+            box = np.array([[1, 1, 1]] * len(img)).astype(np.float32)
+            b_img.append(torch.from_numpy(img))
+            b_loc.append(torch.from_numpy(np.concatenate([ang, box], 1)))
+            b_types.append(torch.LongTensor(types))
+            b_cands.append(cands)
+            b_lens.append(len(img))
+        return {
+            "view_img_fts": pad_tensors(b_img).to(self.device), "loc_fts": pad_tensors(b_loc).to(self.device),
+            "nav_types": pad_tensors(b_types).to(self.device), "view_lens": torch.LongTensor(b_lens).to(self.device),
+            "cand_vpids": b_cands, "obj_img_fts": None, "obj_lens": None,
+        }
+
+    def _nav_gmap_variable(self, obs, gmaps):
+        B = len(obs)
+        b_vpids, b_lens, b_embeds, b_steps, b_pos, b_visited, b_pair, no_vp_left = [], [], [], [], [], [], [], []
+        for i, gmap in enumerate(gmaps):
+            visited, unvisited = [], []
+            for k in gmap.nodes():
+                if self.args.act_visited_nodes:
+                    (visited if k == obs[i]["viewpoint"] else unvisited).append(k)
+                else:
+                    (visited if gmap.visited(k) else unvisited).append(k)
+            no_vp_left.append(len(unvisited) == 0)
+            if self.args.enc_full_graph:
+                vpids = [None] + visited + unvisited
+                vmask = [0] + [1] * len(visited) + [0] * len(unvisited)
+            else:
+                vpids = [None] + unvisited
+                vmask = [0] * len(vpids)
+            steps = [gmap.step_id.get(vp, 0) for vp in vpids]
+            emb = [gmap.embedding(vp) for vp in vpids[1:]]
+            emb = torch.stack([torch.zeros_like(emb[0])] + emb, 0)
+            pos = gmap.pos_features(obs[i]["viewpoint"], vpids, obs[i]["heading"], obs[i]["elevation"])
+            pair = gmap.pair_distances(vpids)
+            b_embeds.append(emb)
+            b_steps.append(torch.LongTensor(steps))
+            b_pos.append(torch.from_numpy(pos))
+            b_pair.append(torch.from_numpy(pair))
+            b_visited.append(torch.BoolTensor(vmask))
+            b_vpids.append(vpids)
+            b_lens.append(len(vpids))
+        lens = torch.LongTensor(b_lens)
+        G = int(lens.max())
+        pair_d = torch.zeros(B, G, G)
+        for i in range(B):
+            pair_d[i, :b_lens[i], :b_lens[i]] = b_pair[i]
+        out = {
+            "gmap_vpids": b_vpids, "gmap_img_embeds": pad_tensors(b_embeds),
+            "gmap_step_ids": pad_tensors(b_steps).to(self.device), "gmap_pos_fts": pad_tensors(b_pos).to(self.device),
+            "gmap_visited_masks": pad_tensors(b_visited, pad=False).to(self.device),
+            "gmap_pair_dists": pair_d.to(self.device), "gmap_masks": gen_seq_masks(lens).to(self.device),
+            "no_vp_left": no_vp_left,
+        }
+        mem = getattr(self.env, "grid_memory", None)
+        if mem is not None and getattr(mem, "slab", None) is not None:
+            out.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)   # device-resident
+        else:
+            out.update(grid_fts=[ob["grid_fts"].to(self.device) for ob in obs],
+                       grid_map=[ob["grid_map"].to(self.device) for ob in obs],
+                       gridmap_pos_fts=torch.stack([ob["gridmap_pos_fts"] for ob in obs], 0).to(self.device))
+        return out
+
+    def _nav_vp_variable(self, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types):
+        B = len(obs)
+        vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
+        b_pos = []
+        for i, gmap in enumerate(gmaps):
+            cand = gmap.pos_features(obs[i]["viewpoint"], cand_vpids[i], obs[i]["heading"], obs[i]["elevation"])
+            start = gmap.pos_features(obs[i]["viewpoint"], [gmap.start_vp], obs[i]["heading"], obs[i]["elevation"])
+            pos = np.zeros((vp_img.size(1), 14), dtype=np.float32)
+            pos[:, :7] = start
+            pos[1:len(cand) + 1, 7:] = cand
+            b_pos.append(torch.from_numpy(pos))
+        nav_masks = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=self.device), nav_types == 1], 1)
+        return {
+            "vp_img_embeds": vp_img, "vp_pos_fts": pad_tensors(b_pos).to(self.device),
+            "vp_masks": gen_seq_masks(view_lens + 1), "vp_nav_masks": nav_masks,
+            "vp_cand_vpids": [[None] + x for x in cand_vpids], "vp_obj_masks": None,
+        }
+
+    def _teacher_action(self, obs, vpids, ended, visited_masks=None):
+        a = np.zeros(len(obs), dtype=np.int64)
+        for i, ob in enumerate(obs):
+            if ended[i]:
+                a[i] = self.args.ignoreid
+            elif ob["viewpoint"] == ob["gt_path"][-1]:
+                a[i] = 0
+            else:
+                scan, cur = ob["scan"], ob["viewpoint"]
+                best, best_d = self.args.ignoreid, float("inf")
+                for j, vp in enumerate(vpids[i]):
+                    if j > 0 and (visited_masks is None or not visited_masks[i][j]):
+                        d = self.env.shortest_distances[scan][vp][ob["gt_path"][-1]] + \
+                            self.env.shortest_distances[scan][cur][vp]
+                        if d < best_d:
+                            best_d, best = d, j
+                a[i] = best
+        return torch.from_numpy(a).to(self.device)
+
+    def make_equiv_action(self, a_t, gmaps, obs, traj):
+        for i, ob in enumerate(obs):
+            action = a_t[i]
+            if action is not None:
+                traj[i]["path"].append(gmaps[i].route(ob["viewpoint"], action))
+                prev = traj[i]["path"][-2][-1] if len(traj[i]["path"][-1]) == 1 else traj[i]["path"][-1][-2]
+                viewidx = self.scanvp_cands["%s_%s" % (ob["scan"], prev)][action]
+                self.env.teleport(i, ob["scan"], action, (viewidx % 12) * math.radians(30),
+                                  (viewidx // 12 - 1) * math.radians(30))
+
+    def _update_scanvp_cands(self, obs):
+        for ob in obs:
+            d = self.scanvp_cands.setdefault("%s_%s" % (ob["scan"], ob["viewpoint"]), {})
+            for cand in ob["candidate"]:
+                d[cand["viewpointId"]] = int(cand["pointId"])
+
+    # ---- the loop --------------------------------------------------------------------------------
+    def rollout(self, train_ml=None, reset=True):
+        obs = self.env.reset() if reset else self.env._get_obs()
+        self._update_scanvp_cands(obs)
+        B = len(obs)
+        gmaps = [TopoMap(ob["viewpoint"]) for ob in obs]
+        for i, ob in enumerate(obs):
+            gmaps[i].observe(ob)
+        traj = [{"instr_id": ob["instr_id"], "path": [[ob["viewpoint"]]], "details": {}} for ob in obs]
+
+        language_inputs = self._language_variable(obs)
+        txt_embeds = self.vln_bert("language", language_inputs)
+
+        ended = np.array([False] * B)
+        just_ended = np.array([False] * B)
+        ml_loss = 0.0
+
+        for t in range(self.args.max_action_len):
+            for i, gmap in enumerate(gmaps):
+                if not ended[i]:
+                    gmap.step_id[obs[i]["viewpoint"]] = t + 1
+
+            pano_inputs = self._panorama_feature_variable(obs)
+            pano_embeds, pano_masks = self.vln_bert("panorama", pano_inputs)
+            avg_pano = torch.sum(pano_embeds * pano_masks.unsqueeze(2), 1) / torch.sum(pano_masks, 1, keepdim=True)
+            for i, gmap in enumerate(gmaps):
+                if not ended[i]:
+                    gmap.add_embedding(obs[i]["viewpoint"], avg_pano[i], overwrite=True)
+                    for j, cvp in enumerate(pano_inputs["cand_vpids"][i]):
+                        if not gmap.visited(cvp):
+                            gmap.add_embedding(cvp, pano_embeds[i, j])
+
+            nav_inputs = self._nav_gmap_variable(obs, gmaps)
+            nav_inputs.update(self._nav_vp_variable(obs, gmaps, pano_embeds, pano_inputs["cand_vpids"],
+                                                    pano_inputs["view_lens"], pano_inputs["nav_types"]))
+            nav_inputs.update({"txt_embeds": txt_embeds, "txt_masks": language_inputs["txt_masks"]})
+            nav_outs = self.vln_bert("navigation", nav_inputs)
+
+            if self.args.fusion == "local":
+                nav_logits, nav_vpids = nav_outs["local_logits"], nav_inputs["vp_cand_vpids"]
+            elif self.args.fusion == "global":
+                nav_logits, nav_vpids = nav_outs["global_logits"], nav_inputs["gmap_vpids"]
+            else:
+                nav_logits, nav_vpids = nav_outs["fused_logits"], nav_inputs["gmap_vpids"]
+            nav_probs = torch.softmax(nav_logits, 1)
+            stop_probs = nav_probs[:, 0].detach().cpu().numpy()       # one D2H per step (reference: B .item() calls)
+            for i, gmap in enumerate(gmaps):
+                if not ended[i]:
+                    gmap.stop_score[obs[i]["viewpoint"]] = {"stop": float(stop_probs[i])}
+
+            nav_targets = None
+            if train_ml is not None or self.feedback == "teacher":
+                nav_targets = self._teacher_action(
+                    obs, nav_vpids, ended,
+                    visited_masks=nav_inputs["gmap_visited_masks"].cpu().numpy() if self.args.fusion != "local" else None)
+            if train_ml is not None:
+                ml_loss = ml_loss + F.cross_entropy(nav_logits, nav_targets, ignore_index=self.args.ignoreid,
+                                                    reduction="sum")
+
+            if self.feedback == "teacher":
+                a_t = nav_targets
+            elif self.feedback == "argmax":
+                a_t = nav_logits.max(1)[1].detach()
+            elif self.feedback == "sample":
+                c = torch.distributions.Categorical(nav_probs)
+                self.logs["entropy"].append(c.entropy().sum().item())
+                a_t = c.sample().detach()
+            elif self.feedback == "expl_sample":        # agent.py:385-395
+                a_t = nav_probs.max(1)[1].detach()
+                rand_explores = np.random.rand(B) > self.args.expl_max_ratio
+                if self.args.fusion == "local":
+                    cpu_nav_masks = nav_inputs["vp_nav_masks"].cpu().numpy()
+                else:
+                    cpu_nav_masks = (nav_inputs["gmap_masks"] & nav_inputs["gmap_visited_masks"].logical_not()).cpu().numpy()
+                for i in range(B):
+                    if rand_explores[i]:
+                        a_t[i] = int(np.random.choice(np.arange(len(cpu_nav_masks[i]))[cpu_nav_masks[i]]))
+            else:
+                raise ValueError("Invalid feedback option: %s" % self.feedback)
+
+            if self.feedback in ("teacher", "sample"):
+                a_t_stop = [ob["viewpoint"] == ob["gt_path"][-1] for ob in obs]
+            else:
+                a_t_stop = (a_t == 0).cpu().numpy()
+            a_t_host = a_t.cpu().numpy()
+
+            if self.trace is not None:
+                self.trace.append({"t": t, "nav_inputs": nav_inputs, "nav_outs": nav_outs, "a_t": a_t_host.copy(),
+                                   "ended": ended.copy(), "nav_vpids": nav_vpids})
+
+            cpu_a_t = []
+            for i in range(B):
+                if a_t_stop[i] or ended[i] or nav_inputs["no_vp_left"][i] or (t == self.args.max_action_len - 1):
+                    cpu_a_t.append(None)
+                    just_ended[i] = True
+                else:
+                    cpu_a_t.append(nav_vpids[i][a_t_host[i]])
+
+            self.make_equiv_action(cpu_a_t, gmaps, obs, traj)
+            for i in range(B):
+                if (not ended[i]) and just_ended[i]:
+                    stop_node, stop_score = None, {"stop": -float("inf")}
+                    for k, v in gmaps[i].stop_score.items():
+                        if v["stop"] > stop_score["stop"]:
+                            stop_score, stop_node = v, k
+                    if stop_node is not None and obs[i]["viewpoint"] != stop_node:
+                        traj[i]["path"].append(gmaps[i].route(obs[i]["viewpoint"], stop_node))
+
+            obs = self.env._get_obs()
+            self._update_scanvp_cands(obs)
+            for i, ob in enumerate(obs):
+                if not ended[i]:
+                    gmaps[i].observe(ob)
+            ended[:] = np.logical_or(ended, np.array([x is None for x in cpu_a_t]))
+            if ended.all():
+                break
+
+        if train_ml is not None:
+            ml_loss = ml_loss * train_ml / B
+            self.loss = self.loss + ml_loss
+            self.logs["IL_loss"].append(float(ml_loss.detach()) if torch.is_tensor(ml_loss) else float(ml_loss))
+        return traj
+
+    # ---- Seq2SeqAgent.test / .train (agent_base.py:150-211) ---------------------------------------
+    def test(self, feedback="argmax", iters=None):
+        """Evaluate once on each instruction of the environment (BaseAgent.test, agent_base.py:49-77)."""
+        self.feedback = feedback
+        self._set_mode(False)
+        self.env.reset_epoch()
+        self.results, looped = {}, False
+        with torch.no_grad():
+            while not looped and (iters is None or iters > 0):
+                for traj in self.rollout():
+                    if traj["instr_id"] in self.results:
+                        looped = True
+                    else:
+                        self.results[traj["instr_id"]] = traj
+                if iters is not None:
+                    iters -= 1
+        return [{"instr_id": k, "trajectory": v["path"]} for k, v in self.results.items()]
+
+    def _set_mode(self, training):
+        m = self.vln_bert
+        if hasattr(m, "train"):
+            m.train(training)
+        mem = getattr(self.env, "grid_memory", None)
+        if mem is not None and hasattr(mem, "keep_for_backward"):
+            mem.keep_for_backward = bool(training)
+
+    # ---- checkpoints in the reference's agent format (agent_base.py:213-259) ------------------------------------
+    def _ckpt_parts(self):
+        if not hasattr(self, "critic"):
+            from .model import Critic
+            self.critic = Critic(self.args).to(self.device)
+        if not hasattr(self, "vln_bert_optimizer"):
+            self.make_optimizer()
+        if not hasattr(self, "critic_optimizer"):
+            self.critic_optimizer = torch.optim.AdamW(self.critic.parameters(), lr=self.args.lr)
+        return (("vln_bert", self.vln_bert, self.vln_bert_optimizer), ("critic", self.critic, self.critic_optimizer))
+
+    def save(self, epoch, path):
+        """{'vln_bert': {epoch, state_dict, optimizer}, 'critic': {...}} -- what the reference's Seq2SeqAgent.save writes."""
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({name: {"epoch": epoch + 1, "state_dict": m.state_dict(), "optimizer": o.state_dict()}
+                    for name, m, o in self._ckpt_parts()}, path)
+
+    def load(self, path):
+        """Loads parameters (and, with args.resume_optimizer, the optimizer states) of a checkpoint in that format, written
+        by this agent or by the reference -- a DistributedDataParallel 'module.' prefix on either side is reconciled and
+        keys the model does not have are skipped, as agent_base.py:230-259 does.  Returns the epoch to resume from."""
+        states = torch.load(path, map_location="cpu")
+        for name, model, opt in self._ckpt_parts():
+            have = model.state_dict()
+            given = states[name]["state_dict"]
+            if set(have) != set(given):
+                mine_ddp = next(iter(have)).startswith("module.")
+                theirs_ddp = next(iter(given)).startswith("module.")
+                if theirs_ddp and not mine_ddp:
+                    given = {k[len("module."):] if k.startswith("module.") else k: v for k, v in given.items()}
+                elif mine_ddp and not theirs_ddp:
+                    given = {"module." + k: v for k, v in given.items()}
+                given = {k: v for k, v in given.items() if k in have}
+            have.update(given)
+            model.load_state_dict(have)
+            if getattr(self.args, "resume_optimizer", False):
+                opt.load_state_dict(states[name]["optimizer"])
+        return states["vln_bert"]["epoch"] - 1
+
+    def make_optimizer(self):
+        """agent_base.py:122-139: one optimizer over all vln_bert parameters at args.lr."""
+        if self.args.optim == "adamW":        # scripts/run_r2r.sh; torch.optim.AdamW semantics on the fused HIP step
+            from .optim import AdamW
+            self.vln_bert_optimizer = AdamW(list(self.vln_bert.parameters()), lr=self.args.lr, betas=(0.9, 0.999),
+                                            eps=1e-8, weight_decay=0.01, decay_first=True)
+        else:
+            opt = {"rms": torch.optim.RMSprop, "adam": torch.optim.Adam, "sgd": torch.optim.SGD}[self.args.optim]
+            self.vln_bert_optimizer = opt(self.vln_bert.parameters(), lr=self.args.lr)
+        from .dist import GradientReducer
+        self.grad_reducer = GradientReducer(self.vln_bert.parameters())
+        return self.vln_bert_optimizer
+
+    def train(self, n_iters, feedback="teacher"):
+        """agent_base.py:164-211: per iteration zero_grad -> rollout(s) accumulate self.loss -> backward ->
+        [all-reduce(mean) of the gradients across ranks, the DDP step] -> clip_grad_norm 40 -> optimizer step."""
+        if not hasattr(self, "vln_bert_optimizer"):
+            self.make_optimizer()
+        self.feedback = feedback
+        self._set_mode(True)
+        self.losses = []
+        for _ in range(n_iters):
+            self.vln_bert_optimizer.zero_grad()
+            self.loss = 0
+            if self.args.train_alg == "imitation":
+                self.feedback = "teacher"
+                self.rollout(train_ml=1.0)
+            elif self.args.train_alg == "dagger":
+                if self.args.ml_weight != 0:
+                    self.feedback = "teacher"
+                    self.rollout(train_ml=self.args.ml_weight)
+                self.feedback = "expl_sample" if self.args.expl_sample else "sample"
+                self.rollout(train_ml=1)
+            else:
+                raise NotImplementedError("train_alg %r (the A2C branch, train_rl=True, is not used by the released "
+                                          "GridMM scripts)" % self.args.train_alg)
+            self.loss.backward()
+            self.grad_reducer.reduce()
+            if self.args.optim == "adamW":
+                self.vln_bert_optimizer.step(max_grad_norm=40.0)          # clip_grad_norm_(40) fused into the step
+            else:
+                torch.nn.utils.clip_grad_norm_(self.vln_bert.parameters(), 40.0)
+                self.vln_bert_optimizer.step()
+            self.losses.append(float(self.loss.detach()))
+        return self.losses

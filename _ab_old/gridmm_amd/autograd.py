@@ -1,0 +1,386 @@
+"""Differentiable wrappers over the HIP kernels (training: SURVEY.md §8 rows a11 / a13 / a14).
+
+The reference trains through torch autograd over nn.Linear / LayerNorm / softmax attention / GELU
+(fine-tune: map_nav_src/r2r/agent_base.py:164-211; pre-train: pretrain_src/train_r2r.py:231-327).  Here
+every one of those ops is a torch.autograd.Function whose forward AND backward are HIP kernels of
+libgridmm_hip.so; torch only records the graph and moves/gathers/concatenates tensors.
+
+  linear      y = x W^T + b            fwd / dX: MFMA bf16x3 tile GEMM (gridmm_linear_planes)
+                                       dW = dY^T X: the same GEMM over transposed planes (gridmm_transpose_split),
+                                       db: column sums from the same transpose pass
+  layer_norm  LN(x (+ r)) g + b        gridmm_layernorm / gridmm_layernorm_bwd
+  gelu, relu                           gridmm_activation
+  attention   softmax(QK^T s + m) V    gridmm_attention_train / gridmm_attention_bwd (exact-fp32 MFMA), optional
+                                       dropout on the probabilities from a counter-based hash (same mask fwd / bwd)
+  grid_aggregate                       gridmm_grid_aggregate / gridmm_grid_aggregate_bwd (grad w.r.t. text_fts)
+
+There is no CPU / eager fallback: the functions raise on non-GPU tensors (ops._p).
+"""
+import math
+import weakref
+
+import torch
+
+from . import _lib, ops
+from .ops import _p, _rows2d, _stream
+
+
+# ------------------------------------------------------------------------------------------------
+# packed-weight cache: bf16 hi/lo planes of W (forward) and W^T (dX), rebuilt when the parameter changes
+# ------------------------------------------------------------------------------------------------
+class _WeightCache:
+    """bf16 hi/lo planes of W (forward GEMM) and W^T (dX GEMM) per nn.Parameter, keyed by the parameter OBJECT
+    (weak) and its version counter, so optimizer steps / load_state_dict re-pack.  Temporaries (torch.cat of q|k|v
+    weights) are never cached: the caching allocator recycles their addresses."""
+
+    def __init__(self):
+        self._ent = {}   # id(param) -> (weakref to param, entry); the weakref's callback drops the entry
+
+    @staticmethod
+    def _pack(w, transposed):
+        src = w.detach().float()
+        return ops.PackedLinear(src.t().contiguous() if transposed else src.contiguous(), None)
+
+    def getter(self, w):
+        """-> get(transposed) returning the PackedLinear of w or w^T."""
+        if not isinstance(w, torch.nn.Parameter):
+            return lambda transposed: self._pack(w, transposed)
+        ver = (w._version, w.data_ptr(), tuple(w.shape))
+        key = id(w)
+        slot = self._ent.get(key)
+        if slot is None or slot[0]() is not w or slot[1]["ver"] != ver:
+            ent = {"ver": ver}
+            self._ent[key] = (weakref.ref(w, lambda _r, key=key: self._ent.pop(key, None)), ent)
+        else:
+            ent = slot[1]
+
+        def get(transposed, ent=ent, w=w):
+            if transposed not in ent:
+                ent[transposed] = self._pack(w, transposed)
+            return ent[transposed]
+        return get
+
+    def clear(self):
+        self._ent.clear()
+
+
+WEIGHTS = _WeightCache()
+SPLITK_OFF = bool(int(__import__('os').environ.get('GRIDMM_SPLITK_OFF', '0')))   # A/B switch for tools/bench_train.py
+
+
+def _as2d(x):
+    x = ops.uniform_rows(x)
+    M, K, ld = _rows2d(x)
+    return x, M, K, ld
+
+
+def _gemm(a2d, pw, bias=None, residual=None):
+    """(M,K) fp32 @ packed (N,K)^T -> (M,N) fp32 through ops.linear (planes kernel when shapes allow)."""
+    pw.bias = bias
+    try:
+        return ops.linear(a2d, pw, residual=residual).f32
+    finally:
+        pw.bias = None
+
+
+def transpose_split(x2d, want_colsum=False, want_rows=False):
+    """fp32 (M,C) -> transposed bf16 hi/lo planes (C,Mp), Mp = roundup(M,32) [, column sums (C,)] [, the row-major
+    planes as an ops.Act] -- one pass over x2d."""
+    lib = _lib.load()
+    x2d, M, C, ld = _as2d(x2d)
+    Mp = (M + 31) // 32 * 32
+    hi = torch.empty(C, Mp, dtype=torch.bfloat16, device=x2d.device)
+    lo = torch.empty_like(hi)
+    cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum else None
+    rows = None
+    if want_rows and C % 8 == 0:
+        rh = torch.empty(M, C, dtype=torch.bfloat16, device=x2d.device)
+        rows = ops.Act(x2d, rh, torch.empty_like(rh))
+    _lib.check(lib.gridmm_transpose_split(_p(x2d), ld, _p(hi), _p(lo), _p(cs), _p(rows.hi if rows else None),
+                                          _p(rows.lo if rows else None), C, M, C, Mp, _stream()),
+               "gridmm_transpose_split")
+    return hi, lo, cs, Mp, rows
+
+
+def _gemm_tn(yt, xt, N, K, M, Mp, dy2d):
+    """dW (N,K) = dY^T X from the transposed planes yt = (hi, lo) of dY and xt of X (contraction over the M rows)."""
+    pw = ops.PackedLinear.__new__(ops.PackedLinear)
+    pw.hi, pw.lo, pw.bias, pw.N, pw.K, pw.Kp = xt[0], xt[1], None, K, Mp, Mp
+    if K % 4 == 0:
+        # few output tiles, long contraction: split the M rows over enough workgroups to fill the chip
+        tiles = -(-N // 128) * -(-K // 128)
+        # measured (profiles/README.md, split-K): only the 768x768 outputs gain (70 -> 47 us at 6912 rows, 52 -> 20 us at 1824)
+        splits = max(1, min(8, 288 // tiles, Mp // 256)) if tiles <= 36 else 1
+        if SPLITK_OFF:
+            splits = 1
+        if splits > 1:
+            lib = _lib.load()
+            dw = torch.empty(N, K, dtype=torch.float32, device=dy2d.device)
+            ws = torch.empty(splits, N, K, dtype=torch.float32, device=dy2d.device)
+            _lib.check(lib.gridmm_linear_planes_splitk(_p(yt[0]), _p(yt[1]), Mp, _p(xt[0]), _p(xt[1]), Mp, _p(dw), _p(ws),
+                                                       N, K, Mp, splits, _stream()), "gridmm_linear_planes_splitk")
+            return dw
+        return ops.linear(ops.Act(None, yt[0], yt[1]), pw).f32
+    # K = 5 / 7 / 14 position-feature layers: fp32-A kernel (any N); A = dY^T zero-padded to Mp columns
+    a = torch.zeros(N, Mp, dtype=torch.float32, device=dy2d.device)
+    a[:, :M] = dy2d.t()
+    return ops.linear(a, pw).f32
+
+
+class _Linear(torch.autograd.Function):
+    """Each activation / gradient is read once per role pair: the forward's input split also emits X^T planes (saved
+    for dW instead of the fp32 input), the backward's dY pass emits row planes (dX GEMM), dY^T planes (dW GEMM) and db."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, packs):
+        K = x.shape[-1]
+        ctx.packs = packs
+        x2 = x.float().contiguous().view(-1, K)
+        r2 = None if residual is None else residual.float().contiguous().view(-1, weight.shape[0])
+        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
+        xt = None
+        a = x2
+        if need_w and K % 8 == 0:
+            xh, xl, _, Mp, rows = transpose_split(x2, want_rows=True)
+            xt, a = (xh, xl, Mp), rows
+        y = _gemm(a, packs(False), None if bias is None else bias.detach().float(), r2)
+        if xt is not None:
+            ctx.save_for_backward(xt[0], xt[1], weight)
+            ctx.Mp, ctx.saved_t = xt[2], True
+        else:
+            ctx.save_for_backward(x2, weight)
+            ctx.saved_t = False
+        ctx.has_bias, ctx.has_res, ctx.M = bias is not None, residual is not None, x2.shape[0]
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight = ctx.saved_tensors[-1]
+        N, K = weight.shape
+        dy2 = dy.contiguous().view(-1, N)
+        M = ctx.M
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx = dw = db = None
+        yh = yl = rows = None
+        if need_w:
+            yh, yl, db, Mp, rows = transpose_split(dy2, want_colsum=ctx.has_bias, want_rows=ctx.needs_input_grad[0])
+        if ctx.needs_input_grad[0]:
+            dx = _gemm(rows if rows is not None else dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
+        if need_w:
+            if ctx.saved_t:
+                xt = (ctx.saved_tensors[0], ctx.saved_tensors[1])
+            else:
+                xh, xl, _, _, _ = transpose_split(ctx.saved_tensors[0])
+                xt = (xh, xl)
+            dw = _gemm_tn((yh, yl), xt, N, K, M, Mp, dy2).to(weight.dtype)
+        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None), None
+
+
+def linear(x, weight, bias=None, residual=None):
+    """x (..., K) @ weight (N, K)^T + bias (+ residual)."""
+    return _Linear.apply(x, weight, bias, residual, WEIGHTS.getter(weight))
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps):
+        x2 = ops.uniform_rows(x.float())
+        r2 = None if residual is None else ops.uniform_rows(residual.float())
+        y = ops.layernorm(x2, gamma.detach(), beta.detach(), eps, residual=r2).f32
+        ctx.save_for_backward(x2, r2, gamma)
+        ctx.eps, ctx.has_res = eps, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, r2, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, H, ldx = _rows2d(x2)
+        dx = torch.empty(x2.shape, dtype=torch.float32, device=dy.device)
+        dg = torch.empty(H, dtype=torch.float32, device=dy.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty((M + 3) // 4 * 2 * H, dtype=torch.float32, device=dy.device)
+        _lib.check(lib.gridmm_layernorm_bwd(_p(x2), ldx, _p(r2), _rows2d(r2)[2] if r2 is not None else 0,
+                                            _p(gamma.detach()), float(ctx.eps), _p(dy), H, _p(dx), H, _p(dg), _p(db),
+                                            _p(ws), M, H, _stream()), "gridmm_layernorm_bwd")
+        return dx, (dx if ctx.has_res else None), dg, db, None
+
+
+def layer_norm(x, mod, residual=None):
+    """mod: nn.LayerNorm-like (weight, bias, eps).  LN(x (+ residual))."""
+    return _LayerNorm.apply(x, residual, mod.weight, mod.bias, mod.eps)
+
+
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        lib = _lib.load()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(lib.gridmm_activation(_p(x), None, _p(y), x.numel(), mode, _stream()), "gridmm_activation")
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(lib.gridmm_activation(_p(x), _p(dy), _p(dx), x.numel(), ctx.mode + 1, _stream()),
+                   "gridmm_activation")
+        return dx, None
+
+
+def gelu(x):
+    return _Activation.apply(x, 0)
+
+
+def relu(x):
+    return _Activation.apply(x, 2)
+
+
+class _Attention(torch.autograd.Function):
+    """q_src (B,Sq,nq*H) with q at column q_col; kv_src (B,Sk,nk*H) with k at k_col, v at v_col (fused projection
+    outputs are consumed in place through strides).  Returns (B,Sq,H)."""
+
+    @staticmethod
+    def forward(ctx, q_src, kv_src, kmask, cols, heads, dropout_p=0.0):
+        lib = _lib.load()
+        H = heads * 64
+        same = kv_src is None
+        if same:
+            kv_src = q_src
+        q_src, kv_src = q_src.contiguous(), kv_src.contiguous()
+        qc, kc, vc = cols
+        B, Sq = q_src.shape[:2]
+        Sk = kv_src.shape[1]
+        q, k, v = q_src[..., qc:qc + H], kv_src[..., kc:kc + H], kv_src[..., vc:vc + H]
+        if kmask is not None:
+            kmask = kmask.contiguous()
+            kmask = kmask.view(torch.uint8) if kmask.dtype == torch.bool else kmask.to(torch.uint8)
+        Sqp = (Sq + 15) // 16 * 16
+        out = torch.empty(B, Sq, H, dtype=torch.float32, device=q_src.device)
+        lse = torch.empty(B, heads, Sqp, dtype=torch.float32, device=q_src.device)
+        scale = 1.0 / math.sqrt(64.0)
+        # one 63-bit seed per call from torch's CPU generator (reproducible under torch.manual_seed); the kernels
+        # derive the keep-mask of element (b,h,q,k) from it, forward and backward alike
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dropout_p > 0 else 0
+        _lib.check(lib.gridmm_attention_train(
+            _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+            _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(lse), Sqp, B, heads, Sq, Sk,
+            scale, float(dropout_p), seed, _stream()), "gridmm_attention_train")
+        ctx.save_for_backward(q_src, kv_src, kmask, out, lse)
+        ctx.cols, ctx.heads, ctx.same, ctx.scale = cols, heads, same, scale
+        ctx.dropout_p, ctx.seed = float(dropout_p), seed
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q_src, kv_src, kmask, out, lse = ctx.saved_tensors
+        heads, H = ctx.heads, ctx.heads * 64
+        qc, kc, vc = ctx.cols
+        B, Sq = q_src.shape[:2]
+        Sk = kv_src.shape[1]
+        Sqp = lse.shape[2]
+        dout = dout.contiguous()
+        dq_src = torch.zeros_like(q_src)
+        dkv_src = dq_src if ctx.same else torch.zeros_like(kv_src)
+        delta = torch.empty_like(lse)
+        q, k, v = q_src[..., qc:qc + H], kv_src[..., kc:kc + H], kv_src[..., vc:vc + H]
+        dq, dk, dv = dq_src[..., qc:qc + H], dkv_src[..., kc:kc + H], dkv_src[..., vc:vc + H]
+        _lib.check(lib.gridmm_attention_bwd(
+            _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+            _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(dout), Sq * H, H, _p(lse),
+            _p(delta), _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0), dk.stride(1), _p(dv), dv.stride(0),
+            dv.stride(1), B, heads, Sq, Sk, Sqp, ctx.scale, ctx.dropout_p, ctx.seed, _stream()), "gridmm_attention_bwd")
+        return dq_src, (None if ctx.same else dkv_src), None, None, None, None
+
+
+def self_attention(qkv, kmask, heads, dropout_p=0.0):
+    """qkv (B,S,3H) = fused [q | k | v] projection.  dropout_p: dropout on the attention probabilities."""
+    H = heads * 64
+    return _Attention.apply(qkv, None, kmask, (0, H, 2 * H), heads, dropout_p)
+
+
+def cross_attention(q, kv, kmask, heads, kv_col=0, dropout_p=0.0):
+    """q (B,Sq,H); kv (B,Sk,n*2H) with [k | v] of this layer at column kv_col."""
+    H = heads * 64
+    return _Attention.apply(q, kv, kmask, (0, kv_col, kv_col + H), heads, dropout_p)
+
+
+def attention_dropout_mask(seed, B, heads, Sq, Sk, p):
+    """The keep-mask the kernels derive from `seed` (host restatement of csrc/common.h dropout_keep; tests only)."""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFF)
+
+    def h32(x):
+        x = x & M
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x85ebca6b)) & M
+        x ^= x >> np.uint64(13); x = (x * np.uint64(0xc2b2ae35)) & M
+        x ^= x >> np.uint64(16)
+        return x & M
+    idx = np.arange(B * heads * Sq * Sk, dtype=np.uint64) & M
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    x = h32(((idx * np.uint64(0x9E3779B1)) & M) ^ lo) ^ hi
+    u = (h32(x) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).reshape(B, heads, Sq, Sk)
+
+
+class _GridAggregate(torch.autograd.Function):
+    """cells (B,196,D) = per-cell softmax(max_l <x_j, text_l>)-weighted sum of the fp16 slab rows."""
+
+    @staticmethod
+    def forward(ctx, text_fts, slab, perm, cell_start):
+        text_fts = text_fts.contiguous()
+        B, L, D = text_fts.shape
+        frag = ops.text_fragments(text_fts)
+        cells, occ, rel, amax = ops.grid_aggregate(slab, perm, cell_start, frag, L, want_relevance=True, want_amax=True)
+        ctx.amax = amax                      # routing of the backward (None: generic kernel, the backward recomputes it)
+        # The grid memory re-bins its whole history in place every step: keep THIS step's point order.  The slab
+        # is append-only within a rollout (rows this step's perm refers to are never rewritten; a training rollout
+        # gets a fresh slab, GridMemoryBatch.reset), so it is referenced, not copied -- and kept out of
+        # save_for_backward, whose version check would trip on the later in-place appends.
+        ctx.save_for_backward(text_fts, perm.clone(), cell_start.clone(), rel)
+        ctx.slab = slab
+        # ... which makes "the slab rows are still the ones this step saw" OUR invariant to check: GridMemoryBatch tags
+        # its slab with an epoch that advances whenever the rows are recycled in place (reset() of a memory that is not
+        # kept for backward); backward refuses to run on a recycled slab instead of returning wrong gradients.
+        ctx.epoch_ref = getattr(slab, "_gridmm_epoch", None)
+        ctx.epoch = None if ctx.epoch_ref is None else ctx.epoch_ref[0]
+        if text_fts.requires_grad and ctx.epoch_ref is not None:
+            slab._gridmm_in_graph = True     # reset() then allocates a fresh slab for the next rollout
+        ctx.mark_non_differentiable(occ)
+        return cells, occ
+
+    @staticmethod
+    def backward(ctx, dcells, _docc):
+        lib = _lib.load()
+        text_fts, perm, cell_start, rel = ctx.saved_tensors
+        slab = ctx.slab
+        if ctx.epoch_ref is not None and ctx.epoch_ref[0] != ctx.epoch:
+            raise RuntimeError("grid_aggregate backward: the grid memory's feature slab was recycled (reset()) after this "
+                               "step's forward; set GridMemoryBatch.keep_for_backward = True for training rollouts")
+        B, L, D = text_fts.shape
+        cap = slab.shape[1]
+        dcells = dcells.contiguous()
+        dtext = torch.empty_like(text_fts)
+        da = torch.empty(B, cap, dtype=torch.float32, device=slab.device)
+        if ctx.amax is not None:
+            dw = torch.empty(B, cap, dtype=torch.float32, device=slab.device)
+            _lib.check(lib.gridmm_grid_aggregate_bwd_routed(_p(slab), _p(perm), _p(cell_start), _p(rel), _p(ctx.amax),
+                                                            _p(dcells), _p(dtext), _p(da), _p(dw), B, cap, D, L,
+                                                            _stream()), "gridmm_grid_aggregate_bwd_routed")
+            return dtext, None, None, None
+        am = torch.empty(B, cap, dtype=torch.int32, device=slab.device)
+        _lib.check(lib.gridmm_grid_aggregate_bwd(_p(slab), _p(perm), _p(cell_start), _p(rel), _p(text_fts),
+                                                 _p(dcells), _p(dtext), _p(da), _p(am), B, cap, D, L, _stream()),
+                   "gridmm_grid_aggregate_bwd")
+        return dtext, None, None, None
+
+
+def grid_aggregate(text_fts, slab, perm, cell_start):
+    return _GridAggregate.apply(text_fts, slab, perm, cell_start)

@@ -1,0 +1,575 @@
+// Backward-pass kernels for training (fine-tune DAgger loop / pre-training).
+//
+// GEMM backward reuses the forward tile kernel (gridmm_linear_planes: C = A B^T on MFMA bf16x3):
+//   dX = dY W      -> A = dY planes [M][N],        "weights" = W^T planes [K][N]        (packed once per weight)
+//   dW = dY^T X    -> A = dY^T planes [N][Mp],     "weights" = X^T planes [K][Mp]       (contraction over rows)
+// so the only new GEMM-side kernel is the transpose+split below (which also yields db = column sums of dY).
+// LayerNorm / GELU / softmax-attention backward are row- or tile-local fp32 kernels.
+#include "common.h"
+
+namespace {
+
+// X fp32 [M][C] (row stride ldx) -> bf16 hi/lo planes [C][Mp] (Mp % 32 == 0, zero padded) and colsum[C]
+// 64 x 64 tiles through LDS; grid (ceil(C/64), ceil(Mp/64)).
+constexpr int TS_TILES = 4;   // 64-row tiles per workgroup (256 rows): 4x fewer column-sum atomics, loads of tile t+1
+                              // are in flight while tile t is split and stored
+__global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ X, int ldx,
+                                                              unsigned short* __restrict__ Th,
+                                                              unsigned short* __restrict__ Tl, float* __restrict__ colsum,
+                                                              unsigned short* __restrict__ Rh,
+                                                              unsigned short* __restrict__ Rl, int ldp,
+                                                              int M, int C, int Mp) {
+  __shared__ float tile[2][64][65];
+  const int c0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int lc = tid & 63, lr = tid >> 6;                 // load role: column lc, rows lr, lr+4, ...
+  const int c = tid >> 2, r0 = (tid & 3) * 16;            // transposed-store role: column c, 16 rows from r0
+  const int rr = tid >> 2, rc = (tid & 3) * 16;           // row-store role: row rr, 16 columns from rc
+  float v[16];
+  auto load = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + lr + 4 * i;
+      v[i] = (m < M && c0 + lc < C) ? X[(size_t)m * ldx + c0 + lc] : 0.f;
+    }
+  };
+  float s = 0.f;
+  const int mbase = blockIdx.y * 64 * TS_TILES;
+  load(mbase);
+  for (int t = 0; t < TS_TILES; ++t) {
+    const int m0 = mbase + 64 * t;
+    if (m0 >= Mp) break;
+    float(*tl)[65] = tile[t & 1];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tl[lr + 4 * i][lc] = v[i];
+    __syncthreads();                                        // (the other buffer's readers finished one barrier ago)
+    if (t + 1 < TS_TILES && m0 + 64 < Mp) load(m0 + 64);    // next tile's global loads fly over the stores below
+    if (Rh && m0 + rr < M) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int c8 = c0 + rc + 8 * half;
+        if (c8 < ldp) {           // ldp % 8 == 0; columns in [C, ldp) are zero (the tile zero-fills beyond C)
+          unsigned int hi[4], lo[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            split2_bf16(tl[rr][rc + 8 * half + 2 * e], tl[rr][rc + 8 * half + 2 * e + 1], hi[e], lo[e]);
+          *reinterpret_cast<uint4*>(Rh + (size_t)(m0 + rr) * ldp + c8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+          *reinterpret_cast<uint4*>(Rl + (size_t)(m0 + rr) * ldp + c8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+      }
+    }
+    if (c0 + c < C) {
+      unsigned int hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = tl[r0 + 2 * e][c], b = tl[r0 + 2 * e + 1][c];
+        s += a + b;
+        split2_bf16(a, b, hi[e], lo[e]);
+      }
+      if (m0 + r0 < Mp) {
+        const size_t o = (size_t)(c0 + c) * Mp + m0 + r0;
+        uint4* ph = reinterpret_cast<uint4*>(Th + o);
+        uint4* pl = reinterpret_cast<uint4*>(Tl + o);
+        ph[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); ph[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+        pl[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); pl[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+      }
+    }
+  }
+  if (colsum) {            // the 4 row-groups of a column sit in adjacent lanes: one atomic per column and workgroup
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((tid & 3) == 0 && c0 + c < C) atomicAdd(&colsum[c0 + c], s);
+  }
+}
+
+// LayerNorm backward, one wave per row.  y = (x - mean) * rstd * gamma + beta,  x = X (+ R)
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+//   dgamma / dbeta: per-workgroup partial sums -> part[blockIdx][2][H], reduced by ln_param_reduce_kernel.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ X, int ldx, const float* __restrict__ R, int ldr, const float* __restrict__ gamma,
+    float eps, const float* __restrict__ dY, int ldy, float* __restrict__ dX, int lddx, float* __restrict__ part,
+    int M, int H) {
+  __shared__ float s_g[4][MAX_H_BWD];
+  __shared__ float s_b[4][MAX_H_BWD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const int nv = H >> 2;
+  float4 xv[NV], gv[NV], dv[NV];
+  const bool live = row < M;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && c < nv) {
+      x = reinterpret_cast<const float4*>(X + (size_t)row * ldx)[c];
+      if (R) {
+        const float4 r = reinterpret_cast<const float4*>(R + (size_t)row * ldr)[c];
+        x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+      }
+      s += (x.x + x.y) + (x.z + x.w);
+    }
+    xv[i] = x;
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (live && c < nv) {
+      const float a = xv[i].x - mean, b = xv[i].y - mean, cc = xv[i].z - mean, d = xv[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), d = g, xh = g;
+    if (live && c < nv) {
+      d = reinterpret_cast<const float4*>(dY + (size_t)row * ldy)[c];
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
+      xh = make_float4((xv[i].x - mean) * rstd, (xv[i].y - mean) * rstd, (xv[i].z - mean) * rstd, (xv[i].w - mean) * rstd);
+      g = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+      sg += (g.x + g.y) + (g.z + g.w);
+      sgx += (g.x * xh.x + g.y * xh.y) + (g.z * xh.z + g.w * xh.w);
+    }
+    xv[i] = xh; gv[i] = g; dv[i] = d;
+  }
+  const float mg = wave_sum(sg) / (float)H, mgx = wave_sum(sgx) / (float)H;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      if (live) {
+        float4 o;
+        o.x = rstd * (gv[i].x - mg - xv[i].x * mgx);
+        o.y = rstd * (gv[i].y - mg - xv[i].y * mgx);
+        o.z = rstd * (gv[i].z - mg - xv[i].z * mgx);
+        o.w = rstd * (gv[i].w - mg - xv[i].w * mgx);
+        reinterpret_cast<float4*>(dX + (size_t)row * lddx)[c] = o;
+      }
+      // per-wave contributions to dgamma (dy * xhat) and dbeta (dy)
+      reinterpret_cast<float4*>(s_g[wave])[c] = live ? make_float4(dv[i].x * xv[i].x, dv[i].y * xv[i].y, dv[i].z * xv[i].z, dv[i].w * xv[i].w)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(s_b[wave])[c] = live ? dv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    part[((size_t)blockIdx.x * 2 + 0) * H + c] = (s_g[0][c] + s_g[1][c]) + (s_g[2][c] + s_g[3][c]);
+    part[((size_t)blockIdx.x * 2 + 1) * H + c] = (s_b[0][c] + s_b[1][c]) + (s_b[2][c] + s_b[3][c]);
+  }
+}
+
+// dgamma[c] = sum_blocks part[blk][0][c], dbeta likewise.  Block = 32 columns x 32 row-lanes: lane r sums blocks
+// r, r+32, ... (coalesced 128-B reads across the 32 columns), then a fixed-order LDS tree -> deterministic.
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ part,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int nblk, int H) {
+  __shared__ float s_g[32][33], s_b[32][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float g = 0.f, b = 0.f;
+  if (c < H)
+    for (int k = ry; k < nblk; k += 32) {
+      g += part[((size_t)k * 2 + 0) * H + c];
+      b += part[((size_t)k * 2 + 1) * H + c];
+    }
+  s_g[ry][cx] = g;
+  s_b[ry][cx] = b;
+  __syncthreads();
+  if (ry == 0 && c < H) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) { sg += s_g[r][cx]; sb += s_b[r][cx]; }
+    dgamma[c] = sg;
+    dbeta[c] = sb;
+  }
+}
+
+// mode 0: y = gelu_erf(x); mode 1: dx = dy * gelu'(x); mode 2: y = relu(x); mode 3: dx = dy * (x > 0)
+__global__ void act_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ out,
+                           size_t n4, int mode) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(X)[i];
+    float4 d = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mode & 1) d = reinterpret_cast<const float4*>(dY)[i];
+    const float xs[4] = {x.x, x.y, x.z, x.w}, ds[4] = {d.x, d.y, d.z, d.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = xs[e];
+      if (mode == 0) o[e] = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+      else if (mode == 1) {
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+        o[e] = ds[e] * (cdf + v * pdf);
+      } else if (mode == 2) o[e] = fmaxf(v, 0.f);
+      else o[e] = v > 0.f ? ds[e] : 0.f;
+    }
+    reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, void* R_hi,
+                                      void* R_lo, int ldp, int M, int C, int Mp, gridmm_stream_t stream) {
+  if (M <= 0 || C <= 0 || Mp < M || Mp % 32) return GRIDMM_EINVAL;
+  if (R_hi && (!R_lo || ldp < C || ldp % 8)) return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (colsum && hipMemsetAsync(colsum, 0, (size_t)C * sizeof(float), st) != hipSuccess) return GRIDMM_ELAUNCH;
+  dim3 grid((C + 63) / 64, (Mp + 64 * TS_TILES - 1) / (64 * TS_TILES)), block(256);
+  GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)T_hi, (unsigned short*)T_lo,
+                colsum, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int ldr, const float* gamma, float eps,
+                                    const float* dY, int ldy, float* dX, int lddx, float* dgamma, float* dbeta,
+                                    float* workspace, int M, int H, gridmm_stream_t stream) {
+  if (M <= 0 || H <= 0 || H % 4 || H > MAX_H_BWD || ldx % 4 || ldy % 4 || lddx % 4 || (R && ldr % 4)) return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nblk = (M + 3) / 4;
+  dim3 grid(nblk), block(256);
+  const int nv = (H / 4 + 63) / 64;
+#define GRIDMM_LNB(NV)                                                                                      \
+  GRIDMM_LAUNCH((layernorm_bwd_kernel<NV>), grid, block, 0, st, X, ldx, R, ldr, gamma, eps, dY, ldy, dX, lddx, \
+                workspace, M, H)
+  if (nv == 1) GRIDMM_LNB(1); else if (nv == 2) GRIDMM_LNB(2); else if (nv == 3) GRIDMM_LNB(3); else GRIDMM_LNB(4);
+#undef GRIDMM_LNB
+  GRIDMM_CHECK_LAUNCH();
+  GRIDMM_LAUNCH(ln_param_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, workspace, dgamma, dbeta, nblk, H);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, int mode,
+                                 gridmm_stream_t stream) {
+  if (n <= 0 || n % 4 || mode < 0 || mode > 3 || ((mode & 1) && !dY)) return GRIDMM_EINVAL;
+  const size_t n4 = (size_t)n / 4;
+  unsigned grid = (unsigned)((n4 + 255) / 256);
+  if (grid > 16384) grid = 16384;
+  GRIDMM_LAUNCH(act_kernel, dim3(grid), dim3(256), 0, as_stream(stream), X, dY, out, n4, mode);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+// ================================================================================================
+// Backward of the instruction-relevance aggregation (gridmm_grid_aggregate) w.r.t. text = text_proj(txt):
+//   w_j = max_l <x_j, t_l>,  a_j = softmax_{j in cell}(w_j),  cells[c] = sum_j a_j x_j
+//   da_j = <dcells[c(j)], x_j>;  dw_j = a_j (da_j - sum_{j' in c} a_j' da_j');  dt[argmax_l(j)] += dw_j x_j
+// (the slab itself is an input, not a parameter).  Two passes over the fp16 slab:
+//   agg_bwd_points_kernel: da_j and argmax_l per point (4 sorted points per wave share every text row load)
+//   agg_bwd_cells_kernel : per (cell, episode) softmax statistics, dw_j, atomic accumulation into dt
+// ================================================================================================
+namespace {
+
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+constexpr int AGG_P = 4;       // points per wave
+constexpr int AGG_MAXV = 6;    // D <= 768: D/128 half2 per lane
+
+template <int NV>
+__global__ __launch_bounds__(256) void agg_bwd_points_kernel(
+    const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
+    const float* __restrict__ text, const float* __restrict__ dcells, float* __restrict__ da,
+    int32_t* __restrict__ amax, int cap, int D, int L) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  const int valid = cs[GRIDMM_CELLS];
+  const int p0 = (blockIdx.x * 4 + wave) * AGG_P;
+  if (p0 >= valid) return;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+  float2 x[AGG_P][NV];
+  int slot[AGG_P];
+  float dav[AGG_P];
+#pragma unroll
+  for (int p = 0; p < AGG_P; ++p) {
+    const int pos = min(p0 + p, valid - 1);
+    slot[p] = perm_b[pos];
+    // cell of sorted position pos: largest c with cs[c] <= pos (binary search over 197 boundaries)
+    int lo = 0, hi = GRIDMM_CELLS;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cs[mid] <= pos) lo = mid; else hi = mid;
+    }
+    const f16x2_t* xr = reinterpret_cast<const f16x2_t*>(slab + ((size_t)b * cap + slot[p]) * D);
+    const float2* dc = reinterpret_cast<const float2*>(dcells + ((size_t)b * GRIDMM_CELLS + lo) * D);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      x[p][i] = make_float2(0.f, 0.f);
+      if (lane + 64 * i < D / 2) {
+        const f16x2_t h = xr[lane + 64 * i];
+        x[p][i] = make_float2((float)h[0], (float)h[1]);
+        const float2 d = dc[lane + 64 * i];
+        s += x[p][i].x * d.x + x[p][i].y * d.y;
+      }
+    }
+    dav[p] = wave_sum(s);
+  }
+  float best[AGG_P];
+  int arg[AGG_P];
+#pragma unroll
+  for (int p = 0; p < AGG_P; ++p) { best[p] = -3.0e38f; arg[p] = 0; }
+  const float2* tb = reinterpret_cast<const float2*>(text + (size_t)b * L * D);
+  for (int l = 0; l < L; ++l) {
+    float2 t[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      t[i] = (lane + 64 * i < D / 2) ? tb[(size_t)l * (D / 2) + lane + 64 * i] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < AGG_P; ++p) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) s += x[p][i].x * t[i].x + x[p][i].y * t[i].y;
+      s = wave_sum(s);
+      if (s > best[p]) { best[p] = s; arg[p] = l; }   // first maximum wins (torch.max returns the first index)
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int p = 0; p < AGG_P; ++p)
+      if (p0 + p < valid) {
+        da[(size_t)b * cap + slot[p]] = dav[p];
+        amax[(size_t)b * cap + slot[p]] = arg[p];
+      }
+  }
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* s_red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = s_red[0];
+  for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, s_red[w]) : r + s_red[w];
+  return r;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void agg_bwd_cells_kernel(
+    const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
+    const float* __restrict__ relevance, const float* __restrict__ da, const int32_t* __restrict__ amax,
+    float* __restrict__ dtext, int cap, int D, int L) {
+  __shared__ float s_red[4];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  const int beg = cs[c], end = cs[c + 1];
+  if (end <= beg) return;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+  const float* w = relevance + (size_t)b * cap;
+  const float* dab = da + (size_t)b * cap;
+  float m = -3.0e38f;
+  for (int p = beg + tid; p < end; p += 256) m = fmaxf(m, w[p]);     // relevance is stored by sorted position
+  m = block_reduce(m, s_red, true);
+  float z = 0.f, sa = 0.f;
+  for (int p = beg + tid; p < end; p += 256) {
+    const int s = perm_b[p];
+    const float e = expf(w[p] - m);
+    z += e;
+    sa += e * dab[s];
+  }
+  z = block_reduce(z, s_red, false);
+  sa = block_reduce(sa, s_red, false) / z;
+  for (int p = beg + wave; p < end; p += 4) {
+    const int s = perm_b[p];
+    const float a = expf(w[p] - m) / z;
+    const float dw = a * (dab[s] - sa);
+    const f16x2_t* xr = reinterpret_cast<const f16x2_t*>(slab + ((size_t)b * cap + s) * D);
+    float* dt = dtext + ((size_t)b * L + amax[(size_t)b * cap + s]) * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (lane + 64 * i < D / 2) {
+        const f16x2_t h = xr[lane + 64 * i];
+        atomicAdd(dt + 2 * (lane + 64 * i), dw * (float)h[0]);
+        atomicAdd(dt + 2 * (lane + 64 * i) + 1, dw * (float)h[1]);
+      }
+    }
+  }
+}
+
+
+// ---- routed variant: the forward already found the arg-max token of every point (amax, by sorted position), so the
+// backward is three streaming passes with no search, no atomics and a deterministic result:
+//   agg_bwd_da_kernel      da_p = <dcells[cell(p)], x_p>                                  (4 sorted points per wave)
+//   agg_bwd_dw_kernel      per (cell, episode): softmax statistics -> dw_p = a_p (da_p - sum_cell a da)
+//   agg_bwd_gather_kernel  per (token, episode): dt[l] = sum over the points routed to l of dw_p x_p
+template <int NV>
+__global__ __launch_bounds__(256) void agg_bwd_da_kernel(
+    const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
+    const float* __restrict__ dcells, float* __restrict__ da, int cap, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  const int valid = cs[GRIDMM_CELLS];
+  const int p0 = (blockIdx.x * 4 + wave) * AGG_P;
+  if (p0 >= valid) return;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+#pragma unroll
+  for (int p = 0; p < AGG_P; ++p) {
+    const int pos = min(p0 + p, valid - 1);
+    int lo = 0, hi = GRIDMM_CELLS;              // cell of sorted position pos: largest c with cs[c] <= pos
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (cs[mid] <= pos) lo = mid; else hi = mid;
+    }
+    const f16x2_t* xr = reinterpret_cast<const f16x2_t*>(slab + ((size_t)b * cap + perm_b[pos]) * D);
+    const float2* dc = reinterpret_cast<const float2*>(dcells + ((size_t)b * GRIDMM_CELLS + lo) * D);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (lane + 64 * i < D / 2) {
+        const f16x2_t h = xr[lane + 64 * i];
+        const float2 d = dc[lane + 64 * i];
+        s += (float)h[0] * d.x + (float)h[1] * d.y;
+      }
+    }
+    s = wave_sum(s);
+    if (lane == 0 && p0 + p < valid) da[(size_t)b * cap + pos] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void agg_bwd_dw_kernel(const int32_t* __restrict__ cell_start,
+                                                         const float* __restrict__ relevance,
+                                                         const float* __restrict__ da, float* __restrict__ dw, int cap) {
+  __shared__ float s_red[4];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  const int beg = cs[c], end = cs[c + 1];
+  if (end <= beg) return;
+  const float* w = relevance + (size_t)b * cap;      // everything here is indexed by sorted position
+  const float* dab = da + (size_t)b * cap;
+  float m = -3.0e38f;
+  for (int p = beg + tid; p < end; p += 256) m = fmaxf(m, w[p]);
+  m = block_reduce(m, s_red, true);
+  float z = 0.f, sa = 0.f;
+  for (int p = beg + tid; p < end; p += 256) {
+    const float e = expf(w[p] - m);
+    z += e;
+    sa += e * dab[p];
+  }
+  z = block_reduce(z, s_red, false);
+  sa = block_reduce(sa, s_red, false) / z;
+  for (int p = beg + tid; p < end; p += 256) dw[(size_t)b * cap + p] = expf(w[p] - m) / z * (dab[p] - sa);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void agg_bwd_gather_kernel(
+    const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
+    const int32_t* __restrict__ amax, const float* __restrict__ dw, float* __restrict__ dtext, int cap, int D, int L) {
+  __shared__ float s_acc[3][AGG_MAXV * 128];
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int valid = cell_start[(size_t)b * (GRIDMM_CELLS + 2) + GRIDMM_CELLS];
+  const int32_t* am = amax + (size_t)b * cap;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+  const float* dwb = dw + (size_t)b * cap;
+  float2 acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = make_float2(0.f, 0.f);
+  for (int p0 = wave * 64; p0 < valid; p0 += 256) {      // each wave scans its own 64-point groups, in point order
+    const int p = p0 + lane;
+    unsigned long long hit = __ballot(p < valid && am[p] == l);
+    while (hit) {
+      const int q = p0 + __builtin_ctzll(hit);
+      hit &= hit - 1;
+      const float g = dwb[q];
+      const f16x2_t* xr = reinterpret_cast<const f16x2_t*>(slab + ((size_t)b * cap + perm_b[q]) * D);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        if (lane + 64 * i < D / 2) {
+          const f16x2_t h = xr[lane + 64 * i];
+          acc[i].x += g * (float)h[0];
+          acc[i].y += g * (float)h[1];
+        }
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < D / 2) reinterpret_cast<float2*>(s_acc[wave - 1])[lane + 64 * i] = acc[i];
+  }
+  __syncthreads();
+  if (wave == 0) {                                         // fixed summation order: deterministic
+    float2* out = reinterpret_cast<float2*>(dtext + ((size_t)b * L + l) * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (lane + 64 * i < D / 2) {
+        float2 r = acc[i];
+        for (int w = 0; w < 3; ++w) {
+          const float2 o = reinterpret_cast<const float2*>(s_acc[w])[lane + 64 * i];
+          r.x += o.x; r.y += o.y;
+        }
+        out[lane + 64 * i] = r;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                         const float* relevance, const float* text, const float* dcells,
+                                         float* dtext, float* da_ws, int32_t* amax_ws, int B, int cap, int D, int L,
+                                         gridmm_stream_t stream) {
+  if (B <= 0 || cap <= 0 || L <= 0 || D <= 0 || D % 2 || D > 128 * AGG_MAXV) return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(dtext, 0, (size_t)B * L * D * sizeof(float), st) != hipSuccess) return GRIDMM_ELAUNCH;
+  const int nv = (D + 127) / 128;
+  dim3 gp((cap + 4 * AGG_P - 1) / (4 * AGG_P), B), gc(GRIDMM_CELLS, B), block(256);
+#define GRIDMM_AGGB(NV)                                                                                          \
+  do {                                                                                                           \
+    GRIDMM_LAUNCH((agg_bwd_points_kernel<NV>), gp, block, 0, st, (const _Float16*)slab, perm, cell_start, text,  \
+                  dcells, da_ws, amax_ws, cap, D, L);                                                            \
+    GRIDMM_CHECK_LAUNCH();                                                                                       \
+    GRIDMM_LAUNCH((agg_bwd_cells_kernel<NV>), gc, block, 0, st, (const _Float16*)slab, perm, cell_start,         \
+                  relevance, da_ws, amax_ws, dtext, cap, D, L);                                                  \
+    GRIDMM_CHECK_LAUNCH();                                                                                       \
+  } while (0)
+  switch (nv) {
+    case 1: GRIDMM_AGGB(1); break;
+    case 2: GRIDMM_AGGB(2); break;
+    case 3: GRIDMM_AGGB(3); break;
+    case 4: GRIDMM_AGGB(4); break;
+    case 5: GRIDMM_AGGB(5); break;
+    default: GRIDMM_AGGB(6); break;
+  }
+#undef GRIDMM_AGGB
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                                const float* relevance, const int32_t* amax, const float* dcells,
+                                                float* dtext, float* da_ws, float* dw_ws, int B, int cap, int D, int L,
+                                                gridmm_stream_t stream) {
+  if (B <= 0 || cap <= 0 || L <= 0 || D <= 0 || D % 2 || D > 128 * AGG_MAXV) return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nv = (D + 127) / 128;
+  dim3 gp((cap + 4 * AGG_P - 1) / (4 * AGG_P), B), gc(GRIDMM_CELLS, B), gl(L, B), block(256);
+#define GRIDMM_AGGR(NV)                                                                                          \
+  do {                                                                                                           \
+    GRIDMM_LAUNCH((agg_bwd_da_kernel<NV>), gp, block, 0, st, (const _Float16*)slab, perm, cell_start, dcells,    \
+                  da_ws, cap, D);                                                                                \
+    GRIDMM_CHECK_LAUNCH();                                                                                       \
+    GRIDMM_LAUNCH(agg_bwd_dw_kernel, gc, block, 0, st, cell_start, relevance, da_ws, dw_ws, cap);                \
+    GRIDMM_CHECK_LAUNCH();                                                                                       \
+    GRIDMM_LAUNCH((agg_bwd_gather_kernel<NV>), gl, block, 0, st, (const _Float16*)slab, perm, cell_start, amax,  \
+                  dw_ws, dtext, cap, D, L);                                                                      \
+    GRIDMM_CHECK_LAUNCH();                                                                                       \
+  } while (0)
+  switch (nv) {
+    case 1: GRIDMM_AGGR(1); break;
+    case 2: GRIDMM_AGGR(2); break;
+    case 3: GRIDMM_AGGR(3); break;
+    case 4: GRIDMM_AGGR(4); break;
+    case 5: GRIDMM_AGGR(5); break;
+    default: GRIDMM_AGGR(6); break;
+  }
+#undef GRIDMM_AGGR
+  return GRIDMM_OK;
+}

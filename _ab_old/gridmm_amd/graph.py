@@ -1,0 +1,131 @@
+"""hipGraph replay of one navigation step (fill_gridmap + forward('navigation')).
+
+The step is ~130 short kernels; launched eagerly from Python it is host-bound (launch gaps ~20 % of
+the step).  Everything on the device side is graph-capturable by construction: the C-ABI only enqueues
+kernels on the caller's stream, the point counters live on the device, and the per-step host inputs
+(pose, heading: a few floats per episode) go through static pinned->device buffers OUTSIDE the graph.
+torch.cuda.CUDAGraph is a hipGraph on ROCm; capture sees the C-ABI launches because they are issued on
+torch's current (capturing) stream.
+
+Shapes are static per graph (B, L, G, V, memory depth): an agent loop would keep one graph per shape
+bucket; bench.py uses one.
+"""
+import torch
+
+
+class GraphedNavStep:
+    def __init__(self, model, mem, batch, depth, restore=None, warmup=2):
+        """depth: (B, n_pts) uint16 device tensor of the observation appended by each step.
+        restore: optional (n_pts0, bbox0) device tensors copied back before each step, so that every replay
+        appends to the same history prefix (benchmarks at a fixed memory depth t)."""
+        self.model, self.mem, self.batch, self.depth = model, mem, dict(batch), depth
+        self.restore = restore
+        dev = mem.device
+        # fused-logit index maps (integer form of the reference's per-call vpid loops, vilmodel.py:881-899): static device
+        # buffers read by the graph, refreshed from pinned host buffers by refresh_fusion_maps() before a replay
+        fm = self.batch.get("fusion_maps")
+        if fm is None:
+            fm = model.fusion_maps(batch, dev)
+        self._fm_dev = tuple(t.clone() for t in fm)
+        self._fm_host = tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in fm)
+        self._fm_done = None
+        self.batch["fusion_maps"] = self._fm_dev
+        self.batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
+        self.graph = None
+        self.outs = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):             # warm-up on a side stream: weight packing, allocator pools
+            for _ in range(warmup):
+                self._device_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outs = self._device_step()
+
+    def _device_step(self):
+        mem = self.mem
+        if self.restore is not None:
+            mem.n_pts.copy_(self.restore[0])
+            mem.bbox.copy_(self.restore[1])
+        mem.project_and_bin(self.depth)
+        return self.model("navigation", self.batch)
+
+    def refresh_fusion_maps(self, gmap_vpids, gmap_visited_masks, vp_cand_vpids):
+        """Host half of the logit fusion for THIS step: the vpid-keyed loops the reference runs inside every
+        forward('navigation') (vilmodel.py:881-899), as integer maps copied into the graph's static buffers."""
+        G, V = self._fm_dev[0].shape[1], self._fm_dev[1].shape[1]
+        a, b = self.model._fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V)
+        if self._fm_done is not None:
+            self._fm_done.synchronize()           # the previous step's async H2D has consumed the pinned buffers
+        self._fm_host[0].copy_(a)
+        self._fm_host[1].copy_(b)
+        self._fm_dev[0].copy_(self._fm_host[0], non_blocking=True)
+        self._fm_dev[1].copy_(self._fm_host[1], non_blocking=True)
+        self._fm_done = torch.cuda.Event()
+        self._fm_done.record()
+
+    def __call__(self, poses, headings, fusion=None):
+        """poses/headings for the (single) appended observation; fusion = (gmap_vpids, gmap_visited_masks (host),
+        vp_cand_vpids) rebuilds the fused-logit index maps for this step; returns the static output dict."""
+        self.mem.set_pose(poses, headings)
+        if fusion is not None:
+            self.refresh_fusion_maps(*fusion)
+        self.graph.replay()
+        return self.outs
+
+
+class GraphedNavStepGroups:
+    """One hipGraph, several episode groups on concurrent streams.
+
+    A navigation step is ~130 kernels, and half of them work on B x 57 query tokens: at B = 32 those launches occupy
+    a fraction of the 256 CUs for a latency-bound ~10-40 us each.  Episodes are independent, so the batch is cut into
+    groups (each with its own GridMemoryBatch and input dict, the weights are shared) whose kernel chains are captured
+    on separate streams forked from / joined to the capture stream: the hardware scheduler overlaps one group's small
+    kernels with the other's.  Results are identical to the single-group step (same kernels, same per-episode math)."""
+
+    def __init__(self, model, groups, warmup=2):
+        """groups: list of dicts(mem, batch, depth, restore)."""
+        self.model, self.groups = model, groups
+        for g in groups:
+            dev = g["mem"].device
+            g["batch"] = dict(g["batch"])
+            if g["batch"].get("fusion_maps") is None:
+                g["batch"]["fusion_maps"] = model.fusion_maps(g["batch"], dev)
+            g["batch"].update(grid_memory=g["mem"], grid_fts=None, grid_map=None, gridmap_pos_fts=None)
+        self.streams = [torch.cuda.Stream() for _ in groups]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                for g in groups:
+                    self._device_step(g)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            cur = torch.cuda.current_stream()
+            outs = []
+            for g, st in zip(groups, self.streams):
+                st.wait_stream(cur)                       # fork
+                with torch.cuda.stream(st):
+                    outs.append(self._device_step(g))
+            for st in self.streams:
+                cur.wait_stream(st)                       # join
+        self.outs = outs
+
+    def _device_step(self, g):
+        mem = g["mem"]
+        if g.get("restore") is not None:
+            mem.n_pts.copy_(g["restore"][0])
+            mem.bbox.copy_(g["restore"][1])
+        mem.project_and_bin(g["depth"])
+        return self.model("navigation", g["batch"])
+
+    def __call__(self, poses, headings):
+        """poses / headings: per group lists for the appended observation; returns the list of static output dicts."""
+        for g, p, h in zip(self.groups, poses, headings):
+            g["mem"].set_pose(p, h)
+        self.graph.replay()
+        return self.outs

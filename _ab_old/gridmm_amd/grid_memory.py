@@ -1,0 +1,218 @@
+"""Device-resident grid memory: the HIP-backed mirror of the reference's per-episode map state.
+
+Reference (relative to /root/reference):
+  state lists                     map_nav_src/r2r/env.py:141-151 (global_semantic, global_position_x/y,
+                                  global_mask, max/min_x/y, heading, global_map)
+  EnvBatch.getGlobalMap           map_nav_src/r2r/env.py:267-374
+  EnvBatch.get_gridmap_pos_fts    map_nav_src/r2r/env.py:242-265
+  H2D of the whole history/step   map_nav_src/r2r/agent.py:168  (O(t^2) PCIe bytes) -- removed here:
+                                  the slab and the point history stay in HBM, only pose/heading
+                                  (a few floats per episode) cross PCIe each step.
+
+Layout in HBM for B episodes, capacity `cap = max_steps * pts_per_obs` points each:
+  slab       (B, cap, D)  fp16   CLIP patch tokens, appended per step (never re-copied)
+  hist_x/y   (B, cap)     fp32   world XY of every point
+  hist_valid (B, cap)     uint8  depth != 0
+  cell_id    (B, cap)     int16  current egocentric cell (x*14+y) or -1       -> `grid_map`
+  perm       (B, cap)     int32  point indices sorted by (cell, index)
+  cell_start (B, 198)     int32  per-cell ranges of perm
+  bbox (B,4), half_len (B,), pos_fts (B,196,5)
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .synthetic import GridGeometry, NATIVE  # noqa: F401  (geometry description only)
+
+
+class GridMemoryBatch:
+    MAX_BIN_SLICES = 16
+
+    def __init__(self, batch_size, geom=NATIVE, max_steps=16, device="cuda"):
+        """max_steps: observations per episode the slab holds.  A rollout appends max_action_len + 1 of them (one from
+        env.reset(), one after every action incl. the last, r2r/agent.py:268-451): 16 for the default max_action_len = 15."""
+        self.B, self.geom, self.max_steps = batch_size, geom, max_steps
+        self.device = torch.device(device)
+        self.n_new = geom.pts_per_obs
+        self.cap = max_steps * self.n_new
+        B, cap, dev = batch_size, self.cap, self.device
+        self.slab = torch.zeros(B, cap, geom.feat_dim, dtype=torch.float16, device=dev)
+        self.slab._gridmm_epoch = [0]
+        self.hist_x = torch.zeros(B, cap, dtype=torch.float32, device=dev)
+        self.hist_y = torch.zeros(B, cap, dtype=torch.float32, device=dev)
+        self.hist_valid = torch.zeros(B, cap, dtype=torch.uint8, device=dev)
+        self.cell_id = torch.full((B, cap), -1, dtype=torch.int16, device=dev)
+        self.perm = torch.zeros(B, cap, dtype=torch.int32, device=dev)
+        self.cell_start = torch.zeros(B, 198, dtype=torch.int32, device=dev)
+        self.bbox = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        self.half_len = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.pos_fts = torch.zeros(B, 196, 5, dtype=torch.float32, device=dev)
+        self.n_pts = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._bin_ws = torch.empty(B, self.MAX_BIN_SLICES * 17, 197, dtype=torch.int32, device=dev)
+        self.n_pts_host = np.zeros(B, np.int64)
+        self.keep_for_backward = False
+        # static per-step inputs (pinned host -> device): the only bytes that cross PCIe each step
+        self._pose_host = torch.zeros(B, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(B, 2)
+        self._head_host = torch.zeros(B, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(B, 2)
+        self._act_host = torch.ones(B, dtype=torch.uint8).pin_memory() if dev.type == "cuda" else torch.ones(B, dtype=torch.uint8)
+        self.pose_d = torch.zeros(B, 2, dtype=torch.float32, device=dev)
+        self.head_d = torch.zeros(B, 2, dtype=torch.float32, device=dev)
+        self.act_d = torch.ones(B, dtype=torch.uint8, device=dev)
+        self._active = None
+        self._h2d_done = None
+        self._bbox_init = torch.tensor([-10000.0, 10000.0, -10000.0, 10000.0], device=dev).repeat(B, 1)
+        # host-side constants, rounded exactly as NumPy rounds them in env.py:118, 290
+        P = geom.patches
+        base = np.array([(2 * c + 1 - P) / P for c in range(P)] * P, np.float32)
+        self.x_off = torch.from_numpy(base * np.float32(geom.tan_half_fov)).to(dev)
+        self._view_ang = [v * math.pi / (geom.n_views / 2) for v in range(geom.n_views)]
+        self.flags = ops.FLAG_VLNCE if geom.vlnce else 0
+        if geom.vlnce:   # per-episode view tables: angle = v*pi/6 - heading (Policy_ViewSelection_GridMap.py:734)
+            pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
+            self._vcos_host = pin(torch.zeros(B, geom.n_views, dtype=torch.float32))
+            self._vsin_host = pin(torch.zeros(B, geom.n_views, dtype=torch.float32))
+            self.view_cos = torch.zeros(B, geom.n_views, dtype=torch.float32, device=dev)
+            self.view_sin = torch.zeros(B, geom.n_views, dtype=torch.float32, device=dev)
+        else:
+            ang = self._view_ang
+            self.view_cos = torch.tensor([np.float32(math.cos(a)) for a in ang], dtype=torch.float32, device=dev)
+            self.view_sin = torch.tensor([np.float32(math.sin(a)) for a in ang], dtype=torch.float32, device=dev)
+        self.reset()
+
+    def reset(self):
+        """EnvBatch.newEpisodes (env.py:178-194).  Device-only work (graph-capturable).
+
+        With `self.keep_for_backward` set (training rollouts), the feature slab of the finished rollout stays
+        untouched -- autograd nodes of that rollout still read it in backward -- and a fresh one is allocated."""
+        if self.keep_for_backward or getattr(self.slab, "_gridmm_in_graph", False):
+            self.slab = torch.zeros_like(self.slab)      # a live autograd graph reads the old rows (autograd._GridAggregate)
+            self.slab._gridmm_epoch = [0]
+        else:
+            self.slab._gridmm_epoch[0] += 1               # rows are recycled in place: stale backward passes must fail
+        self.bbox.copy_(self._bbox_init)
+        self.n_pts.zero_()
+        self.n_pts_host[:] = 0
+        self.cell_id.fill_(-1)
+
+    # ---- host half of a step: a few floats per episode into static (pinned -> device) buffers
+    def set_pose(self, poses, headings, active=None):
+        """poses: B x (x, y) python floats (viewpoint_info, env.py:286); headings: B python floats.
+        Rounded to fp32 on the host exactly as NumPy does (env.py:118-120, 344-348)."""
+        if self._h2d_done is not None:
+            self._h2d_done.synchronize()          # the previous step's async H2D has consumed the pinned buffers
+        # whole-array writes into the pinned buffers; cos / sin stay libm scalars in double (math.cos, as the reference
+        # computes them) and are rounded to fp32 once, exactly like np.float32(math.cos(a))
+        self._pose_host.numpy()[:] = np.asarray([(pz[0], pz[1]) for pz in poses], dtype=np.float64).astype(np.float32)
+        ang = [(-hd + math.pi) if self.geom.vlnce else -hd for hd in headings]       # env.py:337 / VLN-CE :785
+        self._head_host.numpy()[:] = np.array([(math.cos(a), math.sin(a)) for a in ang], dtype=np.float64).astype(np.float32)
+        self.pose_d.copy_(self._pose_host, non_blocking=True)
+        self.head_d.copy_(self._head_host, non_blocking=True)
+        if self.geom.vlnce:
+            rel = [[a0 - hd for a0 in self._view_ang] for hd in headings]
+            self._vcos_host.numpy()[:] = np.array([[math.cos(a) for a in r] for r in rel], dtype=np.float64).astype(np.float32)
+            self._vsin_host.numpy()[:] = np.array([[math.sin(a) for a in r] for r in rel], dtype=np.float64).astype(np.float32)
+            self.view_cos.copy_(self._vcos_host, non_blocking=True)
+            self.view_sin.copy_(self._vsin_host, non_blocking=True)
+        if active is None:
+            self._active = None
+        else:
+            self._act_host.copy_(torch.from_numpy(np.asarray(active, bool).astype(np.uint8)))
+            self.act_d.copy_(self._act_host, non_blocking=True)
+            self._active = np.asarray(active, bool)
+        if self.device.type == "cuda":
+            self._h2d_done = torch.cuda.Event()
+            self._h2d_done.record()
+
+    # ---- device half: kernel launches only (replayable from a hipGraph)
+    def project_and_bin(self, depth):
+        """depth (B, n_views*ppv) uint16 on the device.  Uses the pose/heading set by set_pose()."""
+        ops.grid_project(depth, self.x_off, self.view_cos, self.view_sin, self.pose_d, self.n_pts, self.hist_x,
+                         self.hist_y, self.hist_valid, self.bbox, self.half_len, self.pos_fts,
+                         None if self._active is None else self.act_d,
+                         self.geom.n_views, self.geom.patches ** 2, self.geom.depth_div, self.flags,
+                         self.geom.max_dist)
+        # one workgroup per episode for small memories, else 8 / 16 slices of the history on their own workgroups
+        # (tools/bench_bin.py: N = 7056: 33 -> 18 us, N = 105840: 274 -> 46 us).  Host-known depth: the choice is static
+        # inside a captured graph.
+        n_after = int(self.n_pts_host.max()) + self.n_new
+        slices = int(os.environ.get("GRIDMM_BIN_SLICES", 0)) or (1 if n_after < 3000 else 8 if n_after < 60000 else 16)
+        ops.grid_bin(self.hist_x, self.hist_y, self.hist_valid, self.n_pts, self.pose_d, self.head_d, self.half_len,
+                     self.cell_id, self.perm, self.cell_start, self.flags, workspace=self._bin_ws, slices=slices)
+
+    def step(self, depth, feats, poses, headings, active=None):
+        """Append one observation per episode and re-bin the whole history (getGlobalMap for all i).
+
+        depth  (B, n_views*ppv) uint16  sampled patch-centre depth (host or device)
+        feats  (B, n_views*ppv, D) fp16 patch tokens (host or device), or None when the producer has
+               already written them in place into `next_slot()` (zero-copy append)
+        poses  B x (x, y) python floats; headings B python floats
+        active optional B bools: inactive episodes are left untouched
+        """
+        B, dev, n_new = self.B, self.device, self.n_new
+        act_host = np.ones(B, bool) if active is None else np.asarray(active, bool)
+        if (self.n_pts_host[act_host] + n_new > self.cap).any():
+            raise ValueError("grid memory capacity exceeded (max_steps=%d)" % self.max_steps)
+        depth = torch.as_tensor(depth).to(dev, non_blocking=True)
+        if self.geom.vlnce:
+            depth = depth.to(torch.float32)                     # habitat depth, metres
+        elif depth.dtype != torch.uint16:
+            depth = depth.to(torch.int32).to(torch.uint16)
+        depth = depth.reshape(B, n_new).contiguous()
+        if feats is not None:
+            feats = torch.as_tensor(feats).to(dev, non_blocking=True).reshape(B, n_new, self.geom.feat_dim)
+            if act_host.all() and (self.n_pts_host == self.n_pts_host[0]).all():
+                n0 = int(self.n_pts_host[0])
+                self.slab[:, n0:n0 + n_new].copy_(feats)
+            else:
+                for b in np.nonzero(act_host)[0]:
+                    n0 = int(self.n_pts_host[b])
+                    self.slab[b, n0:n0 + n_new].copy_(feats[b])
+        self.set_pose(poses, headings, active)
+        self.project_and_bin(depth)
+        self.n_pts_host[act_host] += n_new            # host mirror of the device-side counter
+        return self.pos_fts
+
+    def points_upper_bound(self):
+        """Host-known bound of the points per episode after the step in flight (graph replays append one observation
+        to the restored history without touching the host mirror)."""
+        return min(self.cap, int(self.n_pts_host.max()) + self.n_new)
+
+    def next_slot(self):
+        """(B, n_new, D) view of the slab where the next observation's tokens go (lock-step batches)."""
+        n0 = int(self.n_pts_host[0])
+        assert (self.n_pts_host == n0).all(), "next_slot() needs lock-step episodes"
+        return self.slab[:, n0:n0 + self.n_new]
+
+    # ---- the reference's observation form (env.py:610-612), for drop-in callers and tests
+    def grid_fts(self, b):
+        return self.slab[b, :int(self.n_pts_host[b])]
+
+    def grid_map(self, b):
+        return self.cell_id[b, :int(self.n_pts_host[b])].to(torch.float64)
+
+    def as_reference_obs(self):
+        return ([self.grid_fts(b) for b in range(self.B)], [self.grid_map(b) for b in range(self.B)],
+                self.pos_fts)
+
+
+def pack_reference_lists(grid_fts, grid_map):
+    """List form (agent.py:168: per-episode (N_b, D) fp16 + (N_b,) float64 ids) -> packed slab + sorted lists."""
+    B = len(grid_fts)
+    dev = grid_fts[0].device
+    D = grid_fts[0].shape[1]
+    n = [int(t.shape[0]) for t in grid_fts]
+    cap = max(max(n), 1)
+    slab = torch.zeros(B, cap, D, dtype=torch.float16, device=dev)
+    ids = torch.full((B, cap), -1, dtype=torch.int16, device=dev)
+    for b in range(B):
+        if n[b]:
+            slab[b, :n[b]].copy_(grid_fts[b].to(torch.float16))
+            ids[b, :n[b]].copy_(grid_map[b].to(torch.int16))
+    n_pts = torch.tensor(n, dtype=torch.int32, device=dev)
+    perm = torch.empty(B, cap, dtype=torch.int32, device=dev)
+    cell_start = torch.empty(B, 198, dtype=torch.int32, device=dev)
+    ops.grid_sort_ids(ids, n_pts, perm, cell_start)
+    return slab, perm, cell_start

@@ -1,0 +1,564 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/gridmm.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all
+arithmetic on the hot path happens inside libgridmm_hip.so.  Every wrapper
+raises if a tensor is not on the GPU - there is no fallback.
+"""
+import ctypes
+import math
+
+import os
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_QUICKGELU = 0, 1, 2, 3
+N_CELLS = 196
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing (bench.py roofline leg).  Events are recorded on the
+    stream the kernels are launched on (torch's current stream == the stream passed to the C-ABI)."""
+
+    def __init__(self):
+        self.records = []  # (name, work, start_event, end_event)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, name, work, start):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.records.append((name, work, start, e))
+
+    def summary(self):
+        """name -> dict(calls, ms, work) after a device synchronize."""
+        out = {}
+        for name, work, s, e in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "work": 0.0})
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["work"] += work
+        return out
+
+
+TIMER = None  # set to a KernelTimer() to time launches
+
+
+def _timed(name, work, fn):
+    if TIMER is None:
+        return fn()
+    s = TIMER.begin()
+    r = fn()
+    TIMER.end(name, work, s)
+    return r
+
+
+def _p(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise _lib.GridmmLibraryError("gridmm ops need GPU tensors (got %s); no CPU fallback exists" % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _rows2d(t):
+    """View (..., H) with contiguous last dim as (M, H) + row stride; requires a uniform row stride."""
+    if t.stride(-1) != 1:
+        raise ValueError("last dim must be contiguous")
+    if t.dim() == 1:
+        return 1, t.shape[0], t.shape[0]
+    H = t.shape[-1]
+    rs = t.stride(-2)
+    M = 1
+    for d in range(t.dim() - 1):
+        M *= t.shape[d]
+    # leading dims must fold onto a single stride
+    exp = rs
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise ValueError("tensor rows are not uniformly strided: %s %s" % (tuple(t.shape), t.stride()))
+        exp *= t.shape[d]
+    return M, H, rs
+
+
+class PackedLinear:
+    """bf16 hi/lo planes of a Linear weight (N, K) zero-padded to Kp = roundup(K, 32), plus fp32 bias."""
+
+    __slots__ = ("hi", "lo", "bias", "N", "K", "Kp")
+
+    def __init__(self, weight, bias=None):
+        lib = _lib.load()
+        w = weight.detach().to(torch.float32).contiguous()
+        self.N, self.K = w.shape
+        self.Kp = (self.K + 31) // 32 * 32
+        self.hi = torch.empty(self.N, self.Kp, dtype=torch.bfloat16, device=w.device)
+        self.lo = torch.empty_like(self.hi)
+        _lib.check(lib.gridmm_split_weight(_p(w), _p(self.hi), _p(self.lo), self.N, self.K, self.Kp, _stream()),
+                   "gridmm_split_weight")
+        self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+
+
+def _is_uniform(t):
+    try:
+        _rows2d(t)
+        return True
+    except ValueError:
+        return False
+
+
+def uniform_rows(t):
+    """Return t if its rows fold onto one stride, else a packed copy (device-side gridmm_copy_rows)."""
+    if _is_uniform(t):
+        return t
+    if t.dim() == 3 and t.stride(2) == 1 and t.dtype == torch.float32 and t.shape[2] % 4 == 0:
+        out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+        return copy_rows(t, out, 0)
+    return t.contiguous()
+
+
+class Act:
+    """An activation in up to two device representations: fp32 (residual / LayerNorm / attention
+    input) and bf16 hi/lo planes (A operand of the next MFMA GEMM, written by the producer kernel)."""
+
+    __slots__ = ("f32", "hi", "lo")
+
+    def __init__(self, f32=None, hi=None, lo=None):
+        self.f32, self.hi, self.lo = f32, hi, lo
+
+    @property
+    def shape(self):
+        return (self.f32 if self.f32 is not None else self.hi).shape
+
+    @property
+    def device(self):
+        return (self.f32 if self.f32 is not None else self.hi).device
+
+
+def _planes_like(shape, device):
+    """hi / lo planes as the two halves of ONE allocation: a pair moves with a single copy_rows launch."""
+    buf = torch.empty((2,) + tuple(shape), dtype=torch.bfloat16, device=device)
+    return buf[0], buf[1]
+
+
+def split_rows(x):
+    """fp32 (..., K) -> Act with bf16 hi/lo planes (K % 8 == 0)."""
+    lib = _lib.load()
+    x = uniform_rows(x)
+    M, K, ldx = _rows2d(x)
+    assert K % 8 == 0
+    hi, lo = _planes_like(x.shape, x.device)
+    _timed("split_rows", 0.0, lambda: _lib.check(
+        lib.gridmm_split_rows(_p(x), ldx, _p(hi), _p(lo), K, M, K, _stream()), "gridmm_split_rows"))
+    return Act(x, hi, lo)
+
+
+def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_planes=False):
+    """act(x @ W^T + b) (+ residual) -> Act.  x: Act or fp32 tensor (..., K).
+
+    K % 32 == 0 (every hidden-size GEMM): gridmm_linear_planes -- A as bf16 planes (taken from the
+    producer, or split here for external fp32 inputs), LDS-DMA pipeline.  Otherwise (K = 5 / 7 / 14
+    position features): gridmm_linear with the split done in the kernel.
+    """
+    lib = _lib.load()
+    a = x if isinstance(x, Act) else Act(x)
+    shape = a.shape
+    K = shape[-1]
+    if K != pw.K:
+        raise ValueError("linear: bad input %s for weight (%d,%d)" % (tuple(shape), pw.N, pw.K))
+    if residual is not None:
+        residual = uniform_rows(residual)
+    oshape = tuple(shape[:-1]) + (pw.N,)
+    dev = a.device
+    if (K % 32 == 0) and (pw.N % 4 == 0):
+        if a.hi is None or not _is_uniform(a.hi):
+            a = split_rows(a.f32)
+        M, _, lda = _rows2d(a.hi)
+        c = out if out is not None else (torch.empty(oshape, dtype=torch.float32, device=dev) if want_f32 else None)
+        hi = lo = None
+        if want_planes:
+            hi, lo = _planes_like(oshape, dev)
+        ldc = _rows2d(c)[2] if c is not None else 0
+        ldr = _rows2d(residual)[2] if residual is not None else 0
+        _timed("linear", 2.0 * M * pw.N * K, lambda: _lib.check(
+            lib.gridmm_linear_planes(_p(a.hi), _p(a.lo), lda, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual),
+                                     ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream()),
+            "gridmm_linear_planes"))
+        return Act(c, hi, lo)
+    xf = uniform_rows(a.f32)
+    M, _, lda = _rows2d(xf)
+    if xf.dtype != torch.float32:
+        raise ValueError("linear: fp32 input expected")
+    c = out if out is not None else torch.empty(oshape, dtype=torch.float32, device=dev)
+    ldc = _rows2d(c)[2]
+    ldr = _rows2d(residual)[2] if residual is not None else 0
+    _timed("linear_small", 2.0 * M * pw.N * K, lambda: _lib.check(
+        lib.gridmm_linear(_p(xf), lda, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual), ldr,
+                          _p(c), ldc, M, pw.N, K, act, _stream()), "gridmm_linear"))
+    return split_rows(c) if want_planes else Act(c)
+
+
+def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=None, out=None,
+              want_f32=True, want_planes=False):
+    """LN(x (+ residual)) * gamma + beta (+ add1) (+ table[idx]) -> Act (fp32 and/or bf16 planes)."""
+    lib = _lib.load()
+    if isinstance(x, Act):
+        x = x.f32
+    x = uniform_rows(x)
+    residual = None if residual is None else uniform_rows(residual)
+    add1 = None if add1 is None else uniform_rows(add1)
+    M, H, ldx = _rows2d(x)
+    final = None
+    if out is not None and not _is_uniform(out):
+        final, out = out, None
+    if out is None and (want_f32 or final is not None):
+        out = torch.empty(*x.shape, dtype=torch.float32, device=x.device)
+    ldy = _rows2d(out)[2] if out is not None else 0
+    hi = lo = None
+    if want_planes:
+        hi, lo = _planes_like(x.shape, x.device)
+    ldr = ld1 = 0
+    if residual is not None:
+        _, _, ldr = _rows2d(residual)
+    if add1 is not None:
+        _, _, ld1 = _rows2d(add1)
+    if idx is not None:
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        assert idx.numel() == M
+    _timed("layernorm", 0.0, lambda: _lib.check(
+        lib.gridmm_layernorm(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(beta), float(eps), _p(out), ldy,
+                             _p(add1), ld1, _p(table), _p(idx), _p(hi), _p(lo), H, M, H, _stream()),
+        "gridmm_layernorm"))
+    if final is not None:
+        copy_rows(out, final, 0)
+        out = final
+    return Act(out, hi, lo)
+
+
+def attention(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True):
+    """q (B,Sq,H*64) / k,v (B,Sk,H*64) fp32, possibly strided views into fused QKV buffers; kmask (B,Sk)
+    uint8/bool.  Returns an Act (bf16 planes for the output projection by default)."""
+    lib = _lib.load()
+    B, Sq, HD = q.shape
+    Sk = k.shape[1]
+    assert HD == heads * 64 and k.shape[2] == HD and v.shape[2] == HD
+    for t in (q, k, v):
+        assert t.stride(2) == 1 and t.dtype == torch.float32
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    out = torch.empty(B, Sq, HD, dtype=torch.float32, device=q.device) if want_f32 else None
+    hi = lo = None
+    if want_planes:
+        hi, lo = _planes_like((B, Sq, HD), q.device)
+    if kmask is not None:
+        if kmask.dtype == torch.bool:
+            kmask = kmask.view(torch.uint8)
+        assert kmask.shape == (B, Sk) and kmask.stride(1) == 1
+    _timed("attention", 4.0 * B * Sq * Sk * HD, lambda: _lib.check(lib.gridmm_attention(
+        _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+        _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * HD, HD, _p(hi), _p(lo), Sq * HD, HD,
+        B, heads, Sq, Sk, float(scale), _stream()), "gridmm_attention"))
+    return Act(out, hi, lo)
+
+
+def attention_planes(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True):
+    """bf16x3 attention.  q, k, v: (hi, lo) pairs of bf16 plane views (B,S,H*64) -- typically slices of the
+    fused QKV GEMM's plane output.  Returns an Act (planes for the output projection by default)."""
+    lib = _lib.load()
+    qh, ql = q
+    kh, kl = k
+    vh, vl = v
+    B, Sq, HD = qh.shape
+    Sk = kh.shape[1]
+    assert HD == heads * 64 and kh.shape[2] == HD and vh.shape[2] == HD
+    for t in (qh, ql, kh, kl, vh, vl):
+        assert t.dtype == torch.bfloat16 and t.stride(2) == 1
+    assert qh.stride() == ql.stride() and kh.stride() == kl.stride() and vh.stride() == vl.stride()
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    Skp = (Sk + 31) // 32 * 32
+    dev = qh.device
+    th = torch.empty(B, heads, Skp // 32, 64, 32, dtype=torch.bfloat16, device=dev)   # re-tiled V (see attention.hip)
+    tl = torch.empty_like(th)
+    _timed("transpose_v", 0.0, lambda: _lib.check(
+        lib.gridmm_transpose_v(_p(vh), _p(vl), vh.stride(0), vh.stride(1), _p(th), _p(tl), B, heads, Sk, Skp,
+                               _stream()), "gridmm_transpose_v"))
+    out = torch.empty(B, Sq, HD, dtype=torch.float32, device=dev) if want_f32 else None
+    hi = lo = None
+    if want_planes:
+        hi, lo = _planes_like((B, Sq, HD), dev)
+    if kmask is not None:
+        if kmask.dtype == torch.bool:
+            kmask = kmask.view(torch.uint8)
+        assert kmask.shape == (B, Sk) and kmask.stride(1) == 1
+    _timed("attention", 4.0 * B * Sq * Sk * HD, lambda: _lib.check(lib.gridmm_attention_planes(
+        _p(qh), _p(ql), qh.stride(0), qh.stride(1), _p(kh), _p(kl), kh.stride(0), kh.stride(1), _p(th), _p(tl), Skp,
+        _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * HD, HD, _p(hi), _p(lo), Sq * HD, HD,
+        B, heads, Sq, Sk, float(scale), _stream()), "gridmm_attention_planes"))
+    return Act(out, hi, lo)
+
+
+def attention_rows(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True, cfg=0):
+    """bf16x3 attention straight from row-major planes.  q, k, v: (hi, lo) pairs of bf16 plane views (B,S,H*64) --
+    typically column slices of the fused QKV / KV GEMM outputs; K and V rows are staged in LDS by the kernel (no
+    re-tiling pass).  Returns an Act (planes for the output projection by default)."""
+    lib = _lib.load()
+    qh, ql = q
+    kh, kl = k
+    vh, vl = v
+    B, Sq, HD = qh.shape
+    Sk = kh.shape[1]
+    assert HD == heads * 64 and kh.shape[2] == HD and vh.shape == kh.shape
+    for t in (qh, ql, kh, kl, vh, vl):
+        assert t.dtype == torch.bfloat16 and t.stride(2) == 1
+    assert qh.stride() == ql.stride() and kh.stride() == kl.stride() and vh.stride() == vl.stride()
+    if scale is None:
+        scale = 1.0 / math.sqrt(64.0)
+    dev = qh.device
+    out = torch.empty(B, Sq, HD, dtype=torch.float32, device=dev) if want_f32 else None
+    hi = lo = None
+    if want_planes:
+        hi, lo = _planes_like((B, Sq, HD), dev)
+    if kmask is not None:
+        if kmask.dtype == torch.bool:
+            kmask = kmask.view(torch.uint8)
+        assert kmask.shape == (B, Sk) and kmask.stride(1) == 1
+    _timed("attention", 4.0 * B * Sq * Sk * HD, lambda: _lib.check(lib.gridmm_attention_rows_cfg(
+        _p(qh), _p(ql), qh.stride(0), qh.stride(1), _p(kh), _p(kl), kh.stride(0), kh.stride(1), _p(vh), _p(vl),
+        vh.stride(0), vh.stride(1), _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * HD, HD,
+        _p(hi), _p(lo), Sq * HD, HD, B, heads, Sq, Sk, float(scale), int(cfg), _stream()), "gridmm_attention_rows"))
+    return Act(out, hi, lo)
+
+
+class _CLinear(ctypes.Structure):
+    _fields_ = [("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("N", ctypes.c_int),
+                ("K", ctypes.c_int), ("Kp", ctypes.c_int)]
+
+
+class _CLn(ctypes.Structure):
+    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float)]
+
+
+class _CXLayer(ctypes.Structure):
+    _fields_ = [(n, _CLinear) for n in ("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o")] + \
+               [(n, _CLn) for n in ("x_ln", "s_ln", "f_ln")]
+
+
+class XLayerWeights:
+    """gridmm_xlayer_t of one cross-modal layer: packed Linears (PackedLinear) and LayerNorm modules; keeps them alive."""
+
+    def __init__(self, xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln):
+        self.keep = (xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln)
+        c = _CXLayer()
+        for name, pw in zip(("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o"), self.keep[:6]):
+            setattr(c, name, _CLinear(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.bias.data_ptr() if pw.bias is not None else None,
+                                      pw.N, pw.K, pw.Kp))
+        for name, ln in zip(("x_ln", "s_ln", "f_ln"), self.keep[6:]):
+            setattr(c, name, _CLn(ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps)))
+        self.c = c
+        self.H, self.I = xq.N, ffn_i.N
+
+
+_XLAYER_WS = {}
+
+
+def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12):
+    """One GraphLXRTXLayer as ONE C call (gridmm_xattn_layer_fwd): x Act (f32 + planes) (B, Sq, H); kv Act planes
+    (B, Sk, n*H) holding the context's K / V projections at columns k_col / v_col.  Returns Act(f32 + planes)."""
+    lib = _lib.load()
+    B, Sq, H = x.f32.shape
+    Sk = kv.hi.shape[1]
+    dev = x.f32.device
+    assert x.f32.is_contiguous() and x.hi.is_contiguous() and kv.hi.stride(2) == 1 and kv.hi.stride() == kv.lo.stride()
+    need = lib.gridmm_xattn_layer_workspace(B, Sq, H, w.I)
+    key = (dev, need)
+    ws = _XLAYER_WS.get(key)
+    if ws is None:
+        ws = _XLAYER_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    y = torch.empty(B, Sq, H, dtype=torch.float32, device=dev)
+    hi, lo = _planes_like((B, Sq, H), dev)
+    cm = ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask
+    sm = self_mask.view(torch.uint8) if self_mask.dtype == torch.bool else self_mask
+    _lib.check(lib.gridmm_xattn_layer_fwd(ctypes.byref(w.c), _p(x.f32), _p(x.hi), _p(x.lo), _p(kv.hi), _p(kv.lo),
+                                          kv.hi.stride(0), kv.hi.stride(1), int(k_col), int(v_col), _p(cm), cm.stride(0),
+                                          _p(sm), sm.stride(0), _p(y), _p(hi), _p(lo), _p(ws), need, B, Sq, Sk, heads,
+                                          _stream()), "gridmm_xattn_layer_fwd")
+    return Act(y, hi, lo)
+
+
+def tokens_to_slab(tokens, slot, n_views):
+    """tokens (B * n_views, T, D) fp32 (T = 1 class token + patches) -> slot (B, n_views * (T-1), D) fp16 view of the grid
+    memory's slab (GridMemoryBatch.next_slot()): the patch tokens land where fill_gridmap expects the new observation."""
+    lib = _lib.load()
+    N, T, D = tokens.shape
+    B = N // n_views
+    assert N == B * n_views and tokens.dtype == torch.float32 and tokens.is_contiguous()
+    assert slot.dtype == torch.float16 and slot.shape == (B, n_views * (T - 1), D) and slot.stride(1) == D and slot.stride(2) == 1
+    _lib.check(lib.gridmm_tokens_to_slab(_p(tokens), T, D, _p(slot), slot.stride(0), B, n_views, _stream()),
+               "gridmm_tokens_to_slab")
+    return slot
+
+
+def ln_dot(x, gamma, beta, eps, w, b0, out=None):
+    lib = _lib.load()
+    if isinstance(x, Act):
+        x = x.f32
+    x = uniform_rows(x)
+    M, H, ldx = _rows2d(x)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], dtype=torch.float32, device=x.device)
+    _lib.check(lib.gridmm_ln_dot(_p(x), ldx, _p(gamma), _p(beta), float(eps), _p(w), _p(b0), _p(out), M, H,
+                                 _stream()), "gridmm_ln_dot")
+    return out
+
+
+def copy_planes(src, dst, dst_row0=0):
+    """dst.hi/lo[:, dst_row0:dst_row0+rows] = src.hi/lo for Act pairs; one launch when both pairs are the halves of one
+    allocation (what _planes_like hands out), else two."""
+    def paired(a):   # lo sits exactly B batch strides behind hi (also true for row slices of such a pair)
+        return (a.hi.shape == a.lo.shape and a.hi.stride() == a.lo.stride() and a.hi.stride(2) == 1
+                and a.lo.data_ptr() - a.hi.data_ptr() == a.hi.shape[0] * a.hi.stride(0) * a.hi.element_size())
+    if paired(src) and paired(dst):
+        B, rows, H = src.hi.shape
+        s2 = torch.as_strided(src.hi, (2 * B, rows, H), src.hi.stride())
+        d2 = torch.as_strided(dst.hi, (2 * B,) + tuple(dst.hi.shape[1:]), dst.hi.stride())
+        copy_rows(s2, d2, dst_row0)
+    else:
+        copy_rows(src.hi, dst.hi, dst_row0)
+        copy_rows(src.lo, dst.lo, dst_row0)
+    return dst
+
+
+def copy_rows(src, dst, dst_row0=0):
+    """dst[:, dst_row0:dst_row0+rows] = src   for (B, rows, H) fp32 tensors (row-contiguous)."""
+    lib = _lib.load()
+    if src.dtype == torch.bfloat16:   # bf16 planes move as packed words
+        assert dst.dtype == torch.bfloat16 and src.shape[2] % 8 == 0 and src.stride(1) % 2 == 0
+        src, dst = src.view(torch.float32), dst.view(torch.float32)
+    B, rows, H = src.shape
+    assert dst.shape[0] == B and dst.shape[2] == H and src.stride(2) == 1 and dst.stride(2) == 1
+    d = dst[:, dst_row0:dst_row0 + rows]
+    _lib.check(lib.gridmm_copy_rows(_p(src), src.stride(0), src.stride(1), _p(d), d.stride(0), d.stride(1),
+                                    B, rows, H, _stream()), "gridmm_copy_rows")
+    return dst
+
+
+def cells_compact(proj, pos_emb, occ, out, mask):
+    """Compact cells into rows [0,196) of out (B,S_pad,H) / mask (B,S_pad); returns (n_cells, cmax) int32 tensors."""
+    lib = _lib.load()
+    B, S_pad, H = out.shape
+    n_cells = torch.empty(B, dtype=torch.int32, device=out.device)
+    cmax = torch.empty(1, dtype=torch.int32, device=out.device)
+    assert out.is_contiguous() and mask.is_contiguous() and mask.shape == (B, S_pad)
+    _lib.check(lib.gridmm_cells_compact(_p(proj), _p(pos_emb), _p(occ), _p(out), _p(mask), _p(n_cells), _p(cmax),
+                                        B, H, S_pad, _stream()), "gridmm_cells_compact")
+    return n_cells, cmax
+
+
+def fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, cand_of_node,
+                cand_visited):
+    lib = _lib.load()
+    B, G = g_raw.shape
+    V = l_raw.shape[1]
+    dev = g_raw.device
+    outs = [torch.empty(B, G, device=dev), torch.empty(B, V, device=dev), torch.empty(B, G, device=dev),
+            torch.empty(B, G, device=dev)]
+    _lib.check(lib.gridmm_fuse_logits(_p(g_raw), _p(l_raw), _p(grid_raw), _p(fuse_raw), _p(gmap_masks),
+                                      _p(gmap_visited), _p(vp_nav_masks), _p(cand_of_node), _p(cand_visited),
+                                      _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), B, G, V, _stream()),
+               "gridmm_fuse_logits")
+    return outs  # global, local, grid, fused
+
+
+FLAG_VLNCE = 1
+
+
+def grid_project(depth, x_off, view_cos, view_sin, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len,
+                 pos_fts, active, n_views, ppv, depth_div, flags=0, max_dist=30.0):
+    lib = _lib.load()
+    B, cap = hist_x.shape
+    depth_f32 = int(depth.dtype == torch.float32)
+    view_stride = n_views if view_cos.dim() == 2 else 0       # per-episode view tables (VLN-CE) or shared
+    _lib.check(lib.gridmm_grid_project(_p(depth), depth_f32, _p(x_off), _p(view_cos), _p(view_sin), view_stride,
+                                       _p(pose), _p(n_old), _p(hist_x), _p(hist_y), _p(hist_valid), _p(bbox),
+                                       _p(half_len), _p(pos_fts), _p(active), B, n_views, ppv, cap, float(depth_div),
+                                       int(flags), float(max_dist), _stream()), "gridmm_grid_project")
+
+
+def grid_bin(hist_x, hist_y, hist_valid, n_pts, pose, head_cs, half_len, cell_id, perm, cell_start, flags=0,
+             workspace=None, slices=1):
+    """slices > 1 (+ workspace (B, slices, 17, 197) int32): the multi-workgroup form for deep memories."""
+    lib = _lib.load()
+    B, cap = hist_x.shape
+    if slices > 1 and workspace is not None:
+        assert workspace.dtype == torch.int32 and workspace.numel() >= B * slices * 17 * 197
+        _lib.check(lib.gridmm_grid_bin_sliced(_p(hist_x), _p(hist_y), _p(hist_valid), _p(n_pts), _p(pose), _p(head_cs),
+                                              _p(half_len), _p(cell_id), _p(perm), _p(cell_start), _p(workspace),
+                                              int(slices), B, cap, int(flags), _stream()), "gridmm_grid_bin_sliced")
+        return
+    _lib.check(lib.gridmm_grid_bin(_p(hist_x), _p(hist_y), _p(hist_valid), _p(n_pts), _p(pose), _p(head_cs),
+                                   _p(half_len), _p(cell_id), _p(perm), _p(cell_start), B, cap, int(flags),
+                                   _stream()), "gridmm_grid_bin")
+
+
+def grid_sort_ids(cell_id, n_pts, perm, cell_start):
+    lib = _lib.load()
+    B, cap = cell_id.shape
+    _lib.check(lib.gridmm_grid_sort_ids(_p(cell_id), _p(n_pts), _p(perm), _p(cell_start), B, cap, _stream()),
+               "gridmm_grid_sort_ids")
+
+
+def text_fragments(text_fts):
+    """(B, L, D) fp32 -> MFMA B-fragment planes (fp16 hi|lo)."""
+    lib = _lib.load()
+    B, L, D = text_fts.shape
+    Lt = (L + 15) // 16
+    frag = torch.empty(B, 2, Lt, D // 32, 64, 8, dtype=torch.float16, device=text_fts.device)
+    _lib.check(lib.gridmm_text_fragments(_p(text_fts.contiguous()), _p(frag), B, L, D, _stream()),
+               "gridmm_text_fragments")
+    return frag
+
+
+def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_relevance=False, n_points=None,
+                   want_amax=False):
+    """slab (B,cap,D) fp16 -> cells (B,196,D) fp32, occ (B,196) uint8 [, relevance (B,cap) fp32: w of the point at
+    SORTED position p, i.e. of slot perm[b, p]].  n_points: host-known upper bound of the points per episode (defaults to
+    the slab capacity); only steers the chunking.  want_amax (training): also returns the arg-max token of every point by
+    sorted position, (B,cap) int32 -- or None when the shape ran on the generic kernel, which does not produce it."""
+    lib = _lib.load()
+    B, cap, D = slab.shape
+    assert slab.dtype == torch.float16 and slab.is_contiguous()
+    if n_chunks is None:
+        n_chunks = max(1, min(N_CELLS, -(-256 // B)))   # one workgroup per CU (256): 155 us vs 180 us with two rounds
+        # chunks are cut at cell boundaries: with deep memories (>~4400 points per workgroup) a few crowded cells unbalance
+        # them, and finer chunks let the dispatcher level the load (t=15: 1110 -> 990 us; t=5 is best with one round)
+        n_chunks = min(N_CELLS, n_chunks * max(1, min(6, round((n_points or cap) / n_chunks / 4400))))
+        if os.environ.get("GRIDMM_AGG_CHUNKS"):
+            n_chunks = int(os.environ["GRIDMM_AGG_CHUNKS"])
+    dev = slab.device
+    cells = torch.empty(B, N_CELLS, D, dtype=torch.float32, device=dev)
+    occ = torch.empty(B, N_CELLS, dtype=torch.uint8, device=dev)
+    # D = 768: the two-pass path needs the relevance buffer as its intermediate (allocated even when not asked for)
+    if want_relevance or want_amax:
+        rel = torch.zeros(B, cap, dtype=torch.float32, device=dev)
+    else:                                   # D = 768: scratch of the two-pass path (only valid positions are written / read)
+        rel = torch.empty(B, cap, dtype=torch.float32, device=dev) if D == 768 else None
+    chunks = torch.empty(B, n_chunks + 1, dtype=torch.int32, device=dev)
+    amax = torch.empty(B, cap, dtype=torch.int32, device=dev) if want_amax else None
+    status = []
+
+    def launch():
+        rc = lib.gridmm_grid_aggregate_train(_p(slab), _p(perm), _p(cell_start), _p(text_frag), _p(cells), _p(occ),
+                                             _p(rel), _p(amax), _p(chunks), B, cap, D, L, n_chunks, _stream())
+        status.append(rc)
+        _lib.check(min(rc, 0), "gridmm_grid_aggregate_train")
+    _timed("grid_aggregate", 0.0, launch)
+    if want_amax:
+        return cells, occ, rel, (amax if status[-1] == 0 else None)
+    return (cells, occ, rel) if want_relevance else (cells, occ)

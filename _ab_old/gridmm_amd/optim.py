@@ -1,0 +1,152 @@
+"""Optimizer, parameter groups and schedule of the pre-training loop, on the fused HIP step.
+
+Reference (relative to /root/reference/pretrain_src):
+  optim/adamw.py:13-112     AdamW with the HuggingFace "weight decay fix" (eps outside the bias correction, decay after
+                            the update, scaled by the raw lr)
+  optim/misc.py:12-37       build_optimizer: no weight decay on 'bias', 'LayerNorm.bias', 'LayerNorm.weight'
+  optim/sched.py:17-30      warmup_linear / get_lr_sched (lr floor 1e-8)
+  train_r2r.py:288-303      clip_grad_norm_(model.parameters(), opts.grad_norm) then optimizer.step()
+The clip and the update are two streaming HIP kernels per tensor (gridmm_grad_sumsq, gridmm_adamw_step); the global
+norm stays on the device, so a step issues no host synchronisation.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _p, _stream
+
+
+def _bump_version(p):
+    """The kernel writes the parameter through its raw pointer: advance the tensor's version counter by hand so that
+    the packed-weight caches (vilmodel._pack, autograd.WEIGHTS) and autograd's saved-tensor checks see the change."""
+    setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+    if setter is not None:
+        setter([p], [p._version + 1])
+    else:
+        p.add_(0)
+
+
+class AdamW(torch.optim.Optimizer):
+    """adamw.py:13-112 (decay_first=False, the pre-training optimizer) or torch.optim.AdamW ordering
+    (decay_first=True, the fine-tune optimizer of agent_base.py:131)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True,
+                 decay_first=False):
+        if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("invalid AdamW hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      correct_bias=correct_bias, decay_first=decay_first))
+        self._sumsq = None
+
+    def _live(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    yield group, p
+
+    # ---- multi-tensor launch tables (fp32 tensors): one record per parameter, rebuilt every step on the host
+    # (gradient tensors are re-allocated by zero_grad) and shipped with ONE small H2D copy
+    _REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
+                     ("lr", "<f4"), ("step_size", "<f4"), ("eps", "<f4"), ("wd", "<f4")])
+    _CHUNK = 16384
+
+    def _tables(self, items, dev):
+        """items: list of (p, g, exp_avg, exp_avg_sq, lr, step_size, eps, wd) for contiguous fp32 tensors."""
+        rec = np.zeros(len(items), self._REC)
+        first = np.zeros(len(items) + 1, np.int32)
+        for i, (p, g, m, v, lr, ss, eps, wd) in enumerate(items):
+            rec[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, ss, eps, wd)
+            first[i + 1] = first[i] + -(-p.numel() // self._CHUNK)
+        blob = np.concatenate([rec.view(np.uint8), first.view(np.uint8)])
+        d = torch.from_numpy(blob).to(dev, non_blocking=True)
+        return d, rec.nbytes, int(first[-1])
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm=None):
+        """max_grad_norm: fuse clip_grad_norm_(all parameters of this optimizer, max_grad_norm) into the update.
+        Returns the (pre-clip) gradient norm as a device scalar when clipping, else None."""
+        lib = _lib.load()
+        multi, single = [], []
+        for group, p in self._live():
+            if p.dtype not in (torch.float32, torch.float16) or not p.is_contiguous():
+                raise ValueError("AdamW: contiguous fp32 / fp16 parameters expected")
+            state = self.state[p]
+            if len(state) == 0:
+                state["step"] = 0
+                state["exp_avg"] = torch.zeros_like(p)
+                state["exp_avg_sq"] = torch.zeros_like(p)
+            state["step"] += 1
+            b1, b2 = group["betas"]
+            step_size, eps = group["lr"], group["eps"]
+            if group["correct_bias"]:
+                bc2 = math.sqrt(1.0 - b2 ** state["step"])
+                step_size = step_size * bc2 / (1.0 - b1 ** state["step"])
+                if group["decay_first"]:
+                    eps = eps * bc2       # torch.optim.AdamW: m/bc1 / (sqrt(v/bc2) + eps) == step_size * m / (sqrt(v) + eps*sqrt(bc2))
+            g = p.grad.contiguous()
+            if g.dtype != p.dtype:
+                g = g.to(p.dtype)
+            item = (p, g, state["exp_avg"], state["exp_avg_sq"], float(group["lr"]), float(step_size), float(eps),
+                    float(group["weight_decay"]), float(b1), float(b2), int(bool(group["decay_first"])))
+            (multi if p.dtype == torch.float32 else single).append(item)
+        if not multi and not single:
+            return None
+        dev = (multi or single)[0][0].device
+        # all fp32 tensors of one (betas, decay order) class go into one launch; the released configs have one class
+        classes = {}
+        for it in multi:
+            classes.setdefault(it[8:], []).append(it[:8])
+        tables = {k: self._tables(v, dev) for k, v in classes.items()}
+        sumsq = None
+        if max_grad_norm is not None:
+            sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+            part = torch.empty(64, dtype=torch.float32, device=dev)
+            tmp = torch.empty(1, dtype=torch.float32, device=dev)
+            for (blob, rec_bytes, n_chunks), items in zip(tables.values(), classes.values()):
+                _lib.check(lib.gridmm_multi_grad_sumsq(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
+                                                       n_chunks, _p(part), _p(tmp), _stream()), "gridmm_multi_grad_sumsq")
+                sumsq += tmp
+            for p, g, *_ in single:
+                _lib.check(lib.gridmm_grad_sumsq(_p(g), g.numel(), 1, _p(sumsq), _stream()), "gridmm_grad_sumsq")
+        for (b1, b2, df), items in classes.items():
+            blob, rec_bytes, n_chunks = tables[(b1, b2, df)]
+            _lib.check(lib.gridmm_multi_adamw_step(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
+                                                   n_chunks, b1, b2, df, _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
+                                                   float(max_grad_norm or 0.0), _stream()), "gridmm_multi_adamw_step")
+        for p, g, m, v, lr, ss, eps, wd, b1, b2, df in single:            # fp16 parameters (the pre-training grid_proj)
+            _lib.check(lib.gridmm_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), 1, lr, b1, b2, eps, wd, ss, df,
+                                             _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
+                                             float(max_grad_norm or 0.0), _stream()), "gridmm_adamw_step")
+        for it in multi + single:
+            _bump_version(it[0])
+        self._keepalive = (tables, multi, single)      # device tables / cast gradients must outlive the async launches
+        return None if sumsq is None else sumsq.sqrt()
+
+
+def build_optimizer(model, opts):
+    """optim/misc.py:12-37."""
+    named = list(model.named_parameters())
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    groups = [
+        {"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": opts.weight_decay},
+        {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
+    ]
+    if opts.optim != "adamw":
+        raise ValueError("invalid optimizer %r (the released configs use adamw, config/r2r_pretrain.json:15)" % opts.optim)
+    return AdamW(groups, lr=opts.learning_rate, betas=tuple(opts.betas))
+
+
+def warmup_linear(step, warmup_step, tot_step):
+    """optim/sched.py:17-21."""
+    if step < warmup_step:
+        return step / warmup_step
+    return max(0, (tot_step - step) / (tot_step - warmup_step))
+
+
+def get_lr_sched(global_step, opts):
+    """optim/sched.py:24-30."""
+    lr = opts.learning_rate * warmup_linear(global_step, opts.warmup_steps, opts.num_train_steps)
+    return lr if lr > 0 else 1e-8

@@ -1,0 +1,383 @@
+/*
+ * gridmm.h — C-ABI of libgridmm_hip.so: hand-written HIP/CDNA4 (gfx950) kernels for the
+ * GridMM grid-memory forward path.
+ *
+ * The reference (MrZihan/GridMM) is 100 % Python: there is no FFI to mirror.  Each entry
+ * point below replaces the stock-op sequence cited next to it (paths relative to the
+ * reference tree).  Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless a
+ *     parameter is marked [host];
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
+ *   - no allocation inside: outputs / workspaces are caller-provided;
+ *   - returns 0 on success, a negative GRIDMM_E* code otherwise (never throws);
+ *   - re-entrant, no global state.
+ */
+#ifndef GRIDMM_H
+#define GRIDMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRIDMM_OK 0
+#define GRIDMM_EINVAL (-1)   /* bad shape / unsupported size */
+#define GRIDMM_ELAUNCH (-1000) /* launch failed: status = -1000 - hipError_t */
+
+#define GRIDMM_GRID 14
+#define GRIDMM_CELLS 196
+
+typedef void* gridmm_stream_t;
+
+/* ABI version of this header (bumped on any signature change). */
+int gridmm_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Grid memory ("fill_gridmap")
+ * ---------------------------------------------------------------------------------------- */
+
+/* Back-project ONE new observation per episode into world XY and append it to the
+ * device-resident point history; update the running bounding box; derive the map scale and
+ * the 196 cell-centre position features.
+ * Replaces: get_rel_position  map_nav_src/r2r/env.py:115-121,
+ *           EnvBatch.getGlobalMap :289-294 (projection), :312-331 (bbox, half_len),
+ *           EnvBatch.get_gridmap_pos_fts :242-265.
+ * Arithmetic is fp32 in the reference's operation order without FMA contraction (bit-exact XY).
+ *   depth      [B][n_pts] uint16, sampled patch-centre depth, view-major (n_pts = n_views*ppv)
+ *   x_off      [ppv] f32   lateral offsets * tan(fov/2)           (host computes, env.py:118)
+ *   view_cos/sin [n_views] f32, cos/sin of the python-double view angle rounded to f32
+ *   pose       [B][2] f32  (x, y) of the current viewpoint rounded to f32
+ *   n_pts      [B] int32   in: points already in the history of each episode; out: += n_views*ppv
+ *                          (kept on the device so that a whole step can be replayed from a hipGraph)
+ *   hist_x/y   [B][cap] f32, hist_valid [B][cap] uint8: history (new points written at n_old[b])
+ *   bbox       [B][4] f32  running (max_x, min_x, max_y, min_y); init (-10000,10000,-10000,10000)
+ *   half_len   [B] f32 out; pos_fts [B][196][5] f32 out
+ *   active     [B] uint8 or NULL: episodes with 0 are skipped entirely
+ * VLN-CE twin (VLN_CE/vlnce_baselines/models/Policy_ViewSelection_GridMap.py:632-641, 689-825), flags bit 0:
+ *   depth_f32 = 1: depth is float32 metres used as is; view_stride = n_views: per-episode view_cos/sin
+ *   [B][n_views] of (v*pi/6 - heading); gy = -ry + y; cell features through the (x, Z, y) reading of
+ *   vlnce_baselines/models/utils.py:125-144; max_dist 25 (R2R-CE) / 40 (RxR-CE) instead of 30.
+ */
+#define GRIDMM_FLAG_VLNCE 1
+int gridmm_grid_project(const void* depth, int depth_f32, const float* x_off, const float* view_cos,
+                        const float* view_sin, int view_stride, const float* pose, int32_t* n_pts,
+                        float* hist_x, float* hist_y, uint8_t* hist_valid, float* bbox,
+                        float* half_len, float* pos_fts, const uint8_t* active,
+                        int B, int n_views, int ppv, int cap, float depth_div, int flags, float max_dist,
+                        gridmm_stream_t stream);
+
+/* Re-bin the WHOLE history of every episode into the current egocentric 14x14 frame and
+ * build the per-cell point lists (stable counting sort by cell id).
+ * Replaces: EnvBatch.getGlobalMap map_nav_src/r2r/env.py:337-369 (rotate, scale, truncate,
+ *           clamp, 196-iteration mask loop).   Cell ids are bit-exact with the reference.
+ *   n_pts      [B] int32   points in each history (after the append)
+ *   head_cs    [B][2] f32  cos/sin of (-heading) rounded to f32 (host)
+ *   cell_id    [B][cap] int16 out: x*14+y, or -1 for invalid depth
+ *   perm       [B][cap] int32 out: point indices sorted by (cell, index); invalid points last
+ *   cell_start [B][198] int32 out: perm range of cell c is [cell_start[c], cell_start[c+1]);
+ *              cell_start[196] = #valid points, cell_start[197] = n_pts
+ */
+int gridmm_grid_bin(const float* hist_x, const float* hist_y, const uint8_t* hist_valid,
+                    const int32_t* n_pts, const float* pose, const float* head_cs,
+                    const float* half_len, int16_t* cell_id, int32_t* perm, int32_t* cell_start,
+                    int B, int cap, int flags, gridmm_stream_t stream);
+/* (flags bit 0 = GRIDMM_FLAG_VLNCE: head_cs = cos/sin(-heading + pi) and map_x = -(tx cos + ty sin)) */
+
+/* Same counting sort for caller-provided cell ids (the reference's `grid_map` list form,
+ * map_nav_src/r2r/agent.py:168): ids are int16 in {-1, 0..195}. */
+int gridmm_grid_sort_ids(const int16_t* cell_id, const int32_t* n_pts, int32_t* perm,
+                         int32_t* cell_start, int B, int cap, gridmm_stream_t stream);
+
+/* gridmm_grid_bin for deep memories: the same result (bit-exact cell ids, the same stable order), with every episode
+ * cut into `slices` contiguous parts handled by their own workgroups (histogram | scan | scatter; 3 launches).
+ *   workspace  [B][slices][17][197] int32 scratch;  slices = 1 (or workspace NULL) runs gridmm_grid_bin.
+ * Replaces: the same lines as gridmm_grid_bin (map_nav_src/r2r/env.py:337-369). */
+int gridmm_grid_bin_sliced(const float* hist_x, const float* hist_y, const uint8_t* hist_valid,
+                           const int32_t* n_pts, const float* pose, const float* head_cs,
+                           const float* half_len, int16_t* cell_id, int32_t* perm, int32_t* cell_start,
+                           int32_t* workspace, int slices, int B, int cap, int flags, gridmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Instruction-relevance grid aggregation
+ * ---------------------------------------------------------------------------------------- */
+
+/* Split text_fts = text_proj(txt_embeds) (fp32) into fp16 hi + lo planes laid out as MFMA
+ * B-fragments.   text [B][L][D] f32 -> frag [B][2][Lt][D/32][64][8] fp16, Lt = ceil(L/16). */
+int gridmm_text_fragments(const float* text, void* frag, int B, int L, int D,
+                          gridmm_stream_t stream);
+
+/* One pass over the fp16 slab: per point relevance w_j = max_l <x_j, text_l> (all L columns,
+ * padded tokens included, vilmodel.py:798) on MFMA f16 tiles, then per cell
+ * out[c] = sum_j softmax_j(w_j) x_j  (online softmax, fp32) and occ[c] = cell non-empty.
+ * Replaces: map_nav_src/models/vilmodel.py:797-807 (the 196*B python loop).  grid_proj is
+ * applied AFTER the reduction (W (sum_j a_j x_j) + b, since sum_j a_j = 1).
+ *   slab       [B][cap][D] fp16      perm/cell_start as produced by gridmm_grid_bin
+ *   cells      [B][196][D] f32 out (zeros for empty cells); occ [B][196] uint8 out
+ *   relevance  [B][cap] f32 out or NULL: w of the point at SORTED position p (slot perm[b][p]); saved for the backward
+ *              (D = 768: also the intermediate of the two-pass path -- relevance pass, then accumulation pass; with NULL
+ *              that shape runs on the slower single-kernel fallback)
+ *   chunks     [B][n_chunks+1] int32 workspace (cell-aligned work partition, device-built)
+ */
+int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                          const void* text_frag, float* cells, uint8_t* occ, float* relevance,
+                          int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
+                          gridmm_stream_t stream);
+
+/* The same with the routing of the backward as a second by-product (fine-tune / pre-training forward):
+ *   amax [B][cap] int32 out: arg-max instruction token of the point at sorted position p (first maximum, as torch.max).
+ * Returns GRIDMM_OK with amax written, 1 when the shape ran on the generic kernel (amax untouched: use
+ * gridmm_grid_aggregate_bwd, which recomputes it), < 0 on error.  Replaces: vilmodel.py:797-807. */
+int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                const void* text_frag, float* cells, uint8_t* occ, float* relevance, int32_t* amax,
+                                int32_t* chunks, int B, int cap, int D, int L, int n_chunks, gridmm_stream_t stream);
+
+/* Compact non-empty cells to the front (cell order), add the position embedding, build the
+ * key mask exactly as vilmodel.py:813-823 does (including its in-place view quirk).
+ *   proj [B][196][H] f32 = grid_proj(cells)+bias; pos_emb [B][196][H] f32
+ *   out  rows [0,196) of a [B][S_pad][H] buffer (row stride H, batch stride S_pad*H)
+ *   mask rows [0,196) of a [B][S_pad] uint8 buffer;  n_cells [B] int32 out; cmax [1] int32 out
+ */
+int gridmm_cells_compact(const float* proj, const float* pos_emb, const uint8_t* occ, float* out,
+                         uint8_t* mask, int32_t* n_cells, int32_t* cmax, int B, int H, int S_pad,
+                         gridmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder building blocks (QKV / FFN GEMMs on MFMA bf16, fp32 everywhere else)
+ * ---------------------------------------------------------------------------------------- */
+
+/* W [N][K] f32 -> bf16 hi / lo planes [N][Kp], Kp = roundup(K,32), zero padded. */
+int gridmm_split_weight(const float* W, void* hi, void* lo, int N, int K, int Kp,
+                        gridmm_stream_t stream);
+
+#define GRIDMM_ACT_NONE 0
+#define GRIDMM_ACT_GELU 1  /* exact erf gelu (vilmodel.py:47-53, transformer.py:472) */
+#define GRIDMM_ACT_RELU 2
+#define GRIDMM_ACT_QUICKGELU 3  /* x * sigmoid(1.702 x): CLIP's MLP (VLN_CE/.../gridmap/clip.py:26-28); gridmm_linear_planes only */
+
+/* C[M][N] = act(A[M][K] * W^T + bias) (+ residual), fp32 in / fp32 out, the contraction on
+ * MFMA bf16 16x16x32 tiles as a 3-term split (a_hi w_hi + a_lo w_hi + a_hi w_lo, fp32
+ * accumulate): ~2^-16 relative, inside the 1e-3 logit tolerance where plain bf16 is not.
+ * Replaces every nn.Linear on the path (vilmodel.py:124-126, 165, 187, 201, 345-347, ...;
+ * transformer.py in_proj/out_proj/linear1/linear2).
+ *   lda/ldc/ldr in elements; residual may be NULL; bias may be NULL. */
+int gridmm_linear(const float* A, int lda, const void* W_hi, const void* W_lo, int Kp,
+                  const float* bias, const float* residual, int ldr, float* C, int ldc,
+                  int M, int N, int K, int act, gridmm_stream_t stream);
+
+/* Y = LayerNorm(X (+ R)) * gamma + beta, row-wise over H, fp32 two-pass statistics.
+ * Optionally Y += add1 (+ table[idx[row]]).   Replaces BertLayerNorm / nn.LayerNorm uses. */
+int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr, const float* gamma,
+                     const float* beta, float eps, float* Y, int ldy, const float* add1, int ld1,
+                     const float* table, const int64_t* idx, void* Y_hi, void* Y_lo, int ldp,
+                     int M, int H, gridmm_stream_t stream);
+/* (Y may be NULL when only the bf16 hi/lo planes Y_hi/Y_lo [M][ldp] -- the next GEMM's A operand -- are wanted) */
+
+/* fp32 rows -> bf16 hi/lo planes [M][ldp], zero padded to ldp (ldp % 8 == 0). */
+int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, int ldp, int M, int K,
+                      gridmm_stream_t stream);
+
+/* gridmm_linear with BOTH operands as pre-split bf16 planes (the hot-path GEMM: LDS-DMA tile pipeline,
+ * no conversion in the loop).  K % 32 == 0, lda % 8 == 0, N % 4 == 0.  Output as fp32 (C) and/or as
+ * bf16 hi/lo planes (C_hi/C_lo, row stride ldp) for the next GEMM. */
+int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
+                         int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                         void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
+                         gridmm_stream_t stream);
+
+/* Same with an explicit tile configuration (tuning / benchmarking; cfg 0 = the heuristic above). */
+int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
+                             int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                             void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act, int cfg,
+                             gridmm_stream_t stream);
+
+/* Multi-head attention core, head_dim 64, fp32 (MFMA f32 16x16x4), online softmax.
+ * O[b][i][h*64+d] = sum_j softmax_j(scale * <Q[b,i,h], K[b,j,h]>  over keys with kmask=1) V[b,j,h,d]
+ * Masked keys contribute exactly 0 (both mask conventions of the reference, vilmodel.py:136,
+ * 354 (-10000 additive) and transformer.py:176 (key_padding_mask), give 0 in fp32).
+ *   Q/K/V element (b,i,h,d) at ptr[b*bs + i*rs + h*64 + d]  (strides in elements)
+ *   kmask [B][Sk] uint8 (row stride mask_bs) */
+int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
+                     const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs,
+                     float* O, int64_t o_bs, int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs,
+                     int B, int heads, int Sq, int Sk, float scale, gridmm_stream_t stream);
+/* (O may be NULL when only the bf16 hi/lo planes O_hi/O_lo, strides p_bs/p_rs in elements, are wanted) */
+
+/* bf16x3 variant (the one on the hot path): Q and K as the bf16 hi/lo planes the QKV GEMM emits, V as
+ * per-head RE-TILED planes VT[b][h][key tile of 32][d][32 slots] (Skp = roundup(Sk, 32) keys, zero padded;
+ * slot 8g+e <-> key 4g+e for e<4, 16+4g+(e-4) otherwise) built by gridmm_transpose_v.  Both matmuls run on MFMA bf16 16x16x32 with the 3-term split, softmax in fp32. */
+int gridmm_transpose_v(const void* V_hi, const void* V_lo, int64_t v_bs, int v_rs, void* T_hi, void* T_lo,
+                       int B, int heads, int Sk, int Skp, gridmm_stream_t stream);
+int gridmm_attention_planes(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                            const void* K_lo, int64_t k_bs, int k_rs, const void* T_hi, const void* T_lo, int Skp,
+                            const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs, int o_rs, void* O_hi,
+                            void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq, int Sk, float scale,
+                            gridmm_stream_t stream);
+
+/* bf16x3 attention with K AND V taken as the ROW-MAJOR hi/lo planes the QKV / KV GEMMs emit (no re-tiling pass):
+ * a workgroup stages its head's K / V rows once in LDS (LDS-DMA, source-side swizzle) and reads V^T fragments
+ * through the hardware transpose read.  Replaces gridmm_transpose_v + gridmm_attention_planes on the hot path of
+ * BertSelfAttention / BertOutAttention (map_nav_src/models/vilmodel.py:317-379) and of the grid encoder's
+ * nn.MultiheadAttention (map_nav_src/models/transformer.py:176-177).  Strides in elements, rows 16-byte aligned;
+ * Sk <= 512; kmask (B, Sk) bytes, 0 = masked (contributes exactly 0); a fully masked query row yields 0.
+ * _cfg: cfg = 0 picks the launch shape, cfg > 0 forces one (tools/bench_attn2.py). */
+int gridmm_attention_rows(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                          const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo, int64_t v_bs,
+                          int v_rs, const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs, int o_rs, void* O_hi,
+                          void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq, int Sk, float scale,
+                          gridmm_stream_t stream);
+int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                              const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
+                              int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs,
+                              int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq,
+                              int Sk, float scale, int cfg, gridmm_stream_t stream);
+
+/* ---- one cross-modal layer as one call -------------------------------------------------------------------------
+ * GraphLXRTXLayer.forward with graph_sprels = None (map_nav_src/models/vilmodel.py:399-414; pretrain / VLN-CE twins
+ * identical): cross attention of the Sq tokens over a context whose K / V projections the caller has already computed
+ * (KV planes (B, Sk, .), K at column k_col, V at v_col: the local encoder shares one K/V GEMM over its 4 layers,
+ * vilmodel.py:843-853), self attention, feed forward; every block = dense + residual + LayerNorm.  Weights arrive as
+ * the bf16 hi/lo planes of gridmm_split_weight.  All intermediates live in `workspace` (>= gridmm_xattn_layer_workspace
+ * bytes, 256-byte aligned); outputs: Y fp32 (M, H) and/or its bf16 planes.  heads * 64 == H. */
+typedef struct { const void *w_hi, *w_lo; const float* bias; int N, K, Kp; } gridmm_linear_t;   /* nn.Linear(K, N) */
+typedef struct { const float *gamma, *beta; float eps; } gridmm_ln_t;
+typedef struct {
+  gridmm_linear_t xq, xo;        /* visual_attention.att.query, visual_attention.output.dense */
+  gridmm_linear_t sqkv, so;      /* visn_self_att.self.{query|key|value} stacked (3H, H), visn_self_att.output.dense */
+  gridmm_linear_t ffn_i, ffn_o;  /* visn_inter.dense (H -> I, gelu), visn_output.dense (I -> H) */
+  gridmm_ln_t x_ln, s_ln, f_ln;  /* the three output LayerNorms */
+} gridmm_xlayer_t;
+size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I);
+int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
+                           const void* KV_hi, const void* KV_lo, int64_t kv_bs, int kv_rs, int k_col, int v_col,
+                           const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask, int self_mask_bs,
+                           float* Y, void* Y_hi, void* Y_lo, void* workspace, size_t workspace_bytes, int B, int Sq,
+                           int Sk, int heads, gridmm_stream_t stream);
+
+/* Patch tokens of a vision tower -> grid-memory slab: X (B * n_views, T, D) fp32 token rows, token 0 (class token)
+ * dropped; episode b's slot `slab + b * slab_bs` receives n_views * (T-1) rows of D fp16, view-major.  The device-side
+ * replacement of the GPU -> CPU -> GPU round trip at VLN_CE/vlnce_baselines/models/Policy_ViewSelection_GridMap.py:
+ * 340-357, 496 (CLIP tokens to numpy, per-episode python lists, torch.tensor(...).cuda() again). */
+int gridmm_tokens_to_slab(const float* X, int T, int D, void* slab, int64_t slab_bs, int B, int n_views,
+                          gridmm_stream_t stream);
+
+/* out[m] = <LayerNorm(X[m]) * gamma + beta, w> + b0      (tail of ClsPrediction,
+ * vilmodel.py:663-674: Linear -> ReLU -> LN -> Linear(H,1)). */
+int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const float* beta, float eps,
+                  const float* w, const float* b0, float* out, int M, int H,
+                  gridmm_stream_t stream);
+
+/* Logit masking + global/local fusion (vilmodel.py:859-907) with integer index maps.
+ *   g_raw [B][G], l_raw [B][V], grid_raw [B][G] f32: head outputs; fuse_raw [B] f32 (pre-sigmoid) or NULL (0.5)
+ *   gmap_masks, gmap_visited [B][G] uint8; vp_nav_masks [B][V] uint8
+ *   cand_of_node [B][G] int32: j>0 unvisited node -> index k of the same vpid among the
+ *       candidates, or -1 (add the sum of visited candidates' local logits); host-built from
+ *       the python vpid lists.   cand_visited [B][V] uint8: candidate k>0 is a visited node.
+ *   outputs global/grid/fused [B][G], local [B][V] f32 (-inf where masked) */
+int gridmm_fuse_logits(const float* g_raw, const float* l_raw, const float* grid_raw,
+                       const float* fuse_raw, const uint8_t* gmap_masks,
+                       const uint8_t* gmap_visited, const uint8_t* vp_nav_masks,
+                       const int32_t* cand_of_node, const uint8_t* cand_visited,
+                       float* global_logits, float* local_logits, float* grid_logits,
+                       float* fused_logits, int B, int G, int V, gridmm_stream_t stream);
+
+/* Strided row copy / gather used to assemble [cells | gmap | txt] sequences without torch.cat:
+ * dst[b][dst_row0 + i][:] = src[b][i][:] for i < rows.  H floats per row. */
+int gridmm_copy_rows(const float* src, int64_t src_bs, int src_rs, float* dst, int64_t dst_bs,
+                     int dst_rs, int B, int rows, int H, gridmm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training (backward) entry points -- SURVEY.md §8 rows a11 / a13 / a14: the fine-tune loop
+ * (map_nav_src/r2r/agent_base.py:164-211, loss.backward at :199) and the pre-training loop
+ * (pretrain_src/train_r2r.py:231-327) back-propagate through the same encoders; in the reference
+ * that is torch autograd over nn.Linear / LayerNorm / softmax attention / GELU.
+ * ---------------------------------------------------------------------------------------- */
+
+/* X fp32 [M][C] (row stride ldx) -> transposed bf16 hi/lo planes T [C][Mp] (Mp % 32 == 0, zero padded),
+ * plus colsum[C] = sum_m X[m][c] (NULL to skip).  With gridmm_linear_planes (C = A B^T) this gives
+ *   dW [N][K] = dY^T X:  A = T(dY) [N][Mp], B = T(X) [K][Mp];   db = colsum(dY)
+ * (backward of nn.Linear, e.g. vilmodel.py:84-86,128,144). */
+int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, void* R_hi, void* R_lo,
+                           int ldp, int M, int C, int Mp, gridmm_stream_t stream);
+/* (R_hi / R_lo, optional: the row-major planes [M][ldp] of the same X from the same pass -- the A operand of the
+ * forward / dX GEMM -- so an activation or a gradient is read ONCE for both of its GEMM roles) */
+
+/* Backward of y = LayerNorm(X (+ R)) * gamma + beta (BertLayerNorm / nn.LayerNorm, vilmodel.py:33,131,147).
+ *   dX [M][H] (same gradient flows to R); dgamma, dbeta [H]; workspace >= ceil(M/4) * 2 * H floats. */
+int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int ldr, const float* gamma, float eps,
+                         const float* dY, int ldy, float* dX, int lddx, float* dgamma, float* dbeta,
+                         float* workspace, int M, int H, gridmm_stream_t stream);
+
+/* Elementwise activations for training.  mode 0: out = gelu(X) (erf form, vilmodel.py:37-43);
+ * 1: out = dY * gelu'(X); 2: out = relu(X); 3: out = dY * (X > 0).  n % 4 == 0, contiguous. */
+int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, int mode, gridmm_stream_t stream);
+
+/* gridmm_attention that also returns lse [B][heads][Sqp] (Sqp = roundup(Sq,16)): log-sum-exp of the scaled,
+ * masked scores per query -- the only statistic the backward needs. */
+int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
+                           const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
+                           int64_t o_bs, int o_rs, float* lse, int Sqp, int B, int heads, int Sq, int Sk,
+                           float scale, float dropout_p, unsigned long long seed, gridmm_stream_t stream);
+/* dropout_p > 0: dropout on the attention probabilities (vilmodel.py:143,362; transformer.py MultiheadAttention):
+ * element (b,h,q,k) is kept iff a counter-based hash of (seed, ((b*heads+h)*Sq+q)*Sk+k) >= p, survivors scaled by
+ * 1/(1-p); the backward regenerates the mask from the same (dropout_p, seed). */
+
+/* Backward of the attention core: dQ, dK, dV from dO (fp32, exact-fp32 MFMA; masked keys get zero gradient).
+ * delta [B][heads][Sqp] is a workspace (sum_d dO*O per query). */
+int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
+                         const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, const float* O,
+                         int64_t o_bs, int o_rs, const float* dO, int64_t do_bs, int do_rs, const float* lse,
+                         float* delta, float* dQ, int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs, int dk_rs,
+                         float* dV, int64_t dv_bs, int dv_rs, int B, int heads, int Sq, int Sk, int Sqp, float scale,
+                         float dropout_p, unsigned long long seed, gridmm_stream_t stream);
+
+/* Backward of gridmm_grid_aggregate w.r.t. text = text_proj(txt_embeds) (vilmodel.py:795-807; the gradient
+ * reaches text_proj and the language encoder through the max / softmax weights):
+ *   relevance [B][cap] as written by the forward (by sorted position), text [B][L][D] f32, dcells [B][196][D] f32 (gradient of the
+ *   reduced cell vectors, i.e. after grid_proj's own backward) -> dtext [B][L][D] f32.
+ *   da_ws [B][cap] f32 and amax_ws [B][cap] int32 are workspaces. */
+int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                              const float* relevance, const float* text, const float* dcells, float* dtext,
+                              float* da_ws, int32_t* amax_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
+
+/* The same gradient from the forward's routing (gridmm_grid_aggregate_train): three streaming passes, no search, no
+ * atomics, deterministic.  relevance / amax [B][cap] by sorted position; da_ws, dw_ws [B][cap] f32 workspaces. */
+int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                     const float* relevance, const int32_t* amax, const float* dcells, float* dtext,
+                                     float* da_ws, float* dw_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
+
+/* Optimizer step: gradient-norm clipping + AdamW without a host round trip.
+ * gridmm_grad_sumsq adds sum(g^2) of one gradient tensor into *acc (zero it first; call once per tensor).
+ * gridmm_adamw_step updates one parameter tensor in place; with sumsq != NULL the gradient is first scaled by
+ * min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (torch.nn.utils.clip_grad_norm_).  step_size = lr * sqrt(1-b2^t)/(1-b1^t)
+ * is computed by the caller.  decay_first = 0: pretrain_src/optim/adamw.py:56-112 (decay after the update);
+ * decay_first = 1: torch.optim.AdamW order (fine-tune, agent_base.py:131).  dtype 0 = fp32, 1 = fp16 (the
+ * reference's fp16 grid_proj keeps fp16 optimizer state). */
+int gridmm_grad_sumsq(const void* g, int64_t n, int dtype, float* acc, gridmm_stream_t stream);
+int gridmm_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, int dtype, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float step_size, int decay_first,
+                      const float* sumsq, float max_norm, gridmm_stream_t stream);
+
+/* C (fp32, M x N, contiguous) = A W^T like gridmm_linear_planes, with the contraction split over `splits` (2..64)
+ * workgroups per output tile; partial tiles go to `workspace` (splits * M * N floats) and are summed in a fixed order
+ * (deterministic; no bias / activation / planes).  For the weight-gradient GEMMs dW = dY^T X: small output,
+ * contraction over all rows of the batch. */
+int gridmm_linear_planes_splitk(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
+                                int Kp, float* C, float* workspace, int M, int N, int K, int splits,
+                                gridmm_stream_t stream);
+
+/* Multi-tensor forms of the two kernels above for fp32 tensors: ONE launch over all parameters.
+ *   desc        device array of n_tensors records {float* p; const float* g; float* m; float* v; int64 n;
+ *               float lr, step_size, eps, weight_decay;}  (56 bytes, natural C layout)
+ *   chunk_first device int32 [n_tensors + 1]: prefix sums of ceil(n / 16384); n_chunks = chunk_first[n_tensors]
+ * gridmm_multi_grad_sumsq: partial64 = 64-float workspace, out = the global sum of squares (device scalar). */
+int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float* partial64,
+                            float* out, gridmm_stream_t stream);
+int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float beta1,
+                            float beta2, int decay_first, const float* sumsq, float max_norm, gridmm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIDMM_H */

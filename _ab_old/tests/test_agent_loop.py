@@ -1,0 +1,110 @@
+"""The navigation loop (GMapNavAgent.rollout, agent.py:268-451) on scripted synthetic episodes.
+
+Golden: rollout_reduced.npz = the same loop driven with the REFERENCE model (oracle/gen_golden.py).
+CPU: loop + oracle model reproduces it (pins loop + oracle);  GPU: loop + HIP model + device grid memory."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_state_dict
+from oracle import gen_golden
+from oracle.adapters import OracleVLNBert
+
+
+def _check(agent, traj, fx, tol):
+    assert len(agent.trace) == int(fx["n_steps"])
+    worst = 0.0
+    for st in agent.trace:
+        t = st["t"]
+        live = ~fx["t%d_ended" % t]
+        assert np.array_equal(st["ended"], fx["t%d_ended" % t])
+        assert np.array_equal(st["a_t"][live], fx["t%d_a" % t][live]), "chosen actions differ at step %d" % t
+        for key, name in (("fused_logits", "fused"), ("local_logits", "local"), ("global_logits", "global"),
+                          ("grid_logits", "grid")):
+            a, b = st["nav_outs"][key].detach().float().cpu().numpy(), fx["t%d_%s" % (t, name)]
+            assert a.shape == b.shape
+            fin = np.isfinite(b)
+            assert np.array_equal(np.isfinite(a), fin)
+            if fin[live].any():
+                worst = max(worst, float(np.abs(a[live][fin[live]] - b[live][fin[live]]).max()))
+    assert worst <= tol, worst
+    assert json.dumps([t["path"] for t in traj]) == str(fx["traj"])      # same trajectories incl. stop backtrack
+    return worst
+
+
+def test_rollout_with_oracle_model_matches_reference_driven_golden():
+    fx = load_golden("rollout_reduced.npz")
+    agent = gen_golden.make_rollout_agent(OracleVLNBert(golden_state_dict(fx)))
+    traj = agent.rollout()
+    _check(agent, traj, fx, 5e-5)
+    assert all(len(t["path"]) >= 1 for t in traj)
+
+
+def test_teacher_forcing_follows_gt_path_and_accumulates_ce_loss():
+    fx = load_golden("rollout_reduced.npz")
+    agent = gen_golden.make_rollout_agent(OracleVLNBert(golden_state_dict(fx)))
+    agent.feedback = "teacher"
+    traj = agent.rollout(train_ml=1.0)
+    for t, item in zip(traj, agent.env.batch):
+        flat = [vp for seg in t["path"] for vp in seg]
+        # teacher forcing walks towards the goal: the goal is reached within max_action_len or the walk is cut
+        assert flat[0] == item["path"][0]
+    assert float(agent.loss) > 0 and np.isfinite(float(agent.loss))
+
+
+@pytest.mark.gpu
+def test_rollout_on_hip_matches_reference_driven_golden():
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.synthetic import NATIVE
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    fx = load_golden("rollout_reduced.npz")
+    model = GlocalTextPathNavCMT(default_config(**json.loads(str(fx["cfg"])))).cuda().eval()
+    model.load_state_dict(golden_state_dict(fx), strict=True)
+    r = gen_golden.ROLLOUT
+    mem = GridMemoryBatch(r["batch_size"], NATIVE, max_steps=r["max_action_len"] + 2, device="cuda")
+    agent = gen_golden.make_rollout_agent(model, device="cuda", grid_memory=mem)
+    traj = agent.rollout()
+    worst = _check(agent, traj, fx, 3e-4)     # north star: 1e-3
+    print("max logit err over the rollout:", worst)
+
+
+@pytest.mark.gpu
+def test_dagger_training_iterations_on_hip():
+    """Seq2SeqAgent.train (agent_base.py:164-211): teacher rollout (ml_weight) + sampled rollout -> one backward
+    through language / panorama / navigation of every step -> clip 40 -> AdamW.  Checks: finite decreasing
+    imitation loss on a fixed mini-batch, every parameter that the reference would train received a gradient,
+    and the evaluation path afterwards sees the updated weights."""
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.sim_env import SyntheticNavEnv
+    from gridmm_amd.synthetic import NATIVE
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = default_config(num_l_layers=2, num_pano_layers=1, num_x_layers=2, intermediate_size=256, vocab_size=2000,
+                         hidden_dropout_prob=0.0)
+    model = GlocalTextPathNavCMT(cfg).cuda()
+    B = 4
+    mem = GridMemoryBatch(B, NATIVE, max_steps=9, device="cuda")
+    env = SyntheticNavEnv(B, mem, n_scans=2, n_episodes=B, seed=3)       # one fixed mini-batch, revisited
+    args = default_args(max_action_len=7, train_alg="imitation", lr=2e-4)
+    agent = GMapNavAgent(args, env, model, device="cuda")
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    losses = agent.train(6)
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    grads = {k: p.grad is not None for k, p in model.named_parameters()}
+    gradless = sorted(k for k, g in grads.items() if not g)
+    # no gradient, as in the reference (hence its DDP find_unused_parameters=True): sprel_linear is dead code on this
+    # path (vilmodel.py:577-590) and grid_logits do not enter the fine-tune loss (agent.py:340-347 uses fused_logits)
+    assert all(k.startswith(("global_encoder.sprel_linear", "grid_sap_head")) for k in gradless), gradless
+    changed = sum(int(not torch.equal(before[k], v.detach())) for k, v in model.named_parameters())
+    assert changed >= len(before) - len(gradless)
+    # DAgger: two rollouts per iteration share one backward (the first rollout's slab must survive the reset)
+    agent.args.train_alg, agent.args.ml_weight = "dagger", 0.2
+    l2 = agent.train(2)
+    assert all(np.isfinite(l2))
+    res = agent.test()
+    assert len(res) == B and all(len(r["trajectory"]) >= 1 for r in res)

@@ -1,0 +1,125 @@
+"""gridmm_grid_aggregate across the regimes of its two kernels (aggregate_pipe.hip: D <= 512, 33 <= L <= 96 or so;
+aggregate.hip: everything else), against an fp64 restatement of vilmodel.py:793-807 (max over instruction tokens of
+x . t, per-cell softmax-weighted sum) on the same fp16 slab.  The point layouts are chosen to hit the kernel's corner
+cases: ~1 point per cell (32 runs in a 32-point tile: two slot passes, every row flushed), one crowded cell spanning
+dozens of tiles (the open row carried and rescaled from tile to tile), ragged episodes, empty episodes, short last
+tiles, chunk counts from 1 to 24."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(slab, ids, text, L):
+    """slab (N,D) fp16 cpu, ids (N,) int, text (L,D) fp32 -> cells (196,D) f64, occ (196,), w (N,) f64"""
+    x = slab.double()
+    w = (x @ text.double().t()).max(-1).values
+    cells = torch.zeros(196, x.shape[1], dtype=torch.float64)
+    occ = torch.zeros(196, dtype=torch.uint8)
+    for c in ids.unique().tolist():
+        if c < 0:
+            continue
+        sel = ids == c
+        cells[c] = (torch.softmax(w[sel], 0)[:, None] * x[sel]).sum(0)
+        occ[c] = 1
+    return cells, occ, w
+
+
+def _episode_ids(kind, n, rng):
+    if kind == "sparse":            # about one point per cell, unsorted
+        return rng.integers(0, 196, size=n)
+    if kind == "crowded":           # one cell holds 70 % of the points, the rest spread thin
+        ids = rng.integers(0, 196, size=n)
+        ids[rng.random(n) < 0.7] = 77
+        return ids
+    if kind == "blocks":            # runs of 5..40 points, some cells empty
+        out = []
+        while len(out) < n:
+            out += [int(rng.integers(0, 196))] * int(rng.integers(5, 41))
+        return np.array(out[:n])
+    raise ValueError(kind)
+
+
+CASES = [
+    # D, L, kind, points per episode, n_chunks
+    (512, 80, "sparse", [150, 97, 0, 260], None),
+    (512, 80, "crowded", [3000, 1111, 33, 1], None),
+    (512, 80, "blocks", [2048, 2047, 2049, 31], 8),
+    (512, 80, "crowded", [5000, 64], 1),
+    (512, 80, "blocks", [9000, 4000], 24),
+    (512, 96, "blocks", [1500, 700], None),      # 2 B-waves, 16 blocks each
+    (512, 48, "sparse", [400, 300], None),       # 3 R-waves, 11 rows each
+    (512, 33, "crowded", [1200], None),
+    (512, 20, "blocks", [900, 100], None),       # L <= 32: generic kernel
+    (512, 120, "blocks", [900, 100], None),      # L > 96: generic kernel
+    (256, 80, "blocks", [3000, 500], None),
+    (256, 64, "sparse", [190, 10], 4),
+    (768, 80, "blocks", [2000, 300], None),      # D = 768, L <= 80: relevance pass + accumulation pass
+    (768, 80, "sparse", [150, 97, 0, 260], None),
+    (768, 80, "crowded", [9000, 1111, 33, 1], 8),
+    (768, 40, "blocks", [2047, 31], 4),          # 3 token tiles: waves 5..7 hold no text
+    (768, 16, "crowded", [700], None),
+    (768, 96, "blocks", [900, 100], None),       # D = 768, L > 80: generic kernel
+    (512, 80, "crowded", [210000], 8),           # run-head bitmask of the episode exceeds LDS: generic kernel
+    (512, 80, "crowded", [150000], 8),           # largest memories the pipelined kernel takes (4700 tiles per workgroup)
+]
+
+
+@pytest.mark.parametrize("D,L,kind,npts,n_chunks", CASES)
+def test_grid_aggregate_regimes(D, L, kind, npts, n_chunks):
+    from gridmm_amd import ops
+    from gridmm_amd.grid_memory import pack_reference_lists
+    rng = np.random.default_rng(1234 + D + L + len(npts))
+    g = torch.Generator().manual_seed(99 + D + L)
+    B = len(npts)
+    fts, maps = [], []
+    for n in npts:
+        fts.append((torch.randn(n, D, generator=g) * 0.5).half())
+        maps.append(torch.from_numpy(_episode_ids(kind, n, rng).astype(np.int64)) if n else torch.zeros(0, dtype=torch.int64))
+    text = torch.randn(B, L, D, generator=g) * 0.3          # relevance spread of a few units: a real softmax
+    slab, perm, cs = pack_reference_lists([f.cuda() for f in fts], [m.cuda().double() for m in maps])
+    cells, occ, rel, amax = ops.grid_aggregate(slab, perm, cs, ops.text_fragments(text.cuda()), L, n_chunks=n_chunks,
+                                               want_relevance=True, want_amax=True)
+    torch.cuda.synchronize()
+    fast = D in (256, 512) and 33 <= L <= 96 or D == 768 and L <= 80
+    if max(npts) <= 45000:
+        assert (amax is not None) == fast            # the pipelined kernels deliver the backward's routing, the generic one not
+    for b in range(B):
+        ref_cells, ref_occ, w = _ref(fts[b], maps[b], text[b], L)
+        assert torch.equal(occ[b].cpu(), ref_occ)
+        n_valid = int(cs[b, 196])
+        assert n_valid == npts[b]
+        if n_valid:
+            got = torch.zeros(n_valid, dtype=torch.float64)
+            got[perm[b, :n_valid].long().cpu()] = rel[b, :n_valid].double().cpu()   # relevance is by sorted position
+            assert (got - w).abs().max() < 2e-5 * max(1.0, float(w.abs().max()))
+            if amax is not None:                     # arg-max token: attains the maximum (ties / near-ties may differ)
+                tok = amax[b, :n_valid].long().cpu()
+                assert int(tok.min()) >= 0 and int(tok.max()) < L
+                pts = perm[b, :n_valid].long().cpu()
+                s_at = (fts[b][pts].double() * text[b][tok].double()).sum(-1)
+                assert (s_at - w[pts]).abs().max() < 2e-5 * max(1.0, float(w.abs().max()))
+                exact = (fts[b].double() @ text[b].double().t()).argmax(-1)[pts]
+                assert (tok == exact).float().mean() > 0.999
+        err = (cells[b].double().cpu() - ref_cells).abs().max()
+        assert err < 3e-5, (b, float(err))
+        assert (cells[b][ref_occ.cuda() == 0] == 0).all()
+
+
+def test_grid_aggregate_is_deterministic_and_chunk_invariant():
+    """Same inputs, same chunking: bit-identical (no atomics, a cell is reduced inside one workgroup in point order).
+    Different chunkings only move the 32-point tile boundaries inside a cell: fp32 summation-order noise."""
+    from gridmm_amd import ops
+    from gridmm_amd.grid_memory import pack_reference_lists
+    rng = np.random.default_rng(5)
+    g = torch.Generator().manual_seed(5)
+    n, D, L = 4000, 512, 80
+    fts = [(torch.randn(n, D, generator=g) * 0.5).half().cuda()]
+    maps = [torch.from_numpy(_episode_ids("blocks", n, rng)).double().cuda()]
+    frag = ops.text_fragments((torch.randn(1, L, D, generator=g) * 0.3).cuda())
+    slab, perm, cs = pack_reference_lists(fts, maps)
+    outs = [ops.grid_aggregate(slab, perm, cs, frag, L, n_chunks=k)[0].clone() for k in (8, 8, 1, 32)]
+    assert torch.equal(outs[1], outs[0])
+    for o in outs[2:]:
+        assert (o - outs[0]).abs().max() < 2e-6

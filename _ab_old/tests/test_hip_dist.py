@@ -1,0 +1,128 @@
+"""GPU: the training exchange on the REAL (reduced) pre-training model -- two ranks sharing this box's one GPU, gloo
+for the collectives (RCCL needs a GPU per rank): gradients after GradientReducer == mean of the two single-process
+gradients, same grad-less set, for task-switching steps with buckets launched from the backward hooks; and bench.py's
+N = 2 path (GRIDMM_BENCH_SHARE_GPU) end to end.  Reference contract: pretrain_src/train_r2r.py:231-303 (DDP averages the
+per-rank gradients of loss.mean()), utils/misc.py:52-65 (find_unused_parameters=True)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TASKS = ["mlm", "sap", "mlm", "mrc", "sap"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_batch(task, rank):
+    """Same task on every rank (the sampler broadcasts it), different data."""
+    from oracle import gen_golden
+    from gridmm_amd.synthetic import batch_to
+    b = gen_golden.pretrain_batch(task)
+    if rank == 1:
+        b = dict(b)
+        b["traj_view_img_fts"] = [t * 0.9 for t in b["traj_view_img_fts"]] if isinstance(b["traj_view_img_fts"], list) \
+            else b["traj_view_img_fts"] * 0.9
+    return batch_to(b, "cuda")
+
+
+def _sampled(model):
+    """A bounded view of every gradient: norm + first 64 entries."""
+    out = {}
+    for k, p in model.named_parameters():
+        out[k] = None if p.grad is None else (float(p.grad.float().norm()), p.grad.float().reshape(-1)[:64].cpu().numpy().copy())
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import load_golden
+    import test_hip_pretrain as TP
+    from gridmm_amd import dist as D
+    model = TP._model(load_golden("pretrain_reduced.npz"))
+    red = D.GradientReducer(model.parameters(), bucket_mb=0.5)           # a handful of buckets on the reduced model
+    outs, early = [], []
+    for task in TASKS:
+        model.zero_grad(set_to_none=True)
+        red.expect(task)
+        model(_rank_batch(task, rank), task=task, compute_loss=True).mean().backward()
+        early.append(sum(b["work"] is not None for b in red.buckets))
+        red.reduce()
+        torch.cuda.synchronize()
+        outs.append(_sampled(model))
+    q.put((rank, outs, early))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_on_the_real_pretraining_model_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (o, e) for r, o, e in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden
+    import test_hip_pretrain as TP
+    model = TP._model(load_golden("pretrain_reduced.npz"))
+    for step, task in enumerate(TASKS):
+        per_rank = []
+        for r in range(world):
+            model.zero_grad(set_to_none=True)
+            model(_rank_batch(task, r), task=task, compute_loss=True).mean().backward()
+            per_rank.append({k: (None if p.grad is None else p.grad.float().clone()) for k, p in model.named_parameters()})
+        for k in per_rank[0]:
+            g0, g1 = per_rank[0][k], per_rank[1][k]
+            for r in range(world):
+                got = res[r][0][step][k]
+                if g0 is None and g1 is None:
+                    assert got is None, (task, k)                      # unused on every rank: the optimizer skips it
+                    continue
+                want = 0.5 * ((g0 if g0 is not None else 0) + (g1 if g1 is not None else 0))
+                rel = 2e-3 if dict(model.named_parameters())[k].dtype == torch.float16 else 1e-4   # fp16 grads round once more
+                tol = rel * max(float(want.abs().max()), 1e-6)
+                assert got is not None, (task, k)
+                assert abs(got[0] - float(want.norm())) <= rel * max(float(want.norm()), 1e-6) + 1e-7, (task, k)
+                assert np.abs(got[1] - want.reshape(-1)[:64].cpu().numpy()).max() <= tol + 1e-9, (task, k)
+    for r in range(world):
+        e = res[r][1]
+        assert e[0] == 0 and e[1] == 0 and e[3] == 0, e   # first sight of mlm / sap / mrc
+        assert e[2] > 0 and e[4] > 0, e                   # repeated tasks: buckets were launched during backward
+
+
+def test_bench_two_ranks_on_one_gpu_prints_n_gpus_2():
+    """bench.py --gpus 2 through torch.distributed.run, both ranks on this GPU (test hook): the N > 1 code path --
+    rank-sharded episodes, barrier + max-over-ranks timing, rank 0's single JSON line."""
+    env = dict(os.environ, GRIDMM_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--batch", "8", "--no-roofline", "--no-depth-legs", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-train-leg", "--no-producer-leg"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["global_batch"] == 16
+    assert d["replay_check"]["replay_vs_eager_max_abs"] <= 1e-6

@@ -1,0 +1,207 @@
+"""GPU: the differentiable (training) path -- forward parity with the inference path / the reference's golden
+vectors, and parameter gradients against torch autograd through the CPU oracle on the same inputs.
+
+Tolerances: forward logits 2e-4 (as the inference path); gradients 2e-3 relative to the largest entry of the
+same tensor (fp32 reference autograd vs MFMA bf16x3 GEMMs + fp32 attention / LayerNorm backward).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, golden_state_dict, golden_nav_batch
+from oracle import navcmt_oracle as O
+
+pytestmark = pytest.mark.gpu
+GRAD_TOL = 2e-3
+
+
+def _model(fx, dev="cuda"):
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    cfg = default_config(**json.loads(str(fx["cfg"])))
+    m = GlocalTextPathNavCMT(cfg).to(dev).eval()
+    sd = golden_state_dict(fx)
+    m.load_state_dict(sd, strict=True)
+    m.differentiable = True     # eval mode (no dropout) but record the autograd graph
+    return m, sd
+
+
+def _nav_loss(outs, targets):
+    """Sum of the four SAP-style cross-entropies (pretrain_cmt.py:273-290 uses exactly these logits)."""
+    loss = 0
+    for k in ("global_logits", "fused_logits", "grid_logits"):
+        loss = loss + F.cross_entropy(outs[k], targets["g"], reduction="sum")
+    return loss + F.cross_entropy(outs["local_logits"], targets["l"], reduction="sum")
+
+
+def _targets(batch):
+    """A valid (unmasked) target per episode: first unvisited gmap node / first navigable candidate."""
+    gm = batch["gmap_masks"].bool() & ~batch["gmap_visited_masks"].bool()
+    g = torch.tensor([int(torch.nonzero(r)[-1]) for r in gm.cpu()])
+    l = torch.tensor([int(torch.nonzero(r)[-1]) for r in batch["vp_nav_masks"].bool().cpu()])
+    return g, l
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def test_training_forward_matches_golden_and_inference_path():
+    from gridmm_amd.synthetic import batch_to
+    fx = load_golden("nav_reduced.npz")
+    model, _ = _model(fx)
+    batch = batch_to(golden_nav_batch(fx), "cuda")
+    outs = model("navigation", batch)
+    assert outs["fused_logits"].requires_grad
+    with torch.no_grad():
+        ref = model("navigation", batch)
+    for k in ("global_logits", "local_logits", "fused_logits", "grid_logits"):
+        a, e = outs[k].detach().cpu().numpy(), fx["out_" + k]
+        inf = ~np.isfinite(e)
+        assert np.array_equal(~np.isfinite(a), inf)
+        assert np.abs(a[~inf] - e[~inf]).max() < 2e-4
+        assert np.abs(a[~inf] - ref[k].cpu().numpy()[~inf]).max() < 2e-4
+    assert np.abs(outs["gmap_embeds"].detach().cpu().numpy() - fx["out_gmap_embeds"]).max() < 5e-4
+
+
+def _embed_loss(outs, seed=11):
+    """A smooth scalar of the encoder outputs (fixed random projections of gmap_embeds / vp_embeds)."""
+    g = torch.Generator().manual_seed(seed)
+    r1 = torch.randn(outs["gmap_embeds"].shape, generator=g).to(outs["gmap_embeds"].device)
+    r2 = torch.randn(outs["vp_embeds"].shape, generator=g).to(outs["vp_embeds"].device)
+    return (outs["gmap_embeds"] * r1).sum() + (outs["vp_embeds"] * r2).sum()
+
+
+def _grad_report(model, sdr):
+    params = dict(model.named_parameters())
+    with_grad = sorted(k for k, p in params.items() if p.grad is not None)
+    with_grad_o = sorted(k for k, v in sdr.items() if v.grad is not None)
+    assert with_grad == with_grad_o, set(with_grad) ^ set(with_grad_o)    # same set of grad-less parameters
+    scale = max(float(sdr[k].grad.abs().max()) for k in with_grad)
+    # true-zero gradients (key biases: softmax is shift invariant) are compared on the global scale
+    errs = [(float((params[k].grad.cpu().double() - sdr[k].grad.double()).abs().max())
+             / max(float(sdr[k].grad.abs().max()), 1e-3 * scale), k) for k in with_grad]
+    a = torch.cat([params[k].grad.flatten().cpu().double() for k in with_grad])
+    b = torch.cat([sdr[k].grad.flatten().double() for k in with_grad])
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    return max(errs), cos
+
+
+@pytest.mark.parametrize("name", ["nav_reduced.npz", "nav_reduced_obj.npz"])
+def test_navigation_encoder_gradients_match_oracle_autograd(name):
+    """Tight check through everything below the heads (aggregation, grid encoder, cross-modal layers, local encoder,
+    embeddings) with a smooth loss on gmap_embeds / vp_embeds."""
+    from gridmm_amd.synthetic import batch_to
+    fx = load_golden(name)
+    model, sd = _model(fx)
+    cpu = golden_nav_batch(fx)
+    batch = batch_to(cpu, "cuda")
+    batch["txt_embeds"] = batch["txt_embeds"].clone().requires_grad_()
+    _embed_loss(model("navigation", batch)).backward()
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    cpu["txt_embeds"] = cpu["txt_embeds"].clone().requires_grad_()
+    _embed_loss(O.forward_navigation(sdr, cpu)).backward()
+    assert _rel(batch["txt_embeds"].grad, cpu["txt_embeds"].grad) < GRAD_TOL
+    worst, cos = _grad_report(model, sdr)
+    assert worst[0] < GRAD_TOL, worst
+    assert cos > 0.999999
+
+
+@pytest.mark.parametrize("name", ["nav_reduced.npz", "nav_reduced_obj.npz"])
+def test_navigation_loss_gradients_match_oracle_autograd(name):
+    """Full SAP-style loss through the ClsPrediction heads.  The heads contain a ReLU: one pre-activation of the
+    fixture sits at -7e-7 in the fp32 reference and +1e-5 here, which flips that unit's gate and moves the
+    gradient of that episode by a few percent in BOTH correct implementations -- so this check is on the direction
+    of the whole gradient (cosine) and on the loss value; the tight elementwise checks are the encoder test above
+    and tests/test_hip_backward.py."""
+    from gridmm_amd.synthetic import batch_to
+    fx = load_golden(name)
+    model, sd = _model(fx)
+    cpu = golden_nav_batch(fx)
+    g, l = _targets(cpu)
+    batch = batch_to(cpu, "cuda")
+    loss = _nav_loss(model("navigation", batch), {"g": g.cuda(), "l": l.cuda()})
+    loss.backward()
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    loss_o = _nav_loss(O.forward_navigation(sdr, cpu), {"g": g, "l": l})
+    loss_o.backward()
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 1e-4 * max(1.0, abs(float(loss_o.detach())))
+    worst, cos = _grad_report(model, sdr)
+    assert cos > 0.995, (cos, worst)
+
+
+def test_text_and_panorama_gradients_match_oracle_autograd():
+    fx = load_golden("text_pano_reduced.npz")
+    model, sd = _model(fx)
+    d = lambda k: torch.from_numpy(fx[k])
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    txt = model("language", {"txt_ids": d("in_txt_ids").cuda(), "txt_masks": d("in_txt_masks").cuda()})
+    pano, pm = model("panorama", {"view_img_fts": d("in_view_img_fts").cuda(), "obj_img_fts": None,
+                                  "loc_fts": d("in_loc_fts").cuda(), "nav_types": d("in_nav_types").cuda(),
+                                  "view_lens": d("in_view_lens").cuda(), "obj_lens": None})
+    gt = torch.randn(txt.shape, generator=torch.Generator().manual_seed(3))
+    gp = torch.randn(pano.shape, generator=torch.Generator().manual_seed(4))
+    tm = d("in_txt_masks").bool()
+    ((txt * gt.cuda() * tm.cuda().unsqueeze(-1)).sum() + (pano * gp.cuda() * pm.unsqueeze(-1)).sum()).backward()
+    txt_o = O.forward_text(sdr, d("in_txt_ids"), d("in_txt_masks"))
+    pano_o, pm_o = O.forward_panorama(sdr, d("in_view_img_fts"), d("in_loc_fts"), d("in_nav_types"), d("in_view_lens"))
+    ((txt_o * gt * tm.unsqueeze(-1)).sum() + (pano_o * gp * pm_o.unsqueeze(-1)).sum()).backward()
+    assert np.abs(txt.detach().cpu().numpy() - fx["out_txt_embeds"])[tm.numpy()].max() < 5e-4
+    worst, cos = _grad_report(model, sdr)
+    assert worst[0] < GRAD_TOL, worst
+
+
+def test_one_optimizer_step_changes_logits_and_repacks_weights():
+    """After optimizer.step() the packed bf16 planes are rebuilt (parameter _version bumps)."""
+    from gridmm_amd.synthetic import batch_to
+    fx = load_golden("nav_reduced.npz")
+    model, _ = _model(fx)
+    cpu = golden_nav_batch(fx)
+    g, l = _targets(cpu)
+    batch = batch_to(cpu, "cuda")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = _nav_loss(model("navigation", batch), {"g": g.cuda(), "l": l.cuda()})
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[2] < losses[0], losses
+    with torch.no_grad():                       # the inference path sees the updated weights too
+        a = model("navigation", batch)["fused_logits"]
+    b = model("navigation", batch)["fused_logits"]
+    m = torch.isfinite(a)
+    assert float((a[m] - b.detach()[m]).abs().max()) < 5e-4
+
+
+def test_backward_on_recycled_slab_fails_loudly_and_fresh_slab_is_automatic():
+    """autograd._GridAggregate keeps the slab by reference: a reset() between forward and backward must either hand
+    the next rollout a fresh slab (memory seen by a live graph) or make the stale backward raise -- never silently
+    return gradients computed from overwritten rows."""
+    from gridmm_amd import autograd as A, synthetic as S
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    rs = np.random.RandomState(3)
+    dev = torch.device("cuda")
+    mem = GridMemoryBatch(2, S.NATIVE, max_steps=2, device=dev)
+    eps = [S.make_observations(rs, S.NATIVE, 1, feat_scale=0.35) for _ in range(2)]
+    mem.step(np.stack([e[0]["depth"].reshape(-1) for e in eps]), np.stack([e[0]["feats"] for e in eps]),
+             [(e[0]["x"], e[0]["y"]) for e in eps], [e[0]["heading"] for e in eps])
+    text = torch.randn(2, 20, 768, device=dev, requires_grad=True)
+    cells, _ = A.grid_aggregate(text, mem.slab, mem.perm, mem.cell_start)
+    old = mem.slab
+    mem.reset()                                   # keep_for_backward is False, but the slab is in a live graph
+    assert mem.slab is not old and mem.slab.data_ptr() != old.data_ptr()
+    cells.sum().backward()                        # reads the untouched old slab
+    assert torch.isfinite(text.grad).all() and text.grad.abs().max() > 0
+    # a slab recycled in place behind the graph's back: backward refuses
+    text2 = torch.randn(2, 20, 768, device=dev, requires_grad=True)
+    mem.step(np.stack([e[0]["depth"].reshape(-1) for e in eps]), np.stack([e[0]["feats"] for e in eps]),
+             [(e[0]["x"], e[0]["y"]) for e in eps], [e[0]["heading"] for e in eps])
+    cells2, _ = A.grid_aggregate(text2, mem.slab, mem.perm, mem.cell_start)
+    mem.slab._gridmm_in_graph = False             # as if the forward had run without the tag (e.g. an older caller)
+    mem.reset()
+    with pytest.raises(RuntimeError, match="recycled"):
+        cells2.sum().backward()

@@ -1,0 +1,102 @@
+"""Oracle (NumPy restatement of env.py:267-374) vs golden vectors produced by the reference itself."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import gridmap_oracle as G
+
+
+def test_fill_gridmap_bit_exact_vs_reference_golden():
+    fx = load_golden("fill_gridmap_native.npz")
+    checked = 0
+    for e in range(int(fx["n_episodes"])):
+        mem = G.GridMemory(G.NATIVE)
+        rs = np.random.RandomState(e)
+        for t in range(int(fx["e%d_steps" % e])):
+            p = "e%d_t%d_" % (e, t)
+            x, y, h = [float(v) for v in fx[p + "pose"]]
+            feats = rs.standard_normal((588, 768)).astype(np.float16)
+            f, gm, pos, hl = mem.step(fx[p + "depth"], feats, x, y, h)
+            assert f.shape == (588 * (t + 1), 768) and f.dtype == np.float16
+            assert np.array_equal(f[-588:], feats)
+            assert gm.dtype == np.float64
+            assert np.array_equal(gm.astype(np.int16), fx[p + "grid_map"]), (e, t)
+            assert np.array_equal(pos, fx[p + "pos_fts"]), (e, t)
+            checked += gm.size
+    assert checked > 10000
+
+
+def test_all_zero_depth_step_is_all_invalid():
+    fx = load_golden("fill_gridmap_native.npz")
+    assert (fx["e1_t0_grid_map"] == -1).all()          # episode B, first step: depth all zero
+    assert (fx["e1_t1_grid_map"][:588] == -1).all()    # ...and stays invalid in later steps
+    assert (fx["e1_t1_grid_map"][588:] >= 0).any()
+
+
+def test_trunc_matches_x86_indefinite():
+    v = np.array([np.nan, np.inf, -np.inf, 3e9, -3e9, 2.9, -2.9, -0.5], np.float32)
+    out = G.trunc_i32(v)
+    m = np.iinfo(np.int32).min
+    assert out.tolist() == [m, m, m, m, m, 2, -2, 0]
+
+
+def test_pos_fts_row_order_matches_cell_index():
+    pf = G.gridmap_pos_fts(np.float32(5.0))
+    assert pf.shape == (196, 5) and pf.dtype == np.float32
+    # row i*14+j is the centre of cell (x=i, y=j): cell (0,0) is at (-h+c/2, -h+c/2) -> heading pi - asin(<0)
+    assert pf[0, 4] == pf[195, 4]                      # symmetric distances
+    assert pf[0, 0] < 0 and pf[13 * 14, 0] > 0         # sin(heading) sign follows x
+
+
+def test_baseline_geometry_runs_and_is_consistent_with_native_formula():
+    g = G.BASELINE
+    assert g.pts_per_obs == 7056
+    rs = np.random.RandomState(0)
+    mem = G.GridMemory(g)
+    d = rs.randint(0, 20000, size=(36, 196)).astype(np.uint16)
+    f = rs.standard_normal((7056, 512)).astype(np.float16)
+    ft, gm, pos, hl = mem.step(d, f, 1.0, -2.0, math.pi / 6)
+    assert ft.shape == (7056, 512) and gm.shape == (7056,) and pos.shape == (196, 5)
+    assert gm.min() >= -1 and gm.max() <= 195
+
+
+@pytest.mark.reference
+def test_oracle_vs_live_reference(has_reference):
+    if not has_reference:
+        pytest.skip("no /root/reference on this box")
+    from oracle import ref_harness as R
+    rs = np.random.RandomState(77)
+    T = 3
+    idx = G.NATIVE.sample_index()
+    depth_db, clip_db, info, obs = {}, {}, {}, []
+    for t in range(T):
+        d = rs.randint(0, 30000, size=(36, 128, 128, 1)).astype(np.uint16)
+        d[rs.rand(*d.shape) < 0.2] = 0
+        depth_db["s_v%d" % t] = d
+        clip_db["s_v%d" % t] = rs.standard_normal((12, 50, 768)).astype(np.float16)
+        info["s_v%d" % t] = {"x": float(rs.uniform(-9, 9)), "y": float(rs.uniform(-9, 9))}
+    env = R.RefGridEnv(1, depth_db, clip_db, info)
+    mem = G.GridMemory()
+    for t in range(T):
+        h = float(rs.uniform(-4, 4))
+        sem, gmap, pos = env.step(0, "s", "v%d" % t, h)
+        ds = G.sample_depth(depth_db["s_v%d" % t], horizon_slice=slice(12, 24))
+        f, gm, pf, _ = mem.step(ds, clip_db["s_v%d" % t][:, 1:], info["s_v%d" % t]["x"], info["s_v%d" % t]["y"], h)
+        assert np.array_equal(f, sem) and np.array_equal(gm, gmap) and np.array_equal(pf, pos)
+
+
+def test_vlnce_twin_bit_exact_vs_reference_golden():
+    """VLN-CE getGlobalMap (Policy_ViewSelection_GridMap.py:689-825): metres, view angle - heading, mirrored y,
+    rotation by pi, and the (x, Z, y) position-feature quirk of vlnce_baselines/models/utils.py:125-144."""
+    fx = load_golden("fill_gridmap_vlnce.npz")
+    for name, geom in (("r2r", G.VLNCE_R2R), ("rxr", G.VLNCE_RXR)):
+        mem = G.GridMemory(geom)
+        for t in range(int(fx[name + "_steps"])):
+            p = "%s_t%d_" % (name, t)
+            x, y, h = [float(v) for v in fx[p + "pose"]]
+            f, gm, pos, hl = mem.step(fx[p + "depth"], np.zeros((588, 768), np.float16), x, y, h)
+            assert np.array_equal(gm.astype(np.int16), fx[p + "grid_map"]), (name, t)
+            assert np.array_equal(pos, fx[p + "pos_fts"]), (name, t)
+    assert (fx["rxr_t0_grid_map"] == -1).all()

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -26,6 +26,7 @@ SIGNATURES = {
     "gridmm_grid_bin_sliced": [_vp] * 11 + [_i, _i, _i, _i, _vp],
     "gridmm_grid_sort_ids": [_vp] * 4 + [_i, _i, _vp],
     "gridmm_text_fragments": [_vp, _vp, _i, _i, _i, _vp],
+    "gridmm_grid_aggregate_workspace": [_i, _i, _i],
     "gridmm_grid_aggregate": [_vp] * 8 + [_i, _i, _i, _i, _i, _vp],
     "gridmm_grid_aggregate_train": [_vp] * 9 + [_i, _i, _i, _i, _i, _vp],
     "gridmm_cells_compact": [_vp] * 7 + [_i, _i, _i, _vp],
@@ -91,6 +92,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
+    lib.gridmm_grid_aggregate_workspace.restype = ctypes.c_size_t
     v = lib.gridmm_abi_version()
     if v != ABI_VERSION:
         raise GridmmLibraryError("libgridmm_hip.so ABI %d != expected %d (stale build?)" % (v, ABI_VERSION))

@@ -60,6 +60,11 @@ struct CellAccumulator {
   int base, n_heads;                // slot of the open cell; run heads before the current tile
   float m_run;
   f32x4_t acc[NBW], acc_s;
+  // Chunks are cut at POINT positions (equal work), so the first / last run of a chunk may be a piece of a cell that
+  // other chunks continue: such a piece is stored un-normalised as a record (N[D], S, m) in the workspace and the
+  // pieces are combined, in chunk order, by grid_aggregate_merge_kernel.  rec: this chunk's [2][D + 4] floats.
+  float* rec;
+  bool head_partial, tail_partial;  // the chunk's first run started in an earlier chunk / its last run continues
 
   __device__ __forceinline__ void init(float* cells_b_, uint8_t* occ_b_, const int* s_necell_, unsigned char* tab,
                                        int bw_, int nbw_, int lane_) {
@@ -69,14 +74,17 @@ struct CellAccumulator {
     t_q = reinterpret_cast<unsigned short*>(tab + 128);
     bw = bw_; nbw = nbw_; lane = lane_; sl = lane_ & 15; g = lane_ >> 4;
     base = 0; n_heads = 0; m_run = NEG_BIG;
+    rec = nullptr; head_partial = tail_partial = false;
     acc_s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NBW; ++u) acc[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
 
-  __device__ __forceinline__ void flush_rows(bool doit, int cell) {   // normalise + store + clear the rows of the lanes with doit
+  // normalise + store + clear the rows of the lanes with doit; lanes with part (a piece of a split cell; implies doit)
+  // store the raw sums, the denominator and the piece's maximum mval into record `which` instead
+  __device__ __forceinline__ void flush_rows(bool doit, int cell, bool part = false, int which = 0, float mval = 0.f) {
     const float inv = __builtin_amdgcn_rcpf(acc_s[0]);
-    if (doit) {                                  // one exec region for all stores (the block guard is wave-uniform)
+    if (doit && !part) {                         // one exec region for all stores (the block guard is wave-uniform)
       float* dst = cells_b + (size_t)cell * D + bw * 16 + g * 4;
 #pragma unroll
       for (int u = 0; u < NBW; ++u)
@@ -84,6 +92,18 @@ struct CellAccumulator {
           *reinterpret_cast<float4*>(dst + u * nbw * 16) =
               make_float4(acc[u][0] * inv, acc[u][1] * inv, acc[u][2] * inv, acc[u][3] * inv);
       if (g == 0 && bw == 0) occ_b[cell] = 1;
+    }
+    if (part) {
+      float* dst = rec + (size_t)which * (D + 4) + bw * 16 + g * 4;
+#pragma unroll
+      for (int u = 0; u < NBW; ++u)
+        if (bw + u * nbw < NBLK)
+          *reinterpret_cast<float4*>(dst + u * nbw * 16) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+      if (g == 0 && bw == 0) {
+        float* tail = rec + (size_t)which * (D + 4) + D;
+        tail[0] = acc_s[0];
+        tail[1] = mval;
+      }
     }
 #pragma unroll
     for (int u = 0; u < NBW; ++u)
@@ -149,7 +169,7 @@ struct CellAccumulator {
     // pass, unless that pass needs all 16 slots.
     bool flush_old = t > 0 && !cont;
     if (flush_old && nruns >= 16) {
-      flush_rows(sl == base, lds_ld_b32(s_necell + n_heads - 1));
+      flush_rows(sl == base, lds_ld_b32(s_necell + n_heads - 1), head_partial && n_heads == 1 && sl == base, 0, m_run);
       flush_old = false;
     }
     const int start = t == 0 ? 0 : (cont ? base : ((base + 1) & 15));
@@ -230,19 +250,24 @@ struct CellAccumulator {
         }
       }
       const int nlast = min(nruns, q0 + 16);
+      const bool old_row = flush_old && sl == base;
       const bool doit = (qs < nlast && qs != nruns - 1) ||   // every run of this pass but the tile's last (stays open)
-                        (flush_old && sl == base);
+                        old_row;
+      // the chunk's first run (non-empty cell 0 of the chunk) closes here: a piece of a split cell when head_partial
+      const bool part = head_partial && doit && (old_row ? n_heads == 1 : kg0 + qs == 0);
+      const float mval = old_row ? m_run : m0;
       flush_old = false;
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cell)::"memory");
-      flush_rows(doit, cell);
+      flush_rows(doit, cell, part, 0, mval);
     }
     base = (start + nruns - 1) & 15;
     n_heads += __builtin_popcount(hbu);
     m_run = m_last;
   }
 
-  __device__ __forceinline__ void finish() {   // the last cell of the chunk
-    flush_rows(sl == base, lds_ld_b32(s_necell + n_heads - 1));
+  __device__ __forceinline__ void finish() {   // the last cell of the chunk (a single-run chunk: also its first)
+    const bool part = tail_partial || (head_partial && n_heads == 1);
+    flush_rows(sl == base, lds_ld_b32(s_necell + n_heads - 1), part && sl == base, 1, m_run);
   }
 };
 

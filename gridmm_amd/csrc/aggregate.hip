@@ -456,34 +456,48 @@ extern "C" int gridmm_text_fragments(const float* text, void* frag, int B, int L
 
 // aggregate_pipe.hip: the wave-specialised variant (GRIDMM_EINVAL when the shape is outside its range)
 int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
-                               float* cells, uint8_t* occ, float* relevance, int32_t* amax, int B, int cap, int D,
-                               int L, int n_chunks, hipStream_t st);
+                               float* cells, uint8_t* occ, float* relevance, int32_t* amax, float* ws, int B, int cap,
+                               int D, int L, int n_chunks, hipStream_t st);
 
 // aggregate_rel.hip + aggregate_pipe.hip (PREW): the two-pass D = 768 path (needs the `relevance` buffer as scratch)
 int gridmm_grid_relevance_wide(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
                                float* relevance, int32_t* amax, int B, int cap, int D, int L, int n_chunks,
                                hipStream_t st);
 int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int32_t* cell_start, const float* w,
-                               float* cells, uint8_t* occ, int B, int cap, int D, int n_chunks, hipStream_t st);
+                               float* cells, uint8_t* occ, float* ws, int B, int cap, int D, int n_chunks,
+                               hipStream_t st);
+
+static size_t chunk_table_bytes(int B, int n_chunks) {
+  return ((size_t)B * (n_chunks + 1) * sizeof(int32_t) + 15) / 16 * 16;
+}
+
+extern "C" size_t gridmm_grid_aggregate_workspace(int B, int D, int n_chunks) {
+  if (B <= 0 || D <= 0 || n_chunks <= 0) return 0;
+  return chunk_table_bytes(B, n_chunks) + (size_t)B * n_chunks * 2 * (D + 4) * sizeof(float);
+}
 
 // amax (may be NULL): arg-max instruction token of every point, by sorted position -- the routing of the backward.
 // Returns GRIDMM_OK with amax written, 1 when the generic kernel ran (amax untouched), < 0 on error.
 extern "C" int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm, const int32_t* cell_start,
                                            const void* text_frag, float* cells, uint8_t* occ, float* relevance,
-                                           int32_t* amax, int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
+                                           int32_t* amax, void* workspace, int B, int cap, int D, int L, int n_chunks,
                                            gridmm_stream_t stream) {
-  if (B <= 0 || cap <= 0 || L <= 0 || n_chunks <= 0 || n_chunks > GRIDMM_CELLS) return GRIDMM_EINVAL;
+  if (B <= 0 || cap <= 0 || L <= 0 || n_chunks <= 0 || n_chunks > GRIDMM_CELLS || !workspace) return GRIDMM_EINVAL;
+  // workspace: [B][n_chunks + 1] int32 cell-aligned partition (generic kernel) | [B][n_chunks][2][D + 4] f32 records
+  // of split cells (pipelined kernels)
+  int32_t* chunks = static_cast<int32_t*>(workspace);
+  float* ws = reinterpret_cast<float*>(static_cast<char*>(workspace) + chunk_table_bytes(B, n_chunks));
   const int Lt = (L + 15) / 16;
   if (Lt > 16) return GRIDMM_EINVAL;  // L <= 256 (reference: max_instr_len 200)
   hipStream_t st = as_stream(stream);
-  if (gridmm_grid_aggregate_pipe(slab, perm, cell_start, text_frag, cells, occ, relevance, relevance ? amax : nullptr, B,
-                                 cap, D, L, n_chunks, st) == GRIDMM_OK)
+  if (gridmm_grid_aggregate_pipe(slab, perm, cell_start, text_frag, cells, occ, relevance, relevance ? amax : nullptr, ws,
+                                 B, cap, D, L, n_chunks, st) == GRIDMM_OK)
     return GRIDMM_OK;     // D <= 512 and L <= 96: two-stage wave-specialised pipeline; otherwise the generic kernel below
   if (D == 768 && relevance && L <= 80 && (size_t)cap <= 45000 &&
       gridmm_grid_relevance_wide(slab, perm, cell_start, text_frag, relevance, amax, B, cap, D, L, n_chunks, st) ==
           GRIDMM_OK) {
     // D = 768, L <= 80: relevance pass (text fragments spread over 8 waves) + accumulation pass on the resident slab
-    const int rc = gridmm_grid_aggregate_prew(slab, perm, cell_start, relevance, cells, occ, B, cap, D, n_chunks, st);
+    const int rc = gridmm_grid_aggregate_prew(slab, perm, cell_start, relevance, cells, occ, ws, B, cap, D, n_chunks, st);
     if (rc == GRIDMM_OK) return rc;
   }
   GRIDMM_LAUNCH(build_chunks_kernel, dim3(B), dim3(256), 0, st, cell_start, chunks, n_chunks);
@@ -522,9 +536,9 @@ extern "C" int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm
 
 extern "C" int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
                                      const void* text_frag, float* cells, uint8_t* occ, float* relevance,
-                                     int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
+                                     void* workspace, int B, int cap, int D, int L, int n_chunks,
                                      gridmm_stream_t stream) {
-  const int rc = gridmm_grid_aggregate_train(slab, perm, cell_start, text_frag, cells, occ, relevance, nullptr, chunks, B,
+  const int rc = gridmm_grid_aggregate_train(slab, perm, cell_start, text_frag, cells, occ, relevance, nullptr, workspace, B,
                                              cap, D, L, n_chunks, stream);
   return rc > 0 ? GRIDMM_OK : rc;
 }

@@ -16,6 +16,8 @@
 // lgkmcnt wait, a vector load's result register makes the compiler drain the queue): nothing but DMA in the R-waves'
 // vector-memory queue, so the counted s_waitcnt vmcnt is exact; the B-waves' LDS loads are asm (agg_accum.h) because a
 // visible LDS load into a register that a pending global store still names gets an s_waitcnt vmcnt(0) in front.
+// A workgroup takes an equal share of an episode's sorted points (whole tiles); cells that a cut splits are combined
+// from their pieces by grid_aggregate_merge_kernel (see there).
 // PREW instantiation: second pass of the D = 768 path (see the template comment below).
 #include "agg_accum.h"
 
@@ -32,13 +34,95 @@ __device__ long long g_prof[8][8];
 using namespace gridmm_agg;
 constexpr int MAXR = 12;          // rows DMA'd per R-wave and tile, at most (ceil(PT / Lt), Lt >= 3)
 
+// Points per chunk: an equal share of the episode's valid points, in whole tiles.
+__host__ __device__ __forceinline__ int chunk_points(int valid, int n_chunks) {
+  const int share = (valid + n_chunks - 1) / n_chunks;
+  return max(PT, (share + PT - 1) / PT * PT);
+}
+
+// Combines the pieces of the cells that the point-balanced chunking split (records written by CellAccumulator).
+// Workgroup (k, b) acts only if chunk k CLOSES a split cell (its first run started in an earlier chunk and ends here):
+// it re-derives from cell_start which earlier chunks hold the other pieces (the opener's tail record and any chunks
+// lying entirely inside the cell), then N = sum_i exp(m_i - M) N_i, S likewise, M = max m_i, in chunk order
+// (deterministic), and writes the normalised row.  Two dependent memory round trips (cell_start, records).
+template <int D>
+__global__ __launch_bounds__(128) void grid_aggregate_merge_kernel(const int32_t* __restrict__ cell_start,
+                                                                  const float* __restrict__ ws,
+                                                                  float* __restrict__ cells, uint8_t* __restrict__ occ,
+                                                                  int n_chunks) {
+  constexpr int PER = (D / 4 + 127) / 128;     // float4 per thread
+  __shared__ int s_cs[GRIDMM_CELLS + 2];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  for (int i = tid; i < GRIDMM_CELLS + 2; i += 128) s_cs[i] = cs[i];
+  __syncthreads();
+  const int valid = s_cs[GRIDMM_CELLS];
+  const int target = chunk_points(valid, n_chunks);
+  auto count_below = [&](int pos) {            // entries 0..196 of cell_start that are < pos (non-decreasing)
+    int lo = 0, hi = GRIDMM_CELLS + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_cs[mid] < pos) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  struct Meta { int c_lo; bool hp, tp, single; };
+  auto meta = [&](int kk) {
+    const long lo = (long)kk * target;
+    const int p_lo = (int)lo, p_hi = (int)min(lo + target, (long)valid);
+    const int c_lo = count_below(p_lo + 1) - 1, c_hi = count_below(p_hi);
+    return Meta{c_lo, s_cs[c_lo] < p_lo, s_cs[c_hi] > p_hi, s_cs[c_lo + 1] >= p_hi};
+  };
+  if ((long)k * target >= valid) return;
+  const Meta me = meta(k);
+  if (!me.hp || (me.single && me.tp)) return;                  // nothing closes here
+  int j = k - 1;                                               // the opener: the last earlier chunk that is not wholly inside the cell
+  while (j > 0) {
+    const Meta mj = meta(j);
+    if (!(mj.single && mj.hp && mj.tp)) break;
+    --j;
+  }
+  auto rec_of = [&](int i) {                                   // a chunk's closing piece is record 0 unless the chunk is one run
+    const int which = (i == k && !me.single) ? 0 : 1;
+    return ws + (((size_t)b * n_chunks + i) * 2 + which) * (D + 4);
+  };
+  float M = -3.0e38f;
+  for (int i = j; i <= k; ++i) M = fmaxf(M, rec_of(i)[D + 1]);
+  float4 n[PER];
+  float S = 0.f;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) n[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = j; i <= k; ++i) {
+    const float* r = rec_of(i);
+    const float a = expf(r[D + 1] - M);
+    S += a * r[D];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int q = tid + u * 128;
+      if (q < D / 4) {
+        const float4 v = reinterpret_cast<const float4*>(r)[q];
+        n[u].x += a * v.x; n[u].y += a * v.y; n[u].z += a * v.z; n[u].w += a * v.w;
+      }
+    }
+  }
+  const float inv = 1.0f / S;
+  float* dst = cells + ((size_t)b * GRIDMM_CELLS + me.c_lo) * D;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int q = tid + u * 128;
+    if (q < D / 4) reinterpret_cast<float4*>(dst)[q] = make_float4(n[u].x * inv, n[u].y * inv, n[u].z * inv, n[u].w * inv);
+  }
+  if (tid == 0) occ[(size_t)b * GRIDMM_CELLS + me.c_lo] = 1;
+}
+
 // PREW: the relevance of every point is an INPUT (`relevance`, by sorted position; aggregate_rel.hip computed it): the
 // R-waves only feed the ring -- the second pass of the D = 768 path, whose text fragments do not fit one wave.
 template <int KS, int R, int NBW, bool PREW = false>   // D = 32 * KS; NBW = 16-dim blocks per B-wave (at least ceil(D / 16 / B-waves))
 __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
     const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
     const _Float16* __restrict__ text_frag, float* __restrict__ cells, uint8_t* __restrict__ occ,
-    float* __restrict__ relevance, int32_t* __restrict__ amax, int cap, int L, int Lt, int n_chunks) {
+    float* __restrict__ relevance, int32_t* __restrict__ amax, float* __restrict__ ws, int cap, int L, int Lt,
+    int n_chunks) {
   constexpr int D = 32 * KS;
   constexpr int NCH = D / 8;                 // 16-B chunks per row
   constexpr int IPR = (NCH + 63) / 64;       // DMA instructions per row
@@ -61,34 +145,54 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   long long p_wait = 0, p_dma = 0, p_work = 0, p_a = 0, pt2 = 0, pta = 0, pmk = 0;
   long long p_m[6] = {0, 0, 0, 0, 0, 0};
 #endif
-  const int b = blockIdx.y, k = blockIdx.x;
+  // XCD-aware (episode, chunk) order.  Workgroups go to the 8 XCDs round-robin by linear id; with chunk = blockIdx.x the
+  // chunks of ONE episode land on 8 different XCDs and every XCD's L2 fetches every episode's text fragments (160 KB per
+  // workgroup, 41 MB per launch at B = 32 -- the whole prologue).  Here the workgroups of an XCD take a contiguous
+  // range of the (episode-major) chunk list, so an episode's fragments, cell_start and perm are fetched by one L2.
+  int b, k;
+  {
+    const int T = gridDim.x * gridDim.y, lid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lid & 7, j = lid >> 3, q = T >> 3, rem = T & 7;
+    const int f = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;     // bijective for any T
+    b = f / n_chunks;
+    k = f - b * n_chunks;
+  }
   const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
-  // Chunk k of the episode = cells [c_lo, c_hi), cut where the sorted point index crosses k * ceil(valid / n_chunks)
-  // (the same boundaries build_chunks_kernel writes for the generic kernel; computed here, a 15 us serial kernel
-  // less): cell_start is non-decreasing, so a boundary is the count of entries below the target.
+  const bool is_r = wave < Lt;                 // relevance wave (text column tile `wave`)
+  // The set-up is a lambda called at the top of each role's branch: the R-waves issue their text-fragment loads (128
+  // VGPRs) BEFORE it, so that those fly under the cell_start round trip, and the register allocator still never sees the
+  // fragments and the B-waves' accumulators live together.  Same barrier sequence in every branch.
+  int c_lo = 0, c_hi = 0, p_lo = 0, p_hi = 0, ntiles = 0;
+  float* cells_b = cells + (size_t)b * GRIDMM_CELLS * D;
+  uint8_t* occ_b = occ + (size_t)b * GRIDMM_CELLS;
+  auto setup = [&]() -> bool {
+  // Chunk k of the episode = sorted points [p_lo, p_hi): equal shares (whole 32-point tiles) whatever the cell
+  // populations -- a crowded cell (thousands of points at depth 15) is split over chunks, its pieces go to the workspace
+  // as records and grid_aggregate_merge_kernel combines them.  Cells [c_lo, c_hi) overlap the chunk: cell_start is
+  // non-decreasing, so both ends are counts of entries below a position.
   const int mine = tid < GRIDMM_CELLS + 2 ? cs[tid] : 0x7fffffff;
   if (tid < GRIDMM_CELLS + 2) s_cs[tid] = mine;
   const int valid = cs[GRIDMM_CELLS];
-  const long target = (valid + n_chunks - 1) / n_chunks;
   const bool counted = tid <= GRIDMM_CELLS;
-  const int below_lo = __syncthreads_count(counted && mine < k * target);
-  const int below_hi = __syncthreads_count(counted && mine < (k + 1) * target);
-  const int c_lo = k == 0 ? 0 : min(below_lo, GRIDMM_CELLS);
-  const int c_hi = k + 1 == n_chunks ? GRIDMM_CELLS : min(below_hi, GRIDMM_CELLS);
-  if (c_lo >= c_hi) return;
-  const int p_lo = s_cs[c_lo], p_hi = s_cs[c_hi];
-  float* cells_b = cells + (size_t)b * GRIDMM_CELLS * D;
-  uint8_t* occ_b = occ + (size_t)b * GRIDMM_CELLS;
+  const int target = chunk_points(valid, n_chunks);
+  p_lo = (int)min((long)k * target, (long)valid);
+  p_hi = (int)min((long)p_lo + target, (long)valid);
+  const int n_le_lo = __syncthreads_count(counted && mine <= p_lo);
+  const int n_lt_hi = __syncthreads_count(counted && mine < p_hi);
+  c_lo = max(n_le_lo - 1, 0);                  // the (non-empty) cell that holds point p_lo
+  c_hi = n_lt_hi;                              // one past the cell that holds point p_hi - 1
 
-  // empty cells of this chunk: zero vector, occ = 0 (vilmodel.py:803-807)
-  for (int c = c_lo + wave; c < c_hi; c += 8) {
-    if (s_cs[c + 1] == s_cs[c]) {
+  // empty cells: zero vector, occ = 0 (vilmodel.py:803-807); an empty cell belongs to the chunk of its start position
+  for (int c = wave; c < GRIDMM_CELLS; c += 8) {
+    const int st = s_cs[c];
+    if (s_cs[c + 1] == st && min(st / target, n_chunks - 1) == k) {
       for (int d = lane; d < D / 4; d += 64)
         reinterpret_cast<float4*>(cells_b + (size_t)c * D)[d] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (lane == 0) occ_b[c] = 0;
     }
   }
-  if (p_lo >= p_hi) return;
+  if (p_lo >= p_hi) return false;
+  ntiles = (p_hi - p_lo + PT - 1) / PT;
   for (int i = tid; i < 2 * 8 * PT; i += 512) s_wmax[i] = NEG_BIG;      // columns of absent R-waves stay at -inf
   {
     // Points are sorted by cell: the run heads of every tile are known from cell_start alone.  One bit per point (a
@@ -105,20 +209,18 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
         const unsigned long long mk = __ballot(ne);
         if (ne) {
           s_necell[kbase + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = c;
-          atomicOr(&s_hbits[(st - p_lo) >> 5], 1u << ((st - p_lo) & 31));
+          const int hp = max(st - p_lo, 0);                 // (the chunk's first run starts at its first point)
+          atomicOr(&s_hbits[hp >> 5], 1u << (hp & 31));
         }
         kbase += __builtin_popcountll(mk);
       }
     }
   }
+  return true;
+  };
 
-  const bool is_r = wave < Lt;                 // relevance wave (text column tile `wave`)
-
-  const size_t plane = (size_t)Lt * KS * 64 * 8;
-  const _Float16* tf_b = text_frag + (size_t)b * 2 * plane + (size_t)lane * 8;
   const _Float16* slab_b = slab + (size_t)b * cap * D;
   const int32_t* perm_b = perm + (size_t)b * cap;
-  const int ntiles = (p_hi - p_lo + PT - 1) / PT;
 
   // The R-waves feed the ring (the B-waves have global stores in flight, which would make a counted vmcnt wait drain
   // their part of it, and they are the longer leg of an iteration): R-wave w fetches rows w, w + Lt, ... of a tile.
@@ -211,8 +313,6 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
 
   // accumulation (B-waves): B-wave bw owns the 16-dim blocks bw, bw + nbw, ... of every cell (agg_accum.h)
   const int bw = wave - Lt, nbw = 8 - Lt;
-  CellAccumulator<D, NBW> cacc;
-  cacc.init(cells_b, occ_b, s_necell, s_tab + (size_t)(bw < 0 ? 0 : bw) * TAB_BYTES, bw, nbw, lane);
 
   // Queue discipline of an R-wave (in order): iteration i issues DMA(i + R - 2) then IDS(i + R); its top needs DMA(i)
   // (issued at i - R + 2) and IDS(i + R - 2) (issued at i - 2) and leaves the R - 3 younger tiles and IDS(i + R - 1)
@@ -220,7 +320,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   static_assert(R == 3 || R == 4, "ring of 3 (D = 768) or 4 slots");
   auto iter_head_r = [&](int i) {
 #ifdef GRIDMM_AGG_PROF
-    pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta;
+    pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta; else p_m[1] = pt2 - pt0;
 #endif
     // (PREW: nobody computes on tile i in iteration i, so the loaders only need tile i - 1 here and keep tile i flying)
     constexpr int KEEP = PREW ? 1 : R - 3;
@@ -242,7 +342,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   };
   auto iter_head_b = [&](int i) {
 #ifdef GRIDMM_AGG_PROF
-    pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta;
+    pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta; else p_m[1] = pt2 - pt0;
 #endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -254,6 +354,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   // B-waves' accumulators live at the same time.
   if (is_r) {
   if constexpr (PREW) {                         // loader waves of the second pass: ring feed only
+    if (!setup()) return;
     __builtin_amdgcn_s_waitcnt(0);
     for (int t = 0; t < R && t < ntiles; ++t) load_ids(t);
     wait_vm<0>();
@@ -268,11 +369,16 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
     }
   } else {
     f16x8_t thi[KS], tlo[KS];
+    {
+      const size_t plane = (size_t)Lt * KS * 64 * 8;
+      const _Float16* tf = text_frag + (size_t)b * 2 * plane + (size_t)lane * 8 + (size_t)wave * KS * 64 * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      thi[ks] = *reinterpret_cast<const f16x8_t*>(tf_b + ((size_t)wave * KS + ks) * 64 * 8);
-      tlo[ks] = *reinterpret_cast<const f16x8_t*>(tf_b + plane + ((size_t)wave * KS + ks) * 64 * 8);
+      for (int ks = 0; ks < KS; ++ks) {
+        thi[ks] = *reinterpret_cast<const f16x8_t*>(tf + (size_t)ks * 64 * 8);
+        tlo[ks] = *reinterpret_cast<const f16x8_t*>(tf + plane + (size_t)ks * 64 * 8);
+      }
     }
+    if (!setup()) return;
     __builtin_amdgcn_s_waitcnt(0);              // text fragments: retire ordinary loads before the loop
     for (int t = 0; t < R && t < ntiles; ++t) load_ids(t);
     wait_vm<0>();
@@ -355,6 +461,12 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
     }
   }
   } else {
+    if (!setup()) return;
+    CellAccumulator<D, NBW> cacc;              // (declared in this branch: never live together with the text fragments)
+    cacc.init(cells_b, occ_b, s_necell, s_tab + (size_t)bw * TAB_BYTES, bw, nbw, lane);
+    cacc.rec = ws + ((size_t)b * n_chunks + k) * 2 * (D + 4);
+    cacc.head_partial = s_cs[c_lo] < p_lo;
+    cacc.tail_partial = s_cs[c_hi] > p_hi;
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     for (int i = 0; i <= ntiles; ++i) {
@@ -409,7 +521,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
   if (blockIdx.x == 3 && blockIdx.y == 5 && lane == 0) {
     const long long te = PROF_T();
     long long* o = g_prof[wave];
-    o[0] = p_m[0]; o[1] = p_m[1]; o[2] = p_wait; o[3] = p_dma; o[4] = p_work + (te - pta); o[5] = p_a; o[6] = p_m[4]; o[7] = ntiles;
+    o[0] = te - pt0; o[1] = p_m[1]; o[2] = p_wait; o[3] = p_dma; o[4] = p_work + (te - pta); o[5] = p_a; o[6] = p_m[4]; o[7] = ntiles;
   }
 #endif
 }
@@ -424,8 +536,8 @@ extern "C" int gridmm_debug_agg_prof(long long* out) {      // development aid (
 
 // Returns GRIDMM_EINVAL when the shape is outside this variant's range (the caller then uses the generic kernel).
 int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
-                               float* cells, uint8_t* occ, float* relevance, int32_t* amax, int B, int cap, int D,
-                               int L, int n_chunks, hipStream_t st) {
+                               float* cells, uint8_t* occ, float* relevance, int32_t* amax, float* ws, int B, int cap,
+                               int D, int L, int n_chunks, hipStream_t st) {
   const int Lt = (L + 15) / 16;
   // D = 768 (KS = 24) does not fit: 192 VGPRs of resident text fragments + the MFMA working set spill (58 VGPRs at the
   // 256-register budget of 2 waves per SIMD), and a 3 x 48 KB ring leaves one tile of latency cover.
@@ -446,7 +558,7 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
                             (int)lds) != hipSuccess)                                                                 \
       return GRIDMM_EINVAL;                                                                                          \
     GRIDMM_LAUNCH(kern, grid, block, lds, st, (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag,   \
-                  cells, occ, relevance, amax, cap, L, Lt, n_chunks);                                                \
+                  cells, occ, relevance, amax, ws, cap, L, Lt, n_chunks);                                            \
   } while (0)
   if (D == 512) {
     if (nbw >= 4) GRIDMM_AGGP(16, 4, 8); else if (nbw == 3) GRIDMM_AGGP(16, 4, 11); else GRIDMM_AGGP(16, 4, 16);
@@ -454,6 +566,8 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
     if (nbw >= 2) GRIDMM_AGGP(8, 4, 8); else GRIDMM_AGGP(8, 4, 16);
   }
 #undef GRIDMM_AGGP
+  if (D == 512) GRIDMM_LAUNCH(grid_aggregate_merge_kernel<512>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
+  else GRIDMM_LAUNCH(grid_aggregate_merge_kernel<256>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -461,7 +575,8 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
 // Second pass of the D = 768 path: w (relevance by sorted position, from gridmm_grid_relevance_wide) -> cells / occ.
 // 3 loader waves + 5 accumulating waves, ring of 3 x 48 KB.
 int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int32_t* cell_start, const float* w,
-                               float* cells, uint8_t* occ, int B, int cap, int D, int n_chunks, hipStream_t st) {
+                               float* cells, uint8_t* occ, float* ws, int B, int cap, int D, int n_chunks,
+                               hipStream_t st) {
   if (D != 768) return GRIDMM_EINVAL;
   constexpr int R = 3, LOADERS = 3;
   const size_t hb_words = (size_t)(cap + PT - 1) / PT;
@@ -474,8 +589,9 @@ int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int3
       hipSuccess)
     return GRIDMM_EINVAL;
   GRIDMM_LAUNCH(kern, dim3(n_chunks, B), dim3(512), lds, st, (const _Float16*)slab, perm, cell_start,
-                (const _Float16*)nullptr, cells, occ, const_cast<float*>(w), (int32_t*)nullptr, cap, 0, LOADERS,
+                (const _Float16*)nullptr, cells, occ, const_cast<float*>(w), (int32_t*)nullptr, ws, cap, 0, LOADERS,
                 n_chunks);
+  GRIDMM_LAUNCH(grid_aggregate_merge_kernel<768>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -535,10 +535,9 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
     B, cap, D = slab.shape
     assert slab.dtype == torch.float16 and slab.is_contiguous()
     if n_chunks is None:
-        n_chunks = max(1, min(N_CELLS, -(-256 // B)))   # one workgroup per CU (256): 155 us vs 180 us with two rounds
-        # chunks are cut at cell boundaries: with deep memories (>~4400 points per workgroup) a few crowded cells unbalance
-        # them, and finer chunks let the dispatcher level the load (t=15: 1110 -> 990 us; t=5 is best with one round)
-        n_chunks = min(N_CELLS, n_chunks * max(1, min(6, round((n_points or cap) / n_chunks / 4400))))
+        # one workgroup per CU (256): the chunks are equal shares of an episode's sorted points (cells that a cut splits are
+        # merged from their pieces), so one round of workgroups is balanced at any memory depth
+        n_chunks = max(1, min(N_CELLS, -(-256 // B)))
         if os.environ.get("GRIDMM_AGG_CHUNKS"):
             n_chunks = int(os.environ["GRIDMM_AGG_CHUNKS"])
     dev = slab.device
@@ -549,7 +548,7 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
         rel = torch.zeros(B, cap, dtype=torch.float32, device=dev)
     else:                                   # D = 768: scratch of the two-pass path (only valid positions are written / read)
         rel = torch.empty(B, cap, dtype=torch.float32, device=dev) if D == 768 else None
-    chunks = torch.empty(B, n_chunks + 1, dtype=torch.int32, device=dev)
+    chunks = torch.empty(int(lib.gridmm_grid_aggregate_workspace(B, D, n_chunks)), dtype=torch.uint8, device=dev)
     amax = torch.empty(B, cap, dtype=torch.int32, device=dev) if want_amax else None
     status = []
 

@@ -118,11 +118,14 @@ int gridmm_text_fragments(const float* text, void* frag, int B, int L, int D,
  *   relevance  [B][cap] f32 out or NULL: w of the point at SORTED position p (slot perm[b][p]); saved for the backward
  *              (D = 768: also the intermediate of the two-pass path -- relevance pass, then accumulation pass; with NULL
  *              that shape runs on the slower single-kernel fallback)
- *   chunks     [B][n_chunks+1] int32 workspace (cell-aligned work partition, device-built)
+ *   workspace  gridmm_grid_aggregate_workspace(B, D, n_chunks) bytes of device memory (contents undefined on entry):
+ *              an episode's sorted points are cut into n_chunks equal shares, one workgroup each; a cell that a cut
+ *              splits leaves its pieces there (sum, denominator, maximum) and a merge kernel combines them
  */
+size_t gridmm_grid_aggregate_workspace(int B, int D, int n_chunks);
 int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* cell_start,
                           const void* text_frag, float* cells, uint8_t* occ, float* relevance,
-                          int32_t* chunks, int B, int cap, int D, int L, int n_chunks,
+                          void* workspace, int B, int cap, int D, int L, int n_chunks,
                           gridmm_stream_t stream);
 
 /* The same with the routing of the backward as a second by-product (fine-tune / pre-training forward):
@@ -131,7 +134,7 @@ int gridmm_grid_aggregate(const void* slab, const int32_t* perm, const int32_t* 
  * gridmm_grid_aggregate_bwd, which recomputes it), < 0 on error.  Replaces: vilmodel.py:797-807. */
 int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm, const int32_t* cell_start,
                                 const void* text_frag, float* cells, uint8_t* occ, float* relevance, int32_t* amax,
-                                int32_t* chunks, int B, int cap, int D, int L, int n_chunks, gridmm_stream_t stream);
+                                void* workspace, int B, int cap, int D, int L, int n_chunks, gridmm_stream_t stream);
 
 /* Compact non-empty cells to the front (cell order), add the position embedding, build the
  * key mask exactly as vilmodel.py:813-823 does (including its in-place view quirk).

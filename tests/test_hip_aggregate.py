@@ -63,6 +63,11 @@ CASES = [
     (768, 96, "blocks", [900, 100], None),       # D = 768, L > 80: generic kernel
     (512, 80, "crowded", [210000], 8),           # run-head bitmask of the episode exceeds LDS: generic kernel
     (512, 80, "crowded", [150000], 8),           # largest memories the pipelined kernel takes (4700 tiles per workgroup)
+    # point-balanced chunks: the crowded cell is split over many chunks (head pieces, tail pieces, whole-chunk pieces)
+    (512, 80, "crowded", [5000, 64, 700], 24),
+    (512, 80, "crowded", [40, 33, 32, 31, 1, 2], 8),     # fewer tiles than chunks: empty chunks, one-tile chunks
+    (256, 80, "crowded", [3000, 100], 16),
+    (768, 80, "crowded", [4000, 10], 24),
 ]
 
 

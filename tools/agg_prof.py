@@ -3,7 +3,7 @@ import ctypes, sys, torch
 sys.path.insert(0, ".")
 import bench, argparse
 from gridmm_amd import _lib
-sys.argv = ["bench.py", "--steps", "5", "--warmup", "3", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-roofline"] + sys.argv[1:]
+sys.argv = ["bench.py", "--steps", "5", "--warmup", "3", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-roofline", "--no-depth-legs", "--no-producer-leg", "--no-train-leg"] + sys.argv[1:]
 try:
     bench.main()
 except SystemExit:
@@ -13,6 +13,6 @@ lib = _lib.load()
 buf = (ctypes.c_longlong * 64)()
 lib.gridmm_debug_agg_prof.argtypes = [ctypes.c_void_p]
 print("rc", lib.gridmm_debug_agg_prof(buf))
-print("wave 3a tabread+mask wait dma work 3a(old) mfma flush")
+print("wave: total prologue wait(head+barrier) dma_prepare work - vmcnt_wait ntiles   (cycles; workgroup x=3, y=5)")
 for w in range(8):
     print(w, [buf[w * 8 + j] for j in range(8)])
