@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-depth-legs", action="store_true", help="skip the extra t = 5 / t = 15 timings")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the pre-training step timing (train_samples_per_s)")
+    ap.add_argument("--train-leg-only", action="store_true", help="(internal) run the training leg and print its JSON")
     ap.add_argument("--no-producer-leg", action="store_true", help="skip the VLN-CE step with the CLIP tower in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -242,10 +243,13 @@ def producer_leg(args, dev, steps=5):
 def train_leg(args, dev, steps=6):
     """Secondary: one pre-training step (config 3's per-GPU shape) -- forward + backward + gradient clip + fused AdamW
     of the full-size GlocalTextPathCMTPreTraining, B = 32, native grid memory of 3-5 observations, tasks cycling
-    mlm / mrc / sap as the task-mixed loop does (pretrain_src/train_r2r.py:231-303).  Eager launches."""
+    mlm / mrc / sap as the task-mixed loop does (pretrain_src/train_r2r.py:231-303).  Timed twice: launched eagerly from
+    Python, and as one hipGraph per task (gridmm_amd/train_graph.py: same kernels, same updates; lr schedule, AdamW bias
+    correction and dropout seeds advance per replay)."""
     from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
     from gridmm_amd.pretrain_loop import PreTrainer, default_opts
     from gridmm_amd.synthetic import batch_to, make_pretrain_batch
+    from gridmm_amd.train_graph import GraphedTrainStep
     from gridmm_amd.vilmodel import default_config
     cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=["mlm", "mrc", "sap"], image_prob_size=1000, obj_prob_size=0)
     torch.manual_seed(0)
@@ -262,12 +266,40 @@ def train_leg(args, dev, steps=6):
     for i in range(steps):
         tr.train_step(batches[tasks[i % 3]], tasks[i % 3])
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    del tr, model, batches
+    dt_eager = (time.perf_counter() - t0) / steps
+    graphs = {t: GraphedTrainStep(tr, batches[t], t) for t in tasks}
+    for t in tasks:
+        graphs[t]()
+    torch.cuda.synchronize()
+    n = 4 * steps
+    t0 = time.perf_counter()
+    for i in range(n):
+        losses, _ = graphs[tasks[i % 3]]()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    finite = bool(torch.isfinite(losses).all())
+    del graphs, tr, model, batches
     torch.cuda.empty_cache()
+    if not finite:
+        raise SystemExit("bench.py: the captured training step produced non-finite losses")
     return {"train_samples_per_s": args.batch / dt, "ms_per_step": 1e3 * dt, "batch": args.batch,
+            "launch": "hipGraph replay, one graph per task (train_graph.GraphedTrainStep)",
+            "eager": {"train_samples_per_s": args.batch / dt_eager, "ms_per_step": 1e3 * dt_eager},
             "workload": "pre-training step (mlm/mrc/sap cycling), full-size model, native 12x49x768 grid memory t=3..5, "
-                        "fwd + bwd + clip + fused AdamW, eager launches"}
+                        "fwd + bwd + clip + fused AdamW"}
+
+
+def train_leg_subprocess(args):
+    """The training leg in its own process: GraphedTrainStep needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in place before the
+    HIP runtime starts (gridmm_amd/train_graph.py), and the headline graph keeps the runtime's default."""
+    import subprocess
+    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="0")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-leg-only", "--batch", str(args.batch)],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise SystemExit("bench.py: the training leg failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+    return json.loads(lines[-1])
 
 
 def roofline_leg(step, args, geom, L=80):
@@ -394,6 +426,9 @@ def main():
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.train_leg_only:
+        print(json.dumps(train_leg(args, dev)))
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist  # RCCL ("nccl" backend on ROCm)
@@ -432,7 +467,7 @@ def main():
             out["t%d" % t] = {"value": n_gpus * args.batch / sec, "unit": "steps/s", "ms_per_step": 1e3 * sec,
                               "mem_steps": t, "points": geom.pts_per_obs * t}
     if rank == 0 and n_gpus == 1 and not args.no_train_leg:
-        out["train"] = train_leg(args, dev)
+        out["train"] = train_leg_subprocess(args)
     if rank == 0 and n_gpus == 1 and not args.no_producer_leg:
         out["vlnce_with_producer"] = producer_leg(args, dev)
     if rank == 0 and not args.no_roofline:

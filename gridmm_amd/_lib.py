@@ -57,14 +57,14 @@ SIGNATURES = {
     "gridmm_layernorm_bwd": [_vp, _i, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_activation": [_vp, _vp, _vp, _i64, _i, _vp],
     "gridmm_attention_train": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i,
-                               _i, _i, _i, _i, _f, _f, ctypes.c_uint64, _vp],
+                               _i, _i, _i, _i, _f, _f, ctypes.c_uint64, _vp, _vp],
     "gridmm_attention_bwd": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i64, _i,
                              _vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f,
-                             ctypes.c_uint64, _vp],
+                             ctypes.c_uint64, _vp, _vp],
     "gridmm_grid_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_grid_aggregate_bwd_routed": [_vp] * 9 + [_i, _i, _i, _i, _vp],
     "gridmm_grad_sumsq": [_vp, _i64, _i, _vp, _vp],
-    "gridmm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
+    "gridmm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _vp, _vp],
     "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_multi_grad_sumsq": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "gridmm_multi_adamw_step": [_vp, _vp, _i, _i, _f, _f, _i, _vp, _f, _vp],

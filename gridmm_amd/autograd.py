@@ -21,7 +21,7 @@ import weakref
 
 import torch
 
-from . import _lib, ops
+from . import _lib, hostsync as hs, ops
 from .ops import _p, _rows2d, _stream
 
 
@@ -65,6 +65,7 @@ class _WeightCache:
 
 
 WEIGHTS = _WeightCache()
+SEED_DEV = None        # device int64[1]: per-replay seed word of a captured training step (set by train_graph.py)
 SPLITK_OFF = bool(int(__import__('os').environ.get('GRIDMM_SPLITK_OFF', '0')))   # A/B switch for tools/bench_train.py
 
 
@@ -267,14 +268,17 @@ class _Attention(torch.autograd.Function):
         scale = 1.0 / math.sqrt(64.0)
         # one 63-bit seed per call from torch's CPU generator (reproducible under torch.manual_seed); the kernels
         # derive the keep-mask of element (b,h,q,k) from it, forward and backward alike
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dropout_p > 0 else 0
+        seed = hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item())) if dropout_p > 0 else 0
+        # captured steps (train_graph.py): the kernel arguments are frozen in the graph, so the part of the seed that
+        # changes from replay to replay is a device word the kernels read (SEED_DEV, bumped before every replay)
+        seed_dev = SEED_DEV if (dropout_p > 0 and hs.MODE is not None) else None
         _lib.check(lib.gridmm_attention_train(
             _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
             _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(lse), Sqp, B, heads, Sq, Sk,
-            scale, float(dropout_p), seed, _stream()), "gridmm_attention_train")
+            scale, float(dropout_p), seed, _p(seed_dev), _stream()), "gridmm_attention_train")
         ctx.save_for_backward(q_src, kv_src, kmask, out, lse)
         ctx.cols, ctx.heads, ctx.same, ctx.scale = cols, heads, same, scale
-        ctx.dropout_p, ctx.seed = float(dropout_p), seed
+        ctx.dropout_p, ctx.seed, ctx.seed_dev = float(dropout_p), seed, seed_dev
         return out
 
     @staticmethod
@@ -296,7 +300,8 @@ class _Attention(torch.autograd.Function):
             _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
             _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(dout), Sq * H, H, _p(lse),
             _p(delta), _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0), dk.stride(1), _p(dv), dv.stride(0),
-            dv.stride(1), B, heads, Sq, Sk, Sqp, ctx.scale, ctx.dropout_p, ctx.seed, _stream()), "gridmm_attention_bwd")
+            dv.stride(1), B, heads, Sq, Sk, Sqp, ctx.scale, ctx.dropout_p, ctx.seed, _p(ctx.seed_dev), _stream()),
+                   "gridmm_attention_bwd")
         return dq_src, (None if ctx.same else dkv_src), None, None, None, None
 
 

@@ -21,7 +21,9 @@ __global__ __launch_bounds__(256) void attention_kernel(
     int k_rs, const float* __restrict__ V, int64_t v_bs, int v_rs, const uint8_t* __restrict__ kmask,
     int mask_bs, float* __restrict__ O, int64_t o_bs, int o_rs, unsigned short* __restrict__ Ohi,
     unsigned short* __restrict__ Olo, int64_t p_bs, int p_rs, int Sq, int Sk, float scale,
-    float* __restrict__ lse, int Sqp, float drop_p, unsigned long long seed) {
+    float* __restrict__ lse, int Sqp, float drop_p, unsigned long long seed,
+    const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;   // per-replay part of the seed (captured training steps)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 16;
   if (q0 >= Sq) return;
@@ -171,7 +173,7 @@ extern "C" int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const fl
   dim3 grid((Sq + 63) / 64, heads, B), block(256);
   GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
                      v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs,
-                     p_rs, Sq, Sk, scale, (float*)nullptr, 0, 0.f, 0ull);
+                     p_rs, Sq, Sk, scale, (float*)nullptr, 0, 0.f, 0ull, (const unsigned long long*)nullptr);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -180,7 +182,8 @@ extern "C" int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, co
                                       int k_rs, const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask,
                                       int mask_bs, float* O, int64_t o_bs, int o_rs, float* lse, int Sqp, int B,
                                       int heads, int Sq, int Sk, float scale, float dropout_p,
-                                      unsigned long long seed, gridmm_stream_t stream) {
+                                      unsigned long long seed, const unsigned long long* seed_dev,
+                                      gridmm_stream_t stream) {
   if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || !O || !lse || Sqp < Sq || Sqp % 16) return GRIDMM_EINVAL;
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return GRIDMM_EINVAL;
   if ((q_rs | k_rs | v_rs | o_rs) & 3) return GRIDMM_EINVAL;
@@ -188,7 +191,7 @@ extern "C" int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, co
   dim3 grid((Sq + 63) / 64, heads, B), block(256);
   GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
                      v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)nullptr, (unsigned short*)nullptr,
-                     (int64_t)0, 0, Sq, Sk, scale, lse, Sqp, dropout_p, seed);
+                     (int64_t)0, 0, Sq, Sk, scale, lse, Sqp, dropout_p, seed, seed_dev);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(
     const float* __restrict__ V, int64_t v_bs, int v_rs, const uint8_t* __restrict__ kmask, int mask_bs,
     const float* __restrict__ dO, int64_t do_bs, int do_rs, const float* __restrict__ lse,
     const float* __restrict__ delta, float* __restrict__ dQ, int64_t dq_bs, int dq_rs, int Sq, int Sk, int Sqp,
-    float scale, float drop_p, unsigned long long seed) {
+    float scale, float drop_p, unsigned long long seed,
+    const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q0 = (blockIdx.x * 4 + wave) * 16;
   if (q0 >= Sq) return;
@@ -138,7 +140,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(
     const float* __restrict__ V, int64_t v_bs, int v_rs, const uint8_t* __restrict__ kmask, int mask_bs,
     const float* __restrict__ dO, int64_t do_bs, int do_rs, const float* __restrict__ lse,
     const float* __restrict__ delta, float* __restrict__ dK, int64_t dk_bs, int dk_rs, float* __restrict__ dV,
-    int64_t dv_bs, int dv_rs, int Sq, int Sk, int Sqp, float scale, float drop_p, unsigned long long seed) {
+    int64_t dv_bs, int dv_rs, int Sq, int Sk, int Sqp, float scale, float drop_p, unsigned long long seed,
+    const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int key0 = (blockIdx.x * 4 + wave) * 16;
   if (key0 >= Sk) return;
@@ -211,7 +215,8 @@ extern "C" int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, cons
                                     int do_rs, const float* lse, float* delta, float* dQ, int64_t dq_bs, int dq_rs,
                                     float* dK, int64_t dk_bs, int dk_rs, float* dV, int64_t dv_bs, int dv_rs, int B,
                                     int heads, int Sq, int Sk, int Sqp, float scale, float dropout_p,
-                                    unsigned long long seed, gridmm_stream_t stream) {
+                                    unsigned long long seed, const unsigned long long* seed_dev,
+                                    gridmm_stream_t stream) {
   if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || Sqp < Sq || Sqp % 16) return GRIDMM_EINVAL;
   if ((q_rs | k_rs | v_rs | o_rs | do_rs | dq_rs | dk_rs | dv_rs) & 3) return GRIDMM_EINVAL;
   if ((q_bs | k_bs | v_bs | o_bs | do_bs | dq_bs | dk_bs | dv_bs) & 3) return GRIDMM_EINVAL;
@@ -223,11 +228,11 @@ extern "C" int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, cons
   // the K scale is folded into the S = Q K^T product once: dq kernel scales Q, dkv kernel scales K
   GRIDMM_LAUNCH(attention_bwd_dq_kernel, dim3((Sq + 63) / 64, heads, B), dim3(256), 0, st, Q, q_bs, q_rs, K, k_bs,
                 k_rs, V, v_bs, v_rs, kmask, mask_bs, dO, do_bs, do_rs, lse, delta, dQ, dq_bs, dq_rs, Sq, Sk, Sqp,
-                scale, dropout_p, seed);
+                scale, dropout_p, seed, seed_dev);
   GRIDMM_CHECK_LAUNCH();
   GRIDMM_LAUNCH(attention_bwd_dkv_kernel, dim3((Sk + 63) / 64, heads, B), dim3(256), 0, st, Q, q_bs, q_rs, K, k_bs,
                 k_rs, V, v_bs, v_rs, kmask, mask_bs, dO, do_bs, do_rs, lse, delta, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs,
-                Sq, Sk, Sqp, scale, dropout_p, seed);
+                Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -220,7 +220,7 @@ extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void*
   if (M <= 0 || C <= 0 || Mp < M || Mp % 32) return GRIDMM_EINVAL;
   if (R_hi && (!R_lo || ldp < C || ldp % 8)) return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (colsum && hipMemsetAsync(colsum, 0, (size_t)C * sizeof(float), st) != hipSuccess) return GRIDMM_ELAUNCH;
+  if (colsum && !gridmm_zero_f32(colsum, (size_t)C, st)) return GRIDMM_ELAUNCH;
   dim3 grid((C + 63) / 64, (Mp + 64 * TS_TILES - 1) / (64 * TS_TILES)), block(256);
   GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)T_hi, (unsigned short*)T_lo,
                 colsum, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp);
@@ -519,7 +519,7 @@ extern "C" int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, 
                                          gridmm_stream_t stream) {
   if (B <= 0 || cap <= 0 || L <= 0 || D <= 0 || D % 2 || D > 128 * AGG_MAXV) return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(dtext, 0, (size_t)B * L * D * sizeof(float), st) != hipSuccess) return GRIDMM_ELAUNCH;
+  if (!gridmm_zero_f32(dtext, (size_t)B * L * D, st)) return GRIDMM_ELAUNCH;
   const int nv = (D + 127) / 128;
   dim3 gp((cap + 4 * AGG_P - 1) / (4 * AGG_P), B), gc(GRIDMM_CELLS, B), block(256);
 #define GRIDMM_AGGB(NV)                                                                                          \

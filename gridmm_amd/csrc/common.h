@@ -29,6 +29,20 @@ constexpr int MAX_H_BWD = 1024;   // widest row the LayerNorm backward stages in
 
 static inline hipStream_t as_stream(gridmm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Zero-fill as a KERNEL (n floats).  hipMemsetAsync is not used on the training path: replayed from a captured hipGraph
+// its memset nodes left the destination un-cleared (ROCm 7.2: the column sums / partial sums that are then accumulated
+// with atomics came out wrong from the second replay on), a kernel node replays like every other launch.
+static __global__ void gridmm_zero_f32_kernel(float* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+static inline bool gridmm_zero_f32(float* p, size_t n, hipStream_t st) {
+  if (n == 0) return true;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gridmm_zero_f32_kernel, dim3(blocks), dim3(256), 0, st, p, n);
+  return hipGetLastError() == hipSuccess;
+}
+
 // fp32 -> bf16 bits, round-to-nearest-even (inputs are finite on this path).
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
   unsigned int u = __float_as_uint(x);

@@ -33,7 +33,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m,
                                                     T* __restrict__ v, size_t n, float lr, float b1, float b2,
                                                     float eps, float wd, float step_size, int decay_first,
-                                                    const float* __restrict__ sumsq, float max_norm) {
+                                                    const float* __restrict__ sumsq, float max_norm,
+                                                    const float* __restrict__ dyn) {
+  if (dyn) { lr = dyn[0]; step_size = dyn[1]; eps = dyn[2]; }   // captured steps: this step's scalars from device memory
   float scale = 1.f;
   if (sumsq) {
     const float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
@@ -142,16 +144,16 @@ extern "C" int gridmm_grad_sumsq(const void* g, int64_t n, int dtype, float* acc
 
 extern "C" int gridmm_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, int dtype, float lr, float beta1,
                                  float beta2, float eps, float weight_decay, float step_size, int decay_first,
-                                 const float* sumsq, float max_norm, gridmm_stream_t stream) {
+                                 const float* sumsq, float max_norm, const float* dyn, gridmm_stream_t stream) {
   if (n <= 0 || (dtype != 0 && dtype != 1)) return GRIDMM_EINVAL;
   hipStream_t st_ = as_stream(stream);
   if (dtype == 0)
     GRIDMM_LAUNCH((adamw_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st_, (float*)p, (const float*)g, (float*)m,
-                  (float*)v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step_size, decay_first, sumsq, max_norm);
+                  (float*)v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step_size, decay_first, sumsq, max_norm, dyn);
   else
     GRIDMM_LAUNCH((adamw_kernel<_Float16>), dim3(grid_for(n)), dim3(256), 0, st_, (_Float16*)p, (const _Float16*)g,
                   (_Float16*)m, (_Float16*)v, (size_t)n, lr, beta1, beta2, eps, weight_decay, step_size, decay_first,
-                  sumsq, max_norm);
+                  sumsq, max_norm, dyn);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -160,7 +162,7 @@ extern "C" int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first,
                                        float* partial64, float* out, gridmm_stream_t stream) {
   if (n_tensors <= 0 || n_chunks <= 0 || !partial64 || !out) return GRIDMM_EINVAL;
   hipStream_t st_ = as_stream(stream);
-  if (hipMemsetAsync(partial64, 0, 64 * sizeof(float), st_) != hipSuccess) return GRIDMM_ELAUNCH;
+  if (!gridmm_zero_f32(partial64, 64, st_)) return GRIDMM_ELAUNCH;
   GRIDMM_LAUNCH(multi_sumsq_kernel, dim3(n_chunks), dim3(256), 0, st_, (const TensorDesc*)desc, chunk_first, n_tensors,
                 partial64);
   GRIDMM_CHECK_LAUNCH();

@@ -53,21 +53,73 @@ class AdamW(torch.optim.Optimizer):
                      ("lr", "<f4"), ("step_size", "<f4"), ("eps", "<f4"), ("wd", "<f4")])
     _CHUNK = 16384
 
-    def _tables(self, items, dev):
-        """items: list of (p, g, exp_avg, exp_avg_sq, lr, step_size, eps, wd) for contiguous fp32 tensors."""
+    def _tables(self, items, dev, graph_tabs=None, key=None):
+        """items: list of (p, g, exp_avg, exp_avg_sq, lr, step_size, eps, wd) for contiguous fp32 tensors.
+        graph_tabs (captured steps): the table lives in a pinned host pool mirrored by a device pool, both allocated
+        BEFORE the capture; nothing is copied inside the graph -- refresh_graph_tables() rewrites lr / step_size / eps in
+        the pinned copy and uploads the pool on the replay's stream before every replay.  (An H2D copy node inside the
+        graph was tried first: replayed, it raced with the kernels reading the table -- wild pointers at full size.)"""
         rec = np.zeros(len(items), self._REC)
         first = np.zeros(len(items) + 1, np.int32)
         for i, (p, g, m, v, lr, ss, eps, wd) in enumerate(items):
             rec[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, ss, eps, wd)
             first[i + 1] = first[i] + -(-p.numel() // self._CHUNK)
         blob = np.concatenate([rec.view(np.uint8), first.view(np.uint8)])
-        d = torch.from_numpy(blob).to(dev, non_blocking=True)
+        if graph_tabs is None:
+            d = torch.from_numpy(blob).to(dev, non_blocking=True)
+        else:
+            pinned, d = self._carve(graph_tabs, len(blob))
+            pinned.numpy()[:] = blob
+            graph_tabs["multi"][key] = (pinned, d, rec.nbytes, [it[0] for it in items])
         return d, rec.nbytes, int(first[-1])
 
+    @staticmethod
+    def _carve(graph_tabs, nbytes):
+        """Matching slices of the pinned pool and of its device mirror (both allocated by the caller BEFORE the capture)."""
+        o = (graph_tabs["used"] + 63) // 64 * 64
+        if o + nbytes > graph_tabs["pool"].numel():
+            raise RuntimeError("graph_tabs: pinned pool too small")
+        graph_tabs["used"] = o + nbytes
+        return graph_tabs["pool"][o:o + nbytes], graph_tabs["dev_pool"][o:o + nbytes]
+
+    def _step_scalars(self, group, state):
+        b1, b2 = group["betas"]
+        step_size, eps = group["lr"], group["eps"]
+        if group["correct_bias"]:
+            bc2 = math.sqrt(1.0 - b2 ** state["step"])
+            step_size = step_size * bc2 / (1.0 - b1 ** state["step"])
+            if group["decay_first"]:
+                eps = eps * bc2       # torch.optim.AdamW: m/bc1 / (sqrt(v/bc2) + eps) == step_size * m / (sqrt(v) + eps*sqrt(bc2))
+        return float(group["lr"]), float(step_size), float(eps)
+
+    def refresh_graph_tables(self, graph_tabs, advance=True):
+        """Before a replay of a captured step: the next step's lr / bias-corrected step size / eps of every parameter
+        of that graph go into its pinned tables (the graph's own copy nodes upload them)."""
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        for pinned, _, rec_bytes, params in graph_tabs["multi"].values():
+            rec = pinned.numpy()[:rec_bytes].view(self._REC)
+            for i, p in enumerate(params):
+                st = self.state[p]
+                if advance:
+                    st["step"] += 1
+                rec["lr"][i], rec["step_size"][i], rec["eps"][i] = self._step_scalars(group_of[id(p)], st)
+        if graph_tabs["single"] is not None:
+            pinned, _, params = graph_tabs["single"]
+            dyn = pinned.numpy()
+            for i, p in enumerate(params):
+                st = self.state[p]
+                if advance:
+                    st["step"] += 1
+                dyn[3 * i:3 * i + 3] = self._step_scalars(group_of[id(p)], st)
+        n = graph_tabs["used"]
+        graph_tabs["dev_pool"][:n].copy_(graph_tabs["pool"][:n], non_blocking=True)      # ordered before the replay
+
     @torch.no_grad()
-    def step(self, closure=None, max_grad_norm=None):
+    def step(self, closure=None, max_grad_norm=None, graph_tabs=None):
         """max_grad_norm: fuse clip_grad_norm_(all parameters of this optimizer, max_grad_norm) into the update.
-        Returns the (pre-clip) gradient norm as a device scalar when clipping, else None."""
+        Returns the (pre-clip) gradient norm as a device scalar when clipping, else None.
+        graph_tabs: dict(multi={}, single=None, pool=<pinned uint8>, dev_pool=<device uint8>, used=0) filled during the
+        capture of a training step (train_graph.py)."""
         lib = _lib.load()
         multi, single = [], []
         for group, p in self._live():
@@ -80,12 +132,7 @@ class AdamW(torch.optim.Optimizer):
                 state["exp_avg_sq"] = torch.zeros_like(p)
             state["step"] += 1
             b1, b2 = group["betas"]
-            step_size, eps = group["lr"], group["eps"]
-            if group["correct_bias"]:
-                bc2 = math.sqrt(1.0 - b2 ** state["step"])
-                step_size = step_size * bc2 / (1.0 - b1 ** state["step"])
-                if group["decay_first"]:
-                    eps = eps * bc2       # torch.optim.AdamW: m/bc1 / (sqrt(v/bc2) + eps) == step_size * m / (sqrt(v) + eps*sqrt(bc2))
+            _, step_size, eps = self._step_scalars(group, state)
             g = p.grad.contiguous()
             if g.dtype != p.dtype:
                 g = g.to(p.dtype)
@@ -99,7 +146,7 @@ class AdamW(torch.optim.Optimizer):
         classes = {}
         for it in multi:
             classes.setdefault(it[8:], []).append(it[:8])
-        tables = {k: self._tables(v, dev) for k, v in classes.items()}
+        tables = {k: self._tables(v, dev, graph_tabs, k) for k, v in classes.items()}
         sumsq = None
         if max_grad_norm is not None:
             sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -116,10 +163,16 @@ class AdamW(torch.optim.Optimizer):
             _lib.check(lib.gridmm_multi_adamw_step(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
                                                    n_chunks, b1, b2, df, _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
                                                    float(max_grad_norm or 0.0), _stream()), "gridmm_multi_adamw_step")
-        for p, g, m, v, lr, ss, eps, wd, b1, b2, df in single:            # fp16 parameters (the pre-training grid_proj)
+        dyn = None
+        if graph_tabs is not None and single:                              # lr / step_size / eps of the fp16 tensors, per replay
+            pinned, dyn = (t.view(torch.float32) for t in self._carve(graph_tabs, 12 * len(single)))
+            graph_tabs["single"] = (pinned, dyn, [it[0] for it in single])
+        for i, (p, g, m, v, lr, ss, eps, wd, b1, b2, df) in enumerate(single):   # fp16 parameters (the pre-training grid_proj)
             _lib.check(lib.gridmm_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), 1, lr, b1, b2, eps, wd, ss, df,
                                              _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
-                                             float(max_grad_norm or 0.0), _stream()), "gridmm_adamw_step")
+                                             float(max_grad_norm or 0.0),
+                                             ctypes.c_void_p(dyn.data_ptr() + 12 * i) if dyn is not None else ctypes.c_void_p(0),
+                                             _stream()), "gridmm_adamw_step")
         for it in multi + single:
             _bump_version(it[0])
         self._keepalive = (tables, multi, single)      # device tables / cast gradients must outlive the async launches

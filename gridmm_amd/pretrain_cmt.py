@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import autograd as ag, vilmodel as V, vilmodel_train as VT
+from . import autograd as ag, hostsync as hs, vilmodel as V, vilmodel_train as VT
 
 N_CELLS = 196
 
@@ -77,27 +77,31 @@ class GlocalTextPathCMT(nn.Module):
         # the host from the vpid lists (GlobalMapEncoder._aggregate_gmap_features, vilmodel.py:569-604)
         G = batch["gmap_step_ids"].shape[1]
         Tmax = max(step_lens)
-        W = torch.zeros(B, G, Tmax * Vmax)
-        vl = view_lens.cpu().tolist()
-        for i in range(B):
-            visited, unvisited = {}, {}
-            for t in range(step_lens[i]):
-                n = vl[offs[i] + t]
-                visited[batch["traj_vpids"][i][t]] = (t, n)
-                for j, vp in enumerate(batch["traj_cand_vpids"][i][t]):
-                    if vp not in visited:
-                        unvisited.setdefault(vp, []).append((t, j))
-            for k, vp in enumerate(batch["gmap_vpids"][i][1:]):
-                if vp in visited:
-                    t, n = visited[vp]
-                    W[i, k + 1, t * Vmax:t * Vmax + n] = 1.0 / n
-                else:
-                    occ = unvisited[vp]
-                    for t, j in occ:
-                        W[i, k + 1, t * Vmax + j] += 1.0 / len(occ)
+
+        def gmap_weights():                                               # a host decision (hostsync): python loops + upload
+            W = torch.zeros(B, G, Tmax * Vmax)
+            vl = view_lens.cpu().tolist()
+            for i in range(B):
+                visited, unvisited = {}, {}
+                for t in range(step_lens[i]):
+                    n = vl[offs[i] + t]
+                    visited[batch["traj_vpids"][i][t]] = (t, n)
+                    for j, vp in enumerate(batch["traj_cand_vpids"][i][t]):
+                        if vp not in visited:
+                            unvisited.setdefault(vp, []).append((t, j))
+                for k, vp in enumerate(batch["gmap_vpids"][i][1:]):
+                    if vp in visited:
+                        t, n = visited[vp]
+                        W[i, k + 1, t * Vmax:t * Vmax + n] = 1.0 / n
+                    else:
+                        occ = unvisited[vp]
+                        for t, j in occ:
+                            W[i, k + 1, t * Vmax + j] += 1.0 / len(occ)
+            return W.to(dev)
+        W = hs.host(gmap_weights)
         tok = torch.cat([F.pad(traj[offs[i]:offs[i + 1]].reshape(-1, H), (0, 0, 0, (Tmax - step_lens[i]) * Vmax))
                          .unsqueeze(0) for i in range(B)], 0)
-        gmap_img = torch.bmm(W.to(dev), tok)                               # row 0 ([stop]) stays zero
+        gmap_img = torch.bmm(W, tok)                               # row 0 ([stop]) stays zero
         ge, le = b.global_encoder, b.local_encoder
         gmap_input = gmap_img + ge.gmap_step_embeddings(batch["gmap_step_ids"].long()) + ag.layer_norm(
             ag.linear(batch["gmap_pos_fts"].float(), ge.gmap_pos_embeddings[0].weight, ge.gmap_pos_embeddings[0].bias),
@@ -105,9 +109,9 @@ class GlocalTextPathCMT(nn.Module):
         gmap_masks = _seq_masks(batch["gmap_lens"], G)
 
         # local branch input: last step's tokens behind a zero [stop] token (vp_input_embedding, vilmodel.py:545-560)
-        last = torch.tensor([offs[i + 1] - 1 for i in range(B)], device=dev)
+        last = hs.host(lambda: torch.tensor([offs[i + 1] - 1 for i in range(B)], device=dev))
         vp_lens = view_lens[last] + 1
-        max_vp = int(vp_lens.max())
+        max_vp = hs.host(lambda: int(vp_lens.max()))
         vp_img = torch.cat([traj.new_zeros(B, 1, H), traj[last]], 1)[:, :max_vp]
         vp_input = vp_img + ag.layer_norm(
             ag.linear(batch["vp_pos_fts"].float(), le.vp_pos_embeddings[0].weight, le.vp_pos_embeddings[0].bias),
@@ -217,7 +221,7 @@ class RegionClassification(nn.Module):
 def _seq_masks(lens, max_len=None):
     lens = lens.long()
     if max_len is None:
-        max_len = int(lens.max())
+        max_len = hs.host(lambda: int(lens.max()))
     return torch.arange(max_len, device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
 
 
@@ -295,13 +299,13 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         txt = self.bert._mlm_text(self._front(batch))
         labels = batch["txt_labels"]
         sel = labels != -1
-        hidden = txt[sel]                                                     # only masked tokens
+        hidden = hs.select(txt, sel)                                          # only masked tokens
         p = self.mlm_head.predictions
         h = ag.layer_norm(ag.gelu(ag.linear(hidden, p.transform.dense.weight, p.transform.dense.bias)),
                           p.transform.LayerNorm)
         scores = ag.linear(h, p.decoder.weight, p.bias)                       # decoder(h) + bias
         if compute_loss:
-            return F.cross_entropy(scores, labels[sel].long(), reduction="none")
+            return F.cross_entropy(scores, hs.select(labels, sel).long(), reduction="none")
         return scores
 
     @staticmethod
@@ -316,15 +320,15 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         one = torch.ones(B, dtype=torch.long, device=vp_embeds.device)
         masks = batch["vp_view_mrc_masks"].bool()
         view_embeds, _ = _gather_span(vp_embeds, one, f["last_view_lens"], masks.shape[1])      # [stop] at 0
-        view_logits = self._region_head(self.image_classifier, view_embeds[masks])
-        view_targets = batch["vp_view_probs"][masks]
+        view_logits = self._region_head(self.image_classifier, hs.select(view_embeds, masks))
+        view_targets = hs.select(batch["vp_view_probs"], masks)
         obj_logits = obj_targets = None
         if f["last_obj_lens"] is not None:
             omasks = batch["vp_obj_mrc_masks"].bool()
             obj_embeds, _ = _gather_span(vp_embeds, one + f["last_view_lens"], f["last_obj_lens"], omasks.shape[1])
             head = self.image_classifier if self.obj_classifier is None else self.obj_classifier
-            obj_logits = self._region_head(head, obj_embeds[omasks])
-            obj_targets = batch["vp_obj_probs"][omasks]
+            obj_logits = self._region_head(head, hs.select(obj_embeds, omasks))
+            obj_targets = hs.select(batch["vp_obj_probs"], omasks)
         if not compute_loss:
             return view_logits, view_targets, obj_logits, obj_targets
         loss = F.kl_div(F.log_softmax(view_logits, -1), view_targets, reduction="none").sum(1)
@@ -337,7 +341,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         _, vp_embeds, _, f = self._bert_forward(batch)
         B = vp_embeds.shape[0]
         one = torch.ones(B, dtype=torch.long, device=vp_embeds.device)
-        max_obj = int(f["last_obj_lens"].max())
+        max_obj = hs.host(lambda: int(f["last_obj_lens"].max()))
         obj_embeds, obj_masks = _gather_span(vp_embeds, one + f["last_view_lens"], f["last_obj_lens"], max_obj)
         obj_logits = VT.cls_head(self.og_head, obj_embeds).masked_fill(~obj_masks, -float("inf"))
         if compute_loss:
@@ -360,29 +364,31 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         nav_types = batch["traj_nav_types"][f["last"]]
         nav = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=dev), nav_types == 1], 1)[:, :Vp]
         visited = batch["gmap_visited_masks"].bool()
-        cand_of_node = torch.full((B, G), -2, dtype=torch.int32)
-        cand_visited = torch.zeros(B, Vp, dtype=torch.uint8)
-        vis_host = visited.cpu().numpy()
-        for i in range(B):
-            vset = set(vp for vp, m in zip(batch["gmap_vpids"][i], vis_host[i]) if m)
-            tmp = {}
-            for j, cv in enumerate(batch["traj_cand_vpids"][i][-1]):
-                if cv in vset:
-                    cand_visited[i, j + 1] = 1
-                else:
-                    tmp[cv] = j + 1
-            for j, vp in enumerate(batch["gmap_vpids"][i]):
-                if j > 0 and vp not in vset:
-                    cand_of_node[i, j] = tmp.get(vp, -1)
+        def index_maps():                                                 # a host decision (hostsync): vpid loops + upload
+            cand_of_node = torch.full((B, G), -2, dtype=torch.int32)
+            cand_visited = torch.zeros(B, Vp, dtype=torch.uint8)
+            vis_host = visited.cpu().numpy()
+            for i in range(B):
+                vset = set(vp for vp, m in zip(batch["gmap_vpids"][i], vis_host[i]) if m)
+                tmp = {}
+                for j, cv in enumerate(batch["traj_cand_vpids"][i][-1]):
+                    if cv in vset:
+                        cand_visited[i, j + 1] = 1
+                    else:
+                        tmp[cv] = j + 1
+                for j, vp in enumerate(batch["gmap_vpids"][i]):
+                    if j > 0 and vp not in vset:
+                        cand_of_node[i, j] = tmp.get(vp, -1)
+            return cand_of_node.to(dev), cand_visited.to(dev)
+        cand_of_node, cand_visited = hs.host(index_maps)
         global_logits, local_logits, grid_logits, fused_logits = VT.fuse_logits(
-            g_raw, l_raw, grid_raw, fuse_raw, f["gmap_masks"], visited, nav, cand_of_node.to(dev),
-            cand_visited.to(dev))
+            g_raw, l_raw, grid_raw, fuse_raw, f["gmap_masks"], visited, nav, cand_of_node, cand_visited)
         if not compute_loss:
             return global_logits, local_logits, fused_logits, batch["global_act_labels"], batch["local_act_labels"]
         gl, ll = batch["global_act_labels"].long(), batch["local_act_labels"].long()
         losses = [F.cross_entropy(global_logits, gl, reduction="none"), F.cross_entropy(local_logits, ll, reduction="none"),
                   F.cross_entropy(fused_logits, gl, reduction="none"), F.cross_entropy(grid_logits, gl, reduction="none")]
-        n_stop, n_go = int((gl == 0).sum()), int((gl != 0).sum())
+        n_stop, n_go = hs.host(lambda: (int((gl == 0).sum()), int((gl != 0).sum())))
         stop_rate = n_stop / n_go if n_go != 0 else 1.0                       # :278-281: stop samples are re-weighted
         out = 0
         for loss, lab in zip(losses, (gl, ll, gl, gl)):

@@ -1,0 +1,112 @@
+"""A pre-training step (forward + losses + backward + gradient clip + AdamW) as ONE hipGraph.
+
+The eager step (pretrain_loop.PreTrainer.train_step) is ~2000 launches issued from Python: two thirds of its wall
+time is host work.  Captured, the same launches replay from the device's command processor.  What a capture cannot
+contain, and where it goes instead:
+
+  host decisions of the forward        recorded once by an ordinary eager step (hostsync.record), replayed as constants
+  (shapes from lengths, index tensors  during the capture: a graph therefore belongs to ONE batch metadata signature
+  from vpid lists, x[mask] gathers)    (lengths, vpid lists, masked positions); the batch's DATA tensors are static inputs
+  attention-dropout seeds              frozen kernel arguments + a device seed word the kernels read (autograd.SEED_DEV),
+                                       uploaded before every replay; torch.dropout uses torch's graph-safe generator
+  lr schedule, AdamW bias correction   per-parameter lr / step_size / eps live in pinned host tables mirrored on the
+                                       device; AdamW.refresh_graph_tables rewrites and uploads them before a replay
+                                       (no copy / memset NODES in the graph: both misbehaved when replayed)
+  packed-weight caches                 the re-split of every weight is part of the captured step; versions are bumped
+                                       after a replay so that eager users of the caches re-pack
+
+ROCm 7.2 note (measured, tools/dbg_graph_train3.py): with the runtime's pre-recorded graph packets (the default) the
+replay of this graph faults on the device (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION at the third replay of the
+full-size step; bisected to the presence of the two fp16 AdamW launches) and hipMemsetAsync / H2D-copy NODES misbehave;
+with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the HIP runtime starts, the same graph replays
+correctly.  GraphedTrainStep refuses to run without it; bench.py and the tests run this leg in a subprocess that sets it
+(the navigation-step graph of the headline is unaffected and keeps the default).
+
+Reference loop: pretrain_src/train_r2r.py:231-303 (one process; gradient_accumulation_steps == 1).  A training loop over
+real data would keep one graph per (task, padded-shape bucket) and feed index tensors as inputs; this class covers the
+fixed-metadata case (bench.py's train leg, tests/test_hip_train_graph.py).
+"""
+import os
+
+import torch
+
+from . import autograd as ag, dist as D, hostsync as hs
+from .optim import _bump_version, get_lr_sched
+
+
+RUNTIME_ENV = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
+class GraphedTrainStep:
+    def __init__(self, trainer, batch, task, warmup=1, capture_optimizer=True):
+        if os.environ.get(RUNTIME_ENV[0]) != RUNTIME_ENV[1]:
+            raise RuntimeError("GraphedTrainStep needs %s=%s in the environment before torch / HIP start (see the module "
+                               "docstring): replaying this graph with pre-recorded packets faults on ROCm 7.2" % RUNTIME_ENV)
+        o = trainer.opts
+        if o.gradient_accumulation_steps != 1 or D.is_dist():
+            raise ValueError("GraphedTrainStep: one process, gradient_accumulation_steps == 1")
+        self.tr, self.batch, self.task = trainer, batch, task
+        model, opt = trainer.model, trainer.optimizer
+        dev = next(model.parameters()).device
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.seed_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.tabs = dict(multi={}, single=None, pool=torch.empty(1 << 20, dtype=torch.uint8).pin_memory(),
+                         dev_pool=torch.zeros(1 << 20, dtype=torch.uint8, device=dev), used=0)
+        self._done = None
+        prev = ag.SEED_DEV
+        ag.SEED_DEV = self.seed_dev
+        try:
+            with hs.record() as tape:                       # an ordinary (training) step that tapes its host decisions
+                trainer.train_step(batch, task)
+            self.tape = tape
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                   # the same step from the tape: allocator pools, weight caches
+                for _ in range(warmup):
+                    with hs.replay(tape):
+                        trainer.train_step(batch, task)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            opt.zero_grad(set_to_none=True)
+            model.train()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                with hs.replay(tape):
+                    losses = model(batch, task=task, compute_loss=True)
+                    losses.mean().backward()
+                    self.norm = None
+                    if capture_optimizer:
+                        self.norm = opt.step(max_grad_norm=o.grad_norm if o.grad_norm != -1 else None, graph_tabs=self.tabs)
+                self.losses = losses.detach()
+        finally:
+            ag.SEED_DEV = prev
+        self.capture_optimizer = capture_optimizer
+        self.params = [p for tab in self.tabs["multi"].values() for p in tab[3]]
+        if self.tabs["single"] is not None:
+            self.params += self.tabs["single"][2]
+        for p in self.params:                               # the capture pass counted a step that never ran
+            opt.state[p]["step"] -= 1
+
+    def __call__(self):
+        """One training step on the static batch: returns (per-sample losses, pre-clip gradient norm) -- static device
+        tensors, overwritten by the next call."""
+        tr, opt = self.tr, self.tr.optimizer
+        if self._done is not None:
+            self._done.synchronize()                        # the previous replay has read the pinned tables / seed
+        tr.global_step += 1
+        lr = get_lr_sched(tr.global_step, tr.opts)
+        for g in opt.param_groups:
+            g["lr"] = lr
+        if self.capture_optimizer:
+            opt.refresh_graph_tables(self.tabs)
+        self.seed_host[0] = int(torch.randint(0, 2 ** 62, (1,)).item())      # torch's CPU generator, as the eager path
+        self.seed_dev.copy_(self.seed_host, non_blocking=True)
+        self.graph.replay()
+        self._done = torch.cuda.Event()
+        self._done.record()
+        if not self.capture_optimizer:                      # (debugging aid: the update launched eagerly on the static grads)
+            o = tr.opts
+            self.norm = opt.step(max_grad_norm=o.grad_norm if o.grad_norm != -1 else None)
+        for p in self.params:
+            _bump_version(p)
+        return self.losses, self.norm

@@ -15,7 +15,7 @@ the fused attention kernels from a counter-based hash, so the backward regenerat
 import torch
 import torch.nn.functional as F
 
-from . import autograd as ag, ops
+from . import autograd as ag, hostsync as hs, ops
 from .grid_memory import pack_reference_lists
 
 N_CELLS = 196
@@ -129,7 +129,7 @@ def interleave_view_obj(view_embeds, obj_embeds, view_lens, obj_lens):
     B, Vv, H = view_embeds.shape
     Vo = obj_embeds.shape[1]
     vl, ol = view_lens.long().unsqueeze(1), obj_lens.long().unsqueeze(1)
-    P = int((vl + ol).max())
+    P = hs.host(lambda: int((vl + ol).max()))
     p = torch.arange(P, device=view_embeds.device).unsqueeze(0).expand(B, P)
     from_view, from_obj = p < vl, (p >= vl) & (p < vl + ol)
     vg = view_embeds.gather(1, p.clamp(max=Vv - 1).unsqueeze(-1).expand(B, P, H))
@@ -153,7 +153,7 @@ def forward_panorama(model, view_img_fts, obj_img_fts, loc_fts, nav_types, view_
     y = ag.layer_norm(ag.linear(loc_fts.float(), ie.loc_linear.weight, ie.loc_linear.bias), ie.loc_layer_norm)
     x = x + y + ie.nav_type_embedding(nav_types) + model.embeddings.token_type_embeddings.weight[1]
     x = _drop(model, ag.layer_norm(x, ie.layer_norm))
-    masks = torch.arange(int(lens.max()), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
+    masks = torch.arange(hs.host(lambda: int(lens.max())), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
     if ie.pano_encoder is not None:
         x = pre_ln_encoder(model, ie.pano_encoder, x, masks)
     return x, masks
@@ -171,7 +171,7 @@ def grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memo
         if gridmap_pos_fts is None:
             gridmap_pos_fts = grid_memory.pos_fts.clone()    # the buffer is overwritten by the next step
     else:
-        slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
+        slab, perm, cell_start = hs.host(lambda: pack_reference_lists(grid_fts, grid_map))
     cells, occ = ag.grid_aggregate(text_fts, slab, perm, cell_start)
     w = model.grid_proj.weight if proj_weight is None else proj_weight
     proj = ag.linear(cells, w, model.grid_proj.bias if proj_bias is None else proj_bias)                 # grid_proj after the reduction (sum a_j = 1)

@@ -321,10 +321,13 @@ int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, in
 int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
                            const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
                            int64_t o_bs, int o_rs, float* lse, int Sqp, int B, int heads, int Sq, int Sk,
-                           float scale, float dropout_p, unsigned long long seed, gridmm_stream_t stream);
+                           float scale, float dropout_p, unsigned long long seed, const unsigned long long* seed_dev,
+                           gridmm_stream_t stream);
 /* dropout_p > 0: dropout on the attention probabilities (vilmodel.py:143,362; transformer.py MultiheadAttention):
  * element (b,h,q,k) is kept iff a counter-based hash of (seed, ((b*heads+h)*Sq+q)*Sk+k) >= p, survivors scaled by
- * 1/(1-p); the backward regenerates the mask from the same (dropout_p, seed). */
+ * 1/(1-p); the backward regenerates the mask from the same (dropout_p, seed).  seed_dev (device, may be NULL): a
+ * second seed word read by the kernel at run time -- the part of the seed that changes between replays of a captured
+ * (hipGraph) training step, whose kernel arguments are frozen. */
 
 /* Backward of the attention core: dQ, dK, dV from dO (fp32, exact-fp32 MFMA; masked keys get zero gradient).
  * delta [B][heads][Sqp] is a workspace (sum_d dO*O per query). */
@@ -333,7 +336,8 @@ int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, const float* K,
                          int64_t o_bs, int o_rs, const float* dO, int64_t do_bs, int do_rs, const float* lse,
                          float* delta, float* dQ, int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs, int dk_rs,
                          float* dV, int64_t dv_bs, int dv_rs, int B, int heads, int Sq, int Sk, int Sqp, float scale,
-                         float dropout_p, unsigned long long seed, gridmm_stream_t stream);
+                         float dropout_p, unsigned long long seed, const unsigned long long* seed_dev,
+                         gridmm_stream_t stream);
 
 /* Backward of gridmm_grid_aggregate w.r.t. text = text_proj(txt_embeds) (vilmodel.py:795-807; the gradient
  * reaches text_proj and the language encoder through the max / softmax weights):
@@ -356,11 +360,12 @@ int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t* perm, cons
  * min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (torch.nn.utils.clip_grad_norm_).  step_size = lr * sqrt(1-b2^t)/(1-b1^t)
  * is computed by the caller.  decay_first = 0: pretrain_src/optim/adamw.py:56-112 (decay after the update);
  * decay_first = 1: torch.optim.AdamW order (fine-tune, agent_base.py:131).  dtype 0 = fp32, 1 = fp16 (the
- * reference's fp16 grid_proj keeps fp16 optimizer state). */
+ * reference's fp16 grid_proj keeps fp16 optimizer state).  dyn (device float[3], may be NULL): lr, step_size, eps read
+ * at run time instead of the arguments -- for captured (hipGraph) steps, whose kernel arguments are frozen. */
 int gridmm_grad_sumsq(const void* g, int64_t n, int dtype, float* acc, gridmm_stream_t stream);
 int gridmm_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, int dtype, float lr, float beta1,
                       float beta2, float eps, float weight_decay, float step_size, int decay_first,
-                      const float* sumsq, float max_norm, gridmm_stream_t stream);
+                      const float* sumsq, float max_norm, const float* dyn, gridmm_stream_t stream);
 
 /* C (fp32, M x N, contiguous) = A W^T like gridmm_linear_planes, with the contraction split over `splits` (2..64)
  * workgroups per output tile; partial tiles go to `workspace` (splits * M * N floats) and are summed in a fixed order
