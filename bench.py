@@ -311,7 +311,30 @@ def roofline_leg(step, args, geom, L=80):
         step()
     torch.cuda.synchronize()
     summ = ops.TIMER.summary()
+    relaunch = getattr(ops.TIMER, "last_aggregate", None)
     ops.TIMER = None
+    agg_ms = None
+    if relaunch is not None:
+        # Device-side duration of one aggregation launch (main kernel + the merge of split cells): 10 launches captured
+        # in a hipGraph, replayed, HIP events on the replay stream.  The per-launch events of the eager steps above also
+        # time the host's launch overhead between the two kernels.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            relaunch()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(10):
+                relaunch()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        agg_ms = e0.elapsed_time(e1) / 50
     kern = {k: {"calls_per_step": v["calls"] / n, "ms_per_step": v["ms"] / n, "avg_us": 1e3 * v["ms"] / v["calls"]}
             for k, v in summ.items()}
     B, N, D = args.batch, geom.pts_per_obs * args.mem_steps, geom.feat_dim
@@ -325,9 +348,13 @@ def roofline_leg(step, args, geom, L=80):
     if "grid_aggregate" in summ:
         # algorithmic bytes per launch: slab + perm + text fragments (hi+lo) + cell vectors out
         byts = B * (N * D * 2 + N * 4 + 2 * L * D * 2 + 196 * D * 4 + 196)
-        gbs = byts / (summ["grid_aggregate"]["ms"] / summ["grid_aggregate"]["calls"] * 1e-3) / 1e9
+        per_launch_ms = agg_ms if agg_ms is not None else summ["grid_aggregate"]["ms"] / summ["grid_aggregate"]["calls"]
+        gbs = byts / (per_launch_ms * 1e-3) / 1e9
         out["grid_aggregate"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": byts}
+                                 "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": byts,
+                                 "us_per_launch": 1e3 * per_launch_ms,
+                                 "timing": "HIP events around hipGraph replays of the launch (aggregation kernel + merge "
+                                           "kernel)" if agg_ms is not None else "HIP events around the eager launch"}
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_traffic.sh:
     # FETCH_SIZE and WRITE_SIZE in separate runs, (2*FETCH + WRITE) * 1024 with the gfx950 read-side correction)
     import glob

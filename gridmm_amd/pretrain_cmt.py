@@ -17,6 +17,7 @@ to the 196 reduced vectors -- identical algebra, ~1e-3 relative difference from 
 """
 from collections import defaultdict
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -79,7 +80,7 @@ class GlocalTextPathCMT(nn.Module):
         Tmax = max(step_lens)
 
         def gmap_weights():                                               # a host decision (hostsync): python loops + upload
-            W = torch.zeros(B, G, Tmax * Vmax)
+            W = np.zeros((B, G, Tmax * Vmax), np.float32)      # (numpy: ~2000 element writes, each a torch op otherwise)
             vl = view_lens.cpu().tolist()
             for i in range(B):
                 visited, unvisited = {}, {}
@@ -97,7 +98,7 @@ class GlocalTextPathCMT(nn.Module):
                         occ = unvisited[vp]
                         for t, j in occ:
                             W[i, k + 1, t * Vmax + j] += 1.0 / len(occ)
-            return W.to(dev)
+            return torch.from_numpy(W).to(dev)
         W = hs.host(gmap_weights)
         tok = torch.cat([F.pad(traj[offs[i]:offs[i + 1]].reshape(-1, H), (0, 0, 0, (Tmax - step_lens[i]) * Vmax))
                          .unsqueeze(0) for i in range(B)], 0)
@@ -365,8 +366,8 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         nav = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=dev), nav_types == 1], 1)[:, :Vp]
         visited = batch["gmap_visited_masks"].bool()
         def index_maps():                                                 # a host decision (hostsync): vpid loops + upload
-            cand_of_node = torch.full((B, G), -2, dtype=torch.int32)
-            cand_visited = torch.zeros(B, Vp, dtype=torch.uint8)
+            cand_of_node = np.full((B, G), -2, np.int32)
+            cand_visited = np.zeros((B, Vp), np.uint8)
             vis_host = visited.cpu().numpy()
             for i in range(B):
                 vset = set(vp for vp, m in zip(batch["gmap_vpids"][i], vis_host[i]) if m)
@@ -379,7 +380,7 @@ class GlocalTextPathCMTPreTraining(nn.Module):
                 for j, vp in enumerate(batch["gmap_vpids"][i]):
                     if j > 0 and vp not in vset:
                         cand_of_node[i, j] = tmp.get(vp, -1)
-            return cand_of_node.to(dev), cand_visited.to(dev)
+            return torch.from_numpy(cand_of_node).to(dev), torch.from_numpy(cand_visited).to(dev)
         cand_of_node, cand_visited = hs.host(index_maps)
         global_logits, local_logits, grid_logits, fused_logits = VT.fuse_logits(
             g_raw, l_raw, grid_raw, fuse_raw, f["gmap_masks"], visited, nav, cand_of_node, cand_visited)
