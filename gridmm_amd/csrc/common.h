@@ -29,9 +29,11 @@ constexpr int MAX_H_BWD = 1024;   // widest row the LayerNorm backward stages in
 
 static inline hipStream_t as_stream(gridmm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Zero-fill as a KERNEL (n floats).  hipMemsetAsync is not used on the training path: replayed from a captured hipGraph
-// its memset nodes left the destination un-cleared (ROCm 7.2: the column sums / partial sums that are then accumulated
-// with atomics came out wrong from the second replay on), a kernel node replays like every other launch.
+// Zero-fill as a KERNEL (n floats) instead of hipMemsetAsync on the training path.  Observed on ROCm 7.2 inside the
+// captured pre-training step (~2000 nodes, default pre-recorded graph packets): the column sums / partial sums that
+// follow these clears with atomics came out wrong from the second replay on, i.e. the memset nodes had not cleared
+// their destination in time; small graphs do not show it (tools/dbg_memset_node.py).  A kernel node replays like
+// every other launch.
 static __global__ void gridmm_zero_f32_kernel(float* __restrict__ p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
 }

@@ -17,7 +17,8 @@ contain, and where it goes instead:
 
 ROCm 7.2 note (measured, tools/dbg_graph_train3.py): with the runtime's pre-recorded graph packets (the default) the
 replay of this graph faults on the device (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION at the third replay of the
-full-size step; bisected to the presence of the two fp16 AdamW launches) and hipMemsetAsync / H2D-copy NODES misbehave;
+full-size step; bisected to the presence of the two fp16 AdamW launches), and the memset nodes of this graph did not
+clear their destinations in time (csrc/common.h);
 with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the HIP runtime starts, the same graph replays
 correctly.  GraphedTrainStep refuses to run without it; bench.py and the tests run this leg in a subprocess that sets it
 (the navigation-step graph of the headline is unaffected and keeps the default).
@@ -78,6 +79,11 @@ class GraphedTrainStep:
                     if capture_optimizer:
                         self.norm = opt.step(max_grad_norm=o.grad_norm if o.grad_norm != -1 else None, graph_tabs=self.tabs)
                 self.losses = losses.detach()
+            # the gradient buffers of the capture belong to the graph from here on: an eager step that found them in
+            # p.grad would ACCUMULATE into them (train_step clears the gradients at the end of a step, a capture computes
+            # nothing)
+            self.grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}   # static buffers (inspection)
+            opt.zero_grad(set_to_none=True)
         finally:
             ag.SEED_DEV = prev
         self.capture_optimizer = capture_optimizer

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 TASKS = ("mlm", "mrc", "sap")
 
 
-def _setup(drop):
+def _setup(drop, fp32_grid_proj=True):
     from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
     from gridmm_amd.synthetic import batch_to, make_pretrain_batch
     from gridmm_amd.vilmodel import default_config
@@ -25,6 +25,13 @@ def _setup(drop):
                          attention_probs_dropout_prob=drop)
     torch.manual_seed(0)
     model = GlocalTextPathCMTPreTraining(cfg).to(dev)
+    if fp32_grid_proj:
+        # The reference keeps grid_proj (weights, gradients, AdamW state) in fp16 (vilmodel.py:664): its second moment
+        # underflows and the update becomes m / eps, right at the fp16 rounding threshold of the weights.  One-ulp flips
+        # driven by the 1e-6 summation-order noise of the atomics then split the loss trajectories of two otherwise
+        # identical runs (eager vs eager as much as graph vs eager; tools/dbg_determinism.py: 1e-4 ... 3e-3 after 5-8
+        # steps, 1e-5 with an fp32 grid_proj).  Trajectory comparisons use fp32; case_fp16_grid_proj covers the fp16 path.
+        model.bert.grid_proj.float()
     batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i), 4, t, max_steps=3, L=40, vocab=30000,
                                                image_prob_size=1000, n_pts=(588, 588 * 2)), dev)
                for i, t in enumerate(TASKS)}
@@ -60,6 +67,50 @@ def case_equals_eager(task):
     la, _ = ta.train_step(batches[task], task)
     lb, _ = tb.train_step(batches[task], task)
     assert torch.allclose(la, lb, rtol=5e-4, atol=5e-4)
+    # ... and starts from clean gradients (the capture's gradient buffers must not be left in p.grad)
+    for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        tol = 4e-3 if pa.dtype == torch.float16 else 2e-4
+        assert torch.allclose(pa.float(), pb.float(), rtol=0, atol=tol), (n, float((pa.float() - pb.float()).abs().max()))
+
+
+def case_two_graphs():
+    """Two tasks, two graphs, one trainer: building the second graph runs eager steps after the first capture."""
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.train_graph import GraphedTrainStep
+    model, batches = _setup(0.0)
+    ma, mb = copy.deepcopy(model), copy.deepcopy(model)
+    ta, tb = PreTrainer(ma, default_opts(warmup_steps=10)), PreTrainer(mb, default_opts(warmup_steps=10))
+    graphs = {}
+    for t in ("mlm", "sap"):
+        for _ in range(2):
+            ta.train_step(batches[t], t)
+        graphs[t] = GraphedTrainStep(tb, batches[t], t)
+    for i in range(6):
+        t = ("mlm", "sap")[i % 2]
+        la, na = ta.train_step(batches[t], t)
+        lb, nb = graphs[t]()
+        assert torch.allclose(la, lb, rtol=1e-4, atol=1e-4), (i, t, float((la - lb).abs().max()))
+        assert abs(float(na) - float(nb)) <= 1e-3 * float(na)
+
+
+def case_fp16_grid_proj():
+    """The reference's fp16 grid_proj (fp16 gradients and AdamW state through the device-side lr / step-size words):
+    the first replays, before the fp16 rounding noise can split the trajectories."""
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.train_graph import GraphedTrainStep
+    model, batches = _setup(0.0, fp32_grid_proj=False)
+    assert model.bert.grid_proj.weight.dtype == torch.float16
+    ma, mb = copy.deepcopy(model), copy.deepcopy(model)
+    ta, tb = PreTrainer(ma, default_opts(warmup_steps=10)), PreTrainer(mb, default_opts(warmup_steps=10))
+    for _ in range(2):
+        ta.train_step(batches["sap"], "sap")
+    g = GraphedTrainStep(tb, batches["sap"], "sap")
+    for _ in range(2):
+        la, na = ta.train_step(batches["sap"], "sap")
+        lb, nb = g()
+        assert torch.allclose(la, lb, rtol=5e-5, atol=5e-5), float((la - lb).abs().max())
+    wa, wb = ma.bert.grid_proj.weight.float(), mb.bert.grid_proj.weight.float()
+    assert float((wa - wb).abs().max()) <= 2e-4 and not torch.equal(wa, model.bert.grid_proj.weight.float())
 
 
 def case_dropout():
@@ -85,6 +136,10 @@ if __name__ == "__main__":
     case = sys.argv[1]
     if case == "dropout":
         case_dropout()
+    elif case == "fp16_grid_proj":
+        case_fp16_grid_proj()
+    elif case == "two_graphs":
+        case_two_graphs()
     else:
         case_equals_eager(case)
     print("ok", case)
