@@ -294,11 +294,15 @@ def train_leg_subprocess(args):
     HIP runtime starts (gridmm_amd/train_graph.py), and the headline graph keeps the runtime's default."""
     import subprocess
     env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="0")
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-leg-only", "--batch", str(args.batch)],
-                       env=env, capture_output=True, text=True, timeout=1500)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-leg-only", "--batch", str(args.batch)],
+                           env=env, capture_output=True, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "the training leg timed out"}
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
-        raise SystemExit("bench.py: the training leg failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+    if r.returncode != 0 or not lines:      # a secondary key: reported in the line, the headline measurement stands
+        sys.stderr.write("bench.py: the training leg failed:\n" + r.stdout[-2000:] + r.stderr[-4000:] + "\n")
+        return {"error": "the training leg failed (rc %d): %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else "")}
     return json.loads(lines[-1])
 
 
