@@ -42,8 +42,6 @@ def parse():
     ap.add_argument("--shape", default="baseline", choices=["baseline", "native"])
     ap.add_argument("--mem-steps", type=int, default=1, help="observations in each episode's memory (t)")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
-    ap.add_argument("--groups", type=int, default=1,
-                    help="cut the episode batch into this many groups captured on concurrent streams of one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -101,33 +99,7 @@ def build_workload(args, dev, mem_steps=None, device_feats=False):
             dict(batch, gmap_visited_masks=fusion_src[1]), dev)))
 
     step = eager_step
-    if not args.eager and args.groups > 1:
-        from gridmm_amd.graph import GraphedNavStepGroups
-        eager_step()                            # packs the weights, fills the allocator
-        ng = args.groups
-        assert B % ng == 0
-        per = B // ng
-        groups, gp, gh = [], [], []
-        for gi in range(ng):
-            sl = slice(gi * per, (gi + 1) * per)
-            gm = GridMemoryBatch(per, geom, max_steps=t, device=dev)
-            gm.slab.copy_(mem.slab[sl])
-            for k in range(t - 1):
-                gm.step(depth[k][sl], None, poses[k][sl], heads[k][sl])
-            gb = {k: (v[sl] if (torch.is_tensor(v) and v.shape[:1] == (B,)) or (isinstance(v, list) and len(v) == B) else v)
-                  for k, v in batch.items() if k not in ("grid_memory", "fusion_maps")}
-            gb = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()}
-            groups.append(dict(mem=gm, batch=gb, depth=depth[t - 1][sl].contiguous(),
-                               restore=(gm.n_pts.clone(), gm.bbox.clone())))
-            gp.append(poses[t - 1][sl])
-            gh.append(heads[t - 1][sl])
-        g = GraphedNavStepGroups(model, groups)
-        for gr in groups:
-            gr["mem"].n_pts_host[:] = gr["mem"].n_pts_host + n_new
-
-        def step():
-            return g(gp, gh)
-    elif not args.eager:
+    if not args.eager:
         from gridmm_amd.graph import GraphedNavStep
         eager_step()                            # packs the weights, fills the allocator
         g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore)
@@ -490,7 +462,7 @@ def main():
                    "attention": "MFMA bf16 16x16x32, 3-term split, fp32 softmax", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
     }
     out["replay_check"] = check
-    if not args.no_depth_legs and not args.eager and args.groups == 1 and args.mem_steps == 1:
+    if not args.no_depth_legs and not args.eager and args.mem_steps == 1:
         # the memory deepens as an episode proceeds; the headline is t = 1, these are the same step at
         # t = 5 and t = 15 (re-binning and aggregation walk 5x / 15x the points)
         for t in (5, 15):

@@ -74,58 +74,3 @@ class GraphedNavStep:
             self.refresh_fusion_maps(*fusion)
         self.graph.replay()
         return self.outs
-
-
-class GraphedNavStepGroups:
-    """One hipGraph, several episode groups on concurrent streams.
-
-    A navigation step is ~130 kernels, and half of them work on B x 57 query tokens: at B = 32 those launches occupy
-    a fraction of the 256 CUs for a latency-bound ~10-40 us each.  Episodes are independent, so the batch is cut into
-    groups (each with its own GridMemoryBatch and input dict, the weights are shared) whose kernel chains are captured
-    on separate streams forked from / joined to the capture stream: the hardware scheduler overlaps one group's small
-    kernels with the other's.  Results are identical to the single-group step (same kernels, same per-episode math)."""
-
-    def __init__(self, model, groups, warmup=2):
-        """groups: list of dicts(mem, batch, depth, restore)."""
-        self.model, self.groups = model, groups
-        for g in groups:
-            dev = g["mem"].device
-            g["batch"] = dict(g["batch"])
-            if g["batch"].get("fusion_maps") is None:
-                g["batch"]["fusion_maps"] = model.fusion_maps(g["batch"], dev)
-            g["batch"].update(grid_memory=g["mem"], grid_fts=None, grid_map=None, gridmap_pos_fts=None)
-        self.streams = [torch.cuda.Stream() for _ in groups]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                for g in groups:
-                    self._device_step(g)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            cur = torch.cuda.current_stream()
-            outs = []
-            for g, st in zip(groups, self.streams):
-                st.wait_stream(cur)                       # fork
-                with torch.cuda.stream(st):
-                    outs.append(self._device_step(g))
-            for st in self.streams:
-                cur.wait_stream(st)                       # join
-        self.outs = outs
-
-    def _device_step(self, g):
-        mem = g["mem"]
-        if g.get("restore") is not None:
-            mem.n_pts.copy_(g["restore"][0])
-            mem.bbox.copy_(g["restore"][1])
-        mem.project_and_bin(g["depth"])
-        return self.model("navigation", g["batch"])
-
-    def __call__(self, poses, headings):
-        """poses / headings: per group lists for the appended observation; returns the list of static output dicts."""
-        for g, p, h in zip(self.groups, poses, headings):
-            g["mem"].set_pose(p, h)
-        self.graph.replay()
-        return self.outs

@@ -24,7 +24,7 @@ def dev():
 
 
 def _args(**kw):
-    d = dict(batch=32, shape="baseline", mem_steps=1, eager=False, groups=1)
+    d = dict(batch=32, shape="baseline", mem_steps=1, eager=False)
     d.update(kw)
     return argparse.Namespace(**d)
 
