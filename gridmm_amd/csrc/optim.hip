@@ -64,10 +64,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, const T* 
 // are launch-bound).  desc[t] = {p, g, m, v, n, lr, step_size, eps, wd}; chunk_first[t] = first 16K-element chunk of
 // tensor t in the grid (prefix sums, chunk_first[T] = total); a workgroup finds its tensor by binary search.
 struct TensorDesc {
-  float* p; const float* g; float* m; float* v;
+  void* p; const void* g; void* m; void* v;   // dtype 0: float, 1: _Float16 (parameter, gradient and both moments alike)
   long long n;
   float lr, step_size, eps, wd;
+  int dtype, pad;
 };
+static_assert(sizeof(TensorDesc) == 64, "record layout shared with gridmm_amd/optim.py (_REC)");
 constexpr int MT_CHUNK = 16384;
 
 __device__ __forceinline__ int find_tensor(const int* __restrict__ chunk_first, int T, int chunk) {
@@ -88,7 +90,13 @@ __global__ __launch_bounds__(256) void multi_sumsq_kernel(const TensorDesc* __re
   const long long i0 = (long long)(blockIdx.x - chunk_first[t]) * MT_CHUNK;
   const long long i1 = i0 + MT_CHUNK < d.n ? i0 + MT_CHUNK : d.n;
   float s = 0.f;
-  for (long long i = i0 + threadIdx.x; i < i1; i += 256) { const float x = d.g[i]; s += x * x; }
+  if (d.dtype == 0) {
+    const float* g = static_cast<const float*>(d.g);
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) { const float x = g[i]; s += x * x; }
+  } else {
+    const _Float16* g = static_cast<const _Float16*>(d.g);
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) { const float x = (float)g[i]; s += x * x; }
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -99,6 +107,26 @@ __global__ void sum64_kernel(const float* __restrict__ part, float* __restrict__
   float s = part[threadIdx.x];
   s = wave_sum(s);
   if (threadIdx.x == 0) *out = s;
+}
+
+// one chunk of one tensor; same arithmetic (and, for fp16, the same per-op roundings) as adamw_kernel<T>
+template <typename T>
+__device__ __forceinline__ void adamw_range(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m,
+                                            T* __restrict__ v, long long i0, long long i1, float scale,
+                                            const TensorDesc& d, float b1, float b2, int decay_first) {
+  auto rnd = [](float x) { return (float)(T)x; };
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float gi = rnd(ld(g, i) * scale);
+    float pi = ld(p, i);
+    const float mi = rnd(rnd(b1 * ld(m, i)) + (1.f - b1) * gi);
+    const float vi = rnd(rnd(b2 * ld(v, i)) + (1.f - b2) * gi * gi);
+    if (decay_first && d.wd > 0.f) pi = rnd(pi - d.lr * d.wd * pi);
+    pi = rnd(pi - d.step_size * (mi / rnd(rnd(sqrtf(vi)) + d.eps)));
+    if (!decay_first && d.wd > 0.f) pi = rnd(pi - d.lr * d.wd * pi);
+    st(p, i, pi);
+    st(m, i, mi);
+    st(v, i, vi);
+  }
 }
 
 __global__ __launch_bounds__(256) void multi_adamw_kernel(const TensorDesc* __restrict__ desc,
@@ -114,16 +142,12 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const TensorDesc* __re
   }
   const long long i0 = (long long)(blockIdx.x - chunk_first[t]) * MT_CHUNK;
   const long long i1 = i0 + MT_CHUNK < d.n ? i0 + MT_CHUNK : d.n;
-  for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float gi = d.g[i] * scale;
-    float pi = d.p[i];
-    const float mi = b1 * d.m[i] + (1.f - b1) * gi;
-    const float vi = b2 * d.v[i] + (1.f - b2) * gi * gi;
-    if (decay_first && d.wd > 0.f) pi -= d.lr * d.wd * pi;
-    pi -= d.step_size * mi / (sqrtf(vi) + d.eps);
-    if (!decay_first && d.wd > 0.f) pi -= d.lr * d.wd * pi;
-    d.p[i] = pi; d.m[i] = mi; d.v[i] = vi;
-  }
+  if (d.dtype == 0)
+    adamw_range(static_cast<float*>(d.p), static_cast<const float*>(d.g), static_cast<float*>(d.m),
+                static_cast<float*>(d.v), i0, i1, scale, d, b1, b2, decay_first);
+  else   // the reference's fp16 grid_proj: fp16 gradient and moments, every intermediate rounded to fp16 (adamw_kernel)
+    adamw_range(static_cast<_Float16*>(d.p), static_cast<const _Float16*>(d.g), static_cast<_Float16*>(d.m),
+                static_cast<_Float16*>(d.v), i0, i1, scale, d, b1, b2, decay_first);
 }
 
 inline unsigned grid_for(size_t n, size_t cap = 4096) {

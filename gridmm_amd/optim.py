@@ -6,8 +6,9 @@ Reference (relative to /root/reference/pretrain_src):
   optim/misc.py:12-37       build_optimizer: no weight decay on 'bias', 'LayerNorm.bias', 'LayerNorm.weight'
   optim/sched.py:17-30      warmup_linear / get_lr_sched (lr floor 1e-8)
   train_r2r.py:288-303      clip_grad_norm_(model.parameters(), opts.grad_norm) then optimizer.step()
-The clip and the update are two streaming HIP kernels per tensor (gridmm_grad_sumsq, gridmm_adamw_step); the global
-norm stays on the device, so a step issues no host synchronisation.
+The clip and the update are two multi-tensor HIP launches over all live parameters (gridmm_multi_grad_sumsq,
+gridmm_multi_adamw_step; fp32 tensors and the fp16 grid_proj in the same table); the global norm stays on the device, so a
+step issues no host synchronisation.
 """
 import ctypes
 import math
@@ -50,11 +51,11 @@ class AdamW(torch.optim.Optimizer):
     # ---- multi-tensor launch tables (fp32 tensors): one record per parameter, rebuilt every step on the host
     # (gradient tensors are re-allocated by zero_grad) and shipped with ONE small H2D copy
     _REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
-                     ("lr", "<f4"), ("step_size", "<f4"), ("eps", "<f4"), ("wd", "<f4")])
+                     ("lr", "<f4"), ("step_size", "<f4"), ("eps", "<f4"), ("wd", "<f4"), ("dtype", "<i4"), ("pad", "<i4")])
     _CHUNK = 16384
 
     def _tables(self, items, dev, graph_tabs=None, key=None):
-        """items: list of (p, g, exp_avg, exp_avg_sq, lr, step_size, eps, wd) for contiguous fp32 tensors.
+        """items: list of (p, g, exp_avg, exp_avg_sq, lr, step_size, eps, wd) for contiguous fp32 / fp16 tensors.
         graph_tabs (captured steps): the table lives in a pinned host pool mirrored by a device pool, both allocated
         BEFORE the capture; nothing is copied inside the graph -- refresh_graph_tables() rewrites lr / step_size / eps in
         the pinned copy and uploads the pool on the replay's stream before every replay.  (An H2D copy node inside the
@@ -62,7 +63,8 @@ class AdamW(torch.optim.Optimizer):
         rec = np.zeros(len(items), self._REC)
         first = np.zeros(len(items) + 1, np.int32)
         for i, (p, g, m, v, lr, ss, eps, wd) in enumerate(items):
-            rec[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, ss, eps, wd)
+            rec[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, ss, eps, wd,
+                      int(p.dtype == torch.float16), 0)
             first[i + 1] = first[i] + -(-p.numel() // self._CHUNK)
         blob = np.concatenate([rec.view(np.uint8), first.view(np.uint8)])
         if graph_tabs is None:
@@ -103,14 +105,6 @@ class AdamW(torch.optim.Optimizer):
                 if advance:
                     st["step"] += 1
                 rec["lr"][i], rec["step_size"][i], rec["eps"][i] = self._step_scalars(group_of[id(p)], st)
-        if graph_tabs["single"] is not None:
-            pinned, _, params = graph_tabs["single"]
-            dyn = pinned.numpy()
-            for i, p in enumerate(params):
-                st = self.state[p]
-                if advance:
-                    st["step"] += 1
-                dyn[3 * i:3 * i + 3] = self._step_scalars(group_of[id(p)], st)
         n = graph_tabs["used"]
         graph_tabs["dev_pool"][:n].copy_(graph_tabs["pool"][:n], non_blocking=True)      # ordered before the replay
 
@@ -118,10 +112,10 @@ class AdamW(torch.optim.Optimizer):
     def step(self, closure=None, max_grad_norm=None, graph_tabs=None):
         """max_grad_norm: fuse clip_grad_norm_(all parameters of this optimizer, max_grad_norm) into the update.
         Returns the (pre-clip) gradient norm as a device scalar when clipping, else None.
-        graph_tabs: dict(multi={}, single=None, pool=<pinned uint8>, dev_pool=<device uint8>, used=0) filled during the
+        graph_tabs: dict(multi={}, pool=<pinned uint8>, dev_pool=<device uint8>, used=0) filled during the
         capture of a training step (train_graph.py)."""
         lib = _lib.load()
-        multi, single = [], []
+        multi = []
         for group, p in self._live():
             if p.dtype not in (torch.float32, torch.float16) or not p.is_contiguous():
                 raise ValueError("AdamW: contiguous fp32 / fp16 parameters expected")
@@ -136,13 +130,13 @@ class AdamW(torch.optim.Optimizer):
             g = p.grad.contiguous()
             if g.dtype != p.dtype:
                 g = g.to(p.dtype)
-            item = (p, g, state["exp_avg"], state["exp_avg_sq"], float(group["lr"]), float(step_size), float(eps),
-                    float(group["weight_decay"]), float(b1), float(b2), int(bool(group["decay_first"])))
-            (multi if p.dtype == torch.float32 else single).append(item)
-        if not multi and not single:
+            multi.append((p, g, state["exp_avg"], state["exp_avg_sq"], float(group["lr"]), float(step_size), float(eps),
+                          float(group["weight_decay"]), float(b1), float(b2), int(bool(group["decay_first"]))))
+        if not multi:
             return None
-        dev = (multi or single)[0][0].device
-        # all fp32 tensors of one (betas, decay order) class go into one launch; the released configs have one class
+        dev = multi[0][0].device
+        # all tensors of one (betas, decay order) class go into one launch -- fp32 and the fp16 grid_proj alike (a record
+        # carries its dtype); the released configs have one class
         classes = {}
         for it in multi:
             classes.setdefault(it[8:], []).append(it[:8])
@@ -156,26 +150,14 @@ class AdamW(torch.optim.Optimizer):
                 _lib.check(lib.gridmm_multi_grad_sumsq(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
                                                        n_chunks, _p(part), _p(tmp), _stream()), "gridmm_multi_grad_sumsq")
                 sumsq += tmp
-            for p, g, *_ in single:
-                _lib.check(lib.gridmm_grad_sumsq(_p(g), g.numel(), 1, _p(sumsq), _stream()), "gridmm_grad_sumsq")
         for (b1, b2, df), items in classes.items():
             blob, rec_bytes, n_chunks = tables[(b1, b2, df)]
             _lib.check(lib.gridmm_multi_adamw_step(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
                                                    n_chunks, b1, b2, df, _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
                                                    float(max_grad_norm or 0.0), _stream()), "gridmm_multi_adamw_step")
-        dyn = None
-        if graph_tabs is not None and single:                              # lr / step_size / eps of the fp16 tensors, per replay
-            pinned, dyn = (t.view(torch.float32) for t in self._carve(graph_tabs, 12 * len(single)))
-            graph_tabs["single"] = (pinned, dyn, [it[0] for it in single])
-        for i, (p, g, m, v, lr, ss, eps, wd, b1, b2, df) in enumerate(single):   # fp16 parameters (the pre-training grid_proj)
-            _lib.check(lib.gridmm_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), 1, lr, b1, b2, eps, wd, ss, df,
-                                             _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
-                                             float(max_grad_norm or 0.0),
-                                             ctypes.c_void_p(dyn.data_ptr() + 12 * i) if dyn is not None else ctypes.c_void_p(0),
-                                             _stream()), "gridmm_adamw_step")
-        for it in multi + single:
+        for it in multi:
             _bump_version(it[0])
-        self._keepalive = (tables, multi, single)      # device tables / cast gradients must outlive the async launches
+        self._keepalive = (tables, multi)              # device tables / cast gradients must outlive the async launches
         return None if sumsq is None else sumsq.sqrt()
 
 

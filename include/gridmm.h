@@ -375,9 +375,11 @@ int gridmm_linear_planes_splitk(const void* A_hi, const void* A_lo, int lda, con
                                 int Kp, float* C, float* workspace, int M, int N, int K, int splits,
                                 gridmm_stream_t stream);
 
-/* Multi-tensor forms of the two kernels above for fp32 tensors: ONE launch over all parameters.
- *   desc        device array of n_tensors records {float* p; const float* g; float* m; float* v; int64 n;
- *               float lr, step_size, eps, weight_decay;}  (56 bytes, natural C layout)
+/* Multi-tensor forms of the two kernels above: ONE launch over all parameters.
+ *   desc        device array of n_tensors records {void* p; const void* g; void* m; void* v; int64 n;
+ *               float lr, step_size, eps, weight_decay; int32 dtype (0 = fp32, 1 = fp16: parameter, gradient and both
+ *               moments alike); int32 pad;}  (64 bytes, natural C layout).  The scalars are read from the record at run
+ *               time, so a captured (hipGraph) step advances lr / bias correction by rewriting the table.
  *   chunk_first device int32 [n_tensors + 1]: prefix sums of ceil(n / 16384); n_chunks = chunk_first[n_tensors]
  * gridmm_multi_grad_sumsq: partial64 = 64-float workspace, out = the global sum of squares (device scalar). */
 int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float* partial64,

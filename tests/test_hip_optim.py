@@ -147,3 +147,39 @@ def test_optimizer_trajectory_matches_reference_golden():
                 assert float((got - want).abs().max()) < 2e-6, (step, n, float((got - want).abs().max()))
     assert all(torch.equal(p.detach().float().cpu(), torch.from_numpy(fx["init." + n]))
                for n, p in model.named_parameters() if n.startswith("unused"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_single_tensor_entry_points_equal_the_multi_tensor_step(dtype):
+    """gridmm_grad_sumsq / gridmm_adamw_step (one tensor per call; lr / step_size / eps as arguments or, `dyn`, from
+    device memory) against AdamW.step (the multi-tensor table) on the same tensor: the same update (the two gradient norms are summed
+    in different orders, so the clip scale may differ in its last bit); arguments vs `dyn`: identical bits."""
+    import ctypes
+    from gridmm_amd import _lib
+    from gridmm_amd.optim import AdamW
+    from gridmm_amd.ops import _p, _stream
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    p0 = (torch.randn(1000, 37, generator=g) * 0.05).to(dtype).cuda()
+    grads = [(torch.randn(1000, 37, generator=g) * s).to(dtype).cuda() for s in (0.01, 3.0, 1e-4)]
+    pa = torch.nn.Parameter(p0.clone())
+    opt = AdamW([pa], lr=2e-4, betas=(0.9, 0.98), weight_decay=0.01)
+    pb, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pc, mc, vc = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    b1, b2, eps, wd, max_norm = 0.9, 0.98, 1e-6, 0.01, 1.0
+    for t, gr in enumerate(grads, 1):
+        pa.grad = gr.clone()
+        na = opt.step(max_grad_norm=max_norm)
+        ss = 2e-4 * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        for (p, mm, vv, use_dyn) in ((pb, m, v, False), (pc, mc, vc, True)):
+            sumsq = torch.zeros(1, device="cuda")
+            assert lib.gridmm_grad_sumsq(_p(gr), gr.numel(), int(dtype == torch.float16), _p(sumsq), _stream()) == 0
+            dyn = torch.tensor([2e-4, ss, eps], device="cuda") if use_dyn else None
+            lr_a, ss_a, eps_a = (123.0, 456.0, 789.0) if use_dyn else (2e-4, ss, eps)          # ignored when dyn is given
+            assert lib.gridmm_adamw_step(_p(p), _p(gr), _p(mm), _p(vv), p.numel(), int(dtype == torch.float16), lr_a, b1,
+                                         b2, eps_a, wd, ss_a, 0, _p(sumsq), max_norm, _p(dyn), _stream()) == 0
+            assert abs(float(sumsq.sqrt()) - float(na)) <= 1e-5 * float(na)
+        torch.cuda.synchronize()
+        tol = 1e-7 if dtype == torch.float32 else 6.2e-5    # fp16: one ulp at |w| < 0.0625 .. 0.125
+        assert float((pa.detach().float() - pb.float()).abs().max()) <= tol
+        assert torch.equal(pb, pc) and torch.equal(m, mc) and torch.equal(v, vc)
