@@ -39,6 +39,13 @@ class _WeightCache:
     @staticmethod
     def _pack(w, transposed):
         src = w.detach().float()
+        if transposed and src.dim() == 2 and src.shape[1] % 8 == 0 and src.is_contiguous():
+            # W^T planes (K, roundup(N, 32)) in one pass over W (the transposing splitter of the activations) instead of
+            # a transposed copy + a split: one launch less and no fp32 W^T per weight and step
+            hi, lo, _, Np, _ = transpose_split(src)
+            pw = ops.PackedLinear.__new__(ops.PackedLinear)
+            pw.hi, pw.lo, pw.bias, pw.N, pw.K, pw.Kp = hi, lo, None, src.shape[1], src.shape[0], Np
+            return pw
         return ops.PackedLinear(src.t().contiguous() if transposed else src.contiguous(), None)
 
     def getter(self, w):
