@@ -298,8 +298,16 @@ class _Attention(torch.autograd.Function):
         Sk = kv_src.shape[1]
         Sqp = lse.shape[2]
         dout = dout.contiguous()
-        dq_src = torch.zeros_like(q_src)
-        dkv_src = dq_src if ctx.same else torch.zeros_like(kv_src)
+        # the kernels write every row of the q / k / v column blocks; only columns outside them (the K|V blocks of the
+        # other layers in a shared context projection) need the zero fill
+        def covered(width, blocks):
+            return sorted(blocks) == list(range(0, width, H)) and width % H == 0
+        if ctx.same:
+            dq_src = (torch.empty_like if covered(q_src.shape[-1], [qc, kc, vc]) else torch.zeros_like)(q_src)
+            dkv_src = dq_src
+        else:
+            dq_src = (torch.empty_like if covered(q_src.shape[-1], [qc]) else torch.zeros_like)(q_src)
+            dkv_src = (torch.empty_like if covered(kv_src.shape[-1], [kc, vc]) else torch.zeros_like)(kv_src)
         delta = torch.empty_like(lse)
         q, k, v = q_src[..., qc:qc + H], kv_src[..., kc:kc + H], kv_src[..., vc:vc + H]
         dq, dk, dv = dq_src[..., qc:qc + H], dkv_src[..., kc:kc + H], dkv_src[..., vc:vc + H]
