@@ -20,12 +20,16 @@ torch.cuda.synchronize()
 import traceback
 from torch.utils._python_dispatch import TorchDispatchMode
 cnt = collections.Counter()
+heavy = collections.Counter()
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func).replace("aten.", "")
         st = [f for f in traceback.extract_stack() if "/gridmm_amd/" in f.filename]
         where = "%s:%d" % (st[-1].filename.split("/")[-1], st[-1].lineno) if st else "(engine)"
         cnt[(name, where)] += 1
+        big = [a for a in args if torch.is_tensor(a) and a.is_cuda and a.numel() >= 200000]
+        if big and name.split(".")[0] in ("copy_", "mul", "where", "add", "clone", "contiguous", "_to_copy", "masked_fill", "fill_", "zero_", "zeros_like", "native_dropout", "native_dropout_backward", "cat", "gather", "index_select", "slice_backward", "constant_pad_nd", "sum"):
+            heavy[(name, where, tuple(big[0].shape), big[0].is_contiguous())] += 1
         return func(*args, **(kwargs or {}))
 torch.autograd.set_multithreading_enabled(False)
 with Spy():
@@ -38,3 +42,7 @@ print("ops per step:", sum(tot.values()))
 print(tot.most_common(25))
 for (n, w), c in cnt.most_common(60):
     print(c, n, w)
+
+print("---- ops on large CUDA tensors (name, site, shape, contiguous): count")
+for k, c in heavy.most_common(40):
+    print(c, k)
