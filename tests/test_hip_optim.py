@@ -171,9 +171,9 @@ def test_single_tensor_entry_points_equal_the_multi_tensor_step(dtype):
         pa.grad = gr.clone()
         na = opt.step(max_grad_norm=max_norm)
         ss = 2e-4 * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        sumsq = torch.zeros(1, device="cuda")      # once for both variants: its atomics sum in a run-dependent order
+        assert lib.gridmm_grad_sumsq(_p(gr), gr.numel(), int(dtype == torch.float16), _p(sumsq), _stream()) == 0
         for (p, mm, vv, use_dyn) in ((pb, m, v, False), (pc, mc, vc, True)):
-            sumsq = torch.zeros(1, device="cuda")
-            assert lib.gridmm_grad_sumsq(_p(gr), gr.numel(), int(dtype == torch.float16), _p(sumsq), _stream()) == 0
             dyn = torch.tensor([2e-4, ss, eps], device="cuda") if use_dyn else None
             lr_a, ss_a, eps_a = (123.0, 456.0, 789.0) if use_dyn else (2e-4, ss, eps)          # ignored when dyn is given
             assert lib.gridmm_adamw_step(_p(p), _p(gr), _p(mm), _p(vv), p.numel(), int(dtype == torch.float16), lr_a, b1,
