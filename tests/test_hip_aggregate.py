@@ -113,8 +113,9 @@ def test_grid_aggregate_regimes(D, L, kind, npts, n_chunks):
 
 
 def test_grid_aggregate_is_deterministic_and_chunk_invariant():
-    """Same inputs, same chunking: bit-identical (no atomics, a cell is reduced inside one workgroup in point order).
-    Different chunkings only move the 32-point tile boundaries inside a cell: fp32 summation-order noise."""
+    """Same inputs, same chunking: bit-identical (no atomics: a cell is reduced in point order inside a workgroup, the
+    pieces of a cell that a chunk boundary splits are merged in chunk order).  Different chunkings only move the 32-point
+    tile / piece boundaries inside a cell: fp32 summation-order noise."""
     from gridmm_amd import ops
     from gridmm_amd.grid_memory import pack_reference_lists
     rng = np.random.default_rng(5)
@@ -128,3 +129,41 @@ def test_grid_aggregate_is_deterministic_and_chunk_invariant():
     assert torch.equal(outs[1], outs[0])
     for o in outs[2:]:
         assert (o - outs[0]).abs().max() < 2e-6
+
+
+def test_grid_aggregate_chunk_invariance_at_bench_depth():
+    """The benchmark's deepest memory (t = 15: 105 840 points per episode, D = 512, L = 80) with crowded cells -- thousands
+    of points in a few cells, each split over several workgroups: the result does not depend on how many chunks an episode
+    is cut into (1 = no split at all), every launch is bit-reproducible, and each cell is a convex combination of its
+    points (the softmax weights are positive and sum to one)."""
+    from gridmm_amd import ops
+    from gridmm_amd.grid_memory import pack_reference_lists
+    rng = np.random.default_rng(11)
+    g = torch.Generator().manual_seed(11)
+    B, n, D, L = 4, 105840, 512, 80
+    fts = [(torch.randn(n, D, generator=g) * 0.5).half().cuda() for _ in range(B)]
+    maps = []
+    for b in range(B):
+        ids = rng.integers(0, 196, size=n)
+        hot = rng.choice(196, size=5, replace=False)
+        sel = rng.random(n) < 0.55                       # 55 % of the points in five cells: ~11 600 points each
+        ids[sel] = hot[rng.integers(0, 5, size=int(sel.sum()))]
+        ids[rng.random(n) < 0.02] = -1                   # out-of-window points
+        maps.append(torch.from_numpy(ids).double().cuda())
+    frag = ops.text_fragments((torch.randn(B, L, D, generator=g) * 0.3).cuda())
+    slab, perm, cs = pack_reference_lists(fts, maps)
+    ref_cells, ref_occ = ops.grid_aggregate(slab, perm, cs, frag, L, n_chunks=1)
+    ref_cells, ref_occ = ref_cells.clone(), ref_occ.clone()
+    for k in (64, 64, 8, 23, 196):
+        cells, occ = ops.grid_aggregate(slab, perm, cs, frag, L, n_chunks=k)
+        assert torch.equal(occ, ref_occ)
+        assert float((cells - ref_cells).abs().max()) < 5e-6, k
+        if k == 64:
+            first = cells.clone() if "first" not in locals() else first
+            assert torch.equal(cells, first)
+    # convexity on a sample of cells: min over the cell's points <= cell vector <= max
+    ids0 = maps[0].long()
+    for c in [int(x) for x in torch.unique(ids0)[1:6]]:
+        pts = fts[0][ids0 == c].float()
+        v = ref_cells[0, c]
+        assert bool((v <= pts.max(0).values + 1e-4).all() and (v >= pts.min(0).values - 1e-4).all())
