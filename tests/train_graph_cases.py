@@ -120,6 +120,30 @@ def case_fp16_grid_proj():
     assert not torch.equal(w0, mb.bert.grid_proj.weight)         # ... and it does train
 
 
+def case_full_size():
+    """The full-size pre-training twin at bench.py's training shape (161 M parameters, B = 32, L = 80, five steps of native
+    12x49x768 observations): two replays of the sap graph against the eager step, each from a common state."""
+    from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.synthetic import batch_to, make_pretrain_batch
+    from gridmm_amd.train_graph import GraphedTrainStep
+    from gridmm_amd.vilmodel import default_config
+    dev = torch.device("cuda")
+    cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=list(TASKS), image_prob_size=1000, obj_prob_size=0,
+                         hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    model = GlocalTextPathCMTPreTraining(cfg).to(dev)
+    batch = batch_to(make_pretrain_batch(np.random.RandomState(2), 32, "sap", max_steps=5, L=80, vocab=30000,
+                                         image_prob_size=1000, n_pts=(588 * 3, 588 * 5)), dev)
+    ma, mb = copy.deepcopy(model), model
+    ta, tb = PreTrainer(ma, default_opts(warmup_steps=100)), PreTrainer(mb, default_opts(warmup_steps=100))
+    for _ in range(2):
+        ta.train_step(batch, "sap")
+    g = GraphedTrainStep(tb, batch, "sap")
+    for it in range(2):
+        _compare_step(ta, tb, lambda: ta.train_step(batch, "sap"), g, ("full", it))
+
+
 def case_dropout():
     from gridmm_amd.pretrain_loop import PreTrainer, default_opts
     from gridmm_amd.train_graph import GraphedTrainStep
@@ -145,6 +169,8 @@ if __name__ == "__main__":
         case_dropout()
     elif case == "fp16_grid_proj":
         case_fp16_grid_proj()
+    elif case == "full_size":
+        case_full_size()
     elif case == "two_graphs":
         case_two_graphs()
     else:
