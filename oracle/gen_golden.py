@@ -357,6 +357,17 @@ def pretrain_batch(task, with_obj=False):
     return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS[task]), 3, task)
 
 
+# the released pre-training configuration (config/r2r_model_config.json + pretrain_cmt.py defaults): full depth and width
+PRETRAIN_FULL = dict(num_l_layers=9, num_pano_layers=2, num_x_layers=4, intermediate_size=3072, vocab_size=30522,
+                     image_prob_size=1000)
+
+
+def pretrain_full_batch(task):
+    """The batches of pretrain_full_b2.npz (B = 2, L = 40, up to 4 steps, 300-900 grid points), regenerated by the tests."""
+    return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS[task] + 200), 2, task, max_steps=4, L=40, vocab=30522,
+                                 image_prob_size=1000, n_pts=(300, 900))
+
+
 def grad_sample_index(name, numel):
     """Seeded positions at which a parameter's gradient is recorded."""
     import zlib
@@ -364,19 +375,19 @@ def grad_sample_index(name, numel):
     return rs.randint(0, numel, size=min(GRAD_SAMPLES, numel))
 
 
-def gen_pretrain(with_obj=False):
+def gen_pretrain(with_obj=False, full=False):
     """GlocalTextPathCMTPreTraining.forward(batch, task) (pretrain_cmt.py:71-321) in train-step form
     (train_r2r.py:245-262): per-sample loss vectors, then loss.mean().backward(): per-parameter gradient norm,
     seeded samples of every gradient, and the set of parameters that received none.
     with_obj: object tokens in every panorama (REVERIE-style), tasks mrc (view + object branches) / sap / og."""
     torch.set_num_threads(1)
-    over = dict(PRETRAIN_OBJ) if with_obj else {}
-    model = R.build_ref_pretrain_model(seed=9, **over).train()     # dropout probs are 0 in the reduced config
+    over = dict(PRETRAIN_OBJ) if with_obj else (dict(PRETRAIN_FULL) if full else {})
+    model = R.build_ref_pretrain_model(seed=9, **over).train()     # dropout probs are 0 in these configs
     out = {"versions": _versions(), "weight_seed": 9, "cfg": json.dumps(dict(R.PRETRAIN_REDUCED, **over)),
            "param_names": json.dumps([k for k, _ in model.named_parameters()]),
            "param_dtypes": json.dumps({k: str(v.dtype) for k, v in model.state_dict().items()})}
     for task in (("mrc", "sap", "og") if with_obj else ("mlm", "mrc", "sap")):
-        batch = pretrain_batch(task, with_obj)
+        batch = pretrain_full_batch(task) if full else pretrain_batch(task, with_obj)
         model.zero_grad()
         loss = model(batch, task=task, compute_loss=True)
         out["loss_" + task] = loss.detach().float().numpy()
@@ -393,7 +404,8 @@ def gen_pretrain(with_obj=False):
         out["grad_norms_" + task] = np.array(norms, np.float32)
         out["grad_samples_" + task] = np.concatenate(samples).astype(np.float32)
         print(task, "loss", out["loss_" + task], "params with grad", len(names))
-    np.savez_compressed(os.path.join(OUT, "pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz"), **out)
+    name = "pretrain_full_b2.npz" if full else ("pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz")
+    np.savez_compressed(os.path.join(OUT, name), **out)
 
 
 TOPO = dict(n_nodes=24, n_steps=20, seed=5, max_nodes=24)
@@ -689,3 +701,4 @@ if __name__ == "__main__":
     if "navvlnce" in which: gen_nav_vlnce()
     if "panoobj" in which: gen_pano_obj()
     if "pretrainobj" in which: gen_pretrain(True)
+    if "pretrainfull" in which: gen_pretrain(full=True)

@@ -46,12 +46,17 @@ def _model(fx):
 
 
 @pytest.mark.parametrize("task,with_obj", [("mlm", False), ("mrc", False), ("sap", False),
-                                           ("mrc", True), ("sap", True), ("og", True)])
+                                           ("mrc", True), ("sap", True), ("og", True),
+                                           ("mlm", "full"), ("mrc", "full"), ("sap", "full")])
 def test_pretrain_losses_and_gradients_match_reference(task, with_obj):
+    """with_obj == "full": the released full-size configuration (9 / 2 / 4 layers, 3072-wide FFN, 30 522-word vocabulary,
+    161 M parameters), B = 2 -- tests/golden/pretrain_full_b2.npz from the imported reference."""
     from gridmm_amd.synthetic import batch_to
-    fx = load_golden("pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz")
+    full = with_obj == "full"
+    with_obj = with_obj is True
+    fx = load_golden("pretrain_full_b2.npz" if full else ("pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz"))
     model = _model(fx)
-    batch = batch_to(gen_golden.pretrain_batch(task, with_obj), "cuda")
+    batch = batch_to(gen_golden.pretrain_full_batch(task) if full else gen_golden.pretrain_batch(task, with_obj), "cuda")
     loss = model(batch, task=task, compute_loss=True)
     want = fx["loss_" + task]
     got = loss.detach().cpu().numpy()
