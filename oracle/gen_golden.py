@@ -326,20 +326,34 @@ def vlnce_nav_tuple(batch, cand_lens=VLNCE_NAV_CAND_LENS):
             batch["vp_nav_masks"], batch["grid_fts"], batch["grid_map"], batch["gridmap_pos_fts"], list(cand_lens))
 
 
-def gen_nav_vlnce():
-    """VLN-CE GlocalTextPathNavCMT.forward('navigation', tuple) (gridmap/vilmodel.py:710-800): fused logits only."""
-    torch.set_num_threads(1)
-    model = R.build_ref_vlnce_model(seed=7, **REDUCED)
-    batch = _nav_inputs(seed=321, B=3, Ns=[200, 150, 90], L=12, G_=7, V1=9, n_cand=3, n_visited=2)
+def vlnce_full_inputs():
+    """Inputs of nav_vlnce_full_b2 (regenerated identically by the tests from these seeds): two episodes with 1-3
+    observations of 12 views x 49 patches in memory."""
+    return _nav_inputs(seed=654, B=2, Ns=[1764, 588], L=40, G_=12, V1=20, n_cand=3, n_visited=3)
+
+
+VLNCE_FULL_CAND_LENS = [4, 3]
+
+
+def gen_nav_vlnce(full=False):
+    """VLN-CE GlocalTextPathNavCMT.forward('navigation', tuple) (gridmap/vilmodel.py:710-800): fused logits only.
+    full: the released model size (no reduction), inputs regenerated by the tests from seeds."""
+    torch.set_num_threads(4 if full else 1)
+    cfg = {} if full else REDUCED
+    model = R.build_ref_vlnce_model(seed=7, **cfg)
+    batch = vlnce_full_inputs() if full else _nav_inputs(seed=321, B=3, Ns=[200, 150, 90], L=12, G_=7, V1=9, n_cand=3, n_visited=2)
+    cand = VLNCE_FULL_CAND_LENS if full else VLNCE_NAV_CAND_LENS
     with torch.no_grad():
-        fused = model("navigation", vlnce_nav_tuple(batch))
-    out = {"versions": _versions(), "weight_seed": 7, "cfg": json.dumps(REDUCED),
+        fused = model("navigation", vlnce_nav_tuple(batch, cand))
+    out = {"versions": _versions(), "weight_seed": 7, "cfg": json.dumps(cfg),
            "param_names": json.dumps([k for k in model.state_dict()]),
-           "cand_lens": np.array(VLNCE_NAV_CAND_LENS)}
-    _pack_batch(out, batch)
+           "cand_lens": np.array(cand)}
+    if not full:
+        _pack_batch(out, batch)
     out["out_fused_logits"] = fused.numpy()
-    np.savez_compressed(os.path.join(OUT, "nav_vlnce_reduced.npz"), **out)
-    print("nav_vlnce_reduced.npz ok", tuple(fused.shape))
+    name = "nav_vlnce_full_b2.npz" if full else "nav_vlnce_reduced.npz"
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, "ok", tuple(fused.shape))
 
 
 PRETRAIN_SEEDS = {"mlm": 11, "mrc": 12, "sap": 13}
@@ -699,6 +713,7 @@ if __name__ == "__main__":
     if "full" in which: gen_nav_full()
     if "pretrain" in which: gen_pretrain()
     if "navvlnce" in which: gen_nav_vlnce()
+    if "navvlncefull" in which: gen_nav_vlnce(full=True)
     if "panoobj" in which: gen_pano_obj()
     if "pretrainobj" in which: gen_pretrain(True)
     if "pretrainfull" in which: gen_pretrain(full=True)

@@ -181,6 +181,18 @@ def test_vlnce_navigation_matches_reference_golden():
     assert model.grid_proj.weight.grad is not None and model.grid_sap_head.net[0].weight.grad is None
 
 
+def test_vlnce_navigation_full_size_matches_reference_golden():
+    """The VLN-CE twin at the released model size (B = 2, up to 1764 points of 768-D CLIP tokens in memory):
+    tests/golden/nav_vlnce_full_b2.npz, inputs regenerated from the generator's seeds."""
+    from oracle import gen_golden
+    fx = load_golden("nav_vlnce_full_b2.npz")
+    model = _vlnce_model(fx)
+    batch = _to_dev(gen_golden.vlnce_full_inputs())
+    with torch.no_grad():
+        fused = model("navigation", gen_golden.vlnce_nav_tuple(batch, fx["cand_lens"].tolist()))
+    _cmp(fused, fx["out_fused_logits"], LOGIT_TOL)
+
+
 @pytest.mark.parametrize("tag", ["shared", "own"])
 def test_panorama_with_object_tokens_matches_reference_golden(tag):
     """vilmodel.py:745-764: [views | objects] per panorama, objects through img_linear (REVERIE) or obj_linear."""
