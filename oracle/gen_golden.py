@@ -178,31 +178,35 @@ def gen_nav_full():
     print("nav_full_b2 ok", {k: float(v[torch.isfinite(v)].abs().max()) for k, v in outs.items() if v is not None})
 
 
-def gen_text_pano():
-    torch.set_num_threads(1)
-    model = R.build_ref_model(seed=7, **REDUCED)
-    rs = np.random.RandomState(5)
-    B, L = 3, 14
-    lens = np.array([14, 9, 5])
-    txt_ids = rs.randint(1, 2000, size=(B, L)).astype(np.int64) * (np.arange(L)[None] < lens[:, None])
+def gen_text_pano(full=False):
+    """forward('language') / forward('panorama').  full: the released model size (9 language layers, 2 panorama layers,
+    30 522-word vocabulary), B = 2, L = 40."""
+    torch.set_num_threads(4 if full else 1)
+    cfg = {} if full else REDUCED
+    model = R.build_ref_model(seed=7, **cfg)
+    rs = np.random.RandomState(6 if full else 5)
+    B, L = (2, 40) if full else (3, 14)
+    lens = np.array([40, 23]) if full else np.array([14, 9, 5])
+    txt_ids = rs.randint(1, 30000 if full else 2000, size=(B, L)).astype(np.int64) * (np.arange(L)[None] < lens[:, None])
     txt_masks = np.arange(L)[None] < lens[:, None]
     view = rs.standard_normal((B, 36, 768)).astype(np.float32)
     loc = rs.uniform(-1, 1, size=(B, 36, 7)).astype(np.float32)
     nav_types = (rs.rand(B, 36) < 0.15).astype(np.int64)
-    view_lens = np.array([36, 36, 36], np.int64)
+    view_lens = np.full(B, 36, np.int64)
     with torch.no_grad():
         txt = model("language", {"txt_ids": torch.from_numpy(txt_ids), "txt_masks": torch.from_numpy(txt_masks)})
         pano, pmask = model("panorama", {
             "view_img_fts": torch.from_numpy(view), "obj_img_fts": None, "loc_fts": torch.from_numpy(loc),
             "nav_types": torch.from_numpy(nav_types), "view_lens": torch.from_numpy(view_lens), "obj_lens": None})
     np.savez_compressed(
-        os.path.join(OUT, "text_pano_reduced.npz"), versions=_versions(), weight_seed=7, cfg=json.dumps(REDUCED),
+        os.path.join(OUT, "text_pano_full_b2.npz" if full else "text_pano_reduced.npz"), versions=_versions(), weight_seed=7,
+        cfg=json.dumps(cfg),
         param_names=json.dumps([k for k in model.state_dict()]),
         param_shapes=json.dumps([list(v.shape) for v in model.state_dict().values()]),
         in_txt_ids=txt_ids, in_txt_masks=txt_masks, in_view_img_fts=view, in_loc_fts=loc,
         in_nav_types=nav_types, in_view_lens=view_lens, out_txt_embeds=txt.numpy(),
         out_pano_embeds=pano.numpy(), out_pano_masks=pmask.numpy())
-    print("text_pano_reduced ok")
+    print("text_pano_full_b2 ok" if full else "text_pano_reduced ok")
 
 
 def gen_pano_obj():
@@ -710,6 +714,7 @@ if __name__ == "__main__":
     if "nav" in which: gen_nav_reduced(False)
     if "navobj" in which: gen_nav_reduced(True)
     if "textpano" in which: gen_text_pano()
+    if "textpanofull" in which: gen_text_pano(full=True)
     if "full" in which: gen_nav_full()
     if "pretrain" in which: gen_pretrain()
     if "navvlnce" in which: gen_nav_vlnce()

@@ -101,8 +101,10 @@ def test_aggregation_stage_matches_reference_capture():
     assert np.abs(out[:, :C].cpu().numpy() - fx["cap_grid_map_embeds"]).max() < 2e-4
 
 
-def test_text_and_panorama_modes_match_reference_golden():
-    fx = load_golden("text_pano_reduced.npz")
+@pytest.mark.parametrize("fixture", ["text_pano_reduced.npz", "text_pano_full_b2.npz"])
+def test_text_and_panorama_modes_match_reference_golden(fixture):
+    """(the second fixture: the released model size, B = 2, L = 40)"""
+    fx = load_golden(fixture)
     model, _ = _model(fx)
     d = lambda k: torch.from_numpy(fx[k]).cuda()
     txt = model("language", {"txt_ids": d("in_txt_ids"), "txt_masks": d("in_txt_masks")})
