@@ -55,11 +55,14 @@ def test_teacher_forcing_follows_gt_path_and_accumulates_ce_loss():
 
 
 @pytest.mark.gpu
-def test_rollout_on_hip_matches_reference_driven_golden():
+@pytest.mark.parametrize("fixture", ["rollout_reduced.npz", "rollout_full.npz"])
+def test_rollout_on_hip_matches_reference_driven_golden(fixture):
+    """(rollout_full.npz: the released model size inside the loop -- same episodes, the reference model's per-step logits,
+    actions and trajectories)"""
     from gridmm_amd.grid_memory import GridMemoryBatch
     from gridmm_amd.synthetic import NATIVE
     from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
-    fx = load_golden("rollout_reduced.npz")
+    fx = load_golden(fixture)
     model = GlocalTextPathNavCMT(default_config(**json.loads(str(fx["cfg"])))).cuda().eval()
     model.load_state_dict(golden_state_dict(fx), strict=True)
     r = gen_golden.ROLLOUT
