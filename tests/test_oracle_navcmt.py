@@ -48,8 +48,10 @@ def test_compaction_mask_quirk_is_present_in_golden():
     assert any(m[b].sum() != n_occ[b] for b in range(m.shape[0])), "fixture should exercise the quirk"
 
 
-def test_text_and_panorama_oracle_match_reference_golden():
-    fx = load_golden("text_pano_reduced.npz")
+@pytest.mark.parametrize("fixture", ["text_pano_reduced.npz", "text_pano_full_b2.npz"])
+def test_text_and_panorama_oracle_match_reference_golden(fixture):
+    """(text_pano_full_b2.npz: the released model size)"""
+    fx = load_golden(fixture)
     sd = golden_state_dict(fx)
     with torch.no_grad():
         txt = O.forward_text(sd, torch.from_numpy(fx["in_txt_ids"]), torch.from_numpy(fx["in_txt_masks"]))
@@ -58,3 +60,20 @@ def test_text_and_panorama_oracle_match_reference_golden():
     _cmp(txt.numpy(), fx["out_txt_embeds"])
     _cmp(pano.numpy(), fx["out_pano_embeds"])
     assert np.array_equal(pm.numpy(), fx["out_pano_masks"])
+
+
+def test_navigation_oracle_matches_reference_golden_at_full_size():
+    """nav_full_b2.npz: the 161 M-parameter configuration, B = 2, 1764 / 1176 grid points; inputs regenerated from the
+    generator's seeds (the fixture stores outputs only)."""
+    from oracle import gen_golden
+    fx = load_golden("nav_full_b2.npz")
+    sd = golden_state_dict(fx)
+    batch = gen_golden.full_b2_inputs()
+    torch.set_num_threads(4)
+    try:
+        with torch.no_grad():
+            outs = O.forward_navigation(sd, batch)
+    finally:
+        torch.set_num_threads(1)
+    for k in ("gmap_embeds", "vp_embeds", "global_logits", "local_logits", "fused_logits", "grid_logits"):
+        _cmp(outs[k].numpy(), fx["out_" + k], 5e-5)
