@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -46,8 +46,15 @@ SIGNATURES = {
     "gridmm_attention_rows_cfg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
                                   _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp],
     "gridmm_xattn_layer_workspace": [_i, _i, _i, _i],
-    "gridmm_xattn_layer_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp,
+    "gridmm_xattn_layer_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _vp,
                                ctypes.c_size_t, _i, _i, _i, _i, _vp],
+    "gridmm_linear_planes_map": [_vp, _vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gridmm_linear_planes_grouped": [_vp, _i, _vp],
+    "gridmm_layernorm_map": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp],
+    "gridmm_split_rows_map": [_vp, _i, _vp, _vp, _i, _i, _i64, _i, _i, _vp],
+    "gridmm_cells_embed": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "gridmm_node_embed": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp],
+    "gridmm_nav_heads": [_vp, _i] + [_vp] * 16 + [_i, _i, _i, _i, _vp],
     "gridmm_tokens_to_slab": [_vp, _i, _i, _vp, _i64, _i, _i, _vp],
     "gridmm_ln_dot": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_fuse_logits": [_vp] * 13 + [_i, _i, _i, _vp],

@@ -26,8 +26,10 @@ __device__ __forceinline__ int trunc_x86(float v) {
 // ---------------------------------------------------------------------------------------------
 constexpr int FLAG_VLNCE = 1;  // VLN-CE twin: gy = -ry + y; map_x = -(tx cos + ty sin); (x, Z, y) cell features
 
+constexpr int PROJ_THREADS = 1024;   // one workgroup per episode: 16 waves walk the observation's points (7056 at the BASELINE shape)
+
 template <bool DEPTH_F32>
-__global__ __launch_bounds__(256) void grid_project_kernel(
+__global__ __launch_bounds__(PROJ_THREADS) void grid_project_kernel(
     const void* __restrict__ depth_, const float* __restrict__ x_off,
     const float* __restrict__ view_cos, const float* __restrict__ view_sin, int view_stride,
     const float* __restrict__ pose, int32_t* __restrict__ n_old, float* __restrict__ hist_x,
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void grid_project_kernel(
   const int n_new = n_views * ppv, base = n_old[b];
   const float px = pose[2 * b], py = pose[2 * b + 1];
   float mxx = -__builtin_inff(), mnx = __builtin_inff(), mxy = -__builtin_inff(), mny = __builtin_inff();
-  for (int i = tid; i < n_new; i += 256) {
+  for (int i = tid; i < n_new; i += PROJ_THREADS) {
     const int v = i / ppv, p = i - v * ppv;
     float dy;
     bool ok;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void grid_project_kernel(
     mxx = fmaxf(mxx, gx); mnx = fminf(mnx, gx);
     mxy = fmaxf(mxy, gy); mny = fminf(mny, gy);
   }
-  __shared__ float s_red[4][4];
+  __shared__ float s_red[PROJ_THREADS / 64][4];
   __shared__ float s_half;
   mxx = wave_max(mxx); mnx = wave_min(mnx); mxy = wave_max(mxy); mny = wave_min(mny);
   if ((tid & 63) == 0) {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void grid_project_kernel(
   __syncthreads();
   if (tid == 0) {
     float bb[4] = {bbox[4 * b + 0], bbox[4 * b + 1], bbox[4 * b + 2], bbox[4 * b + 3]};
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < PROJ_THREADS / 64; ++w) {
       bb[0] = fmaxf(bb[0], s_red[w][0]); bb[1] = fminf(bb[1], s_red[w][1]);
       bb[2] = fmaxf(bb[2], s_red[w][2]); bb[3] = fminf(bb[3], s_red[w][3]);
     }
@@ -379,11 +381,11 @@ extern "C" int gridmm_grid_project(const void* depth, int depth_f32, const float
   if (B <= 0 || n_views <= 0 || ppv <= 0 || cap < n_views * ppv || (view_stride != 0 && view_stride != n_views))
     return GRIDMM_EINVAL;
   if (depth_f32)
-    GRIDMM_LAUNCH(grid_project_kernel<true>, dim3(B), dim3(256), 0, as_stream(stream), depth, x_off, view_cos,
+    GRIDMM_LAUNCH(grid_project_kernel<true>, dim3(B), dim3(PROJ_THREADS), 0, as_stream(stream), depth, x_off, view_cos,
                   view_sin, view_stride, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len, pos_fts, active,
                   n_views, ppv, cap, depth_div, flags, max_dist);
   else
-    GRIDMM_LAUNCH(grid_project_kernel<false>, dim3(B), dim3(256), 0, as_stream(stream), depth, x_off, view_cos,
+    GRIDMM_LAUNCH(grid_project_kernel<false>, dim3(B), dim3(PROJ_THREADS), 0, as_stream(stream), depth, x_off, view_cos,
                   view_sin, view_stride, pose, n_old, hist_x, hist_y, hist_valid, bbox, half_len, pos_fts, active,
                   n_views, ppv, cap, depth_div, flags, max_dist);
   GRIDMM_CHECK_LAUNCH();

@@ -20,8 +20,8 @@ extern "C" size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I) {
 extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
                                       const void* KV_hi, const void* KV_lo, int64_t kv_bs, int kv_rs, int k_col, int v_col,
                                       const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask, int self_mask_bs,
-                                      float* Y, void* Y_hi, void* Y_lo, void* workspace, size_t workspace_bytes, int B,
-                                      int Sq, int Sk, int heads, gridmm_stream_t stream) {
+                                      float* Y, void* Y_hi, void* Y_lo, int y_p_rpb, int64_t y_p_bs, void* workspace,
+                                      size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream) {
   if (!L || !X || !X_hi || !X_lo || !KV_hi || !KV_lo || !workspace || B <= 0 || Sq <= 0 || Sk <= 0 || heads <= 0)
     return GRIDMM_EINVAL;
   const int H = L->xq.N, I = L->ffn_i.N, M = B * Sq;
@@ -71,8 +71,8 @@ extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, 
                                   0, f_hi, f_lo, I, M, I, H, GRIDMM_ACT_GELU, stream));
   GRIDMM_TRY(gridmm_linear_planes(f_hi, f_lo, I, L->ffn_o.w_hi, L->ffn_o.w_lo, L->ffn_o.Kp, L->ffn_o.bias, bb, H, h, H, nullptr,
                                   nullptr, 0, M, H, I, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_layernorm(h, H, nullptr, 0, L->f_ln.gamma, L->f_ln.beta, L->f_ln.eps, Y, H, nullptr, 0, nullptr, nullptr,
-                              Y_hi, Y_lo, H, M, H, stream));
+  GRIDMM_TRY(gridmm_layernorm_map(h, H, nullptr, 0, L->f_ln.gamma, L->f_ln.beta, L->f_ln.eps, Y, H, nullptr, 0, nullptr,
+                                  nullptr, Y_hi, Y_lo, H, y_p_rpb, y_p_bs, M, H, stream));
 #undef GRIDMM_TRY
   return GRIDMM_OK;
 }

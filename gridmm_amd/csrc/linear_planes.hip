@@ -47,7 +47,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
     const float* __restrict__ bias, const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc,
-    unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo, int ldp, int M, int N, int K) {
+    unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo, int ldp, int M, int N, int K,
+    int a_rpb, long a_bs) {
   constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int STAGE = (2 * BM + 2 * BN) * BK;          // u16 elements per stage: Ahi|Alo|Whi|Wlo
@@ -103,7 +104,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     const int chunk = (lane % CPR) ^ swz<BK>(row);
     if (plane < 2) {
       const int m = min(bm + row, M - 1);
-      src[i] = (plane == 0 ? Ahi : Alo) + (size_t)m * lda + chunk * 8;
+      // batched row map (a_rpb > 0): row m = (episode m / a_rpb, token m % a_rpb) of a [B][.][lda] buffer with batch
+      // stride a_bs -- a sequence that lives inside a longer one ([map | txt] contexts) is read in place
+      size_t aoff = (size_t)m * lda;
+      if (a_rpb > 0) { const int eb = m / a_rpb; aoff = (size_t)eb * a_bs + (size_t)(m - eb * a_rpb) * lda; }
+      src[i] = (plane == 0 ? Ahi : Alo) + aoff + chunk * 8;
       dst[i] = plane * BM * BK + r0 * BK;
     } else {
       const int n = min(bn + row, N - 1);
@@ -374,7 +379,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
 
 // x (M,K) fp32 -> bf16 hi/lo planes (M,ldp), zero padded to ldp
 __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned short* __restrict__ hi,
-                                  unsigned short* __restrict__ lo, int ldp, int M, int K) {
+                                  unsigned short* __restrict__ lo, int ldp, int M, int K, int p_rpb, long p_bs) {
   const size_t nv = (size_t)M * (ldp / 4);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / (ldp / 4)), k = (int)(i % (ldp / 4)) * 4;
@@ -388,8 +393,10 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
       h[e] = hh;
       l[e] = f32_to_bf16_rne(x[e] - bf16_bits_to_f32(hh));
     }
-    *reinterpret_cast<u16x4_t*>(hi + (size_t)m * ldp + k) = h;
-    *reinterpret_cast<u16x4_t*>(lo + (size_t)m * ldp + k) = l;
+    size_t poff = (size_t)m * ldp;
+    if (p_rpb > 0) { const int eb = m / p_rpb; poff = (size_t)eb * p_bs + (size_t)(m - eb * p_rpb) * ldp; }
+    *reinterpret_cast<u16x4_t*>(hi + poff + k) = h;
+    *reinterpret_cast<u16x4_t*>(lo + poff + k) = l;
   }
 }
 
@@ -398,11 +405,11 @@ template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
-           int ksplit = 1) {
+           int ksplit = 1, int a_rpb = 0, long a_bs = 0) {
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM), ksplit), block((BM / WM) * (BN / WN) * 64);
 #define GRIDMM_LP(ACT)                                                                                        \
   GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
-                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K)
+                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
   else if (act == GRIDMM_ACT_RELU) GRIDMM_LP(GRIDMM_ACT_RELU);
@@ -459,16 +466,21 @@ extern "C" int gridmm_linear_planes_splitk(const void* A_hi, const void* A_lo, i
   return GRIDMM_OK;
 }
 
-extern "C" int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, int ldp, int M, int K,
-                                 gridmm_stream_t stream) {
-  if (M <= 0 || K <= 0 || ldp < K || ldp % 8) return GRIDMM_EINVAL;
+extern "C" int gridmm_split_rows_map(const float* X, int ldx, void* hi, void* lo, int ldp, int p_rpb, int64_t p_bs,
+                                     int M, int K, gridmm_stream_t stream) {
+  if (M <= 0 || K <= 0 || ldp < K || ldp % 8 || (p_rpb > 0 && p_bs % 8)) return GRIDMM_EINVAL;
   const size_t nv = (size_t)M * (ldp / 4);
   unsigned grid = (unsigned)((nv + 255) / 256);
   if (grid > 8192) grid = 8192;
   GRIDMM_LAUNCH(split_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), X, ldx, (unsigned short*)hi,
-                (unsigned short*)lo, ldp, M, K);
+                (unsigned short*)lo, ldp, M, K, p_rpb, (long)p_bs);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
+}
+
+extern "C" int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, int ldp, int M, int K,
+                                 gridmm_stream_t stream) {
+  return gridmm_split_rows_map(X, ldx, hi, lo, ldp, 0, 0, M, K, stream);
 }
 
 // Tile selection (cfg 0): estimated time = ceil(workgroups / (256 CUs * resident workgroups per CU)) rounds,
@@ -498,10 +510,10 @@ static int pick_cfg(int M, int N, int K) {
 
 // cfg: 0 = auto; tuning configs 1..6 (tools/bench_gemm.py):
 //   1: 128x128 NS=2   2: 128x128 NS=3   3: 256x128 (8 waves) NS=2   4: 64x64 NS=2   5: 64x64 NS=3   6: 128x64 NS=3
-extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
+static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
                                         const void* W_lo, int Kp, const float* bias, const float* residual,
                                         int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N,
-                                        int K, int act, int cfg, gridmm_stream_t stream) {
+                                        int K, int act, int cfg, int a_rpb, long a_bs, gridmm_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || act < 0 || act > 3)
     return GRIDMM_EINVAL;
   if (K % 64 && (cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 13 || cfg == 108 || cfg == 208)) return GRIDMM_EINVAL;
@@ -511,7 +523,7 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
   unsigned short *ch = (unsigned short*)C_hi, *cl = (unsigned short*)C_lo;
   hipStream_t st = as_stream(stream);
   if (cfg == 0) cfg = pick_cfg(M, N, K);
-#define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st
+#define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st, 1, a_rpb, a_bs
   switch (cfg) {
     case 1: return launch<128, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
     case 2: return launch<128, 128, 64, 32, 2, 64, 0, 0, 0, true>(GRIDMM_ARGS);
@@ -559,6 +571,26 @@ extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int 
     default: return GRIDMM_EINVAL;
   }
 #undef GRIDMM_ARGS
+}
+
+extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
+                                        const void* W_lo, int Kp, const float* bias, const float* residual,
+                                        int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N,
+                                        int K, int act, int cfg, gridmm_stream_t stream) {
+  return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M, N, K, act,
+                                cfg, 0, 0, stream);
+}
+
+// A rows through a batched row map: row m of the GEMM = row (m % a_rpb) of episode (m / a_rpb) in a buffer whose
+// episodes are a_bs elements apart (a_rpb <= 0: plain rows).  Lets a GEMM read a sub-sequence of a longer padded
+// sequence in place -- the instruction rows inside the local encoder's [map | txt] context, the map nodes inside [cells | nodes].
+extern "C" int gridmm_linear_planes_map(const void* A_hi, const void* A_lo, int lda, int a_rpb, int64_t a_bs,
+                                        const void* W_hi, const void* W_lo, int Kp, const float* bias,
+                                        const float* residual, int ldr, float* C, int ldc, void* C_hi, void* C_lo,
+                                        int ldp, int M, int N, int K, int act, gridmm_stream_t stream) {
+  if (a_rpb > 0 && (a_bs % 8)) return GRIDMM_EINVAL;
+  return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M, N, K, act,
+                                0, a_rpb, (long)a_bs, stream);
 }
 
 extern "C" int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void* W_hi,

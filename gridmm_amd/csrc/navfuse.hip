@@ -1,0 +1,420 @@
+// Fused row-wise stages around the encoders of forward('navigation'): everything here is a few hundred KB of fp32 per
+// step, so the cost is launches -- each kernel below replaces 3..12 of them (and the torch.cat / slice-assign nodes in
+// between).  Reference lines: map_nav_src/models/vilmodel.py.
+//   gridmm_cells_embed   :813-823  grid_pos_embeddings (Linear(5,H) + LN) computed inside the cell compaction
+//   gridmm_node_embed    :828-833  gmap / vp position embeddings (Linear(7|14,H) + LN) + image embeds + step table,
+//                        :846-851  and the byte masks of [cells | nodes | txt] and [nodes | views]
+//   gridmm_nav_heads     :859-907  the LN . w tails of the five ClsPrediction heads + masking + logit fusion
+#include "common.h"
+
+namespace {
+
+constexpr int NV = 4;        // float4 per lane: H <= 1024
+constexpr int MAXK = 16;     // position feature widths on this path: 5, 7, 14
+
+// y[c] (c = lane + 64 i) = LN(W f + b) * gamma + beta for one row, one wave; f: K position features (wave-uniform).
+__device__ __forceinline__ void pos_embed_row(const float* __restrict__ f, int K, const float* __restrict__ W,
+                                              const float* __restrict__ bias, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, float eps, int H, int lane, float4* y) {
+  const int nv = H >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv) {
+      v = reinterpret_cast<const float4*>(bias)[c];
+      const float* w = W + (size_t)c * 4 * K;
+      for (int k = 0; k < K; ++k) {
+        const float fk = f[k];
+        v.x += fk * w[k];
+        v.y += fk * w[K + k];
+        v.z += fk * w[2 * K + k];
+        v.w += fk * w[3 * K + k];
+      }
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    y[i] = v;
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = y[i].x - mean, b = y[i].y - mean, cc = y[i].z - mean, d = y[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+      const float4 b = reinterpret_cast<const float4*>(beta)[c];
+      y[i].x = (y[i].x - mean) * rstd * g.x + b.x;
+      y[i].y = (y[i].y - mean) * rstd * g.y + b.y;
+      y[i].z = (y[i].z - mean) * rstd * g.z + b.z;
+      y[i].w = (y[i].w - mean) * rstd * g.w + b.w;
+    }
+  }
+}
+
+// grid (B, 14): block (b, s) writes output rows [14 s, 14 s + 14) of episode b.  Compaction + mask exactly as
+// cells_compact_kernel (rowops.hip; vilmodel.py:813-823 with its in-place view quirk); the position embedding of a
+// compacted row is computed here from the 5 cell-centre features of its source cell.
+__global__ __launch_bounds__(256) void cells_embed_kernel(
+    const float* __restrict__ proj, const float* __restrict__ pos_fts, int K, const float* __restrict__ Wp,
+    const float* __restrict__ bp, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const uint8_t* __restrict__ occ, float* __restrict__ out, uint8_t* __restrict__ mask, int mask_bs,
+    const uint8_t* __restrict__ tail_mask, int n_tail, int32_t* __restrict__ n_cells, int32_t* __restrict__ cmax_out,
+    int B, int H, int S_pad) {
+  __shared__ int s_rank[GRIDMM_CELLS];
+  __shared__ int s_src[GRIDMM_CELLS];
+  __shared__ int s_n, s_tail, s_cmax;
+  __shared__ int s_wmax[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int wmax = 0;
+  for (int e = wave; e < B; e += 4) {
+    int n = 0;
+    for (int c0 = 0; c0 < GRIDMM_CELLS; c0 += 64) {
+      const int c = c0 + lane;
+      const bool o = (c < GRIDMM_CELLS) && occ[e * GRIDMM_CELLS + c];
+      n += __popcll(__ballot(o));
+    }
+    wmax = n > wmax ? n : wmax;
+  }
+  if (lane == 0) s_wmax[wave] = wmax;
+  if (wave == 0) {
+    int base = 0;
+    for (int c0 = 0; c0 < GRIDMM_CELLS; c0 += 64) {
+      const int c = c0 + lane;
+      const bool o = (c < GRIDMM_CELLS) && occ[b * GRIDMM_CELLS + c];
+      const unsigned long long m = __ballot(o);
+      const int r = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (c < GRIDMM_CELLS) s_rank[c] = o ? r : -1;
+      if (o) s_src[r] = c;
+      base += __popcll(m);
+    }
+    if (lane == 0) s_n = base;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int n = s_n;
+    int tail = 0;
+    for (int c0 = 0; c0 < GRIDMM_CELLS; c0 += 64) {
+      const int c = c0 + lane;
+      const bool o = (c >= n) && (c < GRIDMM_CELLS) && occ[b * GRIDMM_CELLS + c];
+      tail += __popcll(__ballot(o));
+    }
+    if (lane == 0) {
+      int cmax = s_wmax[0];
+      for (int w = 1; w < 4; ++w) cmax = s_wmax[w] > cmax ? s_wmax[w] : cmax;
+      s_tail = n + tail;
+      s_cmax = cmax;
+      if (blockIdx.y == 0) n_cells[b] = n;
+      if (b == 0 && blockIdx.y == 0) cmax_out[0] = cmax;
+    }
+  }
+  __syncthreads();
+  const int n = s_n, lim = s_tail, cmax = s_cmax;
+  if (blockIdx.y == 0) {
+    for (int p = tid; p < GRIDMM_CELLS; p += blockDim.x) {
+      uint8_t m;
+      if (p < n) m = 1;
+      else if (p < lim) m = occ[b * GRIDMM_CELLS + p] ? 1 : 0;
+      else m = 0;
+      if (p >= cmax) m = 0;
+      mask[(size_t)b * mask_bs + p] = m;
+    }
+    if (tail_mask)
+      for (int j = tid; j < n_tail; j += blockDim.x) mask[(size_t)b * mask_bs + GRIDMM_CELLS + j] = tail_mask[b * n_tail + j];
+  }
+  const int nv = H >> 2;
+  float* ob = out + (size_t)b * S_pad * H;
+  const int p_lo = blockIdx.y * GRIDMM_GRID;
+  for (int r = wave; r < GRIDMM_GRID; r += 4) {
+    const int p = p_lo + r;
+    float* orow = ob + (size_t)p * H;
+    if (p < n) {
+      const int c = s_src[p];
+      float f[MAXK];
+      for (int k = 0; k < K; ++k) f[k] = pos_fts[((size_t)b * GRIDMM_CELLS + c) * K + k];
+      float4 y[NV];
+      pos_embed_row(f, K, Wp, bp, gamma, beta, eps, H, lane, y);
+      const float* prow = proj + ((size_t)b * GRIDMM_CELLS + c) * H;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int ci = lane + i * 64;
+        if (ci < nv) {
+          const float4 a = reinterpret_cast<const float4*>(prow)[ci];
+          reinterpret_cast<float4*>(orow)[ci] = make_float4(a.x + y[i].x, a.y + y[i].y, a.z + y[i].z, a.w + y[i].w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int ci = lane + i * 64;
+        if (ci < nv) reinterpret_cast<float4*>(orow)[ci] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+}
+
+struct NodeSegs {
+  gridmm_embed_seg_t s[2];
+  int n;
+};
+
+// one wave per row over the rows of both segments; blocks [0, B) also assemble the byte masks of their episode
+__global__ __launch_bounds__(256) void node_embed_kernel(const NodeSegs segs, int H, const uint8_t* __restrict__ gmap_m,
+                                                         int G, const uint8_t* __restrict__ vp_m, int V,
+                                                         const uint8_t* __restrict__ txt_m, int L,
+                                                         uint8_t* __restrict__ kv_masks, int kv_bs, int kv_col0,
+                                                         uint8_t* __restrict__ q_masks, int B) {
+  const int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if ((int)blockIdx.x < B) {
+    const int b = blockIdx.x;
+    if (kv_masks) {
+      for (int j = threadIdx.x; j < G; j += blockDim.x) kv_masks[(size_t)b * kv_bs + kv_col0 + j] = gmap_m[b * G + j];
+      for (int j = threadIdx.x; j < L; j += blockDim.x) kv_masks[(size_t)b * kv_bs + kv_col0 + G + j] = txt_m[b * L + j];
+    }
+    if (q_masks) {
+      for (int j = threadIdx.x; j < G; j += blockDim.x) q_masks[(size_t)b * (G + V) + j] = gmap_m[b * G + j];
+      for (int j = threadIdx.x; j < V; j += blockDim.x) q_masks[(size_t)b * (G + V) + G + j] = vp_m[b * V + j];
+    }
+  }
+  int si = 0;
+  if (segs.n > 1 && row >= segs.s[0].M) { row -= segs.s[0].M; si = 1; }
+  const gridmm_embed_seg_t& S = segs.s[si];
+  if (row >= S.M) return;
+  const int K = S.K, nv = H >> 2;
+  float f[MAXK];
+  for (int k = 0; k < K; ++k) f[k] = S.pos[(size_t)row * K + k];
+  float4 y[NV];
+  pos_embed_row(f, K, S.W, S.bias, S.gamma, S.beta, S.eps, H, lane, y);
+  const float* trow = (S.table && S.idx) ? S.table + (size_t)S.idx[row] * H : nullptr;
+  size_t off = (size_t)row * H;
+  if (S.out_rpb > 0) { const int eb = row / S.out_rpb; off = (size_t)eb * S.out_bs + (size_t)(row - eb * S.out_rpb) * H; }
+  unsigned short *ohi = (unsigned short*)S.out_hi, *olo = (unsigned short*)S.out_lo;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      float4 v = y[i];
+      if (S.add1) {
+        const float4 a = reinterpret_cast<const float4*>(S.add1 + (size_t)row * S.ld1)[c];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      if (trow) {
+        const float4 a = reinterpret_cast<const float4*>(trow)[c];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      if (S.out) reinterpret_cast<float4*>(S.out + off)[c] = v;
+      if (ohi) {
+        uint2 hi, lo;
+        split2_bf16(v.x, v.y, hi.x, lo.x);
+        split2_bf16(v.z, v.w, hi.y, lo.y);
+        reinterpret_cast<uint2*>(ohi + off)[c] = hi;
+        reinterpret_cast<uint2*>(olo + off)[c] = lo;
+      }
+    }
+  }
+}
+
+struct HeadTails { gridmm_cls_tail_t t[5]; };
+
+// <LN(x) * gamma + beta, w> + b0 of one row by one wave (x: row of H floats; add: optional second addend + bias, then ReLU)
+__device__ __forceinline__ float ln_dot_row(const float* __restrict__ x, const float* __restrict__ x2,
+                                            const float* __restrict__ xb, const gridmm_cls_tail_t& T, int H, int lane) {
+  const int nv = H >> 2;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv) {
+      a = reinterpret_cast<const float4*>(x)[c];
+      if (x2) {   // fuse head: the two K-halves of its Linear arrive as separate partial products
+        const float4 p = reinterpret_cast<const float4*>(x2)[c];
+        const float4 q = reinterpret_cast<const float4*>(xb)[c];
+        a.x = fmaxf(a.x + p.x + q.x, 0.f); a.y = fmaxf(a.y + p.y + q.y, 0.f);
+        a.z = fmaxf(a.z + p.z + q.z, 0.f); a.w = fmaxf(a.w + p.w + q.w, 0.f);
+      }
+      s += (a.x + a.y) + (a.z + a.w);
+    }
+    v[i] = a;
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + T.eps);
+  float d = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 g = reinterpret_cast<const float4*>(T.gamma)[c];
+      const float4 b = reinterpret_cast<const float4*>(T.beta)[c];
+      const float4 ww = reinterpret_cast<const float4*>(T.w)[c];
+      d += ((v[i].x - mean) * rstd * g.x + b.x) * ww.x + ((v[i].y - mean) * rstd * g.y + b.y) * ww.y +
+           ((v[i].z - mean) * rstd * g.z + b.z) * ww.z + ((v[i].w - mean) * rstd * g.w + b.w) * ww.w;
+    }
+  }
+  return wave_sum(d) + (T.b0 ? T.b0[0] : 0.f);
+}
+
+// One workgroup (8 waves) per episode: rows = 1 (fuse) + G (global) + V (local) + G (grid) [+ V (object)], then the
+// masking / fusion of fuse_logits_kernel (rowops.hip) on the values kept in LDS.
+__global__ __launch_bounds__(512) void nav_heads_kernel(
+    const float* __restrict__ h_gl, int ld_gl, const float* __restrict__ fuse_a, const float* __restrict__ fuse_b,
+    const float* __restrict__ fuse_bias, const float* __restrict__ h_grid, const HeadTails tails, int has_obj,
+    const uint8_t* __restrict__ gmap_masks, const uint8_t* __restrict__ gmap_visited,
+    const uint8_t* __restrict__ vp_nav_masks, const uint8_t* __restrict__ vp_obj_masks,
+    const int32_t* __restrict__ cand_of_node, const uint8_t* __restrict__ cand_visited,
+    float* __restrict__ global_logits, float* __restrict__ local_logits, float* __restrict__ grid_logits,
+    float* __restrict__ fused_logits, float* __restrict__ obj_logits, int G, int V, int H) {
+  extern __shared__ float sm[];   // g_raw[G] | l_raw[V] | grid_raw[G] | o_raw[V] | fuse_raw
+  float *s_g = sm, *s_l = sm + G, *s_gr = s_l + V, *s_o = s_gr + G, *s_f = s_o + V;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int Sq = G + V;
+  const int rows = 1 + G + V + G + (has_obj ? V : 0);
+  for (int r = wave; r < rows; r += nw) {
+    float val;
+    float* dst;
+    if (r == 0) {
+      if (fuse_a) val = ln_dot_row(fuse_a + (size_t)b * H, fuse_b + (size_t)b * H, fuse_bias, tails.t[0], H, lane);
+      else val = 0.f;
+      dst = s_f;
+    } else if (r < 1 + G) {
+      const int j = r - 1;
+      val = ln_dot_row(h_gl + ((size_t)b * Sq + j) * ld_gl, nullptr, nullptr, tails.t[1], H, lane);
+      dst = s_g + j;
+    } else if (r < 1 + G + V) {
+      const int k = r - 1 - G;
+      val = ln_dot_row(h_gl + ((size_t)b * Sq + G + k) * ld_gl + H, nullptr, nullptr, tails.t[2], H, lane);
+      dst = s_l + k;
+    } else if (r < 1 + G + V + G) {
+      const int j = r - 1 - G - V;
+      val = ln_dot_row(h_grid + ((size_t)b * G + j) * H, nullptr, nullptr, tails.t[3], H, lane);
+      dst = s_gr + j;
+    } else {
+      const int k = r - 1 - G - V - G;
+      val = ln_dot_row(h_gl + ((size_t)b * Sq + G + k) * ld_gl + 2 * H, nullptr, nullptr, tails.t[4], H, lane);
+      dst = s_o + k;
+    }
+    if (lane == 0) *dst = val;
+  }
+  __syncthreads();
+  const float ninf = -__builtin_inff();
+  const float fw = fuse_a ? 1.0f / (1.0f + expf(-s_f[0])) : 0.5f;
+  for (int k = threadIdx.x; k < V; k += blockDim.x) {
+    float v = s_l[k] * (1.0f - fw);
+    if (!vp_nav_masks[b * V + k]) v = ninf;
+    local_logits[b * V + k] = v;
+    if (has_obj) {
+      float o = s_o[k];
+      if (!vp_obj_masks[b * V + k]) o = ninf;
+      obj_logits[b * V + k] = o;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < V; k += blockDim.x) {
+    float v = s_l[k] * (1.0f - fw);
+    if (!vp_nav_masks[b * V + k]) v = ninf;
+    s_l[k] = v;
+  }
+  __syncthreads();
+  float bw = 0.f;   // sum of the local logits of visited candidates, in candidate order (python `bw_logits += ...`)
+  for (int k = 1; k < V; ++k)
+    if (cand_visited[b * V + k]) bw += s_l[k];
+  for (int j = threadIdx.x; j < G; j += blockDim.x) {
+    const bool vis = gmap_visited[b * G + j], valid = gmap_masks[b * G + j];
+    float g = s_g[j] * fw;
+    if (vis || !valid) g = ninf;
+    float gr = s_gr[j];
+    if (vis || !valid) gr = ninf;
+    global_logits[b * G + j] = g;
+    grid_logits[b * G + j] = gr;
+    float f = g;
+    if (j == 0) f += s_l[0];
+    else {
+      const int k = cand_of_node[b * G + j];
+      if (k >= 0) f += s_l[k];
+      else if (k == -1) f += bw;
+    }
+    fused_logits[b * G + j] = f;
+  }
+}
+
+}  // namespace
+
+extern "C" int gridmm_cells_embed(const float* proj, const float* pos_fts, int K, const float* W_pos, const float* b_pos,
+                                  const float* gamma, const float* beta, float eps, const uint8_t* occ, float* out,
+                                  uint8_t* mask, int mask_bs, const uint8_t* tail_mask, int n_tail, int32_t* n_cells,
+                                  int32_t* cmax, int B, int H, int S_pad, gridmm_stream_t stream) {
+  if (B <= 0 || H <= 0 || H % 4 || H > 1024 || K <= 0 || K > MAXK || S_pad < GRIDMM_CELLS + (tail_mask ? n_tail : 0) ||
+      mask_bs < GRIDMM_CELLS + (tail_mask ? n_tail : 0))
+    return GRIDMM_EINVAL;
+  GRIDMM_LAUNCH(cells_embed_kernel, dim3(B, GRIDMM_GRID), dim3(256), 0, as_stream(stream), proj, pos_fts, K, W_pos, b_pos,
+                gamma, beta, eps, occ, out, mask, mask_bs, tail_mask, n_tail, n_cells, cmax, B, H, S_pad);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_node_embed(const gridmm_embed_seg_t* segs, int n_segs, int H, const uint8_t* gmap_masks, int G,
+                                 const uint8_t* vp_masks, int V, const uint8_t* txt_masks, int L, uint8_t* kv_masks,
+                                 int kv_bs, int kv_col0, uint8_t* q_masks, int B, gridmm_stream_t stream) {
+  if (!segs || n_segs < 1 || n_segs > 2 || H <= 0 || H % 4 || H > 1024 || B < 0) return GRIDMM_EINVAL;
+  NodeSegs a;
+  a.n = n_segs;
+  int rows = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const gridmm_embed_seg_t& s = segs[i];
+    if (s.M <= 0 || s.K <= 0 || s.K > MAXK || !s.pos || !s.W || !s.bias || !s.gamma || !s.beta || (!s.out && !s.out_hi) ||
+        (s.out_hi && !s.out_lo) || (s.add1 && s.ld1 % 4) || (s.out_rpb > 0 && s.out_bs % 4))
+      return GRIDMM_EINVAL;
+    a.s[i] = s;
+    rows += s.M;
+  }
+  if ((kv_masks || q_masks) && (!gmap_masks || G <= 0)) return GRIDMM_EINVAL;
+  if (kv_masks && (!txt_masks || kv_bs < kv_col0 + G + L)) return GRIDMM_EINVAL;
+  if (q_masks && (!vp_masks || V <= 0)) return GRIDMM_EINVAL;
+  int blocks = (rows + 3) / 4;
+  if ((kv_masks || q_masks) && blocks < B) blocks = B;
+  GRIDMM_LAUNCH(node_embed_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a, H, gmap_masks, G, vp_masks, V,
+                txt_masks, L, kv_masks, kv_bs, kv_col0, q_masks, (kv_masks || q_masks) ? B : 0);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_nav_heads(const float* h_gl, int ld_gl, const float* fuse_a, const float* fuse_b,
+                                const float* fuse_bias, const float* h_grid, const gridmm_cls_tail_t* tails,
+                                const uint8_t* gmap_masks, const uint8_t* gmap_visited, const uint8_t* vp_nav_masks,
+                                const uint8_t* vp_obj_masks, const int32_t* cand_of_node, const uint8_t* cand_visited,
+                                float* global_logits, float* local_logits, float* grid_logits, float* fused_logits,
+                                float* obj_logits, int B, int G, int V, int H, gridmm_stream_t stream) {
+  if (!h_gl || !h_grid || !tails || B <= 0 || G <= 0 || V <= 0 || G + V > 2048 || H <= 0 || H % 4 || H > 1024 || ld_gl % 4)
+    return GRIDMM_EINVAL;
+  if ((fuse_a && (!fuse_b || !fuse_bias)) || (obj_logits && !vp_obj_masks)) return GRIDMM_EINVAL;
+  const int has_obj = obj_logits ? 1 : 0;
+  if (ld_gl < (2 + has_obj) * H) return GRIDMM_EINVAL;
+  HeadTails t;
+  for (int i = 0; i < 5; ++i) t.t[i] = tails[i < 4 || has_obj ? i : 3];
+  const size_t lds = (size_t)(2 * G + 2 * V + 1) * sizeof(float);
+  GRIDMM_LAUNCH(nav_heads_kernel, dim3(B), dim3(512), lds, as_stream(stream), h_gl, ld_gl, fuse_a, fuse_b, fuse_bias,
+                h_grid, t, has_obj, gmap_masks, gmap_visited, vp_nav_masks, vp_obj_masks, cand_of_node, cand_visited,
+                global_logits, local_logits, grid_logits, fused_logits, obj_logits, G, V, H);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}

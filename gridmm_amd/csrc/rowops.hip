@@ -14,10 +14,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float* __restrict__ Y, int ldy, const float* __restrict__ add1, int ld1,
     const float* __restrict__ table, const int64_t* __restrict__ idx, unsigned short* __restrict__ Yhi,
-    unsigned short* __restrict__ Ylo, int ldp, int M, int H) {
+    unsigned short* __restrict__ Ylo, int ldp, int p_rpb, long p_bs, int M, int H) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  size_t poff = (size_t)row * ldp;   // planes through the batched row map (gridmm_layernorm_map)
+  if (p_rpb > 0) { const int eb = row / p_rpb; poff = (size_t)eb * p_bs + (size_t)(row - eb * p_rpb) * ldp; }
   const int nv = H >> 2;  // float4 per row
   float4 v[NV];
   float s = 0.f;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
           hi[e] = h;
           lo[e] = f32_to_bf16_rne(x[e] - bf16_bits_to_f32(h));
         }
-        reinterpret_cast<u16x4_t*>(Yhi + (size_t)row * ldp)[c] = hi;
-        reinterpret_cast<u16x4_t*>(Ylo + (size_t)row * ldp)[c] = lo;
+        reinterpret_cast<u16x4_t*>(Yhi + poff)[c] = hi;
+        reinterpret_cast<u16x4_t*>(Ylo + poff)[c] = lo;
       }
     }
   }
@@ -278,10 +280,11 @@ __global__ void fuse_logits_kernel(const float* __restrict__ g_raw, const float*
 
 }  // namespace
 
-extern "C" int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr, const float* gamma,
-                                const float* beta, float eps, float* Y, int ldy, const float* add1,
-                                int ld1, const float* table, const int64_t* idx, void* Y_hi, void* Y_lo,
-                                int ldp, int M, int H, gridmm_stream_t stream) {
+extern "C" int gridmm_layernorm_map(const float* X, int ldx, const float* R, int ldr, const float* gamma,
+                                    const float* beta, float eps, float* Y, int ldy, const float* add1,
+                                    int ld1, const float* table, const int64_t* idx, void* Y_hi, void* Y_lo,
+                                    int ldp, int p_rpb, int64_t p_bs, int M, int H, gridmm_stream_t stream) {
+  if (p_rpb > 0 && (p_bs % 4)) return GRIDMM_EINVAL;
   if (M <= 0 || H <= 0 || H % 4 || H > MAX_H || ldx % 4 || (Y && ldy % 4) || (R && ldr % 4) || (add1 && ld1 % 4))
     return GRIDMM_EINVAL;
   if ((!Y && !Y_hi) || (Y_hi && (!Y_lo || ldp % 4))) return GRIDMM_EINVAL;
@@ -290,11 +293,19 @@ extern "C" int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr
   const int nv = (H / 4 + 63) / 64;
 #define GRIDMM_LN(NV)                                                                              \
   GRIDMM_LAUNCH((layernorm_kernel<NV>), grid, block, 0, as_stream(stream), X, ldx, R, ldr, gamma, \
-                     beta, eps, Y, ldy, add1, ld1, table, idx, Yhi, Ylo, ldp, M, H)
+                     beta, eps, Y, ldy, add1, ld1, table, idx, Yhi, Ylo, ldp, p_rpb, (long)p_bs, M, H)
   if (nv == 1) GRIDMM_LN(1); else if (nv == 2) GRIDMM_LN(2); else if (nv == 3) GRIDMM_LN(3); else GRIDMM_LN(4);
 #undef GRIDMM_LN
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
+}
+
+extern "C" int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr, const float* gamma,
+                                const float* beta, float eps, float* Y, int ldy, const float* add1,
+                                int ld1, const float* table, const int64_t* idx, void* Y_hi, void* Y_lo,
+                                int ldp, int M, int H, gridmm_stream_t stream) {
+  return gridmm_layernorm_map(X, ldx, R, ldr, gamma, beta, eps, Y, ldy, add1, ld1, table, idx, Y_hi, Y_lo, ldp, 0, 0, M, H,
+                              stream);
 }
 
 extern "C" int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const float* beta, float eps,

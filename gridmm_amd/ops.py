@@ -88,6 +88,19 @@ def _rows2d(t):
     return M, H, rs
 
 
+def _rows_map(t):
+    """(M, H, row stride, rows_per_batch, batch stride) of a row-contiguous tensor: uniform rows -> rpb = 0; a (B, R, H)
+    view whose episodes are not R rows apart (a sub-sequence of a longer padded sequence) -> the batched row map the
+    *_map entry points take."""
+    try:
+        M, H, ld = _rows2d(t)
+        return M, H, ld, 0, 0
+    except ValueError:
+        if t.dim() == 3 and t.stride(2) == 1:
+            return t.shape[0] * t.shape[1], t.shape[2], t.stride(1), t.shape[1], t.stride(0)
+        raise
+
+
 class PackedLinear:
     """bf16 hi/lo planes of a Linear weight (N, K) zero-padded to Kp = roundup(K, 32), plus fp32 bias."""
 
@@ -147,15 +160,22 @@ def _planes_like(shape, device):
     return buf[0], buf[1]
 
 
-def split_rows(x):
-    """fp32 (..., K) -> Act with bf16 hi/lo planes (K % 8 == 0)."""
+def split_rows(x, out=None):
+    """fp32 (..., K) -> Act with bf16 hi/lo planes (K % 8 == 0).  out = (hi, lo): destination plane views, possibly rows of
+    a longer padded sequence (batched row map)."""
     lib = _lib.load()
     x = uniform_rows(x)
     M, K, ldx = _rows2d(x)
     assert K % 8 == 0
-    hi, lo = _planes_like(x.shape, x.device)
+    if out is None:
+        hi, lo = _planes_like(x.shape, x.device)
+        ldp, rpb, bs = K, 0, 0
+    else:
+        hi, lo = out
+        assert hi.shape == x.shape and hi.stride() == lo.stride() and hi.dtype == torch.bfloat16
+        _, _, ldp, rpb, bs = _rows_map(hi)
     _timed("split_rows", 0.0, lambda: _lib.check(
-        lib.gridmm_split_rows(_p(x), ldx, _p(hi), _p(lo), K, M, K, _stream()), "gridmm_split_rows"))
+        lib.gridmm_split_rows_map(_p(x), ldx, _p(hi), _p(lo), ldp, rpb, bs, M, K, _stream()), "gridmm_split_rows"))
     return Act(x, hi, lo)
 
 
@@ -177,9 +197,13 @@ def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_pla
     oshape = tuple(shape[:-1]) + (pw.N,)
     dev = a.device
     if (K % 32 == 0) and (pw.N % 4 == 0):
-        if a.hi is None or not _is_uniform(a.hi):
+        if a.hi is None:
             a = split_rows(a.f32)
-        M, _, lda = _rows2d(a.hi)
+        try:
+            M, _, lda, rpb, bs = _rows_map(a.hi)
+        except ValueError:
+            a = split_rows(a.f32)
+            M, _, lda, rpb, bs = _rows_map(a.hi)
         c = out if out is not None else (torch.empty(oshape, dtype=torch.float32, device=dev) if want_f32 else None)
         hi = lo = None
         if want_planes:
@@ -187,8 +211,8 @@ def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_pla
         ldc = _rows2d(c)[2] if c is not None else 0
         ldr = _rows2d(residual)[2] if residual is not None else 0
         _timed("linear", 2.0 * M * pw.N * K, lambda: _lib.check(
-            lib.gridmm_linear_planes(_p(a.hi), _p(a.lo), lda, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual),
-                                     ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream()),
+            lib.gridmm_linear_planes_map(_p(a.hi), _p(a.lo), lda, rpb, bs, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias),
+                                         _p(residual), ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream()),
             "gridmm_linear_planes"))
         return Act(c, hi, lo)
     xf = uniform_rows(a.f32)
@@ -205,8 +229,9 @@ def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_pla
 
 
 def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=None, out=None,
-              want_f32=True, want_planes=False):
-    """LN(x (+ residual)) * gamma + beta (+ add1) (+ table[idx]) -> Act (fp32 and/or bf16 planes)."""
+              want_f32=True, want_planes=False, planes_out=None):
+    """LN(x (+ residual)) * gamma + beta (+ add1) (+ table[idx]) -> Act (fp32 and/or bf16 planes).  planes_out = (hi, lo):
+    destination plane views (possibly rows of a longer padded sequence: batched row map)."""
     lib = _lib.load()
     if isinstance(x, Act):
         x = x.f32
@@ -221,7 +246,12 @@ def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=Non
         out = torch.empty(*x.shape, dtype=torch.float32, device=x.device)
     ldy = _rows2d(out)[2] if out is not None else 0
     hi = lo = None
-    if want_planes:
+    ldp, rpb, bs = H, 0, 0
+    if planes_out is not None:
+        hi, lo = planes_out
+        assert hi.shape == x.shape and hi.stride() == lo.stride() and hi.dtype == torch.bfloat16
+        _, _, ldp, rpb, bs = _rows_map(hi)
+    elif want_planes:
         hi, lo = _planes_like(x.shape, x.device)
     ldr = ld1 = 0
     if residual is not None:
@@ -232,8 +262,8 @@ def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=Non
         idx = idx.reshape(-1).to(torch.int64).contiguous()
         assert idx.numel() == M
     _timed("layernorm", 0.0, lambda: _lib.check(
-        lib.gridmm_layernorm(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(beta), float(eps), _p(out), ldy,
-                             _p(add1), ld1, _p(table), _p(idx), _p(hi), _p(lo), H, M, H, _stream()),
+        lib.gridmm_layernorm_map(_p(x), ldx, _p(residual), ldr, _p(gamma), _p(beta), float(eps), _p(out), ldy,
+                                 _p(add1), ld1, _p(table), _p(idx), _p(hi), _p(lo), ldp, rpb, bs, M, H, _stream()),
         "gridmm_layernorm"))
     if final is not None:
         copy_rows(out, final, 0)
@@ -365,31 +395,166 @@ class XLayerWeights:
         self.H, self.I = xq.N, ffn_i.N
 
 
-_XLAYER_WS = {}
-
-
-def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12):
+def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12, planes_out=None):
     """One GraphLXRTXLayer as ONE C call (gridmm_xattn_layer_fwd): x Act (f32 + planes) (B, Sq, H); kv Act planes
-    (B, Sk, n*H) holding the context's K / V projections at columns k_col / v_col.  Returns Act(f32 + planes)."""
+    (B, Sk, n*H) holding the context's K / V projections at columns k_col / v_col.  Returns Act(f32 + planes).
+    planes_out = (hi, lo): where the output planes go (views, possibly rows of a longer padded sequence).  The scratch is
+    allocated per call (stream-ordered by the caching allocator: safe for eager calls, several graphs and streams)."""
     lib = _lib.load()
     B, Sq, H = x.f32.shape
     Sk = kv.hi.shape[1]
     dev = x.f32.device
     assert x.f32.is_contiguous() and x.hi.is_contiguous() and kv.hi.stride(2) == 1 and kv.hi.stride() == kv.lo.stride()
     need = lib.gridmm_xattn_layer_workspace(B, Sq, H, w.I)
-    key = (dev, need)
-    ws = _XLAYER_WS.get(key)
-    if ws is None:
-        ws = _XLAYER_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
     y = torch.empty(B, Sq, H, dtype=torch.float32, device=dev)
-    hi, lo = _planes_like((B, Sq, H), dev)
+    rpb, bs = 0, 0
+    if planes_out is not None:
+        hi, lo = planes_out
+        assert hi.shape == (B, Sq, H) and hi.stride() == lo.stride() and hi.stride(1) == H and hi.stride(2) == 1
+        if hi.stride(0) != Sq * H:
+            rpb, bs = Sq, hi.stride(0)
+    else:
+        hi, lo = _planes_like((B, Sq, H), dev)
     cm = ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask
     sm = self_mask.view(torch.uint8) if self_mask.dtype == torch.bool else self_mask
+    assert cm.stride(1) == 1 and sm.stride(1) == 1
     _lib.check(lib.gridmm_xattn_layer_fwd(ctypes.byref(w.c), _p(x.f32), _p(x.hi), _p(x.lo), _p(kv.hi), _p(kv.lo),
                                           kv.hi.stride(0), kv.hi.stride(1), int(k_col), int(v_col), _p(cm), cm.stride(0),
-                                          _p(sm), sm.stride(0), _p(y), _p(hi), _p(lo), _p(ws), need, B, Sq, Sk, heads,
-                                          _stream()), "gridmm_xattn_layer_fwd")
+                                          _p(sm), sm.stride(0), _p(y), _p(hi), _p(lo), rpb, bs, _p(ws), need, B, Sq, Sk,
+                                          heads, _stream()), "gridmm_xattn_layer_fwd")
     return Act(y, hi, lo)
+
+
+class _CProblem(ctypes.Structure):
+    _fields_ = [("A_hi", ctypes.c_void_p), ("A_lo", ctypes.c_void_p), ("lda", ctypes.c_int), ("a_rpb", ctypes.c_int),
+                ("a_bs", ctypes.c_int64), ("W_hi", ctypes.c_void_p), ("W_lo", ctypes.c_void_p), ("Kp", ctypes.c_int),
+                ("bias", ctypes.c_void_p), ("C", ctypes.c_void_p), ("ldc", ctypes.c_int), ("C_hi", ctypes.c_void_p),
+                ("C_lo", ctypes.c_void_p), ("ldp", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int),
+                ("K", ctypes.c_int), ("act", ctypes.c_int)]
+
+
+def gemm_problem(a_hi, a_lo, lda, M, pw, out, act=ACT_NONE, a_rpb=0, a_bs=0, a_off=0, w_col0=0, K=None, bias=True):
+    """One record of linear_grouped: out (M, N) fp32 = act(A W^T + b); A = plane tensors read from element offset a_off
+    with row stride lda (batched row map a_rpb / a_bs optional); W = PackedLinear, contraction over its columns
+    [w_col0, w_col0 + K)."""
+    K = pw.K if K is None else K
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[-1] == pw.N
+    return _CProblem(a_hi.data_ptr() + 2 * a_off, a_lo.data_ptr() + 2 * a_off, int(lda), int(a_rpb), int(a_bs),
+                     pw.hi.data_ptr() + 2 * w_col0, pw.lo.data_ptr() + 2 * w_col0, pw.Kp,
+                     pw.bias.data_ptr() if (bias and pw.bias is not None) else None, out.data_ptr(), pw.N, None, None, 0,
+                     int(M), pw.N, int(K), int(act))
+
+
+def linear_grouped(problems):
+    """Several small plane GEMMs in one launch (gridmm_linear_planes_grouped); problems: list of gemm_problem()."""
+    lib = _lib.load()
+    arr = (_CProblem * len(problems))(*problems)
+    work = sum(2.0 * p.M * p.N * p.K for p in problems)
+    _timed("linear", work, lambda: _lib.check(lib.gridmm_linear_planes_grouped(arr, len(problems), _stream()),
+                                              "gridmm_linear_planes_grouped"))
+
+
+def cells_embed(proj, pos_fts, lin, ln, occ, out, mask, tail_mask=None):
+    """cells_compact with the grid position embedding (lin = nn.Linear(K, H), ln = nn.LayerNorm) computed inside; mask:
+    (B, >= 196 + n_tail) uint8 view with any row stride; tail_mask (B, n_tail) is copied behind the 196 cell bits.
+    Returns (n_cells, cmax) int32 tensors."""
+    lib = _lib.load()
+    B, S_pad, H = out.shape
+    K = pos_fts.shape[-1]
+    dev = out.device
+    n_cells = torch.empty(B, dtype=torch.int32, device=dev)
+    cmax = torch.empty(1, dtype=torch.int32, device=dev)
+    assert out.is_contiguous() and mask.stride(1) == 1 and mask.dtype == torch.uint8 and proj.is_contiguous()
+    pos_fts = pos_fts.float().contiguous()
+    n_tail = 0 if tail_mask is None else tail_mask.shape[1]
+    assert tail_mask is None or tail_mask.is_contiguous()
+    _timed("cells_embed", 0.0, lambda: _lib.check(lib.gridmm_cells_embed(
+        _p(proj), _p(pos_fts), K, _p(lin.weight), _p(lin.bias), _p(ln.weight), _p(ln.bias), float(ln.eps), _p(occ),
+        _p(out), _p(mask), mask.stride(0), _p(tail_mask), n_tail, _p(n_cells), _p(cmax), B, H, S_pad, _stream()),
+        "gridmm_cells_embed"))
+    return n_cells, cmax
+
+
+class _CEmbedSeg(ctypes.Structure):
+    _fields_ = [("pos", ctypes.c_void_p), ("K", ctypes.c_int), ("W", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("add1", ctypes.c_void_p),
+                ("ld1", ctypes.c_int), ("table", ctypes.c_void_p), ("idx", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("out_hi", ctypes.c_void_p), ("out_lo", ctypes.c_void_p), ("out_rpb", ctypes.c_int),
+                ("out_bs", ctypes.c_int64), ("M", ctypes.c_int)]
+
+
+def embed_seg(pos, lin, ln, add1, out, table=None, idx=None, planes=None):
+    """One segment of node_embed: out (B, R, H) fp32 view (rows of a longer sequence allowed) = LN(lin(pos)) + add1
+    (+ table[idx]); planes = (hi, lo) views with the SAME strides as out."""
+    keep = []
+    pos = pos.float().contiguous()
+    add1 = add1.float().contiguous()
+    keep += [pos, add1]
+    B, R, H = out.shape
+    assert out.stride(2) == 1 and out.stride(1) == H and pos.shape[:2] == (B, R) and add1.shape == (B, R, H)
+    rpb, bs = (0, 0) if out.stride(0) == R * H else (R, out.stride(0))
+    if idx is not None:
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        keep.append(idx)
+    hi = lo = None
+    if planes is not None:
+        hi, lo = planes
+        assert hi.stride() == out.stride() and lo.stride() == out.stride()
+    seg = _CEmbedSeg(pos.data_ptr(), pos.shape[-1], lin.weight.data_ptr(), lin.bias.data_ptr(), ln.weight.data_ptr(),
+                     ln.bias.data_ptr(), float(ln.eps), add1.data_ptr(), H, table.data_ptr() if table is not None else None,
+                     idx.data_ptr() if idx is not None else None, out.data_ptr(), hi.data_ptr() if hi is not None else None,
+                     lo.data_ptr() if lo is not None else None, rpb, bs, B * R)
+    seg._keep = keep
+    return seg
+
+
+def node_embed(segs, H, gmap_m, vp_m, txt_m, kv_masks, kv_col0, q_masks):
+    """Position embeddings of the map nodes / candidate views (embed_seg records) + the byte masks of the [cells | nodes |
+    txt] context (written from column kv_col0 of kv_masks on) and of the [nodes | views] queries, one launch."""
+    lib = _lib.load()
+    arr = (_CEmbedSeg * len(segs))(*segs)
+    B, G = gmap_m.shape
+    V, L = vp_m.shape[1], txt_m.shape[1]
+    for m in (gmap_m, vp_m, txt_m, q_masks):
+        assert m.dtype == torch.uint8 and m.is_contiguous()
+    assert kv_masks.dtype == torch.uint8 and kv_masks.stride(1) == 1 and q_masks.shape == (B, G + V)
+    _timed("node_embed", 0.0, lambda: _lib.check(lib.gridmm_node_embed(
+        arr, len(segs), H, _p(gmap_m), G, _p(vp_m), V, _p(txt_m), L, _p(kv_masks), kv_masks.stride(0), int(kv_col0),
+        _p(q_masks), B, _stream()), "gridmm_node_embed"))
+
+
+class _CClsTail(ctypes.Structure):
+    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float), ("w", ctypes.c_void_p),
+                ("b0", ctypes.c_void_p)]
+
+
+def cls_tail(net):
+    """ClsPrediction.net -> the LayerNorm . Linear(H, 1) tail record (net = [Linear, ReLU, LayerNorm, Linear])."""
+    return _CClsTail(net[2].weight.data_ptr(), net[2].bias.data_ptr(), float(net[2].eps), net[3].weight.data_ptr(),
+                     net[3].bias.data_ptr() if net[3].bias is not None else None)
+
+
+def nav_heads(h_gl, fuse_a, fuse_b, fuse_bias, h_grid, tails, gmap_masks, gmap_visited, vp_nav_masks, vp_obj_masks,
+              cand_of_node, cand_visited, G, V):
+    """LN . w tails of the heads + masking + fusion (gridmm_nav_heads).  tails: [fuse, global, local, grid, object] cls_tail
+    records (object may be None).  Returns (global, local, grid, fused, obj or None)."""
+    lib = _lib.load()
+    B = gmap_masks.shape[0]
+    H = h_grid.shape[-1]
+    dev = h_gl.device
+    outs = [torch.empty(B, G, device=dev), torch.empty(B, V, device=dev), torch.empty(B, G, device=dev),
+            torch.empty(B, G, device=dev)]
+    obj = torch.empty(B, V, device=dev) if vp_obj_masks is not None else None
+    t = [x if x is not None else tails[3] for x in tails]
+    if fuse_a is None:
+        t[0] = tails[1]
+    arr = (_CClsTail * 5)(*t)
+    _timed("nav_heads", 0.0, lambda: _lib.check(lib.gridmm_nav_heads(
+        _p(h_gl), h_gl.shape[-1], _p(fuse_a), _p(fuse_b), _p(fuse_bias), _p(h_grid), arr, _p(gmap_masks), _p(gmap_visited),
+        _p(vp_nav_masks), _p(vp_obj_masks), _p(cand_of_node), _p(cand_visited), _p(outs[0]), _p(outs[1]), _p(outs[2]),
+        _p(outs[3]), _p(obj), B, G, V, H, _stream()), "gridmm_nav_heads"))
+    return outs[0], outs[1], outs[2], outs[3], obj
 
 
 def tokens_to_slab(tokens, slot, n_views):

@@ -293,16 +293,16 @@ class GlocalTextPathNavCMT(nn.Module):
         h = ops.linear(c, self._lin(xatt.output.dense, key + ".o"), residual=x.f32)
         return self._ln(xatt.output.LayerNorm, h, want_planes=True)
 
-    def _ffn(self, inter, out, key, x):
+    def _ffn(self, inter, out, key, x, planes_out=None):
         h = ops.linear(x, self._lin(inter.dense, key + ".i"), act=ops.ACT_GELU, want_f32=False, want_planes=True)
         o = ops.linear(h, self._lin(out.dense, key + ".f"), residual=x.f32)
-        return self._ln(out.LayerNorm, o, want_planes=True)
+        return self._ln(out.LayerNorm, o, want_planes=True, planes_out=planes_out)
 
     def _bert_layer(self, layer, key, x, kmask):
         a = self._self_attention(layer.attention, key + ".att", x, kmask)
         return self._ffn(layer.intermediate, layer.output, key, a)
 
-    def _x_layer(self, layer, key, lang, lang_mask, visn, visn_mask, kv=None):
+    def _x_layer(self, layer, key, lang, lang_mask, visn, visn_mask, kv=None, planes_out=None):
         """GraphLXRTXLayer.forward with graph_sprels=None (vilmodel.py:399-414).  One C call per layer
         (gridmm_xattn_layer_fwd) unless per-kernel timing is on (ops.TIMER: the eleven launches are issued one by one)."""
         if ops.TIMER is None and visn.f32 is not None and visn.hi is not None and visn.f32.is_contiguous():
@@ -314,15 +314,17 @@ class GlocalTextPathNavCMT(nn.Module):
             pws = (self._qkv(layer.visual_attention.att, key + ".x", "q"), self._lin(layer.visual_attention.output.dense, key + ".x.o"),
                    self._qkv(sa.self, key + ".s"), self._lin(sa.output.dense, key + ".s.o"),
                    self._lin(ff.visn_inter.dense, key + ".i"), self._lin(ff.visn_output.dense, key + ".f"))
+            lns = (layer.visual_attention.output.LayerNorm, sa.output.LayerNorm, ff.visn_output.LayerNorm)
+            sig = pws + tuple(p.data_ptr() for ln in lns for p in (ln.weight, ln.bias))
             ent = self._packed.get(key + ".xlayer")
-            if ent is None or any(a is not b for a, b in zip(ent[0], pws)):
-                ent = (pws, ops.XLayerWeights(*pws, layer.visual_attention.output.LayerNorm, sa.output.LayerNorm,
-                                              ff.visn_output.LayerNorm))
+            if ent is None or len(ent[0]) != len(sig) or any(a is not b and a != b for a, b in zip(ent[0], sig)):
+                ent = (sig, ops.XLayerWeights(*pws, *lns))
                 self._packed[key + ".xlayer"] = ent
-            return ops.xattn_layer(ent[1], visn, kv[0], kv[1], kv[1] + H, lang_mask, visn_mask, heads=self.heads)
+            return ops.xattn_layer(ent[1], visn, kv[0], kv[1], kv[1] + H, lang_mask, visn_mask, heads=self.heads,
+                                   planes_out=planes_out)
         a = self._cross_attention(layer.visual_attention, key + ".x", visn, lang, lang_mask, kv=kv)
         a = self._self_attention(layer.visn_self_att, key + ".s", a, visn_mask)
-        return self._ffn(layer.visn_inter, layer.visn_output, key, a)
+        return self._ffn(layer.visn_inter, layer.visn_output, key, a, planes_out=planes_out)
 
     def _pre_ln_encoder(self, enc, key, x, kmask):
         """TransformerEncoder, normalize_before=True (transformer.py:170-182), final LN eps 1e-12.
@@ -454,15 +456,25 @@ class GlocalTextPathNavCMT(nn.Module):
                                  vp_img_embeds, vp_pos_fts, vp_masks, grid_fts, grid_map, gridmap_pos_fts,
                                  grid_memory=None):
         """vilmodel.py:788-856: aggregation, grid encoder, grid/text layer, local encoder -> (gmap_embeds (B,G,H),
-        vp_embeds (B,V,H), map_embeds (B,196+G,H)).  Shared with the VLN-CE twin (gridmap/vilmodel.py:710-776)."""
+        vp_embeds (B,V,H), map_embeds (B,196+G,H)).  Shared with the VLN-CE twin (gridmap/vilmodel.py:710-776).
+
+        Sequences are never concatenated: ONE plane buffer `kv` (B, 196+G+L, H) is the local encoder's [map | txt] context
+        (vilmodel.py:846-848); the instruction planes are split straight into its tail, the grid/text layer's last
+        LayerNorm writes the map planes into its head, and the GEMMs that need only one part read it in place through
+        the batched row map of gridmm_linear_planes_map.  The byte masks live the same way in `kv_masks`."""
         dev = txt_embeds.device
         B, L, H = txt_embeds.shape
         G, V = gmap_masks.shape[1], vp_masks.shape[1]
+        S = N_CELLS + G
         txt_embeds = txt_embeds.float().contiguous()
-        txt_m, gmap_m, vp_m = self._u8(txt_masks), self._u8(gmap_masks), self._u8(vp_masks)
+        txt_m, gmap_m, vp_m = (self._u8(m).contiguous() for m in (txt_masks, gmap_masks, vp_masks))
+        kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
+        kv_masks = torch.empty(B, S + L, dtype=torch.uint8, device=dev)
+        q_masks = torch.empty(B, G + V, dtype=torch.uint8, device=dev)
+        map_masks = kv_masks[:, :S]
 
         # ---- grid memory -> 196 instruction-weighted cell vectors (vilmodel.py:793-807)
-        txt = ops.split_rows(txt_embeds)                       # fp32 + bf16 planes of the instruction tokens
+        txt = ops.split_rows(txt_embeds, out=(kv.hi[:, S:], kv.lo[:, S:]))   # fp32 + planes (in place in the context)
         text_fts = ops.linear(txt, self._lin(self.text_proj, "text_proj")).f32
         frag = ops.text_fragments(text_fts)
         n_points = None
@@ -475,38 +487,32 @@ class GlocalTextPathNavCMT(nn.Module):
             slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
         cells, occ = ops.grid_aggregate(slab, perm, cell_start, frag, L, n_points=n_points)
         proj = ops.linear(cells, self._lin(self.grid_proj, "grid_proj")).f32
-        gp = self.grid_pos_embeddings
-        pos_emb = self._ln(gp[1], ops.linear(gridmap_pos_fts.float().contiguous(), self._lin(gp[0], "grid_pos"))).f32
 
-        # ---- [cells | gmap nodes] sequence, padded to 196 + G (vilmodel.py:813-837)
-        S = N_CELLS + G
+        # ---- [cells | gmap nodes] sequence, padded to 196 + G (vilmodel.py:813-837); position embeddings of cells, nodes
+        # and views + all byte masks in two launches
         map_embeds = torch.empty(B, S, H, dtype=torch.float32, device=dev)
-        map_masks = torch.empty(B, S, dtype=torch.uint8, device=dev)
-        ops.cells_compact(proj, pos_emb, occ, map_embeds, map_masks)
-        map_masks[:, N_CELLS:] = gmap_m
-        ge = self.global_encoder
-        self._ln(ge.gmap_pos_embeddings[1],
-                 ops.linear(gmap_pos_fts.float().contiguous(), self._lin(ge.gmap_pos_embeddings[0], "gmap_pos")),
-                 add1=gmap_img_embeds.float().contiguous(), table=ge.gmap_step_embeddings.weight,
-                 idx=gmap_step_ids, out=map_embeds[:, N_CELLS:])
+        gp = self.grid_pos_embeddings
+        self._cells = ops.cells_embed(proj, gridmap_pos_fts, gp[0], gp[1], occ, map_embeds, kv_masks, tail_mask=gmap_m)
         q = torch.empty(B, G + V, H, dtype=torch.float32, device=dev)
-        le = self.local_encoder
-        self._ln(le.vp_pos_embeddings[1],
-                 ops.linear(vp_pos_fts.float().contiguous(), self._lin(le.vp_pos_embeddings[0], "vp_pos")),
-                 add1=vp_img_embeds.float().contiguous(), out=q[:, G:])
+        qp = ops._planes_like((B, G + V, H), dev)
+        ge, le = self.global_encoder, self.local_encoder
+        ops.node_embed(
+            [ops.embed_seg(gmap_pos_fts, ge.gmap_pos_embeddings[0], ge.gmap_pos_embeddings[1], gmap_img_embeds,
+                           map_embeds[:, N_CELLS:], table=ge.gmap_step_embeddings.weight, idx=gmap_step_ids),
+             ops.embed_seg(vp_pos_fts, le.vp_pos_embeddings[0], le.vp_pos_embeddings[1], vp_img_embeds, q[:, G:],
+                           planes=(qp[0][:, G:], qp[1][:, G:]))],
+            H, gmap_m, vp_m, txt_m, kv_masks, N_CELLS, q_masks)
 
         # ---- grid encoder + grid/text cross-modal layer (vilmodel.py:840-841)
         mp = self._pre_ln_encoder(self.grid_encoder, "grid_enc", map_embeds, map_masks)
+        nl = len(self.grid_txt_encoder.x_layers)
         for i, layer in enumerate(self.grid_txt_encoder.x_layers):
-            mp = self._x_layer(layer, "grid_txt.%d" % i, txt, txt_m, mp, map_masks)
+            mp = self._x_layer(layer, "grid_txt.%d" % i, txt, txt_m, mp, map_masks,
+                               planes_out=(kv.hi[:, :S], kv.lo[:, :S]) if i == nl - 1 else None)
         map_embeds = mp.f32
 
         # ---- local encoder over q = [gmap | vp], kv = [map | txt] (vilmodel.py:843-856).  The context is the
         # same for all layers, so the K/V projections of every layer run as ONE GEMM (N = layers * 2H).
-        kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
-        ops.copy_planes(mp, kv, 0)
-        ops.copy_planes(txt, kv, S)
-        kv_masks = torch.cat([map_masks, txt_m], 1)
         xl = le.encoder.x_layers
         kv_all = ops.linear(kv, self._pack("local.kv_all",
                                            [w for l in xl for w in (l.visual_attention.att.key.weight,
@@ -515,42 +521,72 @@ class GlocalTextPathNavCMT(nn.Module):
                                                                     l.visual_attention.att.value.bias)]),
                             want_f32=False, want_planes=True)
         ops.copy_rows(map_embeds[:, N_CELLS:], q, 0)
-        qa = ops.split_rows(q)
-        q_masks = torch.cat([gmap_m, vp_m], 1)
+        ops.copy_planes(ops.Act(None, kv.hi[:, N_CELLS:S], kv.lo[:, N_CELLS:S]), ops.Act(None, qp[0], qp[1]), 0)
+        qa = ops.Act(q, qp[0], qp[1])
         for i, layer in enumerate(xl):
             qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks, kv=(kv_all, 2 * H * i))
         q = qa.f32
-        self._last_acts = (qa, mp)            # bf16 planes of the same tensors: the heads read them without re-splitting
+        self._last_acts = (qa, kv, S + L)     # planes of the outputs: the heads read them in place
         return q[:, :G], q[:, G:], map_embeds
 
     @torch.no_grad()
     def _heads_infer(self, gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, gmap_vpids, vp_nav_masks,
                      vp_obj_masks, vp_cand_vpids, fusion_maps, G, V, dev):
-        """vilmodel.py:859-907."""
-        fuse_raw = None
-        if self.sap_fuse_linear is not None:
-            fuse_raw = self._cls(self.sap_fuse_linear, "fuse", torch.cat([gmap_embeds[:, 0], vp_embeds[:, 0]], 1))
+        """vilmodel.py:859-907: the ClsPrediction heads as ONE grouped GEMM launch (fuse head = two K-halves over row 0
+        of the node / view blocks, global + local (+ object) heads stacked over all G + V rows, grid head over the
+        pre-local-encoder node rows read in place from the context planes) + ONE tail / masking / fusion launch."""
         acts, self._last_acts = getattr(self, "_last_acts", None), None
-        if acts is not None and acts[0].hi is not None and acts[0].f32.data_ptr() == gmap_embeds.data_ptr():
-            # global + local heads as ONE GEMM over all G + V query rows (N = 2H, planes straight from the last
-            # LayerNorm), then LayerNorm . w per head on its half of the columns; rows a head does not own are dropped
-            qa, mp = acts
-            H = gmap_embeds.shape[-1]
-            gh, lh = self.global_sap_head.net, self.local_sap_head.net
-            h = ops.linear(qa, self._pack("ghead+lhead", [gh[0].weight, lh[0].weight], [gh[0].bias, lh[0].bias]),
-                           act=ops.ACT_RELU).f32
-            g_raw = ops.ln_dot(h[..., :H], gh[2].weight, gh[2].bias, gh[2].eps, gh[3].weight.view(-1), gh[3].bias)[:, :G].contiguous()
-            l_raw = ops.ln_dot(h[..., H:], lh[2].weight, lh[2].bias, lh[2].eps, lh[3].weight.view(-1), lh[3].bias)[:, G:].contiguous()
-            gp = ops.Act(None, *ops._planes_like((gmap_embeds.shape[0], G, H), dev))
-            ops.copy_planes(ops.Act(None, mp.hi[:, N_CELLS:], mp.lo[:, N_CELLS:]), gp, 0)
-            grid_raw = self._cls(self.grid_sap_head, "gridhead", gp)
-        else:
-            g_raw = self._cls(self.global_sap_head, "ghead", gmap_embeds)
-            grid_raw = self._cls(self.grid_sap_head, "gridhead", map_embeds[:, N_CELLS:])
-            l_raw = self._cls(self.local_sap_head, "lhead", vp_embeds)
+        B, H = gmap_embeds.shape[0], gmap_embeds.shape[-1]
         if fusion_maps is None:   # host-built from the python vpid lists; pass precomputed device tensors to avoid
             cand_of_node, cand_visited = self._fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V)
             fusion_maps = (cand_of_node.to(dev), cand_visited.to(dev))   # the H2D (needed under graph capture)
+        has_obj = vp_obj_masks is not None
+        if acts is None or acts[0].f32.data_ptr() != gmap_embeds.data_ptr():
+            return self._heads_infer_unfused(gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, vp_nav_masks,
+                                             vp_obj_masks, fusion_maps, G, V)
+        qa, kv, SL = acts
+        Sq = G + V
+        gh, lh = self.global_sap_head.net, self.local_sap_head.net
+        stack = [gh[0], lh[0]] + ([self.og_head.net[0]] if has_obj else [])
+        pw_gl = self._pack("ghead+lhead+og" if has_obj else "ghead+lhead", [m.weight for m in stack], [m.bias for m in stack])
+        pw_grid = self._lin(self.grid_sap_head.net[0], "gridhead")
+        h_gl = torch.empty(B * Sq, pw_gl.N, dtype=torch.float32, device=dev)
+        h_grid = torch.empty(B * G, H, dtype=torch.float32, device=dev)
+        probs = [ops.gemm_problem(qa.hi, qa.lo, H, B * Sq, pw_gl, h_gl, act=ops.ACT_RELU),
+                 ops.gemm_problem(kv.hi, kv.lo, H, B * G, pw_grid, h_grid, act=ops.ACT_RELU, a_rpb=G, a_bs=SL * H,
+                                  a_off=N_CELLS * H)]
+        fa = fb = fbias = None
+        if self.sap_fuse_linear is not None:
+            pw_f = self._lin(self.sap_fuse_linear.net[0], "fuse")
+            fa = torch.empty(B, H, dtype=torch.float32, device=dev)
+            fb = torch.empty(B, H, dtype=torch.float32, device=dev)
+            fbias = pw_f.bias
+            probs += [ops.gemm_problem(qa.hi, qa.lo, Sq * H, B, pw_f, fa, K=H, bias=False),
+                      ops.gemm_problem(qa.hi, qa.lo, Sq * H, B, pw_f, fb, K=H, bias=False, a_off=G * H, w_col0=H)]
+        ops.linear_grouped(probs)
+        tails = [ops.cls_tail(self.sap_fuse_linear.net) if self.sap_fuse_linear is not None else None,
+                 ops.cls_tail(gh), ops.cls_tail(lh), ops.cls_tail(self.grid_sap_head.net),
+                 ops.cls_tail(self.og_head.net) if has_obj else None]
+        global_logits, local_logits, grid_logits, fused_logits, obj_logits = ops.nav_heads(
+            h_gl, fa, fb, fbias, h_grid, tails, gmap_m.contiguous(), self._u8(gmap_visited_masks).contiguous(),
+            self._u8(vp_nav_masks).contiguous(), self._u8(vp_obj_masks).contiguous() if has_obj else None,
+            fusion_maps[0], fusion_maps[1], G, V)
+        return {
+            "gmap_embeds": gmap_embeds, "vp_embeds": vp_embeds, "global_logits": global_logits,
+            "local_logits": local_logits, "fused_logits": fused_logits, "obj_logits": obj_logits,
+            "grid_logits": grid_logits,
+        }
+
+    @torch.no_grad()
+    def _heads_infer_unfused(self, gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, vp_nav_masks,
+                             vp_obj_masks, fusion_maps, G, V):
+        """The same heads from plain fp32 embeddings, one launch per op (callers that hand in their own tensors)."""
+        fuse_raw = None
+        if self.sap_fuse_linear is not None:
+            fuse_raw = self._cls(self.sap_fuse_linear, "fuse", torch.cat([gmap_embeds[:, 0], vp_embeds[:, 0]], 1))
+        g_raw = self._cls(self.global_sap_head, "ghead", gmap_embeds)
+        grid_raw = self._cls(self.grid_sap_head, "gridhead", map_embeds[:, N_CELLS:])
+        l_raw = self._cls(self.local_sap_head, "lhead", vp_embeds)
         global_logits, local_logits, grid_logits, fused_logits = ops.fuse_logits(
             g_raw, l_raw, grid_raw, fuse_raw, gmap_m, self._u8(gmap_visited_masks), self._u8(vp_nav_masks),
             fusion_maps[0], fusion_maps[1])

@@ -181,6 +181,16 @@ int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr, const flo
 int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, int ldp, int M, int K,
                       gridmm_stream_t stream);
 
+/* gridmm_layernorm / gridmm_split_rows with the bf16 PLANES written through a batched row map (p_rpb rows per
+ * episode, episodes p_bs elements apart; p_rpb <= 0: plain [M][ldp]): the producer of a sequence writes it straight into
+ * its place inside a longer one (the [map | txt] context of the local encoder, vilmodel.py:846-848) -- no torch.cat. */
+int gridmm_layernorm_map(const float* X, int ldx, const float* R, int ldr, const float* gamma, const float* beta,
+                         float eps, float* Y, int ldy, const float* add1, int ld1, const float* table,
+                         const int64_t* idx, void* Y_hi, void* Y_lo, int ldp, int p_rpb, int64_t p_bs, int M, int H,
+                         gridmm_stream_t stream);
+int gridmm_split_rows_map(const float* X, int ldx, void* hi, void* lo, int ldp, int p_rpb, int64_t p_bs, int M, int K,
+                          gridmm_stream_t stream);
+
 /* gridmm_linear with BOTH operands as pre-split bf16 planes (the hot-path GEMM: LDS-DMA tile pipeline,
  * no conversion in the loop).  K % 32 == 0, lda % 8 == 0, N % 4 == 0.  Output as fp32 (C) and/or as
  * bf16 hi/lo planes (C_hi/C_lo, row stride ldp) for the next GEMM. */
@@ -194,6 +204,29 @@ int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const 
                              int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
                              void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act, int cfg,
                              gridmm_stream_t stream);
+
+/* gridmm_linear_planes with the A rows taken through a batched row map: GEMM row m = row (m % a_rpb) of episode
+ * (m / a_rpb) in a buffer whose episodes lie a_bs elements apart (a_rpb <= 0: plain rows, a_bs ignored; a_bs % 8 == 0).
+ * A sub-sequence of a longer padded sequence is multiplied in place -- the instruction rows of the local encoder's
+ * [map | txt] context (vilmodel.py:846-848), the map-node rows of [cells | nodes] (:843, :872) -- instead of being
+ * gathered by torch.cat / slicing first. */
+int gridmm_linear_planes_map(const void* A_hi, const void* A_lo, int lda, int a_rpb, int64_t a_bs, const void* W_hi,
+                             const void* W_lo, int Kp, const float* bias, const float* residual, int ldr, float* C,
+                             int ldc, void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
+                             gridmm_stream_t stream);
+
+/* Several small plane GEMMs C_i = act_i(A_i W_i^T + b_i) in ONE launch (64x64 tiles, K % 64 == 0): the ClsPrediction
+ * heads at the end of forward('navigation') (vilmodel.py:859-877, 903-905) are 32..1824 rows each.  `problems` is a
+ * [host] array of n_problems <= GRIDMM_MAX_GROUPED records; A rows through the row map of gridmm_linear_planes_map;
+ * act in {NONE, GELU, RELU}; outputs fp32 (C, ldc) and/or bf16 planes (C_hi / C_lo, ldp). */
+#define GRIDMM_MAX_GROUPED 8
+typedef struct {
+  const void *A_hi, *A_lo; int lda; int a_rpb; int64_t a_bs;
+  const void *W_hi, *W_lo; int Kp; const float* bias;
+  float* C; int ldc; void *C_hi, *C_lo; int ldp;
+  int M, N, K, act;
+} gridmm_gemm_problem_t;
+int gridmm_linear_planes_grouped(const gridmm_gemm_problem_t* problems, int n_problems, gridmm_stream_t stream);
 
 /* Multi-head attention core, head_dim 64, fp32 (MFMA f32 16x16x4), online softmax.
  * O[b][i][h*64+d] = sum_j softmax_j(scale * <Q[b,i,h], K[b,j,h]>  over keys with kmask=1) V[b,j,h,d]
@@ -255,8 +288,10 @@ size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I);
 int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
                            const void* KV_hi, const void* KV_lo, int64_t kv_bs, int kv_rs, int k_col, int v_col,
                            const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask, int self_mask_bs,
-                           float* Y, void* Y_hi, void* Y_lo, void* workspace, size_t workspace_bytes, int B, int Sq,
-                           int Sk, int heads, gridmm_stream_t stream);
+                           float* Y, void* Y_hi, void* Y_lo, int y_p_rpb, int64_t y_p_bs, void* workspace,
+                           size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream);
+/* (y_p_rpb > 0: the output PLANES go through the row map of gridmm_layernorm_map -- Sq rows per episode into a buffer
+ * whose episodes are y_p_bs elements apart, e.g. the [map | txt] context of the next encoder; 0: plain [M][H]) */
 
 /* Patch tokens of a vision tower -> grid-memory slab: X (B * n_views, T, D) fp32 token rows, token 0 (class token)
  * dropped; episode b's slot `slab + b * slab_bs` receives n_views * (T-1) rows of D fp16, view-major.  The device-side
@@ -284,6 +319,53 @@ int gridmm_fuse_logits(const float* g_raw, const float* l_raw, const float* grid
                        const int32_t* cand_of_node, const uint8_t* cand_visited,
                        float* global_logits, float* local_logits, float* grid_logits,
                        float* fused_logits, int B, int G, int V, gridmm_stream_t stream);
+
+/* ---- fused row-wise stages of forward('navigation') (launch-count reduction; gridmm_amd/csrc/navfuse.hip) -------------
+ * gridmm_cells_embed = gridmm_cells_compact with grid_pos_embeddings (Linear(K=5, H) + LayerNorm, vilmodel.py:697-700,
+ * 816) evaluated inside: out row p < n_b = proj[src cell] + LN(W_pos pos_fts[src cell] + b_pos) * gamma + beta, rows
+ * [n_b, 196) zero; the key mask as gridmm_cells_compact (quirk included) at row stride mask_bs, followed by n_tail bytes
+ * copied from tail_mask [B][n_tail] (the map-node mask of the [cells | nodes] sequence; NULL to skip).
+ *   W_pos [H][K] f32 row-major (the nn.Linear weight as is), pos_fts [B][196][K] f32 */
+int gridmm_cells_embed(const float* proj, const float* pos_fts, int K, const float* W_pos, const float* b_pos,
+                       const float* gamma, const float* beta, float eps, const uint8_t* occ, float* out,
+                       uint8_t* mask, int mask_bs, const uint8_t* tail_mask, int n_tail, int32_t* n_cells,
+                       int32_t* cmax, int B, int H, int S_pad, gridmm_stream_t stream);
+
+/* Position embeddings of graph nodes / candidate views: out[m] = LN(W pos[m] + b) * gamma + beta (+ add1[m])
+ * (+ table[idx[m]]) for up to two row segments in one launch (vilmodel.py:828-833: gmap_pos_embeddings + image embeds +
+ * step embedding; vp_pos_embeddings + image embeds), fp32 and/or bf16 planes, output rows through a batched row map
+ * (out_rpb rows per episode, episodes out_bs elements apart, row stride H; out_rpb <= 0: plain).  `segs` is a [host] array.
+ * The same launch assembles the byte masks of the two sequences the encoders attend over (vilmodel.py:846-851):
+ *   kv_masks[b][kv_col0 ..] = [gmap_masks[b] (G) | txt_masks[b] (L)]   (row stride kv_bs; NULL to skip)
+ *   q_masks [b]             = [gmap_masks[b] (G) | vp_masks[b] (V)]    (contiguous [B][G+V]; NULL to skip) */
+typedef struct {
+  const float* pos; int K;                       /* [M][K] position features, K <= 16 */
+  const float *W, *bias, *gamma, *beta; float eps; /* nn.Linear(K, H) weight [H][K] + bias, LayerNorm */
+  const float* add1; int ld1;                    /* [M][ld1] or NULL */
+  const float* table; const int64_t* idx;        /* embedding table [.][H] + row index [M], or NULL */
+  float* out; void *out_hi, *out_lo; int out_rpb; int64_t out_bs;
+  int M;
+} gridmm_embed_seg_t;
+int gridmm_node_embed(const gridmm_embed_seg_t* segs, int n_segs, int H, const uint8_t* gmap_masks, int G,
+                      const uint8_t* vp_masks, int V, const uint8_t* txt_masks, int L, uint8_t* kv_masks, int kv_bs,
+                      int kv_col0, uint8_t* q_masks, int B, gridmm_stream_t stream);
+
+/* The tails of the ClsPrediction heads (LayerNorm . w + b0 after Linear + ReLU, vilmodel.py:663-674) for one step, then
+ * gridmm_fuse_logits' masking / fusion (vilmodel.py:859-907), one workgroup per episode:
+ *   h_gl   [B*(G+V)][ld_gl] f32: relu(Linear) of global_sap_head at columns [0,H) (node rows), local_sap_head at [H,2H)
+ *          (view rows), og_head at [2H,3H) (view rows; only read when obj_logits != NULL)
+ *   fuse_a, fuse_b [B][H] f32: the two K-halves of sap_fuse_linear's Linear (gmap[:,0] and vp[:,0] parts, no bias, no
+ *          activation), fuse_bias [H]; NULL -> fusion weight 0.5 (vilmodel.py:864)
+ *   h_grid [B*G][H] f32: relu(Linear) of grid_sap_head over the pre-local-encoder node rows
+ *   tails  [host] 5 records: fuse, global, local, grid, object
+ *   masks / index maps / logit outputs as gridmm_fuse_logits; obj_logits [B][V] masked by vp_obj_masks (or NULL) */
+typedef struct { const float *gamma, *beta; float eps; const float* w; const float* b0; } gridmm_cls_tail_t;
+int gridmm_nav_heads(const float* h_gl, int ld_gl, const float* fuse_a, const float* fuse_b, const float* fuse_bias,
+                     const float* h_grid, const gridmm_cls_tail_t* tails, const uint8_t* gmap_masks,
+                     const uint8_t* gmap_visited, const uint8_t* vp_nav_masks, const uint8_t* vp_obj_masks,
+                     const int32_t* cand_of_node, const uint8_t* cand_visited, float* global_logits,
+                     float* local_logits, float* grid_logits, float* fused_logits, float* obj_logits, int B, int G,
+                     int V, int H, gridmm_stream_t stream);
 
 /* Strided row copy / gather used to assemble [cells | gmap | txt] sequences without torch.cat:
  * dst[b][dst_row0 + i][:] = src[b][i][:] for i < rows.  H floats per row. */
