@@ -54,7 +54,7 @@ SIGNATURES = {
     "gridmm_split_rows_map": [_vp, _i, _vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "gridmm_cells_embed": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_node_embed": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp],
-    "gridmm_nav_heads": [_vp, _i] + [_vp] * 16 + [_i, _i, _i, _i, _vp],
+    "gridmm_nav_heads": [_vp, _i] + [_vp] * 17 + [_i, _i, _i, _i, _vp],
     "gridmm_tokens_to_slab": [_vp, _i, _i, _vp, _i64, _i, _i, _vp],
     "gridmm_ln_dot": [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_fuse_logits": [_vp] * 13 + [_i, _i, _i, _vp],
@@ -100,6 +100,8 @@ def load():
         fn.restype = ctypes.c_int
     lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
     lib.gridmm_grid_aggregate_workspace.restype = ctypes.c_size_t
+    lib.gridmm_nav_heads_workspace.argtypes = [_i, _i, _i]
+    lib.gridmm_nav_heads_workspace.restype = ctypes.c_size_t
     v = lib.gridmm_abi_version()
     if v != ABI_VERSION:
         raise GridmmLibraryError("libgridmm_hip.so ABI %d != expected %d (stale build?)" % (v, ABI_VERSION))

@@ -12,8 +12,17 @@ namespace {
 constexpr int NV = 4;        // float4 per lane: H <= 1024
 constexpr int MAXK = 16;     // position feature widths on this path: 5, 7, 14
 
-// y[c] (c = lane + 64 i) = LN(W f + b) * gamma + beta for one row, one wave; f: K position features (wave-uniform).
-__device__ __forceinline__ void pos_embed_row(const float* __restrict__ f, int K, const float* __restrict__ W,
+// W [H][K] (the nn.Linear weight) -> LDS image W^T [K][H]: one conflict-free ds_read_b128 per lane, k and 4 outputs
+__device__ __forceinline__ void stage_wt(const float* __restrict__ W, int K, int H, float* __restrict__ wT) {
+  for (int i = threadIdx.x; i < K * H; i += blockDim.x) {
+    const int k = i / H, n = i - k * H;
+    wT[i] = W[(size_t)n * K + k];
+  }
+}
+
+// y[c] (c = lane + 64 i) = LN(W f + b) * gamma + beta for one row, one wave; fval: lane k < K holds the row's k-th
+// position feature (broadcast by v_readlane), wT: stage_wt image.
+__device__ __forceinline__ void pos_embed_row(float fval, int K, const float* __restrict__ wT,
                                               const float* __restrict__ bias, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, float eps, int H, int lane, float4* y) {
   const int nv = H >> 2;
@@ -21,20 +30,24 @@ __device__ __forceinline__ void pos_embed_row(const float* __restrict__ f, int K
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < nv) {
-      v = reinterpret_cast<const float4*>(bias)[c];
-      const float* w = W + (size_t)c * 4 * K;
-      for (int k = 0; k < K; ++k) {
-        const float fk = f[k];
-        v.x += fk * w[k];
-        v.y += fk * w[K + k];
-        v.z += fk * w[2 * K + k];
-        v.w += fk * w[3 * K + k];
+    y[i] = (c < nv) ? reinterpret_cast<const float4*>(bias)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int k = 0; k < K; ++k) {
+    const float fk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fval), k));
+    const float4* wr = reinterpret_cast<const float4*>(wT + (size_t)k * H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float4 w = wr[c];
+        y[i].x += fk * w.x; y[i].y += fk * w.y; y[i].z += fk * w.z; y[i].w += fk * w.w;
       }
-      s += (v.x + v.y) + (v.z + v.w);
     }
-    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) s += (y[i].x + y[i].y) + (y[i].z + y[i].w);
   }
   const float mean = wave_sum(s) / (float)H;
   float q = 0.f;
@@ -74,7 +87,9 @@ __global__ __launch_bounds__(256) void cells_embed_kernel(
   __shared__ int s_src[GRIDMM_CELLS];
   __shared__ int s_n, s_tail, s_cmax;
   __shared__ int s_wmax[4];
+  extern __shared__ float s_wT[];   // K * H floats
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  stage_wt(Wp, K, H, s_wT);
   int wmax = 0;
   for (int e = wave; e < B; e += 4) {
     int n = 0;
@@ -139,10 +154,9 @@ __global__ __launch_bounds__(256) void cells_embed_kernel(
     float* orow = ob + (size_t)p * H;
     if (p < n) {
       const int c = s_src[p];
-      float f[MAXK];
-      for (int k = 0; k < K; ++k) f[k] = pos_fts[((size_t)b * GRIDMM_CELLS + c) * K + k];
+      const float fval = lane < K ? pos_fts[((size_t)b * GRIDMM_CELLS + c) * K + lane] : 0.f;
       float4 y[NV];
-      pos_embed_row(f, K, Wp, bp, gamma, beta, eps, H, lane, y);
+      pos_embed_row(fval, K, s_wT, bp, gamma, beta, eps, H, lane, y);
       const float* prow = proj + ((size_t)b * GRIDMM_CELLS + c) * H;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -167,14 +181,17 @@ struct NodeSegs {
   int n;
 };
 
-// one wave per row over the rows of both segments; blocks [0, B) also assemble the byte masks of their episode
-__global__ __launch_bounds__(256) void node_embed_kernel(const NodeSegs segs, int H, const uint8_t* __restrict__ gmap_m,
-                                                         int G, const uint8_t* __restrict__ vp_m, int V,
+// 16 rows of ONE segment per block (4 per wave; the segment's W^T staged in LDS once); blocks [0, B) also assemble the byte
+// masks of their episode
+constexpr int NE_ROWS = 16;
+__global__ __launch_bounds__(256) void node_embed_kernel(const NodeSegs segs, int blocks0, int H,
+                                                         const uint8_t* __restrict__ gmap_m, int G,
+                                                         const uint8_t* __restrict__ vp_m, int V,
                                                          const uint8_t* __restrict__ txt_m, int L,
                                                          uint8_t* __restrict__ kv_masks, int kv_bs, int kv_col0,
                                                          uint8_t* __restrict__ q_masks, int B) {
-  const int lane = threadIdx.x & 63;
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  extern __shared__ float s_wT[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x < B) {
     const int b = blockIdx.x;
     if (kv_masks) {
@@ -186,39 +203,45 @@ __global__ __launch_bounds__(256) void node_embed_kernel(const NodeSegs segs, in
       for (int j = threadIdx.x; j < V; j += blockDim.x) q_masks[(size_t)b * (G + V) + G + j] = vp_m[b * V + j];
     }
   }
-  int si = 0;
-  if (segs.n > 1 && row >= segs.s[0].M) { row -= segs.s[0].M; si = 1; }
+  const int si = ((int)blockIdx.x >= blocks0) ? 1 : 0;
+  if (si >= segs.n) return;
   const gridmm_embed_seg_t& S = segs.s[si];
-  if (row >= S.M) return;
+  const int row0 = ((int)blockIdx.x - (si ? blocks0 : 0)) * NE_ROWS;
+  if (row0 >= S.M) return;
   const int K = S.K, nv = H >> 2;
-  float f[MAXK];
-  for (int k = 0; k < K; ++k) f[k] = S.pos[(size_t)row * K + k];
-  float4 y[NV];
-  pos_embed_row(f, K, S.W, S.bias, S.gamma, S.beta, S.eps, H, lane, y);
-  const float* trow = (S.table && S.idx) ? S.table + (size_t)S.idx[row] * H : nullptr;
-  size_t off = (size_t)row * H;
-  if (S.out_rpb > 0) { const int eb = row / S.out_rpb; off = (size_t)eb * S.out_bs + (size_t)(row - eb * S.out_rpb) * H; }
+  stage_wt(S.W, K, H, s_wT);
+  __syncthreads();
   unsigned short *ohi = (unsigned short*)S.out_hi, *olo = (unsigned short*)S.out_lo;
+  for (int r = wave; r < NE_ROWS; r += 4) {
+    const int row = row0 + r;
+    if (row >= S.M) break;
+    const float fval = lane < K ? S.pos[(size_t)row * K + lane] : 0.f;
+    float4 y[NV];
+    pos_embed_row(fval, K, s_wT, S.bias, S.gamma, S.beta, S.eps, H, lane, y);
+    const float* trow = (S.table && S.idx) ? S.table + (size_t)S.idx[row] * H : nullptr;
+    size_t off = (size_t)row * H;
+    if (S.out_rpb > 0) { const int eb = row / S.out_rpb; off = (size_t)eb * S.out_bs + (size_t)(row - eb * S.out_rpb) * H; }
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      float4 v = y[i];
-      if (S.add1) {
-        const float4 a = reinterpret_cast<const float4*>(S.add1 + (size_t)row * S.ld1)[c];
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-      }
-      if (trow) {
-        const float4 a = reinterpret_cast<const float4*>(trow)[c];
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-      }
-      if (S.out) reinterpret_cast<float4*>(S.out + off)[c] = v;
-      if (ohi) {
-        uint2 hi, lo;
-        split2_bf16(v.x, v.y, hi.x, lo.x);
-        split2_bf16(v.z, v.w, hi.y, lo.y);
-        reinterpret_cast<uint2*>(ohi + off)[c] = hi;
-        reinterpret_cast<uint2*>(olo + off)[c] = lo;
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        float4 v = y[i];
+        if (S.add1) {
+          const float4 a = reinterpret_cast<const float4*>(S.add1 + (size_t)row * S.ld1)[c];
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (trow) {
+          const float4 a = reinterpret_cast<const float4*>(trow)[c];
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (S.out) reinterpret_cast<float4*>(S.out + off)[c] = v;
+        if (ohi) {
+          uint2 hi, lo;
+          split2_bf16(v.x, v.y, hi.x, lo.x);
+          split2_bf16(v.z, v.w, hi.y, lo.y);
+          reinterpret_cast<uint2*>(ohi + off)[c] = hi;
+          reinterpret_cast<uint2*>(olo + off)[c] = lo;
+        }
       }
     }
   }
@@ -274,65 +297,55 @@ __device__ __forceinline__ float ln_dot_row(const float* __restrict__ x, const f
   return wave_sum(d) + (T.b0 ? T.b0[0] : 0.f);
 }
 
-// One workgroup (8 waves) per episode: rows = 1 (fuse) + G (global) + V (local) + G (grid) [+ V (object)], then the
-// masking / fusion of fuse_logits_kernel (rowops.hip) on the values kept in LDS.
-__global__ __launch_bounds__(512) void nav_heads_kernel(
+// Launch 1: one wave per head row over the whole batch -- rows of episode b: 1 (fuse) + G (global) + V (local) + G (grid)
+// [+ V (object)] -> raw[b][.] (workspace).  Launch 2: the masking / fusion of fuse_logits_kernel (rowops.hip) per episode.
+__global__ __launch_bounds__(256) void nav_head_rows_kernel(
     const float* __restrict__ h_gl, int ld_gl, const float* __restrict__ fuse_a, const float* __restrict__ fuse_b,
     const float* __restrict__ fuse_bias, const float* __restrict__ h_grid, const HeadTails tails, int has_obj,
-    const uint8_t* __restrict__ gmap_masks, const uint8_t* __restrict__ gmap_visited,
-    const uint8_t* __restrict__ vp_nav_masks, const uint8_t* __restrict__ vp_obj_masks,
-    const int32_t* __restrict__ cand_of_node, const uint8_t* __restrict__ cand_visited,
-    float* __restrict__ global_logits, float* __restrict__ local_logits, float* __restrict__ grid_logits,
-    float* __restrict__ fused_logits, float* __restrict__ obj_logits, int G, int V, int H) {
-  extern __shared__ float sm[];   // g_raw[G] | l_raw[V] | grid_raw[G] | o_raw[V] | fuse_raw
-  float *s_g = sm, *s_l = sm + G, *s_gr = s_l + V, *s_o = s_gr + G, *s_f = s_o + V;
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int Sq = G + V;
+    float* __restrict__ raw, int B, int G, int V, int H) {
+  const int lane = threadIdx.x & 63;
   const int rows = 1 + G + V + G + (has_obj ? V : 0);
-  for (int r = wave; r < rows; r += nw) {
-    float val;
-    float* dst;
-    if (r == 0) {
-      if (fuse_a) val = ln_dot_row(fuse_a + (size_t)b * H, fuse_b + (size_t)b * H, fuse_bias, tails.t[0], H, lane);
-      else val = 0.f;
-      dst = s_f;
-    } else if (r < 1 + G) {
-      const int j = r - 1;
-      val = ln_dot_row(h_gl + ((size_t)b * Sq + j) * ld_gl, nullptr, nullptr, tails.t[1], H, lane);
-      dst = s_g + j;
-    } else if (r < 1 + G + V) {
-      const int k = r - 1 - G;
-      val = ln_dot_row(h_gl + ((size_t)b * Sq + G + k) * ld_gl + H, nullptr, nullptr, tails.t[2], H, lane);
-      dst = s_l + k;
-    } else if (r < 1 + G + V + G) {
-      const int j = r - 1 - G - V;
-      val = ln_dot_row(h_grid + ((size_t)b * G + j) * H, nullptr, nullptr, tails.t[3], H, lane);
-      dst = s_gr + j;
-    } else {
-      const int k = r - 1 - G - V - G;
-      val = ln_dot_row(h_gl + ((size_t)b * Sq + G + k) * ld_gl + 2 * H, nullptr, nullptr, tails.t[4], H, lane);
-      dst = s_o + k;
-    }
-    if (lane == 0) *dst = val;
+  const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= B * rows) return;
+  const int b = id / rows, r = id - b * rows, Sq = G + V;
+  float val;
+  if (r == 0) {
+    val = fuse_a ? ln_dot_row(fuse_a + (size_t)b * H, fuse_b + (size_t)b * H, fuse_bias, tails.t[0], H, lane) : 0.f;
+  } else if (r < 1 + G) {
+    val = ln_dot_row(h_gl + ((size_t)b * Sq + (r - 1)) * ld_gl, nullptr, nullptr, tails.t[1], H, lane);
+  } else if (r < 1 + G + V) {
+    val = ln_dot_row(h_gl + ((size_t)b * Sq + G + (r - 1 - G)) * ld_gl + H, nullptr, nullptr, tails.t[2], H, lane);
+  } else if (r < 1 + G + V + G) {
+    val = ln_dot_row(h_grid + ((size_t)b * G + (r - 1 - G - V)) * H, nullptr, nullptr, tails.t[3], H, lane);
+  } else {
+    val = ln_dot_row(h_gl + ((size_t)b * Sq + G + (r - 1 - G - V - G)) * ld_gl + 2 * H, nullptr, nullptr, tails.t[4], H, lane);
   }
-  __syncthreads();
+  if (lane == 0) raw[(size_t)b * rows + r] = val;
+}
+
+__global__ __launch_bounds__(64) void nav_fuse_kernel(
+    const float* __restrict__ raw, int has_fuse, int has_obj, const uint8_t* __restrict__ gmap_masks,
+    const uint8_t* __restrict__ gmap_visited, const uint8_t* __restrict__ vp_nav_masks,
+    const uint8_t* __restrict__ vp_obj_masks, const int32_t* __restrict__ cand_of_node,
+    const uint8_t* __restrict__ cand_visited, float* __restrict__ global_logits, float* __restrict__ local_logits,
+    float* __restrict__ grid_logits, float* __restrict__ fused_logits, float* __restrict__ obj_logits, int G, int V) {
+  extern __shared__ float s_l[];   // V masked local logits
+  const int b = blockIdx.x;
+  const int rows = 1 + G + V + G + (has_obj ? V : 0);
+  const float* rb = raw + (size_t)b * rows;
+  const float *r_g = rb + 1, *r_l = r_g + G, *r_gr = r_l + V, *r_o = r_gr + G;
   const float ninf = -__builtin_inff();
-  const float fw = fuse_a ? 1.0f / (1.0f + expf(-s_f[0])) : 0.5f;
+  const float fw = has_fuse ? 1.0f / (1.0f + expf(-rb[0])) : 0.5f;
   for (int k = threadIdx.x; k < V; k += blockDim.x) {
-    float v = s_l[k] * (1.0f - fw);
+    float v = r_l[k] * (1.0f - fw);
     if (!vp_nav_masks[b * V + k]) v = ninf;
+    s_l[k] = v;
     local_logits[b * V + k] = v;
     if (has_obj) {
-      float o = s_o[k];
+      float o = r_o[k];
       if (!vp_obj_masks[b * V + k]) o = ninf;
       obj_logits[b * V + k] = o;
     }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < V; k += blockDim.x) {
-    float v = s_l[k] * (1.0f - fw);
-    if (!vp_nav_masks[b * V + k]) v = ninf;
-    s_l[k] = v;
   }
   __syncthreads();
   float bw = 0.f;   // sum of the local logits of visited candidates, in candidate order (python `bw_logits += ...`)
@@ -340,9 +353,9 @@ __global__ __launch_bounds__(512) void nav_heads_kernel(
     if (cand_visited[b * V + k]) bw += s_l[k];
   for (int j = threadIdx.x; j < G; j += blockDim.x) {
     const bool vis = gmap_visited[b * G + j], valid = gmap_masks[b * G + j];
-    float g = s_g[j] * fw;
+    float g = r_g[j] * fw;
     if (vis || !valid) g = ninf;
-    float gr = s_gr[j];
+    float gr = r_gr[j];
     if (vis || !valid) gr = ninf;
     global_logits[b * G + j] = g;
     grid_logits[b * G + j] = gr;
@@ -366,7 +379,7 @@ extern "C" int gridmm_cells_embed(const float* proj, const float* pos_fts, int K
   if (B <= 0 || H <= 0 || H % 4 || H > 1024 || K <= 0 || K > MAXK || S_pad < GRIDMM_CELLS + (tail_mask ? n_tail : 0) ||
       mask_bs < GRIDMM_CELLS + (tail_mask ? n_tail : 0))
     return GRIDMM_EINVAL;
-  GRIDMM_LAUNCH(cells_embed_kernel, dim3(B, GRIDMM_GRID), dim3(256), 0, as_stream(stream), proj, pos_fts, K, W_pos, b_pos,
+  GRIDMM_LAUNCH(cells_embed_kernel, dim3(B, GRIDMM_GRID), dim3(256), (size_t)K * H * sizeof(float), as_stream(stream), proj, pos_fts, K, W_pos, b_pos,
                 gamma, beta, eps, occ, out, mask, mask_bs, tail_mask, n_tail, n_cells, cmax, B, H, S_pad);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
@@ -390,12 +403,20 @@ extern "C" int gridmm_node_embed(const gridmm_embed_seg_t* segs, int n_segs, int
   if ((kv_masks || q_masks) && (!gmap_masks || G <= 0)) return GRIDMM_EINVAL;
   if (kv_masks && (!txt_masks || kv_bs < kv_col0 + G + L)) return GRIDMM_EINVAL;
   if (q_masks && (!vp_masks || V <= 0)) return GRIDMM_EINVAL;
-  int blocks = (rows + 3) / 4;
+  const int blocks0 = (a.s[0].M + NE_ROWS - 1) / NE_ROWS;
+  int blocks = blocks0 + (n_segs > 1 ? (a.s[1].M + NE_ROWS - 1) / NE_ROWS : 0), maxk = a.s[0].K;
+  if (n_segs > 1 && a.s[1].K > maxk) maxk = a.s[1].K;
   if ((kv_masks || q_masks) && blocks < B) blocks = B;
-  GRIDMM_LAUNCH(node_embed_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a, H, gmap_masks, G, vp_masks, V,
-                txt_masks, L, kv_masks, kv_bs, kv_col0, q_masks, (kv_masks || q_masks) ? B : 0);
+  (void)rows;
+  GRIDMM_LAUNCH(node_embed_kernel, dim3(blocks), dim3(256), (size_t)maxk * H * sizeof(float), as_stream(stream), a, blocks0,
+                H, gmap_masks, G, vp_masks, V, txt_masks, L, kv_masks, kv_bs, kv_col0, q_masks,
+                (kv_masks || q_masks) ? B : 0);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
+}
+
+extern "C" size_t gridmm_nav_heads_workspace(int B, int G, int V) {
+  return (size_t)B * (1 + 2 * G + 2 * V) * sizeof(float);
 }
 
 extern "C" int gridmm_nav_heads(const float* h_gl, int ld_gl, const float* fuse_a, const float* fuse_b,
@@ -403,18 +424,23 @@ extern "C" int gridmm_nav_heads(const float* h_gl, int ld_gl, const float* fuse_
                                 const uint8_t* gmap_masks, const uint8_t* gmap_visited, const uint8_t* vp_nav_masks,
                                 const uint8_t* vp_obj_masks, const int32_t* cand_of_node, const uint8_t* cand_visited,
                                 float* global_logits, float* local_logits, float* grid_logits, float* fused_logits,
-                                float* obj_logits, int B, int G, int V, int H, gridmm_stream_t stream) {
-  if (!h_gl || !h_grid || !tails || B <= 0 || G <= 0 || V <= 0 || G + V > 2048 || H <= 0 || H % 4 || H > 1024 || ld_gl % 4)
+                                float* obj_logits, void* workspace, int B, int G, int V, int H, gridmm_stream_t stream) {
+  if (!h_gl || !h_grid || !tails || !workspace || B <= 0 || G <= 0 || V <= 0 || V > 4096 || H <= 0 || H % 4 || H > 1024 ||
+      ld_gl % 4)
     return GRIDMM_EINVAL;
   if ((fuse_a && (!fuse_b || !fuse_bias)) || (obj_logits && !vp_obj_masks)) return GRIDMM_EINVAL;
   const int has_obj = obj_logits ? 1 : 0;
   if (ld_gl < (2 + has_obj) * H) return GRIDMM_EINVAL;
   HeadTails t;
   for (int i = 0; i < 5; ++i) t.t[i] = tails[i < 4 || has_obj ? i : 3];
-  const size_t lds = (size_t)(2 * G + 2 * V + 1) * sizeof(float);
-  GRIDMM_LAUNCH(nav_heads_kernel, dim3(B), dim3(512), lds, as_stream(stream), h_gl, ld_gl, fuse_a, fuse_b, fuse_bias,
-                h_grid, t, has_obj, gmap_masks, gmap_visited, vp_nav_masks, vp_obj_masks, cand_of_node, cand_visited,
-                global_logits, local_logits, grid_logits, fused_logits, obj_logits, G, V, H);
+  const int rows = 1 + G + V + G + (has_obj ? V : 0);
+  float* raw = (float*)workspace;
+  GRIDMM_LAUNCH(nav_head_rows_kernel, dim3((B * rows + 3) / 4), dim3(256), 0, as_stream(stream), h_gl, ld_gl, fuse_a, fuse_b,
+                fuse_bias, h_grid, t, has_obj, raw, B, G, V, H);
+  GRIDMM_CHECK_LAUNCH();
+  GRIDMM_LAUNCH(nav_fuse_kernel, dim3(B), dim3(64), (size_t)V * sizeof(float), as_stream(stream), raw, fuse_a ? 1 : 0,
+                has_obj, gmap_masks, gmap_visited, vp_nav_masks, vp_obj_masks, cand_of_node, cand_visited, global_logits,
+                local_logits, grid_logits, fused_logits, obj_logits, G, V);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

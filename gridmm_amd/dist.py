@@ -65,27 +65,47 @@ class GradientReducer:
     Replaces DistributedDataParallel(find_unused_parameters=True) of the reference (fine-tune:
     map_nav_src/r2r/agent_base.py:115-117; pre-training: pretrain_src/utils/misc.py:52-65,
     train_r2r.py:256-258) with explicit, few and large collectives:
-      * PERSISTENT flat fp32 buckets of `bucket_mb` (default 128 MiB: xGMI is point-to-point, a ring all-reduce is
-        per-link bound, so few large transfers beat many 25 MiB DDP buckets; ~645 MB of fp32 gradients for the
-        161 M-parameter model = 5 buckets), filled in reverse parameter order -- the order backward produces them;
-      * a post-accumulate hook per parameter copies the finished gradient into its bucket slot (the only copy: fp32
-        parameters then keep the slot as their .grad, so the reduced values need no copy back) and, once every
-        gradient the bucket expects has arrived, launches the bucket's asynchronous all-reduce WHILE backward is
-        still running;
-      * `find_unused_parameters` semantics without a per-step host sync: which parameters receive a gradient depends
-        only on the code path (the pre-training task), so the used-set of a step is compared across ranks the first
-        time it is seen (one small all-reduce + .cpu()) and trusted afterwards; `expect(key)` tells the reducer which
-        used-set the coming backward will produce (e.g. the task name), which is what lets buckets launch early.
-        A parameter unused on every rank keeps grad None, so the optimizer skips it exactly as it does
-        single-process; one unused here but used elsewhere contributes zeros.
+      * PERSISTENT flat fp32 buckets of `bucket_mb` (default 128 MiB; ~645 MB of fp32 gradients for the 161 M-parameter
+        model = 5 buckets), filled in reverse parameter order -- the order backward produces them.  A post-accumulate
+        hook per parameter copies the finished gradient into its bucket slot (the only copy: fp32 parameters then keep
+        the slot as their .grad) and, once every gradient this rank expects in the bucket has arrived, launches the
+        bucket's exchange WHILE backward is still running, on a side stream.
+      * `algo`: how a bucket travels.  "ring" = one all_reduce (RCCL ring: per-link bound on point-to-point xGMI);
+        "rsag" = reduce_scatter_tensor + all_gather_into_tensor; "direct" = every rank sends shard j straight to rank j
+        (all_to_all_single: all 7 xGMI links busy at once), sums the world shards it received in fp32 in a fixed order
+        (deterministic), and the reduced shards travel back the same way -- the direct reduce-scatter / all-gather of
+        SURVEY.md §8e.  "auto" = "direct" on RCCL with world > 2, "ring" otherwise (gloo has no reduce_scatter).
+      * `payload`: "fp32", or "bf16" -- gradients rounded to bf16 on the wire (half the bytes); with algo "direct" the
+        sum itself stays fp32 (inputs and the reduced shard are rounded once each).
+      * COLLECTIVE ORDER IS RANK-INDEPENDENT BY CONSTRUCTION: buckets are launched strictly in bucket order (an early
+        launch of bucket k waits for buckets < k), and which buckets are launched for a code path (`expect(key)`, e.g.
+        the pre-training task) is the UNION of the used-sets of all ranks, agreed through a host-side control group (gloo;
+        a few bytes per step, no device synchronisation).  `find_unused_parameters` semantics: the first step of a key
+        exchanges the used vectors (control group) and launches after backward; later steps launch during backward from
+        the remembered (local used-set, union) pair and exchange ONE flag; a rank whose backward deviates (a gradient
+        arriving after its bucket left, or outside the union) raises the flag and all ranks run a repair round (used /
+        late vectors over the control group, one extra data collective for the stragglers).  Ranks that use different
+        parameter subsets for the same key (rank 0 head_a, rank 1 head_b) are the normal case of that scheme, not an error.
+        A parameter unused on every rank keeps grad None, so the optimizer skips it exactly as it does single-process.
     World size 1 (or no process group): no-op.
     """
 
-    def __init__(self, params, bucket_mb=128, overlap=True):
+    def __init__(self, params, bucket_mb=128, overlap=True, algo="auto", payload="fp32"):
         self.params = [p for p in params if p.requires_grad]
         self.overlap = overlap
+        self.world = dist.get_world_size() if is_dist() else 1
+        backend = dist.get_backend() if is_dist() else None
+        if algo == "auto":
+            algo = "direct" if (backend == "nccl" and self.world > 2) else "ring"
+        if algo == "rsag" and backend != "nccl":
+            algo = "ring"                                # gloo: no reduce_scatter
+        assert algo in ("ring", "rsag", "direct") and payload in ("fp32", "bf16")
+        self.algo, self.payload = algo, payload
+        self._ctl = None
+        if is_dist():                                    # control plane: CPU tensors over gloo (collective call: every rank builds a reducer)
+            self._ctl = dist.group.WORLD if backend == "gloo" else dist.new_group(backend="gloo")
         limit = max(1, int(bucket_mb * (1 << 20) // 4))
-        self.buckets, self.slot = [], {}                 # bucket: dict(idx, numel, flat, work, pending); slot[i] = (b, off)
+        self.buckets, self.slot = [], {}                 # slot[i] = (bucket, offset)
         cur, n = [], 0
         for i in reversed(range(len(self.params))):
             k = self.params[i].numel()
@@ -98,18 +118,22 @@ class GradientReducer:
         if cur:
             self.buckets.append(dict(idx=cur, numel=n))
         for b in self.buckets:
-            b.update(flat=None, work=None, pending=None)
+            w = max(self.world, 1)
+            b.update(flat=None, work=None, pending=None, padded=-(-b["numel"] // (w * 64)) * (w * 64), wire=None, recv=None,
+                     shard=None)
         self._ready = [False] * len(self.params)
         self._late = []
-        self._verified = set()                           # used-sets already compared across ranks
-        self._sig_by_key, self._key, self._expected = {}, None, None
+        self._known = {}                                 # key -> (local used tuple, union used tuple)
+        self._key, self._early, self._next, self._launch_set = None, False, 0, None
+        self._comm = None                                # side stream of the exchange (cuda only)
         self._hook_fns = [self._make_hook(i) for i in range(len(self.params))]
         self._hooks = [p.register_post_accumulate_grad_hook(f) for p, f in zip(self.params, self._hook_fns)]
+        self.stats = {"launched_early": 0, "launched_late": 0, "repairs": 0}
 
     # ---- bucket plumbing
     def _flat(self, b):
         if b["flat"] is None:
-            b["flat"] = torch.zeros(b["numel"], dtype=torch.float32, device=self.params[b["idx"][0]].device)
+            b["flat"] = torch.zeros(b["padded"], dtype=torch.float32, device=self.params[b["idx"][0]].device)
         return b["flat"]
 
     def _view(self, i):
@@ -117,11 +141,68 @@ class GradientReducer:
         p = self.params[i]
         return self._flat(self.buckets[bi])[off:off + p.numel()].view(p.shape)
 
-    def _launch(self, b):
+    def _exchange(self, flat, b=None):
+        """SUM of `flat` over ranks, in place (flat.numel() % world == 0 for the sharded algorithms)."""
+        world, wire_dt = self.world, (torch.bfloat16 if self.payload == "bf16" else torch.float32)
+        n = flat.numel()
+        if self.algo == "ring" or n % world:
+            if wire_dt == torch.float32:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            else:
+                w = flat.to(wire_dt)
+                dist.all_reduce(w, op=dist.ReduceOp.SUM)
+                flat.copy_(w)
+            return
+        keep = b if b is not None else {}
+        wire = flat
+        if wire_dt != torch.float32:
+            if keep.get("wire") is None:
+                keep["wire"] = torch.empty(n, dtype=wire_dt, device=flat.device)
+            wire = keep["wire"]
+            wire.copy_(flat)
+        sh = n // world
+        if self.algo == "rsag":
+            if keep.get("shard") is None:
+                keep["shard"] = torch.empty(sh, dtype=wire_dt, device=flat.device)
+            dist.reduce_scatter_tensor(keep["shard"], wire, op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(wire, keep["shard"])
+        else:                                            # direct: shard j -> rank j, ordered fp32 sum, reduced shards back
+            if keep.get("recv") is None:
+                keep["recv"] = torch.empty(n, dtype=wire_dt, device=flat.device)
+            recv = keep["recv"]
+            dist.all_to_all_single(recv, wire)
+            mine = recv.view(world, sh).sum(0, dtype=torch.float32)       # rank order: deterministic
+            recv.view(world, sh).copy_(mine.to(wire_dt).unsqueeze(0).expand(world, sh))
+            dist.all_to_all_single(wire, recv)
+        if wire is not flat:
+            flat.copy_(wire)
+
+    def _launch(self, b, early):
         for i in b["idx"]:                               # slots nobody filled this step must not carry last step's values
             if not self._ready[i]:
                 self._view(i).zero_()
-        b["work"] = dist.all_reduce(self._flat(b), op=dist.ReduceOp.SUM, async_op=True)
+        flat = self._flat(b)
+        if flat.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=flat.device)
+            self._comm.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self._comm):
+                self._exchange(flat, b)
+        else:
+            self._exchange(flat, b)
+        b["work"] = True
+        self.stats["launched_early" if early else "launched_late"] += 1
+
+    def _advance(self, early=True):
+        """Launch, strictly in bucket order, every bucket of the launch set whose locally expected gradients are all in."""
+        nb = len(self.buckets)
+        while self._next < nb:
+            b = self.buckets[self._next]
+            if self._launch_set[self._next]:
+                if early and b["pending"]:
+                    return
+                self._launch(b, early)
+            self._next += 1
 
     def _make_hook(self, i):
         def hook(p):
@@ -129,7 +210,7 @@ class GradientReducer:
                 return
             bi, _ = self.slot[i]
             b = self.buckets[bi]
-            if b["work"] is not None:                    # the prediction said "unused": reduced separately in reduce()
+            if b["work"] is not None:                    # its bucket has left: repaired in reduce()
                 self._late.append(i)
                 return
             v = self._view(i)
@@ -137,68 +218,101 @@ class GradientReducer:
             if p.dtype == torch.float32:
                 p.grad = v                               # gradient IS the bucket slot from here on
             self._ready[i] = True
-            if b["pending"] is not None:
+            if self._early:
                 b["pending"].discard(i)
-                if not b["pending"]:
-                    self._launch(b)
+                self._advance(True)
         return hook
 
     def expect(self, key, final=True):
-        """Announce the code path of the coming backward (any hashable, e.g. the pre-training task).  Steps with a key
-        whose used-set is already known launch their buckets during backward.  final=False: a gradient-accumulation
+        """Announce the code path of the coming backward (any hashable, e.g. the pre-training task; the SAME on every
+        rank).  Steps with a known key launch their buckets during backward.  final=False: a gradient-accumulation
         micro-step that is NOT followed by reduce() -- gradients keep accumulating in the slots, nothing is launched."""
         self._key = key
-        sig = self._sig_by_key.get(key)
-        self._expected = sig
-        early = sig is not None and self.overlap and final
-        for b in self.buckets:
-            b["pending"] = ({i for i in b["idx"] if sig[i] and not self._ready[i]} or None) if early else None
+        known = self._known.get(key) if key is not None else None
+        self._early = bool(known is not None and self.overlap and final and is_dist())
+        self._next = 0
+        if known is not None:
+            local, union = known
+            self._launch_set = [any(union[i] for i in b["idx"]) for b in self.buckets]
+            for b in self.buckets:
+                b["pending"] = {i for i in b["idx"] if local[i] and not self._ready[i]}
+        else:
+            self._launch_set = None
+
+    def _ctl_sum(self, ints):
+        t = torch.tensor(ints, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._ctl)
+        return t.tolist()
 
     def reduce(self):
         """Call after backward: finishes the exchange; parameters' .grad then hold the mean over ranks."""
         if not is_dist() or not self.params:
             return
-        world = dist.get_world_size()
+        world, n = self.world, len(self.params)
         for i, p in enumerate(self.params):              # gradients produced before the hooks existed / outside autograd
             if p.grad is not None and not self._ready[i] and i not in self._late:
                 self._hook_fns[i](p)
-        sig = tuple(self._ready[i] or (i in self._late) for i in range(len(self.params)))
-        union = sig
-        if sig not in self._verified:
+        self._early = False
+        late_set = set(self._late)
+        sig = tuple(self._ready[i] or (i in late_set) for i in range(n))
+        known = self._known.get(self._key) if self._key is not None else None
+        late_counts = None
+        if known is not None:                            # launch set agreed on an earlier step of this key
+            union = known[1]
+            self._advance(False)                         # whatever backward did not launch, in order
+            stray = [i for i in range(n) if self._ready[i] and not self._launch_set[self.slot[i][0]]]
+            flag = 1 if (self._late or stray or sig != known[0]) else 0   # any deviation from the remembered path
+            if self._ctl_sum([flag])[0] > 0:             # somebody deviated from the remembered path: repair round
+                self.stats["repairs"] += 1
+                mine_late = [int(i in late_set or i in stray) for i in range(n)]
+                tot = self._ctl_sum([int(u) for u in sig] + mine_late)
+                union = tuple(c > 0 for c in tot[:n])
+                late_counts = tot[n:]
+        else:                                            # first step of this key: agree on the union, then launch in order
+            union = tuple(c > 0 for c in self._ctl_sum([int(u) for u in sig]))
+            self._launch_set = [any(union[i] for i in b["idx"]) for b in self.buckets]
+            self._next = 0
+            self._advance(False)
+        fix = None
+        if late_counts is not None and any(c > 0 for c in late_counts):
+            # stragglers: gradients that (on some rank) missed their bucket (late) or sit in a bucket outside the launch
+            # set (stray).  Every rank contributes its own late / stray gradient (zeros otherwise) to ONE extra collective;
+            # the bucket part of such a parameter -- the on-time ranks' sum -- is added below.
+            fix_idx = [i for i in range(n) if late_counts[i] > 0]
+            mine = late_set | set(stray)
             dev = self.params[0].device
-            used = torch.tensor([int(u) for u in sig], dtype=torch.int32, device=dev)
-            dist.all_reduce(used, op=dist.ReduceOp.SUM)
-            counts = used.cpu().tolist()
-            union = tuple(c > 0 for c in counts)
-            if all(c in (0, world) for c in counts):
-                self._verified.add(sig)                  # every rank took the same path: no exchange next time
-        for b in self.buckets:
-            if b["work"] is None and any(union[i] for i in b["idx"]):
-                self._launch(b)
-        late = None
-        if self._late:                                   # mispredicted parameters: one extra small all-reduce
-            late = torch.cat([self.params[i].grad.reshape(-1).float() for i in self._late])
-            dist.all_reduce(late, op=dist.ReduceOp.SUM)
+            parts = [(self.params[i].grad.reshape(-1).float().clone() if i in mine else
+                      torch.zeros(self.params[i].numel(), dtype=torch.float32, device=dev)) for i in fix_idx]
+            fix = torch.cat(parts)
+            keep = (self.algo, self.payload)
+            self.algo, self.payload = "ring", "fp32"
+            self._exchange(fix)
+            self.algo, self.payload = keep
+        if self._comm is not None:
+            torch.cuda.current_stream(self.params[0].device).wait_stream(self._comm)
         for b in self.buckets:
             if b["work"] is not None:
-                b["work"].wait()
                 b["flat"].div_(world)
-        o = 0
-        for i in self._late:
-            p = self.params[i]
-            p.grad = (late[o:o + p.numel()] / world).view_as(p).to(p.dtype)
-            o += p.numel()
+        if fix is not None:
+            o = 0
+            for i in fix_idx:
+                p = self.params[i]
+                total = (fix[o:o + p.numel()] / world).view_as(p)
+                o += p.numel()
+                if self.buckets[self.slot[i][0]]["work"] is not None:
+                    total = total + self._view(i)        # what the on-time ranks put into the bucket (already / world)
+                self._view(i).copy_(total)
+                self._ready[i] = False                   # -> p.grad is (re)pointed at the slot below
         for i, p in enumerate(self.params):
-            if i in self._late:
-                continue
             if not union[i]:
                 p.grad = None                            # unused on every rank: the optimizer skips it
             elif p.dtype != torch.float32:
                 p.grad = self._view(i).to(p.dtype)
             elif not self._ready[i]:
-                p.grad = self._view(i)                   # unused here, used elsewhere: the others' mean contribution
-        self._sig_by_key[self._key] = union
-        self._ready = [False] * len(self.params)
+                p.grad = self._view(i)                   # unused here, used elsewhere (or repaired): the slot holds the mean
+        if self._key is not None:
+            self._known[self._key] = (sig, union)
+        self._ready = [False] * n
         self._late = []
         for b in self.buckets:
             b["work"], b["pending"] = None, None

@@ -550,10 +550,11 @@ def nav_heads(h_gl, fuse_a, fuse_b, fuse_bias, h_grid, tails, gmap_masks, gmap_v
     if fuse_a is None:
         t[0] = tails[1]
     arr = (_CClsTail * 5)(*t)
+    ws = torch.empty(int(lib.gridmm_nav_heads_workspace(B, G, V)), dtype=torch.uint8, device=dev)
     _timed("nav_heads", 0.0, lambda: _lib.check(lib.gridmm_nav_heads(
         _p(h_gl), h_gl.shape[-1], _p(fuse_a), _p(fuse_b), _p(fuse_bias), _p(h_grid), arr, _p(gmap_masks), _p(gmap_visited),
         _p(vp_nav_masks), _p(vp_obj_masks), _p(cand_of_node), _p(cand_visited), _p(outs[0]), _p(outs[1]), _p(outs[2]),
-        _p(outs[3]), _p(obj), B, G, V, H, _stream()), "gridmm_nav_heads"))
+        _p(outs[3]), _p(obj), _p(ws), B, G, V, H, _stream()), "gridmm_nav_heads"))
     return outs[0], outs[1], outs[2], outs[3], obj
 
 

@@ -351,7 +351,8 @@ int gridmm_node_embed(const gridmm_embed_seg_t* segs, int n_segs, int H, const u
                       int kv_col0, uint8_t* q_masks, int B, gridmm_stream_t stream);
 
 /* The tails of the ClsPrediction heads (LayerNorm . w + b0 after Linear + ReLU, vilmodel.py:663-674) for one step, then
- * gridmm_fuse_logits' masking / fusion (vilmodel.py:859-907), one workgroup per episode:
+ * gridmm_fuse_logits' masking / fusion (vilmodel.py:859-907): one wave per head row over the batch, then one workgroup
+ * per episode (two launches; the raw head outputs pass through `workspace`, gridmm_nav_heads_workspace bytes):
  *   h_gl   [B*(G+V)][ld_gl] f32: relu(Linear) of global_sap_head at columns [0,H) (node rows), local_sap_head at [H,2H)
  *          (view rows), og_head at [2H,3H) (view rows; only read when obj_logits != NULL)
  *   fuse_a, fuse_b [B][H] f32: the two K-halves of sap_fuse_linear's Linear (gmap[:,0] and vp[:,0] parts, no bias, no
@@ -360,12 +361,13 @@ int gridmm_node_embed(const gridmm_embed_seg_t* segs, int n_segs, int H, const u
  *   tails  [host] 5 records: fuse, global, local, grid, object
  *   masks / index maps / logit outputs as gridmm_fuse_logits; obj_logits [B][V] masked by vp_obj_masks (or NULL) */
 typedef struct { const float *gamma, *beta; float eps; const float* w; const float* b0; } gridmm_cls_tail_t;
+size_t gridmm_nav_heads_workspace(int B, int G, int V);
 int gridmm_nav_heads(const float* h_gl, int ld_gl, const float* fuse_a, const float* fuse_b, const float* fuse_bias,
                      const float* h_grid, const gridmm_cls_tail_t* tails, const uint8_t* gmap_masks,
                      const uint8_t* gmap_visited, const uint8_t* vp_nav_masks, const uint8_t* vp_obj_masks,
                      const int32_t* cand_of_node, const uint8_t* cand_visited, float* global_logits,
-                     float* local_logits, float* grid_logits, float* fused_logits, float* obj_logits, int B, int G,
-                     int V, int H, gridmm_stream_t stream);
+                     float* local_logits, float* grid_logits, float* fused_logits, float* obj_logits, void* workspace,
+                     int B, int G, int V, int H, gridmm_stream_t stream);
 
 /* Strided row copy / gather used to assemble [cells | gmap | txt] sequences without torch.cat:
  * dst[b][dst_row0 + i][:] = src[b][i][:] for i < rows.  H floats per row. */
