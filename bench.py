@@ -53,26 +53,31 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(args, dev, mem_steps=None, device_feats=False):
+def build_workload(args, dev, mem_steps=None, device_feats=False, depth_mode="uniform", buckets=None, batch_size=None,
+                   with_obj=False, n_obj=0):
     """mem_steps overrides args.mem_steps (the extra t = 5 / 15 legs); device_feats fills the slab with N(0,1) drawn on
-    the GPU instead of the host-generated features (no oracle leg runs on those workloads)."""
+    the GPU instead of the host-generated features (no oracle leg runs on those workloads).  depth_mode / buckets: the
+    sparse-map leg (synthetic.make_observations "ring", graph.GraphedNavStep buckets); batch_size / with_obj / n_obj:
+    configs 1 and 4 (B = 1 latency, REVERIE object tokens)."""
     from gridmm_amd import synthetic as S
     from gridmm_amd.grid_memory import GridMemoryBatch
     from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
 
     geom = S.BASELINE if args.shape == "baseline" else S.NATIVE
     torch.manual_seed(0)
-    model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim)).eval()
+    model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim, obj_feat_size=768 if with_obj else 0)).eval()
     # BERT-style random init leaves LayerNorm at (1, 0); fine for timing
     model.to(dev)
     rs = np.random.RandomState(int(os.environ.get("RANK", "0")))
-    B, t = args.batch, (args.mem_steps if mem_steps is None else mem_steps)
-    host_batch = S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, min_len=30)
+    B, t = (batch_size or args.batch), (args.mem_steps if mem_steps is None else mem_steps)
+    host_batch = S.make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37 + n_obj, n_cand=4, min_len=30, with_obj=with_obj,
+                                  **({"n_obj": n_obj} if with_obj else {}))
     batch = S.batch_to(host_batch, dev)
     # what a caller has on the host each step for the fused-logit index maps (vilmodel.py:881-899)
     fusion_src = (host_batch["gmap_vpids"], host_batch["gmap_visited_masks"].numpy(), host_batch["vp_cand_vpids"])
     mem = GridMemoryBatch(B, geom, max_steps=t, device=dev)
-    eps = [S.make_observations(rs, geom, t, with_feats=not device_feats) for _ in range(B)]
+    okw = dict(depth_mode=depth_mode, inner_frac=0.004) if depth_mode != "uniform" else {}
+    eps = [S.make_observations(rs, geom, t, with_feats=not device_feats, **okw) for _ in range(B)]
     n_new = geom.pts_per_obs
     depth = [torch.from_numpy(np.stack([e[k]["depth"].reshape(-1) for e in eps])).to(dev) for k in range(t)]
     # tokens are written into the slab once, before timing (zero-copy append: producer-owned slot)
@@ -102,11 +107,14 @@ def build_workload(args, dev, mem_steps=None, device_feats=False):
     if not args.eager:
         from gridmm_amd.graph import GraphedNavStep
         eager_step()                            # packs the weights, fills the allocator
-        g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore)
+        g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore, buckets=buckets)
         mem.n_pts_host[:] = n_host0 + n_new
+        if buckets:
+            g(poses[t - 1], heads[t - 1], fusion=fusion_src, check=True)     # settles the bucket prediction
 
         def step():   # host half (pose / heading floats, fused-logit index maps) + one graph replay
-            return g(poses[t - 1], heads[t - 1], fusion=fusion_src)
+            return g(poses[t - 1], heads[t - 1], fusion=fusion_src, check=False)
+        step.graph = g
     return model, batch, mem, eps, step, eager_step, geom
 
 
@@ -158,6 +166,77 @@ def extra_depth_leg(args, dev, dist, mem_steps, steps):
     del model, batch, mem, step, eager_step
     torch.cuda.empty_cache()
     return dt / steps
+
+
+def sparse_map_leg(args, dev, dist, steps):
+    """Varlen map sequences (vilmodel.py:809-823 max_cell_num): the headline step on episodes whose depth occupies ~90-120
+    of the 196 cells (synthetic 'ring' depth), once on the 196-row padded sequence and once with the bucketed back graphs."""
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT
+    res = {}
+    for name, buckets in (("padded_196", None), ("bucketed", GlocalTextPathNavCMT.DEFAULT_BUCKETS)):
+        model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev, device_feats=True, depth_mode="ring",
+                                                                        buckets=buckets)
+        dt = time_steps(step, steps, 2, dist) / steps
+        res[name] = {"ms_per_step": 1e3 * dt, "value": args.batch / dt}
+        if buckets:
+            g = step.graph
+            cmax = int(g.cmax[g.last_bucket].item())
+            if cmax > g.last_bucket:
+                raise SystemExit("bench.py: sparse-map leg ran on bucket %d with %d occupied cells" % (g.last_bucket, cmax))
+            res[name].update(bucket=g.last_bucket, cmax=cmax, buckets=list(buckets))
+            a = {k: v.clone() for k, v in step().items() if k in LOGIT_KEYS}
+            torch.cuda.synchronize()
+            b = eager_step()                       # the 196-row eager path on the same inputs
+            worst = 0.0
+            for k in LOGIT_KEYS:
+                f = torch.isfinite(b[k])
+                if not torch.equal(f, torch.isfinite(a[k])):
+                    raise SystemExit("bench.py: bucketed %s masks differ from the padded path" % k)
+                worst = max(worst, float((a[k][f] - b[k][f]).abs().max()))
+            if worst > 1e-4:
+                raise SystemExit("bench.py: bucketed logits differ from the padded path by %.3g" % worst)
+            res[name]["max_abs_vs_padded"] = worst
+        del model, batch, mem, step, eager_step
+        torch.cuda.empty_cache()
+    res["speedup"] = res["padded_196"]["ms_per_step"] / res["bucketed"]["ms_per_step"]
+    res["workload"] = "the headline step on 'ring' depth (walls at ~3 m + 0.4 % nearer points): ~90-120 occupied cells"
+    return res
+
+
+def config_legs(args, dev, steps):
+    """BASELINE.json configs[0] and configs[3] at their stated sizes, same step, full-size model:
+    b1_latency: B = 1 episode (the val_unseen plumbing config): wall time of ONE step incl. its host half, a device
+                synchronize after every step (latency, not throughput);
+    reverie_b16: B = 16, 36 views + 21 object tokens (V1 = 58), obj_logits from og_head (map_nav_src/reverie/env.py:263-372,
+                vilmodel.py:745-764, 903-907)."""
+    res = {}
+    model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev, device_feats=True, batch_size=1)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(max(steps, 20)):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
+    res["b1_latency"] = {"latency_ms_median": 1e3 * lat[len(lat) // 2], "latency_ms_min": 1e3 * lat[0], "batch": 1,
+                         "steps_per_s": 1.0 / lat[len(lat) // 2], "replay_check": check_replay(step, eager_step)}
+    del model, batch, mem, step, eager_step
+    torch.cuda.empty_cache()
+    model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev, device_feats=True, batch_size=16,
+                                                                    with_obj=True, n_obj=21)
+    dt = time_steps(step, steps, 2, None) / steps
+    out = step()
+    torch.cuda.synchronize()
+    obj = out["obj_logits"]
+    assert obj is not None and obj.shape == (16, 58) and bool(torch.isfinite(obj).any())
+    res["reverie_b16"] = {"value": 16 / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt, "batch": 16, "V1": 58, "object_tokens": 21,
+                          "replay_check": check_replay(step, eager_step)}
+    del model, batch, mem, step, eager_step
+    torch.cuda.empty_cache()
+    return res
 
 
 def producer_leg(args, dev, steps=5):
@@ -212,65 +291,152 @@ def producer_leg(args, dev, steps=5):
                         "forward('navigation'), t=1, full-size model and tower, random init" % B}
 
 
-def train_leg(args, dev, steps=6):
-    """Secondary: one pre-training step (config 3's per-GPU shape) -- forward + backward + gradient clip + fused AdamW
-    of the full-size GlocalTextPathCMTPreTraining, B = 32, native grid memory of 3-5 observations, tasks cycling
-    mlm / mrc / sap as the task-mixed loop does (pretrain_src/train_r2r.py:231-303).  Timed twice: launched eagerly from
-    Python, and as one hipGraph per task (gridmm_amd/train_graph.py: same kernels, same updates; lr schedule, AdamW bias
-    correction and dropout seeds advance per replay)."""
+def _init_dist(dev):
+    """(dist module or None, rank, world): RCCL ("nccl") process group, or gloo when N ranks share one GPU (test hook)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        return None, 0, 1
+    import torch.distributed as dist
+    if os.environ.get("GRIDMM_BENCH_SHARE_GPU"):
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
+    return dist, rank, world
+
+
+def _timed_loop(fn, n, dist):
+    """Seconds per call of fn over n calls, bracketed by barrier + device synchronize, MAX over ranks."""
+    from gridmm_amd.dist import max_over_ranks
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    return max_over_ranks(time.perf_counter() - t0) / n
+
+
+def exchange_sweep(reducer, dev, dist, iters=5):
+    """The gradient exchange alone (same bucket sizes as the training step), per algorithm and payload: ms per step's
+    worth of gradients, max over ranks.  Evidence for SURVEY 8e's ring vs direct reduce-scatter / all-gather estimate."""
+    res = {}
+    share = bool(os.environ.get("GRIDMM_BENCH_SHARE_GPU"))
+    flats = [torch.randn(b["padded"], device=dev) * 1e-3 for b in reducer.buckets]
+    keep = (reducer.algo, reducer.payload)
+    for algo in ("ring", "direct") if share else ("ring", "rsag", "direct"):
+        for payload in ("fp32", "bf16"):
+            reducer.algo, reducer.payload = algo, payload
+            scratch = [dict() for _ in flats]
+
+            def once(_):
+                for f, k in zip(flats, scratch):
+                    reducer._exchange(f, k)
+            once(0)
+            res["%s_%s" % (algo, payload)] = 1e3 * _timed_loop(once, iters, dist)
+    reducer.algo, reducer.payload = keep
+    return res
+
+
+def train_leg(args, dev, steps=None):
+    """One pre-training step (config 3's per-GPU shape) -- forward + backward + [gradient exchange] + gradient clip + fused
+    AdamW of the full-size GlocalTextPathCMTPreTraining, B = 32 per rank, native grid memory of 3-5 observations, tasks
+    cycling mlm / mrc / sap as the task-mixed loop does (pretrain_src/train_r2r.py:231-303).  Timed launched eagerly from
+    Python and as one hipGraph per task (gridmm_amd/train_graph.py: same kernels, same updates; lr schedule, AdamW bias
+    correction and dropout seeds advance per replay).  With WORLD_SIZE > 1 every rank trains its own batch and
+    gridmm_amd.dist.GradientReducer exchanges the gradients (the DDP all-reduce of pretrain_src/utils/misc.py:52-65):
+    eager = exchange launched from the backward hooks (overlapped), graph = captured forward + backward, eager exchange,
+    eager update; value = whole-job samples/s (max-over-ranks time)."""
     from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
     from gridmm_amd.pretrain_loop import PreTrainer, default_opts
     from gridmm_amd.synthetic import batch_to, make_pretrain_batch
     from gridmm_amd.train_graph import GraphedTrainStep
     from gridmm_amd.vilmodel import default_config
+    dist, rank, world = _init_dist(dev)
+    steps = steps or int(os.environ.get("GRIDMM_BENCH_TRAIN_STEPS", "6"))
     cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=["mlm", "mrc", "sap"], image_prob_size=1000, obj_prob_size=0)
     torch.manual_seed(0)
     model = GlocalTextPathCMTPreTraining(cfg).to(dev)
-    tr = PreTrainer(model, default_opts(warmup_steps=100))
+    rkw = dict(algo=os.environ.get("GRIDMM_EXCHANGE_ALGO", "auto"), payload=os.environ.get("GRIDMM_EXCHANGE_PAYLOAD", "fp32"))
+    tr = PreTrainer(model, default_opts(warmup_steps=100), reducer_kw=rkw)
     tasks = ("mlm", "mrc", "sap")
-    batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i), args.batch, t, max_steps=5, L=80, vocab=30000,
+    batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i + 10 * rank), args.batch, t, max_steps=5, L=80, vocab=30000,
                                                image_prob_size=1000, n_pts=(588 * 3, 588 * 5)), dev)
                for i, t in enumerate(tasks)}
-    for t in tasks:
-        tr.train_step(batches[t], t)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        tr.train_step(batches[tasks[i % 3]], tasks[i % 3])
-    torch.cuda.synchronize()
-    dt_eager = (time.perf_counter() - t0) / steps
+    for _ in range(2):                       # first sight of each task agrees on its used-set; the second launches early
+        for t in tasks:
+            tr.train_step(batches[t], t)
+    dt_eager = _timed_loop(lambda i: tr.train_step(batches[tasks[i % 3]], tasks[i % 3]), steps, dist)
+    out_dist = None
+    if world > 1:
+        tr.exchange = False                  # the same step without the exchange (ranks drift apart: timing only)
+        dt_noex = _timed_loop(lambda i: tr.train_step(batches[tasks[i % 3]], tasks[i % 3]), steps, dist)
+        tr.exchange = True
+        from gridmm_amd.dist import broadcast_parameters
+        broadcast_parameters(model.parameters())
+        sweep = exchange_sweep(tr.reducer, dev, dist, iters=max(1, min(5, steps)))
+        alone = sweep["%s_%s" % (tr.reducer.algo, tr.reducer.payload)]
+        exposed = max(0.0, 1e3 * (dt_eager - dt_noex))
+        out_dist = {"world": world, "algo": tr.reducer.algo, "payload": tr.reducer.payload,
+                    "buckets": len(tr.reducer.buckets), "gradient_mb": sum(b["numel"] for b in tr.reducer.buckets) * 4 / 1e6,
+                    "allreduce_ms": alone, "exposed_ms_eager": exposed,
+                    "overlapped_fraction_eager": max(0.0, min(1.0, 1.0 - exposed / alone)) if alone > 0 else None,
+                    "ms_per_step_without_exchange": 1e3 * dt_noex, "exchange_alone_ms": sweep,
+                    "reducer_stats": dict(tr.reducer.stats),
+                    "backend": "gloo (ranks share one GPU: test hook)" if os.environ.get("GRIDMM_BENCH_SHARE_GPU") else "nccl (RCCL)"}
     graphs = {t: GraphedTrainStep(tr, batches[t], t) for t in tasks}
     for t in tasks:
         graphs[t]()
-    torch.cuda.synchronize()
-    n = 4 * steps
-    t0 = time.perf_counter()
-    for i in range(n):
-        losses, _ = graphs[tasks[i % 3]]()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    finite = bool(torch.isfinite(losses).all())
+    n = 4 * steps if world == 1 else 2 * steps
+    last = {}
+
+    def gstep(i):
+        last["losses"], _ = graphs[tasks[i % 3]]()
+    dt = _timed_loop(gstep, n, dist)
+    finite = bool(torch.isfinite(last["losses"]).all())
     del graphs, tr, model, batches
     torch.cuda.empty_cache()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     if not finite:
         raise SystemExit("bench.py: the captured training step produced non-finite losses")
-    return {"train_samples_per_s": args.batch / dt, "ms_per_step": 1e3 * dt, "batch": args.batch,
-            "launch": "hipGraph replay, one graph per task (train_graph.GraphedTrainStep)",
-            "eager": {"train_samples_per_s": args.batch / dt_eager, "ms_per_step": 1e3 * dt_eager},
-            "workload": "pre-training step (mlm/mrc/sap cycling), full-size model, native 12x49x768 grid memory t=3..5, "
-                        "fwd + bwd + clip + fused AdamW"}
+    best = min(dt, dt_eager)
+    res = {"train_samples_per_s": world * args.batch / best, "ms_per_step": 1e3 * best, "batch": args.batch, "n_gpus": world,
+           "global_batch": world * args.batch,
+           "launch": ("hipGraph replay, one graph per task (train_graph.GraphedTrainStep)" if world == 1 else
+                      "best of: eager launches with the exchange overlapped from the backward hooks | hipGraph of forward + "
+                      "backward, then eager exchange + update"),
+           "graph": {"train_samples_per_s": world * args.batch / dt, "ms_per_step": 1e3 * dt},
+           "eager": {"train_samples_per_s": world * args.batch / dt_eager, "ms_per_step": 1e3 * dt_eager},
+           "workload": "pre-training step (mlm/mrc/sap cycling), full-size model, native 12x49x768 grid memory t=3..5, "
+                       "fwd + bwd + clip + fused AdamW"}
+    if out_dist is not None:
+        res["exchange"] = out_dist
+    return res if rank == 0 else None
 
 
-def train_leg_subprocess(args):
+def train_leg_subprocess(args, world=1):
     """The training leg in its own process: GraphedTrainStep needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in place before the
-    HIP runtime starts (gridmm_amd/train_graph.py), and the headline graph keeps the runtime's default."""
+    HIP runtime starts (gridmm_amd/train_graph.py), and the headline graph keeps the runtime's default.  With several
+    ranks EVERY rank starts its child (same RANK / LOCAL_RANK / WORLD_SIZE, the next master port: the children form their
+    own process group); rank 0's child prints the JSON."""
     import subprocess
     env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="0")
+    if world > 1:
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            env.pop(k)        # (TORCHELASTIC_USE_AGENT_STORE would make the children look for the launcher's store on the new port)
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-leg-only", "--batch", str(args.batch)],
-                           env=env, capture_output=True, text=True, timeout=900)
+                           env=env, capture_output=True, text=True, timeout=1200)
     except subprocess.TimeoutExpired:
         return {"error": "the training leg timed out"}
+    if int(os.environ.get("RANK", "0")) != 0:
+        return None
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:      # a secondary key: reported in the line, the headline measurement stands
         sys.stderr.write("bench.py: the training leg failed:\n" + r.stdout[-2000:] + r.stderr[-4000:] + "\n")
@@ -430,7 +596,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.train_leg_only:
-        print(json.dumps(train_leg(args, dev)))
+        res = train_leg(args, dev)
+        if res is not None:
+            print(json.dumps(res))
         return
     dist = None
     if world > 1:
@@ -469,8 +637,15 @@ def main():
             sec = extra_depth_leg(args, dev, dist, t, max(5, args.steps // 2))
             out["t%d" % t] = {"value": n_gpus * args.batch / sec, "unit": "steps/s", "ms_per_step": 1e3 * sec,
                               "mem_steps": t, "points": geom.pts_per_obs * t}
-    if rank == 0 and n_gpus == 1 and not args.no_train_leg:
-        out["train"] = train_leg_subprocess(args)
+    if not args.no_depth_legs and not args.eager and args.mem_steps == 1 and n_gpus == 1:
+        out["sparse_map"] = sparse_map_leg(args, dev, dist, max(5, args.steps // 2))
+    if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1:
+        out.update(config_legs(args, dev, max(5, args.steps // 2)))
+    if not args.no_train_leg:
+        # config 3's shape: the pre-training step on EVERY rank with the RCCL gradient exchange (whole-job samples/s)
+        tl = train_leg_subprocess(args, n_gpus)
+        if rank == 0:
+            out["train"] = tl
     if rank == 0 and n_gpus == 1 and not args.no_producer_leg:
         out["vlnce_with_producer"] = producer_leg(args, dev)
     if rank == 0 and not args.no_roofline:

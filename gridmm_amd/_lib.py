@@ -52,7 +52,7 @@ SIGNATURES = {
     "gridmm_linear_planes_grouped": [_vp, _i, _vp],
     "gridmm_layernorm_map": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "gridmm_split_rows_map": [_vp, _i, _vp, _vp, _i, _i, _i64, _i, _i, _vp],
-    "gridmm_cells_embed": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "gridmm_cells_embed": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_node_embed": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp],
     "gridmm_nav_heads": [_vp, _i] + [_vp] * 17 + [_i, _i, _i, _i, _vp],
     "gridmm_tokens_to_slab": [_vp, _i, _i, _vp, _i64, _i, _i, _vp],

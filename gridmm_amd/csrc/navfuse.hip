@@ -12,12 +12,13 @@ namespace {
 constexpr int NV = 4;        // float4 per lane: H <= 1024
 constexpr int MAXK = 16;     // position feature widths on this path: 5, 7, 14
 
-// W [H][K] (the nn.Linear weight) -> LDS image W^T [K][H]: one conflict-free ds_read_b128 per lane, k and 4 outputs
-__device__ __forceinline__ void stage_wt(const float* __restrict__ W, int K, int H, float* __restrict__ wT) {
-  for (int i = threadIdx.x; i < K * H; i += blockDim.x) {
-    const int k = i / H, n = i - k * H;
-    wT[i] = W[(size_t)n * K + k];
-  }
+// W^T [K][H] (the nn.Linear weight transposed once on the host) -> LDS: coalesced 128-bit copies; the row loop then reads
+// one conflict-free ds_read_b128 per lane, k and 4 outputs
+__device__ __forceinline__ void stage_wt(const float* __restrict__ WT, int K, int H, float* __restrict__ wT) {
+  const int n4 = (K * H) >> 2;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n4; i += blockDim.x)
+    reinterpret_cast<float4*>(wT)[i] = reinterpret_cast<const float4*>(WT)[i];
 }
 
 // y[c] (c = lane + 64 i) = LN(W f + b) * gamma + beta for one row, one wave; fval: lane k < K holds the row's k-th
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void cells_embed_kernel(
     const float* __restrict__ bp, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const uint8_t* __restrict__ occ, float* __restrict__ out, uint8_t* __restrict__ mask, int mask_bs,
     const uint8_t* __restrict__ tail_mask, int n_tail, int32_t* __restrict__ n_cells, int32_t* __restrict__ cmax_out,
-    int B, int H, int S_pad) {
+    int B, int H, int S_pad, int c_pad) {
   __shared__ int s_rank[GRIDMM_CELLS];
   __shared__ int s_src[GRIDMM_CELLS];
   __shared__ int s_n, s_tail, s_cmax;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void cells_embed_kernel(
   __syncthreads();
   const int n = s_n, lim = s_tail, cmax = s_cmax;
   if (blockIdx.y == 0) {
-    for (int p = tid; p < GRIDMM_CELLS; p += blockDim.x) {
+    for (int p = tid; p < c_pad; p += blockDim.x) {
       uint8_t m;
       if (p < n) m = 1;
       else if (p < lim) m = occ[b * GRIDMM_CELLS + p] ? 1 : 0;
@@ -144,13 +145,14 @@ __global__ __launch_bounds__(256) void cells_embed_kernel(
       mask[(size_t)b * mask_bs + p] = m;
     }
     if (tail_mask)
-      for (int j = tid; j < n_tail; j += blockDim.x) mask[(size_t)b * mask_bs + GRIDMM_CELLS + j] = tail_mask[b * n_tail + j];
+      for (int j = tid; j < n_tail; j += blockDim.x) mask[(size_t)b * mask_bs + c_pad + j] = tail_mask[b * n_tail + j];
   }
   const int nv = H >> 2;
   float* ob = out + (size_t)b * S_pad * H;
   const int p_lo = blockIdx.y * GRIDMM_GRID;
   for (int r = wave; r < GRIDMM_GRID; r += 4) {
     const int p = p_lo + r;
+    if (p >= c_pad) break;           // a sequence padded to c_pad < 196 cell rows (valid when cmax <= c_pad)
     float* orow = ob + (size_t)p * H;
     if (p < n) {
       const int c = s_src[p];
@@ -375,12 +377,13 @@ __global__ __launch_bounds__(64) void nav_fuse_kernel(
 extern "C" int gridmm_cells_embed(const float* proj, const float* pos_fts, int K, const float* W_pos, const float* b_pos,
                                   const float* gamma, const float* beta, float eps, const uint8_t* occ, float* out,
                                   uint8_t* mask, int mask_bs, const uint8_t* tail_mask, int n_tail, int32_t* n_cells,
-                                  int32_t* cmax, int B, int H, int S_pad, gridmm_stream_t stream) {
-  if (B <= 0 || H <= 0 || H % 4 || H > 1024 || K <= 0 || K > MAXK || S_pad < GRIDMM_CELLS + (tail_mask ? n_tail : 0) ||
-      mask_bs < GRIDMM_CELLS + (tail_mask ? n_tail : 0))
+                                  int32_t* cmax, int B, int H, int S_pad, int c_pad, gridmm_stream_t stream) {
+  if (c_pad <= 0) c_pad = GRIDMM_CELLS;
+  if (B <= 0 || H <= 0 || H % 4 || H > 1024 || K <= 0 || K > MAXK || c_pad > GRIDMM_CELLS ||
+      S_pad < c_pad + (tail_mask ? n_tail : 0) || mask_bs < c_pad + (tail_mask ? n_tail : 0))
     return GRIDMM_EINVAL;
-  GRIDMM_LAUNCH(cells_embed_kernel, dim3(B, GRIDMM_GRID), dim3(256), (size_t)K * H * sizeof(float), as_stream(stream), proj, pos_fts, K, W_pos, b_pos,
-                gamma, beta, eps, occ, out, mask, mask_bs, tail_mask, n_tail, n_cells, cmax, B, H, S_pad);
+  GRIDMM_LAUNCH(cells_embed_kernel, dim3(B, (c_pad + GRIDMM_GRID - 1) / GRIDMM_GRID), dim3(256), (size_t)K * H * sizeof(float), as_stream(stream), proj, pos_fts, K, W_pos, b_pos,
+                gamma, beta, eps, occ, out, mask, mask_bs, tail_mask, n_tail, n_cells, cmax, B, H, S_pad, c_pad);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

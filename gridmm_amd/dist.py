@@ -129,6 +129,7 @@ class GradientReducer:
         self._hook_fns = [self._make_hook(i) for i in range(len(self.params))]
         self._hooks = [p.register_post_accumulate_grad_hook(f) for p, f in zip(self.params, self._hook_fns)]
         self.stats = {"launched_early": 0, "launched_late": 0, "repairs": 0}
+        self.enabled = True                              # False: hooks are inert (a hipGraph capture of the backward)
 
     # ---- bucket plumbing
     def _flat(self, b):
@@ -206,7 +207,7 @@ class GradientReducer:
 
     def _make_hook(self, i):
         def hook(p):
-            if not is_dist():
+            if not is_dist() or not self.enabled:
                 return
             bi, _ = self.slot[i]
             b = self.buckets[bi]

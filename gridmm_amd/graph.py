@@ -9,12 +9,19 @@ torch's current (capturing) stream.
 
 Shapes are static per graph (B, L, G, V, memory depth): an agent loop would keep one graph per shape
 bucket; bench.py uses one.
+
+Varlen map sequences (`buckets=`): the reference cuts the [cells | nodes] sequence to the batch's largest occupied-cell
+count (map_nav_src/models/vilmodel.py:809-823, ops.py:46-68).  Here the step is TWO graphs: a front one (fill_gridmap,
+text_proj, aggregation, grid_proj: independent of the count) and one back graph per bucket C in `buckets` (encoders + heads
+on C + G rows).  The bucket of a step is predicted from the previous step's count (it changes slowly along an episode);
+the back graph writes the true count, and a step whose count exceeded its bucket is redone on the right one (the front
+outputs are static buffers: nothing is re-projected).  Results equal the 196-row path (tests/test_hip_graph_step.py).
 """
 import torch
 
 
 class GraphedNavStep:
-    def __init__(self, model, mem, batch, depth, restore=None, warmup=2):
+    def __init__(self, model, mem, batch, depth, restore=None, warmup=2, buckets=None):
         """depth: (B, n_pts) uint16 device tensor of the observation appended by each step.
         restore: optional (n_pts0, bbox0) device tensors copied back before each step, so that every replay
         appends to the same history prefix (benchmarks at a fixed memory depth t)."""
@@ -33,6 +40,11 @@ class GraphedNavStep:
         self.batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
         self.graph = None
         self.outs = None
+        self.buckets = tuple(sorted(set(int(c) for c in buckets))) if buckets else None
+        if self.buckets:
+            assert self.buckets[-1] == 196, "the last bucket must hold all 196 cells"
+            self._init_bucketed(warmup)
+            return
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):             # warm-up on a side stream: weight packing, allocator pools
@@ -43,6 +55,58 @@ class GraphedNavStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outs = self._device_step()
+
+    def _init_bucketed(self, warmup):
+        model = self.model
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):             # warm-up: weight packing, allocator pools, every bucket's shapes
+            for _ in range(warmup):
+                fr = self._device_front()
+                for c in self.buckets:
+                    model.navigation_back(fr, c, self.batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.front = self._device_front()
+        self.back, self.back_outs, self.cmax = {}, {}, {}
+        for c in self.buckets:                    # same memory pool: the back graphs read the front graph's outputs
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph.pool()):
+                self.back_outs[c] = model.navigation_back(self.front, c, self.batch)
+                self.cmax[c] = model._cells[1]
+            self.back[c] = g
+        self.bucket = self.buckets[-1]            # prediction for the next step
+        self.last_bucket, self.redone = None, 0
+
+    def _device_front(self):
+        mem = self.mem
+        if self.restore is not None:
+            mem.n_pts.copy_(self.restore[0])
+            mem.bbox.copy_(self.restore[1])
+        mem.project_and_bin(self.depth)
+        return self.model.navigation_front(self.batch)
+
+    def _pick(self, cmax):
+        for c in self.buckets:
+            if cmax <= c:
+                return c
+        return self.buckets[-1]
+
+    def _call_bucketed(self, check):
+        self.graph.replay()
+        c = self.bucket
+        self.back[c].replay()
+        if check:                                 # the caller reads the logits next anyway: one small D2H with them
+            cmax = int(self.cmax[c].item())
+            if cmax > c:                          # mispredicted: redo the back half on the bucket that holds the count
+                c = self._pick(cmax)
+                self.back[c].replay()
+                self.redone += 1
+            self.bucket = self._pick(cmax)        # the count changes slowly along an episode
+        self.last_bucket = c
+        return self.back_outs[c]
 
     def _device_step(self):
         mem = self.mem
@@ -66,11 +130,15 @@ class GraphedNavStep:
         self._fm_done = torch.cuda.Event()
         self._fm_done.record()
 
-    def __call__(self, poses, headings, fusion=None):
+    def __call__(self, poses, headings, fusion=None, check=True):
         """poses/headings for the (single) appended observation; fusion = (gmap_vpids, gmap_visited_masks (host),
-        vp_cand_vpids) rebuilds the fused-logit index maps for this step; returns the static output dict."""
+        vp_cand_vpids) rebuilds the fused-logit index maps for this step; returns the static output dict.
+        check (bucketed graphs only): read the occupied-cell count after the step and redo it on a larger bucket if the
+        prediction was too small; check=False leaves that to the caller (self.cmax[self.last_bucket] vs self.last_bucket)."""
         self.mem.set_pose(poses, headings)
         if fusion is not None:
             self.refresh_fusion_maps(*fusion)
+        if self.buckets:
+            return self._call_bucketed(check)
         self.graph.replay()
         return self.outs

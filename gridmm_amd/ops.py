@@ -455,7 +455,12 @@ def linear_grouped(problems):
                                               "gridmm_linear_planes_grouped"))
 
 
-def cells_embed(proj, pos_fts, lin, ln, occ, out, mask, tail_mask=None):
+def linear_wt(lin):
+    """nn.Linear(K, H) weight as the [K][H] fp32 image the fused embedding kernels stage in LDS (cache it per weight version)."""
+    return lin.weight.detach().float().t().contiguous()
+
+
+def cells_embed(proj, pos_fts, lin, ln, occ, out, mask, tail_mask=None, wT=None, c_pad=N_CELLS):
     """cells_compact with the grid position embedding (lin = nn.Linear(K, H), ln = nn.LayerNorm) computed inside; mask:
     (B, >= 196 + n_tail) uint8 view with any row stride; tail_mask (B, n_tail) is copied behind the 196 cell bits.
     Returns (n_cells, cmax) int32 tensors."""
@@ -469,9 +474,11 @@ def cells_embed(proj, pos_fts, lin, ln, occ, out, mask, tail_mask=None):
     pos_fts = pos_fts.float().contiguous()
     n_tail = 0 if tail_mask is None else tail_mask.shape[1]
     assert tail_mask is None or tail_mask.is_contiguous()
+    wT = linear_wt(lin) if wT is None else wT
+    assert wT.shape == (K, H) and wT.is_contiguous()
     _timed("cells_embed", 0.0, lambda: _lib.check(lib.gridmm_cells_embed(
-        _p(proj), _p(pos_fts), K, _p(lin.weight), _p(lin.bias), _p(ln.weight), _p(ln.bias), float(ln.eps), _p(occ),
-        _p(out), _p(mask), mask.stride(0), _p(tail_mask), n_tail, _p(n_cells), _p(cmax), B, H, S_pad, _stream()),
+        _p(proj), _p(pos_fts), K, _p(wT), _p(lin.bias), _p(ln.weight), _p(ln.bias), float(ln.eps), _p(occ),
+        _p(out), _p(mask), mask.stride(0), _p(tail_mask), n_tail, _p(n_cells), _p(cmax), B, H, S_pad, int(c_pad), _stream()),
         "gridmm_cells_embed"))
     return n_cells, cmax
 
@@ -484,10 +491,11 @@ class _CEmbedSeg(ctypes.Structure):
                 ("out_bs", ctypes.c_int64), ("M", ctypes.c_int)]
 
 
-def embed_seg(pos, lin, ln, add1, out, table=None, idx=None, planes=None):
+def embed_seg(pos, lin, ln, add1, out, table=None, idx=None, planes=None, wT=None):
     """One segment of node_embed: out (B, R, H) fp32 view (rows of a longer sequence allowed) = LN(lin(pos)) + add1
-    (+ table[idx]); planes = (hi, lo) views with the SAME strides as out."""
-    keep = []
+    (+ table[idx]); planes = (hi, lo) views with the SAME strides as out; wT = linear_wt(lin) (cached by the caller)."""
+    wT = linear_wt(lin) if wT is None else wT
+    keep = [wT]
     pos = pos.float().contiguous()
     add1 = add1.float().contiguous()
     keep += [pos, add1]
@@ -501,7 +509,8 @@ def embed_seg(pos, lin, ln, add1, out, table=None, idx=None, planes=None):
     if planes is not None:
         hi, lo = planes
         assert hi.stride() == out.stride() and lo.stride() == out.stride()
-    seg = _CEmbedSeg(pos.data_ptr(), pos.shape[-1], lin.weight.data_ptr(), lin.bias.data_ptr(), ln.weight.data_ptr(),
+    assert wT.shape == (pos.shape[-1], H) and wT.is_contiguous()
+    seg = _CEmbedSeg(pos.data_ptr(), pos.shape[-1], wT.data_ptr(), lin.bias.data_ptr(), ln.weight.data_ptr(),
                      ln.bias.data_ptr(), float(ln.eps), add1.data_ptr(), H, table.data_ptr() if table is not None else None,
                      idx.data_ptr() if idx is not None else None, out.data_ptr(), hi.data_ptr() if hi is not None else None,
                      lo.data_ptr() if lo is not None else None, rpb, bs, B * R)

@@ -46,13 +46,15 @@ class TaskSampler:
 
 
 class PreTrainer:
-    def __init__(self, model, opts):
+    def __init__(self, model, opts, reducer_kw=None):
+        """reducer_kw: GradientReducer options (bucket_mb, overlap, algo = ring | rsag | direct | auto, payload = fp32 | bf16)."""
         self.model, self.opts = model, opts
         D.broadcast_parameters(model.parameters())            # DDP construction broadcasts rank 0's weights
         self.optimizer = build_optimizer(model, opts)
-        self.reducer = D.GradientReducer(model.parameters())
+        self.reducer = D.GradientReducer(model.parameters(), **(reducer_kw or {}))
         self.global_step = 0
         self._micro = 0
+        self.exchange = True      # False: skip the gradient exchange (bench.py times the step with and without it)
         self.optimizer.zero_grad()
 
     def train_step(self, batch, task):
@@ -64,7 +66,9 @@ class PreTrainer:
         if o.gradient_accumulation_steps > 1:
             loss = loss / o.gradient_accumulation_steps
         last = (self._micro + 1) % o.gradient_accumulation_steps == 0
-        self.reducer.expect(task if o.gradient_accumulation_steps == 1 else None, final=last)
+        self.reducer.enabled = self.exchange
+        if self.exchange:
+            self.reducer.expect(task if o.gradient_accumulation_steps == 1 else None, final=last)
         loss.backward()                                        # the reducer's hooks launch the exchange from in here
         self._micro += 1
         norm = None
@@ -73,7 +77,8 @@ class PreTrainer:
             lr = get_lr_sched(self.global_step, o)
             for g in self.optimizer.param_groups:
                 g["lr"] = lr
-            self.reducer.reduce()                              # the DDP exchange (no-op on one rank)
+            if self.exchange:
+                self.reducer.reduce()                          # the DDP exchange (no-op on one rank)
             norm = self.optimizer.step(max_grad_norm=o.grad_norm if o.grad_norm != -1 else None)
             self.optimizer.zero_grad()
         return losses.detach(), norm

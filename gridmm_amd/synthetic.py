@@ -37,13 +37,25 @@ VLNCE_R2R = GridGeometry(depth_div=1.0, tan_half_fov=math.tan(math.pi / 4.), vln
 VLNCE_RXR = GridGeometry(depth_div=1.0, tan_half_fov=math.tan(math.pi * 79. / 360.), vlnce=True, max_dist=40.0)
 
 
-def make_observations(rs, geom, steps, feat_scale=1.0, zero_frac=0.1, with_feats=True):
+def make_observations(rs, geom, steps, feat_scale=1.0, zero_frac=0.1, with_feats=True, depth_mode="uniform",
+                      inner_frac=0.01):
     """One episode's observation sequence: list of dicts(depth, feats, x, y, heading).  with_feats=False leaves
-    feats None (callers that fill the slab on the device) and draws nothing for them."""
+    feats None (callers that fill the slab on the device) and draws nothing for them.
+    depth_mode "uniform": depth ~ U[0, 5 m) -- every one of the 196 cells ends up occupied (SURVEY 8d's generator);
+    "ring": walls at one distance (N(3 m, 5 %)) plus a fraction `inner_frac` of nearer points: the map scale rule
+    (half_len = 2/3 of the extent, env.py:322-331) clamps the wall points into the border cells, so an episode occupies
+    roughly 60-120 cells -- the regime in which the reference's max_cell_num truncation shortens the sequence."""
     obs = []
     x, y = float(rs.uniform(-5, 5)), float(rs.uniform(-5, 5))
     for _ in range(steps):
-        d = rs.randint(0, 20000, size=(geom.n_views, geom.patches ** 2)).astype(np.uint16)
+        if depth_mode == "ring":
+            shape = (geom.n_views, geom.patches ** 2)
+            r = rs.normal(12000.0, 600.0, size=shape)
+            inner = rs.rand(*shape) < inner_frac
+            r[inner] = rs.uniform(2400.0, 12000.0, size=int(inner.sum()))
+            d = np.clip(r, 1, 65535).astype(np.uint16)
+        else:
+            d = rs.randint(0, 20000, size=(geom.n_views, geom.patches ** 2)).astype(np.uint16)
         d[rs.rand(*d.shape) < zero_frac] = 0
         f = (rs.standard_normal((geom.pts_per_obs, geom.feat_dim)) * feat_scale).astype(np.float16) if with_feats else None
         obs.append(dict(depth=d, feats=f, x=x, y=y, heading=float(rs.randint(0, 12)) * math.pi / 6))
@@ -53,7 +65,7 @@ def make_observations(rs, geom, steps, feat_scale=1.0, zero_frac=0.1, with_feats
 
 
 def make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, H=768,
-                   min_len=30, ragged_gmap=True, with_obj=False):
+                   min_len=30, ragged_gmap=True, with_obj=False, n_obj=5):
     """Navigation-mode inputs EXCEPT the grid memory (grid_fts / grid_map / gridmap_pos_fts).
 
     Returns a dict of CPU tensors + python vpid lists with the reference's key names.
@@ -108,9 +120,15 @@ def make_nav_batch(rs, B, L=80, G=20, n_visited=6, V1=37, n_cand=4, H=768,
         "vp_obj_masks": None,
         "vp_cand_vpids": vp_cand_vpids,
     }
-    if with_obj:
+    if with_obj:      # the last n_obj view slots are object tokens (map_nav_src/reverie/env.py:263-372: up to 20 + padding)
         m = np.zeros((B, V1), bool)
-        m[:, V1 - 5:] = True
+        if n_obj == 5:
+            m[:, V1 - 5:] = True
+        else:         # ragged object counts, the batch maximum = n_obj
+            cnt = rs.randint(max(1, n_obj // 2), n_obj + 1, size=B)
+            cnt[rs.randint(B)] = n_obj
+            for b in range(B):
+                m[b, V1 - n_obj:V1 - n_obj + cnt[b]] = True
         batch["vp_obj_masks"] = torch.from_numpy(m)
     return batch
 

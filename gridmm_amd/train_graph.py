@@ -25,7 +25,13 @@ correctly.  GraphedTrainStep refuses to run without it (GRIDMM_TRAIN_GRAPH_ANY_R
 re-testing a newer runtime); bench.py and the tests run this leg in a subprocess that sets it
 (the navigation-step graph of the headline is unaffected and keeps the default).
 
-Reference loop: pretrain_src/train_r2r.py:231-303 (one process; gradient_accumulation_steps == 1).  A training loop over
+Several ranks (torch.distributed initialised): the graph holds forward + backward only; after a replay the static
+gradient buffers go through GradientReducer (eager RCCL exchange, pretrain_src/utils/misc.py:52-65) and the clip + AdamW
+update is launched eagerly on the reduced gradients (two multi-tensor launches).  The reducer's hooks are inert during the
+capture.  The batch tensors recorded on the host tape (the packed grid features, the label counts of the sap stop
+re-weighting) are FROZEN at record time: a graph belongs to one batch, in-place edits of those inputs are not seen.
+
+Reference loop: pretrain_src/train_r2r.py:231-303 (gradient_accumulation_steps == 1).  A training loop over
 real data would keep one graph per (task, padded-shape bucket) and feed index tensors as inputs; this class covers the
 fixed-metadata case (bench.py's train leg, tests/test_hip_train_graph.py).
 """
@@ -46,8 +52,11 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep needs %s=%s in the environment before torch / HIP start (see the module "
                                "docstring): replaying this graph with pre-recorded packets faults on ROCm 7.2" % RUNTIME_ENV)
         o = trainer.opts
-        if o.gradient_accumulation_steps != 1 or D.is_dist():
-            raise ValueError("GraphedTrainStep: one process, gradient_accumulation_steps == 1")
+        if o.gradient_accumulation_steps != 1:
+            raise ValueError("GraphedTrainStep: gradient_accumulation_steps == 1")
+        self.dist = D.is_dist()
+        if self.dist:
+            capture_optimizer = False                       # exchange between the captured backward and the update
         self.tr, self.batch, self.task = trainer, batch, task
         model, opt = trainer.model, trainer.optimizer
         dev = next(model.parameters()).device
@@ -73,6 +82,7 @@ class GraphedTrainStep:
             opt.zero_grad(set_to_none=True)
             model.train()
             self.graph = torch.cuda.CUDAGraph()
+            trainer.reducer.enabled = False                 # no bucket copies / collectives inside the capture
             with torch.cuda.graph(self.graph):
                 with hs.replay(tape):
                     losses = model(batch, task=task, compute_loss=True)
@@ -85,13 +95,17 @@ class GraphedTrainStep:
             # p.grad would ACCUMULATE into them (train_step clears the gradients at the end of a step, a capture computes
             # nothing)
             self.grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}   # static buffers (inspection)
+            self._grad_of = [(p, p.grad) for p in model.parameters() if p.grad is not None]
             opt.zero_grad(set_to_none=True)
         finally:
             ag.SEED_DEV = prev
+            trainer.reducer.enabled = True
         self.capture_optimizer = capture_optimizer
         self.params = [p for tab in self.tabs["multi"].values() for p in tab[3]]
         for p in self.params:                               # the capture pass counted a step that never ran
             opt.state[p]["step"] -= 1
+        if not capture_optimizer:
+            self.params = [p for p, _ in self._grad_of]
 
     def __call__(self):
         """One training step on the static batch: returns (per-sample losses, pre-clip gradient norm) -- static device
@@ -110,9 +124,16 @@ class GraphedTrainStep:
         self.graph.replay()
         self._done = torch.cuda.Event()
         self._done.record()
-        if not self.capture_optimizer:                      # (debugging aid: the update launched eagerly on the static grads)
+        if not self.capture_optimizer:                      # several ranks (or debugging): exchange + update launched eagerly
             o = tr.opts
+            for p, g in self._grad_of:
+                p.grad = g                                  # the graph's static gradient buffers
+            if self.dist:
+                tr.reducer.expect(self.task)
+                tr.reducer.reduce()                         # copies into the buckets, RCCL exchange, p.grad = mean
             self.norm = opt.step(max_grad_norm=o.grad_norm if o.grad_norm != -1 else None)
+            opt.zero_grad(set_to_none=True)
+            return self.losses, self.norm                   # (opt.step bumped the parameter versions itself)
         for p in self.params:
             _bump_version(p)
         return self.losses, self.norm

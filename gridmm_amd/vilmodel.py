@@ -259,6 +259,15 @@ class GlocalTextPathNavCMT(nn.Module):
     def _lin(self, mod, key):
         return self._pack(key, [mod.weight], [mod.bias])
 
+    def _wt(self, mod, key):
+        """[K][H] fp32 image of a small nn.Linear(K, H) weight for the fused embedding kernels, rebuilt on a version change."""
+        ver = (mod.weight.data_ptr(), mod.weight._version)
+        ent = self._packed.get(key + ".wT")
+        if ent is None or ent[0] != ver:
+            ent = (ver, ops.linear_wt(mod))
+            self._packed[key + ".wT"] = ent
+        return ent[1]
+
     def _qkv(self, att, key, which="qkv"):
         mods = {"qkv": [att.query, att.key, att.value], "kv": [att.key, att.value], "q": [att.query]}[which]
         return self._pack(key + "." + which, [m.weight for m in mods], [m.bias for m in mods])
@@ -451,30 +460,22 @@ class GlocalTextPathNavCMT(nn.Module):
         return self._heads_infer(gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, gmap_vpids,
                                  vp_nav_masks, vp_obj_masks, vp_cand_vpids, fusion_maps, G, V, dev)
 
+    # Cell rows of the padded [cells | nodes] sequence.  None: always 196 (no host decision anywhere: the whole step is one
+    # hipGraph).  A tuple of ascending bucket sizes ending in 196: the reference's max_cell_num truncation
+    # (vilmodel.py:809-823, ops.py:46-68 pad_tensors_wgrad) -- eager calls read the batch's largest occupied-cell count
+    # (one small D2H, as the reference's python max() does) and run the encoders on the smallest bucket that holds it;
+    # graph.GraphedNavStep keeps one captured back half per bucket and predicts the bucket from the previous step.
+    varlen_buckets = None
+    DEFAULT_BUCKETS = (64, 96, 128, 160, N_CELLS)
+
     @torch.no_grad()
-    def _encode_navigation_infer(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
-                                 vp_img_embeds, vp_pos_fts, vp_masks, grid_fts, grid_map, gridmap_pos_fts,
-                                 grid_memory=None):
-        """vilmodel.py:788-856: aggregation, grid encoder, grid/text layer, local encoder -> (gmap_embeds (B,G,H),
-        vp_embeds (B,V,H), map_embeds (B,196+G,H)).  Shared with the VLN-CE twin (gridmap/vilmodel.py:710-776).
-
-        Sequences are never concatenated: ONE plane buffer `kv` (B, 196+G+L, H) is the local encoder's [map | txt] context
-        (vilmodel.py:846-848); the instruction planes are split straight into its tail, the grid/text layer's last
-        LayerNorm writes the map planes into its head, and the GEMMs that need only one part read it in place through
-        the batched row map of gridmm_linear_planes_map.  The byte masks live the same way in `kv_masks`."""
-        dev = txt_embeds.device
+    def _nav_front(self, txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None, txt_planes=None):
+        """vilmodel.py:793-807: text_proj, instruction-relevance aggregation of the grid memory, grid_proj on the 196
+        reduced cell vectors.  Independent of how many cells are occupied.  txt_planes = (hi, lo): where the bf16 planes
+        of the instruction go (e.g. the tail of the local encoder's context buffer)."""
         B, L, H = txt_embeds.shape
-        G, V = gmap_masks.shape[1], vp_masks.shape[1]
-        S = N_CELLS + G
         txt_embeds = txt_embeds.float().contiguous()
-        txt_m, gmap_m, vp_m = (self._u8(m).contiguous() for m in (txt_masks, gmap_masks, vp_masks))
-        kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
-        kv_masks = torch.empty(B, S + L, dtype=torch.uint8, device=dev)
-        q_masks = torch.empty(B, G + V, dtype=torch.uint8, device=dev)
-        map_masks = kv_masks[:, :S]
-
-        # ---- grid memory -> 196 instruction-weighted cell vectors (vilmodel.py:793-807)
-        txt = ops.split_rows(txt_embeds, out=(kv.hi[:, S:], kv.lo[:, S:]))   # fp32 + planes (in place in the context)
+        txt = ops.split_rows(txt_embeds, out=txt_planes)   # fp32 + planes
         text_fts = ops.linear(txt, self._lin(self.text_proj, "text_proj")).f32
         frag = ops.text_fragments(text_fts)
         n_points = None
@@ -487,21 +488,43 @@ class GlocalTextPathNavCMT(nn.Module):
             slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
         cells, occ = ops.grid_aggregate(slab, perm, cell_start, frag, L, n_points=n_points)
         proj = ops.linear(cells, self._lin(self.grid_proj, "grid_proj")).f32
+        return SimpleNamespace(txt=txt, txt_m=self._u8(txt_masks).contiguous(), proj=proj, occ=occ,
+                               gridmap_pos_fts=gridmap_pos_fts, in_place=txt_planes is not None)
 
-        # ---- [cells | gmap nodes] sequence, padded to 196 + G (vilmodel.py:813-837); position embeddings of cells, nodes
-        # and views + all byte masks in two launches
+    @torch.no_grad()
+    def _nav_back(self, fr, c_pad, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks, vp_img_embeds, vp_pos_fts,
+                  vp_masks, kv=None):
+        """vilmodel.py:813-856 on a [cells | nodes] sequence padded to c_pad + G rows (c_pad >= the batch's largest
+        occupied-cell count): position embeddings, grid encoder, grid/text layer, local encoder."""
+        txt, txt_m = fr.txt, fr.txt_m
+        dev = txt.f32.device
+        B, L, H = txt.f32.shape
+        G, V = gmap_masks.shape[1], vp_masks.shape[1]
+        S = c_pad + G
+        gmap_m, vp_m = (self._u8(m).contiguous() for m in (gmap_masks, vp_masks))
+        if kv is None:
+            kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
+            ops.copy_planes(txt, kv, S)                  # (callers that know c_pad up front let _nav_front write in place)
+        kv_masks = torch.empty(B, S + L, dtype=torch.uint8, device=dev)
+        q_masks = torch.empty(B, G + V, dtype=torch.uint8, device=dev)
+        map_masks = kv_masks[:, :S]
+
+        # ---- [cells | gmap nodes] sequence (vilmodel.py:813-837); position embeddings of cells, nodes and views + all
+        # byte masks in two launches
         map_embeds = torch.empty(B, S, H, dtype=torch.float32, device=dev)
         gp = self.grid_pos_embeddings
-        self._cells = ops.cells_embed(proj, gridmap_pos_fts, gp[0], gp[1], occ, map_embeds, kv_masks, tail_mask=gmap_m)
+        self._cells = ops.cells_embed(fr.proj, fr.gridmap_pos_fts, gp[0], gp[1], fr.occ, map_embeds, kv_masks,
+                                      tail_mask=gmap_m, wT=self._wt(gp[0], "grid_pos"), c_pad=c_pad)
         q = torch.empty(B, G + V, H, dtype=torch.float32, device=dev)
         qp = ops._planes_like((B, G + V, H), dev)
         ge, le = self.global_encoder, self.local_encoder
         ops.node_embed(
             [ops.embed_seg(gmap_pos_fts, ge.gmap_pos_embeddings[0], ge.gmap_pos_embeddings[1], gmap_img_embeds,
-                           map_embeds[:, N_CELLS:], table=ge.gmap_step_embeddings.weight, idx=gmap_step_ids),
+                           map_embeds[:, c_pad:], table=ge.gmap_step_embeddings.weight, idx=gmap_step_ids,
+                           wT=self._wt(ge.gmap_pos_embeddings[0], "gmap_pos")),
              ops.embed_seg(vp_pos_fts, le.vp_pos_embeddings[0], le.vp_pos_embeddings[1], vp_img_embeds, q[:, G:],
-                           planes=(qp[0][:, G:], qp[1][:, G:]))],
-            H, gmap_m, vp_m, txt_m, kv_masks, N_CELLS, q_masks)
+                           planes=(qp[0][:, G:], qp[1][:, G:]), wT=self._wt(le.vp_pos_embeddings[0], "vp_pos"))],
+            H, gmap_m, vp_m, txt_m, kv_masks, c_pad, q_masks)
 
         # ---- grid encoder + grid/text cross-modal layer (vilmodel.py:840-841)
         mp = self._pre_ln_encoder(self.grid_encoder, "grid_enc", map_embeds, map_masks)
@@ -520,14 +543,65 @@ class GlocalTextPathNavCMT(nn.Module):
                                            [b for l in xl for b in (l.visual_attention.att.key.bias,
                                                                     l.visual_attention.att.value.bias)]),
                             want_f32=False, want_planes=True)
-        ops.copy_rows(map_embeds[:, N_CELLS:], q, 0)
-        ops.copy_planes(ops.Act(None, kv.hi[:, N_CELLS:S], kv.lo[:, N_CELLS:S]), ops.Act(None, qp[0], qp[1]), 0)
+        ops.copy_rows(map_embeds[:, c_pad:], q, 0)
+        ops.copy_planes(ops.Act(None, kv.hi[:, c_pad:S], kv.lo[:, c_pad:S]), ops.Act(None, qp[0], qp[1]), 0)
         qa = ops.Act(q, qp[0], qp[1])
         for i, layer in enumerate(xl):
             qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks, kv=(kv_all, 2 * H * i))
         q = qa.f32
-        self._last_acts = (qa, kv, S + L)     # planes of the outputs: the heads read them in place
+        self._last_acts = (qa, kv, S + L, c_pad)     # planes of the outputs: the heads read them in place
         return q[:, :G], q[:, G:], map_embeds
+
+    @torch.no_grad()
+    def navigation_front(self, batch):
+        """First half of forward('navigation', batch) (independent of the occupied-cell count): see _nav_front."""
+        return self._nav_front(batch["txt_embeds"], batch["txt_masks"], batch.get("grid_fts"), batch.get("grid_map"),
+                               batch.get("gridmap_pos_fts"), grid_memory=batch.get("grid_memory"))
+
+    @torch.no_grad()
+    def navigation_back(self, fr, c_pad, batch):
+        """Second half on a sequence padded to c_pad cell rows -> the output dict of forward('navigation').  Valid when
+        the batch's largest occupied-cell count (self._cells[1], a device int32 written by this call) is <= c_pad."""
+        dev = batch["txt_embeds"].device
+        G, V = batch["gmap_masks"].shape[1], batch["vp_masks"].shape[1]
+        gmap_embeds, vp_embeds, map_embeds = self._nav_back(
+            fr, int(c_pad), batch["gmap_img_embeds"], batch["gmap_step_ids"], batch["gmap_pos_fts"], batch["gmap_masks"],
+            batch["vp_img_embeds"], batch["vp_pos_fts"], batch["vp_masks"])
+        return self._heads_infer(gmap_embeds, vp_embeds, map_embeds, self._u8(batch["gmap_masks"]),
+                                 batch["gmap_visited_masks"], batch["gmap_vpids"], batch["vp_nav_masks"],
+                                 batch.get("vp_obj_masks"), batch["vp_cand_vpids"], batch.get("fusion_maps"), G, V, dev)
+
+    def pick_bucket(self, cmax):
+        """Smallest configured bucket that holds cmax occupied cells (196 when varlen is off)."""
+        for c in (self.varlen_buckets or (N_CELLS,)):
+            if cmax <= c:
+                return int(c)
+        return N_CELLS
+
+    @torch.no_grad()
+    def _encode_navigation_infer(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
+                                 vp_img_embeds, vp_pos_fts, vp_masks, grid_fts, grid_map, gridmap_pos_fts,
+                                 grid_memory=None):
+        """vilmodel.py:788-856: aggregation, grid encoder, grid/text layer, local encoder -> (gmap_embeds (B,G,H),
+        vp_embeds (B,V,H), map_embeds (B,c_pad+G,H)).  Shared with the VLN-CE twin (gridmap/vilmodel.py:710-776).
+
+        Sequences are never concatenated: ONE plane buffer `kv` (B, c_pad+G+L, H) is the local encoder's [map | txt]
+        context (vilmodel.py:846-848); the instruction planes are split straight into its tail, the grid/text layer's
+        last LayerNorm writes the map planes into its head, and the GEMMs that need only one part read it in place
+        through the batched row map of gridmm_linear_planes_map.  The byte masks live the same way in `kv_masks`."""
+        dev = txt_embeds.device
+        B, L, H = txt_embeds.shape
+        G = gmap_masks.shape[1]
+        back = (gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks, vp_img_embeds, vp_pos_fts, vp_masks)
+        if self.varlen_buckets and not torch.cuda.is_current_stream_capturing():
+            fr = self._nav_front(txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory)
+            cmax = int(fr.occ.sum(1, dtype=torch.int32).max())      # the reference's max_cell_num (host decision)
+            return self._nav_back(fr, self.pick_bucket(cmax), *back)
+        S = N_CELLS + G
+        kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
+        fr = self._nav_front(txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory,
+                             txt_planes=(kv.hi[:, S:], kv.lo[:, S:]))
+        return self._nav_back(fr, N_CELLS, *back, kv=kv)
 
     @torch.no_grad()
     def _heads_infer(self, gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, gmap_vpids, vp_nav_masks,
@@ -544,7 +618,7 @@ class GlocalTextPathNavCMT(nn.Module):
         if acts is None or acts[0].f32.data_ptr() != gmap_embeds.data_ptr():
             return self._heads_infer_unfused(gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, vp_nav_masks,
                                              vp_obj_masks, fusion_maps, G, V)
-        qa, kv, SL = acts
+        qa, kv, SL, c_pad = acts
         Sq = G + V
         gh, lh = self.global_sap_head.net, self.local_sap_head.net
         stack = [gh[0], lh[0]] + ([self.og_head.net[0]] if has_obj else [])
@@ -554,7 +628,7 @@ class GlocalTextPathNavCMT(nn.Module):
         h_grid = torch.empty(B * G, H, dtype=torch.float32, device=dev)
         probs = [ops.gemm_problem(qa.hi, qa.lo, H, B * Sq, pw_gl, h_gl, act=ops.ACT_RELU),
                  ops.gemm_problem(kv.hi, kv.lo, H, B * G, pw_grid, h_grid, act=ops.ACT_RELU, a_rpb=G, a_bs=SL * H,
-                                  a_off=N_CELLS * H)]
+                                  a_off=c_pad * H)]
         fa = fb = fbias = None
         if self.sap_fuse_linear is not None:
             pw_f = self._lin(self.sap_fuse_linear.net[0], "fuse")
@@ -585,7 +659,7 @@ class GlocalTextPathNavCMT(nn.Module):
         if self.sap_fuse_linear is not None:
             fuse_raw = self._cls(self.sap_fuse_linear, "fuse", torch.cat([gmap_embeds[:, 0], vp_embeds[:, 0]], 1))
         g_raw = self._cls(self.global_sap_head, "ghead", gmap_embeds)
-        grid_raw = self._cls(self.grid_sap_head, "gridhead", map_embeds[:, N_CELLS:])
+        grid_raw = self._cls(self.grid_sap_head, "gridhead", map_embeds[:, map_embeds.shape[1] - G:])
         l_raw = self._cls(self.local_sap_head, "lhead", vp_embeds)
         global_logits, local_logits, grid_logits, fused_logits = ops.fuse_logits(
             g_raw, l_raw, grid_raw, fuse_raw, gmap_m, self._u8(gmap_visited_masks), self._u8(vp_nav_masks),

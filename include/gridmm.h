@@ -325,11 +325,15 @@ int gridmm_fuse_logits(const float* g_raw, const float* l_raw, const float* grid
  * 816) evaluated inside: out row p < n_b = proj[src cell] + LN(W_pos pos_fts[src cell] + b_pos) * gamma + beta, rows
  * [n_b, 196) zero; the key mask as gridmm_cells_compact (quirk included) at row stride mask_bs, followed by n_tail bytes
  * copied from tail_mask [B][n_tail] (the map-node mask of the [cells | nodes] sequence; NULL to skip).
- *   W_pos [H][K] f32 row-major (the nn.Linear weight as is), pos_fts [B][196][K] f32 */
+ *   W_pos [K][H] f32: the nn.Linear(K, H) weight TRANSPOSED (built once per weight version), pos_fts [B][196][K] f32 */
 int gridmm_cells_embed(const float* proj, const float* pos_fts, int K, const float* W_pos, const float* b_pos,
                        const float* gamma, const float* beta, float eps, const uint8_t* occ, float* out,
                        uint8_t* mask, int mask_bs, const uint8_t* tail_mask, int n_tail, int32_t* n_cells,
-                       int32_t* cmax, int B, int H, int S_pad, gridmm_stream_t stream);
+                       int32_t* cmax, int B, int H, int S_pad, int c_pad, gridmm_stream_t stream);
+/* (c_pad: cell rows of the padded sequence, <= 196; 0 = 196.  The reference cuts the sequence to the batch's largest
+ * occupied-cell count, vilmodel.py:809-823 / ops.py:46-68 pad_tensors_wgrad; a caller that knows a bound c_pad >= cmax --
+ * e.g. the previous step's cmax rounded up to a bucket -- gets the same result on c_pad + n_tail rows: rows [0, c_pad) and
+ * mask columns [0, c_pad) are written, the tail mask follows at column c_pad; cmax > c_pad truncates: check cmax and redo.) */
 
 /* Position embeddings of graph nodes / candidate views: out[m] = LN(W pos[m] + b) * gamma + beta (+ add1[m])
  * (+ table[idx[m]]) for up to two row segments in one launch (vilmodel.py:828-833: gmap_pos_embeddings + image embeds +
@@ -340,7 +344,7 @@ int gridmm_cells_embed(const float* proj, const float* pos_fts, int K, const flo
  *   q_masks [b]             = [gmap_masks[b] (G) | vp_masks[b] (V)]    (contiguous [B][G+V]; NULL to skip) */
 typedef struct {
   const float* pos; int K;                       /* [M][K] position features, K <= 16 */
-  const float *W, *bias, *gamma, *beta; float eps; /* nn.Linear(K, H) weight [H][K] + bias, LayerNorm */
+  const float *W, *bias, *gamma, *beta; float eps; /* nn.Linear(K, H) weight TRANSPOSED [K][H] + bias, LayerNorm */
   const float* add1; int ld1;                    /* [M][ld1] or NULL */
   const float* table; const int64_t* idx;        /* embedding table [.][H] + row index [M], or NULL */
   float* out; void *out_hi, *out_lo; int out_rpb; int64_t out_bs;

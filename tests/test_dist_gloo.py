@@ -208,3 +208,62 @@ def test_gradient_reducer_hooks_overlap_and_task_switching_world2():
         early = res[r][1]
         assert early[0] == 0 and early[1] == 0          # first sight of each task: nothing to predict from
         assert early[2] > 0 and early[3] > 0 and early[4] > 0   # known used-sets: buckets go out during backward
+
+
+def _mixed_worker(rank, world, port, algo, payload, q):
+    """ranks that use DIFFERENT parameter subsets for the same announced key, several steps, early launches on:
+    the collective order must not depend on the rank (it hung / aborted with rank-dependent launches)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gridmm_amd import dist as D
+    model = _Tiny()
+    red = D.GradientReducer(model.parameters(), bucket_mb=1e-4, overlap=True, algo=algo, payload=payload)
+    g = torch.Generator().manual_seed(23)
+    outs = []
+    for step in range(4):
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+        xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+        for p in model.parameters():
+            p.grad = None
+        red.expect("x")
+        # step 2 swaps the heads on both ranks (a deviation from the remembered path of key "x" on every rank)
+        task = ("a" if rank == 0 else "b") if step != 2 else ("b" if rank == 0 else "a")
+        _tiny_loss(model, xs, ys, task).backward()
+        red.reduce()
+        outs.append({k: (None if p.grad is None else p.grad.detach().numpy().copy()) for k, p in model.named_parameters()})
+    q.put((rank, outs, dict(red.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo,payload", [("ring", "fp32"), ("direct", "fp32"), ("direct", "bf16")])
+def test_gradient_reducer_mixed_usage_multi_step_world2(algo, payload):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mixed_worker, args=(r, world, port, algo, payload, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (o, st) for r, o, st in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _Tiny()
+    g = torch.Generator().manual_seed(23)
+    tol = 1e-6 if payload == "fp32" else 2.0 ** -7
+    for step in range(4):
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+        for p in model.parameters():
+            p.grad = None
+        t0, t1 = ("a", "b") if step != 2 else ("b", "a")
+        (0.5 * (_tiny_loss(model, x[:4], y[:4], t0) + _tiny_loss(model, x[4:], y[4:], t1))).backward()
+        for k, p in model.named_parameters():
+            for r in range(world):
+                got = res[r][0][step][k]
+                if p.grad is None:
+                    assert got is None, (step, k)
+                else:
+                    assert got is not None, (step, k)
+                    err = (torch.from_numpy(got) - p.grad).abs().max().item()
+                    assert err <= tol * max(1.0, p.grad.abs().max().item()), (step, k, err)
+    assert res[0][1]["launched_early"] > 0 and res[1][1]["launched_early"] > 0      # overlap stayed on

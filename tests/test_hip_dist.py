@@ -126,3 +126,27 @@ def test_bench_two_ranks_on_one_gpu_prints_n_gpus_2():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["global_batch"] == 16
     assert d["replay_check"]["replay_vs_eager_max_abs"] <= 1e-6
+
+
+def test_bench_train_leg_two_ranks_exchanges_gradients():
+    """The multi-rank training leg of bench.py (config 3's measuring path): both ranks on this GPU (gloo), every rank runs the
+    full-size pre-training step, GradientReducer exchanges the gradients (direct reduce-scatter / all-gather form), the
+    captured variant replays forward + backward and exchanges eagerly; rank 0 reports whole-job samples/s + the exchange
+    timings."""
+    env = dict(os.environ, GRIDMM_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", GRIDMM_BENCH_TRAIN_STEPS="1",
+               GRIDMM_EXCHANGE_ALGO="direct")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--no-roofline", "--no-depth-legs", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-producer-leg"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    t = d["train"]
+    assert "error" not in t, t
+    assert t["n_gpus"] == 2 and t["global_batch"] == 8 and t["train_samples_per_s"] > 0
+    ex = t["exchange"]
+    assert ex["world"] == 2 and ex["algo"] == "direct" and ex["allreduce_ms"] > 0 and ex["buckets"] >= 4
+    assert set(ex["exchange_alone_ms"]) >= {"ring_fp32", "direct_fp32", "direct_bf16"}
+    assert ex["reducer_stats"]["launched_early"] > 0          # known tasks: buckets left during backward
