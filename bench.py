@@ -239,6 +239,48 @@ def config_legs(args, dev, steps):
     return res
 
 
+def rollout_leg(args, dev, rollouts=3):
+    """End to end: GMapNavAgent.rollout (map_nav_src/r2r/agent.py:268-451) over the synthetic environment, B = 32
+    episodes x up to 15 steps at the BASELINE observation shape -- 'language' once, then per step 'panorama', TopoMap
+    update, input collation, fill_gridmap, 'navigation', action selection, env step (argmax feedback, no_grad, varlen map
+    sequences on).  value = episode-steps / wall second of whole rollouts; the second pass synchronises around every
+    section to show where the wall time goes (host sections are Python)."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.sim_env import SyntheticNavEnv
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    geom, B, T = S.BASELINE, args.batch, 15
+    torch.manual_seed(0)
+    model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim)).eval().to(dev)
+    model.varlen_buckets = GlocalTextPathNavCMT.DEFAULT_BUCKETS
+    mem = GridMemoryBatch(B, geom, max_steps=T + 2, device=dev)
+    env = SyntheticNavEnv(B, mem, n_scans=4, n_episodes=4 * B, seed=3, geom=geom, vocab=30000)
+    agent = GMapNavAgent(default_args(max_action_len=T), env, model, device=dev)
+    agent.feedback = "argmax"
+    agent._set_mode(False)
+    with torch.no_grad():
+        agent.rollout()                       # fills the environment's feature memo, packs the weights
+        torch.cuda.synchronize()
+        n0, t0 = agent.nav_steps, time.perf_counter()
+        for _ in range(rollouts):
+            agent.rollout()
+        torch.cuda.synchronize()
+        dt, steps = time.perf_counter() - t0, agent.nav_steps - n0
+        agent.timers = {}
+        n1 = agent.nav_steps
+        agent.rollout()
+        torch.cuda.synchronize()
+        prof_steps = agent.nav_steps - n1
+    tot = sum(agent.timers.values())
+    return {"value": B * steps / dt, "unit": "episode-steps/s", "ms_per_step": 1e3 * dt / steps, "batch": B,
+            "steps_per_rollout": steps / rollouts, "max_action_len": T,
+            "sections_ms_per_step": {k: 1e3 * v / prof_steps for k, v in sorted(agent.timers.items(), key=lambda kv: -kv[1])},
+            "host_share": sum(v for k, v in agent.timers.items() if k.startswith("host") or k.startswith("env")) / tot,
+            "workload": "GMapNavAgent.rollout, synthetic buildings (24 viewpoints, 36 views, 36x196x512 observations), "
+                        "argmax actions, eager launches, varlen map sequences"}
+
+
 def producer_leg(args, dev, steps=5):
     """Config 5's shape with the PRODUCER in the timed region: per step the CLIP ViT-B/32 tower encodes the
     12 view images of every episode (B x 12 x 3 x 224 x 224, already normalised and resident), writes the patch tokens
@@ -641,6 +683,11 @@ def main():
         out["sparse_map"] = sparse_map_leg(args, dev, dist, max(5, args.steps // 2))
     if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1:
         out.update(config_legs(args, dev, max(5, args.steps // 2)))
+    if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1:
+        try:
+            out["rollout"] = rollout_leg(args, dev)
+        except Exception as e:      # a secondary key: reported in the line, the headline measurement stands
+            out["rollout"] = {"error": repr(e)[:300]}
     if not args.no_train_leg:
         # config 3's shape: the pre-training step on EVERY rank with the RCCL gradient exchange (whole-job samples/s)
         tl = train_leg_subprocess(args, n_gpus)

@@ -210,8 +210,23 @@ class GMapNavAgent:
                 d[cand["viewpointId"]] = int(cand["pointId"])
 
     # ---- the loop --------------------------------------------------------------------------------
+    def _tick(self, name, t0):
+        """bench.py's rollout leg: with self.timers (a dict) set, wall time per section incl. a device synchronize."""
+        if self.timers is None:
+            return 0.0
+        import time
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        if t0:
+            self.timers[name] = self.timers.get(name, 0.0) + (t - t0)
+        return t
+
+    timers = None
+
     def rollout(self, train_ml=None, reset=True):
+        t0 = self._tick(None, 0.0)
         obs = self.env.reset() if reset else self.env._get_obs()
+        t0 = self._tick("env (grid memory step + observation dicts)", t0)
         self._update_scanvp_cands(obs)
         B = len(obs)
         gmaps = [TopoMap(ob["viewpoint"]) for ob in obs]
@@ -221,18 +236,22 @@ class GMapNavAgent:
 
         language_inputs = self._language_variable(obs)
         txt_embeds = self.vln_bert("language", language_inputs)
+        t0 = self._tick("language", t0)
 
         ended = np.array([False] * B)
         just_ended = np.array([False] * B)
         ml_loss = 0.0
 
         for t in range(self.args.max_action_len):
+            self.nav_steps = getattr(self, "nav_steps", 0) + 1
             for i, gmap in enumerate(gmaps):
                 if not ended[i]:
                     gmap.step_id[obs[i]["viewpoint"]] = t + 1
 
             pano_inputs = self._panorama_feature_variable(obs)
+            t0 = self._tick("host: collate panorama inputs", t0)
             pano_embeds, pano_masks = self.vln_bert("panorama", pano_inputs)
+            t0 = self._tick("panorama", t0)
             avg_pano = torch.sum(pano_embeds * pano_masks.unsqueeze(2), 1) / torch.sum(pano_masks, 1, keepdim=True)
             for i, gmap in enumerate(gmaps):
                 if not ended[i]:
@@ -245,7 +264,9 @@ class GMapNavAgent:
             nav_inputs.update(self._nav_vp_variable(obs, gmaps, pano_embeds, pano_inputs["cand_vpids"],
                                                     pano_inputs["view_lens"], pano_inputs["nav_types"]))
             nav_inputs.update({"txt_embeds": txt_embeds, "txt_masks": language_inputs["txt_masks"]})
+            t0 = self._tick("host: TopoMap update + collate navigation inputs", t0)
             nav_outs = self.vln_bert("navigation", nav_inputs)
+            t0 = self._tick("navigation", t0)
 
             if self.args.fusion == "local":
                 nav_logits, nav_vpids = nav_outs["local_logits"], nav_inputs["vp_cand_vpids"]
@@ -317,7 +338,9 @@ class GMapNavAgent:
                     if stop_node is not None and obs[i]["viewpoint"] != stop_node:
                         traj[i]["path"].append(gmaps[i].route(obs[i]["viewpoint"], stop_node))
 
+            t0 = self._tick("host: action selection + env step", t0)
             obs = self.env._get_obs()
+            t0 = self._tick("env (grid memory step + observation dicts)", t0)
             self._update_scanvp_cands(obs)
             for i, ob in enumerate(obs):
                 if not ended[i]:
@@ -365,8 +388,10 @@ class GMapNavAgent:
             self.critic = Critic(self.args).to(self.device)
         if not hasattr(self, "vln_bert_optimizer"):
             self.make_optimizer()
-        if not hasattr(self, "critic_optimizer"):
-            self.critic_optimizer = torch.optim.AdamW(self.critic.parameters(), lr=self.args.lr)
+        if not hasattr(self, "critic_optimizer"):    # agent_base.py:122-139: the same optimizer class as vln_bert's
+            opt = {"rms": torch.optim.RMSprop, "adam": torch.optim.Adam, "adamW": torch.optim.AdamW,
+                   "sgd": torch.optim.SGD}[self.args.optim]
+            self.critic_optimizer = opt(self.critic.parameters(), lr=self.args.lr)
         return (("vln_bert", self.vln_bert, self.vln_bert_optimizer), ("critic", self.critic, self.critic_optimizer))
 
     def save(self, epoch, path):
@@ -395,7 +420,16 @@ class GMapNavAgent:
             have.update(given)
             model.load_state_dict(have)
             if getattr(self.args, "resume_optimizer", False):
+                defaults = [dict(g) for g in opt.param_groups]
                 opt.load_state_dict(states[name]["optimizer"])
+                from .optim import AdamW
+                if isinstance(opt, AdamW):    # a torch.optim.AdamW state (reference checkpoint): restore what it does not carry
+                    for g, d in zip(opt.param_groups, defaults):
+                        for k in ("correct_bias", "decay_first"):
+                            g.setdefault(k, d[k])
+                    for st in opt.state.values():
+                        if torch.is_tensor(st.get("step")):
+                            st["step"] = int(st["step"].item())
         return states["vln_bert"]["epoch"] - 1
 
     def make_optimizer(self):

@@ -12,18 +12,12 @@ namespace {
 constexpr int NV = 4;        // float4 per lane: H <= 1024
 constexpr int MAXK = 16;     // position feature widths on this path: 5, 7, 14
 
-// W^T [K][H] (the nn.Linear weight transposed once on the host) -> LDS: coalesced 128-bit copies; the row loop then reads
-// one conflict-free ds_read_b128 per lane, k and 4 outputs
-__device__ __forceinline__ void stage_wt(const float* __restrict__ WT, int K, int H, float* __restrict__ wT) {
-  const int n4 = (K * H) >> 2;
-#pragma unroll 4
-  for (int i = threadIdx.x; i < n4; i += blockDim.x)
-    reinterpret_cast<float4*>(wT)[i] = reinterpret_cast<const float4*>(WT)[i];
-}
-
 // y[c] (c = lane + 64 i) = LN(W f + b) * gamma + beta for one row, one wave; fval: lane k < K holds the row's k-th
-// position feature (broadcast by v_readlane), wT: stage_wt image.
-__device__ __forceinline__ void pos_embed_row(float fval, int K, const float* __restrict__ wT,
+// position feature (broadcast by v_readlane); WT = W^T [K][H] (the nn.Linear weight transposed once on the host): lanes
+// read it as coalesced float4 straight from L1 / L2 (15-43 KB, shared by every row of the launch), all K x 3 loads
+// independent of each other so they fly together.  KT > 0: compile-time K (5 / 7 / 14 on this path), else runtime K.
+template <int KT>
+__device__ __forceinline__ void pos_embed_row(float fval, int K, const float* __restrict__ WT,
                                               const float* __restrict__ bias, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, float eps, int H, int lane, float4* y) {
   const int nv = H >> 2;
@@ -33,9 +27,9 @@ __device__ __forceinline__ void pos_embed_row(float fval, int K, const float* __
     const int c = lane + i * 64;
     y[i] = (c < nv) ? reinterpret_cast<const float4*>(bias)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int k = 0; k < K; ++k) {
+  auto step = [&](int k) {
     const float fk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fval), k));
-    const float4* wr = reinterpret_cast<const float4*>(wT + (size_t)k * H);
+    const float4* wr = reinterpret_cast<const float4*>(WT + (size_t)k * H);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
@@ -44,6 +38,12 @@ __device__ __forceinline__ void pos_embed_row(float fval, int K, const float* __
         y[i].x += fk * w.x; y[i].y += fk * w.y; y[i].z += fk * w.z; y[i].w += fk * w.w;
       }
     }
+  };
+  if (KT > 0) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) step(k);
+  } else {
+    for (int k = 0; k < K; ++k) step(k);
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -75,67 +75,80 @@ __device__ __forceinline__ void pos_embed_row(float fval, int K, const float* __
   }
 }
 
-// grid (B, 14): block (b, s) writes output rows [14 s, 14 s + 14) of episode b.  Compaction + mask exactly as
-// cells_compact_kernel (rowops.hip; vilmodel.py:813-823 with its in-place view quirk); the position embedding of a
-// compacted row is computed here from the 5 cell-centre features of its source cell.
+template <typename F>
+__device__ __forceinline__ void dispatch_k(int K, F&& f) {     // f.template operator()<KT>()
+  if (K == 5) f.template operator()<5>();
+  else if (K == 7) f.template operator()<7>();
+  else if (K == 14) f.template operator()<14>();
+  else f.template operator()<0>();
+}
+
+// grid (B, 49): block (b, s) writes output rows [4 s, 4 s + 4) of episode b, one wave per row.  Compaction + mask exactly
+// as cells_compact_kernel (rowops.hip; vilmodel.py:813-823 with its in-place view quirk); the position embedding of a
+// compacted row is computed here from the K cell-centre features of its source cell.  Only the blocks of slice 0 count
+// the occupied cells of the other episodes (cmax, for the mask): one 4-byte word of occupancy bits per lane and episode.
 __global__ __launch_bounds__(256) void cells_embed_kernel(
-    const float* __restrict__ proj, const float* __restrict__ pos_fts, int K, const float* __restrict__ Wp,
+    const float* __restrict__ proj, const float* __restrict__ pos_fts, int K, const float* __restrict__ WpT,
     const float* __restrict__ bp, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const uint8_t* __restrict__ occ, float* __restrict__ out, uint8_t* __restrict__ mask, int mask_bs,
     const uint8_t* __restrict__ tail_mask, int n_tail, int32_t* __restrict__ n_cells, int32_t* __restrict__ cmax_out,
     int B, int H, int S_pad, int c_pad) {
-  __shared__ int s_rank[GRIDMM_CELLS];
   __shared__ int s_src[GRIDMM_CELLS];
   __shared__ int s_n, s_tail, s_cmax;
   __shared__ int s_wmax[4];
-  extern __shared__ float s_wT[];   // K * H floats
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  stage_wt(Wp, K, H, s_wT);
-  int wmax = 0;
-  for (int e = wave; e < B; e += 4) {
-    int n = 0;
-    for (int c0 = 0; c0 < GRIDMM_CELLS; c0 += 64) {
-      const int c = c0 + lane;
-      const bool o = (c < GRIDMM_CELLS) && occ[e * GRIDMM_CELLS + c];
-      n += __popcll(__ballot(o));
+  constexpr int WORDS = GRIDMM_CELLS / 4;      // 49 words of 4 occupancy bytes (0 / 1) per episode
+  if (blockIdx.y == 0) {
+    int wmax = 0;
+    const uint32_t* ow = reinterpret_cast<const uint32_t*>(occ);
+    for (int e0 = wave; e0 < B; e0 += 16) {    // 4 episodes per trip: the loads are independent
+      uint32_t w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 4 * u;
+        w[u] = (e < B && lane < WORDS) ? ow[(size_t)e * WORDS + lane] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = (int)wave_sum((float)__popc(w[u]));
+        wmax = n > wmax ? n : wmax;
+      }
     }
-    wmax = n > wmax ? n : wmax;
+    if (lane == 0) s_wmax[wave] = wmax;
   }
-  if (lane == 0) s_wmax[wave] = wmax;
-  if (wave == 0) {
+  if (wave == 0) {                             // ranks of this episode's occupied cells (ballot prefix)
     int base = 0;
     for (int c0 = 0; c0 < GRIDMM_CELLS; c0 += 64) {
       const int c = c0 + lane;
       const bool o = (c < GRIDMM_CELLS) && occ[b * GRIDMM_CELLS + c];
       const unsigned long long m = __ballot(o);
       const int r = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (c < GRIDMM_CELLS) s_rank[c] = o ? r : -1;
       if (o) s_src[r] = c;
       base += __popcll(m);
     }
     if (lane == 0) s_n = base;
   }
   __syncthreads();
-  if (wave == 0) {
-    const int n = s_n;
-    int tail = 0;
-    for (int c0 = 0; c0 < GRIDMM_CELLS; c0 += 64) {
-      const int c = c0 + lane;
-      const bool o = (c >= n) && (c < GRIDMM_CELLS) && occ[b * GRIDMM_CELLS + c];
-      tail += __popcll(__ballot(o));
-    }
-    if (lane == 0) {
-      int cmax = s_wmax[0];
-      for (int w = 1; w < 4; ++w) cmax = s_wmax[w] > cmax ? s_wmax[w] : cmax;
-      s_tail = n + tail;
-      s_cmax = cmax;
-      if (blockIdx.y == 0) n_cells[b] = n;
-      if (b == 0 && blockIdx.y == 0) cmax_out[0] = cmax;
-    }
-  }
-  __syncthreads();
-  const int n = s_n, lim = s_tail, cmax = s_cmax;
   if (blockIdx.y == 0) {
+    if (wave == 0) {
+      const int n = s_n;
+      int tail = 0;
+      for (int c0 = 0; c0 < GRIDMM_CELLS; c0 += 64) {
+        const int c = c0 + lane;
+        const bool o = (c >= n) && (c < GRIDMM_CELLS) && occ[b * GRIDMM_CELLS + c];
+        tail += __popcll(__ballot(o));
+      }
+      if (lane == 0) {
+        int cmax = s_wmax[0];
+        for (int w = 1; w < 4; ++w) cmax = s_wmax[w] > cmax ? s_wmax[w] : cmax;
+        s_tail = n + tail;
+        s_cmax = cmax;
+        n_cells[b] = n;
+        if (b == 0) cmax_out[0] = cmax;
+      }
+    }
+    __syncthreads();
+    const int n = s_n, lim = s_tail, cmax = s_cmax;
     for (int p = tid; p < c_pad; p += blockDim.x) {
       uint8_t m;
       if (p < n) m = 1;
@@ -147,33 +160,33 @@ __global__ __launch_bounds__(256) void cells_embed_kernel(
     if (tail_mask)
       for (int j = tid; j < n_tail; j += blockDim.x) mask[(size_t)b * mask_bs + c_pad + j] = tail_mask[b * n_tail + j];
   }
-  const int nv = H >> 2;
-  float* ob = out + (size_t)b * S_pad * H;
-  const int p_lo = blockIdx.y * GRIDMM_GRID;
-  for (int r = wave; r < GRIDMM_GRID; r += 4) {
-    const int p = p_lo + r;
-    if (p >= c_pad) break;           // a sequence padded to c_pad < 196 cell rows (valid when cmax <= c_pad)
-    float* orow = ob + (size_t)p * H;
-    if (p < n) {
-      const int c = s_src[p];
-      const float fval = lane < K ? pos_fts[((size_t)b * GRIDMM_CELLS + c) * K + lane] : 0.f;
-      float4 y[NV];
-      pos_embed_row(fval, K, s_wT, bp, gamma, beta, eps, H, lane, y);
-      const float* prow = proj + ((size_t)b * GRIDMM_CELLS + c) * H;
+  const int n = s_n, nv = H >> 2;
+  const int p = blockIdx.y * 4 + wave;
+  if (p >= c_pad) return;                      // a sequence padded to c_pad < 196 cell rows (valid when cmax <= c_pad)
+  float* orow = out + ((size_t)b * S_pad + p) * H;
+  if (p < n) {
+    const int c = s_src[p];
+    const float fval = lane < K ? pos_fts[((size_t)b * GRIDMM_CELLS + c) * K + lane] : 0.f;
+    const float* prow = proj + ((size_t)b * GRIDMM_CELLS + c) * H;
+    float4 a[NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int ci = lane + i * 64;
-        if (ci < nv) {
-          const float4 a = reinterpret_cast<const float4*>(prow)[ci];
-          reinterpret_cast<float4*>(orow)[ci] = make_float4(a.x + y[i].x, a.y + y[i].y, a.z + y[i].z, a.w + y[i].w);
-        }
-      }
-    } else {
+    for (int i = 0; i < NV; ++i) {
+      const int ci = lane + i * 64;
+      a[i] = ci < nv ? reinterpret_cast<const float4*>(prow)[ci] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 y[NV];
+    dispatch_k(K, [&]<int KT>() { pos_embed_row<KT>(fval, K, WpT, bp, gamma, beta, eps, H, lane, y); });
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int ci = lane + i * 64;
-        if (ci < nv) reinterpret_cast<float4*>(orow)[ci] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+    for (int i = 0; i < NV; ++i) {
+      const int ci = lane + i * 64;
+      if (ci < nv)
+        reinterpret_cast<float4*>(orow)[ci] = make_float4(a[i].x + y[i].x, a[i].y + y[i].y, a[i].z + y[i].z, a[i].w + y[i].w);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int ci = lane + i * 64;
+      if (ci < nv) reinterpret_cast<float4*>(orow)[ci] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -183,16 +196,14 @@ struct NodeSegs {
   int n;
 };
 
-// 16 rows of ONE segment per block (4 per wave; the segment's W^T staged in LDS once); blocks [0, B) also assemble the byte
-// masks of their episode
-constexpr int NE_ROWS = 16;
-__global__ __launch_bounds__(256) void node_embed_kernel(const NodeSegs segs, int blocks0, int H,
+// one wave per row over the rows of both segments (4 rows per block); blocks [0, B) also assemble the byte masks of their
+// episode
+__global__ __launch_bounds__(256) void node_embed_kernel(const NodeSegs segs, int H,
                                                          const uint8_t* __restrict__ gmap_m, int G,
                                                          const uint8_t* __restrict__ vp_m, int V,
                                                          const uint8_t* __restrict__ txt_m, int L,
                                                          uint8_t* __restrict__ kv_masks, int kv_bs, int kv_col0,
                                                          uint8_t* __restrict__ q_masks, int B) {
-  extern __shared__ float s_wT[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x < B) {
     const int b = blockIdx.x;
@@ -205,45 +216,44 @@ __global__ __launch_bounds__(256) void node_embed_kernel(const NodeSegs segs, in
       for (int j = threadIdx.x; j < V; j += blockDim.x) q_masks[(size_t)b * (G + V) + G + j] = vp_m[b * V + j];
     }
   }
-  const int si = ((int)blockIdx.x >= blocks0) ? 1 : 0;
-  if (si >= segs.n) return;
+  int row = blockIdx.x * 4 + wave, si = 0;
+  if (segs.n > 1 && row >= segs.s[0].M) { row -= segs.s[0].M; si = 1; }
   const gridmm_embed_seg_t& S = segs.s[si];
-  const int row0 = ((int)blockIdx.x - (si ? blocks0 : 0)) * NE_ROWS;
-  if (row0 >= S.M) return;
+  if (row >= S.M) return;
   const int K = S.K, nv = H >> 2;
-  stage_wt(S.W, K, H, s_wT);
-  __syncthreads();
-  unsigned short *ohi = (unsigned short*)S.out_hi, *olo = (unsigned short*)S.out_lo;
-  for (int r = wave; r < NE_ROWS; r += 4) {
-    const int row = row0 + r;
-    if (row >= S.M) break;
-    const float fval = lane < K ? S.pos[(size_t)row * K + lane] : 0.f;
-    float4 y[NV];
-    pos_embed_row(fval, K, s_wT, S.bias, S.gamma, S.beta, S.eps, H, lane, y);
-    const float* trow = (S.table && S.idx) ? S.table + (size_t)S.idx[row] * H : nullptr;
-    size_t off = (size_t)row * H;
-    if (S.out_rpb > 0) { const int eb = row / S.out_rpb; off = (size_t)eb * S.out_bs + (size_t)(row - eb * S.out_rpb) * H; }
+  const float fval = lane < K ? S.pos[(size_t)row * K + lane] : 0.f;
+  const float* trow = (S.table && S.idx) ? S.table + (size_t)S.idx[row] * H : nullptr;
+  float4 ad[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = lane + i * 64;
-      if (c < nv) {
-        float4 v = y[i];
-        if (S.add1) {
-          const float4 a = reinterpret_cast<const float4*>(S.add1 + (size_t)row * S.ld1)[c];
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-        }
-        if (trow) {
-          const float4 a = reinterpret_cast<const float4*>(trow)[c];
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-        }
-        if (S.out) reinterpret_cast<float4*>(S.out + off)[c] = v;
-        if (ohi) {
-          uint2 hi, lo;
-          split2_bf16(v.x, v.y, hi.x, lo.x);
-          split2_bf16(v.z, v.w, hi.y, lo.y);
-          reinterpret_cast<uint2*>(ohi + off)[c] = hi;
-          reinterpret_cast<uint2*>(olo + off)[c] = lo;
-        }
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv) {
+      if (S.add1) v = reinterpret_cast<const float4*>(S.add1 + (size_t)row * S.ld1)[c];
+      if (trow) {
+        const float4 t = reinterpret_cast<const float4*>(trow)[c];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+    }
+    ad[i] = v;
+  }
+  float4 y[NV];
+  dispatch_k(K, [&]<int KT>() { pos_embed_row<KT>(fval, K, S.W, S.bias, S.gamma, S.beta, S.eps, H, lane, y); });
+  size_t off = (size_t)row * H;
+  if (S.out_rpb > 0) { const int eb = row / S.out_rpb; off = (size_t)eb * S.out_bs + (size_t)(row - eb * S.out_rpb) * H; }
+  unsigned short *ohi = (unsigned short*)S.out_hi, *olo = (unsigned short*)S.out_lo;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 v = make_float4(y[i].x + ad[i].x, y[i].y + ad[i].y, y[i].z + ad[i].z, y[i].w + ad[i].w);
+      if (S.out) reinterpret_cast<float4*>(S.out + off)[c] = v;
+      if (ohi) {
+        uint2 hi, lo;
+        split2_bf16(v.x, v.y, hi.x, lo.x);
+        split2_bf16(v.z, v.w, hi.y, lo.y);
+        reinterpret_cast<uint2*>(ohi + off)[c] = hi;
+        reinterpret_cast<uint2*>(olo + off)[c] = lo;
       }
     }
   }
@@ -382,7 +392,7 @@ extern "C" int gridmm_cells_embed(const float* proj, const float* pos_fts, int K
   if (B <= 0 || H <= 0 || H % 4 || H > 1024 || K <= 0 || K > MAXK || c_pad > GRIDMM_CELLS ||
       S_pad < c_pad + (tail_mask ? n_tail : 0) || mask_bs < c_pad + (tail_mask ? n_tail : 0))
     return GRIDMM_EINVAL;
-  GRIDMM_LAUNCH(cells_embed_kernel, dim3(B, (c_pad + GRIDMM_GRID - 1) / GRIDMM_GRID), dim3(256), (size_t)K * H * sizeof(float), as_stream(stream), proj, pos_fts, K, W_pos, b_pos,
+  GRIDMM_LAUNCH(cells_embed_kernel, dim3(B, (c_pad + 3) / 4), dim3(256), 0, as_stream(stream), proj, pos_fts, K, W_pos, b_pos,
                 gamma, beta, eps, occ, out, mask, mask_bs, tail_mask, n_tail, n_cells, cmax, B, H, S_pad, c_pad);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
@@ -406,14 +416,10 @@ extern "C" int gridmm_node_embed(const gridmm_embed_seg_t* segs, int n_segs, int
   if ((kv_masks || q_masks) && (!gmap_masks || G <= 0)) return GRIDMM_EINVAL;
   if (kv_masks && (!txt_masks || kv_bs < kv_col0 + G + L)) return GRIDMM_EINVAL;
   if (q_masks && (!vp_masks || V <= 0)) return GRIDMM_EINVAL;
-  const int blocks0 = (a.s[0].M + NE_ROWS - 1) / NE_ROWS;
-  int blocks = blocks0 + (n_segs > 1 ? (a.s[1].M + NE_ROWS - 1) / NE_ROWS : 0), maxk = a.s[0].K;
-  if (n_segs > 1 && a.s[1].K > maxk) maxk = a.s[1].K;
+  int blocks = (rows + 3) / 4;
   if ((kv_masks || q_masks) && blocks < B) blocks = B;
-  (void)rows;
-  GRIDMM_LAUNCH(node_embed_kernel, dim3(blocks), dim3(256), (size_t)maxk * H * sizeof(float), as_stream(stream), a, blocks0,
-                H, gmap_masks, G, vp_masks, V, txt_masks, L, kv_masks, kv_bs, kv_col0, q_masks,
-                (kv_masks || q_masks) ? B : 0);
+  GRIDMM_LAUNCH(node_embed_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a, H, gmap_masks, G, vp_masks, V, txt_masks,
+                L, kv_masks, kv_bs, kv_col0, q_masks, (kv_masks || q_masks) ? B : 0);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
