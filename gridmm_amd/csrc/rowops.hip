@@ -8,7 +8,11 @@ namespace {
 constexpr int MAX_H = 1024;  // hidden sizes on this path: 768
 
 // One wave per row; H % 4 == 0; each lane holds H/256 float4 (3 for H = 768).
-template <int NV>
+// FULL (H == 256 * NV: every lane owns exactly NV chunks): no per-chunk guards, so the loads of a phase are issued
+// together -- with guards the compiler emits one branch + one s_waitcnt per chunk and operand, i.e. ~10 serialised memory
+// round trips per row, which is what a 1824-row launch (456 workgroups, one round) costs; gamma / beta / add1 / table rows
+// are fetched BEFORE the two wave reductions so that they fly under them.
+template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ R, int ldr,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -21,53 +25,62 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   size_t poff = (size_t)row * ldp;   // planes through the batched row map (gridmm_layernorm_map)
   if (p_rpb > 0) { const int eb = row / p_rpb; poff = (size_t)eb * p_bs + (size_t)(row - eb * p_rpb) * ldp; }
   const int nv = H >> 2;  // float4 per row
-  float4 v[NV];
-  float s = 0.f;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto ok = [&](int i) { return FULL || lane + i * 64 < nv; };
+  float4 v[NV], g[NV], bt[NV], ex[NV], tb[NV];
+  const float4* xr = reinterpret_cast<const float4*>(X + (size_t)row * ldx);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = ok(i) ? xr[lane + i * 64] : zero4;
+  if (R) {
+    const float4* rr = reinterpret_cast<const float4*>(R + (size_t)row * ldr);
+    float4 r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = ok(i) ? rr[lane + i * 64] : zero4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i].x += r[i].x; v[i].y += r[i].y; v[i].z += r[i].z; v[i].w += r[i].w; }
+  }
+  // operands of the output phase: issued now, consumed after the reductions
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < nv) {
-      x = reinterpret_cast<const float4*>(X + (size_t)row * ldx)[c];
-      if (R) {
-        const float4 r = reinterpret_cast<const float4*>(R + (size_t)row * ldr)[c];
-        x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
-      }
-      s += (x.x + x.y) + (x.z + x.w);
-    }
-    v[i] = x;
+    g[i] = ok(i) ? reinterpret_cast<const float4*>(gamma)[lane + i * 64] : zero4;
+    bt[i] = ok(i) ? reinterpret_cast<const float4*>(beta)[lane + i * 64] : zero4;
+    ex[i] = zero4;
+    tb[i] = zero4;
   }
+  if (add1) {
+    const float4* ar = reinterpret_cast<const float4*>(add1 + (size_t)row * ld1);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (ok(i)) ex[i] = ar[lane + i * 64];
+  }
+  if (table && idx) {
+    const float4* tr = reinterpret_cast<const float4*>(table + (size_t)idx[row] * H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (ok(i)) tb[i] = tr[lane + i * 64];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);     // absent chunks are zero
   const float mean = wave_sum(s) / (float)H;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
+    if (ok(i)) {
       const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (cc * cc + d * d);
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
-  const float* trow = (table && idx) ? table + (size_t)idx[row] * H : nullptr;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
-    if (c < nv) {
-      const float4 g = reinterpret_cast<const float4*>(gamma)[c];
-      const float4 b = reinterpret_cast<const float4*>(beta)[c];
+    if (ok(i)) {
       float4 y;
-      y.x = (v[i].x - mean) * rstd * g.x + b.x;
-      y.y = (v[i].y - mean) * rstd * g.y + b.y;
-      y.z = (v[i].z - mean) * rstd * g.z + b.z;
-      y.w = (v[i].w - mean) * rstd * g.w + b.w;
-      if (add1) {
-        const float4 a = reinterpret_cast<const float4*>(add1 + (size_t)row * ld1)[c];
-        y.x += a.x; y.y += a.y; y.z += a.z; y.w += a.w;
-      }
-      if (trow) {
-        const float4 a = reinterpret_cast<const float4*>(trow)[c];
-        y.x += a.x; y.y += a.y; y.z += a.z; y.w += a.w;
-      }
+      y.x = (v[i].x - mean) * rstd * g[i].x + bt[i].x;
+      y.y = (v[i].y - mean) * rstd * g[i].y + bt[i].y;
+      y.z = (v[i].z - mean) * rstd * g[i].z + bt[i].z;
+      y.w = (v[i].w - mean) * rstd * g[i].w + bt[i].w;
+      if (add1) { y.x += ex[i].x; y.y += ex[i].y; y.z += ex[i].z; y.w += ex[i].w; }
+      if (table && idx) { y.x += tb[i].x; y.y += tb[i].y; y.z += tb[i].z; y.w += tb[i].w; }
       if (Y) reinterpret_cast<float4*>(Y + (size_t)row * ldy)[c] = y;
       if (Yhi) {
         const float x[4] = {y.x, y.y, y.z, y.w};
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   }
 }
 
-template <int NV>
+template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void ln_dot_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, const float* __restrict__ w,
@@ -94,24 +107,25 @@ __global__ __launch_bounds__(256) void ln_dot_kernel(
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nv = H >> 2;
-  float4 v[NV];
-  float s = 0.f;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto ok = [&](int i) { return FULL || lane + i * 64 < nv; };
+  float4 v[NV], g[NV], bt[NV], ww[NV];
+  const float4* xr = reinterpret_cast<const float4*>(X + (size_t)row * ldx);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < nv) {
-      x = reinterpret_cast<const float4*>(X + (size_t)row * ldx)[c];
-      s += (x.x + x.y) + (x.z + x.w);
-    }
-    v[i] = x;
+    v[i] = ok(i) ? xr[lane + i * 64] : zero4;
+    g[i] = ok(i) ? reinterpret_cast<const float4*>(gamma)[lane + i * 64] : zero4;
+    bt[i] = ok(i) ? reinterpret_cast<const float4*>(beta)[lane + i * 64] : zero4;
+    ww[i] = ok(i) ? reinterpret_cast<const float4*>(w)[lane + i * 64] : zero4;
   }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   const float mean = wave_sum(s) / (float)H;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
+    if (ok(i)) {
       const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (cc * cc + d * d);
     }
@@ -120,13 +134,9 @@ __global__ __launch_bounds__(256) void ln_dot_kernel(
   float d = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      const float4 g = reinterpret_cast<const float4*>(gamma)[c];
-      const float4 b = reinterpret_cast<const float4*>(beta)[c];
-      const float4 ww = reinterpret_cast<const float4*>(w)[c];
-      d += ((v[i].x - mean) * rstd * g.x + b.x) * ww.x + ((v[i].y - mean) * rstd * g.y + b.y) * ww.y +
-           ((v[i].z - mean) * rstd * g.z + b.z) * ww.z + ((v[i].w - mean) * rstd * g.w + b.w) * ww.w;
+    if (ok(i)) {
+      d += ((v[i].x - mean) * rstd * g[i].x + bt[i].x) * ww[i].x + ((v[i].y - mean) * rstd * g[i].y + bt[i].y) * ww[i].y +
+           ((v[i].z - mean) * rstd * g[i].z + bt[i].z) * ww[i].z + ((v[i].w - mean) * rstd * g[i].w + bt[i].w) * ww[i].w;
     }
   }
   d = wave_sum(d);
@@ -291,10 +301,12 @@ extern "C" int gridmm_layernorm_map(const float* X, int ldx, const float* R, int
   unsigned short *Yhi = (unsigned short*)Y_hi, *Ylo = (unsigned short*)Y_lo;
   dim3 grid((M + 3) / 4), block(256);
   const int nv = (H / 4 + 63) / 64;
-#define GRIDMM_LN(NV)                                                                              \
-  GRIDMM_LAUNCH((layernorm_kernel<NV>), grid, block, 0, as_stream(stream), X, ldx, R, ldr, gamma, \
+  const bool full = (H % 256) == 0;
+#define GRIDMM_LN(NV, F)                                                                              \
+  GRIDMM_LAUNCH((layernorm_kernel<NV, F>), grid, block, 0, as_stream(stream), X, ldx, R, ldr, gamma, \
                      beta, eps, Y, ldy, add1, ld1, table, idx, Yhi, Ylo, ldp, p_rpb, (long)p_bs, M, H)
-  if (nv == 1) GRIDMM_LN(1); else if (nv == 2) GRIDMM_LN(2); else if (nv == 3) GRIDMM_LN(3); else GRIDMM_LN(4);
+  if (full) { if (nv == 1) GRIDMM_LN(1, true); else if (nv == 2) GRIDMM_LN(2, true); else if (nv == 3) GRIDMM_LN(3, true); else GRIDMM_LN(4, true); }
+  else { if (nv == 1) GRIDMM_LN(1, false); else if (nv == 2) GRIDMM_LN(2, false); else if (nv == 3) GRIDMM_LN(3, false); else GRIDMM_LN(4, false); }
 #undef GRIDMM_LN
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
@@ -314,10 +326,12 @@ extern "C" int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const 
   if (M <= 0 || H <= 0 || H % 4 || H > MAX_H || ldx % 4) return GRIDMM_EINVAL;
   dim3 grid((M + 3) / 4), block(256);
   const int nv = (H / 4 + 63) / 64;
-#define GRIDMM_LD(NV)                                                                             \
-  GRIDMM_LAUNCH((ln_dot_kernel<NV>), grid, block, 0, as_stream(stream), X, ldx, gamma, beta, eps, \
+  const bool full = (H % 256) == 0;
+#define GRIDMM_LD(NV, F)                                                                             \
+  GRIDMM_LAUNCH((ln_dot_kernel<NV, F>), grid, block, 0, as_stream(stream), X, ldx, gamma, beta, eps, \
                      w, b0, out, M, H)
-  if (nv == 1) GRIDMM_LD(1); else if (nv == 2) GRIDMM_LD(2); else if (nv == 3) GRIDMM_LD(3); else GRIDMM_LD(4);
+  if (full) { if (nv == 1) GRIDMM_LD(1, true); else if (nv == 2) GRIDMM_LD(2, true); else if (nv == 3) GRIDMM_LD(3, true); else GRIDMM_LD(4, true); }
+  else { if (nv == 1) GRIDMM_LD(1, false); else if (nv == 2) GRIDMM_LD(2, false); else if (nv == 3) GRIDMM_LD(3, false); else GRIDMM_LD(4, false); }
 #undef GRIDMM_LD
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
