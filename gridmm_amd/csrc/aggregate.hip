@@ -463,6 +463,9 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
 int gridmm_grid_relevance_wide(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
                                float* relevance, int32_t* amax, int B, int cap, int D, int L, int n_chunks,
                                hipStream_t st);
+int gridmm_grid_relevance_gemm(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
+                               float* relevance, int32_t* amax, int B, int cap, int D, int L, int n_chunks,
+                               hipStream_t st);
 int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int32_t* cell_start, const float* w,
                                float* cells, uint8_t* occ, float* ws, int B, int cap, int D, int n_chunks,
                                hipStream_t st);
@@ -497,6 +500,13 @@ extern "C" int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm
       gridmm_grid_relevance_wide(slab, perm, cell_start, text_frag, relevance, amax, B, cap, D, L, n_chunks, st) ==
           GRIDMM_OK) {
     // D = 768, L <= 80: relevance pass (text fragments spread over 8 waves) + accumulation pass on the resident slab
+    const int rc = gridmm_grid_aggregate_prew(slab, perm, cell_start, relevance, cells, occ, ws, B, cap, D, n_chunks, st);
+    if (rc == GRIDMM_OK) return rc;
+  }
+  if (relevance && gridmm_grid_relevance_gemm(slab, perm, cell_start, text_frag, relevance, amax, B, cap, D, L, n_chunks,
+                                               st) == GRIDMM_OK) {
+    // long instructions (L > 96; any L at D = 768 with a deep memory): relevance as a GEMM over 128-point tiles
+    // (aggregate_relg.hip) + the accumulation pass
     const int rc = gridmm_grid_aggregate_prew(slab, perm, cell_start, relevance, cells, occ, ws, B, cap, D, n_chunks, st);
     if (rc == GRIDMM_OK) return rc;
   }

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
     pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta; else p_m[1] = pt2 - pt0;
 #endif
     // (PREW: nobody computes on tile i in iteration i, so the loaders only need tile i - 1 here and keep tile i flying)
-    constexpr int KEEP = PREW ? 1 : R - 3;
+    constexpr int KEEP = PREW ? R - 2 : R - 3;
     if (i >= 1 && i + R - 1 < ntiles) wait_vm_dyn(KEEP * my_rows * IPR + ids_instrs);   // steady state
     else if (PREW ? i < ntiles : i + 1 < ntiles) wait_vm_dyn(KEEP * my_rows * IPR);      // first / last iterations: tiles only
     else wait_vm<0>();
@@ -572,26 +572,40 @@ int gridmm_grid_aggregate_pipe(const void* slab, const int32_t* perm, const int3
   return GRIDMM_OK;
 }
 
-// Second pass of the D = 768 path: w (relevance by sorted position, from gridmm_grid_relevance_wide) -> cells / occ.
-// 3 loader waves + 5 accumulating waves, ring of 3 x 48 KB.
+// Second pass of the two-pass paths: w (relevance by sorted position, from gridmm_grid_relevance_wide / _gemm) -> cells /
+// occ.  3 loader waves + 5 accumulating waves; ring of 3 x 48 KB (D = 768) or 4 x 32 / 16 KB (D = 512 / 256).
 int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int32_t* cell_start, const float* w,
                                float* cells, uint8_t* occ, float* ws, int B, int cap, int D, int n_chunks,
                                hipStream_t st) {
-  if (D != 768) return GRIDMM_EINVAL;
-  constexpr int R = 3, LOADERS = 3;
+  if (D != 768 && D != 512 && D != 256) return GRIDMM_EINVAL;
+  constexpr int LOADERS = 3;
+  const int R = D == 768 ? 3 : 4;
   const size_t hb_words = (size_t)(cap + PT - 1) / PT;
   const size_t lds = (size_t)R * PT * D * 2 + 2 * 8 * PT * sizeof(float) + 200 * sizeof(int) + 8 * TAB_BYTES +
                      8 * 4 * MAXR * sizeof(int) + 200 * sizeof(int) + 8 * PT * sizeof(float) +
                      2 * 8 * PT * sizeof(int) + hb_words * sizeof(unsigned);
-  if (lds > 160 * 1024) return GRIDMM_EINVAL;                // up to ~60k points per episode
-  auto kern = grid_aggregate_pipe_kernel<24, R, 10, true>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-      hipSuccess)
-    return GRIDMM_EINVAL;
-  GRIDMM_LAUNCH(kern, dim3(n_chunks, B), dim3(512), lds, st, (const _Float16*)slab, perm, cell_start,
-                (const _Float16*)nullptr, cells, occ, const_cast<float*>(w), (int32_t*)nullptr, ws, cap, 0, LOADERS,
-                n_chunks);
-  GRIDMM_LAUNCH(grid_aggregate_merge_kernel<768>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
+  if (lds > 160 * 1024) return GRIDMM_EINVAL;                // D = 768: up to ~60k points per episode
+#define GRIDMM_PREW(KS, RR, NBW)                                                                                   \
+  do {                                                                                                             \
+    auto kern = grid_aggregate_pipe_kernel<KS, RR, NBW, true>;                                                     \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                            (int)lds) != hipSuccess)                                                               \
+      return GRIDMM_EINVAL;                                                                                        \
+    GRIDMM_LAUNCH(kern, dim3(n_chunks, B), dim3(512), lds, st, (const _Float16*)slab, perm, cell_start,            \
+                  (const _Float16*)nullptr, cells, occ, const_cast<float*>(w), (int32_t*)nullptr, ws, cap, 0, LOADERS, \
+                  n_chunks);                                                                                       \
+  } while (0)
+  if (D == 768) {
+    GRIDMM_PREW(24, 3, 10);
+    GRIDMM_LAUNCH(grid_aggregate_merge_kernel<768>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
+  } else if (D == 512) {
+    GRIDMM_PREW(16, 4, 7);
+    GRIDMM_LAUNCH(grid_aggregate_merge_kernel<512>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
+  } else {
+    GRIDMM_PREW(8, 4, 4);
+    GRIDMM_LAUNCH(grid_aggregate_merge_kernel<256>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
+  }
+#undef GRIDMM_PREW
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -49,6 +49,7 @@ class KernelTimer:
 
 
 TIMER = None  # set to a KernelTimer() to time launches
+LAST_AGGREGATE_RC = None
 
 
 def _timed(name, work, fn):
@@ -718,11 +719,12 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
     dev = slab.device
     cells = torch.empty(B, N_CELLS, D, dtype=torch.float32, device=dev)
     occ = torch.empty(B, N_CELLS, dtype=torch.uint8, device=dev)
-    # D = 768: the two-pass path needs the relevance buffer as its intermediate (allocated even when not asked for)
+    # the two-pass paths (D = 768; instructions outside 33..96 tokens at D <= 512) need the relevance buffer as their
+    # intermediate: allocated even when not asked for
     if want_relevance or want_amax:
         rel = torch.zeros(B, cap, dtype=torch.float32, device=dev)
-    else:                                   # D = 768: scratch of the two-pass path (only valid positions are written / read)
-        rel = torch.empty(B, cap, dtype=torch.float32, device=dev) if D == 768 else None
+    else:                                   # scratch of a two-pass path (only valid positions are written / read)
+        rel = torch.empty(B, cap, dtype=torch.float32, device=dev) if (D == 768 or not 33 <= L <= 96) else None
     chunks = torch.empty(int(lib.gridmm_grid_aggregate_workspace(B, D, n_chunks)), dtype=torch.uint8, device=dev)
     amax = torch.empty(B, cap, dtype=torch.int32, device=dev) if want_amax else None
     status = []
@@ -731,6 +733,8 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
         rc = lib.gridmm_grid_aggregate_train(_p(slab), _p(perm), _p(cell_start), _p(text_frag), _p(cells), _p(occ),
                                              _p(rel), _p(amax), _p(chunks), B, cap, D, L, n_chunks, _stream())
         status.append(rc)
+        global LAST_AGGREGATE_RC
+        LAST_AGGREGATE_RC = rc       # 0: a pipelined path (one pass, or relevance + accumulation passes); 1: the generic kernel
         _lib.check(min(rc, 0), "gridmm_grid_aggregate_train")
     if TIMER is not None:
         TIMER.last_aggregate = launch        # bench.py re-launches it inside a hipGraph for the device-side duration

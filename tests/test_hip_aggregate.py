@@ -51,8 +51,15 @@ CASES = [
     (512, 96, "blocks", [1500, 700], None),      # 2 B-waves, 16 blocks each
     (512, 48, "sparse", [400, 300], None),       # 3 R-waves, 11 rows each
     (512, 33, "crowded", [1200], None),
-    (512, 20, "blocks", [900, 100], None),       # L <= 32: generic kernel
-    (512, 120, "blocks", [900, 100], None),      # L > 96: generic kernel
+    (512, 20, "blocks", [900, 100], None),       # L <= 32: relevance GEMM pass + accumulation pass
+    (512, 120, "blocks", [900, 100], None),      # L > 96: relevance GEMM pass + accumulation pass (aggregate_relg.hip)
+    (512, 200, "blocks", [2048, 2047, 300, 31], None),   # max_instr_len of the reference's scripts
+    (512, 200, "crowded", [9000, 1111, 33, 1], 8),
+    (512, 250, "sparse", [400, 300, 0], None),   # 16 token tiles
+    (256, 200, "blocks", [3000, 500], None),
+    (768, 120, "blocks", [2000, 300], None),
+    (768, 200, "crowded", [5000, 64, 700], 24),
+    (768, 200, "sparse", [150, 97, 0, 260], None),
     (256, 80, "blocks", [3000, 500], None),
     (256, 64, "sparse", [190, 10], 4),
     (768, 80, "blocks", [2000, 300], None),      # D = 768, L <= 80: relevance pass + accumulation pass
@@ -60,7 +67,7 @@ CASES = [
     (768, 80, "crowded", [9000, 1111, 33, 1], 8),
     (768, 40, "blocks", [2047, 31], 4),          # 3 token tiles: waves 5..7 hold no text
     (768, 16, "crowded", [700], None),
-    (768, 96, "blocks", [900, 100], None),       # D = 768, L > 80: generic kernel
+    (768, 96, "blocks", [900, 100], None),       # D = 768, L > 80: relevance GEMM pass
     (512, 80, "crowded", [210000], 8),           # run-head bitmask of the episode exceeds LDS: generic kernel
     (512, 80, "crowded", [150000], 8),           # largest memories the pipelined kernel takes (4700 tiles per workgroup)
     # point-balanced chunks: the crowded cell is split over many chunks (head pieces, tail pieces, whole-chunk pieces)
@@ -87,9 +94,10 @@ def test_grid_aggregate_regimes(D, L, kind, npts, n_chunks):
     cells, occ, rel, amax = ops.grid_aggregate(slab, perm, cs, ops.text_fragments(text.cuda()), L, n_chunks=n_chunks,
                                                want_relevance=True, want_amax=True)
     torch.cuda.synchronize()
-    fast = D in (256, 512) and 33 <= L <= 96 or D == 768 and L <= 80
     if max(npts) <= 45000:
-        assert (amax is not None) == fast            # the pipelined kernels deliver the backward's routing, the generic one not
+        # every shape up to L = 256 runs on a pipelined path (one pass: D <= 512, 33 <= L <= 96; else relevance +
+        # accumulation passes), which also delivers the backward's routing; the generic kernel (rc 1) does not
+        assert ops.LAST_AGGREGATE_RC == 0 and amax is not None
     for b in range(B):
         ref_cells, ref_occ, w = _ref(fts[b], maps[b], text[b], L)
         assert torch.equal(occ[b].cpu(), ref_occ)
