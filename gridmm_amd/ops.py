@@ -725,6 +725,8 @@ def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_rel
         rel = torch.zeros(B, cap, dtype=torch.float32, device=dev)
     else:                                   # scratch of a two-pass path (only valid positions are written / read)
         rel = torch.empty(B, cap, dtype=torch.float32, device=dev) if (D == 768 or not 33 <= L <= 96) else None
+        if os.environ.get("GRIDMM_AGG_FORCE_GENERIC") == "1":
+            rel = None                      # tools/bench_agg_long.py: without the intermediate the dispatcher falls back
     chunks = torch.empty(int(lib.gridmm_grid_aggregate_workspace(B, D, n_chunks)), dtype=torch.uint8, device=dev)
     amax = torch.empty(B, cap, dtype=torch.int32, device=dev) if want_amax else None
     status = []
