@@ -256,6 +256,7 @@ def rollout_leg(args, dev, rollouts=3):
     model.varlen_buckets = GlocalTextPathNavCMT.DEFAULT_BUCKETS
     mem = GridMemoryBatch(B, geom, max_steps=T + 2, device=dev)
     env = SyntheticNavEnv(B, mem, n_scans=4, n_episodes=4 * B, seed=3, geom=geom, vocab=30000)
+    env.build_device_store(dev)               # observations resident in HBM: an env step moves no feature bytes over PCIe
     agent = GMapNavAgent(default_args(max_action_len=T), env, model, device=dev)
     agent.feedback = "argmax"
     agent._set_mode(False)
@@ -278,7 +279,7 @@ def rollout_leg(args, dev, rollouts=3):
             "sections_ms_per_step": {k: 1e3 * v / prof_steps for k, v in sorted(agent.timers.items(), key=lambda kv: -kv[1])},
             "host_share": sum(v for k, v in agent.timers.items() if k.startswith("host") or k.startswith("env")) / tot,
             "workload": "GMapNavAgent.rollout, synthetic buildings (24 viewpoints, 36 views, 36x196x512 observations), "
-                        "argmax actions, eager launches, varlen map sequences"}
+                        "argmax actions, eager launches, varlen map sequences, observation store resident in HBM"}
 
 
 def producer_leg(args, dev, steps=5):

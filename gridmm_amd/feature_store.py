@@ -115,6 +115,41 @@ class PackedStore:
         return depth, feats, poses
 
 
+class DeviceStore:
+    """The packed store resident in HBM (row f1 + f3 together): tokens (n, pts, D) fp16, depth (n, pts) uint16 (or fp32
+    metres for VLN-CE geometry) and poses on the device; an environment step then moves NO observation bytes over PCIe --
+    `append(mem, keys)` gathers the B observations straight into the grid memory's next slot (device copy) and returns
+    the depth rows + host poses that GridMemoryBatch.step() takes.  288 GB of HBM hold ~39 000 native observations
+    (588 x 768 fp16 = 0.9 MB each: all of R2R's 10 567 panoramas take 9.6 GB) or ~40 000 BASELINE-shape ones."""
+
+    def __init__(self, keys, tokens, depth, poses, device):
+        import torch
+        self.keys = list(keys)
+        self.index = {k: i for i, k in enumerate(self.keys)}
+        self.device = torch.device(device)
+        self.tokens = torch.as_tensor(np.ascontiguousarray(tokens)).to(self.device)
+        d = np.ascontiguousarray(depth)
+        self._u16 = d.dtype == np.uint16
+        # (uint16 rows are gathered through an int16 view of the same bytes: index_select has no uint16 kernel)
+        self.depth = torch.as_tensor(d.view(np.int16) if self._u16 else d).to(self.device)
+        self.poses = [tuple(float(v) for v in p) for p in poses]
+
+    @classmethod
+    def from_packed(cls, store, device):
+        """PackedStore (mmap) -> HBM, one upload."""
+        return cls(store.keys, store.tokens, store.depth, [tuple(store.pose[i]) for i in range(store.n)], device)
+
+    def append(self, mem, keys):
+        """Write the observations of `keys` (one per episode of the lock-step batch) into mem.next_slot(); returns
+        (depth (B, pts) device tensor, [(x, y)] host floats) for mem.step(depth, None, poses, headings)."""
+        import torch
+        idx = torch.tensor([self.index[k] for k in keys], dtype=torch.int64, device=self.device)
+        slot = mem.next_slot()
+        slot.copy_(self.tokens.index_select(0, idx).view(slot.shape))       # device-side gather, no PCIe
+        d = self.depth.index_select(0, idx)
+        return (d.view(torch.uint16) if self._u16 else d), [(self.poses[self.index[k]][0], self.poses[self.index[k]][1]) for k in keys]
+
+
 DEPTH_W = 128
 SAMPLE_IDX = [9, 27, 45, 63, 81, 99, 117]        # env.py:279
 

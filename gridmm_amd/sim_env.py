@@ -174,6 +174,22 @@ class SyntheticNavEnv:
         self.ix = 0
         self.batch = None
         self.sims = [_SimState() for _ in range(batch_size)]
+        self.device_store = None          # feature_store.DeviceStore: observations resident in HBM (build_device_store)
+
+    def build_device_store(self, device):
+        """All viewpoints of all buildings -> one DeviceStore (patch tokens + sampled depth + pose); from then on an
+        environment step gathers its observations on the device and the observation dicts carry no grid fields (the
+        agent hands the grid memory to the model as a handle, agent.py:150-152)."""
+        from .feature_store import DeviceStore
+        keys, tok, dep, poses = [], [], [], []
+        for sname, sc in self.scans.items():
+            for vp in sc.vps:
+                keys.append(vp)
+                tok.append(sc.patch_tokens(vp, self.geom))
+                dep.append(sc.depth(vp, self.geom).reshape(-1))
+                poses.append(sc.pos[vp])
+        self.device_store = DeviceStore(keys, np.stack(tok), np.stack(dep), poses, device)
+        return self.device_store
 
     # ---- simulator surface used by the agent (agent.py:255: sims[i].newEpisode)
     def teleport(self, i, scan, vp, heading, elevation):
@@ -230,11 +246,16 @@ class SyntheticNavEnv:
         """env.py:583-623 + EnvBatch.getStates (env.py:377-400)."""
         B = self.batch_size
         states = self.sims
-        depth = np.stack([self.scans[s.scan].depth(s.vp, self.geom).reshape(-1) for s in states])
-        feats = np.stack([self.scans[s.scan].patch_tokens(s.vp, self.geom) for s in states])
-        poses = [self.scans[s.scan].pos[s.vp][:2] for s in states]
-        self.grid_memory.step(depth, feats, poses, [s.heading for s in states])
-        grid_fts, grid_map, pos_fts = self.grid_memory.as_reference_obs()
+        if self.device_store is not None:
+            depth, poses = self.device_store.append(self.grid_memory, [s.vp for s in states])
+            self.grid_memory.step(depth, None, poses, [s.heading for s in states])
+            grid_fts = grid_map = pos_fts = [None] * B
+        else:
+            depth = np.stack([self.scans[s.scan].depth(s.vp, self.geom).reshape(-1) for s in states])
+            feats = np.stack([self.scans[s.scan].patch_tokens(s.vp, self.geom) for s in states])
+            poses = [self.scans[s.scan].pos[s.vp][:2] for s in states]
+            self.grid_memory.step(depth, feats, poses, [s.heading for s in states])
+            grid_fts, grid_map, pos_fts = self.grid_memory.as_reference_obs()
         obs = []
         for i, s in enumerate(states):
             item = self.batch[i]

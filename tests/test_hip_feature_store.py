@@ -60,6 +60,16 @@ def test_store_to_device_grid_memory_matches_oracle_and_list_form(tmp_path):
             assert np.array_equal(mem.slab[b, :n].cpu().numpy(), ref[b][0])
             assert np.abs(mem.pos_fts[b].cpu().numpy() - ref[b][2]).max() < 2e-6
 
+    # the same walk with the store resident in HBM (DeviceStore: observations gathered on the device, no PCIe traffic)
+    ds = FS.DeviceStore.from_packed(st, dev)
+    mem2 = GridMemoryBatch(B, S.NATIVE, max_steps=T, device=dev)
+    for t in range(T):
+        d, poses = ds.append(mem2, [walks[b][t] for b in range(B)])
+        mem2.step(d, None, poses, [heads[b][t] for b in range(B)])
+    torch.cuda.synchronize()
+    assert torch.equal(mem2.cell_id, mem.cell_id) and torch.equal(mem2.slab, mem.slab) and torch.equal(mem2.perm, mem.perm)
+    assert torch.equal(mem2.pos_fts, mem.pos_fts)
+
     cfg = default_config(num_l_layers=1, num_pano_layers=1, num_x_layers=2, intermediate_size=256, vocab_size=1000)
     model = GlocalTextPathNavCMT(cfg).eval()
     sd = {k: (det_tensor(k, v.shape, 1) if v.dtype.is_floating_point else v) for k, v in model.state_dict().items()}
