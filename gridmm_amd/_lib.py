@@ -70,6 +70,9 @@ SIGNATURES = {
                              ctypes.c_uint64, _vp, _vp],
     "gridmm_grid_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_grid_aggregate_bwd_routed": [_vp] * 9 + [_i, _i, _i, _i, _vp],
+    "gridmm_fuse_logits_bwd": [_vp] * 16 + [_i, _i, _i, _vp],
+    "gridmm_cells_compact_bwd": [_vp, _i64, _vp, _vp, _i, _i, _vp],
+    "gridmm_dropout": [_vp, _vp, _i64, _f, ctypes.c_uint64, _vp, _vp],
     "gridmm_grad_sumsq": [_vp, _i64, _i, _vp, _vp],
     "gridmm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _vp, _vp],
     "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -404,3 +404,119 @@ class _GridAggregate(torch.autograd.Function):
 
 def grid_aggregate(text_fts, slab, perm, cell_start):
     return _GridAggregate.apply(text_fts, slab, perm, cell_start)
+
+
+# ---- row-wise training stages on the library's kernels (csrc/train_rowops.hip) ---------------------------------------
+class _Dropout(torch.autograd.Function):
+    """Hidden-state dropout (vilmodel.py:86,166,205; transformer.py dropout / dropout1 / dropout2): counter-based keep-mask
+    from one seed per call (torch's CPU generator: reproducible under torch.manual_seed); the backward re-applies it."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        lib = _lib.load()
+        x = x.contiguous()
+        seed = hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item()))
+        seed_dev = SEED_DEV if hs.MODE is not None else None          # captured steps: the per-replay seed word
+        y = torch.empty_like(x)
+        _lib.check(lib.gridmm_dropout(_p(x), _p(y), x.numel(), float(p), seed, _p(seed_dev), _stream()), "gridmm_dropout")
+        ctx.p, ctx.seed, ctx.seed_dev = float(p), seed, seed_dev
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.check(lib.gridmm_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, _p(ctx.seed_dev), _stream()),
+                   "gridmm_dropout")
+        return dx, None
+
+
+def dropout(x, p):
+    """x fp32 with numel % 4 == 0 (hidden states: last dim 768)."""
+    return _Dropout.apply(x, p) if p > 0 else x
+
+
+def dropout_mask(seed, n, p):
+    """The keep-mask gridmm_dropout derives from `seed` for n elements (host restatement of csrc/common.h; tests only)."""
+    import numpy as np
+    m32 = np.uint64(0xFFFFFFFF)
+
+    def h32(x):
+        x = x & m32
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x85ebca6b)) & m32
+        x ^= x >> np.uint64(13); x = (x * np.uint64(0xc2b2ae35)) & m32
+        x ^= x >> np.uint64(16)
+        return x
+    idx = np.arange(n, dtype=np.uint64)
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    x = h32(((idx * np.uint64(0x9E3779B1)) & m32) ^ lo) ^ hi
+    return (h32(x) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0) >= np.float32(p)
+
+
+class _CellsCompact(torch.autograd.Function):
+    """x (B,196,H) = grid_proj(cells) + position embedding, occ (B,196) uint8 -> rows compacted to the front in cell order,
+    zeros behind (vilmodel.py:813-823); backward: rows scattered back (gridmm_cells_compact_bwd)."""
+
+    @staticmethod
+    def forward(ctx, proj, pos, occ):
+        B, C, H = proj.shape
+        out = torch.empty(B, C, H, dtype=torch.float32, device=proj.device)
+        mask = torch.empty(B, C, dtype=torch.uint8, device=proj.device)
+        from . import ops
+        ops.cells_compact(proj.contiguous(), pos.contiguous(), occ, out, mask)
+        ctx.save_for_backward(occ)
+        ctx.mark_non_differentiable(mask)
+        return out, mask
+
+    @staticmethod
+    def backward(ctx, dout, _dmask):
+        lib = _lib.load()
+        (occ,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, C, H = dout.shape
+        d = torch.empty(B, C, H, dtype=torch.float32, device=dout.device)
+        _lib.check(lib.gridmm_cells_compact_bwd(_p(dout), C * H, _p(occ), _p(d), B, H, _stream()), "gridmm_cells_compact_bwd")
+        return d, d, None
+
+
+def cells_compact(proj, pos, occ):
+    """-> (compacted (B,196,H), key mask (B,196) uint8 with the reference's view quirk)."""
+    return _CellsCompact.apply(proj, pos, occ)
+
+
+class _FuseLogits(torch.autograd.Function):
+    """gridmm_fuse_logits / gridmm_fuse_logits_bwd (vilmodel.py:859-899) with the integer index maps."""
+
+    @staticmethod
+    def forward(ctx, g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, cand_of_node, cand_visited):
+        from . import ops
+        u8 = lambda m: (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()   # noqa: E731
+        gm, gv, vn = u8(gmap_masks), u8(gmap_visited), u8(vp_nav_masks)
+        g_raw, l_raw, grid_raw = g_raw.contiguous(), l_raw.contiguous(), grid_raw.contiguous()
+        fuse_raw = None if fuse_raw is None else fuse_raw.contiguous()
+        con, cv = cand_of_node.to(torch.int32).contiguous(), u8(cand_visited)
+        outs = ops.fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gm, gv, vn, con, cv)
+        ctx.save_for_backward(g_raw, l_raw, fuse_raw, gm, gv, vn, con, cv)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_global, d_local, d_grid, d_fused):
+        lib = _lib.load()
+        g_raw, l_raw, fuse_raw, gm, gv, vn, con, cv = ctx.saved_tensors
+        B, G = g_raw.shape
+        V = l_raw.shape[1]
+        c = lambda t: None if t is None else t.contiguous()   # noqa: E731
+        d_global, d_local, d_grid, d_fused = c(d_global), c(d_local), c(d_grid), c(d_fused)
+        dg, dl, dgr = torch.empty_like(g_raw), torch.empty_like(l_raw), torch.empty_like(g_raw)
+        df = None if fuse_raw is None else torch.empty_like(fuse_raw)
+        _lib.check(lib.gridmm_fuse_logits_bwd(_p(g_raw), _p(l_raw), _p(fuse_raw), _p(gm), _p(gv), _p(vn), _p(con), _p(cv),
+                                              _p(d_global), _p(d_local), _p(d_grid), _p(d_fused), _p(dg), _p(dl), _p(dgr),
+                                              _p(df), B, G, V, _stream()), "gridmm_fuse_logits_bwd")
+        return dg, dl, dgr, df, None, None, None, None, None
+
+
+def fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, cand_of_node, cand_visited):
+    """-> (global, local, grid, fused) logits, -inf where masked."""
+    return _FuseLogits.apply(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, cand_of_node,
+                             cand_visited)

@@ -1,0 +1,151 @@
+// Training counterparts of the row-wise stages: the backward of the logit masking / fusion, the backward of the cell
+// compaction, and hidden-state dropout -- so that the differentiable forward (gridmm_amd/vilmodel_train.py) has no stock
+// torch gather / where / dropout on the path SURVEY.md §8 covers.  Reference: map_nav_src/models/vilmodel.py.
+#include "common.h"
+
+namespace {
+
+// One workgroup per episode.  Forward (fuse_logits_kernel, rowops.hip; vilmodel.py:859-899):
+//   fw = sigmoid(fuse_raw);  global_j = g_j fw (-inf if visited / padded);  grid_j = gr_j (same mask)
+//   local_k = l_k (1 - fw) (-inf unless navigable);  fused_j = global_j + add_j,
+//   add_0 = local_0;  add_j = local_{con[j]} (con >= 0) | sum_{k >= 1, cand_visited[k]} local_k (con == -1) | 0 (con == -2)
+// Backward: masked positions pass no gradient (masked_fill); a masked local that was added to a fused logit made it
+// -inf, whose incoming gradient is 0 from any softmax / cross-entropy, so it is treated as 0 as well.
+__global__ __launch_bounds__(64) void fuse_logits_bwd_kernel(
+    const float* __restrict__ g_raw, const float* __restrict__ l_raw, const float* __restrict__ fuse_raw,
+    const uint8_t* __restrict__ gmap_masks, const uint8_t* __restrict__ gmap_visited,
+    const uint8_t* __restrict__ vp_nav_masks, const int32_t* __restrict__ cand_of_node,
+    const uint8_t* __restrict__ cand_visited, const float* __restrict__ d_global, const float* __restrict__ d_local,
+    const float* __restrict__ d_grid, const float* __restrict__ d_fused, float* __restrict__ d_g_raw,
+    float* __restrict__ d_l_raw, float* __restrict__ d_grid_raw, float* __restrict__ d_fuse_raw, int G, int V) {
+  extern __shared__ float sm[];          // dL[V]: total gradient on the masked local logits
+  float* dL = sm;
+  __shared__ float s_part[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float fw = fuse_raw ? 1.0f / (1.0f + expf(-fuse_raw[b])) : 0.5f;
+  for (int k = tid; k < V; k += blockDim.x) dL[k] = d_local ? d_local[b * V + k] : 0.f;
+  __syncthreads();
+  float dfw = 0.f, dbw = 0.f;            // dbw: gradient on the sum of visited candidates' local logits
+  // nodes: one thread per node adds into dL through LDS atomics (G, V <= a few dozen)
+  for (int j = tid; j < G; j += blockDim.x) {
+    const bool ok = gmap_masks[b * G + j] && !gmap_visited[b * G + j];
+    const float df = d_fused ? d_fused[b * G + j] : 0.f;
+    const float dG = ok ? (d_global ? d_global[b * G + j] : 0.f) + df : 0.f;
+    d_g_raw[b * G + j] = dG * fw;
+    dfw += dG * g_raw[b * G + j];
+    d_grid_raw[b * G + j] = (ok && d_grid) ? d_grid[b * G + j] : 0.f;
+    if (j == 0) atomicAdd(&dL[0], df);
+    else {
+      const int k = cand_of_node[b * G + j];
+      if (k >= 0) atomicAdd(&dL[k], df);
+      else if (k == -1) dbw += df;
+    }
+  }
+  s_part[tid] = dbw;
+  __syncthreads();
+  float dbw_all = 0.f;
+  for (int i = 0; i < (int)blockDim.x; ++i) dbw_all += s_part[i];     // fixed order: deterministic
+  __syncthreads();
+  for (int k = tid; k < V; k += blockDim.x) {
+    float d = dL[k];
+    if (k >= 1 && cand_visited[b * V + k]) d += dbw_all;
+    if (!vp_nav_masks[b * V + k]) d = 0.f;
+    d_l_raw[b * V + k] = d * (1.0f - fw);
+    dfw -= d * l_raw[b * V + k];
+  }
+  s_part[tid] = dfw;
+  __syncthreads();
+  if (tid == 0 && d_fuse_raw) {
+    float s = 0.f;
+    for (int i = 0; i < (int)blockDim.x; ++i) s += s_part[i];
+    d_fuse_raw[b] = s * fw * (1.0f - fw);
+  }
+}
+
+// d_cells[b][c] = d_out[b][rank(c)] for occupied cells (rank = number of occupied cells before c), 0 for empty ones:
+// the backward of the compaction of vilmodel.py:813-823 (the same gradient reaches grid_proj's output and the position
+// embedding, which are summed before the compaction).
+__global__ __launch_bounds__(256) void cells_compact_bwd_kernel(const float* __restrict__ d_out, int64_t d_out_bs,
+                                                                const uint8_t* __restrict__ occ,
+                                                                float* __restrict__ d_cells, int H) {
+  __shared__ int s_rank[GRIDMM_CELLS];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    int base = 0;
+    for (int c0 = 0; c0 < GRIDMM_CELLS; c0 += 64) {
+      const int c = c0 + lane;
+      const bool o = (c < GRIDMM_CELLS) && occ[b * GRIDMM_CELLS + c];
+      const unsigned long long m = __ballot(o);
+      if (c < GRIDMM_CELLS) s_rank[c] = o ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+      base += __popcll(m);
+    }
+  }
+  __syncthreads();
+  const int nv = H >> 2;
+  const int c_lo = blockIdx.y * GRIDMM_GRID;
+  for (int i = tid; i < GRIDMM_GRID * nv; i += blockDim.x) {
+    const int c = c_lo + i / nv, q = i % nv;
+    const int r = s_rank[c];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= 0) v = reinterpret_cast<const float4*>(d_out + (size_t)b * d_out_bs + (size_t)r * H)[q];
+    reinterpret_cast<float4*>(d_cells + ((size_t)b * GRIDMM_CELLS + c) * H)[q] = v;
+  }
+}
+
+// y = keep(seed, i) ? x / (1 - p) : 0 -- hidden-state dropout (BertSelfOutput / BertOutput / embeddings,
+// vilmodel.py:86,166,205; transformer.py dropout1 / dropout2) from the same counter-based hash as the attention dropout
+// (common.h): the backward is the same call on the incoming gradient with the same seed, nothing is stored.
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4, float p,
+                               unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
+  const float scale = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const unsigned int e = (unsigned int)(i * 4);
+    float4 o;
+    o.x = dropout_keep(seed, e, p) ? v.x * scale : 0.f;
+    o.y = dropout_keep(seed, e + 1, p) ? v.y * scale : 0.f;
+    o.z = dropout_keep(seed, e + 2, p) ? v.z * scale : 0.f;
+    o.w = dropout_keep(seed, e + 3, p) ? v.w * scale : 0.f;
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int gridmm_fuse_logits_bwd(const float* g_raw, const float* l_raw, const float* fuse_raw,
+                                      const uint8_t* gmap_masks, const uint8_t* gmap_visited,
+                                      const uint8_t* vp_nav_masks, const int32_t* cand_of_node,
+                                      const uint8_t* cand_visited, const float* d_global, const float* d_local,
+                                      const float* d_grid, const float* d_fused, float* d_g_raw, float* d_l_raw,
+                                      float* d_grid_raw, float* d_fuse_raw, int B, int G, int V,
+                                      gridmm_stream_t stream) {
+  if (B <= 0 || G <= 0 || V <= 0 || V > 4096 || !g_raw || !l_raw || !d_g_raw || !d_l_raw || !d_grid_raw ||
+      (fuse_raw && !d_fuse_raw))
+    return GRIDMM_EINVAL;
+  GRIDMM_LAUNCH(fuse_logits_bwd_kernel, dim3(B), dim3(64), V * sizeof(float), as_stream(stream), g_raw, l_raw, fuse_raw,
+                gmap_masks, gmap_visited, vp_nav_masks, cand_of_node, cand_visited, d_global, d_local, d_grid, d_fused,
+                d_g_raw, d_l_raw, d_grid_raw, d_fuse_raw, G, V);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_cells_compact_bwd(const float* d_out, int64_t d_out_bs, const uint8_t* occ, float* d_cells, int B,
+                                        int H, gridmm_stream_t stream) {
+  if (B <= 0 || H <= 0 || H % 4 || d_out_bs % 4 || !d_out || !occ || !d_cells) return GRIDMM_EINVAL;
+  GRIDMM_LAUNCH(cells_compact_bwd_kernel, dim3(B, GRIDMM_GRID), dim3(256), 0, as_stream(stream), d_out, d_out_bs, occ,
+                d_cells, H);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_dropout(const float* x, float* y, int64_t n, float p, unsigned long long seed,
+                              const unsigned long long* seed_dev, gridmm_stream_t stream) {
+  if (n <= 0 || n % 4 || n >= ((int64_t)1 << 32) || !(p >= 0.f && p < 1.f) || !x || !y) return GRIDMM_EINVAL;
+  const size_t n4 = (size_t)n / 4;
+  unsigned blocks = (unsigned)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  GRIDMM_LAUNCH(dropout_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, n4, p, seed, seed_dev);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}

@@ -23,7 +23,9 @@ N_CELLS = 196
 
 def _drop(model, x, p=None):
     p = model.config.hidden_dropout_prob if p is None else p
-    return F.dropout(x, p, True) if (model.training and p > 0) else x
+    if not (model.training and p > 0):
+        return x
+    return ag.dropout(x, p) if (x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0) else F.dropout(x, p, True)
 
 
 def _attn_p(model):
@@ -177,22 +179,20 @@ def grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memo
     proj = ag.linear(cells, w, model.grid_proj.bias if proj_bias is None else proj_bias)                 # grid_proj after the reduction (sum a_j = 1)
     gp = model.grid_pos_embeddings
     pos = ag.layer_norm(ag.linear(gridmap_pos_fts.float(), gp[0].weight, gp[0].bias), gp[1])
-    x = proj + pos
-    occ_b = occ.bool()
-    n = occ_b.sum(1)
-    order = torch.argsort((~occ_b).to(torch.uint8), dim=1, stable=True)          # occupied cells first, in cell order
-    x = x.gather(1, order.unsqueeze(-1).expand(-1, -1, H))
-    x = x * (torch.arange(N_CELLS, device=dev).unsqueeze(0) < n.unsqueeze(1)).unsqueeze(-1)
-    with torch.no_grad():   # the mask (with the stale-ones quirk) from the same kernel the inference path uses
-        scratch = torch.empty(B, N_CELLS, H, dtype=torch.float32, device=dev)
-        mask = torch.empty(B, N_CELLS, dtype=torch.uint8, device=dev)
-        ops.cells_compact(proj.detach(), pos.detach(), occ, scratch, mask)
+    # compaction (occupied cells first, in cell order, zeros behind) + the key mask with the reference's stale-ones quirk:
+    # the kernel of the inference path, its backward scatters the rows back (csrc/train_rowops.hip)
+    x, mask = ag.cells_compact(proj, pos, occ)
     return x, mask.bool()
 
 
 def fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited_masks, vp_nav_masks, cand_of_node,
                 cand_visited):
-    """:859-899 with the integer index maps of GlocalTextPathNavCMT._fusion_index_maps, differentiable."""
+    """:859-899 with the integer index maps of GlocalTextPathNavCMT._fusion_index_maps, differentiable: on the GPU the
+    library's forward / backward kernels (gridmm_fuse_logits, gridmm_fuse_logits_bwd); the torch expression below is the
+    CPU restatement the tests compare them with."""
+    if g_raw.is_cuda:
+        return ag.fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited_masks, vp_nav_masks, cand_of_node,
+                              cand_visited)
     ninf = -float("inf")
     fw = torch.sigmoid(fuse_raw).unsqueeze(1) if fuse_raw is not None else 0.5
     global_logits = (g_raw * fw).masked_fill(gmap_visited_masks.bool(), ninf).masked_fill(~gmap_masks.bool(), ninf)

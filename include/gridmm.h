@@ -442,6 +442,26 @@ int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t* perm, cons
                                      const float* relevance, const int32_t* amax, const float* dcells, float* dtext,
                                      float* da_ws, float* dw_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
 
+/* Backward of gridmm_fuse_logits (vilmodel.py:859-899) -- SURVEY.md 8b's gridmm_fuse_logits_bwd: gradients of the four
+ * logit sets (any of them NULL = zero) -> gradients of the three raw head outputs and of the pre-sigmoid fusion weight
+ * (d_fuse_raw [B], NULL when fuse_raw is NULL).  Masked positions pass no gradient; deterministic (fixed-order sums). */
+int gridmm_fuse_logits_bwd(const float* g_raw, const float* l_raw, const float* fuse_raw, const uint8_t* gmap_masks,
+                           const uint8_t* gmap_visited, const uint8_t* vp_nav_masks, const int32_t* cand_of_node,
+                           const uint8_t* cand_visited, const float* d_global, const float* d_local, const float* d_grid,
+                           const float* d_fused, float* d_g_raw, float* d_l_raw, float* d_grid_raw, float* d_fuse_raw,
+                           int B, int G, int V, gridmm_stream_t stream);
+
+/* Backward of the cell compaction (gridmm_cells_compact / vilmodel.py:813-823): d_out rows [0,196) of a [B][.][H] buffer
+ * (batch stride d_out_bs elements) -> d_cells [B][196][H] in cell order (zeros for empty cells). */
+int gridmm_cells_compact_bwd(const float* d_out, int64_t d_out_bs, const uint8_t* occ, float* d_cells, int B, int H,
+                             gridmm_stream_t stream);
+
+/* Hidden-state dropout (vilmodel.py:86,166,205; transformer.py:179-181): y[i] = keep_i ? x[i] / (1 - p) : 0 with keep_i
+ * from the counter-based hash of (seed [+ *seed_dev], i) that the attention dropout uses; the backward is the same call
+ * on the gradient.  n % 4 == 0, n < 2^32; seed_dev (device, may be NULL): per-replay seed word of captured steps. */
+int gridmm_dropout(const float* x, float* y, int64_t n, float p, unsigned long long seed,
+                   const unsigned long long* seed_dev, gridmm_stream_t stream);
+
 /* Optimizer step: gradient-norm clipping + AdamW without a host round trip.
  * gridmm_grad_sumsq adds sum(g^2) of one gradient tensor into *acc (zero it first; call once per tensor).
  * gridmm_adamw_step updates one parameter tensor in place; with sumsq != NULL the gradient is first scaled by
