@@ -3,8 +3,12 @@
 and -- after loss.mean().backward() as train_r2r.py:245-262 does -- every parameter's gradient norm, 48 seeded
 samples of every gradient, and the set of parameters without a gradient.
 
-Tolerances: the reference computes grid_proj + the per-cell reduction in fp16 (vilmodel.py:693-703), this build in
-fp32 -> losses agree to 2e-3 relative, gradients to 2e-2 of the tensor's largest sampled entry / norm.
+Tolerances (measured: tools/grad_errs.py; median gradient error 1e-5 .. 7e-5): losses agree to 2e-3 relative (measured
+<= 1.4e-5); every gradient to 5e-3 of the tensor's largest sampled entry / norm, EXCEPT text_proj.{weight,bias} (2e-2;
+measured 0.4-1.5 %): the reference takes the instruction-relevance product, grid_proj and the per-cell reduction in fp16
+(pretrain_src/model/vilmodel.py:664,690-703), this build in fp32 / f16 hi+lo -- the relevance values differ at the fp16
+rounding level, which moves a few arg-max routes of the max over tokens, and text_proj is the only parameter whose whole
+gradient flows through that routing.
 
 mrc: RegionClassification holds a ReLU (pretrain_cmt.py:15-18) and one of its 7680 pre-activations in this fixture sits
 within 1e-4 of zero: perturbing the REFERENCE's own weights by 1e-4 relative moves its mrc gradients by 2-8 %
@@ -83,7 +87,10 @@ def test_pretrain_losses_and_gradients_match_reference(task, with_obj):
         en = abs(float(g.norm()) - float(n_ref)) / max(float(n_ref), 1e-3 * scale)
         errs += [(e, k), (en, k + " [norm]")]
     errs.sort(reverse=True)
-    assert errs[0][0] < (1e-1 if task == "mrc" else 2e-2), errs[:12]
+    gate_flip = task == "mrc" and not full       # the reduced mrc fixtures: a ReLU pre-activation within 1e-4 of zero (see above)
+    for e, k in errs:
+        bound = 1e-1 if gate_flip else (2e-2 if "text_proj" in k else 5e-3)
+        assert e < bound, (k, e, errs[:8])
     a, b = np.concatenate(got_all).astype(np.float64), np.concatenate(ref_all).astype(np.float64)
     cos = float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
     assert cos > 0.999, cos
