@@ -14,9 +14,10 @@ import json
 import re
 import sys
 
-CLASSES = [("linear", r"linear_planes_kernel|linear_kernel"), ("grid_aggregate", r"grid_aggregate_kernel|grid_aggregate_pipe_kernel"),
+CLASSES = [("linear", r"linear_planes_kernel|linear_planes_grouped_kernel|linear_kernel"), ("grid_aggregate", r"grid_aggregate_kernel|grid_aggregate_pipe_kernel"),
            ("attention", r"attention_rows_kernel|attention_planes_kernel|attention_kernel"), ("transpose_v", r"transpose_v_kernel"),
-           ("layernorm", r"layernorm_kernel"), ("split_rows", r"split_rows_kernel"),
+           ("layernorm", r"layernorm_kernel"), ("split_rows", r"split_rows_kernel"), ("embed", r"cells_embed_kernel|node_embed_kernel"),
+           ("heads", r"nav_head_rows_kernel|nav_fuse_kernel"),
            ("grid_project", r"grid_project_kernel"), ("grid_bin", r"grid_bin_sort_kernel")]
 
 

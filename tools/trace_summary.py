@@ -6,7 +6,7 @@ steps = sys.argv[2] if len(sys.argv) > 2 else '1'
 # the aggregation is two kernels, so counting 'grid_aggregate' over-counts): cells_compact_kernel, else grid_project_kernel
 def _count(name):
     return float(sum(name in r['Kernel_Name'] for r in rows))
-steps = (_count('cells_compact_kernel') or _count('grid_project_kernel') or 1.0) if steps == 'auto' else float(steps)
+steps = (_count('cells_embed_kernel') or _count('cells_compact_kernel') or _count('grid_project_kernel') or 1.0) if steps == 'auto' else float(steps)
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 def short(n):
     m = re.search(r'(linear_planes_kernel<[^>]*>|linear_kernel<[^>]*>|attention_rows_kernel<[^>]*>|attention_planes_kernel<\d>|attention_kernel|tokens_to_slab_kernel|transpose_v_kernel|grid_aggregate_pipe_kernel|grid_aggregate_kernel|layernorm_kernel<\d>|ln_dot_kernel|copy_rows_kernel|cells_compact_kernel|grid_bin_sort_kernel|grid_project_kernel|split_rows_kernel|fuse_logits|text_fragments|build_chunks|split_weight)', n)
