@@ -498,6 +498,7 @@ class _FuseLogits(torch.autograd.Function):
         con, cv = cand_of_node.to(torch.int32).contiguous(), u8(cand_visited)
         outs = ops.fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gm, gv, vn, con, cv)
         ctx.save_for_backward(g_raw, l_raw, fuse_raw, gm, gv, vn, con, cv)
+        ctx.set_materialize_grads(False)      # an output the loss does not use arrives as None, not as zeros
         return tuple(outs)
 
     @staticmethod
@@ -508,12 +509,19 @@ class _FuseLogits(torch.autograd.Function):
         V = l_raw.shape[1]
         c = lambda t: None if t is None else t.contiguous()   # noqa: E731
         d_global, d_local, d_grid, d_fused = c(d_global), c(d_local), c(d_grid), c(d_fused)
+        if d_global is None and d_local is None and d_grid is None and d_fused is None:
+            return (None,) * 9
         dg, dl, dgr = torch.empty_like(g_raw), torch.empty_like(l_raw), torch.empty_like(g_raw)
         df = None if fuse_raw is None else torch.empty_like(fuse_raw)
         _lib.check(lib.gridmm_fuse_logits_bwd(_p(g_raw), _p(l_raw), _p(fuse_raw), _p(gm), _p(gv), _p(vn), _p(con), _p(cv),
                                               _p(d_global), _p(d_local), _p(d_grid), _p(d_fused), _p(dg), _p(dl), _p(dgr),
                                               _p(df), B, G, V, _stream()), "gridmm_fuse_logits_bwd")
-        return dg, dl, dgr, df, None, None, None, None, None
+        # a head whose logits the loss does not use gets NO gradient (its parameters keep grad None and the optimizer skips
+        # them, weight decay included: grid_sap_head in the fine-tune loss, agent.py:340-347)
+        used_gl = d_global is not None or d_fused is not None
+        used_l = d_local is not None or d_fused is not None
+        return (dg if used_gl else None, dl if used_l else None, dgr if d_grid is not None else None,
+                df if (used_gl or used_l) else None, None, None, None, None, None)
 
 
 def fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, cand_of_node, cand_visited):
