@@ -141,6 +141,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, packs):
+        ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         K = x.shape[-1]
         ctx.packs = packs
         x2 = x.float().contiguous().view(-1, K)
@@ -163,6 +164,8 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 5
         weight = ctx.saved_tensors[-1]
         N, K = weight.shape
         dy2 = dy.contiguous().view(-1, N)
@@ -192,6 +195,7 @@ def linear(x, weight, bias=None, residual=None):
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, eps):
+        ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         x2 = ops.uniform_rows(x.float())
         r2 = None if residual is None else ops.uniform_rows(residual.float())
         y = ops.layernorm(x2, gamma.detach(), beta.detach(), eps, residual=r2).f32
@@ -201,6 +205,8 @@ class _LayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 5
         lib = _lib.load()
         x2, r2, gamma = ctx.saved_tensors
         dy = dy.contiguous()
@@ -223,6 +229,7 @@ def layer_norm(x, mod, residual=None):
 class _Activation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mode):
+        ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         lib = _lib.load()
         x = x.contiguous()
         y = torch.empty_like(x)
@@ -233,6 +240,8 @@ class _Activation(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 2
         lib = _lib.load()
         (x,) = ctx.saved_tensors
         dy = dy.contiguous()
@@ -256,6 +265,7 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q_src, kv_src, kmask, cols, heads, dropout_p=0.0):
+        ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         lib = _lib.load()
         H = heads * 64
         same = kv_src is None
@@ -290,6 +300,8 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if dout is None:
+            return (None,) * 6
         lib = _lib.load()
         q_src, kv_src, kmask, out, lse = ctx.saved_tensors
         heads, H = ctx.heads, ctx.heads * 64
@@ -355,6 +367,7 @@ class _GridAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, text_fts, slab, perm, cell_start):
+        ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         text_fts = text_fts.contiguous()
         B, L, D = text_fts.shape
         frag = ops.text_fragments(text_fts)
@@ -378,6 +391,8 @@ class _GridAggregate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcells, _docc):
+        if dcells is None:
+            return (None,) * 4
         lib = _lib.load()
         text_fts, perm, cell_start, rel = ctx.saved_tensors
         slab = ctx.slab
@@ -413,6 +428,7 @@ class _Dropout(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, p):
+        ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         lib = _lib.load()
         x = x.contiguous()
         seed = hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item()))
@@ -424,6 +440,8 @@ class _Dropout(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 2
         lib = _lib.load()
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
@@ -460,6 +478,7 @@ class _CellsCompact(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, proj, pos, occ):
+        ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         B, C, H = proj.shape
         out = torch.empty(B, C, H, dtype=torch.float32, device=proj.device)
         mask = torch.empty(B, C, dtype=torch.uint8, device=proj.device)
@@ -471,6 +490,8 @@ class _CellsCompact(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dmask):
+        if dout is None:
+            return (None,) * 3
         lib = _lib.load()
         (occ,) = ctx.saved_tensors
         dout = dout.contiguous()
