@@ -33,9 +33,17 @@ class GraphedNavStep:
         fm = self.batch.get("fusion_maps")
         if fm is None:
             fm = model.fusion_maps(batch, dev)
-        self._fm_dev = tuple(t.clone() for t in fm)
-        self._fm_host = tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in fm)
-        self._fm_done = None
+        # the maps live in the caller area of the grid memory's staging buffer: they travel with the pose floats in the
+        # step's ONE host-to-device copy (GridMemoryBatch.set_pose)
+        n0, n1 = fm[0].numel() * 4, fm[1].numel()
+        off1 = (n0 + 15) // 16 * 16
+        hview, dview = mem.stage_extra(off1 + n1)
+        self._fm_host = (hview[:n0].view(torch.int32).view(fm[0].shape), hview[off1:off1 + n1].view(fm[1].shape))
+        self._fm_dev = (dview[:n0].view(torch.int32).view(fm[0].shape), dview[off1:off1 + n1].view(fm[1].shape))
+        self._fm_host[0].copy_(fm[0].cpu())
+        self._fm_host[1].copy_(fm[1].cpu())
+        self._fm_dev[0].copy_(fm[0])
+        self._fm_dev[1].copy_(fm[1])
         self.batch["fusion_maps"] = self._fm_dev
         self.batch.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)
         self.graph = None
@@ -121,23 +129,19 @@ class GraphedNavStep:
         forward('navigation') (vilmodel.py:881-899), as integer maps copied into the graph's static buffers."""
         G, V = self._fm_dev[0].shape[1], self._fm_dev[1].shape[1]
         a, b = self.model._fusion_index_maps(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, V)
-        if self._fm_done is not None:
-            self._fm_done.synchronize()           # the previous step's async H2D has consumed the pinned buffers
-        self._fm_host[0].copy_(a)
+        if self.mem._h2d_done is not None:
+            self.mem._h2d_done.synchronize()      # the previous step's async H2D has consumed the pinned staging buffer
+        self._fm_host[0].copy_(a)                 # uploaded by the set_pose() that follows
         self._fm_host[1].copy_(b)
-        self._fm_dev[0].copy_(self._fm_host[0], non_blocking=True)
-        self._fm_dev[1].copy_(self._fm_host[1], non_blocking=True)
-        self._fm_done = torch.cuda.Event()
-        self._fm_done.record()
 
     def __call__(self, poses, headings, fusion=None, check=True):
         """poses/headings for the (single) appended observation; fusion = (gmap_vpids, gmap_visited_masks (host),
         vp_cand_vpids) rebuilds the fused-logit index maps for this step; returns the static output dict.
         check (bucketed graphs only): read the occupied-cell count after the step and redo it on a larger bucket if the
         prediction was too small; check=False leaves that to the caller (self.cmax[self.last_bucket] vs self.last_bucket)."""
-        self.mem.set_pose(poses, headings)
         if fusion is not None:
             self.refresh_fusion_maps(*fusion)
+        self.mem.set_pose(poses, headings)        # ONE H2D: pose, heading, index maps
         if self.buckets:
             return self._call_bucketed(check)
         self.graph.replay()

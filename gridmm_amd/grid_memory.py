@@ -54,13 +54,31 @@ class GridMemoryBatch:
         self._bin_ws = torch.empty(B, self.MAX_BIN_SLICES * 17, 197, dtype=torch.int32, device=dev)
         self.n_pts_host = np.zeros(B, np.int64)
         self.keep_for_backward = False
-        # static per-step inputs (pinned host -> device): the only bytes that cross PCIe each step
-        self._pose_host = torch.zeros(B, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(B, 2)
-        self._head_host = torch.zeros(B, 2, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(B, 2)
-        self._act_host = torch.ones(B, dtype=torch.uint8).pin_memory() if dev.type == "cuda" else torch.ones(B, dtype=torch.uint8)
-        self.pose_d = torch.zeros(B, 2, dtype=torch.float32, device=dev)
-        self.head_d = torch.zeros(B, 2, dtype=torch.float32, device=dev)
-        self.act_d = torch.ones(B, dtype=torch.uint8, device=dev)
+        # static per-step inputs (pinned host -> device): the only bytes that cross PCIe each step.  ONE staging buffer
+        # (pose | cos/sin(-heading) | active flags | per-episode view tables (VLN-CE) | EXTRA bytes for the caller, e.g.
+        # graph.GraphedNavStep's fused-logit index maps) and ONE async copy per step: every H2D is a ~4 us copy kernel on
+        # the step's stream (rocprofv3: six of them per step were 1 % of the headline step)
+        nv = geom.n_views if geom.vlnce else 0
+        self.STAGE_EXTRA = 1 << 16
+        o_pose, o_head, o_act = 0, B * 8, B * 16
+        o_vc = (o_act + B + 15) // 16 * 16
+        o_vs = o_vc + B * nv * 4
+        self._stage_extra_off = (o_vs + B * nv * 4 + 63) // 64 * 64
+        nbytes = self._stage_extra_off + self.STAGE_EXTRA
+        self._stage_host = torch.zeros(nbytes, dtype=torch.uint8)
+        if dev.type == "cuda":
+            self._stage_host = self._stage_host.pin_memory()
+        self._stage_dev = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self._stage_used = self._stage_extra_off           # bytes uploaded per step (grows when the extra area is used)
+
+        def views(buf):
+            f = lambda o, n, shape: buf[o:o + 4 * n].view(torch.float32).view(*shape)   # noqa: E731
+            return (f(o_pose, B * 2, (B, 2)), f(o_head, B * 2, (B, 2)), buf[o_act:o_act + B],
+                    f(o_vc, B * nv, (B, nv)) if nv else None, f(o_vs, B * nv, (B, nv)) if nv else None)
+        self._pose_host, self._head_host, self._act_host, self._vcos_host, self._vsin_host = views(self._stage_host)
+        self.pose_d, self.head_d, self.act_d, vcos_d, vsin_d = views(self._stage_dev)
+        self._act_host.fill_(1)
+        self.act_d.fill_(1)
         self._active = None
         self._h2d_done = None
         self._bbox_init = torch.tensor([-10000.0, 10000.0, -10000.0, 10000.0], device=dev).repeat(B, 1)
@@ -71,11 +89,7 @@ class GridMemoryBatch:
         self._view_ang = [v * math.pi / (geom.n_views / 2) for v in range(geom.n_views)]
         self.flags = ops.FLAG_VLNCE if geom.vlnce else 0
         if geom.vlnce:   # per-episode view tables: angle = v*pi/6 - heading (Policy_ViewSelection_GridMap.py:734)
-            pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
-            self._vcos_host = pin(torch.zeros(B, geom.n_views, dtype=torch.float32))
-            self._vsin_host = pin(torch.zeros(B, geom.n_views, dtype=torch.float32))
-            self.view_cos = torch.zeros(B, geom.n_views, dtype=torch.float32, device=dev)
-            self.view_sin = torch.zeros(B, geom.n_views, dtype=torch.float32, device=dev)
+            self.view_cos, self.view_sin = vcos_d, vsin_d
         else:
             ang = self._view_ang
             self.view_cos = torch.tensor([np.float32(math.cos(a)) for a in ang], dtype=torch.float32, device=dev)
@@ -108,23 +122,28 @@ class GridMemoryBatch:
         self._pose_host.numpy()[:] = np.asarray([(pz[0], pz[1]) for pz in poses], dtype=np.float64).astype(np.float32)
         ang = [(-hd + math.pi) if self.geom.vlnce else -hd for hd in headings]       # env.py:337 / VLN-CE :785
         self._head_host.numpy()[:] = np.array([(math.cos(a), math.sin(a)) for a in ang], dtype=np.float64).astype(np.float32)
-        self.pose_d.copy_(self._pose_host, non_blocking=True)
-        self.head_d.copy_(self._head_host, non_blocking=True)
         if self.geom.vlnce:
             rel = [[a0 - hd for a0 in self._view_ang] for hd in headings]
             self._vcos_host.numpy()[:] = np.array([[math.cos(a) for a in r] for r in rel], dtype=np.float64).astype(np.float32)
             self._vsin_host.numpy()[:] = np.array([[math.sin(a) for a in r] for r in rel], dtype=np.float64).astype(np.float32)
-            self.view_cos.copy_(self._vcos_host, non_blocking=True)
-            self.view_sin.copy_(self._vsin_host, non_blocking=True)
         if active is None:
             self._active = None
         else:
             self._act_host.copy_(torch.from_numpy(np.asarray(active, bool).astype(np.uint8)))
-            self.act_d.copy_(self._act_host, non_blocking=True)
             self._active = np.asarray(active, bool)
+        n = self._stage_used
+        self._stage_dev[:n].copy_(self._stage_host[:n], non_blocking=True)       # the step's one H2D
         if self.device.type == "cuda":
             self._h2d_done = torch.cuda.Event()
             self._h2d_done.record()
+
+    def stage_extra(self, nbytes):
+        """(pinned host view, device view) of `nbytes` of the staging buffer's caller area: whatever the caller writes into
+        the host view before set_pose() / step() travels with the pose in the same copy."""
+        assert nbytes <= self.STAGE_EXTRA
+        o = self._stage_extra_off
+        self._stage_used = max(self._stage_used, o + nbytes)
+        return self._stage_host[o:o + nbytes], self._stage_dev[o:o + nbytes]
 
     # ---- device half: kernel launches only (replayable from a hipGraph)
     def project_and_bin(self, depth):
