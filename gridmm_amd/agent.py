@@ -68,6 +68,11 @@ class GMapNavAgent:
         self.loss = 0.0
         self.logs = {"entropy": [], "IL_loss": []}
         self.trace = None      # optional list: per-step dict(nav_inputs / nav_outs / a_t) for parity tests
+        # the per-episode methods below restate the reference's collation line by line; the loop itself runs their
+        # batched equivalents (collate.NavCollator: same dictionaries, ~10x less host time) unless fast_collate is off
+        self.fast_collate = True
+        from .collate import NavCollator
+        self.collator = NavCollator(args, self.device)
 
     # ---- collation -----------------------------------------------------------------------------
     def _language_variable(self, obs):
@@ -147,6 +152,11 @@ class GMapNavAgent:
             "gmap_pair_dists": pair_d.to(self.device), "gmap_masks": gen_seq_masks(lens).to(self.device),
             "no_vp_left": no_vp_left,
         }
+        out.update(self._grid_variable(obs))
+        return out
+
+    def _grid_variable(self, obs):
+        out = {}
         mem = getattr(self.env, "grid_memory", None)
         if mem is not None and getattr(mem, "slab", None) is not None:
             out.update(grid_memory=mem, grid_fts=None, grid_map=None, gridmap_pos_fts=None)   # device-resident
@@ -230,6 +240,7 @@ class GMapNavAgent:
         self._update_scanvp_cands(obs)
         B = len(obs)
         gmaps = [TopoMap(ob["viewpoint"]) for ob in obs]
+        self.collator.reset(B)
         for i, ob in enumerate(obs):
             gmaps[i].observe(ob)
         traj = [{"instr_id": ob["instr_id"], "path": [[ob["viewpoint"]]], "details": {}} for ob in obs]
@@ -248,21 +259,27 @@ class GMapNavAgent:
                 if not ended[i]:
                     gmap.step_id[obs[i]["viewpoint"]] = t + 1
 
-            pano_inputs = self._panorama_feature_variable(obs)
+            fast = self.fast_collate
+            pano_inputs = self.collator.panorama(obs) if fast else self._panorama_feature_variable(obs)
             t0 = self._tick("host: collate panorama inputs", t0)
             pano_embeds, pano_masks = self.vln_bert("panorama", pano_inputs)
             t0 = self._tick("panorama", t0)
-            avg_pano = torch.sum(pano_embeds * pano_masks.unsqueeze(2), 1) / torch.sum(pano_masks, 1, keepdim=True)
-            for i, gmap in enumerate(gmaps):
-                if not ended[i]:
-                    gmap.add_embedding(obs[i]["viewpoint"], avg_pano[i], overwrite=True)
-                    for j, cvp in enumerate(pano_inputs["cand_vpids"][i]):
-                        if not gmap.visited(cvp):
-                            gmap.add_embedding(cvp, pano_embeds[i, j])
-
-            nav_inputs = self._nav_gmap_variable(obs, gmaps)
-            nav_inputs.update(self._nav_vp_variable(obs, gmaps, pano_embeds, pano_inputs["cand_vpids"],
-                                                    pano_inputs["view_lens"], pano_inputs["nav_types"]))
+            if fast:
+                self.collator.update_embeddings(obs, gmaps, ended, pano_embeds, pano_masks, pano_inputs["cand_vpids"])
+                nav_inputs = self.collator.navigation(obs, gmaps, pano_embeds, pano_inputs["cand_vpids"],
+                                                      pano_inputs["view_lens"], pano_inputs["nav_types"])
+                nav_inputs.update(self._grid_variable(obs))
+            else:
+                avg_pano = torch.sum(pano_embeds * pano_masks.unsqueeze(2), 1) / torch.sum(pano_masks, 1, keepdim=True)
+                for i, gmap in enumerate(gmaps):
+                    if not ended[i]:
+                        gmap.add_embedding(obs[i]["viewpoint"], avg_pano[i], overwrite=True)
+                        for j, cvp in enumerate(pano_inputs["cand_vpids"][i]):
+                            if not gmap.visited(cvp):
+                                gmap.add_embedding(cvp, pano_embeds[i, j])
+                nav_inputs = self._nav_gmap_variable(obs, gmaps)
+                nav_inputs.update(self._nav_vp_variable(obs, gmaps, pano_embeds, pano_inputs["cand_vpids"],
+                                                        pano_inputs["view_lens"], pano_inputs["nav_types"]))
             nav_inputs.update({"txt_embeds": txt_embeds, "txt_masks": language_inputs["txt_masks"]})
             t0 = self._tick("host: TopoMap update + collate navigation inputs", t0)
             nav_outs = self.vln_bert("navigation", nav_inputs)
@@ -317,7 +334,7 @@ class GMapNavAgent:
             a_t_host = a_t.cpu().numpy()
 
             if self.trace is not None:
-                self.trace.append({"t": t, "nav_inputs": nav_inputs, "nav_outs": nav_outs, "a_t": a_t_host.copy(),
+                self.trace.append({"t": t, "pano_inputs": pano_inputs, "nav_inputs": nav_inputs, "nav_outs": nav_outs, "a_t": a_t_host.copy(),
                                    "ended": ended.copy(), "nav_vpids": nav_vpids})
 
             cpu_a_t = []

@@ -39,6 +39,25 @@ def angle_features(headings, elevations, angle_feat_size=4):
     return np.tile(quad, (1, max(1, angle_feat_size // 4)))
 
 
+def batched_pos_features(delta, base_heading, base_elevation, graph, hops, angle_feat_size=4):
+    """pos_features of many (origin, target) pairs at once: delta (N, 3) float64 target - origin, base heading /
+    elevation (N,), graph distance and hops (N,) -> (N, angle_feat_size + 3) float32.  Same arithmetic, in the same
+    precisions, as heading_elevation_distance + angle_features + TopoMap.pos_features."""
+    flat = np.maximum(np.sqrt(delta[:, 0] ** 2 + delta[:, 1] ** 2), 1e-8)
+    full = np.maximum(np.sqrt(delta[:, 0] ** 2 + delta[:, 1] ** 2 + delta[:, 2] ** 2), 1e-8)
+    heading = np.arcsin(delta[:, 0] / flat)
+    heading = np.where(delta[:, 1] < 0, np.pi - heading, heading) - base_heading
+    elevation = np.arcsin(delta[:, 2] / full) - base_elevation
+    h, e = heading.astype(np.float32), elevation.astype(np.float32)
+    out = np.empty((len(h), angle_feat_size + 3), dtype=np.float32)
+    quad = np.stack([np.sin(h), np.cos(h), np.sin(e), np.cos(e)], 1)
+    out[:, :angle_feat_size] = np.tile(quad, (1, max(1, angle_feat_size // 4)))
+    out[:, angle_feat_size] = (full / MAX_DIST).astype(np.float32)
+    out[:, angle_feat_size + 1] = (graph / MAX_DIST).astype(np.float32)
+    out[:, angle_feat_size + 2] = (hops / MAX_STEP).astype(np.float32)
+    return out
+
+
 class TopoMap:
     def __init__(self, start_vp, capacity=32):
         self.start_vp = start_vp
@@ -141,6 +160,28 @@ class TopoMap:
 
     def hops(self, a, b):
         return 0 if a == b else len(self._route_ids(self._id[a], self._id[b]))
+
+    def index(self, vp):
+        """Dense id of a known viewpoint (insertion order)."""
+        return self._id[vp]
+
+    def hops_from(self, cur, ids):
+        """Route lengths from node id `cur` to every id in `ids` (0 for cur itself): direct edges are read off the
+        pivot matrix, only multi-leg routes are unrolled."""
+        v = self.via[cur, ids]
+        out = np.where(ids == cur, 0.0, 1.0)
+        for j in np.flatnonzero(v >= 0):
+            if ids[j] != cur:
+                out[j] = len(self._route_ids(cur, int(ids[j])))
+        return out
+
+    def relative_geometry(self, cur, ids):
+        """Raw inputs of pos_features for node ids `ids` seen from node `cur`: (position deltas (n, 3), graph distance
+        (n,) with UNREACHABLE for unknown routes and 0 for cur itself, hops (n,)) -- so that a caller can run the
+        trigonometry of many episodes in one vectorised pass (batched_pos_features)."""
+        graph = np.where(ids == cur, 0.0, self.dist[cur, ids])
+        graph = np.where(np.isfinite(graph), graph, float(UNREACHABLE))
+        return self.pos[ids] - self.pos[cur], graph, self.hops_from(cur, ids)
 
     def pair_distances(self, vpids):
         """(n, n) float32 matrix of graph distances between the named nodes; rows/columns of `None` entries (the

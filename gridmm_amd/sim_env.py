@@ -106,8 +106,8 @@ class SyntheticScan:
 
     # ---- per-viewpoint "sensor" data: a pure function of the key, memoised like the reference's in-memory feature
     #      store (utils/data.py ImageFeaturesDB keeps every viewpoint it has read)
-    def _memo(self, key, make, limit=160):
-        c = self.__dict__.setdefault("_memo_store", {})
+    def _memo(self, key, make, limit=160, store="_memo_store"):
+        c = self.__dict__.setdefault(store, {})
         if key not in c:
             if len(c) >= limit:
                 c.pop(next(iter(c)))
@@ -242,6 +242,11 @@ class SyntheticNavEnv:
             })
         return cands
 
+    def _static_obs(self, sc, s, vi):
+        feature = sc.view_features(s.vp, self.image_feat_size)
+        return (feature, self.make_candidate(feature, s.scan, s.vp, vi),
+                np.concatenate((feature, self.angle_feature[vi]), -1).astype(np.float32))
+
     def _get_obs(self):
         """env.py:583-623 + EnvBatch.getStates (env.py:377-400)."""
         B = self.batch_size
@@ -260,15 +265,17 @@ class SyntheticNavEnv:
         for i, s in enumerate(states):
             item = self.batch[i]
             sc = self.scans[s.scan]
-            feature = sc.view_features(s.vp, self.image_feat_size)
             vi = s.view_index
-            cand = self.make_candidate(feature, s.scan, s.vp, vi)
+            # (candidates and the angle-extended view features are pure functions of (viewpoint, view index): kept like
+            # the reference keeps its buffered_state_dict, env.py:529-575; consumers treat them as read-only)
+            feature, cand, full_feature = sc._memo(("obs", s.vp, vi, self.image_feat_size), lambda: self._static_obs(sc, s, vi),
+                                                   limit=4096, store="_obs_store")
             x, y, z = sc.pos[s.vp]
             obs.append({
                 "instr_id": item["instr_id"], "scan": s.scan, "viewpoint": s.vp, "viewIndex": vi,
                 "position": (np.float32(x), np.float32(y), np.float32(z)),
                 "heading": np.float32(s.heading), "elevation": np.float32(s.elevation),
-                "feature": np.concatenate((feature, self.angle_feature[vi]), -1).astype(np.float32),
+                "feature": full_feature,
                 "candidate": cand, "instruction": item["instruction"],
                 "instr_encoding": [np.int32(t) for t in item["instr_encoding"]],
                 "gt_path": item["path"], "path_id": item["path_id"],

@@ -111,3 +111,73 @@ def test_dagger_training_iterations_on_hip():
     assert all(np.isfinite(l2))
     res = agent.test()
     assert len(res) == B and all(len(r["trajectory"]) >= 1 for r in res)
+
+
+class _StubMem:
+    slab = True
+
+    def reset(self):
+        pass
+
+    def step(self, *a):
+        pass
+
+
+class _StubStore:
+    def append(self, mem, keys):
+        return None, [(0.0, 0.0)] * len(keys)
+
+
+class _StubModel:
+    """Random embeddings / logits of the right shapes from a seeded generator: both collation paths see the same
+    stream as long as they call the model with the same shapes in the same order."""
+
+    def __init__(self, H=64):
+        self.H, self.g = H, torch.Generator().manual_seed(0)
+
+    def __call__(self, mode, b):
+        if mode == "language":
+            return torch.randn(*b["txt_ids"].shape, self.H, generator=self.g)
+        if mode == "panorama":
+            B, V = b["view_img_fts"].shape[:2]
+            return torch.randn(B, V, self.H, generator=self.g), torch.arange(V)[None] < b["view_lens"][:, None]
+        gm = b["gmap_masks"] & ~b["gmap_visited_masks"]
+        gl = torch.randn(gm.shape, generator=self.g).masked_fill(~gm, -float("inf"))
+        ll = torch.randn(b["vp_nav_masks"].shape, generator=self.g).masked_fill(~b["vp_nav_masks"], -float("inf"))
+        return {"global_logits": gl, "local_logits": ll, "fused_logits": gl, "grid_logits": gl}
+
+
+@pytest.mark.parametrize("over", [{}, {"enc_full_graph": False}, {"act_visited_nodes": True}])
+def test_batched_collation_equals_the_per_episode_restatement(over):
+    """collate.NavCollator (what the loop runs) against agent.py's line-by-line restatement of the reference's
+    _panorama_feature_variable / _nav_gmap_variable / _nav_vp_variable + TopoMap node embeddings: every key of
+    pano_inputs and nav_inputs at every step of a 10-step rollout -- integer / bool / name entries identical, floats
+    within 1 ulp of 1.0 (the running mean is a multiplication by 1/count instead of a division)."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.sim_env import SyntheticNavEnv
+
+    def run(fast):
+        env = SyntheticNavEnv(8, _StubMem(), n_scans=2, n_episodes=16, seed=3, geom=S.NATIVE, vocab=3000)
+        env.device_store = _StubStore()
+        ag = GMapNavAgent(default_args(max_action_len=10, **over), env, _StubModel(), device="cpu")
+        ag.fast_collate, ag.trace = fast, []
+        with torch.no_grad():
+            traj = ag.rollout()
+        return ag.trace, traj
+
+    (a, ta), (b, tb) = run(False), run(True)
+    assert len(a) == len(b) >= 5 and ta == tb
+    for x, y in zip(a, b):
+        for part in ("pano_inputs", "nav_inputs"):
+            assert set(x[part]) == set(y[part])
+            for k, v in x[part].items():
+                w = y[part][k]
+                if torch.is_tensor(v):
+                    assert v.shape == w.shape and v.dtype == w.dtype, k
+                    if v.dtype.is_floating_point:
+                        assert torch.allclose(v, w, atol=2e-7, rtol=2e-7), (k, float((v - w).abs().max()))
+                    else:
+                        assert torch.equal(v, w), k
+                elif k != "grid_memory":
+                    assert v == w, k
