@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -60,7 +60,7 @@ SIGNATURES = {
     "gridmm_fuse_logits": [_vp] * 13 + [_i, _i, _i, _vp],
     "gridmm_copy_rows": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp],
     # training (backward)
-    "gridmm_transpose_split": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_transpose_split": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_layernorm_bwd": [_vp, _i, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_activation": [_vp, _vp, _vp, _i64, _i, _vp],
     "gridmm_attention_train": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i,

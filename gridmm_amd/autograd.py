@@ -48,6 +48,18 @@ class _WeightCache:
             return pw
         return ops.PackedLinear(src.t().contiguous() if transposed else src.contiguous(), None)
 
+    @staticmethod
+    def _pack_both(w):
+        src = w.detach()
+        hi, lo, _, Np, rows = transpose_split(src, want_rows=True)
+        out = []
+        for h, l, N, K, Kp in ((rows.hi, rows.lo, src.shape[0], src.shape[1], src.shape[1]),
+                               (hi, lo, src.shape[1], src.shape[0], Np)):
+            pw = ops.PackedLinear.__new__(ops.PackedLinear)
+            pw.hi, pw.lo, pw.bias, pw.N, pw.K, pw.Kp = h, l, None, N, K, Kp
+            out.append(pw)
+        return out
+
     def getter(self, w):
         """-> get(transposed) returning the PackedLinear of w or w^T."""
         if not isinstance(w, torch.nn.Parameter):
@@ -63,7 +75,13 @@ class _WeightCache:
 
         def get(transposed, ent=ent, w=w):
             if transposed not in ent:
-                ent[transposed] = self._pack(w, transposed)
+                if (w.requires_grad and torch.is_grad_enabled() and w.dim() == 2 and w.dtype == torch.float32
+                        and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0 and w.is_contiguous()):
+                    # a trained weight is needed in both orientations every step (forward: W, dX: W^T): one pass over
+                    # it writes both pairs of planes instead of a split launch + a transposing launch
+                    ent[False], ent[True] = self._pack_both(w)
+                else:
+                    ent[transposed] = self._pack(w, transposed)
             return ent[transposed]
         return get
 
@@ -100,11 +118,12 @@ def transpose_split(x2d, want_colsum=False, want_rows=False):
     hi = torch.empty(C, Mp, dtype=torch.bfloat16, device=x2d.device)
     lo = torch.empty_like(hi)
     cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum else None
+    cs_ws = torch.empty((Mp + 255) // 256, C, dtype=torch.float32, device=x2d.device) if want_colsum else None
     rows = None
     if want_rows and C % 8 == 0:
         rh = torch.empty(M, C, dtype=torch.bfloat16, device=x2d.device)
         rows = ops.Act(x2d, rh, torch.empty_like(rh))
-    _lib.check(lib.gridmm_transpose_split(_p(x2d), ld, _p(hi), _p(lo), _p(cs), _p(rows.hi if rows else None),
+    _lib.check(lib.gridmm_transpose_split(_p(x2d), ld, _p(hi), _p(lo), _p(cs), _p(cs_ws), _p(rows.hi if rows else None),
                                           _p(rows.lo if rows else None), C, M, C, Mp, _stream()),
                "gridmm_transpose_split")
     return hi, lo, cs, Mp, rows

@@ -11,11 +11,11 @@ namespace {
 
 // X fp32 [M][C] (row stride ldx) -> bf16 hi/lo planes [C][Mp] (Mp % 32 == 0, zero padded) and colsum[C]
 // 64 x 64 tiles through LDS; grid (ceil(C/64), ceil(Mp/64)).
-constexpr int TS_TILES = 4;   // 64-row tiles per workgroup (256 rows): 4x fewer column-sum atomics, loads of tile t+1
-                              // are in flight while tile t is split and stored
+constexpr int TS_TILES = 4;   // 64-row tiles per workgroup (256 rows): one column-sum partial per 256 rows, loads of
+                              // tile t+1 are in flight while tile t is split and stored
 __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __restrict__ X, int ldx,
                                                               unsigned short* __restrict__ Th,
-                                                              unsigned short* __restrict__ Tl, float* __restrict__ colsum,
+                                                              unsigned short* __restrict__ Tl, float* __restrict__ colpart,
                                                               unsigned short* __restrict__ Rh,
                                                               unsigned short* __restrict__ Rl, int ldp,
                                                               int M, int C, int Mp) {
@@ -74,11 +74,20 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
       }
     }
   }
-  if (colsum) {            // the 4 row-groups of a column sit in adjacent lanes: one atomic per column and workgroup
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if ((tid & 3) == 0 && c0 + c < C) atomicAdd(&colsum[c0 + c], s);
+  if (colpart) {           // the 4 row-groups of a column sit in adjacent lanes: one partial per column and workgroup,
+    s += __shfl_xor(s, 1, 64);   // summed over the row blocks in a fixed order by colsum_reduce_kernel (no atomics:
+    s += __shfl_xor(s, 2, 64);   // db is bit-reproducible from run to run)
+    if ((tid & 3) == 0 && c0 + c < C) colpart[(size_t)blockIdx.y * C + c0 + c] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ colsum,
+                                                            int n_part, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < n_part; ++r) s += part[(size_t)r * C + c];
+  colsum[c] = s;
 }
 
 // LayerNorm backward, one wave per row.  y = (x - mean) * rstd * gamma + beta,  x = X (+ R)
@@ -215,16 +224,21 @@ __global__ void act_kernel(const float* __restrict__ X, const float* __restrict_
 
 }  // namespace
 
-extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, void* R_hi,
-                                      void* R_lo, int ldp, int M, int C, int Mp, gridmm_stream_t stream) {
+extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum,
+                                      float* colsum_ws, void* R_hi, void* R_lo, int ldp, int M, int C, int Mp,
+                                      gridmm_stream_t stream) {
   if (M <= 0 || C <= 0 || Mp < M || Mp % 32) return GRIDMM_EINVAL;
   if (R_hi && (!R_lo || ldp < C || ldp % 8)) return GRIDMM_EINVAL;
+  if (colsum && !colsum_ws) return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (colsum && !gridmm_zero_f32(colsum, (size_t)C, st)) return GRIDMM_ELAUNCH;
   dim3 grid((C + 63) / 64, (Mp + 64 * TS_TILES - 1) / (64 * TS_TILES)), block(256);
   GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)T_hi, (unsigned short*)T_lo,
-                colsum, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp);
+                colsum ? colsum_ws : nullptr, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp);
   GRIDMM_CHECK_LAUNCH();
+  if (colsum) {
+    GRIDMM_LAUNCH(colsum_reduce_kernel, dim3((C + 255) / 256), block, 0, st, colsum_ws, colsum, (int)grid.y, C);
+    GRIDMM_CHECK_LAUNCH();
+  }
   return GRIDMM_OK;
 }
 

@@ -100,13 +100,19 @@ __global__ __launch_bounds__(256) void multi_sumsq_kernel(const TensorDesc* __re
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc + (blockIdx.x & 63), (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));   // 64 partial slots
+  if (threadIdx.x == 0) acc[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);   // one partial per chunk: no atomics
 }
 
-__global__ void sum64_kernel(const float* __restrict__ part, float* __restrict__ out) {
-  float s = part[threadIdx.x];
+// the per-chunk partials in a fixed order (thread t takes chunks t, t + 256, ...; then the wave / LDS tree): the
+// gradient norm -- and with it the clip factor of every parameter -- is bit-reproducible from run to run
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float s_w[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
   s = wave_sum(s);
-  if (threadIdx.x == 0) *out = s;
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 // one chunk of one tensor; same arithmetic (and, for fp16, the same per-op roundings) as adamw_kernel<T>
@@ -183,14 +189,13 @@ extern "C" int gridmm_adamw_step(void* p, const void* g, void* m, void* v, int64
 }
 
 extern "C" int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tensors, int n_chunks,
-                                       float* partial64, float* out, gridmm_stream_t stream) {
-  if (n_tensors <= 0 || n_chunks <= 0 || !partial64 || !out) return GRIDMM_EINVAL;
+                                       float* partial, float* out, gridmm_stream_t stream) {
+  if (n_tensors <= 0 || n_chunks <= 0 || !partial || !out) return GRIDMM_EINVAL;
   hipStream_t st_ = as_stream(stream);
-  if (!gridmm_zero_f32(partial64, 64, st_)) return GRIDMM_ELAUNCH;
   GRIDMM_LAUNCH(multi_sumsq_kernel, dim3(n_chunks), dim3(256), 0, st_, (const TensorDesc*)desc, chunk_first, n_tensors,
-                partial64);
+                partial);
   GRIDMM_CHECK_LAUNCH();
-  GRIDMM_LAUNCH(sum64_kernel, dim3(1), dim3(64), 0, st_, partial64, out);
+  GRIDMM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, st_, partial, n_chunks, out);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

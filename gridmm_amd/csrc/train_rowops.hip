@@ -26,7 +26,8 @@ __global__ __launch_bounds__(64) void fuse_logits_bwd_kernel(
   for (int k = tid; k < V; k += blockDim.x) dL[k] = d_local ? d_local[b * V + k] : 0.f;
   __syncthreads();
   float dfw = 0.f, dbw = 0.f;            // dbw: gradient on the sum of visited candidates' local logits
-  // nodes: one thread per node adds into dL through LDS atomics (G, V <= a few dozen)
+  // nodes: one thread per node; the scatter of d_fused into dL is done afterwards by one thread in node order
+  // (G, V <= a few dozen; no float atomics: bit-reproducible whatever cand_of_node looks like)
   for (int j = tid; j < G; j += blockDim.x) {
     const bool ok = gmap_masks[b * G + j] && !gmap_visited[b * G + j];
     const float df = d_fused ? d_fused[b * G + j] : 0.f;
@@ -34,11 +35,13 @@ __global__ __launch_bounds__(64) void fuse_logits_bwd_kernel(
     d_g_raw[b * G + j] = dG * fw;
     dfw += dG * g_raw[b * G + j];
     d_grid_raw[b * G + j] = (ok && d_grid) ? d_grid[b * G + j] : 0.f;
-    if (j == 0) atomicAdd(&dL[0], df);
-    else {
+    if (j > 0 && cand_of_node[b * G + j] == -1) dbw += df;
+  }
+  if (tid == 0 && d_fused) {
+    dL[0] += d_fused[b * G];
+    for (int j = 1; j < G; ++j) {
       const int k = cand_of_node[b * G + j];
-      if (k >= 0) atomicAdd(&dL[k], df);
-      else if (k == -1) dbw += df;
+      if (k >= 0) dL[k] += d_fused[b * G + j];
     }
   }
   s_part[tid] = dbw;

@@ -144,7 +144,7 @@ class AdamW(torch.optim.Optimizer):
         sumsq = None
         if max_grad_norm is not None:
             sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-            part = torch.empty(64, dtype=torch.float32, device=dev)
+            part = torch.empty(max(t[2] for t in tables.values()), dtype=torch.float32, device=dev)
             tmp = torch.empty(1, dtype=torch.float32, device=dev)
             for (blob, rec_bytes, n_chunks), items in zip(tables.values(), classes.values()):
                 _lib.check(lib.gridmm_multi_grad_sumsq(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),

@@ -389,8 +389,10 @@ int gridmm_copy_rows(const float* src, int64_t src_bs, int src_rs, float* dst, i
  * plus colsum[C] = sum_m X[m][c] (NULL to skip).  With gridmm_linear_planes (C = A B^T) this gives
  *   dW [N][K] = dY^T X:  A = T(dY) [N][Mp], B = T(X) [K][Mp];   db = colsum(dY)
  * (backward of nn.Linear, e.g. vilmodel.py:84-86,128,144). */
-int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, void* R_hi, void* R_lo,
-                           int ldp, int M, int C, int Mp, gridmm_stream_t stream);
+int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, float* colsum_ws, void* R_hi,
+                           void* R_lo, int ldp, int M, int C, int Mp, gridmm_stream_t stream);
+/* (colsum != NULL needs colsum_ws >= ceil(Mp / 256) * C floats: one partial per 256-row block, summed in a fixed
+ * order -- no float atomics, db is bit-reproducible from run to run) */
 /* (R_hi / R_lo, optional: the row-major planes [M][ldp] of the same X from the same pass -- the A operand of the
  * forward / dX GEMM -- so an activation or a gradient is read ONCE for both of its GEMM roles) */
 
@@ -489,8 +491,9 @@ int gridmm_linear_planes_splitk(const void* A_hi, const void* A_lo, int lda, con
  *               moments alike); int32 pad;}  (64 bytes, natural C layout).  The scalars are read from the record at run
  *               time, so a captured (hipGraph) step advances lr / bias correction by rewriting the table.
  *   chunk_first device int32 [n_tensors + 1]: prefix sums of ceil(n / 16384); n_chunks = chunk_first[n_tensors]
- * gridmm_multi_grad_sumsq: partial64 = 64-float workspace, out = the global sum of squares (device scalar). */
-int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float* partial64,
+ * gridmm_multi_grad_sumsq: partial = n_chunks-float workspace (one partial per chunk, summed in a fixed order: the norm
+ * is bit-reproducible), out = the global sum of squares (device scalar). */
+int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float* partial,
                             float* out, gridmm_stream_t stream);
 int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float beta1,
                             float beta2, int decay_first, const float* sumsq, float max_norm, gridmm_stream_t stream);

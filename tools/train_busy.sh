@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open(glob.glob("$OUT/kt/**/*kernel_stats.csv", recurs
 tot = sum(float(r["TotalDurationNs"]) for r in rows); calls = sum(int(r["Calls"]) for r in rows)
 n = $N + 3
 print("kernel time per step %.2f ms, launches per step %.0f" % (tot / n / 1e6, calls / n))
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:25]:
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
     print("%-90s calls/step %6.1f  ms/step %6.3f" % (r["Name"][:90], int(r["Calls"]) / n, float(r["TotalDurationNs"]) / n / 1e6))
 PY
 rm -rf $OUT/kt
