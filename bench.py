@@ -239,7 +239,7 @@ def config_legs(args, dev, steps):
     return res
 
 
-def rollout_leg(args, dev, rollouts=3):
+def rollout_leg(args, dev, rollouts=4):
     """End to end: GMapNavAgent.rollout (map_nav_src/r2r/agent.py:268-451) over the synthetic environment, B = 32
     episodes x up to 15 steps at the BASELINE observation shape -- 'language' once, then per step 'panorama', TopoMap
     update, input collation, fill_gridmap, 'navigation', action selection, env step (argmax feedback, no_grad, varlen map
@@ -260,8 +260,10 @@ def rollout_leg(args, dev, rollouts=3):
     agent = GMapNavAgent(default_args(max_action_len=T), env, model, device=dev)
     agent.feedback = "argmax"
     agent._set_mode(False)
+    agent.enable_graph_replay()               # 'panorama' / 'navigation' from hipGraphs keyed by (bucketed) shape
     with torch.no_grad():
-        agent.rollout()                       # fills the environment's feature memo, packs the weights
+        for _ in range(4):                    # one epoch of the 4 mini-batches: fills the environment's feature memo, packs
+            agent.rollout()                   # the weights, captures the graphs of the shapes these rollouts visit
         torch.cuda.synchronize()
         n0, t0 = agent.nav_steps, time.perf_counter()
         for _ in range(rollouts):
@@ -279,7 +281,9 @@ def rollout_leg(args, dev, rollouts=3):
             "sections_ms_per_step": {k: 1e3 * v / prof_steps for k, v in sorted(agent.timers.items(), key=lambda kv: -kv[1])},
             "host_share": sum(v for k, v in agent.timers.items() if k.startswith("host") or k.startswith("env")) / tot,
             "workload": "GMapNavAgent.rollout, synthetic buildings (24 viewpoints, 36 views, 36x196x512 observations), "
-                        "argmax actions, eager launches, varlen map sequences, observation store resident in HBM"}
+                        "argmax actions, hipGraph replay per shape bucket (%d navigation graphs captured, %d replays), varlen "
+                        "map sequences, batched host collation, observation store resident in HBM"
+                        % (agent._graphs[1].captures, agent._graphs[1].replays)}
 
 
 def producer_leg(args, dev, steps=5):

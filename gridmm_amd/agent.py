@@ -73,6 +73,32 @@ class GMapNavAgent:
         self.fast_collate = True
         from .collate import NavCollator
         self.collator = NavCollator(args, self.device)
+        self._graphs = None
+
+    # node / view axes padded to these sizes when the model calls are replayed from hipGraphs (one graph per shape key)
+    NODE_BUCKETS = (8, 12, 16, 24, 32, 48, 64, 96, 128)
+    VIEW_BUCKETS = (36, 40, 48, 64)
+
+    def enable_graph_replay(self, model=None):
+        """Inference rollouts on the HIP model: 'panorama' and the shape-dependent half of 'navigation' are replayed from
+        hipGraphs keyed by shape (graph.NavigationGraphs / PanoramaGraphs); the collator pads the node and view axes to
+        buckets so that a rollout touches a handful of keys.  Same logits on the real rows (masked padding)."""
+        from .collate import NavCollator
+        from .graph import NavigationGraphs, PanoramaGraphs
+        model = model if model is not None else getattr(self.vln_bert, "vln_bert", self.vln_bert)
+        self.collator = NavCollator(self.args, self.device, node_buckets=self.NODE_BUCKETS, view_buckets=self.VIEW_BUCKETS)
+        self._graphs = (PanoramaGraphs(model), NavigationGraphs(model))
+        self.fast_collate = True
+
+    def _model_call(self, mode, batch):
+        if self._graphs is not None and not torch.is_grad_enabled():
+            if mode == "panorama":
+                out = self._graphs[0](batch)
+                return (out[0].clone(), out[1].clone()) if self.trace is not None else out
+            if mode == "navigation":
+                out = self._graphs[1](batch)
+                return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()} if self.trace is not None else out
+        return self.vln_bert(mode, batch)
 
     # ---- collation -----------------------------------------------------------------------------
     def _language_variable(self, obs):
@@ -262,7 +288,7 @@ class GMapNavAgent:
             fast = self.fast_collate
             pano_inputs = self.collator.panorama(obs) if fast else self._panorama_feature_variable(obs)
             t0 = self._tick("host: collate panorama inputs", t0)
-            pano_embeds, pano_masks = self.vln_bert("panorama", pano_inputs)
+            pano_embeds, pano_masks = self._model_call("panorama", pano_inputs)
             t0 = self._tick("panorama", t0)
             if fast:
                 self.collator.update_embeddings(obs, gmaps, ended, pano_embeds, pano_masks, pano_inputs["cand_vpids"])
@@ -282,7 +308,7 @@ class GMapNavAgent:
                                                         pano_inputs["view_lens"], pano_inputs["nav_types"]))
             nav_inputs.update({"txt_embeds": txt_embeds, "txt_masks": language_inputs["txt_masks"]})
             t0 = self._tick("host: TopoMap update + collate navigation inputs", t0)
-            nav_outs = self.vln_bert("navigation", nav_inputs)
+            nav_outs = self._model_call("navigation", nav_inputs)
             t0 = self._tick("navigation", t0)
 
             if self.args.fusion == "local":

@@ -24,15 +24,26 @@ from .graph_utils import UNREACHABLE, batched_pos_features
 
 
 class NavCollator:
-    def __init__(self, args, device, node_slots=48):
+    def __init__(self, args, device, node_slots=48, node_buckets=None, view_buckets=None):
+        """node_buckets / view_buckets: ascending sizes to which the graph-node axis G / the view axis V are padded
+        (masked rows: the model's outputs on the real rows do not change) so that the per-step shapes come from a small
+        set -- what graph.NavigationGraphs keys its captured graphs by.  None: the reference's shapes (max over the batch)."""
         self.args, self.device = args, torch.device(device)
         self.node_slots = node_slots
+        self.node_buckets, self.view_buckets = node_buckets, view_buckets
         self.pool = None              # (B, slots, H) running sums; slot 0 stays zero (stop token / padding)
         self.cnt = None               # (B, slots) host counts
 
     def reset(self, batch_size):
         self.pool = None
         self.cnt = np.zeros((batch_size, self.node_slots), dtype=np.int32)
+
+    @staticmethod
+    def _bucket(n, buckets):
+        for b in buckets or ():
+            if n <= b:
+                return int(b)
+        return n
 
     def _dev(self, a):
         return torch.from_numpy(a).to(self.device)
@@ -53,7 +64,7 @@ class NavCollator:
             n_cand.append(len(cands))
         lens = np.array([r.shape[0] for r in rows], dtype=np.int64)
         self._view_lens = lens
-        V, W = int(lens.max()), rows[0].shape[1]
+        V, W = self._bucket(int(lens.max()), self.view_buckets), rows[0].shape[1]
         full = np.zeros((B, V, W + 3), dtype=np.float32)
         types = np.zeros((B, V), dtype=np.int64)
         for i, r in enumerate(rows):
@@ -145,8 +156,10 @@ class NavCollator:
         feats = batched_pos_features(np.concatenate(deltas), np.concatenate(base_h), np.concatenate(base_e),
                                      np.concatenate(graphs), np.concatenate(hopss))
         F = feats.shape[1]
-        G = 1 + max(len(r[1]) for r in recs)
+        G = self._bucket(1 + max(len(r[1]) for r in recs), self.node_buckets)
         V1 = pano_embeds.shape[1] + 1
+        cand_of_node = np.full((B, G), -2, dtype=np.int32)     # integer form of the vpid-keyed fusion loops
+        cand_visited = np.zeros((B, V1), dtype=np.uint8)       # (vilmodel.py:884-899; GlocalTextPathNavCMT._fusion_index_maps)
         gpos = np.zeros((B, G, F), dtype=np.float32)
         pair = np.zeros((B, G, G), dtype=np.float32)
         steps = np.zeros((B, G), dtype=np.int64)
@@ -180,6 +193,15 @@ class NavCollator:
             inv[i, 1:m + 1] = np.float32(1.0) / c.astype(np.float32)
             vpids.append([None] + names)
             no_vp_left.append(n_unv == 0)
+            seen_names = set(names[:n_vis])
+            col = {}
+            for j, cv in enumerate(cand_vpids[i]):
+                if cv in seen_names:
+                    cand_visited[i, j + 1] = 1
+                else:
+                    col[cv] = j + 1
+            for j in range(n_vis, m):
+                cand_of_node[i, j + 1] = col.get(names[j], -1)
         slot_d, inv_d = self._dev(slot), self._dev(inv)
         rows = torch.arange(B, device=self.device).unsqueeze(1)
         gmap_img = self.pool[rows, slot_d] * inv_d.unsqueeze(2)
@@ -188,11 +210,12 @@ class NavCollator:
             "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited),
             "gmap_pair_dists": self._dev(pair),
             "gmap_masks": self._dev(np.arange(G)[None] < lens[:, None]), "no_vp_left": no_vp_left,
+            "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),
         }
         vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
         nav_masks = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=self.device), nav_types == 1], 1)
         vl = view_lens + 1
-        v_max = int(self._view_lens.max()) + 1 if getattr(self, "_view_lens", None) is not None else int(vl.max())
+        v_max = V1                    # == max(view_lens) + 1 on the reference's shapes; the padded width with view buckets
         out.update({
             "vp_img_embeds": vp_img, "vp_pos_fts": self._dev(vpos),
             "vp_masks": torch.arange(v_max, device=vl.device).unsqueeze(0) < vl.unsqueeze(1),

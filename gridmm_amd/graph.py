@@ -19,6 +19,8 @@ outputs are static buffers: nothing is re-projected).  Results equal the 196-row
 """
 import torch
 
+from . import ops
+
 
 class GraphedNavStep:
     def __init__(self, model, mem, batch, depth, restore=None, warmup=2, buckets=None):
@@ -146,3 +148,135 @@ class GraphedNavStep:
             return self._call_bucketed(check)
         self.graph.replay()
         return self.outs
+
+
+class NavigationGraphs:
+    """forward('navigation') for callers whose shapes change from step to step (GMapNavAgent.rollout: the topological
+    map grows, instructions differ in length between mini-batches): the half of the step that depends on those shapes
+    -- position embeddings, grid encoder, grid/text layer, local encoder, heads: ~80 of the ~90 launches -- is replayed
+    from a hipGraph captured once per shape key (L, G, V + 1, cell bucket); the first half (text projection +
+    instruction-relevance aggregation + grid_proj, 6 launches whose grid sizes follow the memory depth t) is launched
+    eagerly and handed over through static buffers.  With collate.NavCollator padding G and V to buckets, a rollout
+    touches a handful of keys; graphs share one memory pool (they never run concurrently) and the least recently used
+    one is dropped beyond `max_graphs`.
+
+    The occupied-cell bucket comes from the grid memory's tracked count (GridMemoryBatch.cmax_hint) when available, else
+    from a read-back of this call's occupancy bytes.  Outputs are the graph's static tensors: consume (or clone) them
+    before the next call with the same key.  Same results as the eager call (tests/test_hip_graph_step.py)."""
+
+    TENSOR_KEYS = ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_masks", "gmap_visited_masks",
+                   "vp_img_embeds", "vp_pos_fts", "vp_masks", "vp_nav_masks", "vp_obj_masks")
+
+    def __init__(self, model, max_graphs=96):
+        self.model, self.max_graphs = model, max_graphs
+        self.graphs = {}            # key -> dict(graph, static inputs, front buffers, outs); insertion order = recency
+        self.pool = None
+        self.captures = self.replays = 0
+
+    def _inputs(self, batch):
+        ins = {k: batch[k] for k in self.TENSOR_KEYS if batch.get(k) is not None}
+        fm = batch.get("fusion_maps")
+        if fm is None:
+            fm = self.model.fusion_maps(batch, batch["txt_embeds"].device)
+        ins["fm0"], ins["fm1"] = fm
+        return ins
+
+    @staticmethod
+    def _front_tensors(fr):
+        return {"txt_f32": fr.txt.f32, "txt_hi": fr.txt.hi, "txt_lo": fr.txt.lo, "txt_m": fr.txt_m, "proj": fr.proj,
+                "occ": fr.occ, "pos": fr.gridmap_pos_fts}
+
+    def _static_batch(self, ent, batch):
+        b = {k: ent["ins"].get(k) for k in self.TENSOR_KEYS}
+        b.update(txt_embeds=batch["txt_embeds"], fusion_maps=(ent["ins"]["fm0"], ent["ins"]["fm1"]),
+                 gmap_vpids=None, vp_cand_vpids=None)
+        return b
+
+    def _capture(self, key, fr, batch, c_pad):
+        from types import SimpleNamespace
+        model = self.model
+        ent = {"ins": {k: v.clone() for k, v in self._inputs(batch).items()},
+               "fr": {k: v.clone() for k, v in self._front_tensors(fr).items()}}
+        f = ent["fr"]
+        f["txt_hi"], f["txt_lo"] = ops._planes_like(fr.txt.hi.shape, fr.txt.hi.device)   # one allocation: moved by one launch
+        ent["front"] = SimpleNamespace(txt=ops.Act(f["txt_f32"], f["txt_hi"], f["txt_lo"]), txt_m=f["txt_m"], proj=f["proj"],
+                                       occ=f["occ"], gridmap_pos_fts=f["pos"], in_place=False)
+        sb = self._static_batch(ent, batch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):             # warm-up on a side stream: allocator pools, weight packs of this shape
+            model.navigation_back(ent["front"], c_pad, sb)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool):
+            ent["outs"] = model.navigation_back(ent["front"], c_pad, sb)
+        if self.pool is None:
+            self.pool = g.pool()
+        ent["graph"] = g
+        self.captures += 1
+        while len(self.graphs) >= self.max_graphs:
+            self.graphs.pop(next(iter(self.graphs)))
+        self.graphs[key] = ent
+        return ent
+
+    @torch.no_grad()
+    def __call__(self, batch):
+        model, mem = self.model, batch.get("grid_memory")
+        fr = model.navigation_front(batch)
+        cmax = mem.cmax_hint() if mem is not None and hasattr(mem, "cmax_hint") else None
+        if cmax is None:
+            cmax = int(fr.occ.sum(1, dtype=torch.int32).max())
+        c_pad = model.pick_bucket(cmax)
+        ins = self._inputs(batch)
+        key = (tuple(fr.txt.f32.shape), batch["gmap_masks"].shape[1], batch["vp_masks"].shape[1], c_pad,
+               tuple(sorted(ins)))
+        ent = self.graphs.pop(key, None)
+        if ent is None:
+            ent = self._capture(key, fr, batch, c_pad)
+        else:
+            self.graphs[key] = ent                # most recently used
+        for k, v in ins.items():
+            ent["ins"][k].copy_(v)
+        for k, v in self._front_tensors(fr).items():
+            ent["fr"][k].copy_(v)
+        ent["graph"].replay()
+        self.replays += 1
+        return ent["outs"]
+
+
+class PanoramaGraphs:
+    """forward('panorama') (view-only form) replayed from one hipGraph per input shape (B, V): ~20 launches per call.
+    Static outputs: consume before the next call with the same shape."""
+
+    KEYS = ("view_img_fts", "loc_fts", "nav_types", "view_lens")
+
+    def __init__(self, model):
+        self.model, self.graphs, self.pool = model, {}, None
+
+    @torch.no_grad()
+    def __call__(self, batch):
+        if batch.get("obj_img_fts") is not None:
+            return self.model("panorama", batch)          # the interleaved view / object form reads lengths on the host
+        key = tuple(batch["view_img_fts"].shape)
+        ent = self.graphs.get(key)
+        if ent is None:
+            ent = {"ins": {k: batch[k].clone() for k in self.KEYS}}
+            sb = dict(ent["ins"], obj_img_fts=None, obj_lens=None)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.model("panorama", sb)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool):
+                ent["outs"] = self.model("panorama", sb)
+            if self.pool is None:
+                self.pool = g.pool()
+            ent["graph"] = g
+            self.graphs[key] = ent
+        for k in self.KEYS:
+            ent["ins"][k].copy_(batch[k])
+        ent["graph"].replay()
+        return ent["outs"]

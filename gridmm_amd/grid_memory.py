@@ -81,6 +81,9 @@ class GridMemoryBatch:
         self.act_d.fill_(1)
         self._active = None
         self._h2d_done = None
+        self._cmax_event = None
+        self._cmax_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._cmax_host = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(1, dtype=torch.int32)
         self._bbox_init = torch.tensor([-10000.0, 10000.0, -10000.0, 10000.0], device=dev).repeat(B, 1)
         # host-side constants, rounded exactly as NumPy rounds them in env.py:118, 290
         P = geom.patches
@@ -110,6 +113,7 @@ class GridMemoryBatch:
         self.n_pts.zero_()
         self.n_pts_host[:] = 0
         self.cell_id.fill_(-1)
+        self._cmax_event = None
 
     # ---- host half of a step: a few floats per episode into static (pinned -> device) buffers
     def set_pose(self, poses, headings, active=None):
@@ -192,7 +196,26 @@ class GridMemoryBatch:
         self.set_pose(poses, headings, active)
         self.project_and_bin(depth)
         self.n_pts_host[act_host] += n_new            # host mirror of the device-side counter
+        self._cmax_event = None
+        if self.track_cmax and dev.type == "cuda":
+            # the batch's largest occupied-cell count (the reference's max_cell_num, vilmodel.py:809-823) goes to a pinned
+            # word behind the binning kernels: by the time the caller has collated the navigation inputs it is on the host,
+            # and the varlen path picks its sequence bucket without stalling the stream (cmax_hint)
+            cs = self.cell_start[:, :197]                 # 196 cell ranges (+ the invalid-point bin behind them)
+            self._cmax_dev.copy_((cs[:, 1:] > cs[:, :-1]).sum(1, dtype=torch.int32).max())
+            self._cmax_host.copy_(self._cmax_dev, non_blocking=True)
+            self._cmax_event = torch.cuda.Event()
+            self._cmax_event.record()
         return self.pos_fts
+
+    track_cmax = False
+
+    def cmax_hint(self):
+        """Largest occupied-cell count over the batch after the last step(), or None when it was not tracked."""
+        if self._cmax_event is None:
+            return None
+        self._cmax_event.synchronize()
+        return int(self._cmax_host[0])
 
     def points_upper_bound(self):
         """Host-known bound of the points per episode after the step in flight (graph replays append one observation

@@ -599,6 +599,7 @@ def copy_planes(src, dst, dst_row0=0):
     allocation (what _planes_like hands out), else two."""
     def paired(a):   # lo sits exactly B batch strides behind hi (also true for row slices of such a pair)
         return (a.hi.shape == a.lo.shape and a.hi.stride() == a.lo.stride() and a.hi.stride(2) == 1
+                and a.hi.untyped_storage().data_ptr() == a.lo.untyped_storage().data_ptr()
                 and a.lo.data_ptr() - a.hi.data_ptr() == a.hi.shape[0] * a.hi.stride(0) * a.hi.element_size())
     if paired(src) and paired(dst):
         B, rows, H = src.hi.shape

@@ -189,6 +189,7 @@ class SyntheticNavEnv:
                 dep.append(sc.depth(vp, self.geom).reshape(-1))
                 poses.append(sc.pos[vp])
         self.device_store = DeviceStore(keys, np.stack(tok), np.stack(dep), poses, device)
+        self.grid_memory.track_cmax = True        # the varlen navigation path then needs no mid-step read-back
         return self.device_store
 
     # ---- simulator surface used by the agent (agent.py:255: sims[i].newEpisode)

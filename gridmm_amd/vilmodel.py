@@ -406,7 +406,10 @@ class GlocalTextPathNavCMT(nn.Module):
         y = self._ln(ie.loc_layer_norm, ops.linear(loc_fts.float().contiguous(), self._lin(ie.loc_linear, "loc")),
                      add1=extra)
         x = self._ln(ie.layer_norm, x, residual=y.f32).f32
-        masks = torch.arange(int(lens.max()), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
+        # (views only: the mask spans the padded view axis as it is -- no read-back of the largest length; a caller may
+        # pad the axis beyond it, e.g. to a graph shape bucket.  With objects the interleaved rows end at max(lens).)
+        n = x.shape[1] if obj_img_fts is None else int(lens.max())
+        masks = torch.arange(n, device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
         if ie.pano_encoder is not None:
             x = self._pre_ln_encoder(ie.pano_encoder, "pano", x, self._u8(masks)).f32
         return x, masks
@@ -595,7 +598,11 @@ class GlocalTextPathNavCMT(nn.Module):
         back = (gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks, vp_img_embeds, vp_pos_fts, vp_masks)
         if self.varlen_buckets and not torch.cuda.is_current_stream_capturing():
             fr = self._nav_front(txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory)
-            cmax = int(fr.occ.sum(1, dtype=torch.int32).max())      # the reference's max_cell_num (host decision)
+            # the reference's max_cell_num (a host decision): from the grid memory's pinned word when it tracked the
+            # count behind its last step (no stall), else read back from the occupancy bytes of this call
+            cmax = grid_memory.cmax_hint() if grid_memory is not None and hasattr(grid_memory, "cmax_hint") else None
+            if cmax is None:
+                cmax = int(fr.occ.sum(1, dtype=torch.int32).max())
             return self._nav_back(fr, self.pick_bucket(cmax), *back)
         S = N_CELLS + G
         kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))

@@ -170,7 +170,7 @@ def test_batched_collation_equals_the_per_episode_restatement(over):
     assert len(a) == len(b) >= 5 and ta == tb
     for x, y in zip(a, b):
         for part in ("pano_inputs", "nav_inputs"):
-            assert set(x[part]) == set(y[part])
+            assert set(x[part]) == set(y[part]) - {"fusion_maps"}
             for k, v in x[part].items():
                 w = y[part][k]
                 if torch.is_tensor(v):
@@ -181,3 +181,55 @@ def test_batched_collation_equals_the_per_episode_restatement(over):
                         assert torch.equal(v, w), k
                 elif k != "grid_memory":
                     assert v == w, k
+        # the collator's integer maps of the logit fusion == the model's own host loops over the vpid lists
+        from gridmm_amd.vilmodel import GlocalTextPathNavCMT
+        n = x["nav_inputs"]
+        want = GlocalTextPathNavCMT._fusion_index_maps(n["gmap_vpids"], n["gmap_visited_masks"], n["vp_cand_vpids"],
+                                                       n["gmap_masks"].shape[1], n["vp_masks"].shape[1])
+        got = y["nav_inputs"]["fusion_maps"]
+        assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+
+
+@pytest.mark.gpu
+def test_rollout_with_graph_replay_equals_the_eager_rollout():
+    """GMapNavAgent.enable_graph_replay(): 'panorama' + the shape-dependent half of 'navigation' from hipGraphs keyed by
+    shape, node / view axes padded to buckets, varlen cell buckets from the grid memory's tracked count -- same actions
+    and trajectories as the eager rollout on the reference's shapes, logits of the real rows within 2e-5."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.sim_env import SyntheticNavEnv
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    dev, B, T = torch.device("cuda"), 6, 8
+    torch.manual_seed(0)
+    cfg = default_config(num_l_layers=2, num_pano_layers=1, num_x_layers=2, intermediate_size=512, vocab_size=3000)
+    model = GlocalTextPathNavCMT(cfg).eval().to(dev)
+    model.varlen_buckets = GlocalTextPathNavCMT.DEFAULT_BUCKETS
+
+    def run(graphs):
+        mem = GridMemoryBatch(B, S.NATIVE, max_steps=T + 2, device=dev)
+        env = SyntheticNavEnv(B, mem, n_scans=2, n_episodes=2 * B, seed=5, geom=S.NATIVE, vocab=3000)
+        env.build_device_store(dev)
+        ag = GMapNavAgent(default_args(max_action_len=T), env, model, device=dev)
+        ag.feedback = "argmax"
+        ag._set_mode(False)
+        if graphs:
+            ag.enable_graph_replay()
+        ag.trace = []
+        with torch.no_grad():
+            traj = [ag.rollout(), ag.rollout()]          # second mini-batch: other instruction lengths, graphs reused
+        return ag, traj
+
+    (ea, te), (ga, tg) = run(False), run(True)
+    assert te == tg and len(ea.trace) == len(ga.trace)
+    for x, y in zip(ea.trace, ga.trace):
+        assert np.array_equal(x["a_t"], y["a_t"])
+        for k in ("fused_logits", "global_logits", "local_logits", "grid_logits"):
+            a, b = x["nav_outs"][k], y["nav_outs"][k]
+            b = b[:, :a.shape[1]]
+            f = torch.isfinite(a)
+            assert torch.equal(f, torch.isfinite(b)), k
+            assert (a[f] - b[f]).abs().max() < 2e-5, (k, float((a[f] - b[f]).abs().max()))
+        assert not torch.isfinite(y["nav_outs"]["fused_logits"][:, x["nav_outs"]["fused_logits"].shape[1]:]).any()
+    g = ga._graphs[1]
+    assert g.replays == len(ga.trace) and g.captures < g.replays

@@ -63,6 +63,7 @@ def test_store_to_device_grid_memory_matches_oracle_and_list_form(tmp_path):
     # the same walk with the store resident in HBM (DeviceStore: observations gathered on the device, no PCIe traffic)
     ds = FS.DeviceStore.from_packed(st, dev)
     mem2 = GridMemoryBatch(B, S.NATIVE, max_steps=T, device=dev)
+    mem2.track_cmax = True             # the occupied-cell count follows every step to a pinned word (varlen hint)
     for t in range(T):
         d, poses = ds.append(mem2, [walks[b][t] for b in range(B)])
         mem2.step(d, None, poses, [heads[b][t] for b in range(B)])
@@ -84,6 +85,16 @@ def test_store_to_device_grid_memory_matches_oracle_and_list_form(tmp_path):
         want = O.forward_navigation(sd, dict(batch, grid_fts=[torch.from_numpy(r[0]) for r in ref],
                                              grid_map=[torch.from_numpy(r[1]) for r in ref],
                                              gridmap_pos_fts=torch.from_numpy(np.stack([r[2] for r in ref]))))
+        # varlen map sequence chosen from the memory's tracked count (no read-back inside the call)
+        occupied = max(len(np.unique(r[1][r[1] >= 0])) for r in ref)
+        assert mem2.cmax_hint() == occupied
+        model.varlen_buckets = tuple(sorted({min(196, (occupied + 15) // 16 * 16), 196}))
+        var = model("navigation", dict(S.batch_to(batch, dev), grid_memory=mem2, grid_fts=None, grid_map=None,
+                                       gridmap_pos_fts=None))
+        model.varlen_buckets = None
+    for k in ("global_logits", "local_logits", "fused_logits", "grid_logits"):
+        f = torch.isfinite(got[k])
+        assert torch.equal(f, torch.isfinite(var[k])) and (got[k][f] - var[k][f]).abs().max() < 2e-5, k
     for k in ("global_logits", "local_logits", "fused_logits", "grid_logits"):
         a, l, w = got[k].cpu(), lst[k].cpu(), want[k]
         f = torch.isfinite(w)
