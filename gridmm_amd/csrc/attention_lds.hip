@@ -63,8 +63,8 @@ __device__ unsigned long long g_att_prof[8];
 #define GRIDMM_T(i) do { } while (0)
 #endif
 
-template <int NQ, int NW, int KC, int AB = 0>
-__global__ __launch_bounds__((NW + 1) * 64) void attention_rows_kernel(
+template <int NQ, int NW, int KC, int AB = 0, int NL = 1>
+__global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
     const unsigned short* __restrict__ Qh, const unsigned short* __restrict__ Ql, int64_t q_bs, int q_rs,
     const unsigned short* __restrict__ Kh, const unsigned short* __restrict__ Kl, int64_t k_bs, int k_rs,
     const unsigned short* __restrict__ Vh, const unsigned short* __restrict__ Vl, int64_t v_bs, int v_rs,
@@ -108,8 +108,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void attention_rows_kernel(
   auto stage = [&](int key0c, int buf) {   // piece = (plane, 8 key rows); lane -> (row r0 + lane / 8, slot lane % 8)
     if (AB == 1 || AB == 3) return;        // timing ablation: no staging
     const int lrow = lane >> 3, coff = ((lane & 7) ^ (lrow & 6)) << 3;   // r0 % 8 == 0: the slot swizzle is per lane
+    const int li = NL > 1 ? wave - NW : 0;                               // the NL loader waves take every NL-th row group
 #pragma unroll
-    for (int r0 = 0; r0 < KC; r0 += 8) {
+    for (int r0 = 8 * li; r0 < KC; r0 += 8 * NL) {
       const int key = min(key0c + r0 + lrow, Sk - 1);
       const size_t ko = (size_t)key * k_rs + coff, vo = (size_t)key * v_rs + coff;
       unsigned short* d = kvbuf + buf * (4 * PLANE) + r0 * 64;
@@ -123,9 +124,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void attention_rows_kernel(
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = __builtin_readcyclecounter();
 #endif
-  if (wave == NW) {                        // ---------------- loader wave
+  if (wave >= NW) {                        // ---------------- loader wave(s)
     stage(0, 0);
-    {   // validity words from independent byte loads, under the first DMA
+    if (wave == NW) {   // validity words from independent byte loads, under the first DMA
       const uint8_t* mrow = kmask ? kmask + (size_t)b * mask_bs : nullptr;
       for (int i = 0; i < ((Sk + 63) >> 6); ++i) {
         const int k = i * 64 + lane;
@@ -367,16 +368,17 @@ extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int
   if ((!O && !O_hi) || (O_hi && (!O_lo || (p_rs & 3) || (p_bs & 3))) || (O && ((o_rs & 3) || (o_bs & 3))))
     return GRIDMM_EINVAL;
   const int nqt = (Sq + 15) / 16;
-  if (cfg == 0) cfg = nqt <= 4 ? 5 : 3;   // tools/bench_attn2.py: 57-query calls 7-17 us with (1, 4, 32); 216-query calls 27-40 us with (1, 8, 64)
+  if (cfg == 0) cfg = nqt <= 4 ? 5 : 9;   // tools/bench_attn2.py: 57-query calls 7-17 us with (1, 4, 32); 216-query calls 25-38 us with (1, 8, 32)
 #define GRIDMM_ATT_ARGS                                                                                             \
   (const unsigned short*)Q_hi, (const unsigned short*)Q_lo, q_bs, q_rs, (const unsigned short*)K_hi,               \
       (const unsigned short*)K_lo, k_bs, k_rs, (const unsigned short*)V_hi, (const unsigned short*)V_lo, v_bs, v_rs, \
       kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs, p_rs, Sq, Sk, scale
-#define GRIDMM_ATTX(NQ, NW, KC, AB)                                                                                     \
+#define GRIDMM_ATTL(NQ, NW, KC, AB, NL)                                                                                 \
   do {                                                                                                              \
-    dim3 grid((nqt + (NQ) * (NW) - 1) / ((NQ) * (NW)), heads, B), block(((NW) + 1) * 64);                                  \
-    GRIDMM_LAUNCH((attention_rows_kernel<NQ, NW, KC, AB>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS);    \
+    dim3 grid((nqt + (NQ) * (NW) - 1) / ((NQ) * (NW)), heads, B), block(((NW) + (NL)) * 64);                               \
+    GRIDMM_LAUNCH((attention_rows_kernel<NQ, NW, KC, AB, NL>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS); \
   } while (0)
+#define GRIDMM_ATTX(NQ, NW, KC, AB) GRIDMM_ATTL(NQ, NW, KC, AB, 1)
 #define GRIDMM_ATT(NQ, NW, KC) GRIDMM_ATTX(NQ, NW, KC, 0)
   switch (cfg) {
     case 1: GRIDMM_ATT(1, 4, 64); break;
@@ -384,6 +386,14 @@ extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int
     case 3: GRIDMM_ATT(1, 8, 64); break;
     case 5: GRIDMM_ATT(1, 4, 32); break;
     case 6: GRIDMM_ATT(2, 4, 32); break;
+    case 7: GRIDMM_ATT(2, 8, 64); break;
+    case 8: GRIDMM_ATT(2, 8, 32); break;
+    case 9: GRIDMM_ATT(1, 8, 32); break;
+    case 14: GRIDMM_ATTL(1, 8, 64, 0, 2); break;   // two loader waves
+    case 15: GRIDMM_ATTL(1, 4, 32, 0, 2); break;
+    case 16: GRIDMM_ATTL(2, 8, 64, 0, 2); break;
+    case 17: GRIDMM_ATTL(2, 4, 64, 0, 2); break;
+    case 18: GRIDMM_ATTL(1, 4, 64, 0, 2); break;
     case 11: GRIDMM_ATTX(2, 4, 64, 1); break;   // ablations of cfg 2: no staging / no math
     case 12: GRIDMM_ATTX(2, 4, 64, 2); break;
     case 13: GRIDMM_ATTX(2, 4, 64, 3); break;
@@ -391,6 +401,7 @@ extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int
   }
 #undef GRIDMM_ATT
 #undef GRIDMM_ATTX
+#undef GRIDMM_ATTL
 #undef GRIDMM_ATT_ARGS
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;

@@ -43,7 +43,7 @@ for (name, Sq, Sk, Wq, Wk) in [("grid self", 216, 216, 2304, 2304), ("grid x tex
             for _ in range(3): rows(c)()
         torch.cuda.synchronize()
         continue
-    print("%-12s attention_rows cfg 1,2,3,5,6:" % name, " ".join("%5.1f" % gtime(rows(c)) for c in (1, 2, 3, 5, 6)), "us | cfg 2 without staging %.1f, without math %.1f, neither %.1f" % (gtime(rows(11)), gtime(rows(12)), gtime(rows(13))), flush=True)
+    print("%-12s attention_rows cfg 1,2,3,5,6,7,8,9 | 14..18:" % name, " ".join("%5.1f" % gtime(rows(c)) for c in (1, 2, 3, 5, 6, 7, 8, 9)), "|", " ".join("%5.1f" % gtime(rows(c)) for c in (14, 15, 16, 17, 18)), "us | cfg 2 without staging %.1f, without math %.1f, neither %.1f" % (gtime(rows(11)), gtime(rows(12)), gtime(rows(13))), flush=True)
     mf = 4.0 * B * Sq * Sk * 768 * 3
     t1, t2 = gtime(tr), gtime(at)
     print("%-12s Sq=%3d Sk=%3d | transpose_v %5.1f us | attention_planes %5.1f us (%.0f TF on the pipe; MFMA floor %.1f us)" % (name, Sq, Sk, t1, t2, mf / t2 / 1e6, mf / 2.5e9), flush=True)
