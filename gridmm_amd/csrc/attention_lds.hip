@@ -75,7 +75,7 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
   constexpr int PLANE = KC * 64;                                  // u16 per plane image
   constexpr int NT = KC / 32;                                     // key tiles per chunk
   __shared__ __attribute__((aligned(16))) unsigned short kvbuf[2 * 4 * PLANE];   // 2 x (K hi | K lo | V hi | V lo)
-  __shared__ unsigned s_mw[16];                                   // key validity, one word per 32 keys (Sk <= 512)
+  __shared__ unsigned s_mw[64];                                   // key validity, one word per 32 keys (Sk <= 2048)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
@@ -363,7 +363,7 @@ extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int
                                          int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
                                          int64_t o_bs, int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B,
                                          int heads, int Sq, int Sk, float scale, int cfg, gridmm_stream_t stream) {
-  if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || Sk > 512) return GRIDMM_EINVAL;   // mask words: 16 x 32 keys
+  if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || Sk > 2048) return GRIDMM_EINVAL;   // mask words: 64 x 32 keys
   if ((q_rs | k_rs | v_rs) & 7 || (q_bs | k_bs | v_bs) & 7) return GRIDMM_EINVAL;      // 16-byte aligned rows
   if ((!O && !O_hi) || (O_hi && (!O_lo || (p_rs & 3) || (p_bs & 3))) || (O && ((o_rs & 3) || (o_bs & 3))))
     return GRIDMM_EINVAL;

@@ -256,7 +256,7 @@ int gridmm_attention_planes(const void* Q_hi, const void* Q_lo, int64_t q_bs, in
  * through the hardware transpose read.  Replaces gridmm_transpose_v + gridmm_attention_planes on the hot path of
  * BertSelfAttention / BertOutAttention (map_nav_src/models/vilmodel.py:317-379) and of the grid encoder's
  * nn.MultiheadAttention (map_nav_src/models/transformer.py:176-177).  Strides in elements, rows 16-byte aligned;
- * Sk <= 512; kmask (B, Sk) bytes, 0 = masked (contributes exactly 0); a fully masked query row yields 0.
+ * Sk <= 2048; kmask (B, Sk) bytes, 0 = masked (contributes exactly 0); a fully masked query row yields 0.
  * _cfg: cfg = 0 picks the launch shape, cfg > 0 forces one (tools/bench_attn2.py). */
 int gridmm_attention_rows(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
                           const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo, int64_t v_bs,

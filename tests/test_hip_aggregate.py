@@ -57,6 +57,9 @@ CASES = [
     (512, 200, "crowded", [9000, 1111, 33, 1], 8),
     (512, 250, "sparse", [400, 300, 0], None),   # 16 token tiles
     (256, 200, "blocks", [3000, 500], None),
+    (512, 300, "blocks", [2048, 300, 31], None),   # past the pipelined paths (L <= 256): generic kernel, any L <= 512
+    (768, 300, "crowded", [3000, 64, 700], 8),     # (rxr_pretrain.json: max_txt_len 300)
+    (768, 512, "sparse", [400, 300, 0], None),     # BERT's position table
     (768, 120, "blocks", [2000, 300], None),
     (768, 200, "crowded", [5000, 64, 700], 24),
     (768, 200, "sparse", [150, 97, 0, 260], None),
@@ -94,7 +97,7 @@ def test_grid_aggregate_regimes(D, L, kind, npts, n_chunks):
     cells, occ, rel, amax = ops.grid_aggregate(slab, perm, cs, ops.text_fragments(text.cuda()), L, n_chunks=n_chunks,
                                                want_relevance=True, want_amax=True)
     torch.cuda.synchronize()
-    if max(npts) <= 45000:
+    if max(npts) <= 45000 and L <= 256:
         # every shape up to L = 256 runs on a pipelined path (one pass: D <= 512, 33 <= L <= 96; else relevance +
         # accumulation passes), which also delivers the backward's routing; the generic kernel (rc 1) does not
         assert ops.LAST_AGGREGATE_RC == 0 and amax is not None

@@ -242,8 +242,9 @@ def test_empty_and_degenerate_grid_memories_match_oracle():
     _cmp(got["gmap_embeds"], want["gmap_embeds"].numpy(), EMBED_TOL)
 
 
-@pytest.mark.parametrize("seed,geom_name,T", [(1, "NATIVE", 3), (2, "NATIVE", 6), (3, "BASELINE", 2), (4, "NATIVE", 1)])
-def test_step_sequence_matches_oracle_over_seeds(seed, geom_name, T):
+@pytest.mark.parametrize("seed,geom_name,T,long", [(1, "NATIVE", 3, False), (2, "NATIVE", 6, False), (3, "BASELINE", 2, False),
+                                                   (4, "NATIVE", 1, False), (5, "NATIVE", 2, True)])
+def test_step_sequence_matches_oracle_over_seeds(seed, geom_name, T, long):
     """fill_gridmap over T observations + forward('navigation') on the device-resident memory vs the oracle's literal
     loops, fresh random episodes per seed: cell ids bit-exact at every step, logits within LOGIT_TOL.  NATIVE runs the
     two-pass D = 768 aggregation (relevance pass + accumulation pass), BASELINE the single pipelined kernel."""
@@ -272,7 +273,11 @@ def test_step_sequence_matches_oracle_over_seeds(seed, geom_name, T):
         for b in range(B):
             n = ref[b][1].shape[0]
             assert np.array_equal(mem.cell_id[b, :n].cpu().numpy(), ref[b][1].astype(np.int16)), (t, b)
-    batch = S.make_nav_batch(rs, B, L=40 + 10 * seed, G=8, n_visited=3, V1=10, n_cand=3, min_len=8)
+    if long:   # RxR-sized sequences (scripts/run_rxr.sh: max_instr_len 250; rxr_pretrain.json: 300) and a long topological
+        # map: 196 + 90 + 300 = 586 keys in the local encoder's context (past the 512 keys of the round-2 attention kernel)
+        batch = S.make_nav_batch(rs, B, L=300, G=90, n_visited=40, V1=37, n_cand=5, min_len=120)
+    else:
+        batch = S.make_nav_batch(rs, B, L=40 + 10 * seed, G=8, n_visited=3, V1=10, n_cand=3, min_len=8)
     cpu = dict(batch, grid_fts=[torch.from_numpy(r[0]) for r in ref], grid_map=[torch.from_numpy(r[1]) for r in ref],
                gridmap_pos_fts=torch.from_numpy(np.stack([r[2] for r in ref])))
     with torch.no_grad():
