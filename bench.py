@@ -382,13 +382,16 @@ def exchange_sweep(reducer, dev, dist, iters=5):
             def once(_):
                 for f, k in zip(flats, scratch):
                     reducer._exchange(f, k)
-            once(0)
-            res["%s_%s" % (algo, payload)] = 1e3 * _timed_loop(once, iters, dist)
+            try:                             # (a collective this RCCL build rejects fails on every rank alike)
+                once(0)
+                res["%s_%s" % (algo, payload)] = 1e3 * _timed_loop(once, iters, dist)
+            except Exception as e:
+                res["%s_%s" % (algo, payload)] = "failed: " + repr(e)[:160]
     reducer.algo, reducer.payload = keep
     return res
 
 
-def train_leg(args, dev, steps=None):
+def train_leg(args, dev, steps=None, emit=None):
     """One pre-training step (config 3's per-GPU shape) -- forward + backward + [gradient exchange] + gradient clip + fused
     AdamW of the full-size GlocalTextPathCMTPreTraining, B = 32 per rank, native grid memory of 3-5 observations, tasks
     cycling mlm / mrc / sap as the task-mixed loop does (pretrain_src/train_r2r.py:231-303).  Timed launched eagerly from
@@ -407,7 +410,9 @@ def train_leg(args, dev, steps=None):
     cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=["mlm", "mrc", "sap"], image_prob_size=1000, obj_prob_size=0)
     torch.manual_seed(0)
     model = GlocalTextPathCMTPreTraining(cfg).to(dev)
-    rkw = dict(algo=os.environ.get("GRIDMM_EXCHANGE_ALGO", "auto"), payload=os.environ.get("GRIDMM_EXCHANGE_PAYLOAD", "fp32"))
+    # the timed step uses the plain ring all_reduce unless told otherwise (the one collective every RCCL build runs); the
+    # sweep after it times reduce-scatter + all-gather and the direct all-to-all form on the same buckets
+    rkw = dict(algo=os.environ.get("GRIDMM_EXCHANGE_ALGO", "ring"), payload=os.environ.get("GRIDMM_EXCHANGE_PAYLOAD", "fp32"))
     tr = PreTrainer(model, default_opts(warmup_steps=100), reducer_kw=rkw)
     tasks = ("mlm", "mrc", "sap")
     batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i + 10 * rank), args.batch, t, max_steps=5, L=80, vocab=30000,
@@ -417,23 +422,13 @@ def train_leg(args, dev, steps=None):
         for t in tasks:
             tr.train_step(batches[t], t)
     dt_eager = _timed_loop(lambda i: tr.train_step(batches[tasks[i % 3]], tasks[i % 3]), steps, dist)
-    out_dist = None
+    dt_noex = None
     if world > 1:
         tr.exchange = False                  # the same step without the exchange (ranks drift apart: timing only)
         dt_noex = _timed_loop(lambda i: tr.train_step(batches[tasks[i % 3]], tasks[i % 3]), steps, dist)
         tr.exchange = True
         from gridmm_amd.dist import broadcast_parameters
         broadcast_parameters(model.parameters())
-        sweep = exchange_sweep(tr.reducer, dev, dist, iters=max(1, min(5, steps)))
-        alone = sweep["%s_%s" % (tr.reducer.algo, tr.reducer.payload)]
-        exposed = max(0.0, 1e3 * (dt_eager - dt_noex))
-        out_dist = {"world": world, "algo": tr.reducer.algo, "payload": tr.reducer.payload,
-                    "buckets": len(tr.reducer.buckets), "gradient_mb": sum(b["numel"] for b in tr.reducer.buckets) * 4 / 1e6,
-                    "allreduce_ms": alone, "exposed_ms_eager": exposed,
-                    "overlapped_fraction_eager": max(0.0, min(1.0, 1.0 - exposed / alone)) if alone > 0 else None,
-                    "ms_per_step_without_exchange": 1e3 * dt_noex, "exchange_alone_ms": sweep,
-                    "reducer_stats": dict(tr.reducer.stats),
-                    "backend": "gloo (ranks share one GPU: test hook)" if os.environ.get("GRIDMM_BENCH_SHARE_GPU") else "nccl (RCCL)"}
     graphs = {t: GraphedTrainStep(tr, batches[t], t) for t in tasks}
     for t in tasks:
         graphs[t]()
@@ -444,11 +439,6 @@ def train_leg(args, dev, steps=None):
         last["losses"], _ = graphs[tasks[i % 3]]()
     dt = _timed_loop(gstep, n, dist)
     finite = bool(torch.isfinite(last["losses"]).all())
-    del graphs, tr, model, batches
-    torch.cuda.empty_cache()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if not finite:
         raise SystemExit("bench.py: the captured training step produced non-finite losses")
     best = min(dt, dt_eager)
@@ -461,8 +451,29 @@ def train_leg(args, dev, steps=None):
            "eager": {"train_samples_per_s": world * args.batch / dt_eager, "ms_per_step": 1e3 * dt_eager},
            "workload": "pre-training step (mlm/mrc/sap cycling), full-size model, native 12x49x768 grid memory t=3..5, "
                        "fwd + bwd + clip + fused AdamW"}
-    if out_dist is not None:
-        res["exchange"] = out_dist
+    if world > 1:
+        exposed = max(0.0, 1e3 * (dt_eager - dt_noex))
+        res["exchange"] = {"world": world, "algo": tr.reducer.algo, "payload": tr.reducer.payload,
+                           "buckets": len(tr.reducer.buckets),
+                           "gradient_mb": sum(b["numel"] for b in tr.reducer.buckets) * 4 / 1e6,
+                           "exposed_ms_eager": exposed, "ms_per_step_without_exchange": 1e3 * dt_noex,
+                           "reducer_stats": dict(tr.reducer.stats),
+                           "backend": "gloo (ranks share one GPU: test hook)" if os.environ.get("GRIDMM_BENCH_SHARE_GPU") else "nccl (RCCL)"}
+        if emit is not None and rank == 0:
+            emit(res)                        # the step timings are out before the per-algorithm sweep starts
+        del graphs
+        sweep = exchange_sweep(tr.reducer, dev, dist, iters=max(1, min(5, steps)))
+        alone = sweep.get("%s_%s" % (tr.reducer.algo, tr.reducer.payload))
+        timed = {k: v for k, v in sweep.items() if isinstance(v, float)}
+        res["exchange"].update(exchange_alone_ms=sweep, allreduce_ms=alone, fastest=min(timed, key=timed.get) if timed else None,
+                               overlapped_fraction_eager=(max(0.0, min(1.0, 1.0 - exposed / alone))
+                                                          if isinstance(alone, float) and alone > 0 else None))
+    graphs = None
+    del tr, model, batches
+    torch.cuda.empty_cache()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return res if rank == 0 else None
 
 
@@ -477,11 +488,19 @@ def train_leg_subprocess(args, world=1):
         env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
         for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
             env.pop(k)        # (TORCHELASTIC_USE_AGENT_STORE would make the children look for the launcher's store on the new port)
+    limit = float(os.environ.get("GRIDMM_BENCH_TRAIN_TIMEOUT", "420"))
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--train-leg-only", "--batch", str(args.batch)],
-                           env=env, capture_output=True, text=True, timeout=1200)
-    except subprocess.TimeoutExpired:
-        return {"error": "the training leg timed out"}
+                           env=env, capture_output=True, text=True, timeout=limit)
+    except subprocess.TimeoutExpired as e:
+        # the child prints its step timings before the per-algorithm exchange sweep: keep what it got to
+        part = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        lines = [l for l in part.strip().splitlines() if l.startswith("{")]
+        if int(os.environ.get("RANK", "0")) != 0:
+            return None
+        if lines:
+            return dict(json.loads(lines[-1]), note="the training leg was cut after %.0f s (exchange sweep unfinished)" % limit)
+        return {"error": "the training leg timed out after %.0f s" % limit}
     if int(os.environ.get("RANK", "0")) != 0:
         return None
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
@@ -643,9 +662,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.train_leg_only:
-        res = train_leg(args, dev)
+        res = train_leg(args, dev, emit=lambda r: print(json.dumps(r), flush=True))
         if res is not None:
-            print(json.dumps(res))
+            print(json.dumps(res), flush=True)
         return
     dist = None
     if world > 1:
