@@ -17,7 +17,7 @@ def _run(case, env_extra):
                           capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("case", ["mlm", "mrc", "sap", "dropout", "two_graphs", "fp16_grid_proj", "full_size"])
+@pytest.mark.parametrize("case", ["mlm", "mrc", "sap", "dropout", "two_graphs", "fp16_grid_proj", "full_size", "trajectory"])
 def test_graphed_training_step(case):
     r = _run(case, {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"})
     assert r.returncode == 0 and ("ok " + case) in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -39,11 +39,10 @@ def _setup(drop, fp32_grid_proj=True):
 
 
 def _sync(ta, tb):
-    """tb <- ta: parameters and AdamW moments (the step counters advance identically by construction).  The losses are a
-    deterministic function of the state, but the backward's atomics make the gradients run-dependent at 1e-7, and the
-    model has discontinuities (the arg-max token routing of the aggregation backward, the fp16 grid_proj at its rounding
-    threshold): two runs left alone split into distinct trajectories after a few steps -- eager vs eager as much as graph
-    vs eager (tools/dbg_determinism.py).  So every step is compared from a common state."""
+    """tb <- ta: parameters and AdamW moments (the step counters advance identically by construction).  Rounds 1-2 needed
+    this: the backward's float atomics made gradients run-dependent at 1e-7 and the model's discontinuities (arg-max token
+    routing, the fp16 grid_proj at its rounding threshold) split two runs after a few steps.  Round 3 removed the atomics
+    (case_trajectory compares un-synchronised trajectories bit for bit); these per-step comparisons stay as they were."""
     with torch.no_grad():
         for pa, pb in zip(ta.model.parameters(), tb.model.parameters()):
             pb.copy_(pa)
@@ -144,6 +143,29 @@ def case_full_size():
         _compare_step(ta, tb, lambda: ta.train_step(batch, "sap"), g, ("full", it))
 
 
+def case_trajectory():
+    """Graph replays against eager steps LEFT ALONE (no re-synchronisation of the two trainers): with no float atomics on
+    the training path the two trajectories are bit-identical -- losses, gradient norms and parameters after 9 steps of the
+    three tasks cycling, the reference's fp16 grid_proj included (round 2 had to compare every step from a common state)."""
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.train_graph import GraphedTrainStep
+    model, batches = _setup(0.0, fp32_grid_proj=False)
+    ma, mb = copy.deepcopy(model), copy.deepcopy(model)
+    ta, tb = PreTrainer(ma, default_opts(warmup_steps=10)), PreTrainer(mb, default_opts(warmup_steps=10))
+    graphs = {}
+    for t in TASKS:
+        for _ in range(2):
+            ta.train_step(batches[t], t)
+        graphs[t] = GraphedTrainStep(tb, batches[t], t)
+    for i in range(9):
+        t = TASKS[i % 3]
+        la, na = ta.train_step(batches[t], t)
+        lb, nb = graphs[t]()
+        assert torch.equal(la, lb) and torch.equal(na, nb), (i, t, float((la - lb).abs().max()), float(na), float(nb))
+    for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.equal(pa, pb), n
+
+
 def case_dropout():
     from gridmm_amd.pretrain_loop import PreTrainer, default_opts
     from gridmm_amd.train_graph import GraphedTrainStep
@@ -173,6 +195,8 @@ if __name__ == "__main__":
         case_full_size()
     elif case == "two_graphs":
         case_two_graphs()
+    elif case == "trajectory":
+        case_trajectory()
     else:
         case_equals_eager(case)
     print("ok", case)
