@@ -469,7 +469,7 @@ class GlocalTextPathNavCMT(nn.Module):
     # (one small D2H, as the reference's python max() does) and run the encoders on the smallest bucket that holds it;
     # graph.GraphedNavStep keeps one captured back half per bucket and predicts the bucket from the previous step.
     varlen_buckets = None
-    DEFAULT_BUCKETS = (64, 96, 128, 160, N_CELLS)
+    DEFAULT_BUCKETS = (64, 80, 96, 112, 128, 144, 160, 176, N_CELLS)   # 16-row steps: a step costs what its occupied cells cost
 
     @torch.no_grad()
     def _nav_front(self, txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None, txt_planes=None):
