@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .graph_utils import TopoMap
+from .graph_utils import TopoMap, TopoMapBatch
 
 
 def default_args(**over):
@@ -265,7 +265,11 @@ class GMapNavAgent:
         t0 = self._tick("env (grid memory step + observation dicts)", t0)
         self._update_scanvp_cands(obs)
         B = len(obs)
-        gmaps = [TopoMap(ob["viewpoint"]) for ob in obs]
+        if self.fast_collate:      # the B maps as rows of one set of arrays: the collator reads them in whole-array passes
+            tbatch = TopoMapBatch([ob["viewpoint"] for ob in obs])
+            gmaps = tbatch.maps
+        else:
+            tbatch, gmaps = None, [TopoMap(ob["viewpoint"]) for ob in obs]
         self.collator.reset(B)
         for i, ob in enumerate(obs):
             gmaps[i].observe(ob)
@@ -283,7 +287,10 @@ class GMapNavAgent:
             self.nav_steps = getattr(self, "nav_steps", 0) + 1
             for i, gmap in enumerate(gmaps):
                 if not ended[i]:
-                    gmap.step_id[obs[i]["viewpoint"]] = t + 1
+                    if tbatch is not None:
+                        tbatch.mark_step(i, obs[i]["viewpoint"], t + 1)
+                    else:
+                        gmap.step_id[obs[i]["viewpoint"]] = t + 1
 
             fast = self.fast_collate
             pano_inputs = self.collator.panorama(obs) if fast else self._panorama_feature_variable(obs)

@@ -51,29 +51,29 @@ class NavCollator:
     # ---- agent.py:51-94 ---------------------------------------------------------------------------
     def panorama(self, obs):
         fs, B = self.args.image_feat_size, len(obs)
-        rows, cands_all, n_cand = [], [], []
-        for ob in obs:
-            cands = ob["candidate"]
-            used = {int(cc["pointId"]) for cc in cands}
-            rest = [k for k in range(36) if k not in used]
-            feat = ob["feature"]
-            parts = [cc["feature"][None] for cc in cands]
-            parts.append(np.asarray(feat)[rest] if isinstance(feat, np.ndarray) else np.stack([feat[k] for k in rest]))
-            rows.append(np.concatenate(parts, 0))
-            cands_all.append([cc["viewpointId"] for cc in cands])
-            n_cand.append(len(cands))
-        lens = np.array([r.shape[0] for r in rows], dtype=np.int64)
+        cands_all = [[cc["viewpointId"] for cc in ob["candidate"]] for ob in obs]
+        pids = [[int(cc["pointId"]) for cc in ob["candidate"]] for ob in obs]
+        n_cand = np.fromiter((len(p) for p in pids), dtype=np.int64, count=B)
+        lens = np.fromiter((len(p) + 36 - len(set(p)) for p in pids), dtype=np.int64, count=B)
         self._view_lens = lens
-        V, W = self._bucket(int(lens.max()), self.view_buckets), rows[0].shape[1]
-        full = np.zeros((B, V, W + 3), dtype=np.float32)
+        W = np.asarray(obs[0]["feature"]).shape[1]
+        A = W - fs                                      # angle columns
+        V = self._bucket(int(lens.max()), self.view_buckets)
+        img = np.zeros((B, V, fs), dtype=np.float32)
+        loc = np.zeros((B, V, A + 3), dtype=np.float32)
         types = np.zeros((B, V), dtype=np.int64)
-        for i, r in enumerate(rows):
-            full[i, :lens[i], :W] = r
-            full[i, :lens[i], W:] = 1.0           # the constant "box" columns of valid rows
-            types[i, :n_cand[i]] = 1
+        for i, ob in enumerate(obs):                    # candidates' views first, then the views that face no candidate
+            feat, nc, n = np.asarray(ob["feature"]), int(n_cand[i]), int(lens[i])
+            rest = np.ones(36, dtype=bool)
+            if nc:
+                rest[pids[i]] = False
+                cf = np.stack([cc["feature"] for cc in ob["candidate"]])
+                img[i, :nc], loc[i, :nc, :A] = cf[:, :fs], cf[:, fs:]
+                types[i, :nc] = 1
+            img[i, nc:n], loc[i, nc:n, :A] = feat[rest, :fs], feat[rest, fs:]
+            loc[i, :n, A:] = 1.0                        # the constant "box" columns of valid rows
         return {
-            "view_img_fts": self._dev(np.ascontiguousarray(full[:, :, :fs])),
-            "loc_fts": self._dev(np.ascontiguousarray(full[:, :, fs:])),
+            "view_img_fts": self._dev(img), "loc_fts": self._dev(loc),
             "nav_types": self._dev(types), "view_lens": self._dev(lens),
             "cand_vpids": cands_all, "obj_img_fts": None, "obj_lens": None,
         }
@@ -93,7 +93,7 @@ class NavCollator:
 
     def _apply(self, src, sets, adds):
         for ops, accumulate in ((sets, False), (adds, True)):
-            if not ops:
+            if len(ops) == 0:
                 continue
             ix = self._dev(np.asarray(ops, dtype=np.int64).T.copy())
             vals = src[ix[0], ix[2]]
@@ -108,6 +108,12 @@ class NavCollator:
         src = torch.cat([avg.unsqueeze(1), pano_embeds], 1)               # row 0: the panorama mean
         if self.pool is None:
             self.pool = src.new_zeros(src.shape[0], self.cnt.shape[1], src.shape[2])
+        tb = getattr(gmaps[0], "_batch", None)
+        if tb is not None and all(getattr(g, "_batch", None) is tb for g in gmaps):
+            cid, cm = self._cand_ids(gmaps, cand_vpids)
+            srt = np.sort(np.where(cm, cid, -1 - np.arange(cid.shape[1])[None]), axis=1)
+            if not (srt[:, 1:] == srt[:, :-1]).any():            # (a node twice among one panorama's candidates: loop form)
+                return self._update_embeddings_batched(tb, obs, gmaps, ended, src, cid, cm)
         sets, adds, touched = [], [], set()
         for i, g in enumerate(gmaps):
             if ended[i]:
@@ -129,8 +135,159 @@ class NavCollator:
                     self.cnt[i, slot] += 1
         self._apply(src, sets, adds)
 
+    def _cand_ids(self, gmaps, cand_vpids):
+        B = len(gmaps)
+        nc = np.fromiter((len(c) for c in cand_vpids), dtype=np.int64, count=B)
+        cid = np.zeros((B, max(int(nc.max()) if B else 0, 1)), dtype=np.int64)
+        for i, (g, cs) in enumerate(zip(gmaps, cand_vpids)):
+            if cs:
+                cid[i, :len(cs)] = [g._id[c] for c in cs]
+        return cid, np.arange(cid.shape[1])[None] < nc[:, None]
+
+    def _update_embeddings_batched(self, tb, obs, gmaps, ended, src, cid, cm):
+        B = len(obs)
+        bi = np.arange(B)
+        if self.cnt.shape[1] <= tb.cap:
+            self._grow(tb.cap)
+        live = ~np.asarray(ended, dtype=bool)
+        cur = np.fromiter((g.index(ob["viewpoint"]) for g, ob in zip(gmaps, obs)), dtype=np.int64, count=B)
+        lb = bi[live]
+        sets = [np.stack([lb, cur[live] + 1, np.zeros(len(lb), dtype=np.int64)], 1)]     # current node := panorama mean
+        self.cnt[lb, cur[live] + 1] = 1
+        take = cm & live[:, None] & ~tb.seen[bi[:, None], cid]                            # unvisited candidates
+        i, j = np.nonzero(take)
+        slot = cid[i, j] + 1
+        first = self.cnt[i, slot] == 0
+        sets.append(np.stack([i[first], slot[first], j[first] + 1], 1))
+        adds = np.stack([i[~first], slot[~first], j[~first] + 1], 1)
+        self.cnt[i[first], slot[first]] = 1
+        np.add.at(self.cnt, (i[~first], slot[~first]), 1)
+        self._apply(src, np.concatenate(sets), adds)
+
     # ---- agent.py:96-205 ----------------------------------------------------------------------------
     def navigation(self, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types, grid_memory=None):
+        batch = getattr(gmaps[0], "_batch", None)
+        if batch is not None and all(getattr(g, "_batch", None) is batch for g in gmaps):
+            return self._navigation_batched(batch, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types)
+        return self._navigation_loop(obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types)
+
+    def _navigation_batched(self, tb, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types):
+        """The same dictionary from the (B, cap, ...) arrays of a graph_utils.TopoMapBatch: node order, geometry, pair
+        distances, step ids, embedding slots and the fusion maps of all episodes in one pass of whole-array operations
+        (the per-episode Python that is left: name lists for the caller, routes with more than one leg)."""
+        a, B, cap = self.args, len(obs), tb.cap
+        bi = np.arange(B)
+        n = tb.n
+        cur = np.fromiter((g.index(ob["viewpoint"]) for g, ob in zip(gmaps, obs)), dtype=np.int64, count=B)
+        start = np.fromiter((g.index(g.start_vp) for g in gmaps), dtype=np.int64, count=B)
+        ar = np.arange(cap)
+        valid = ar[None] < n[:, None]
+        if a.act_visited_nodes:
+            seen = np.zeros((B, cap), dtype=bool)
+            seen[bi, cur] = True
+        else:
+            seen = tb.seen & valid
+        n_vis_all = seen.sum(1)
+        if a.enc_full_graph:               # [visited in id order | unvisited in id order]
+            key = np.where(valid, np.where(seen, ar[None], cap + ar[None]), 4 * cap)
+            m, n_vis = n.copy(), n_vis_all
+        else:                              # unvisited only
+            key = np.where(valid & ~seen, ar[None], 4 * cap)
+            m, n_vis = n - n_vis_all, np.zeros(B, dtype=np.int64)
+        n_unv = n - n_vis_all
+        order = np.argsort(key, axis=1, kind="stable")
+        M = int(m.max())
+        G = self._bucket(1 + M, self.node_buckets)
+        ids = order[:, :M]                                             # (B, M) node ids, garbage past m[b]
+        jm = np.arange(M)[None] < m[:, None]
+        ids = np.where(jm, ids, 0)
+        cid, cm = self._cand_ids(gmaps, cand_vpids)
+        C = int(cm.sum(1).max()) if B else 0
+        tgt = np.concatenate([ids, cid, start[:, None]], 1)            # (B, T)
+        tm = np.concatenate([jm, cm, np.ones((B, 1), dtype=bool)], 1)
+        T = tgt.shape[1]
+        delta = tb.pos[bi[:, None], tgt] - tb.pos[bi, cur][:, None, :]
+        is_cur = tgt == cur[:, None]
+        graph = np.where(is_cur, 0.0, tb.dist[bi[:, None], cur[:, None], tgt])
+        graph = np.where(np.isfinite(graph), graph, float(UNREACHABLE))
+        via = tb.via[bi[:, None], cur[:, None], tgt]
+        hops = np.where(is_cur, 0.0, 1.0)
+        for i, j in zip(*np.nonzero((via >= 0) & tm & ~is_cur)):       # routes with more than one leg: unrolled
+            hops[i, j] = len(gmaps[i]._route_ids(int(cur[i]), int(tgt[i, j])))
+        bh = np.array([float(ob["heading"]) for ob in obs])
+        be = np.array([float(ob["elevation"]) for ob in obs])
+        feats = batched_pos_features(delta.reshape(-1, 3), np.repeat(bh, T), np.repeat(be, T), graph.reshape(-1),
+                                     hops.reshape(-1)).reshape(B, T, -1)
+        F = feats.shape[2]
+        V1 = pano_embeds.shape[1] + 1
+        gpos = np.zeros((B, G, F), dtype=np.float32)
+        gpos[:, 0] = np.array([0, 1, 0, 1] + [0] * (F - 4), dtype=np.float32)      # the stop token
+        gpos[:, 1:M + 1] = feats[:, :M] * jm[:, :, None]
+        vpos = np.zeros((B, V1, 2 * F), dtype=np.float32)
+        vpos[:, :, :F] = feats[:, T - 1][:, None, :]
+        if C:
+            vpos[:, 1:C + 1, F:] = feats[:, M:M + C] * cm[:, :C, None]
+        pair = np.zeros((B, G, G), dtype=np.float32)
+        if M:
+            sub = tb.dist[bi[:, None, None], ids[:, :, None], ids[:, None, :]]
+            sub = np.where(np.isfinite(sub), sub, float(UNREACHABLE))
+            sub[:, np.arange(M), np.arange(M)] = 0.0
+            pair[:, 1:M + 1, 1:M + 1] = sub * (jm[:, :, None] & jm[:, None, :])
+        steps = np.zeros((B, G), dtype=np.int64)
+        steps[:, 1:M + 1] = tb.step[bi[:, None], ids] * jm
+        visited = np.zeros((B, G), dtype=bool)
+        visited[:, 1:M + 1] = np.arange(M)[None] < n_vis[:, None]
+        slot = np.zeros((B, G), dtype=np.int64)
+        slot[:, 1:M + 1] = (ids + 1) * jm
+        if self.cnt.shape[1] <= cap:
+            self._grow(cap)
+        c = self.cnt[bi[:, None], slot[:, 1:M + 1]]
+        if ((c == 0) & jm).any():
+            i, j = [int(v[0]) for v in np.nonzero((c == 0) & jm)]
+            raise KeyError("graph node without an embedding: %s" % gmaps[i].names[int(ids[i, j])])
+        inv = np.ones((B, G), dtype=np.float32)
+        inv[:, 1:M + 1] = np.where(jm, np.float32(1.0) / np.maximum(c, 1).astype(np.float32), np.float32(1.0))
+        # fusion maps (vilmodel.py:884-899): candidate column of every unvisited node, candidates that are visited nodes
+        cand_of_node = np.full((B, G), -2, dtype=np.int32)
+        cand_visited = np.zeros((B, V1), dtype=np.uint8)
+        if C:
+            cvis = seen[bi[:, None], cid] & cm if a.enc_full_graph else np.zeros_like(cm)
+            cand_visited[:, 1:C + 1] = cvis[:, :C]
+            eq = (ids[:, :, None] == cid[:, None, :]) & (cm & ~cvis)[:, None, :]                    # (B, M, C)
+            last = cid.shape[1] - 1 - np.argmax(eq[:, :, ::-1], axis=2)                             # last match wins
+            col = np.where(eq.any(2), last + 1, -1)
+        else:
+            col = np.full((B, M), -1, dtype=np.int64)
+        unv_node = jm & (np.arange(M)[None] >= n_vis[:, None])
+        cand_of_node[:, 1:M + 1] = np.where(unv_node, col, -2)
+        vpids = [[None] + [g.names[k] for k in ids[i, :m[i]]] for i, g in enumerate(gmaps)]
+        lens = m + 1
+        slot_d, inv_d = self._dev(slot), self._dev(inv)
+        rows = torch.arange(B, device=self.device).unsqueeze(1)
+        gmap_img = self.pool[rows, slot_d] * inv_d.unsqueeze(2)
+        out = {
+            "gmap_vpids": vpids, "gmap_img_embeds": gmap_img, "gmap_step_ids": self._dev(steps),
+            "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited),
+            "gmap_pair_dists": self._dev(pair),
+            "gmap_masks": self._dev(np.arange(G)[None] < lens[:, None]), "no_vp_left": [bool(v == 0) for v in n_unv],
+            "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),
+        }
+        return self._vp_part(out, pano_embeds, cand_vpids, view_lens, nav_types, vpos)
+
+    def _vp_part(self, out, pano_embeds, cand_vpids, view_lens, nav_types, vpos):
+        B, V1 = pano_embeds.shape[0], pano_embeds.shape[1] + 1
+        vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
+        nav_masks = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=self.device), nav_types == 1], 1)
+        vl = view_lens + 1
+        out.update({
+            "vp_img_embeds": vp_img, "vp_pos_fts": self._dev(vpos),
+            "vp_masks": torch.arange(V1, device=vl.device).unsqueeze(0) < vl.unsqueeze(1),
+            "vp_nav_masks": nav_masks, "vp_cand_vpids": [[None] + x for x in cand_vpids], "vp_obj_masks": None,
+        })
+        return out
+
+    def _navigation_loop(self, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types):
+        """Per-episode form (maps that own their arrays)."""
         a, B = self.args, len(obs)
         recs, deltas, graphs, hopss, base_h, base_e = [], [], [], [], [], []
         for i, g in enumerate(gmaps):
@@ -212,13 +369,4 @@ class NavCollator:
             "gmap_masks": self._dev(np.arange(G)[None] < lens[:, None]), "no_vp_left": no_vp_left,
             "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),
         }
-        vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
-        nav_masks = torch.cat([torch.ones(B, 1, dtype=torch.bool, device=self.device), nav_types == 1], 1)
-        vl = view_lens + 1
-        v_max = V1                    # == max(view_lens) + 1 on the reference's shapes; the padded width with view buckets
-        out.update({
-            "vp_img_embeds": vp_img, "vp_pos_fts": self._dev(vpos),
-            "vp_masks": torch.arange(v_max, device=vl.device).unsqueeze(0) < vl.unsqueeze(1),
-            "vp_nav_masks": nav_masks, "vp_cand_vpids": [[None] + x for x in cand_vpids], "vp_obj_masks": None,
-        })
-        return out
+        return self._vp_part(out, pano_embeds, cand_vpids, view_lens, nav_types, vpos)

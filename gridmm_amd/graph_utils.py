@@ -59,12 +59,18 @@ def batched_pos_features(delta, base_heading, base_elevation, graph, hops, angle
 
 
 class TopoMap:
-    def __init__(self, start_vp, capacity=32):
+    def __init__(self, start_vp, capacity=32, batch=None, row=0):
+        """batch / row: the arrays are row `row` of a TopoMapBatch's (B, cap, ...) storage (views), so that a caller can
+        run one vectorised pass over all episodes of a lock-step batch; alone, the map owns its arrays."""
         self.start_vp = start_vp
         self._id = {}                  # viewpoint name -> dense integer id (insertion order)
         self.names = []                # id -> name
-        self._alloc(capacity)
-        self.n = 0
+        self._batch, self._row = batch, row
+        if batch is None:
+            self._alloc(capacity)
+        else:
+            batch._attach(self)
+        self._n = 0
         self._emb = []                 # id -> [running sum (tensor), count] or None
         self.step_id = {}              # name -> navigation step at which it was last visited
         self.stop_score = {}           # name -> {'stop': p}
@@ -76,7 +82,20 @@ class TopoMap:
         self.via = np.full((cap, cap), -1, dtype=np.int32)          # -1: direct edge (or nothing known)
         self.seen = np.zeros(cap, dtype=bool)                       # visited = has been a relaxation pivot
 
+    @property
+    def n(self):
+        return self._n
+
+    @n.setter
+    def n(self, v):
+        self._n = v
+        if self._batch is not None:
+            self._batch.n[self._row] = v
+
     def _grow(self):
+        if self._batch is not None:
+            self._batch.grow()         # re-points the arrays of every map of the batch
+            return
         old = (self.pos, self.dist, self.via, self.seen)
         c = old[0].shape[0]
         self._alloc(2 * c)
@@ -228,3 +247,44 @@ class TopoMap:
             ang[slots, 0], ang[slots, 1] = h, e
             rel[slots, 0], rel[slots, 1], rel[slots, 2] = line / MAX_DIST, graph / MAX_DIST, hops / MAX_STEP
         return np.concatenate([angle_features(ang[:, 0], ang[:, 1], angle_feat_size), rel], 1)
+
+
+class TopoMapBatch:
+    """Storage of the B topological maps of a lock-step batch as (B, cap, ...) arrays; `maps[b]` is a TopoMap whose
+    arrays are views of row b.  Per-episode calls (observe, route, pos_features, ...) work as before; a collator reads
+    the batch arrays directly (collate.NavCollator.navigation)."""
+
+    def __init__(self, start_vps, capacity=64):
+        self.B, self.cap = len(start_vps), capacity
+        self._alloc(capacity)
+        self.n = np.zeros(self.B, dtype=np.int64)
+        self.step = np.zeros((self.B, capacity), dtype=np.int64)     # last navigation step at which a node was visited
+        self.maps = []
+        self.maps = [TopoMap(vp, batch=self, row=b) for b, vp in enumerate(start_vps)]
+
+    def _alloc(self, cap):
+        B = self.B
+        self.pos = np.zeros((B, cap, 3), dtype=np.float64)
+        self.dist = np.full((B, cap, cap), np.inf, dtype=np.float64)
+        self.via = np.full((B, cap, cap), -1, dtype=np.int32)
+        self.seen = np.zeros((B, cap), dtype=bool)
+
+    def _attach(self, m):
+        b = m._row
+        m.pos, m.dist, m.via, m.seen = self.pos[b], self.dist[b], self.via[b], self.seen[b]
+
+    def grow(self):
+        old, c = (self.pos, self.dist, self.via, self.seen, self.step), self.cap
+        self.cap = 2 * c
+        self._alloc(self.cap)
+        self.pos[:, :c], self.dist[:, :c, :c], self.via[:, :c, :c], self.seen[:, :c] = old[:4]
+        self.step = np.zeros((self.B, self.cap), dtype=np.int64)
+        self.step[:, :c] = old[4]
+        for m in self.maps:
+            self._attach(m)
+
+    def mark_step(self, b, vp, t):
+        """The agent's `gmap.step_id[vp] = t` (agent.py:277-279) mirrored into the batch array."""
+        m = self.maps[b]
+        m.step_id[vp] = t
+        self.step[b, m.index(vp)] = t
