@@ -293,6 +293,11 @@ class GMapNavAgent:
                         gmap.step_id[obs[i]["viewpoint"]] = t + 1
 
             fast = self.fast_collate
+            mem = getattr(self.env, "grid_memory", None)
+            if self._graphs is not None and not torch.is_grad_enabled() and getattr(mem, "slab", None) is not None:
+                # the half of 'navigation' that needs only the instruction and the grid memory starts now: the device works
+                # through it while the host collates the panorama / graph inputs
+                self._graphs[1].begin(txt_embeds, language_inputs["txt_masks"], mem)
             pano_inputs = self.collator.panorama(obs) if fast else self._panorama_feature_variable(obs)
             t0 = self._tick("host: collate panorama inputs", t0)
             pano_embeds, pano_masks = self._model_call("panorama", pano_inputs)

@@ -221,9 +221,23 @@ class NavigationGraphs:
         return ent
 
     @torch.no_grad()
+    def begin(self, txt_embeds, txt_masks, grid_memory):
+        """Launch the shape-independent half (text projection, aggregation, grid_proj) NOW -- e.g. right after the
+        environment step, so that the device works through it while the host is still collating the rest of the inputs.
+        The next __call__ with the same instruction tensor and grid memory picks the result up."""
+        self._early = (txt_embeds, grid_memory,
+                       self.model.navigation_front({"txt_embeds": txt_embeds, "txt_masks": txt_masks, "grid_memory": grid_memory}))
+
+    _early = None
+
+    @torch.no_grad()
     def __call__(self, batch):
         model, mem = self.model, batch.get("grid_memory")
-        fr = model.navigation_front(batch)
+        early, self._early = self._early, None
+        if early is not None and early[0] is batch["txt_embeds"] and early[1] is mem:
+            fr = early[2]
+        else:
+            fr = model.navigation_front(batch)
         cmax = mem.cmax_hint() if mem is not None and hasattr(mem, "cmax_hint") else None
         if cmax is None:
             cmax = int(fr.occ.sum(1, dtype=torch.int32).max())
