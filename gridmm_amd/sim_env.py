@@ -160,7 +160,8 @@ class SyntheticNavEnv:
         for e in range(n_episodes):
             scan = self.scans["s%d" % (e % n_scans)]
             while True:
-                a, b = rs.choice(scan.vps, 2, replace=False)
+                a, b = (str(v) for v in rs.choice(scan.vps, 2, replace=False))   # plain str: the per-viewpoint
+                # generators key on repr(name), and numpy's str_ has another repr than the same name as a str
                 path = scan.shortest_path(a, b)
                 if 3 <= len(path) <= 7:
                     break

@@ -270,7 +270,7 @@ def gen_fill_gridmap_vlnce():
     print("fill_gridmap_vlnce: ok")
 
 
-ROLLOUT = dict(batch_size=3, n_scans=2, n_episodes=3, seed=11, max_action_len=6)
+ROLLOUT = dict(batch_size=3, n_scans=2, n_episodes=3, seed=12, max_action_len=6)
 
 
 def make_rollout_agent(vln_bert, device="cpu", grid_memory=None):
@@ -293,7 +293,8 @@ def gen_rollout(full=False):
     import collections
     torch.set_num_threads(4 if full else 1)
     cfg = {} if full else REDUCED
-    wseed = 3 if full else 7          # (seeds 7 and 9 leave 1.9e-3 / 9e-4 argmax margins at the full size: below the fixture's 2e-3 bar)
+    wseed = 7          # (full size, episode seed 12: 6 steps with a 2.7e-3 argmax margin; weight seeds 3 / 5 / 9 / 11 / 13 stop at
+    # step 0 or leave margins below the fixture's 2e-3 bar -- /tmp-style search over (episode seed, weight seed) pairs)
     model = R.build_ref_model(seed=wseed, **cfg)
 
     def ref_bert(mode, batch):
@@ -301,6 +302,7 @@ def gen_rollout(full=False):
             return model(mode, collections.defaultdict(lambda: None, batch))
 
     agent = make_rollout_agent(ref_bert)
+    agent.fast_collate = False        # the per-episode restatement of the reference's collation feeds the reference model
     traj = agent.rollout()
     out = {"versions": _versions(), "weight_seed": wseed, "cfg": json.dumps(cfg),
            "param_names": json.dumps([k for k in model.state_dict()]),

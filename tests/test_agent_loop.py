@@ -233,3 +233,38 @@ def test_rollout_with_graph_replay_equals_the_eager_rollout():
         assert not torch.isfinite(y["nav_outs"]["fused_logits"][:, x["nav_outs"]["fused_logits"].shape[1]:]).any()
     g = ga._graphs[1]
     assert g.replays == len(ga.trace) and g.captures < g.replays
+
+
+@pytest.mark.gpu
+def test_device_store_environment_equals_host_assembled_observations():
+    """SyntheticNavEnv with the observations resident in HBM (feature_store.DeviceStore: device-side gather into the
+    grid memory's next slot) against the same environment assembling every observation on the host and uploading it: the
+    same grid memory bit for bit (slab, cell ids, sort, position features) and the same logits at every step."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.sim_env import SyntheticNavEnv
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    dev, B, T = torch.device("cuda"), 5, 6
+    torch.manual_seed(1)
+    cfg = default_config(num_l_layers=1, num_pano_layers=1, num_x_layers=2, intermediate_size=256, vocab_size=3000)
+    model = GlocalTextPathNavCMT(cfg).eval().to(dev)
+    runs = []
+    for dev_store in (False, True):
+        mem = GridMemoryBatch(B, S.NATIVE, max_steps=T + 2, device=dev)
+        env = SyntheticNavEnv(B, mem, n_scans=2, n_episodes=2 * B, seed=9, geom=S.NATIVE, vocab=3000)
+        if dev_store:
+            env.build_device_store(dev)
+        ag = GMapNavAgent(default_args(max_action_len=T), env, model, device=dev)
+        ag.feedback, ag.trace = "argmax", []
+        ag._set_mode(False)
+        with torch.no_grad():
+            traj = ag.rollout()
+        runs.append((ag.trace, traj, mem))
+    (a, ta, ma), (b, tb, mb) = runs
+    assert ta == tb and len(a) == len(b) >= 3
+    for k in ("slab", "cell_id", "perm", "cell_start", "pos_fts", "n_pts"):
+        assert torch.equal(getattr(ma, k), getattr(mb, k)), k
+    for x, y in zip(a, b):
+        for k in ("fused_logits", "global_logits", "local_logits", "grid_logits"):
+            assert torch.equal(x["nav_outs"][k], y["nav_outs"][k]), (x["t"], k)

@@ -4,7 +4,11 @@ backward through every step, clip 40, AdamW.  Secondary measurement; the headlin
 usage: PYTHONPATH=. python tools/bench_finetune.py [--batch 32] [--shape baseline|native] [--iters 4]"""
 import argparse
 import json
+import os
+import sys
 import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 import numpy as np
 import torch
@@ -17,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--max-action-len", type=int, default=7)
+    ap.add_argument("--host-store", action="store_true", help="observations assembled on the host per step (round 1-2 form)")
     a = ap.parse_args()
     from gridmm_amd.agent import GMapNavAgent, default_args
     from gridmm_amd.grid_memory import GridMemoryBatch
@@ -29,6 +34,8 @@ def main():
     model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim)).cuda()
     mem = GridMemoryBatch(a.batch, geom, max_steps=a.max_action_len + 2, device="cuda")
     env = SyntheticNavEnv(a.batch, mem, n_scans=4, n_episodes=4 * a.batch, seed=3, geom=geom, vocab=30000)
+    if not a.host_store:
+        env.build_device_store("cuda")        # observations resident in HBM: an env step moves no feature bytes over PCIe
     agent = GMapNavAgent(default_args(max_action_len=a.max_action_len, train_alg="imitation", lr=1e-5), env, model,
                          device="cuda")
     agent.train(max(a.warmup, 4))             # also fills the environment's feature memo (4 passes over the episode list)
