@@ -75,7 +75,7 @@ class _WeightCache:
 
         def get(transposed, ent=ent, w=w):
             if transposed not in ent:
-                if (w.requires_grad and torch.is_grad_enabled() and w.dim() == 2 and w.dtype == torch.float32
+                if (w.requires_grad and w.dim() == 2 and w.dtype == torch.float32   # (grad mode is off inside Function.forward)
                         and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0 and w.is_contiguous()):
                     # a trained weight is needed in both orientations every step (forward: W, dX: W^T): one pass over
                     # it writes both pairs of planes instead of a split launch + a transposing launch
