@@ -294,7 +294,7 @@ def gen_rollout(full=False):
     torch.set_num_threads(4 if full else 1)
     cfg = {} if full else REDUCED
     wseed = 7          # (full size, episode seed 12: 6 steps with a 2.7e-3 argmax margin; weight seeds 3 / 5 / 9 / 11 / 13 stop at
-    # step 0 or leave margins below the fixture's 2e-3 bar -- /tmp-style search over (episode seed, weight seed) pairs)
+    # step 0 or leave margins below the fixture's 2e-3 bar: oracle/search_rollout_seeds.py)
     model = R.build_ref_model(seed=wseed, **cfg)
 
     def ref_bert(mode, batch):
