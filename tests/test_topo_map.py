@@ -58,3 +58,34 @@ def test_topo_map_degenerate_queries():
     f = tm.pos_features("a", [None, "a"], 0.3, 0.1)
     assert np.allclose(f[0], [0, 1, 0, 1, 0, 0, 0])                       # stop token: zero angles / distances
     assert np.allclose(f[1, 4:], 0) and np.isclose(f[1, 0], np.sin(-0.3), atol=1e-6)
+
+
+def test_topo_map_batch_rows_equal_standalone_maps():
+    """graph_utils.TopoMapBatch: B maps as rows of one set of arrays (what the batched collation reads).  Every row must
+    behave exactly like a stand-alone TopoMap -- including growth of the shared storage past its initial capacity."""
+    from gridmm_amd.graph_utils import TopoMapBatch
+    g = np.load(GOLD)
+    T = len(g["in_walk"])
+    starts = ["vp%02d" % g["in_walk"][0]] * 3
+    tb = TopoMapBatch(starts, capacity=4)                    # grows several times over the 20-step walk
+    alone = [TopoMap(s, capacity=4) for s in starts]
+    for t in range(T):
+        for b in range(3):
+            ob = _obs(g, (t + 3 * b) % T if b else t)        # the rows walk differently
+            if ob["viewpoint"] not in alone[b] and t:        # (keep walks connected: only move to known nodes)
+                ob = _obs(g, t)
+            tb.maps[b].observe(ob)
+            alone[b].observe(ob)
+            tb.mark_step(b, ob["viewpoint"], t + 1)
+            alone[b].step_id[ob["viewpoint"]] = t + 1
+        for b in range(3):
+            m, a = tb.maps[b], alone[b]
+            n = a.n
+            assert m.n == n == tb.n[b] and m.nodes() == a.nodes()
+            assert np.array_equal(m.dist[:n, :n], a.dist[:n, :n]) and np.array_equal(m.via[:n, :n], a.via[:n, :n])
+            assert np.array_equal(m.seen[:n], a.seen[:n]) and np.array_equal(m.pos[:n], a.pos[:n])
+            assert np.array_equal(tb.dist[b, :n, :n], a.dist[:n, :n])           # the batch arrays ARE the rows' storage
+            assert [int(tb.step[b, m.index(v)]) for v in a.nodes()] == [a.step_id.get(v, 0) for v in a.nodes()]
+            cur = a.nodes()[-1]
+            np.testing.assert_array_equal(m.pos_features(cur, a.nodes(), 0.3, 0.1), a.pos_features(cur, a.nodes(), 0.3, 0.1))
+    assert tb.cap > 4
