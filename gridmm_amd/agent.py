@@ -271,6 +271,9 @@ class GMapNavAgent:
         else:
             tbatch, gmaps = None, [TopoMap(ob["viewpoint"]) for ob in obs]
         self.collator.reset(B)
+        if self._graphs is not None:
+            for g in self._graphs:
+                g.validate()               # weights updated since the graphs were captured (training between evaluations)?
         for i, ob in enumerate(obs):
             gmaps[i].observe(ob)
         traj = [{"instr_id": ob["instr_id"], "path": [[ob["viewpoint"]]], "details": {}} for ob in obs]

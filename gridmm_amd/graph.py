@@ -164,6 +164,18 @@ class NavigationGraphs:
     from a read-back of this call's occupancy bytes.  Outputs are the graph's static tensors: consume (or clone) them
     before the next call with the same key.  Same results as the eager call (tests/test_hip_graph_step.py)."""
 
+    @staticmethod
+    def weights_token(model):
+        """Changes whenever a parameter is updated in place or replaced (optimizer step, load_state_dict): captured graphs
+        hold the packed weight planes of the capture, so they must be dropped then (`validate`)."""
+        return hash(tuple((p.data_ptr(), p._version) for p in model.parameters()))
+
+    def validate(self):
+        tok = self.weights_token(self.model)
+        if tok != getattr(self, "_tok", None):
+            self.graphs.clear()
+            self._tok, self._early = tok, None
+
     TENSOR_KEYS = ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_masks", "gmap_visited_masks",
                    "vp_img_embeds", "vp_pos_fts", "vp_masks", "vp_nav_masks", "vp_obj_masks")
 
@@ -225,8 +237,13 @@ class NavigationGraphs:
         """Launch the shape-independent half (text projection, aggregation, grid_proj) NOW -- e.g. right after the
         environment step, so that the device works through it while the host is still collating the rest of the inputs.
         The next __call__ with the same instruction tensor and grid memory picks the result up."""
-        self._early = (txt_embeds, grid_memory,
+        self._early = (txt_embeds, grid_memory, self._mem_state(grid_memory),
                        self.model.navigation_front({"txt_embeds": txt_embeds, "txt_masks": txt_masks, "grid_memory": grid_memory}))
+
+    @staticmethod
+    def _mem_state(mem):
+        """(slab identity, reset epoch, points appended so far): an early front belongs to one state of the memory."""
+        return (id(mem.slab), mem.slab._gridmm_epoch[0], int(mem.n_pts_host.sum()))
 
     _early = None
 
@@ -234,8 +251,8 @@ class NavigationGraphs:
     def __call__(self, batch):
         model, mem = self.model, batch.get("grid_memory")
         early, self._early = self._early, None
-        if early is not None and early[0] is batch["txt_embeds"] and early[1] is mem:
-            fr = early[2]
+        if early is not None and early[0] is batch["txt_embeds"] and early[1] is mem and early[2] == self._mem_state(mem):
+            fr = early[3]
         else:
             fr = model.navigation_front(batch)
         cmax = mem.cmax_hint() if mem is not None and hasattr(mem, "cmax_hint") else None
@@ -267,6 +284,12 @@ class PanoramaGraphs:
 
     def __init__(self, model):
         self.model, self.graphs, self.pool = model, {}, None
+
+    def validate(self):
+        tok = NavigationGraphs.weights_token(self.model)
+        if tok != getattr(self, "_tok", None):
+            self.graphs.clear()
+            self._tok = tok
 
     @torch.no_grad()
     def __call__(self, batch):

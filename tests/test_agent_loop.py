@@ -233,6 +233,25 @@ def test_rollout_with_graph_replay_equals_the_eager_rollout():
         assert not torch.isfinite(y["nav_outs"]["fused_logits"][:, x["nav_outs"]["fused_logits"].shape[1]:]).any()
     g = ga._graphs[1]
     assert g.replays == len(ga.trace) and g.captures < g.replays
+    # an in-place weight update (an optimizer step between two evaluations): the captured graphs hold the packed weight
+    # planes of their capture, so the next rollout must drop and re-capture them
+    with torch.no_grad():
+        model.text_proj.weight.mul_(1.25)
+        model.global_sap_head.net[0].weight.mul_(0.9)
+    caps, env, graphs = g.captures, ga.env, ga._graphs
+    ix0 = env.ix
+    ga.trace = []
+    with torch.no_grad():
+        t1 = ga.rollout()
+    tr1, ga.trace, ga._graphs, env.ix = ga.trace, [], None, ix0          # the same mini-batch again, eager launches
+    with torch.no_grad():
+        t2 = ga.rollout()
+    assert t1 == t2 and g.captures > caps and len(tr1) == len(ga.trace)
+    for x, y in zip(tr1, ga.trace):
+        for k in ("fused_logits", "grid_logits"):
+            f = torch.isfinite(y["nav_outs"][k])
+            assert torch.equal(f, torch.isfinite(x["nav_outs"][k]))
+            assert (x["nav_outs"][k][f] - y["nav_outs"][k][f]).abs().max() < 2e-5, k
 
 
 @pytest.mark.gpu
