@@ -127,12 +127,23 @@ class DeviceStore:
         self.keys = list(keys)
         self.index = {k: i for i, k in enumerate(self.keys)}
         self.device = torch.device(device)
-        self.tokens = torch.as_tensor(np.ascontiguousarray(tokens)).to(self.device)
-        d = np.ascontiguousarray(depth)
-        self._u16 = d.dtype == np.uint16
+        self._u16 = np.dtype(depth.dtype) == np.uint16
         # (uint16 rows are gathered through an int16 view of the same bytes: index_select has no uint16 kernel)
-        self.depth = torch.as_tensor(d.view(np.int16) if self._u16 else d).to(self.device)
+        self.tokens = self._upload(tokens, torch.float16, np.float16)
+        self.depth = self._upload(depth, torch.int16 if self._u16 else torch.float32, np.int16 if self._u16 else np.float32)
         self.poses = [tuple(float(v) for v in p) for p in poses]
+
+    def _upload(self, src, tdtype, ndtype, chunk=512):
+        """Host array (possibly a read-only mmap of the packed store) -> device tensor, `chunk` records at a time through
+        a writable staging copy: bounded host memory whatever the store's size."""
+        import torch
+        n = len(src)
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=tdtype, device=self.device)
+        for i in range(0, n, chunk):
+            blk = np.array(src[i:i + chunk])                  # writable copy of this block
+            blk = blk.view(ndtype) if blk.dtype.itemsize == np.dtype(ndtype).itemsize and blk.dtype != ndtype else blk.astype(ndtype, copy=False)
+            out[i:i + chunk].copy_(torch.from_numpy(blk))
+        return out
 
     @classmethod
     def from_packed(cls, store, device):
