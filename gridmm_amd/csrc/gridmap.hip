@@ -235,10 +235,10 @@ __global__ __launch_bounds__(1024) void grid_bin_sort_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // The same sort for deep memories (tens of thousands of points per episode), cut into S slices per episode so that
-// S x B workgroups work on it instead of B: histogram | scan | scatter.  Wave w of slice s owns the contiguous
+// S x B workgroups work on it instead of B: histogram | scatter (the scan over slices and bins is the scatter's prologue).  Wave w of slice s owns the contiguous
 // sub-slice (16 s + w) of the history, so the order inside a cell is still ascending point index.
 // ws [B][S][16 + 1][NBIN] int32: rows 0..15 = exclusive prefix of the slice's 16 per-wave histograms, row 16 = the
-// slice's total per bin, turned into the slice's absolute base per bin by the scan (S rows per bin: short).
+// slice's total per bin (S rows per bin: short).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void slice_range(int n, int S, int gw, int& lo, int& hi) {
   const int per_wave = ((n + S * SORT_WAVES * 64 - 1) / (S * SORT_WAVES * 64)) * 64;   // multiple of 64
@@ -297,51 +297,51 @@ __global__ __launch_bounds__(1024) void grid_bin_hist_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void grid_bin_scan_kernel(int32_t* __restrict__ ws, int32_t* __restrict__ cell_start,
-                                                            int S) {
-  __shared__ int s_start[NBIN + 1];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  int32_t* tot = ws + (size_t)b * S * (SORT_WAVES + 1) * NBIN + SORT_WAVES * NBIN;   // row 16 of slice 0
-  const size_t stride = (size_t)(SORT_WAVES + 1) * NBIN;
-  int mine[64];
-  int run = 0;
-  if (tid < NBIN) {                      // exclusive scan over the slices of a bin
-    for (int r = 0; r < S; ++r) {
-      const int v = tot[r * stride + tid];
-      mine[r] = run;
-      run += v;
-    }
-    s_start[tid] = run;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int k = 0; k < NBIN; ++k) {
-      const int v = s_start[k];
-      s_start[k] = acc;
-      acc += v;
-    }
-    s_start[NBIN] = acc;  // == n
-  }
-  __syncthreads();
-  if (tid < NBIN) {
-    const int base = s_start[tid];
-    for (int r = 0; r < S; ++r) tot[r * stride + tid] = base + mine[r];   // absolute base of slice r in this bin
-  }
-  if (tid <= NBIN) cell_start[(size_t)b * (NBIN + 1) + tid] = s_start[tid];
-}
-
+// The scan over (slice, bin) totals is redone by every scatter workgroup in its prologue (S x 197 ints from L2 and a
+// 197-wide prefix: ~1 us) instead of a launch of its own between the histogram and the scatter (8.6 us of launch, ramp
+// and one-workgroup-per-episode work); slice 0 of an episode writes cell_start.
 __global__ __launch_bounds__(1024) void grid_bin_scatter_kernel(const int16_t* __restrict__ cell_id,
                                                                 const int32_t* __restrict__ n_pts,
                                                                 const int32_t* __restrict__ ws,
-                                                                int32_t* __restrict__ perm, int cap) {
+                                                                int32_t* __restrict__ perm,
+                                                                int32_t* __restrict__ cell_start, int cap) {
   __shared__ int s_cur[SORT_WAVES][NBIN];
+  __shared__ int s_tot[256], s_base[NBIN];
   const int sl = blockIdx.x, S = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int lo, hi;
   slice_range(n_pts[b], S, sl * SORT_WAVES + wave, lo, hi);
-  const int32_t* in_ws = ws + ((size_t)b * S + sl) * (SORT_WAVES + 1) * NBIN;
+  const size_t stride = (size_t)(SORT_WAVES + 1) * NBIN;
+  const int32_t* tot = ws + (size_t)b * S * stride + SORT_WAVES * NBIN;     // row 16 of slice 0: per-bin totals of a slice
+  int before = 0, all = 0;               // points of this bin in the slices before mine / in all slices
+  if (tid < 256) {
+    if (tid < NBIN)
+      for (int r = 0; r < S; ++r) {
+        const int v = tot[r * stride + tid];
+        if (r < sl) before += v;
+        all += v;
+      }
+    s_tot[tid] = all;
+  }
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {    // inclusive prefix over the bins (Hillis-Steele, 8 steps)
+    int v = 0;
+    if (tid < 256 && tid >= d) v = s_tot[tid - d];
+    __syncthreads();
+    if (tid < 256) s_tot[tid] += v;
+    __syncthreads();
+  }
+  if (tid < NBIN) {
+    const int start = s_tot[tid] - all;  // exclusive: first sorted position of the bin
+    s_base[tid] = start + before;        // absolute base of this slice in the bin
+    if (sl == 0) {
+      cell_start[(size_t)b * (NBIN + 1) + tid] = start;
+      if (tid == NBIN - 1) cell_start[(size_t)b * (NBIN + 1) + NBIN] = s_tot[tid];   // == n
+    }
+  }
+  __syncthreads();
+  const int32_t* in_ws = ws + ((size_t)b * S + sl) * stride;
   for (int i = tid; i < SORT_WAVES * NBIN; i += 1024)          // write cursor = slice base of the bin + wave prefix
-    (&s_cur[0][0])[i] = in_ws[i] + in_ws[SORT_WAVES * NBIN + i % NBIN];
+    (&s_cur[0][0])[i] = in_ws[i] + s_base[i % NBIN];
   __syncthreads();
   const int16_t* ids = cell_id + (size_t)b * cap;
   int32_t* pm = perm + (size_t)b * cap;
@@ -425,8 +425,8 @@ extern "C" int gridmm_grid_bin_sliced(const float* hist_x, const float* hist_y, 
   hipStream_t st = as_stream(stream);
   GRIDMM_LAUNCH((grid_bin_hist_kernel<true>), dim3(slices, B), dim3(1024), 0, st, hist_x, hist_y, hist_valid, n_pts,
                 pose, head_cs, half_len, cell_id, workspace, cap, flags);
-  GRIDMM_LAUNCH(grid_bin_scan_kernel, dim3(B), dim3(256), 0, st, workspace, cell_start, slices);
-  GRIDMM_LAUNCH(grid_bin_scatter_kernel, dim3(slices, B), dim3(1024), 0, st, cell_id, n_pts, workspace, perm, cap);
+  GRIDMM_LAUNCH(grid_bin_scatter_kernel, dim3(slices, B), dim3(1024), 0, st, cell_id, n_pts, workspace, perm, cell_start,
+                cap);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
