@@ -232,3 +232,27 @@ def test_training_trajectory_is_bit_reproducible():
     for i, ((l1, n1), (l2, n2)) in enumerate(zip(la, lb)):
         assert torch.equal(l1, l2) and torch.equal(n1, n2), (i, float((l1 - l2).abs().max()), float(n1), float(n2))
     assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+
+
+@pytest.mark.gpu
+def test_pretrain_step_with_300_token_instructions():
+    """rxr_pretrain.json: max_txt_len 300 -- past the pipelined aggregation paths (L <= 256): the generic aggregation
+    kernel and the search-based aggregation backward run; the step is finite and moves text_proj (whose only gradient
+    path is the relevance routing)."""
+    from train_graph_cases import _setup
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.synthetic import batch_to, make_pretrain_batch
+    model, _ = _setup(0.0)
+    tr = PreTrainer(model, default_opts(warmup_steps=2))
+    w0 = model.bert.text_proj.weight.detach().clone()
+    for i, t in enumerate(("mlm", "sap")):
+        for seed in range(40, 80):                 # (instruction lengths are drawn from 8 .. L - 1: take a long draw)
+            batch = make_pretrain_batch(np.random.RandomState(seed + 100 * i), 3, t, max_steps=3, L=300, vocab=30000,
+                                        image_prob_size=1000, n_pts=(588, 588 * 2))
+            if batch["txt_ids"].shape[1] > 270:
+                break
+        batch = batch_to(batch, "cuda")
+        assert 256 < batch["txt_ids"].shape[1] <= 300
+        loss, norm = tr.train_step(batch, t)
+        assert torch.isfinite(loss).all() and torch.isfinite(norm) and float(norm) > 0
+    assert not torch.equal(w0, model.bert.text_proj.weight)
