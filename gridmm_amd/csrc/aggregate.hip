@@ -491,8 +491,8 @@ extern "C" int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm
   int32_t* chunks = static_cast<int32_t*>(workspace);
   float* ws = reinterpret_cast<float*>(static_cast<char*>(workspace) + chunk_table_bytes(B, n_chunks));
   const int Lt = (L + 15) / 16;
-  if (Lt > 32) return GRIDMM_EINVAL;  // L <= 512, BERT's position table (reference: max_instr_len 200 / 250, max_txt_len 300); the
-                                      // pipelined paths take L <= 256, longer instructions run the generic kernel
+  if (Lt > 32) return GRIDMM_EINVAL;  // L <= 512, BERT's position table (reference: max_instr_len 200 / 250, max_txt_len 300);
+                                      // past 256 tokens the relevance GEMM runs as two launches over token groups
   hipStream_t st = as_stream(stream);
   if (gridmm_grid_aggregate_pipe(slab, perm, cell_start, text_frag, cells, occ, relevance, relevance ? amax : nullptr, ws,
                                  B, cap, D, L, n_chunks, st) == GRIDMM_OK)

@@ -322,8 +322,11 @@ __global__ __launch_bounds__(512) void grid_aggregate_pipe_kernel(
 #ifdef GRIDMM_AGG_PROF
     pt2 = PROF_T(); if (i > 0) p_work += pt2 - pta; else p_m[1] = pt2 - pt0;
 #endif
-    // (PREW: nobody computes on tile i in iteration i, so the loaders only need tile i - 1 here and keep tile i flying)
-    constexpr int KEEP = PREW ? R - 2 : R - 3;
+    // What may stay in flight at the top of iteration i is what was issued AFTER the ids of tile i + R - 2 (dma_prepare
+    // reads them right below): the rows of ONE tile and the next id fetch.  (PREW: nobody computes on tile i in iteration
+    // i, so with three slots the loaders keep tile i flying; with four slots the round-3 first version kept two tiles,
+    // i.e. counted the wait past those ids -- a race that showed at D = 256, whose short iterations outran the id fetch.)
+    constexpr int KEEP = PREW ? 1 : R - 3;
     if (i >= 1 && i + R - 1 < ntiles) wait_vm_dyn(KEEP * my_rows * IPR + ids_instrs);   // steady state
     else if (PREW ? i < ntiles : i + 1 < ntiles) wait_vm_dyn(KEEP * my_rows * IPR);      // first / last iterations: tiles only
     else wait_vm<0>();
@@ -602,7 +605,8 @@ int gridmm_grid_aggregate_prew(const void* slab, const int32_t* perm, const int3
     GRIDMM_PREW(16, 4, 7);
     GRIDMM_LAUNCH(grid_aggregate_merge_kernel<512>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
   } else {
-    GRIDMM_PREW(8, 4, 4);
+    GRIDMM_PREW(8, 4, 8);     // (NBW = 4 would do for 16 blocks over 5 waves, but the accumulator's single-group form -- one
+                              // transpose-read group, NBW <= GB -- gave run-dependent results here: the two-group form is the tested one)
     GRIDMM_LAUNCH(grid_aggregate_merge_kernel<256>, dim3(n_chunks, B), dim3(128), 0, st, cell_start, ws, cells, occ, n_chunks);
   }
 #undef GRIDMM_PREW

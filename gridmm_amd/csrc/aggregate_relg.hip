@@ -58,7 +58,10 @@ template <int KS, int LTMAX, int GNS, int BKS>   // BKS: 32-wide k-steps per rin
 __global__ __launch_bounds__(GMW * 64) void grid_relevance_gemm_kernel(
     const _Float16* __restrict__ slab, const int32_t* __restrict__ perm, const int32_t* __restrict__ cell_start,
     const _Float16* __restrict__ text_frag, float* __restrict__ relevance, int32_t* __restrict__ amax, int cap, int L,
-    int Lt, int n_chunks) {
+    int Lt_all, int tile0, int Lt, int n_chunks) {
+  // Lt_all: token tiles of the whole instruction (plane stride of text_frag); this launch takes the Lt <= LTMAX tiles from
+  // tile0 on.  tile0 > 0 (instructions of more than 256 tokens run as two launches over token groups): the result is
+  // combined with what the earlier group stored -- a later token replaces the stored maximum only if strictly larger.
   constexpr int D = 32 * KS;
   constexpr int STAGE = BKS * (2 * LTMAX * 512 + GPT * 32);   // halfs per ring stage: text blocks | point rows
   constexpr int KSTEPS = KS / BKS;                             // ring stages per tile
@@ -90,8 +93,8 @@ __global__ __launch_bounds__(GMW * 64) void grid_relevance_gemm_kernel(
   const int n_text = BKS * 2 * Lt;                         // text pieces per stage: (k-step, plane, token tile)
   const int tpw = (n_text + GMW - 1) / GMW;                // per wave (the last ones repeat a valid piece)
   const int ppw = tpw + 2 * BKS;                           // + the point pieces: DMA instructions per wave and stage
-  const size_t plane = (size_t)Lt * KS * 512;
-  const _Float16* tf_b = text_frag + (size_t)b * 2 * plane + (size_t)lane * 8;
+  const size_t plane = (size_t)Lt_all * KS * 512;
+  const _Float16* tf_b = text_frag + (size_t)b * 2 * plane + (size_t)tile0 * KS * 512 + (size_t)lane * 8;
   const int prow = BKS == 1 ? lane >> 2 : lane >> 3;       // row inside a 1-KiB point piece (16 rows x 64 B / 8 rows x 128 B)
   // Row ids travel by LDS-DMA as well (a register load would have to be waited for with a vmcnt the compiler picks --
   // it drained the ring every iteration): every wave fetches 64 of a tile's 256 ids (wave w and w + 4 the same quarter:
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(GMW * 64) void grid_relevance_gemm_kernel(
         for (int c = 0; c < LTMAX; ++c) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int tok = c * 16 + 4 * g + r;
+            const int tok = (tile0 + c) * 16 + 4 * g + r;
             const float v = tok < L ? acc[c][nf][r] : NEG_BIG;
             if (v > best) { best = v; arg = tok; }               // ascending tokens: the first maximum stays
           }
@@ -224,8 +227,12 @@ __global__ __launch_bounds__(GMW * 64) void grid_relevance_gemm_kernel(
         }
         const int p = p_lo + t * GPT + wave * 32 + nf * 16 + frow;
         if (g == 0 && p < p_hi) {
-          rel_b[p] = best;
-          if (amax) amax[(size_t)b * cap + p] = arg;
+          bool keep = true;
+          if (tile0 > 0) keep = best > rel_b[p];     // (the load drains the DMA queue once per tile: stored = true below)
+          if (keep) {
+            rel_b[p] = best;
+            if (amax) amax[(size_t)b * cap + p] = arg;
+          }
         }
       }
       stored = true;
@@ -251,9 +258,10 @@ extern "C" int gridmm_debug_relg_prof(long long* out) {      // development aid 
 int gridmm_grid_relevance_gemm(const void* slab, const int32_t* perm, const int32_t* cell_start, const void* text_frag,
                                float* relevance, int32_t* amax, int B, int cap, int D, int L, int n_chunks,
                                hipStream_t st) {
-  const int Lt = (L + 15) / 16;
-  if (!relevance || Lt < 1 || Lt > 16 || (D != 256 && D != 512 && D != 768)) return GRIDMM_EINVAL;
+  const int Lt_all = (L + 15) / 16;
+  if (!relevance || Lt_all < 1 || Lt_all > 32 || (D != 256 && D != 512 && D != 768)) return GRIDMM_EINVAL;
   dim3 grid(n_chunks, B), block(GMW * 64);
+  // more than 16 token tiles (L > 256; rxr_pretrain.json: 300): two launches over token groups, the second one combines
   // two k-steps per ring stage where the LDS holds two such stages (Lt <= 10: the per-stage costs -- DMA issue, the wait
   // for the gathered rows, the barrier -- are ~2000 cycles whatever the stage carries), else one k-step, three stages
 #define GRIDMM_RELG(KS, LTM, NS, BKS)                                                                              \
@@ -264,7 +272,7 @@ int gridmm_grid_relevance_gemm(const void* slab, const int32_t* perm, const int3
                             (int)lds) != hipSuccess)                                                               \
       return GRIDMM_EINVAL;                                                                                        \
     GRIDMM_LAUNCH(kern, grid, block, lds, st, (const _Float16*)slab, perm, cell_start, (const _Float16*)text_frag, \
-                  relevance, amax, cap, L, Lt, n_chunks);                                                          \
+                  relevance, amax, cap, L, Lt_all, tile0, Lt, n_chunks);                                           \
   } while (0)
 #define GRIDMM_RELG_D(KS)                                  \
   do {                                                     \
@@ -275,9 +283,12 @@ int gridmm_grid_relevance_gemm(const void* slab, const int32_t* perm, const int3
     else if (Lt <= 13) GRIDMM_RELG(KS, 13, 3, 1);          \
     else GRIDMM_RELG(KS, 16, 3, 1);                        \
   } while (0)
-  if (D == 256) GRIDMM_RELG_D(8);
-  else if (D == 512) GRIDMM_RELG_D(16);
-  else GRIDMM_RELG_D(24);
+  for (int tile0 = 0; tile0 < Lt_all; tile0 += 16) {
+    const int Lt = Lt_all - tile0 < 16 ? Lt_all - tile0 : 16;
+    if (D == 256) GRIDMM_RELG_D(8);
+    else if (D == 512) GRIDMM_RELG_D(16);
+    else GRIDMM_RELG_D(24);
+  }
 #undef GRIDMM_RELG_D
 #undef GRIDMM_RELG
   GRIDMM_CHECK_LAUNCH();

@@ -57,9 +57,12 @@ CASES = [
     (512, 200, "crowded", [9000, 1111, 33, 1], 8),
     (512, 250, "sparse", [400, 300, 0], None),   # 16 token tiles
     (256, 200, "blocks", [3000, 500], None),
-    (512, 300, "blocks", [2048, 300, 31], None),   # past the pipelined paths (L <= 256): generic kernel, any L <= 512
+    (512, 300, "blocks", [2048, 300, 31], None),   # more than 16 token tiles: relevance GEMM in two launches over token groups
     (768, 300, "crowded", [3000, 64, 700], 8),     # (rxr_pretrain.json: max_txt_len 300)
     (768, 512, "sparse", [400, 300, 0], None),     # BERT's position table
+    (256, 270, "crowded", [1500, 40], 4),          # second group of one token tile (17 tiles)
+    (256, 200, "crowded", [1500, 40], 4),          # D = 256 accumulation pass, many tiles per workgroup (a round-3 race:
+    (256, 120, "crowded", [1500, 40], 8),          #  run-dependent sums, NaN -- the single-group accumulator form)
     (768, 120, "blocks", [2000, 300], None),
     (768, 200, "crowded", [5000, 64, 700], 24),
     (768, 200, "sparse", [150, 97, 0, 260], None),
@@ -97,8 +100,11 @@ def test_grid_aggregate_regimes(D, L, kind, npts, n_chunks):
     cells, occ, rel, amax = ops.grid_aggregate(slab, perm, cs, ops.text_fragments(text.cuda()), L, n_chunks=n_chunks,
                                                want_relevance=True, want_amax=True)
     torch.cuda.synchronize()
-    if max(npts) <= 45000 and L <= 256:
-        # every shape up to L = 256 runs on a pipelined path (one pass: D <= 512, 33 <= L <= 96; else relevance +
+    again = ops.grid_aggregate(slab, perm, cs, ops.text_fragments(text.cuda()), L, n_chunks=n_chunks, want_relevance=True,
+                               want_amax=True)
+    assert torch.equal(again[0], cells) and torch.equal(again[2], rel)          # no run-to-run variation on any path
+    if max(npts) <= 45000:
+        # every shape up to L = 512 runs on a pipelined path (past 256 tokens: the relevance GEMM over two token groups) (one pass: D <= 512, 33 <= L <= 96; else relevance +
         # accumulation passes), which also delivers the backward's routing; the generic kernel (rc 1) does not
         assert ops.LAST_AGGREGATE_RC == 0 and amax is not None
     for b in range(B):

@@ -236,9 +236,9 @@ def test_training_trajectory_is_bit_reproducible():
 
 @pytest.mark.gpu
 def test_pretrain_step_with_300_token_instructions():
-    """rxr_pretrain.json: max_txt_len 300 -- past the pipelined aggregation paths (L <= 256): the generic aggregation
-    kernel and the search-based aggregation backward run; the step is finite and moves text_proj (whose only gradient
-    path is the relevance routing)."""
+    """rxr_pretrain.json: max_txt_len 300 -- more than 16 token tiles: the relevance GEMM runs over two token groups and
+    still delivers the backward's routing (deterministic gather form); the step is finite and moves text_proj (whose only
+    gradient path is the relevance routing)."""
     from train_graph_cases import _setup
     from gridmm_amd.pretrain_loop import PreTrainer, default_opts
     from gridmm_amd.synthetic import batch_to, make_pretrain_batch
