@@ -1,0 +1,222 @@
+"""Randomised shape sweep of the hot-path kernels on the GPU: every case is checked against an fp64 / oracle reference AND
+run twice for bit-equality (a race shows as run-to-run variation long before it shows as a wrong value).
+usage: python tools/fuzz_kernels.py [--cases 40] [--seed 0] [--only gemm,attention,layernorm,aggregate,nav]
+Prints one line per failing case and a summary; exit code 1 on any failure."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from gridmm_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda")
+FAILS = []
+
+
+def fail(kind, case, msg):
+    FAILS.append((kind, case, msg))
+    print("FAIL %-10s %s : %s" % (kind, case, msg), flush=True)
+
+
+def fuzz_gemm(rs, n):
+    for _ in range(n):
+        M = int(rs.choice([1, 7, 57, 64, 129, 500, 1824, 2560, 4097, 6912]))
+        K = int(rs.choice([32, 64, 96, 512, 768, 1536, 3072]))
+        N = int(rs.choice([4, 12, 64, 196, 512, 768, 1000, 2304, 3072]))
+        act = int(rs.choice([ops.ACT_NONE, ops.ACT_GELU, ops.ACT_RELU]))
+        res = bool(rs.rand() < 0.4)
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        x = torch.randn(M, K, generator=g)
+        w, b = torch.randn(N, K, generator=g) / np.sqrt(K), torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g) if res else None
+        pw = ops.PackedLinear(w.to(DEV), b.to(DEV))
+        xa = ops.split_rows(x.to(DEV))
+        outs = []
+        for _rep in range(2):
+            y = ops.linear(xa, pw, act=act, residual=None if r is None else r.to(DEV), want_f32=True, want_planes=True)
+            torch.cuda.synchronize()
+            outs.append((y.f32.clone(), y.hi.clone(), y.lo.clone()))
+        ref = x.double() @ w.double().t() + b.double()
+        if act == ops.ACT_GELU:
+            ref = torch.nn.functional.gelu(ref)
+        elif act == ops.ACT_RELU:
+            ref = torch.relu(ref)
+        if r is not None:
+            ref = ref + r.double()
+        err = float((outs[0][0].double().cpu() - ref).abs().max())
+        case = (M, N, K, act, res)
+        if err > 3e-4 * max(1.0, float(ref.abs().max())):
+            fail("gemm", case, "max abs err %.3e" % err)
+        if not all(torch.equal(a, b2) for a, b2 in zip(outs[0], outs[1])):
+            fail("gemm", case, "run-to-run variation")
+        rec = outs[0][1].float() + outs[0][2].float()
+        if float((rec - outs[0][0]).abs().max()) > 2.0 ** -15 * max(1e-6, float(outs[0][0].abs().max())):
+            fail("gemm", case, "planes do not reconstruct the fp32 output")
+
+
+def fuzz_attention(rs, n):
+    for _ in range(n):
+        B = int(rs.choice([1, 2, 5]))
+        Sq = int(rs.choice([1, 5, 16, 57, 90, 216, 300]))
+        Sk = int(rs.choice([1, 31, 32, 57, 80, 216, 296, 513, 700, 1100]))
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        q, kv = torch.randn(B, Sq, 768, generator=g), torch.randn(B, Sk, 1536, generator=g)
+        mask = torch.rand(B, Sk, generator=g) < 0.8
+        mask[:, 0] = True
+        if rs.rand() < 0.3 and Sk >= 2:
+            mask[0, Sk // 2:] = False
+        qa, ka = ops.split_rows(q.to(DEV)), ops.split_rows(kv.to(DEV))
+        ksl, vsl = (ka.hi[..., :768], ka.lo[..., :768]), (ka.hi[..., 768:], ka.lo[..., 768:])
+        outs = []
+        for _rep in range(2):
+            o = ops.attention_rows((qa.hi, qa.lo), ksl, vsl, mask.to(DEV), want_f32=True, want_planes=True)
+            torch.cuda.synchronize()
+            outs.append((o.f32.clone(), o.hi.clone(), o.lo.clone()))
+
+        def heads(t):
+            return t.reshape(B, -1, 12, 64).permute(0, 2, 1, 3).double()
+        s = heads(q) @ heads(kv[..., :768]).transpose(-1, -2) / 8.0
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+        ref = (torch.softmax(s, -1) @ heads(kv[..., 768:])).permute(0, 2, 1, 3).reshape(B, Sq, 768)
+        err = float((outs[0][0].double().cpu() - ref).abs().max())
+        case = (B, Sq, Sk)
+        if not (err < 3e-4):
+            fail("attention", case, "max abs err %.3e" % err)
+        if not all(torch.equal(a, b2) for a, b2 in zip(outs[0], outs[1])):
+            fail("attention", case, "run-to-run variation")
+
+
+def fuzz_layernorm(rs, n):
+    for _ in range(n):
+        M = int(rs.choice([1, 3, 57, 1824, 2049, 6912]))
+        H = 768
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        x, r = torch.randn(M, H, generator=g) * 3, torch.randn(M, H, generator=g)
+        gm, bt = torch.randn(H, generator=g), torch.randn(H, generator=g)
+        use_r = bool(rs.rand() < 0.5)
+        outs = []
+        for _rep in range(2):
+            y = ops.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV), 1e-12, residual=r.to(DEV) if use_r else None, want_planes=True)
+            torch.cuda.synchronize()
+            outs.append((y.f32.clone(), y.hi.clone(), y.lo.clone()))
+        ref = torch.nn.functional.layer_norm((x + r if use_r else x).double(), (H,), gm.double(), bt.double(), 1e-12)
+        err = float((outs[0][0].double().cpu() - ref).abs().max())
+        if err > 2e-5 * max(1.0, float(ref.abs().max())):
+            fail("layernorm", (M, use_r), "max abs err %.3e" % err)
+        if not all(torch.equal(a, b2) for a, b2 in zip(outs[0], outs[1])):
+            fail("layernorm", (M, use_r), "run-to-run variation")
+
+
+def fuzz_aggregate(rs, n):
+    import test_hip_aggregate as T
+    from gridmm_amd.grid_memory import pack_reference_lists
+    for _ in range(n):
+        D = int(rs.choice([256, 512, 768]))
+        L = int(rs.choice([5, 16, 33, 48, 80, 96, 97, 120, 200, 256, 257, 300, 512]))
+        kind = str(rs.choice(["sparse", "crowded", "blocks"]))
+        B = int(rs.choice([1, 2, 4]))
+        npts = [int(rs.choice([0, 1, 31, 32, 33, 200, 588, 1500, 4000, 9000])) for _ in range(B)]
+        n_chunks = rs.choice([None, 1, 2, 4, 8, 24, 64])
+        n_chunks = None if n_chunks is None else int(n_chunks)
+        seed = int(rs.randint(1 << 30))
+        rng, g = np.random.default_rng(seed), torch.Generator().manual_seed(seed)
+        fts, maps = [], []
+        for npt in npts:
+            fts.append((torch.randn(npt, D, generator=g) * 0.5).half())
+            maps.append(torch.from_numpy(T._episode_ids(kind, npt, rng).astype(np.int64)) if npt else torch.zeros(0, dtype=torch.int64))
+        text = torch.randn(B, L, D, generator=g) * 0.3
+        case = (D, L, kind, npts, n_chunks)
+        if max(npts) == 0:
+            continue
+        slab, perm, cs = pack_reference_lists([f.to(DEV) for f in fts], [m.to(DEV).double() for m in maps])
+        outs = []
+        for _rep in range(2):
+            cells, occ, rel, amax = ops.grid_aggregate(slab, perm, cs, ops.text_fragments(text.to(DEV)), L, n_chunks=n_chunks,
+                                                       want_relevance=True, want_amax=True)
+            torch.cuda.synchronize()
+            outs.append((cells.clone(), occ.clone(), rel.clone()))
+        if not all(torch.equal(a, b2) for a, b2 in zip(outs[0], outs[1])):
+            fail("aggregate", case, "run-to-run variation (rc %d)" % ops.LAST_AGGREGATE_RC)
+        for b in range(B):
+            ref_cells, ref_occ, w = T._ref(fts[b], maps[b], text[b], L)
+            if not torch.equal(outs[0][1][b].cpu(), ref_occ):
+                fail("aggregate", case, "occupancy differs (episode %d)" % b)
+            err = float((outs[0][0][b].double().cpu() - ref_cells).abs().max())
+            if not (err < 3e-5):
+                fail("aggregate", case, "episode %d max abs err %.3e (rc %d)" % (b, err, ops.LAST_AGGREGATE_RC))
+
+
+def fuzz_nav(rs, n):
+    """Whole forward('navigation') on a reduced model against the CPU oracle, random batch / graph / view / instruction
+    sizes, list-form grid inputs, with and without varlen buckets."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    from oracle import gridmap_oracle as G, navcmt_oracle as O
+    from oracle.ref_harness import det_tensor
+    cfg = default_config(num_l_layers=1, num_pano_layers=1, num_x_layers=2, intermediate_size=256, vocab_size=1000)
+    model = GlocalTextPathNavCMT(cfg).eval()
+    sd = {k: (det_tensor(k, v.shape, 3) if v.dtype.is_floating_point else v) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    model.to(DEV)
+    for _ in range(n):
+        B = int(rs.choice([1, 2, 3, 5]))
+        L = int(rs.choice([6, 20, 40, 80, 130]))
+        Gn = int(rs.choice([8, 10, 12, 30, 60]))
+        V1 = int(rs.choice([4, 10, 37, 58]))
+        T = int(rs.choice([1, 2, 4]))
+        seed = int(rs.randint(1 << 30))
+        r2 = np.random.RandomState(seed)
+        mems = [G.GridMemory(G.NATIVE) for _ in range(B)]
+        ref = None
+        for t in range(T):
+            eps = [S.make_observations(r2, S.NATIVE, 1, feat_scale=0.35)[0] for _ in range(B)]
+            ref = [mems[b].step(eps[b]["depth"], eps[b]["feats"], eps[b]["x"], eps[b]["y"], eps[b]["heading"]) for b in range(B)]
+        batch = S.make_nav_batch(r2, B, L=L, G=Gn, n_visited=max(2, (Gn - 4) // 3), V1=V1, n_cand=min(3, V1 - 1), min_len=min(5, L))
+        cpu = dict(batch, grid_fts=[torch.from_numpy(r[0]) for r in ref], grid_map=[torch.from_numpy(r[1]) for r in ref],
+                   gridmap_pos_fts=torch.from_numpy(np.stack([r[2] for r in ref])))
+        case = (B, L, Gn, V1, T)
+        with torch.no_grad():
+            want = O.forward_navigation(sd, cpu)
+            gpu = dict(S.batch_to(batch, DEV), grid_fts=[x.to(DEV) for x in cpu["grid_fts"]],
+                       grid_map=[x.to(DEV) for x in cpu["grid_map"]], gridmap_pos_fts=cpu["gridmap_pos_fts"].to(DEV))
+            for buckets in (None, GlocalTextPathNavCMT.DEFAULT_BUCKETS):
+                model.varlen_buckets = buckets
+                a = model("navigation", gpu)
+                b2 = model("navigation", gpu)
+                torch.cuda.synchronize()
+                for k in ("global_logits", "local_logits", "fused_logits", "grid_logits"):
+                    w, x, y = want[k], a[k].cpu(), b2[k].cpu()
+                    f = torch.isfinite(w)
+                    if not torch.equal(f, torch.isfinite(x)):
+                        fail("nav", case, "%s: -inf placement differs (buckets %s)" % (k, buckets is not None))
+                        continue
+                    err = float((x[f] - w[f]).abs().max()) if f.any() else 0.0
+                    if not (err < 3e-4):
+                        fail("nav", case, "%s max abs err %.3e (buckets %s)" % (k, err, buckets is not None))
+                    if not torch.equal(x, y):
+                        fail("nav", case, "%s run-to-run variation (buckets %s)" % (k, buckets is not None))
+        model.varlen_buckets = None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,nav")
+    a = ap.parse_args()
+    rs = np.random.RandomState(a.seed)
+    table = {"gemm": fuzz_gemm, "attention": fuzz_attention, "layernorm": fuzz_layernorm, "aggregate": fuzz_aggregate,
+             "nav": lambda r, n: fuzz_nav(r, max(4, n // 4))}
+    for name in a.only.split(","):
+        before = len(FAILS)
+        table[name](rs, a.cases)
+        print("%-10s %d cases, %d failures" % (name, a.cases if name != "nav" else max(4, a.cases // 4), len(FAILS) - before), flush=True)
+    return 1 if FAILS else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
