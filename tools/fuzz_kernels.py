@@ -1,6 +1,6 @@
 """Randomised shape sweep of the hot-path kernels on the GPU: every case is checked against an fp64 / oracle reference AND
 run twice for bit-equality (a race shows as run-to-run variation long before it shows as a wrong value).
-usage: python tools/fuzz_kernels.py [--cases 40] [--seed 0] [--only gemm,attention,layernorm,aggregate,nav]
+usage: python tools/fuzz_kernels.py [--cases 40] [--seed 0] [--only gemm,attention,layernorm,aggregate,nav,linear_bwd,attn_bwd,agg_bwd]
 Prints one line per failing case and a summary; exit code 1 on any failure."""
 import argparse
 import os
@@ -202,19 +202,146 @@ def fuzz_nav(rs, n):
         model.varlen_buckets = None
 
 
+def _rel(a, b):
+    return float((a.detach().double() - b.detach().double()).abs().max() / (b.detach().double().abs().max() + 1e-30))
+
+
+def fuzz_linear_bwd(rs, n):
+    from gridmm_amd import autograd as ag
+    for _ in range(n):
+        lead = int(rs.choice([1, 2, 3]))
+        M = int(rs.choice([1, 5, 33, 57, 130, 300, 700, 2304]))
+        K = int(rs.choice([5, 7, 14, 32, 64, 768, 3072]))
+        N = int(rs.choice([1, 32, 64, 96, 768, 1000, 3072]))
+        bias, res = bool(rs.rand() < 0.7), bool(rs.rand() < 0.3)
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        x0 = torch.randn(lead, M, K, generator=g)
+        w0, b0 = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g) * 0.1
+        r0, dy = torch.randn(lead, M, N, generator=g), torch.randn(lead, M, N, generator=g).to(DEV)
+        runs = []
+        for _rep in range(2):
+            x, w = x0.to(DEV).requires_grad_(), w0.to(DEV).requires_grad_()
+            b = b0.to(DEV).requires_grad_() if bias else None
+            r = r0.to(DEV).requires_grad_() if res else None
+            y = ag.linear(x, w, b, r)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            runs.append([y.detach().clone()] + [t.grad.clone() for t in (x, w, b, r) if t is not None])
+        xd, wd = x0.double().requires_grad_(), w0.double().requires_grad_()
+        bd = b0.double().requires_grad_() if bias else None
+        rd = r0.double().requires_grad_() if res else None
+        yd = torch.nn.functional.linear(xd, wd, bd)
+        if res:
+            yd = yd + rd
+        yd.backward(dy.double().cpu())
+        want = [yd] + [t.grad for t in (xd, wd, bd, rd) if t is not None]
+        case = (lead, M, K, N, bias, res)
+        for i, (a, e) in enumerate(zip(runs[0], want)):
+            if _rel(a.cpu(), e) > 5e-5:
+                fail("linear_bwd", case, "tensor %d rel err %.2e" % (i, _rel(a.cpu(), e)))
+        if not all(torch.equal(a, b2) for a, b2 in zip(runs[0], runs[1])):
+            fail("linear_bwd", case, "run-to-run variation")
+
+
+def fuzz_attention_bwd(rs, n):
+    from gridmm_amd import autograd as ag
+
+    def ref_att(q, k, v, kmask, heads):
+        B, Sq, H = q.shape
+        qh, kh, vh = (t.reshape(B, -1, heads, 64).transpose(1, 2) for t in (q, k, v))
+        s_ = qh @ kh.transpose(-1, -2) / 8.0
+        s_ = s_.masked_fill(~kmask[:, None, None, :], -float("inf"))
+        return (torch.softmax(s_, -1) @ vh).transpose(1, 2).reshape(B, Sq, H)
+    for _ in range(n):
+        B, heads = int(rs.choice([1, 2, 3])), int(rs.choice([2, 12]))
+        Sq = int(rs.choice([1, 17, 57, 80, 216, 300]))
+        Sk = int(rs.choice([3, 45, 80, 216, 296, 350]))
+        H = heads * 64
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        lens = torch.randint(max(1, Sk // 3), Sk + 1, (B,), generator=g)
+        lens[0] = Sk
+        kmask = torch.arange(Sk)[None] < lens[:, None]
+        q0, kv0 = torch.randn(B, Sq, H, generator=g), torch.randn(B, Sk, 2 * H, generator=g)
+        dy = torch.randn(B, Sq, H, generator=g)
+        runs = []
+        for _rep in range(2):
+            q, kv = q0.to(DEV).requires_grad_(), kv0.to(DEV).requires_grad_()
+            y = ag.cross_attention(q, kv, kmask.to(DEV), heads, kv_col=0)
+            y.backward(dy.to(DEV))
+            torch.cuda.synchronize()
+            runs.append([y.detach().clone(), q.grad.clone(), kv.grad.clone()])
+        qd, kvd = q0.double().requires_grad_(), kv0.double().requires_grad_()
+        yd = ref_att(qd, kvd[..., :H], kvd[..., H:], kmask, heads)
+        yd.backward(dy.double())
+        case = (B, heads, Sq, Sk)
+        for i, (a, e) in enumerate(zip(runs[0], (yd, qd.grad, kvd.grad))):
+            if _rel(a.cpu(), e) > 5e-5:
+                fail("attn_bwd", case, "tensor %d rel err %.2e" % (i, _rel(a.cpu(), e)))
+        if not all(torch.equal(a, b2) for a, b2 in zip(runs[0], runs[1])):
+            fail("attn_bwd", case, "run-to-run variation")
+
+
+def fuzz_aggregate_bwd(rs, n):
+    from gridmm_amd import autograd as ag
+    for _ in range(n):
+        B, D = int(rs.choice([1, 2, 3])), int(rs.choice([256, 512, 768]))
+        L = int(rs.choice([8, 20, 40, 80, 96, 112, 144, 200, 270, 300]))
+        n_obs = int(rs.choice([1, 2, 4]))
+        cap = 588 * n_obs
+        r2 = np.random.RandomState(int(rs.randint(1 << 30)))
+        n_pts = r2.randint(cap // 2, cap + 1, size=B)
+        slab = torch.from_numpy((r2.standard_normal((B, cap, D)) * 0.35).astype(np.float16)).to(DEV)
+        ids = r2.randint(-1, 196, size=(B, cap)).astype(np.int16)
+        ids[:, :50] = r2.randint(0, 4, size=(B, 50))
+        for b in range(B):
+            ids[b, n_pts[b]:] = -1
+        ids_t = torch.from_numpy(ids).to(DEV)
+        perm = torch.empty(B, cap, dtype=torch.int32, device=DEV)
+        cell_start = torch.empty(B, 198, dtype=torch.int32, device=DEV)
+        ops.grid_sort_ids(ids_t, torch.from_numpy(n_pts.astype(np.int32)).to(DEV), perm, cell_start)
+        text0 = torch.from_numpy(r2.standard_normal((B, L, D)).astype(np.float32)) * 0.3
+        dcells = torch.from_numpy(r2.standard_normal((B, 196, D)).astype(np.float32)).to(DEV)
+        runs = []
+        for _rep in range(2):
+            text = text0.to(DEV).requires_grad_()
+            cells, occ = ag.grid_aggregate(text, slab, perm, cell_start)
+            cells.backward(dcells)
+            torch.cuda.synchronize()
+            runs.append([cells.detach().clone(), text.grad.clone()])
+        td = text0.to(DEV).double().requires_grad_()
+        ref = torch.zeros(B, 196, D, dtype=torch.float64, device=DEV)
+        for b in range(B):
+            x = slab[b].double()
+            w = (x @ td[b].t()).max(-1)[0]
+            for c in range(196):
+                sel = ids_t[b] == c
+                if sel.any():
+                    ref[b, c] = (torch.softmax(w[sel], 0)[:, None] * x[sel]).sum(0)
+        ref.backward(dcells.double())
+        case = (B, D, L, n_obs)
+        if _rel(runs[0][0], ref) > 1e-4:
+            fail("agg_bwd", case, "cells rel err %.2e" % _rel(runs[0][0], ref))
+        if _rel(runs[0][1], td.grad) > 2e-3:
+            fail("agg_bwd", case, "dtext rel err %.2e" % _rel(runs[0][1], td.grad))
+        if not all(torch.equal(a, b2) for a, b2 in zip(runs[0], runs[1])):
+            fail("agg_bwd", case, "run-to-run variation")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,nav")
+    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,nav,linear_bwd,attn_bwd,agg_bwd")
     a = ap.parse_args()
     rs = np.random.RandomState(a.seed)
     table = {"gemm": fuzz_gemm, "attention": fuzz_attention, "layernorm": fuzz_layernorm, "aggregate": fuzz_aggregate,
-             "nav": lambda r, n: fuzz_nav(r, max(4, n // 4))}
+             "nav": lambda r, n: fuzz_nav(r, max(4, n // 4)), "linear_bwd": fuzz_linear_bwd,
+             "attn_bwd": lambda r, n: fuzz_attention_bwd(r, max(4, n // 2)),
+             "agg_bwd": lambda r, n: fuzz_aggregate_bwd(r, max(4, n // 4))}
     for name in a.only.split(","):
         before = len(FAILS)
         table[name](rs, a.cases)
-        print("%-10s %d cases, %d failures" % (name, a.cases if name != "nav" else max(4, a.cases // 4), len(FAILS) - before), flush=True)
+        print("%-10s done, %d failures" % (name, len(FAILS) - before), flush=True)
     return 1 if FAILS else 0
 
 
