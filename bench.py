@@ -168,6 +168,20 @@ def extra_depth_leg(args, dev, dist, mem_steps, steps):
     return dt / steps
 
 
+def larger_batch_leg(args, dev, steps):
+    """The same step with several of the reference's batches resident at once (288 GB of HBM hold them easily): B = 64 and
+    B = 128 episodes per GPU, t = 1.  Secondary keys: the metric is quoted at B = 32; the thin GEMMs of the local encoder
+    (57 query rows per episode) fill the chip better with more episodes per launch."""
+    res = {}
+    for B in (64, 128):
+        model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev, device_feats=True, batch_size=B)
+        dt = time_steps(step, steps, 2, None) / steps
+        res["b%d" % B] = {"value": B / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt, "batch": B}
+        del model, batch, mem, step, eager_step
+        torch.cuda.empty_cache()
+    return res
+
+
 def sparse_map_leg(args, dev, dist, steps):
     """Varlen map sequences (vilmodel.py:809-823 max_cell_num): the headline step on episodes whose depth occupies ~90-120
     of the 196 cells (synthetic 'ring' depth), once on the 196-row padded sequence and once with the bucketed back graphs."""
@@ -707,6 +721,8 @@ def main():
         out["sparse_map"] = sparse_map_leg(args, dev, dist, max(5, args.steps // 2))
     if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1:
         out.update(config_legs(args, dev, max(5, args.steps // 2)))
+        if args.batch == 32 and args.mem_steps == 1:
+            out["larger_batches"] = larger_batch_leg(args, dev, max(5, args.steps // 2))
     if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1:
         try:
             out["rollout"] = rollout_leg(args, dev)
