@@ -327,17 +327,59 @@ def fuzz_aggregate_bwd(rs, n):
             fail("agg_bwd", case, "run-to-run variation")
 
 
+def fuzz_gridmap(rs, n):
+    """Re-binning + stable sort of ragged histories (episodes skipped by `active` masks) for every slice count, against
+    numpy's stable argsort of the cell ids the kernel itself wrote (the ids are pinned bit-exact on the oracle elsewhere)."""
+    from gridmm_amd import synthetic
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    for _ in range(n):
+        geom = synthetic.BASELINE if rs.rand() < 0.5 else synthetic.NATIVE
+        B, T = int(rs.choice([1, 2, 3, 5])), int(rs.choice([1, 2, 3, 6, 10]))
+        mem = GridMemoryBatch(B, geom, max_steps=T, device=DEV)
+        for k in range(T):
+            depth = np.stack([rs.randint(0, 20000, size=geom.n_views * geom.patches ** 2).astype(np.uint16) for _ in range(B)])
+            depth[rs.rand(*depth.shape) < 0.15] = 0
+            active = rs.rand(B) < 0.75
+            active[rs.randint(B)] = True
+            feats = torch.zeros(B, geom.pts_per_obs, geom.feat_dim, dtype=torch.float16, device=DEV)
+            mem.step(depth, feats, [(float(rs.uniform(-6, 6)), float(rs.uniform(-6, 6))) for _ in range(B)],
+                     [float(rs.uniform(-7, 7)) for _ in range(B)], active=None if active.all() else active)
+        n_pts = mem.n_pts.cpu().numpy()
+        case = (geom.pts_per_obs, B, T, n_pts.tolist())
+        ref = None
+        for S_ in (1, 2, 4, 8, 16):
+            ops.grid_bin(mem.hist_x, mem.hist_y, mem.hist_valid, mem.n_pts, mem.pose_d, mem.head_d, mem.half_len, mem.cell_id,
+                         mem.perm, mem.cell_start, mem.flags, workspace=mem._bin_ws, slices=S_)
+            torch.cuda.synchronize()
+            ids, perm, cs = mem.cell_id.cpu().numpy(), mem.perm.cpu().numpy(), mem.cell_start.cpu().numpy()
+            for b in range(B):
+                nb = int(n_pts[b])
+                key = np.where(ids[b, :nb] < 0, 196, ids[b, :nb]).astype(np.int64)
+                want = np.argsort(key, kind="stable")
+                counts = np.bincount(key, minlength=197)
+                starts = np.concatenate([[0], np.cumsum(counts)])
+                if not np.array_equal(perm[b, :nb], want):
+                    fail("gridmap", case, "perm differs (S=%d, episode %d)" % (S_, b))
+                if not np.array_equal(cs[b, :198], starts[:198]):
+                    fail("gridmap", case, "cell_start differs (S=%d, episode %d)" % (S_, b))
+            if ref is None:
+                ref = ids.copy()
+            elif not np.array_equal(ref, ids):
+                fail("gridmap", case, "cell ids differ between slice counts (S=%d)" % S_)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,nav,linear_bwd,attn_bwd,agg_bwd")
+    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,nav,linear_bwd,attn_bwd,agg_bwd,gridmap")
     a = ap.parse_args()
     rs = np.random.RandomState(a.seed)
     table = {"gemm": fuzz_gemm, "attention": fuzz_attention, "layernorm": fuzz_layernorm, "aggregate": fuzz_aggregate,
              "nav": lambda r, n: fuzz_nav(r, max(4, n // 4)), "linear_bwd": fuzz_linear_bwd,
              "attn_bwd": lambda r, n: fuzz_attention_bwd(r, max(4, n // 2)),
-             "agg_bwd": lambda r, n: fuzz_aggregate_bwd(r, max(4, n // 4))}
+             "agg_bwd": lambda r, n: fuzz_aggregate_bwd(r, max(4, n // 4)),
+             "gridmap": lambda r, n: fuzz_gridmap(r, max(4, n // 4))}
     for name in a.only.split(","):
         before = len(FAILS)
         table[name](rs, a.cases)
