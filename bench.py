@@ -107,7 +107,7 @@ def build_workload(args, dev, mem_steps=None, device_feats=False, depth_mode="un
     if not args.eager:
         from gridmm_amd.graph import GraphedNavStep
         eager_step()                            # packs the weights, fills the allocator
-        g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore, buckets=buckets)
+        g = GraphedNavStep(model, mem, batch, depth[t - 1], restore=restore, buckets=buckets, count_nodes=not buckets)
         mem.n_pts_host[:] = n_host0 + n_new
         if buckets:
             g(poses[t - 1], heads[t - 1], fusion=fusion_src, check=True)     # settles the bucket prediction
@@ -710,6 +710,8 @@ def main():
                    "attention": "MFMA bf16 16x16x32, 3-term split, fp32 softmax", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
     }
     out["replay_check"] = check
+    if getattr(step, "graph", None) is not None and step.graph.n_nodes is not None:
+        out["graph_nodes"] = step.graph.n_nodes       # nodes of one replayed step (hipGraphGetNodes)
     if not args.no_depth_legs and not args.eager and args.mem_steps == 1:
         # the memory deepens as an episode proceeds; the headline is t = 1, these are the same step at
         # t = 5 and t = 15 (re-binning and aggregation walk 5x / 15x the points)

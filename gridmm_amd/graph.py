@@ -22,8 +22,25 @@ import torch
 from . import ops
 
 
+def count_graph_nodes(fn):
+    """Kernel / copy nodes of `fn` captured as a hipGraph (a throw-away capture with keep_graph=True, hipGraphGetNodes through
+    ctypes); None when the runtime does not expose the raw graph."""
+    import ctypes
+    try:
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(g):
+            fn()
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_size_t(0)
+        rc = hip.hipGraphGetNodes(ctypes.c_void_p(g.raw_cuda_graph()), None, ctypes.byref(n))
+        g.reset()
+        return int(n.value) if rc == 0 else None
+    except Exception:
+        return None
+
+
 class GraphedNavStep:
-    def __init__(self, model, mem, batch, depth, restore=None, warmup=2, buckets=None):
+    def __init__(self, model, mem, batch, depth, restore=None, warmup=2, buckets=None, count_nodes=False):
         """depth: (B, n_pts) uint16 device tensor of the observation appended by each step.
         restore: optional (n_pts0, bbox0) device tensors copied back before each step, so that every replay
         appends to the same history prefix (benchmarks at a fixed memory depth t)."""
@@ -65,6 +82,9 @@ class GraphedNavStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outs = self._device_step()
+        self.n_nodes = count_graph_nodes(self._device_step) if count_nodes else None
+
+    n_nodes = None
 
     def _init_bucketed(self, warmup):
         model = self.model
