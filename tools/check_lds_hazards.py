@@ -59,11 +59,9 @@ def hazards(asm_text):
 
 
 def check_file(path, flags=("-O3", "-std=c++17")):
-    extra = ["-std=c++20"] if os.path.basename(path) == "navfuse.hip" else []
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *[f for f in flags if not (extra and f.startswith("-std"))], *extra,
-               "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, path]
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *flags, "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, path]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("compile failed: %s\n%s" % (path, r.stderr[-2000:]))
