@@ -144,8 +144,8 @@ class GlocalTextPathCMT(nn.Module):
         xl = b.local_encoder.encoder.x_layers
         kv_all = VT._cat_linear(kv_embeds, [m for l in xl for m in (l.visual_attention.att.key,
                                                                     l.visual_attention.att.value)])
-        for i, layer in enumerate(xl):
-            q = VT.x_layer(b, layer, kv_all, kv_masks, q, q_masks, kv_col=2 * H * i)
+        for layer, kv in zip(xl, kv_all.split(2 * H, dim=-1)):       # (split: see vilmodel_train.encode_navigation)
+            q = VT.x_layer(b, layer, kv, kv_masks, q, q_masks)
         return q[:, :G], q[:, G:], gridmap_embeds, f
 
     _ARGS = ("txt_ids", "txt_lens", "traj_view_img_fts", "traj_obj_img_fts", "traj_loc_fts", "traj_nav_types",

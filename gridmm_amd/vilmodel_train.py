@@ -234,8 +234,11 @@ def encode_navigation(model, txt_embeds, txt_masks, cells, cell_masks, gmap_img_
     q_masks = torch.cat([gmap_masks, vp_masks], 1)
     xl = le.encoder.x_layers
     kv_all = _cat_linear(kv_embeds, [m for l in xl for m in (l.visual_attention.att.key, l.visual_attention.att.value)])
-    for i, layer in enumerate(xl):
-        q = x_layer(model, layer, kv_all, kv_masks, q, q_masks, kv_col=2 * H * i)
+    # every layer reads ITS [k | v] column block through a split view: the backward of the split is one concatenation of
+    # the layers' (B, Sk, 2H) gradients (a shared kv_col form made every layer return a zero-filled full-width tensor,
+    # summed three times: 4 fills + 3 adds of the whole 6144-wide context projection per step)
+    for layer, kv in zip(xl, kv_all.split(2 * H, dim=-1)):
+        q = x_layer(model, layer, kv, kv_masks, q, q_masks)
     return q[:, :G], q[:, G:], map_embeds
 
 
