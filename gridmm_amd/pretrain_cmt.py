@@ -100,8 +100,16 @@ class GlocalTextPathCMT(nn.Module):
                             W[i, k + 1, t * Vmax + j] += 1.0 / len(occ)
             return torch.from_numpy(W).to(dev)
         W = hs.host(gmap_weights)
-        tok = torch.cat([F.pad(traj[offs[i]:offs[i + 1]].reshape(-1, H), (0, 0, 0, (Tmax - step_lens[i]) * Vmax))
-                         .unsqueeze(0) for i in range(B)], 0)
+        # (B, Tmax * Vmax, H) padded token blocks as ONE gather from [traj rows | a zero row] (host-built row index; a
+        # per-episode pad + cat was 2 x 32 tiny launches per step with its backward)
+        def pad_index():
+            idx = np.full((B, Tmax * Vmax), traj.shape[0] * Vmax, dtype=np.int64)         # the zero row
+            for i in range(B):
+                n = step_lens[i] * Vmax
+                idx[i, :n] = offs[i] * Vmax + np.arange(n)
+            return torch.from_numpy(idx.reshape(-1)).to(dev)
+        rows = torch.cat([traj.reshape(-1, H), traj.new_zeros(1, H)], 0)
+        tok = rows.index_select(0, hs.host(pad_index)).view(B, Tmax * Vmax, H)
         gmap_img = torch.bmm(W, tok)                               # row 0 ([stop]) stays zero
         ge, le = b.global_encoder, b.local_encoder
         gmap_input = gmap_img + ge.gmap_step_embeddings(batch["gmap_step_ids"].long()) + ag.layer_norm(
