@@ -290,7 +290,11 @@ class _Attention(torch.autograd.Function):
         same = kv_src is None
         if same:
             kv_src = q_src
-        q_src, kv_src = q_src.contiguous(), kv_src.contiguous()
+        def usable(t):     # the kernels take batch / row strides: a column block of a wider projection is read in place
+            return t.dtype == torch.float32 and t.stride(-1) == 1 and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 \
+                and t.data_ptr() % 16 == 0
+        q_src = q_src if usable(q_src) else q_src.contiguous()
+        kv_src = q_src if same else (kv_src if usable(kv_src) else kv_src.contiguous())
         qc, kc, vc = cols
         B, Sq = q_src.shape[:2]
         Sk = kv_src.shape[1]
@@ -333,12 +337,13 @@ class _Attention(torch.autograd.Function):
         # other layers in a shared context projection) need the zero fill
         def covered(width, blocks):
             return sorted(blocks) == list(range(0, width, H)) and width % H == 0
+        cf = dict(memory_format=torch.contiguous_format)     # (the sources may be strided column blocks: dense gradients)
         if ctx.same:
-            dq_src = (torch.empty_like if covered(q_src.shape[-1], [qc, kc, vc]) else torch.zeros_like)(q_src)
+            dq_src = (torch.empty_like if covered(q_src.shape[-1], [qc, kc, vc]) else torch.zeros_like)(q_src, **cf)
             dkv_src = dq_src
         else:
-            dq_src = (torch.empty_like if covered(q_src.shape[-1], [qc]) else torch.zeros_like)(q_src)
-            dkv_src = (torch.empty_like if covered(kv_src.shape[-1], [kc, vc]) else torch.zeros_like)(kv_src)
+            dq_src = (torch.empty_like if covered(q_src.shape[-1], [qc]) else torch.zeros_like)(q_src, **cf)
+            dkv_src = (torch.empty_like if covered(kv_src.shape[-1], [kc, vc]) else torch.zeros_like)(kv_src, **cf)
         delta = torch.empty_like(lse)
         q, k, v = q_src[..., qc:qc + H], kv_src[..., kc:kc + H], kv_src[..., vc:vc + H]
         dq, dk, dv = dq_src[..., qc:qc + H], dkv_src[..., kc:kc + H], dkv_src[..., vc:vc + H]
