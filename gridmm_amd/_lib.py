@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -73,6 +73,8 @@ SIGNATURES = {
     "gridmm_fuse_logits_bwd": [_vp] * 16 + [_i, _i, _i, _vp],
     "gridmm_cells_compact_bwd": [_vp, _i64, _vp, _vp, _i, _i, _vp],
     "gridmm_dropout": [_vp, _vp, _i64, _f, ctypes.c_uint64, _vp, _vp],
+    "gridmm_layernorm_dropout": [_vp, _vp, _i, _vp, _vp, _f, _vp, _f, ctypes.c_uint64, _vp, _i, _i, _vp],
+    "gridmm_layernorm_dropout_bwd": [_vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, ctypes.c_uint64, _vp, _i, _i, _vp],
     "gridmm_grad_sumsq": [_vp, _i64, _i, _vp, _vp],
     "gridmm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _vp, _vp],
     "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -240,8 +240,53 @@ class _LayerNorm(torch.autograd.Function):
         return dx, (dx if ctx.has_res else None), dg, db, None
 
 
-def layer_norm(x, mod, residual=None):
-    """mod: nn.LayerNorm-like (weight, bias, eps).  LN(x (+ residual))."""
+class _LayerNormDropout(torch.autograd.Function):
+    """LN(dropout(x) + residual) in one launch each way (gridmm_layernorm_dropout / _bwd): the hidden-state dropout of
+    BertSelfOutput / BertOutput rides on the LayerNorm kernels; same mask as gridmm_dropout on the contiguous tensor."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps, p):
+        ctx.set_materialize_grads(False)
+        lib = _lib.load()
+        H = x.shape[-1]
+        x2 = x.float().contiguous()
+        r2 = None if residual is None else ops.uniform_rows(residual.float())
+        M = x2.numel() // H
+        seed = hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item()))
+        seed_dev = SEED_DEV if hs.MODE is not None else None          # captured steps: the per-replay seed word
+        y = torch.empty_like(x2)
+        _lib.check(lib.gridmm_layernorm_dropout(_p(x2), _p(r2), _rows2d(r2)[2] if r2 is not None else 0, _p(gamma.detach()),
+                                                _p(beta.detach()), float(eps), _p(y), float(p), seed, _p(seed_dev), M, H,
+                                                _stream()), "gridmm_layernorm_dropout")
+        ctx.save_for_backward(x2, r2, gamma)
+        ctx.eps, ctx.has_res, ctx.p, ctx.seed, ctx.seed_dev = eps, residual is not None, float(p), seed, seed_dev
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 6
+        lib = _lib.load()
+        x2, r2, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        H = x2.shape[-1]
+        M = x2.numel() // H
+        dx = torch.empty_like(x2)
+        dr = torch.empty_like(x2) if ctx.has_res else None
+        dg = torch.empty(H, dtype=torch.float32, device=dy.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty((M + 3) // 4 * 2 * H, dtype=torch.float32, device=dy.device)
+        _lib.check(lib.gridmm_layernorm_dropout_bwd(_p(x2), _p(r2), _rows2d(r2)[2] if r2 is not None else 0,
+                                                    _p(gamma.detach()), float(ctx.eps), _p(dy), _p(dx), _p(dr), _p(dg), _p(db),
+                                                    _p(ws), ctx.p, ctx.seed, _p(ctx.seed_dev), M, H, _stream()),
+                   "gridmm_layernorm_dropout_bwd")
+        return dx, dr, dg, db, None, None
+
+
+def layer_norm(x, mod, residual=None, dropout_p=0.0):
+    """mod: nn.LayerNorm-like (weight, bias, eps).  LN(x (+ residual)); dropout_p > 0: LN(dropout(x) (+ residual))."""
+    if dropout_p > 0 and x.is_cuda and x.shape[-1] % 4 == 0:
+        return _LayerNormDropout.apply(x, residual, mod.weight, mod.bias, mod.eps, float(dropout_p))
     return _LayerNorm.apply(x, residual, mod.weight, mod.bias, mod.eps)
 
 

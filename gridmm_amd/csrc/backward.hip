@@ -93,11 +93,15 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
 // LayerNorm backward, one wave per row.  y = (x - mean) * rstd * gamma + beta,  x = X (+ R)
 //   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 //   dgamma / dbeta: per-workgroup partial sums -> part[blockIdx][2][H], reduced by ln_param_reduce_kernel.
-template <int NV>
+// DROP (gridmm_layernorm_dropout_bwd): the forward normalised dropout(X) + R; the mask is regenerated here, the residual
+// branch receives the plain gradient (dR) and X's branch the masked, rescaled one (dX) -- the backward of the dropout
+// costs one extra store instead of a launch and a pass.
+template <int NV, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ R, int ldr, const float* __restrict__ gamma,
     float eps, const float* __restrict__ dY, int ldy, float* __restrict__ dX, int lddx, float* __restrict__ part,
-    int M, int H) {
+    int M, int H, float* __restrict__ dR = nullptr, int lddr = 0, float drop_p = 0.f, unsigned long long seed = 0,
+    const unsigned long long* __restrict__ seed_dev = nullptr) {
   __shared__ float s_g[4][MAX_H_BWD];
   __shared__ float s_b[4][MAX_H_BWD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,12 +110,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   float4 xv[NV], gv[NV], dv[NV];
   const bool live = row < M;
   float s = 0.f;
+  float scale = 1.f;
+  if constexpr (DROP) {
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
+    scale = 1.0f / (1.0f - drop_p);
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live && c < nv) {
       x = reinterpret_cast<const float4*>(X + (size_t)row * ldx)[c];
+      if constexpr (DROP) {
+        const unsigned int e = (unsigned int)row * (unsigned int)H + 4u * (unsigned int)c;
+        x.x = dropout_keep(seed, e, drop_p) ? __fmul_rn(x.x, scale) : 0.f;
+        x.y = dropout_keep(seed, e + 1, drop_p) ? __fmul_rn(x.y, scale) : 0.f;
+        x.z = dropout_keep(seed, e + 2, drop_p) ? __fmul_rn(x.z, scale) : 0.f;
+        x.w = dropout_keep(seed, e + 3, drop_p) ? __fmul_rn(x.w, scale) : 0.f;
+      }
       if (R) {
         const float4 r = reinterpret_cast<const float4*>(R + (size_t)row * ldr)[c];
         x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
@@ -157,6 +173,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         o.y = rstd * (gv[i].y - mg - xv[i].y * mgx);
         o.z = rstd * (gv[i].z - mg - xv[i].z * mgx);
         o.w = rstd * (gv[i].w - mg - xv[i].w * mgx);
+        if constexpr (DROP) {
+          if (dR) reinterpret_cast<float4*>(dR + (size_t)row * lddr)[c] = o;
+          const unsigned int e = (unsigned int)row * (unsigned int)H + 4u * (unsigned int)c;
+          o.x = dropout_keep(seed, e, drop_p) ? o.x * scale : 0.f;
+          o.y = dropout_keep(seed, e + 1, drop_p) ? o.y * scale : 0.f;
+          o.z = dropout_keep(seed, e + 2, drop_p) ? o.z * scale : 0.f;
+          o.w = dropout_keep(seed, e + 3, drop_p) ? o.w * scale : 0.f;
+        }
         reinterpret_cast<float4*>(dX + (size_t)row * lddx)[c] = o;
       }
       // per-wave contributions to dgamma (dy * xhat) and dbeta (dy)
@@ -239,6 +263,28 @@ extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void*
     GRIDMM_LAUNCH(colsum_reduce_kernel, dim3((C + 255) / 256), block, 0, st, colsum_ws, colsum, (int)grid.y, C);
     GRIDMM_CHECK_LAUNCH();
   }
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int ldr, const float* gamma, float eps,
+                                            const float* dY, float* dX, float* dR, float* dgamma, float* dbeta,
+                                            float* workspace, float p, unsigned long long seed,
+                                            const unsigned long long* seed_dev, int M, int H, gridmm_stream_t stream) {
+  if (M <= 0 || H <= 0 || H % 4 || H > MAX_H_BWD || (R && ldr % 4) || !(p >= 0.f && p < 1.f) ||
+      (size_t)M * H >= (1ull << 32))
+    return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nblk = (M + 3) / 4;
+  dim3 grid(nblk), block(256);
+  const int nv = (H / 4 + 63) / 64;
+#define GRIDMM_LNBD(NV)                                                                                          \
+  GRIDMM_LAUNCH((layernorm_bwd_kernel<NV, true>), grid, block, 0, st, X, H, R, ldr, gamma, eps, dY, H, dX, H, workspace, \
+                M, H, dR, H, p, seed, seed_dev)
+  if (nv == 1) GRIDMM_LNBD(1); else if (nv == 2) GRIDMM_LNBD(2); else if (nv == 3) GRIDMM_LNBD(3); else GRIDMM_LNBD(4);
+#undef GRIDMM_LNBD
+  GRIDMM_CHECK_LAUNCH();
+  GRIDMM_LAUNCH(ln_param_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, workspace, dgamma, dbeta, nblk, H);
+  GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
 

@@ -12,13 +12,17 @@ constexpr int MAX_H = 1024;  // hidden sizes on this path: 768
 // together -- with guards the compiler emits one branch + one s_waitcnt per chunk and operand, i.e. ~10 serialised memory
 // round trips per row, which is what a 1824-row launch (456 workgroups, one round) costs; gamma / beta / add1 / table rows
 // are fetched BEFORE the two wave reductions so that they fly under them.
-template <int NV, bool FULL>
+// DROP (training, gridmm_layernorm_dropout): X is the output of a dense layer whose hidden-state dropout is applied HERE,
+// on load -- keep(seed, row * H + col) ? x / (1 - p) : 0, the mask of gridmm_dropout on the contiguous (M, H) tensor --
+// so LN(dropout(X) + R) costs no launch and no pass of its own (BertSelfOutput / BertOutput, vilmodel.py:160-170, 199-211).
+template <int NV, bool FULL, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ R, int ldr,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float* __restrict__ Y, int ldy, const float* __restrict__ add1, int ld1,
     const float* __restrict__ table, const int64_t* __restrict__ idx, unsigned short* __restrict__ Yhi,
-    unsigned short* __restrict__ Ylo, int ldp, int p_rpb, long p_bs, int M, int H) {
+    unsigned short* __restrict__ Ylo, int ldp, int p_rpb, long p_bs, int M, int H, float drop_p = 0.f,
+    unsigned long long seed = 0, const unsigned long long* __restrict__ seed_dev = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -31,6 +35,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   const float4* xr = reinterpret_cast<const float4*>(X + (size_t)row * ldx);
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = ok(i) ? xr[lane + i * 64] : zero4;
+  if constexpr (DROP) {
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
+    const float scale = 1.0f / (1.0f - drop_p);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const unsigned int e = (unsigned int)row * (unsigned int)H + 4u * (unsigned int)(lane + i * 64);
+      v[i].x = dropout_keep(seed, e, drop_p) ? __fmul_rn(v[i].x, scale) : 0.f;
+      v[i].y = dropout_keep(seed, e + 1, drop_p) ? __fmul_rn(v[i].y, scale) : 0.f;
+      v[i].z = dropout_keep(seed, e + 2, drop_p) ? __fmul_rn(v[i].z, scale) : 0.f;
+      v[i].w = dropout_keep(seed, e + 3, drop_p) ? __fmul_rn(v[i].w, scale) : 0.f;
+    }
+  }
   if (R) {
     const float4* rr = reinterpret_cast<const float4*>(R + (size_t)row * ldr);
     float4 r[NV];
@@ -318,6 +334,26 @@ extern "C" int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr
                                 int ldp, int M, int H, gridmm_stream_t stream) {
   return gridmm_layernorm_map(X, ldx, R, ldr, gamma, beta, eps, Y, ldy, add1, ld1, table, idx, Y_hi, Y_lo, ldp, 0, 0, M, H,
                               stream);
+}
+
+extern "C" int gridmm_layernorm_dropout(const float* X, const float* R, int ldr, const float* gamma, const float* beta,
+                                        float eps, float* Y, float p, unsigned long long seed,
+                                        const unsigned long long* seed_dev, int M, int H, gridmm_stream_t stream) {
+  if (M <= 0 || H <= 0 || H % 4 || H > MAX_H || !X || !Y || !(p >= 0.f && p < 1.f) || (R && ldr % 4) ||
+      (size_t)M * H >= (1ull << 32))
+    return GRIDMM_EINVAL;
+  dim3 grid((M + 3) / 4), block(256);
+  const int nv = (H / 4 + 63) / 64;
+  const bool full = (H % 256) == 0;
+#define GRIDMM_LND(NV, F)                                                                                             \
+  GRIDMM_LAUNCH((layernorm_kernel<NV, F, true>), grid, block, 0, as_stream(stream), X, H, R, ldr, gamma, beta, eps, Y, H, \
+                (const float*)nullptr, 0, (const float*)nullptr, (const int64_t*)nullptr, (unsigned short*)nullptr,  \
+                (unsigned short*)nullptr, 0, 0, 0L, M, H, p, seed, seed_dev)
+  if (full) { if (nv == 1) GRIDMM_LND(1, true); else if (nv == 2) GRIDMM_LND(2, true); else if (nv == 3) GRIDMM_LND(3, true); else GRIDMM_LND(4, true); }
+  else { if (nv == 1) GRIDMM_LND(1, false); else if (nv == 2) GRIDMM_LND(2, false); else if (nv == 3) GRIDMM_LND(3, false); else GRIDMM_LND(4, false); }
+#undef GRIDMM_LND
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
 }
 
 extern "C" int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const float* beta, float eps,

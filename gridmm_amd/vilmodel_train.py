@@ -28,6 +28,11 @@ def _drop(model, x, p=None):
     return ag.dropout(x, p) if (x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0) else F.dropout(x, p, True)
 
 
+def _hidden_p(model):
+    """hidden_dropout_prob in train() mode, for the LayerNorms that apply the dropout of the dense layer in front of them."""
+    return float(model.config.hidden_dropout_prob) if model.training else 0.0
+
+
 def _attn_p(model):
     """attention_probs_dropout_prob (vilmodel.py:112,334), active in train() only."""
     return float(model.config.attention_probs_dropout_prob) if model.training else 0.0
@@ -45,23 +50,23 @@ def self_attention_block(model, att, x, kmask):
     s = att.self
     qkv = _cat_linear(x, [s.query, s.key, s.value])
     ctx = ag.self_attention(qkv, kmask, model.heads, _attn_p(model))
-    h = _drop(model, ag.linear(ctx, att.output.dense.weight, att.output.dense.bias))
-    return ag.layer_norm(h, att.output.LayerNorm, residual=x)
+    h = ag.linear(ctx, att.output.dense.weight, att.output.dense.bias)
+    return ag.layer_norm(h, att.output.LayerNorm, residual=x, dropout_p=_hidden_p(model))
 
 
 def cross_attention_block(model, xatt, x, ctx_kv, ctx_mask, kv_col=0):
     """BertXAttention (:370-379); ctx_kv = [k | v] projections of the context (possibly several layers wide)."""
     q = ag.linear(x, xatt.att.query.weight, xatt.att.query.bias)
     c = ag.cross_attention(q, ctx_kv, ctx_mask, model.heads, kv_col=kv_col, dropout_p=_attn_p(model))
-    h = _drop(model, ag.linear(c, xatt.output.dense.weight, xatt.output.dense.bias))
-    return ag.layer_norm(h, xatt.output.LayerNorm, residual=x)
+    h = ag.linear(c, xatt.output.dense.weight, xatt.output.dense.bias)
+    return ag.layer_norm(h, xatt.output.LayerNorm, residual=x, dropout_p=_hidden_p(model))
 
 
 def ffn_block(model, inter, out, x):
     """BertIntermediate + BertOutput (:185-211)."""
     h = ag.gelu(ag.linear(x, inter.dense.weight, inter.dense.bias))
-    o = _drop(model, ag.linear(h, out.dense.weight, out.dense.bias))
-    return ag.layer_norm(o, out.LayerNorm, residual=x)
+    o = ag.linear(h, out.dense.weight, out.dense.bias)
+    return ag.layer_norm(o, out.LayerNorm, residual=x, dropout_p=_hidden_p(model))
 
 
 def bert_layer(model, layer, x, kmask):

@@ -402,6 +402,19 @@ int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int ldr, const
                          const float* dY, int ldy, float* dX, int lddx, float* dgamma, float* dbeta,
                          float* workspace, int M, int H, gridmm_stream_t stream);
 
+/* Training: y = LayerNorm(dropout(X) + R) and its backward, with the hidden-state dropout of BertSelfOutput / BertOutput
+ * (vilmodel.py:160-170, 199-211: dense -> dropout -> LayerNorm(. + input)) applied inside the LayerNorm kernels:
+ * keep(seed, row * H + col) ? x / (1 - p) : 0 -- the mask gridmm_dropout derives for the contiguous (M, H) tensor, so the
+ * fused form equals gridmm_dropout followed by gridmm_layernorm bit for bit.  X, Y, dY, dX, dR contiguous (M, H);
+ * dX = gradient of X (masked, rescaled), dR = gradient of R; workspace as gridmm_layernorm_bwd; seed_dev as gridmm_dropout. */
+int gridmm_layernorm_dropout(const float* X, const float* R, int ldr, const float* gamma, const float* beta, float eps,
+                             float* Y, float p, unsigned long long seed, const unsigned long long* seed_dev, int M, int H,
+                             gridmm_stream_t stream);
+int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int ldr, const float* gamma, float eps, const float* dY,
+                                 float* dX, float* dR, float* dgamma, float* dbeta, float* workspace, float p,
+                                 unsigned long long seed, const unsigned long long* seed_dev, int M, int H,
+                                 gridmm_stream_t stream);
+
 /* Elementwise activations for training.  mode 0: out = gelu(X) (erf form, vilmodel.py:37-43);
  * 1: out = dY * gelu'(X); 2: out = relu(X); 3: out = dY * (X > 0).  n % 4 == 0, contiguous. */
 int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, int mode, gridmm_stream_t stream);

@@ -105,3 +105,34 @@ def test_dropout_mask_is_the_documented_hash_and_the_backward_reuses_it():
     assert torch.allclose(x.grad, torch.where(keep, w / (1 - p), torch.zeros_like(w)), rtol=1e-6)
     y2 = ag.dropout(x, p)                                            # a new call draws a new seed
     assert not torch.equal(y2 != 0, y != 0)
+
+
+@pytest.mark.parametrize("M,H,res", [(57, 768, True), (1824, 768, True), (300, 768, False), (33, 64, True)])
+def test_layernorm_with_fused_dropout_equals_dropout_then_layernorm(M, H, res):
+    """gridmm_layernorm_dropout / _bwd (LN(dropout(x) + r) in one launch each way) against gridmm_dropout followed by
+    gridmm_layernorm and their backward kernels: the same seed gives the same mask, outputs and all four gradients are
+    bit-identical."""
+    from gridmm_amd import autograd as ag
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(M + H)
+    x0, r0 = torch.randn(2, M, H, generator=g), torch.randn(2, M, H, generator=g)
+    ln = torch.nn.LayerNorm(H, eps=1e-12).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(H, generator=g))
+        ln.bias.copy_(torch.randn(H, generator=g))
+    dy = torch.randn(2, M, H, generator=g).to(dev)
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(123)
+        x = x0.to(dev).requires_grad_()
+        r = r0.to(dev).requires_grad_() if res else None
+        ln.zero_grad(set_to_none=True)
+        if fused:
+            y = ag.layer_norm(x, ln, residual=r, dropout_p=0.1)
+        else:
+            y = ag.layer_norm(ag.dropout(x, 0.1), ln, residual=r)
+        y.backward(dy)
+        outs.append([y.detach().clone(), x.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()] + ([r.grad.clone()] if res else []))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    assert float((outs[0][1] == 0).float().mean()) > 0.05          # a real mask: ~10 % of x's gradient is dropped
