@@ -8,7 +8,8 @@ Workload = BASELINE.json configs[1]: B=32 episodes per GPU, slab 36 views x 196 
 points, memory depth t=1), L=80 instruction tokens, G=20 map nodes, 36 views + stop, full-size model
 (161 M-parameter architecture with text_proj/grid_proj at D_in=512), random-init weights, synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-execs itself under
+                                                            torch.distributed.run, one rank per device)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Episodes are independent: ranks shard the episode batch, no collective on the step path ("weak" scaling,
@@ -664,8 +665,36 @@ def torch_gpu_baseline(model, batch, mem, args):
                       % (args.batch, dt)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: re-exec under torch.distributed.run, one rank per
+    device -- what the reference's own scripts do (map_nav_src/scripts/run_r2r.sh:65, pretrain_src/run_r2r.sh:6-8:
+    torch.distributed.launch --nproc_per_node).  The parent only forwards the children's output (rank 0's JSON line)
+    and exit code; a one-rank line for --gpus N cannot be printed."""
+    import subprocess
+    share = bool(os.environ.get("GRIDMM_BENCH_SHARE_GPU"))
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        raise SystemExit("bench.py: --gpus %d but this node exposes %d device(s)" % (args.gpus, have))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -687,7 +716,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, "
+                         "or plainly as `python bench.py --gpus %d`, which starts the ranks itself)"
+                         % (args.gpus, world, args.gpus, args.gpus))
 
     model, batch, mem, eps, step, eager_step, geom = build_workload(args, dev)
     dt = time_steps(step, args.steps, args.warmup, dist)

@@ -287,6 +287,8 @@ def layer_norm(x, mod, residual=None, dropout_p=0.0):
     """mod: nn.LayerNorm-like (weight, bias, eps).  LN(x (+ residual)); dropout_p > 0: LN(dropout(x) (+ residual))."""
     if dropout_p > 0 and x.is_cuda and x.shape[-1] % 4 == 0:
         return _LayerNormDropout.apply(x, residual, mod.weight, mod.bias, mod.eps, float(dropout_p))
+    if dropout_p > 0:
+        x = dropout(x, dropout_p)          # widths the fused kernel does not take: same semantics in two launches
     return _LayerNorm.apply(x, residual, mod.weight, mod.bias, mod.eps)
 
 

@@ -17,6 +17,8 @@ on C + G rows).  The bucket of a step is predicted from the previous step's coun
 the back graph writes the true count, and a step whose count exceeded its bucket is redone on the right one (the front
 outputs are static buffers: nothing is re-projected).  Results equal the 196-row path (tests/test_hip_graph_step.py).
 """
+import os
+
 import torch
 
 from . import ops
@@ -181,8 +183,11 @@ class NavigationGraphs:
     one is dropped beyond `max_graphs`.
 
     The occupied-cell bucket comes from the grid memory's tracked count (GridMemoryBatch.cmax_hint) when available, else
-    from a read-back of this call's occupancy bytes.  Outputs are the graph's static tensors: consume (or clone) them
-    before the next call with the same key.  Same results as the eager call (tests/test_hip_graph_step.py)."""
+    from a read-back of this call's occupancy bytes (the hint is dropped by the memory whenever it is re-binned by a
+    route other than step(), so a stale count cannot pick a bucket that is too small; `check_cmax` / GRIDMM_CHECK_CMAX=1
+    additionally reads this call's own occupancy back and raises on a mismatch).  Outputs are the graph's static
+    tensors and all graphs share ONE memory pool: they are valid only until the next call with ANY key -- consume or
+    clone them before calling again.  Same results as the eager call (tests/test_hip_graph_step.py)."""
 
     @staticmethod
     def weights_token(model):
@@ -266,6 +271,7 @@ class NavigationGraphs:
         return (id(mem.slab), mem.slab._gridmm_epoch[0], int(mem.n_pts_host.sum()))
 
     _early = None
+    check_cmax = bool(int(os.environ.get("GRIDMM_CHECK_CMAX", "0")))
 
     @torch.no_grad()
     def __call__(self, batch):
@@ -279,6 +285,11 @@ class NavigationGraphs:
         if cmax is None:
             cmax = int(fr.occ.sum(1, dtype=torch.int32).max())
         c_pad = model.pick_bucket(cmax)
+        if self.check_cmax:
+            true = int(fr.occ.sum(1, dtype=torch.int32).max())
+            if true > c_pad:
+                raise RuntimeError("NavigationGraphs: cell bucket %d chosen from a tracked count of %d, but this call's "
+                                   "memory has %d occupied cells" % (c_pad, cmax, true))
         ins = self._inputs(batch)
         key = (tuple(fr.txt.f32.shape), batch["gmap_masks"].shape[1], batch["vp_masks"].shape[1], c_pad,
                tuple(sorted(ins)))
@@ -298,7 +309,7 @@ class NavigationGraphs:
 
 class PanoramaGraphs:
     """forward('panorama') (view-only form) replayed from one hipGraph per input shape (B, V): ~20 launches per call.
-    Static outputs: consume before the next call with the same shape."""
+    Static outputs in one shared pool: valid until the next call with ANY shape."""
 
     KEYS = ("view_img_fts", "loc_fts", "nav_types", "view_lens")
 

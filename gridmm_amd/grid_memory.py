@@ -119,6 +119,7 @@ class GridMemoryBatch:
     def set_pose(self, poses, headings, active=None):
         """poses: B x (x, y) python floats (viewpoint_info, env.py:286); headings: B python floats.
         Rounded to fp32 on the host exactly as NumPy does (env.py:118-120, 344-348)."""
+        self._cmax_event = None                   # a new pose re-bins the memory: the tracked cell count is stale
         if self._h2d_done is not None:
             self._h2d_done.synchronize()          # the previous step's async H2D has consumed the pinned buffers
         # whole-array writes into the pinned buffers; cos / sin stay libm scalars in double (math.cos, as the reference
@@ -143,15 +144,19 @@ class GridMemoryBatch:
 
     def stage_extra(self, nbytes):
         """(pinned host view, device view) of `nbytes` of the staging buffer's caller area: whatever the caller writes into
-        the host view before set_pose() / step() travels with the pose in the same copy."""
-        assert nbytes <= self.STAGE_EXTRA
-        o = self._stage_extra_off
-        self._stage_used = max(self._stage_used, o + nbytes)
+        the host view before set_pose() / step() travels with the pose in the same copy.  Regions are never reused: a
+        second claimant (another GraphedNavStep on this memory) gets the bytes behind the first one's."""
+        o = (self._stage_used + 15) // 16 * 16        # bump allocator: every caller gets its own region
+        if o + nbytes > self._stage_extra_off + self.STAGE_EXTRA:
+            raise ValueError("grid memory staging buffer: %d bytes requested, %d of %d already claimed"
+                             % (nbytes, o - self._stage_extra_off, self.STAGE_EXTRA))
+        self._stage_used = o + nbytes
         return self._stage_host[o:o + nbytes], self._stage_dev[o:o + nbytes]
 
     # ---- device half: kernel launches only (replayable from a hipGraph)
     def project_and_bin(self, depth):
         """depth (B, n_views*ppv) uint16 on the device.  Uses the pose/heading set by set_pose()."""
+        self._cmax_event = None                   # only step() re-records the count behind these launches (cmax_hint)
         ops.grid_project(depth, self.x_off, self.view_cos, self.view_sin, self.pose_d, self.n_pts, self.hist_x,
                          self.hist_y, self.hist_valid, self.bbox, self.half_len, self.pos_fts,
                          None if self._active is None else self.act_d,
@@ -211,7 +216,9 @@ class GridMemoryBatch:
     track_cmax = False
 
     def cmax_hint(self):
-        """Largest occupied-cell count over the batch after the last step(), or None when it was not tracked."""
+        """Largest occupied-cell count over the batch after the last step(), or None when it was not tracked -- or when
+        the memory has been re-binned since by another route (set_pose / project_and_bin / reset, a graph replay after
+        set_pose): the count then belongs to an older binning and callers must read the occupancy of their own call."""
         if self._cmax_event is None:
             return None
         self._cmax_event.synchronize()

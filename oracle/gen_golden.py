@@ -30,7 +30,7 @@ from . import gridmap_oracle as G
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gridmm_amd import synthetic as S  # noqa: E402  (input generators only)
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("GRIDMM_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 REDUCED = dict(num_l_layers=1, num_pano_layers=1, num_x_layers=1, intermediate_size=64, vocab_size=2000)
 
 
@@ -467,8 +467,7 @@ def gen_topo_map():
     step the pair distances, hop counts, routes from the current node, visited flags, position features and node
     embedding means -> tests/golden/topo_map.npz (pins gridmm_amd/graph_utils.TopoMap)."""
     R.install_shims()
-    if R.REF_NAV not in sys.path:
-        sys.path.insert(0, R.REF_NAV)
+    R.use_tree(R.REF_NAV)
     from models import graph_utils as G       # the reference's module
     inp = topo_walk_inputs()
     N, T = TOPO["max_nodes"], len(inp["walk"])
@@ -528,9 +527,7 @@ def optim_toy_grad(name, shape, step):
 def gen_optim():
     """pretrain_src/optim/adamw.py:56-112 + sched.py:17-30 + misc.py:12-37 driven as train_r2r.py:266-296 does
     (lr schedule -> clip_grad_norm_ -> step) -> tests/golden/optim_reduced.npz (pins gridmm_amd/optim.py + optim.hip)."""
-    pre = os.path.join(R.REF_ROOT, "pretrain_src")
-    if pre not in sys.path:
-        sys.path.insert(0, pre)
+    R.use_tree(R.REF_PRETRAIN)
     from optim.misc import build_optimizer          # the reference's modules
     from optim.sched import get_lr_sched
     o = OPTIM

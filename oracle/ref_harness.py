@@ -59,6 +59,32 @@ def install_shims():
                 sys.modules[name] = types.ModuleType(name)
 
 
+def use_tree(tree):
+    """Make `tree` (map_nav_src or pretrain_src) THE reference tree for top-level imports: both trees have a `utils`
+    package (and `models` / `model`, `optim`, `data`), so whichever was imported first would shadow the other's --
+    r2r/env.py:15 `from utils.data import ...` found pretrain_src/utils once an optimiser fixture had run in the same
+    process.  Puts `tree` first on sys.path, drops the other reference trees from it, and forgets every cached module
+    that was loaded from another reference tree (module objects already handed out keep working: they hold their own
+    references)."""
+    tree = os.path.abspath(tree)
+    root = os.path.abspath(REF_ROOT) + os.sep
+    sys.path[:] = [p for p in sys.path if not os.path.abspath(p or ".").startswith(root)]
+    sys.path.insert(0, tree)
+    for name, m in list(sys.modules.items()):
+        if name.startswith("_ref_") or name.startswith("vlnce_baselines"):
+            continue                       # the VLN-CE modules are imported under private package names
+        where = getattr(m, "__file__", None)
+        if where is None:
+            try:
+                where = (list(getattr(m, "__path__", [])) or [None])[0]   # namespace packages (no __init__.py)
+            except Exception:
+                where = None
+        if where and os.path.abspath(where).startswith(root) and not os.path.abspath(where).startswith(tree + os.sep):
+            del sys.modules[name]
+    import importlib
+    importlib.invalidate_caches()
+
+
 _VIL = None
 _ENV = None
 
@@ -69,8 +95,7 @@ def import_vilmodel():
     if _VIL is not None:
         return _VIL
     install_shims()
-    if REF_NAV not in sys.path:
-        sys.path.insert(0, REF_NAV)
+    use_tree(REF_NAV)
     from models import vilmodel  # noqa: the reference's module
 
     # transformers 5.x: init_weights()/post_init() are incompatible with this class.
@@ -85,8 +110,7 @@ def import_env():
     if _ENV is not None:
         return _ENV
     install_shims()
-    if REF_NAV not in sys.path:
-        sys.path.insert(0, REF_NAV)
+    use_tree(REF_NAV)
     from r2r import env  # noqa
 
     _ENV = env
@@ -172,8 +196,7 @@ def import_pretrain():
     if _PRE is not None:
         return _PRE
     install_shims()
-    if REF_PRETRAIN not in sys.path:
-        sys.path.insert(0, REF_PRETRAIN)
+    use_tree(REF_PRETRAIN)
     from model import pretrain_cmt, vilmodel as pvil  # noqa: the reference's modules
 
     pvil.BertPreTrainedModel.init_weights = lambda self: None

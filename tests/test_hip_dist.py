@@ -128,6 +128,22 @@ def test_bench_two_ranks_on_one_gpu_prints_n_gpus_2():
     assert d["replay_check"]["replay_vs_eager_max_abs"] <= 1e-6
 
 
+def test_bench_plain_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver's N = 1 command line reads with another N): the
+    script re-execs itself under torch.distributed.run and prints ONE line with n_gpus = 2 -- never a one-rank line."""
+    env = dict(os.environ, GRIDMM_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--no-roofline", "--no-depth-legs", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-train-leg", "--no-producer-leg"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["value"] > 0
+
+
 def test_bench_train_leg_two_ranks_exchanges_gradients():
     """The multi-rank training leg of bench.py (config 3's measuring path): both ranks on this GPU (gloo), every rank runs the
     full-size pre-training step, GradientReducer exchanges the gradients (direct reduce-scatter / all-gather form), the

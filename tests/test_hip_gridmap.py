@@ -153,3 +153,38 @@ def test_sliced_rebin_is_identical_to_the_single_workgroup_sort(slices):
         assert torch.equal(c0[b, :k], c1[b, :k]) and torch.equal(p0[b, :k], p1[b, :k])
         assert sorted(p1[b, :k].tolist()) == list(range(k))                      # a permutation
         assert (p1[b, k:] == -1).all() and (c1[b, k:] == -7).all()               # nothing written past the history
+
+
+def test_tracked_cell_count_is_dropped_when_the_memory_is_rebinned_by_another_route():
+    """GridMemoryBatch.cmax_hint() feeds the varlen bucket choice of NavigationGraphs / the eager varlen path: a count
+    recorded by step() must not survive a re-binning that did not go through step() (set_pose + project_and_bin, a graph
+    replay after set_pose, reset) -- a stale count that is too small would silently drop occupied cells."""
+    from gridmm_amd import synthetic as S
+    rs = np.random.RandomState(3)
+    mem = _mem(2, S.NATIVE, 3)
+    mem.track_cmax = True
+    obs = [S.make_observations(rs, S.NATIVE, 2, with_feats=True) for _ in range(2)]
+    d0 = np.stack([o[0]["depth"].reshape(-1) for o in obs])
+    f0 = np.stack([o[0]["feats"] for o in obs])
+    mem.step(d0, f0, [(o[0]["x"], o[0]["y"]) for o in obs], [o[0]["heading"] for o in obs])
+    cs = mem.cell_start[:, :197]
+    assert mem.cmax_hint() == int((cs[:, 1:] > cs[:, :-1]).sum(1).max())
+    mem.set_pose([(o[1]["x"], o[1]["y"]) for o in obs], [o[1]["heading"] for o in obs])
+    assert mem.cmax_hint() is None
+    mem.step(d0, f0, [(o[1]["x"], o[1]["y"]) for o in obs], [o[1]["heading"] for o in obs])
+    assert mem.cmax_hint() is not None
+    mem.project_and_bin(torch.from_numpy(d0.astype(np.int32)).to(torch.uint16).cuda().reshape(2, -1))
+    assert mem.cmax_hint() is None
+    mem.reset()
+    assert mem.cmax_hint() is None
+
+
+def test_stage_extra_hands_out_disjoint_regions():
+    from gridmm_amd import synthetic as S
+    mem = _mem(2, S.NATIVE, 1)
+    h0, d0 = mem.stage_extra(100)
+    h1, d1 = mem.stage_extra(40)
+    assert h0.data_ptr() + 100 <= h1.data_ptr() and d0.data_ptr() + 100 <= d1.data_ptr()
+    assert h1.data_ptr() % 16 == 0
+    with pytest.raises(ValueError):
+        mem.stage_extra(mem.STAGE_EXTRA)

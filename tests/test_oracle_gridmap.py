@@ -100,3 +100,25 @@ def test_vlnce_twin_bit_exact_vs_reference_golden():
             assert np.array_equal(gm.astype(np.int16), fx[p + "grid_map"]), (name, t)
             assert np.array_equal(pos, fx[p + "pos_fts"]), (name, t)
     assert (fx["rxr_t0_grid_map"] == -1).all()
+
+
+@pytest.mark.reference
+def test_pin_regenerates_across_reference_trees_in_one_process(has_reference, tmp_path):
+    """The documented one-shot regeneration (`python -m oracle.gen_golden`) walks generators that import map_nav_src AND
+    pretrain_src, whose top-level packages clash (`utils`, `optim`, `models` / `model`): optim (pretrain_src) -> fill
+    (map_nav_src/r2r/env.py:15 `from utils.data import ...`) -> topo in ONE process must work and reproduce the committed
+    fixtures bit for bit (oracle.ref_harness.use_tree)."""
+    if not has_reference:
+        pytest.skip("no /root/reference on this box")
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRIDMM_GOLDEN_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "oracle.gen_golden", "optim", "fill", "topo"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from compare_golden import compare
+    assert sorted(os.listdir(tmp_path)) == ["fill_gridmap_native.npz", "optim_reduced.npz", "topo_map.npz"]
+    assert compare(str(tmp_path)) == 0
