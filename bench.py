@@ -410,40 +410,63 @@ def train_leg(args, dev, steps=None, emit=None):
     """One pre-training step (config 3's per-GPU shape) -- forward + backward + [gradient exchange] + gradient clip + fused
     AdamW of the full-size GlocalTextPathCMTPreTraining, B = 32 per rank, native grid memory of 3-5 observations, tasks
     cycling mlm / mrc / sap as the task-mixed loop does (pretrain_src/train_r2r.py:231-303).  Timed launched eagerly from
-    Python and as one hipGraph per task (gridmm_amd/train_graph.py: same kernels, same updates; lr schedule, AdamW bias
-    correction and dropout seeds advance per replay).  With WORLD_SIZE > 1 every rank trains its own batch and
+    Python and from hipGraphs (gridmm_amd/train_graph.py: same kernels, same updates; lr schedule, AdamW bias correction
+    and dropout seeds advance per replay).  With WORLD_SIZE > 1 every rank trains its own batch and
     gridmm_amd.dist.GradientReducer exchanges the gradients (the DDP all-reduce of pretrain_src/utils/misc.py:52-65):
-    eager = exchange launched from the backward hooks (overlapped), graph = captured forward + backward, eager exchange,
-    eager update; value = whole-job samples/s (max-over-ranks time)."""
+    eager = buckets launched from the backward hooks; graph = forward graph + one graph per backward segment, complete
+    buckets launched on the side stream between segment launches, eager clip + AdamW.  Both are also timed WITHOUT the
+    exchange (exposed_ms_* = the difference) and the graph step is timed once per exchange algorithm; value = whole-job
+    samples/s (max-over-ranks time)."""
     from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
     from gridmm_amd.pretrain_loop import PreTrainer, default_opts
     from gridmm_amd.synthetic import batch_to, make_pretrain_batch
     from gridmm_amd.train_graph import GraphedTrainStep
     from gridmm_amd.vilmodel import default_config
     dist, rank, world = _init_dist(dev)
+    share = bool(os.environ.get("GRIDMM_BENCH_SHARE_GPU"))
     steps = steps or int(os.environ.get("GRIDMM_BENCH_TRAIN_STEPS", "6"))
     cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=["mlm", "mrc", "sap"], image_prob_size=1000, obj_prob_size=0)
     torch.manual_seed(0)
     model = GlocalTextPathCMTPreTraining(cfg).to(dev)
-    # the timed step uses the plain ring all_reduce unless told otherwise (the one collective every RCCL build runs); the
-    # sweep after it times reduce-scatter + all-gather and the direct all-to-all form on the same buckets
+    # The first pass uses the ring all_reduce (the one collective every RCCL build runs) so that a number exists whatever
+    # happens next; the captured step is then re-timed with the direct reduce-scatter / all-gather (all_to_all_single: every
+    # xGMI link at once), its bf16 payload and reduce_scatter + all_gather, and the headline keys are those of the fastest
+    # fp32 algorithm.  A collective that raises is recorded and ends the sweep.
     rkw = dict(algo=os.environ.get("GRIDMM_EXCHANGE_ALGO", "ring"), payload=os.environ.get("GRIDMM_EXCHANGE_PAYLOAD", "fp32"))
     tr = PreTrainer(model, default_opts(warmup_steps=100), reducer_kw=rkw)
     tasks = ("mlm", "mrc", "sap")
     batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i + 10 * rank), args.batch, t, max_steps=5, L=80, vocab=30000,
                                                image_prob_size=1000, n_pts=(588 * 3, 588 * 5)), dev)
                for i, t in enumerate(tasks)}
-    for _ in range(2):                       # first sight of each task agrees on its used-set; the second launches early
+    fallback = None
+    try:
+        for t in tasks:                      # first sight of each task agrees on its used-set ...
+            tr.train_step(batches[t], t)
+    except Exception as e:                   # (a collective this RCCL build rejects fails on every rank alike)
+        if world == 1 or tr.reducer.algo == "ring":
+            raise
+        fallback = "%s failed (%s): ring all_reduce instead" % (tr.reducer.algo, repr(e)[:200])
+        tr.reducer.algo = "ring"
+        tr.optimizer.zero_grad()
         for t in tasks:
             tr.train_step(batches[t], t)
+    for t in tasks:                          # ... the second launches its buckets from inside backward
+        tr.train_step(batches[t], t)
+
+    def resync():
+        """After a timing loop without the exchange the ranks have drifted apart: rank 0's weights and AdamW moments again."""
+        if world > 1:
+            from gridmm_amd.dist import broadcast_parameters
+            broadcast_parameters(model.parameters())
+            st = [v for p in model.parameters() for k, v in sorted(tr.optimizer.state.get(p, {}).items()) if torch.is_tensor(v)]
+            broadcast_parameters(st)
     dt_eager = _timed_loop(lambda i: tr.train_step(batches[tasks[i % 3]], tasks[i % 3]), steps, dist)
     dt_noex = None
     if world > 1:
         tr.exchange = False                  # the same step without the exchange (ranks drift apart: timing only)
         dt_noex = _timed_loop(lambda i: tr.train_step(batches[tasks[i % 3]], tasks[i % 3]), steps, dist)
         tr.exchange = True
-        from gridmm_amd.dist import broadcast_parameters
-        broadcast_parameters(model.parameters())
+        resync()
     graphs = {t: GraphedTrainStep(tr, batches[t], t) for t in tasks}
     for t in tasks:
         graphs[t]()
@@ -453,36 +476,74 @@ def train_leg(args, dev, steps=None, emit=None):
     def gstep(i):
         last["losses"], _ = graphs[tasks[i % 3]]()
     dt = _timed_loop(gstep, n, dist)
+    seg_launches = list(getattr(graphs[tasks[0]], "launched_after_segment", []))
     finite = bool(torch.isfinite(last["losses"]).all())
     if not finite:
         raise SystemExit("bench.py: the captured training step produced non-finite losses")
-    best = min(dt, dt_eager)
-    res = {"train_samples_per_s": world * args.batch / best, "ms_per_step": 1e3 * best, "batch": args.batch, "n_gpus": world,
+    res = {"train_samples_per_s": world * args.batch / dt, "ms_per_step": 1e3 * dt, "batch": args.batch, "n_gpus": world,
            "global_batch": world * args.batch,
            "launch": ("hipGraph replay, one graph per task (train_graph.GraphedTrainStep)" if world == 1 else
-                      "best of: eager launches with the exchange overlapped from the backward hooks | hipGraph of forward + "
-                      "backward, then eager exchange + update"),
+                      "hipGraph replay: forward graph + %d backward-segment graphs per task, gradient buckets exchanged on a "
+                      "side stream between segment launches, eager clip + AdamW" % (len(graphs[tasks[0]].graphs) - 1)),
            "graph": {"train_samples_per_s": world * args.batch / dt, "ms_per_step": 1e3 * dt},
            "eager": {"train_samples_per_s": world * args.batch / dt_eager, "ms_per_step": 1e3 * dt_eager},
+           "best_samples_per_s": world * args.batch / min(dt, dt_eager),
            "workload": "pre-training step (mlm/mrc/sap cycling), full-size model, native 12x49x768 grid memory t=3..5, "
                        "fwd + bwd + clip + fused AdamW"}
     if world > 1:
+        tr.exchange = False
+        dt_graph_noex = _timed_loop(gstep, n, dist)
+        tr.exchange = True
+        resync()
         exposed = max(0.0, 1e3 * (dt_eager - dt_noex))
+        exposed_g = max(0.0, 1e3 * (dt - dt_graph_noex))
         res["exchange"] = {"world": world, "algo": tr.reducer.algo, "payload": tr.reducer.payload,
                            "buckets": len(tr.reducer.buckets),
                            "gradient_mb": sum(b["numel"] for b in tr.reducer.buckets) * 4 / 1e6,
                            "exposed_ms_eager": exposed, "ms_per_step_without_exchange": 1e3 * dt_noex,
+                           "exposed_ms_graph": exposed_g, "graph_ms_per_step_without_exchange": 1e3 * dt_graph_noex,
+                           "buckets_launched_after_segment": seg_launches,
                            "reducer_stats": dict(tr.reducer.stats),
-                           "backend": "gloo (ranks share one GPU: test hook)" if os.environ.get("GRIDMM_BENCH_SHARE_GPU") else "nccl (RCCL)"}
+                           "backend": "gloo (ranks share one GPU: test hook; blocking collectives on a helper thread)" if share else "nccl (RCCL)"}
+        if fallback:
+            res["exchange"]["fallback"] = fallback
         if emit is not None and rank == 0:
-            emit(res)                        # the step timings are out before the per-algorithm sweep starts
+            emit(res)                        # the step timings are out before anything else is tried
+        # the captured step once per exchange algorithm (the exchange is launched eagerly: no re-capture)
+        by_algo = {"%s_%s" % (tr.reducer.algo, tr.reducer.payload): 1e3 * dt}
+        keep = (tr.reducer.algo, tr.reducer.payload)
+        cands = [("ring", "fp32"), ("direct", "fp32")] + ([] if share else [("direct", "bf16"), ("rsag", "fp32")])
+        for algo, payload in cands:
+            key = "%s_%s" % (algo, payload)
+            if key in by_algo or (fallback and algo != "ring"):
+                continue
+            tr.reducer.algo, tr.reducer.payload = algo, payload
+            try:
+                gstep(0)
+                by_algo[key] = 1e3 * _timed_loop(gstep, max(1, n // 2), dist)
+            except Exception as e:
+                by_algo[key] = "failed: " + repr(e)[:160]
+                break                        # (a failed collective may leave the communicator unusable: stop here)
+        tr.reducer.algo, tr.reducer.payload = keep
+        timed = {k: v for k, v in by_algo.items() if isinstance(v, float)}
+        fastest = min(timed, key=timed.get)
+        f32 = {k: v for k, v in timed.items() if k.endswith("fp32")}
+        head = min(f32, key=f32.get)             # headline = the fastest exchange that keeps fp32 gradients on the wire
+        res["exchange"].update(graph_ms_per_step_by_algo=by_algo, fastest_graph_step=fastest, headline_algo=head,
+                               exposed_ms_graph_by_algo={k: max(0.0, v - 1e3 * dt_graph_noex) for k, v in timed.items()})
+        res.update(train_samples_per_s=world * args.batch / (1e-3 * f32[head]), ms_per_step=f32[head])
+        res["graph"] = {"train_samples_per_s": world * args.batch / (1e-3 * f32[head]), "ms_per_step": f32[head], "exchange": head}
+        res["best_samples_per_s"] = world * args.batch / min(dt_eager, 1e-3 * timed[fastest])
+        if emit is not None and rank == 0:
+            emit(res)
         del graphs
         sweep = exchange_sweep(tr.reducer, dev, dist, iters=max(1, min(5, steps)))
         alone = sweep.get("%s_%s" % (tr.reducer.algo, tr.reducer.payload))
-        timed = {k: v for k, v in sweep.items() if isinstance(v, float)}
-        res["exchange"].update(exchange_alone_ms=sweep, allreduce_ms=alone, fastest=min(timed, key=timed.get) if timed else None,
-                               overlapped_fraction_eager=(max(0.0, min(1.0, 1.0 - exposed / alone))
-                                                          if isinstance(alone, float) and alone > 0 else None))
+        res["exchange"].update(exchange_alone_ms=sweep, allreduce_ms=alone,
+                               fastest=min((k for k, v in sweep.items() if isinstance(v, float)), key=sweep.get, default=None))
+        if isinstance(alone, float) and alone > 0:
+            res["exchange"].update(overlapped_fraction_eager=max(0.0, min(1.0, 1.0 - exposed / alone)),
+                                   overlapped_fraction_graph=max(0.0, min(1.0, 1.0 - exposed_g / alone)))
     graphs = None
     del tr, model, batches
     torch.cuda.empty_cache()

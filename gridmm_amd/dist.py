@@ -59,6 +59,21 @@ def max_over_ranks(seconds, device=None):
     return float(t.item())
 
 
+_CTL = {}
+
+
+def control_group():
+    """One gloo group per process for the reducers' host-side control traffic (a collective call: every rank makes it at
+    the same point).  Separate from the data group even when that is gloo too: control all-reduces are issued from the main
+    thread while a helper thread may be inside a data collective (GradientReducer._launch), and gloo pairs collectives of
+    one group by call order."""
+    key = id(dist.group.WORLD)
+    if key not in _CTL:
+        _CTL.clear()
+        _CTL[key] = dist.new_group(backend="gloo")
+    return _CTL[key]
+
+
 class GradientReducer:
     """The one exchange of a training step: all-reduce(mean) of the parameter gradients across ranks.
 
@@ -90,9 +105,12 @@ class GradientReducer:
     World size 1 (or no process group): no-op.
     """
 
-    def __init__(self, params, bucket_mb=128, overlap=True, algo="auto", payload="fp32"):
+    def __init__(self, params, bucket_mb=128, overlap=True, algo="auto", payload="fp32", async_host="auto"):
         self.params = [p for p in params if p.requires_grad]
         self.overlap = overlap
+        self.async_host = async_host     # see _launch: gloo collectives on device buckets run on a helper thread
+        self._pool = None
+        self._capture_log = None         # a list while a hipGraph capture of the backward is running (begin_capture)
         self.world = dist.get_world_size() if is_dist() else 1
         backend = dist.get_backend() if is_dist() else None
         if algo == "auto":
@@ -103,7 +121,7 @@ class GradientReducer:
         self.algo, self.payload = algo, payload
         self._ctl = None
         if is_dist():                                    # control plane: CPU tensors over gloo (collective call: every rank builds a reducer)
-            self._ctl = dist.group.WORLD if backend == "gloo" else dist.new_group(backend="gloo")
+            self._ctl = control_group()
         limit = max(1, int(bucket_mb * (1 << 20) // 4))
         self.buckets, self.slot = [], {}                 # slot[i] = (bucket, offset)
         cur, n = [], 0
@@ -183,16 +201,76 @@ class GradientReducer:
             if not self._ready[i]:
                 self._view(i).zero_()
         flat = self._flat(b)
+        b["work"] = True
         if flat.is_cuda:
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=flat.device)
             self._comm.wait_stream(torch.cuda.current_stream(flat.device))
-            with torch.cuda.stream(self._comm):
-                self._exchange(flat, b)
+            if self._host_async():
+                # RCCL enqueues a collective and returns; gloo (CPU tests, and the "N ranks on one GPU" test hook) blocks
+                # the calling thread until the bytes have travelled.  To exercise the SAME overlap structure without RCCL
+                # the blocking calls run, in bucket order, on one helper thread: the main thread goes on launching backward.
+                if self._pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool = ThreadPoolExecutor(max_workers=1)
+                dev = flat.device
+
+                def job():
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(self._comm):
+                        self._exchange(flat, b)
+                b["work"] = self._pool.submit(job)
+            else:
+                with torch.cuda.stream(self._comm):
+                    self._exchange(flat, b)
         else:
             self._exchange(flat, b)
-        b["work"] = True
         self.stats["launched_early" if early else "launched_late"] += 1
+
+    def _host_async(self):
+        if self.async_host == "auto":
+            return is_dist() and dist.get_backend() == "gloo"
+        return bool(self.async_host)
+
+    def _join(self):
+        """Wait for the helper thread's exchanges (no-op on RCCL: there the calls were only enqueued)."""
+        for b in self.buckets:
+            w = b["work"]
+            if w is not None and w is not True:
+                w.result()
+                b["work"] = True
+
+    # ---- hipGraph capture of the backward (train_graph.GraphedTrainStep, several ranks)
+    def begin_capture(self):
+        """From here to end_capture() the hooks only move a finished gradient into its bucket slot (a kernel the capture
+        records; fp32 parameters keep the slot as their .grad) and log the parameter: no host bookkeeping, no collective.
+        take_capture_log() between graph segments tells which parameters each segment finished."""
+        for b in self.buckets:
+            self._flat(b)                                # allocated OUTSIDE the graph's memory pool
+        self._capture_log = []
+
+    def take_capture_log(self):
+        log, self._capture_log = self._capture_log, []
+        return log
+
+    def end_capture(self):
+        self._capture_log = None
+
+    def mark_ready(self, idx, grads=None):
+        """The replayed graph segment has (enqueued the kernels that) put the gradients of parameters `idx` into their bucket
+        slots: the host side of what the hooks do in an eager backward -- readiness bookkeeping, .grad pointing at the
+        slot, and the launch of every bucket that is now complete (in bucket order, on the side stream, behind the
+        segment just enqueued)."""
+        if not is_dist() or not self.enabled:
+            return
+        for i in idx:
+            p = self.params[i]
+            p.grad = self._view(i) if p.dtype == torch.float32 else (grads[i] if grads is not None else self._view(i).to(p.dtype))
+            self._ready[i] = True
+            if self._early:
+                self.buckets[self.slot[i][0]]["pending"].discard(i)
+        if self._early:
+            self._advance(True)
 
     def _advance(self, early=True):
         """Launch, strictly in bucket order, every bucket of the launch set whose locally expected gradients are all in."""
@@ -207,6 +285,13 @@ class GradientReducer:
 
     def _make_hook(self, i):
         def hook(p):
+            if self._capture_log is not None:            # a captured backward: the copy is a graph node, nothing else happens
+                v = self._view(i)
+                v.copy_(p.grad)
+                if p.dtype == torch.float32:
+                    p.grad = v
+                self._capture_log.append(i)
+                return
             if not is_dist() or not self.enabled:
                 return
             bi, _ = self.slot[i]
@@ -287,8 +372,10 @@ class GradientReducer:
             fix = torch.cat(parts)
             keep = (self.algo, self.payload)
             self.algo, self.payload = "ring", "fp32"
+            self._join()                                 # data collectives stay in one order: buckets first
             self._exchange(fix)
             self.algo, self.payload = keep
+        self._join()
         if self._comm is not None:
             torch.cuda.current_stream(self.params[0].device).wait_stream(self._comm)
         for b in self.buckets:

@@ -65,3 +65,38 @@ def select(x, mask):
         return x[mask]
     idx = host(lambda: mask.reshape(-1).nonzero().squeeze(1))
     return x.reshape((-1,) + tuple(x.shape[mask.dim():])).index_select(0, idx)
+
+
+# ---- backward segments (train_graph.GraphedTrainStep with several ranks) -------------------------------------------
+# A captured backward that should overlap its gradient exchange has to be cut into several graphs: bucket k's exchange can
+# only start once a graph that finishes its gradients has been launched.  The model marks natural separators of its
+# autograd graph with boundary(level, t); while CUTS is a list the marked tensor is replaced by a detached leaf, so that
+# the part of the graph above it and the part below it are separate autograd graphs; segmented_backward() then runs them
+# level by level, handing each leaf's accumulated gradient to the tensor it was cut from.  Level j tensors may only be
+# consumed by code whose own boundaries have a smaller level (or none): when level j starts, its leaves hold their full
+# gradient.  CUTS is None (the default): boundary() returns its argument, the backward is the usual single pass.
+CUTS = None
+
+
+def boundary(level, t):
+    if CUTS is None or not t.requires_grad:
+        return t
+    leaf = t.detach().requires_grad_()
+    CUTS.append((level, t, leaf))
+    return leaf
+
+
+def segmented_backward(loss, cuts, segment=None):
+    """loss.backward() in len(levels) + 1 passes.  segment: optional context-manager factory called with the segment
+    number around each pass (a hipGraph capture per segment).  Same gradients as the single pass up to the summation
+    order of tensors with several consumers."""
+    import torch
+    seg = segment or (lambda k: contextlib.nullcontext())
+    with seg(0):
+        loss.backward()
+    for k, lv in enumerate(sorted({c[0] for c in cuts}), 1):
+        roots = [(o, leaf.grad) for (L, o, leaf) in cuts if L == lv and leaf.grad is not None]
+        with seg(k):
+            if roots:
+                torch.autograd.backward([o for o, _ in roots], [g for _, g in roots])
+    return len({c[0] for c in cuts}) + 1

@@ -55,7 +55,9 @@ class GlocalTextPathCMT(nn.Module):
         b = self
         dev = batch["txt_ids"].device
         txt_masks = _seq_masks(batch["txt_lens"], batch["txt_ids"].shape[1])
-        txt_embeds = VT.forward_text(b, batch["txt_ids"].long(), txt_masks)
+        # (hs.boundary: separators of the autograd graph for the segmented backward of the captured multi-rank step --
+        # identity unless hostsync.CUTS is active)
+        txt_embeds = hs.boundary(VT.CUT_ENC, VT.forward_text(b, batch["txt_ids"].long(), txt_masks))
         cells, cell_masks = VT.grid_cells(b, txt_embeds, batch["grid_fts"], batch["grid_map"],
                                           batch["gridmap_pos_fts"], proj_weight=b.grid_proj.weight.float(),
                                           proj_bias=b.grid_proj.bias.float())
@@ -66,6 +68,7 @@ class GlocalTextPathCMT(nn.Module):
         traj, traj_masks = VT.forward_panorama(b, batch["traj_view_img_fts"], batch["traj_obj_img_fts"],
                                                batch["traj_loc_fts"], batch["traj_nav_types"].long(), only_view_lens,
                                                obj_lens)
+        traj = hs.boundary(VT.CUT_ENC, traj)
         step_lens = [int(x) for x in batch["traj_step_lens"]]
         view_lens = only_view_lens if obj_lens is None else only_view_lens + obj_lens      # traj_vp_lens (:512-516)
         Vmax, H = traj.shape[1], traj.shape[2]
@@ -134,6 +137,7 @@ class GlocalTextPathCMT(nn.Module):
             xa = layer.visual_attention
             kv = VT._cat_linear(txt_embeds, [xa.att.key, xa.att.value])
             map_embeds = VT.x_layer(b, layer, kv, txt_masks, map_embeds, map_masks)
+        map_embeds, vp_input = hs.boundary(VT.CUT_MAP, map_embeds), hs.boundary(VT.CUT_MAP, vp_input)
         return dict(txt_embeds=txt_embeds, txt_masks=txt_masks, map_embeds=map_embeds, map_masks=map_masks,
                     gmap_masks=gmap_masks, vp_input=vp_input, vp_masks=vp_masks, last=last, view_lens=view_lens,
                     last_view_lens=only_view_lens[last], last_obj_lens=None if obj_lens is None else obj_lens[last])

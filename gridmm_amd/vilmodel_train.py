@@ -21,6 +21,11 @@ from .grid_memory import pack_reference_lists
 N_CELLS = 196
 
 
+# hostsync.boundary levels (order in which the backward reaches them): 1 = the map / view-point streams entering the local
+# encoder, 2 = the outputs of the text and panorama encoders, 3.. = inside the text encoder
+CUT_MAP, CUT_ENC, CUT_TEXT = 1, 2, 2
+
+
 def _drop(model, x, p=None):
     p = model.config.hidden_dropout_prob if p is None else p
     if not (model.training and p > 0):
@@ -125,8 +130,15 @@ def text_embeddings(model, txt_ids):
 def forward_text(model, txt_ids, txt_masks):
     """:730-734."""
     x = text_embeddings(model, txt_ids)
-    for layer in model.lang_encoder.layer:
+    layers = model.lang_encoder.layer
+    n = len(layers)
+    for i, layer in enumerate(layers):
         x = bert_layer(model, layer, x, txt_masks)
+        if i + 1 < n and (n - 1 - i) % 3 == 0:
+            # backward segments of the captured multi-rank step (hostsync.boundary; identity otherwise): the text encoder
+            # holds a third of the parameters and is the LAST thing backward reaches -- cut every three layers so that its
+            # gradient buckets leave while the layers below are still in backward
+            x = hs.boundary(CUT_TEXT + (n - 1 - i) // 3, x)
     return x
 
 

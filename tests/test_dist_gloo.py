@@ -267,3 +267,108 @@ def test_gradient_reducer_mixed_usage_multi_step_world2(algo, payload):
                     err = (torch.from_numpy(got) - p.grad).abs().max().item()
                     assert err <= tol * max(1.0, p.grad.abs().max().item()), (step, k, err)
     assert res[0][1]["launched_early"] > 0 and res[1][1]["launched_early"] > 0      # overlap stayed on
+
+
+# ---- segmented backward + mark_ready: the host protocol of the captured multi-rank training step ---------------------
+class _Chain(torch.nn.Module):
+    """Three blocks with hostsync boundaries between them and a weight shared by the first and the last block (the MLM
+    decoder / word-embedding tie of the pre-training model): backward in three segments."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.tied = torch.nn.Parameter(torch.randn(6, 6, generator=g) * 0.3)
+        self.l1 = torch.nn.Linear(6, 6)
+        self.l2 = torch.nn.Linear(6, 6)
+        self.l3 = torch.nn.Linear(6, 3)
+        for p in (*self.l1.parameters(), *self.l2.parameters(), *self.l3.parameters()):
+            p.data = torch.randn(p.shape, generator=g) * 0.3
+
+    def forward(self, x):
+        from gridmm_amd import hostsync as hs
+        h0 = hs.boundary(2, torch.tanh(self.l1(x @ self.tied)))          # consumed by block 2 AND by the head below
+        h1 = hs.boundary(1, torch.tanh(self.l2(h0)))
+        return self.l3(h1 @ self.tied + h0)
+
+
+def _segment_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib
+    from gridmm_amd import dist as D, hostsync as hs
+    model = _Chain()
+    red = D.GradientReducer(model.parameters(), bucket_mb=1e-4)          # several buckets
+    g = torch.Generator().manual_seed(31)
+    outs, early = [], []
+    seg_final = None
+    for step in range(4):
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+        xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+        for p in model.parameters():
+            p.grad = None
+        red.expect("k")
+        if step == 0:                         # an ordinary eager step first: the key's used-set becomes known
+            torch.nn.functional.cross_entropy(model(xs), ys).backward()
+        else:
+            # what GraphedTrainStep does: backward in segments with the hooks in capture mode (copy into the slot + log),
+            # then -- per segment, as after each graph replay -- mark_ready() for the parameters that segment FINISHED
+            hs.CUTS = cuts = []
+            loss = torch.nn.functional.cross_entropy(model(xs), ys)
+            hs.CUTS = None
+            logs = []
+
+            @contextlib.contextmanager
+            def seg(k):
+                yield
+                logs.append(red.take_capture_log())
+            red.enabled = False
+            red.begin_capture()
+            n = hs.segmented_backward(loss, cuts, seg)
+            red.end_capture()
+            red.enabled = True
+            assert n == 3 and len(logs) == 3
+            last = {i: k for k, log in enumerate(logs) for i in log}
+            seg_final = [[i for i, kk in last.items() if kk == k] for k in range(n)]
+            for p in model.parameters():      # (a replay only runs kernels: the host sees no gradients until mark_ready)
+                p.grad = None
+            for k in range(n):
+                red.mark_ready(seg_final[k])
+                if k == 0:
+                    early.append(sum(b["work"] is not None for b in red.buckets))
+        red.reduce()
+        outs.append({k: (None if p.grad is None else p.grad.detach().numpy().copy()) for k, p in model.named_parameters()})
+    q.put((rank, outs, early, seg_final, dict(red.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_segmented_backward_feeds_the_reducer_like_an_eager_backward_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_segment_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: rest for r, *rest in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _Chain()
+    g = torch.Generator().manual_seed(31)
+    for step in range(4):
+        x, y = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+        for p in model.parameters():
+            p.grad = None
+        (0.5 * (torch.nn.functional.cross_entropy(model(x[:4]), y[:4]) +
+                torch.nn.functional.cross_entropy(model(x[4:]), y[4:]))).backward()
+        for k, p in model.named_parameters():
+            for r in range(world):
+                got = res[r][0][step][k]
+                assert got is not None and torch.allclose(torch.from_numpy(got), p.grad, atol=1e-6), (step, k)
+    names = [k for k, _ in model.named_parameters()]
+    for r in range(world):
+        outs, early, seg_final, stats = res[r]
+        final = {names[i]: k for k, idx in enumerate(seg_final) for i in idx}
+        assert final["tied"] == 2 and final["l3.weight"] == 0 and final["l2.weight"] == 1 and final["l1.weight"] == 2
+        assert all(e > 0 for e in early), early        # buckets left after the FIRST segment, before the others ran
+        assert stats["repairs"] == 0

@@ -14,10 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _run(case, env_extra):
     env = dict(os.environ, **env_extra)
     return subprocess.run([sys.executable, os.path.join(HERE, "train_graph_cases.py"), case], env=env,
-                          capture_output=True, text=True, timeout=600)
+                          capture_output=True, text=True, timeout=1200)
 
 
-@pytest.mark.parametrize("case", ["mlm", "mrc", "sap", "dropout", "two_graphs", "fp16_grid_proj", "full_size", "trajectory"])
+@pytest.mark.parametrize("case", ["mlm", "mrc", "sap", "dropout", "two_graphs", "fp16_grid_proj", "full_size", "trajectory",
+                                  "segments_sap", "segments_mlm", "dist2"])
 def test_graphed_training_step(case):
     r = _run(case, {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"})
     assert r.returncode == 0 and ("ok " + case) in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

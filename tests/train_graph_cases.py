@@ -15,13 +15,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 TASKS = ("mlm", "mrc", "sap")
 
 
-def _setup(drop, fp32_grid_proj=True):
+def _setup(drop, fp32_grid_proj=True, layers=2, seed_off=0):
     from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
     from gridmm_amd.synthetic import batch_to, make_pretrain_batch
     from gridmm_amd.vilmodel import default_config
     dev = torch.device("cuda")
     cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=list(TASKS), image_prob_size=1000, obj_prob_size=0,
-                         num_l_layers=2, num_pano_layers=1, num_x_layers=2, hidden_dropout_prob=drop,
+                         num_l_layers=layers, num_pano_layers=1, num_x_layers=2, hidden_dropout_prob=drop,
                          attention_probs_dropout_prob=drop)
     torch.manual_seed(0)
     model = GlocalTextPathCMTPreTraining(cfg).to(dev)
@@ -32,7 +32,7 @@ def _setup(drop, fp32_grid_proj=True):
         # identical runs (eager vs eager as much as graph vs eager; tools/dbg_determinism.py: 1e-4 ... 3e-3 after 5-8
         # steps, 1e-5 with an fp32 grid_proj).  Trajectory comparisons use fp32; case_fp16_grid_proj covers the fp16 path.
         model.bert.grid_proj.float()
-    batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i), 4, t, max_steps=3, L=40, vocab=30000,
+    batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i + seed_off), 4, t, max_steps=3, L=40, vocab=30000,
                                                image_prob_size=1000, n_pts=(588, 588 * 2)), dev)
                for i, t in enumerate(TASKS)}
     return model, batches
@@ -66,15 +66,17 @@ def _compare_step(ta, tb, eager, graphed, tag):
         assert d <= tol, (tag, n, d)
 
 
-def case_equals_eager(task):
+def case_equals_eager(task, segments=None, layers=2):
     from gridmm_amd.pretrain_loop import PreTrainer, default_opts
     from gridmm_amd.train_graph import GraphedTrainStep
-    model, batches = _setup(0.0)
+    model, batches = _setup(0.0, layers=layers)
     ma, mb = copy.deepcopy(model), copy.deepcopy(model)
     ta, tb = PreTrainer(ma, default_opts(warmup_steps=10)), PreTrainer(mb, default_opts(warmup_steps=10))
     for _ in range(2):                                   # what the graphed object runs while it is built: record + warm-up
         ta.train_step(batches[task], task)
-    g = GraphedTrainStep(tb, batches[task], task)
+    g = GraphedTrainStep(tb, batches[task], task, segments=segments)
+    if segments:
+        assert len(g.graphs) >= 4 and sum(len(x) for x in g.seg_final) == len(g.params), [len(x) for x in g.seg_final]
     assert tb.global_step == ta.global_step == 2
     for it in range(5):                                  # lr warm-up and AdamW bias correction advance with every replay
         _compare_step(ta, tb, lambda: ta.train_step(batches[task], task), g, (task, it))
@@ -83,6 +85,56 @@ def case_equals_eager(task):
     # gradient buffers must not be left in p.grad, where an eager backward would accumulate into them)
     _compare_step(ta, tb, lambda: ta.train_step(batches[task], task), lambda: tb.train_step(batches[task], task), (task, "eager"))
     _compare_step(ta, tb, lambda: ta.train_step(batches[task], task), g, (task, "again"))
+
+
+def _dist2_worker(rank, world, port):
+    """One rank of case_dist2 (both ranks on this box's one GPU, gloo): eager exchange-overlapped steps (trainer A) against
+    the segmented captured step (trainer B) -- same losses, norms and parameters, and buckets that leave BEFORE the last
+    backward segment has been launched."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.train_graph import GraphedTrainStep
+    model, batches = _setup(0.0, layers=5, seed_off=10 * rank)          # same weights (seed 0), different data per rank
+    ma, mb = copy.deepcopy(model), copy.deepcopy(model)
+    kw = dict(bucket_mb=8, algo="ring")
+    ta, tb = PreTrainer(ma, default_opts(warmup_steps=10), reducer_kw=kw), PreTrainer(mb, default_opts(warmup_steps=10), reducer_kw=kw)
+    assert len(tb.reducer.buckets) >= 4
+    for task in ("sap", "mlm"):
+        for _ in range(2):
+            ta.train_step(batches[task], task)
+        g = GraphedTrainStep(tb, batches[task], task)
+        assert g.segmented and len(g.graphs) >= 4
+        for it in range(4):
+            _compare_step(ta, tb, lambda: ta.train_step(batches[task], task), g, (task, it, rank))
+            assert g.launched_after_segment[-1] > 0, g.launched_after_segment
+            # overlap: at least one bucket was handed to the exchange while later segments were still to be launched
+            assert g.launched_after_segment[-2] > 0, g.launched_after_segment
+        # ranks agree after the exchange
+        flat = torch.cat([p.detach().float().reshape(-1) for p in mb.parameters()])
+        other = flat.clone()
+        dist.broadcast(other, 0)
+        assert torch.equal(flat, other)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def case_dist2():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dist2_worker, args=(r, 2, port)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0, p.exitcode
 
 
 def case_two_graphs():
@@ -197,6 +249,12 @@ if __name__ == "__main__":
         case_two_graphs()
     elif case == "trajectory":
         case_trajectory()
+    elif case.startswith("segments_"):
+        # the backward as one graph per autograd segment (the multi-rank form), single process: 5 text layers -> a cut
+        # inside the text encoder as well
+        case_equals_eager(case.split("_", 1)[1], segments=True, layers=5)
+    elif case == "dist2":
+        case_dist2()
     else:
         case_equals_eager(case)
     print("ok", case)
