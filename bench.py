@@ -554,12 +554,13 @@ def train_leg(args, dev, steps=None, emit=None):
 
 
 def train_leg_subprocess(args, world=1):
-    """The training leg in its own process: GraphedTrainStep needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in place before the
-    HIP runtime starts (gridmm_amd/train_graph.py), and the headline graph keeps the runtime's default.  With several
+    """The training leg in its own process (its 200 M-parameter model, graphs and pools are gone when it returns; a failure
+    in this secondary leg cannot take the headline line with it).  Default runtime settings: the captured step holds
+    kernel nodes only (gridmm_amd/train_graph.py).  With several
     ranks EVERY rank starts its child (same RANK / LOCAL_RANK / WORLD_SIZE, the next master port: the children form their
     own process group); rank 0's child prints the JSON."""
     import subprocess
-    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="0")
+    env = dict(os.environ)
     if world > 1:
         env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
         for k in [k for k in env if k.startswith("TORCHELASTIC_")]:

@@ -448,7 +448,7 @@ class _GridAggregate(torch.autograd.Function):
         # is append-only within a rollout (rows this step's perm refers to are never rewritten; a training rollout
         # gets a fresh slab, GridMemoryBatch.reset), so it is referenced, not copied -- and kept out of
         # save_for_backward, whose version check would trip on the later in-place appends.
-        ctx.save_for_backward(text_fts, perm.clone(), cell_start.clone(), rel)
+        ctx.save_for_backward(text_fts, kernel_copy(perm), kernel_copy(cell_start), rel)
         ctx.slab = slab
         # ... which makes "the slab rows are still the ones this step saw" OUR invariant to check: GridMemoryBatch tags
         # its slab with an epoch that advances whenever the rows are recycled in place (reset() of a memory that is not
@@ -519,6 +519,72 @@ class _Dropout(torch.autograd.Function):
         _lib.check(lib.gridmm_dropout(_p(dy), _p(dx), dy.numel(), ctx.p, ctx.seed, _p(ctx.seed_dev), _stream()),
                    "gridmm_dropout")
         return dx, None
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel-only forms of the few torch operations that become MEMCPY / MEMSET nodes when the step is captured
+# ------------------------------------------------------------------------------------------------
+# A captured training step must consist of kernel nodes only: the runtime's pre-recorded graph packets (ROCm 7.2 default)
+# mishandle copy / fill nodes in a large graph -- one queue slot of the replay keeps the packet of an EARLIER dispatch,
+# whose kernel arguments have been recycled by then (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION as soon as eager work
+# alternates with replays; DESIGN.md section 5, tools/dbg_train_graph_fault.py, tools/find_copy_nodes.py).  torch issues
+# such nodes for contiguous device-to-device copies (clone, select_backward), for the semaphores of a large `sum`
+# (the gradient of a broadcast add) and inside the sort-based embedding backward.
+def kernel_copy(x):
+    """x.clone() as an elementwise kernel (a contiguous same-dtype copy_ is a hipMemcpyAsync, i.e. a memcpy node)."""
+    if x.dtype.is_floating_point:
+        return x * 1
+    if x.dtype == torch.bool:
+        return x | False
+    return x + 0
+
+
+def _colsum(dy2d):
+    """(M, C) -> (C,) as a GEMM with a row of ones (torch's reduction zeroes its semaphores with a memset node)."""
+    return torch.mm(torch.ones(1, dy2d.shape[0], dtype=dy2d.dtype, device=dy2d.device), dy2d).view(-1)
+
+
+class _AddRow(torch.autograd.Function):
+    """x + table[row] broadcast over the leading dims of x (the token-type rows of BertEmbeddings / ImageEmbeddings:
+    map_nav_src/models/vilmodel.py:72-77, 486-490); backward: dx = dy, dtable[row] = column sums of dy."""
+
+    @staticmethod
+    def forward(ctx, x, table, row):
+        ctx.row, ctx.shape = int(row), table.shape
+        return x + table[int(row)]
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dt = torch.zeros(ctx.shape, dtype=dy.dtype, device=dy.device)
+        dt[ctx.row].add_(_colsum(dy.view(-1, dy.shape[-1])))
+        return dy, dt, None
+
+
+def add_row(x, table, row):
+    return _AddRow.apply(x, table, row)
+
+
+class _SmallEmbedding(torch.autograd.Function):
+    """table[idx] for a table of a few rows (nav_type_embedding: 3 rows); backward as onehot^T @ dy (deterministic, a
+    GEMM) instead of torch's sort-based embedding backward."""
+
+    @staticmethod
+    def forward(ctx, idx, table):
+        ctx.save_for_backward(idx)
+        ctx.n = table.shape[0]
+        return table.index_select(0, idx.reshape(-1)).view(*idx.shape, table.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, dy.shape[-1])
+        onehot = (idx.reshape(1, -1) == torch.arange(ctx.n, device=idx.device).view(-1, 1)).to(dy2.dtype)
+        return None, torch.mm(onehot, dy2)
+
+
+def small_embedding(idx, table):
+    return _SmallEmbedding.apply(idx, table)
 
 
 def dropout(x, p):

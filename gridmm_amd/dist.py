@@ -287,7 +287,11 @@ class GradientReducer:
         def hook(p):
             if self._capture_log is not None:            # a captured backward: the copy is a graph node, nothing else happens
                 v = self._view(i)
-                v.copy_(p.grad)
+                if p.grad.dtype == v.dtype and p.grad.is_contiguous():
+                    if p.grad.data_ptr() != v.data_ptr():
+                        torch.mul(p.grad, 1, out=v)      # a KERNEL node (copy_ here would be a memcpy node: train_graph.py)
+                else:
+                    v.copy_(p.grad)                      # dtype conversion: an elementwise kernel already
                 if p.dtype == torch.float32:
                     p.grad = v
                 self._capture_log.append(i)

@@ -24,6 +24,33 @@ import torch
 from . import ops
 
 
+NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "waitEvent", 7: "eventRecord"}
+
+
+def graph_node_types(g):
+    """{node type name: count} of a torch.cuda.CUDAGraph created with keep_graph=True (hipGraphGetNodes /
+    hipGraphNodeGetType through ctypes), or None when the runtime does not expose the raw graph."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        raw = ctypes.c_void_p(g.raw_cuda_graph())
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+            return None
+        arr = (ctypes.c_void_p * n.value)()
+        if hip.hipGraphGetNodes(raw, arr, ctypes.byref(n)) != 0:
+            return None
+        hist = {}
+        for node in arr:
+            ty = ctypes.c_int(-1)
+            hip.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(ty))
+            k = NODE_TYPES.get(ty.value, str(ty.value))
+            hist[k] = hist.get(k, 0) + 1
+        return hist
+    except Exception:
+        return None
+
+
 def count_graph_nodes(fn):
     """Kernel / copy nodes of `fn` captured as a hipGraph (a throw-away capture with keep_graph=True, hipGraphGetNodes through
     ctypes); None when the runtime does not expose the raw graph."""

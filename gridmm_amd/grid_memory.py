@@ -183,14 +183,14 @@ class GridMemoryBatch:
         act_host = np.ones(B, bool) if active is None else np.asarray(active, bool)
         if (self.n_pts_host[act_host] + n_new > self.cap).any():
             raise ValueError("grid memory capacity exceeded (max_steps=%d)" % self.max_steps)
-        depth = torch.as_tensor(depth).to(dev, non_blocking=True)
+        depth = _to_device(depth, dev)
         if self.geom.vlnce:
             depth = depth.to(torch.float32)                     # habitat depth, metres
         elif depth.dtype != torch.uint16:
             depth = depth.to(torch.int32).to(torch.uint16)
         depth = depth.reshape(B, n_new).contiguous()
         if feats is not None:
-            feats = torch.as_tensor(feats).to(dev, non_blocking=True).reshape(B, n_new, self.geom.feat_dim)
+            feats = _to_device(feats, dev).reshape(B, n_new, self.geom.feat_dim)
             if act_host.all() and (self.n_pts_host == self.n_pts_host[0]).all():
                 n0 = int(self.n_pts_host[0])
                 self.slab[:, n0:n0 + n_new].copy_(feats)
@@ -245,6 +245,14 @@ class GridMemoryBatch:
     def as_reference_obs(self):
         return ([self.grid_fts(b) for b in range(self.B)], [self.grid_map(b) for b in range(self.B)],
                 self.pos_fts)
+
+
+def _to_device(x, dev):
+    """Host -> device: asynchronous only from PINNED memory.  An asynchronous copy from pageable memory is not ordered
+    against the host on ROCm (the runtime may pin the source in place and copy it after the call has returned): a caller
+    that passes a temporary array would have it freed under the copy."""
+    t = torch.as_tensor(x)
+    return t.to(dev, non_blocking=bool(t.device.type == "cpu" and t.is_pinned()))
 
 
 def pack_reference_lists(grid_fts, grid_map):

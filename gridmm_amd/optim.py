@@ -68,12 +68,37 @@ class AdamW(torch.optim.Optimizer):
             first[i + 1] = first[i] + -(-p.numel() // self._CHUNK)
         blob = np.concatenate([rec.view(np.uint8), first.view(np.uint8)])
         if graph_tabs is None:
-            d = torch.from_numpy(blob).to(dev, non_blocking=True)
+            # through pinned memory (a ring: a slot is rewritten only after the copy issued from it has completed), so that
+            # the upload is a plain asynchronous DMA and never a staged pageable copy (measured host-synchronous on this
+            # ROCm stack, tools/repro_pageable_h2d.py -- correct either way, but it stalls the launching thread)
+            pinned, d = self._pinned_slot(len(blob), dev)
+            pinned.numpy()[:] = blob
+            d.copy_(pinned, non_blocking=True)
+            self._ring[self._ring_pos][2].record()
         else:
             pinned, d = self._carve(graph_tabs, len(blob))
             pinned.numpy()[:] = blob
             graph_tabs["multi"][key] = (pinned, d, rec.nbytes, [it[0] for it in items])
         return d, rec.nbytes, int(first[-1])
+
+    _RING = 4
+
+    def _pinned_slot(self, nbytes, dev):
+        """(pinned host bytes, device bytes) from a small ring: a slot is reused only after the copy issued from it has
+        completed (the event recorded behind it), so the host never rewrites a table the device has not fetched yet."""
+        ring = self.__dict__.setdefault("_ring", [])
+        if len(ring) < self._RING:
+            ring.append([torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory(),
+                         torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev), torch.cuda.Event()])
+            self._ring_pos = len(ring) - 1
+        else:
+            self._ring_pos = (self._ring_pos + 1) % self._RING
+            ring[self._ring_pos][2].synchronize()
+        slot = ring[self._ring_pos]
+        if slot[0].numel() < nbytes or slot[1].device != torch.device(dev):
+            slot[0] = torch.empty(2 * nbytes, dtype=torch.uint8).pin_memory()
+            slot[1] = torch.empty(2 * nbytes, dtype=torch.uint8, device=dev)
+        return slot[0][:nbytes], slot[1][:nbytes]
 
     @staticmethod
     def _carve(graph_tabs, nbytes):

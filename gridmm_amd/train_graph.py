@@ -11,19 +11,24 @@ contain, and where it goes instead:
                                        uploaded before every replay; torch.dropout uses torch's graph-safe generator
   lr schedule, AdamW bias correction   per-parameter lr / step_size / eps live in pinned host tables mirrored on the
                                        device; AdamW.refresh_graph_tables rewrites and uploads them before a replay
-                                       (no copy / memset NODES in the graph: both misbehaved when replayed)
+                                       (no copy / memset NODES in the graph: see KERNEL NODES ONLY below)
   packed-weight caches                 the re-split of every weight is part of the captured step; versions are bumped
                                        after a replay so that eager users of the caches re-pack
 
-ROCm 7.2 note (measured, tools/dbg_graph_train3.py): with the runtime's pre-recorded graph packets (the default) the
-replay of this graph faults on the device (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION at the third replay of the
-full-size step; it needs dropout on, a non-zero lr and the fp16 grid_proj tensors in the captured update -- through their
-own launches or through the multi-tensor table alike -- and goes away with unrelated eager work between replays), and
-the memset nodes of this graph did not clear their destinations in time (csrc/common.h);
-with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the HIP runtime starts, the same graph replays
-correctly.  GraphedTrainStep refuses to run without it (GRIDMM_TRAIN_GRAPH_ANY_RUNTIME=1 overrides the check, for
-re-testing a newer runtime); bench.py and the tests run this leg in a subprocess that sets it
-(the navigation-step graph of the headline is unaffected and keeps the default).
+KERNEL NODES ONLY.  Rounds 2-3 ran this class only with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: with the runtime's default
+pre-recorded graph packets the full-size step died with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION as soon as eager work
+alternated with replays.  Root cause (round 4; tools/dbg_train_graph_fault.py, tools/find_copy_nodes.py,
+profiles/r4_train_graph_fault.txt): the 1100-1300-node graph held SEVEN non-kernel nodes issued by torch -- 4 memcpy
+(two .clone() in the aggregation's forward, two select_backward copies of the token-type rows) and 3 memset (the
+semaphores of two large `sum`s = gradients of the broadcast token-type adds, and the sort-based embedding backward of
+nav_type_embedding).  With such nodes in a large graph the replay leaves ONE queue slot holding the packet of an EARLIER
+dispatch (the fault dump showed a rocprim partition kernel from the record step, always 322-324 packets before the
+write pointer); its kernel-argument block has been recycled by later eager launches, hence wild pointers -- and "memset
+nodes that did not clear in time" (round 2) is the same thing seen from the other side.  With no eager work between
+replays the stale slot re-executes a harmless packet of the previous replay, which is why soaks passed.  The fix is ours:
+every one of those operations now has a kernel form (autograd.kernel_copy / add_row / small_embedding, the reducer's slot
+copies), the graphs are captured with keep_graph and CHECKED (hipGraphNodeGetType): a graph with a non-kernel node is
+refused unless DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is set.  All scenarios that faulted pass on the default runtime.
 
 Several ranks (torch.distributed initialised): the step is SEVERAL graphs -- forward + loss, then one graph per segment
 of the backward (hostsync.boundary marks in the model) -- so that the gradient exchange overlaps the backward as DDP's
@@ -49,11 +54,36 @@ from .optim import _bump_version, get_lr_sched
 RUNTIME_ENV = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
+def _new_graph():
+    """A CUDAGraph that keeps its hipGraph_t so that the node types can be inspected (older torch: a plain one)."""
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError:
+        return torch.cuda.CUDAGraph()
+
+
+def check_kernel_only(graphs, what):
+    """Refuse a captured step that holds memcpy / memset / other non-kernel nodes when the runtime replays pre-recorded
+    packets (see the module docstring); returns the summed node-type histogram (None if the runtime hides the graph)."""
+    from .graph import graph_node_types
+    total = {}
+    for g in graphs:
+        h = graph_node_types(g)
+        if h is None:
+            return None
+        for k, v in h.items():
+            total[k] = total.get(k, 0) + v
+    other = {k: v for k, v in total.items() if k != "kernel"}
+    if other and os.environ.get(RUNTIME_ENV[0]) != RUNTIME_ENV[1] and not os.environ.get("GRIDMM_TRAIN_GRAPH_ANY_RUNTIME"):
+        raise RuntimeError("%s: the captured graph holds non-kernel nodes %s.  The runtime's pre-recorded graph packets replay "
+                           "such graphs incorrectly (stale queue slot -> wild kernel arguments): give the operation a kernel "
+                           "form (autograd.kernel_copy and friends; tools/find_copy_nodes.py names the torch op), or set "
+                           "%s=%s before torch / HIP start" % (what, other, RUNTIME_ENV[0], RUNTIME_ENV[1]))
+    return total
+
+
 class GraphedTrainStep:
     def __init__(self, trainer, batch, task, warmup=1, capture_optimizer=True, segments=None):
-        if os.environ.get(RUNTIME_ENV[0]) != RUNTIME_ENV[1] and not os.environ.get("GRIDMM_TRAIN_GRAPH_ANY_RUNTIME"):
-            raise RuntimeError("GraphedTrainStep needs %s=%s in the environment before torch / HIP start (see the module "
-                               "docstring): replaying this graph with pre-recorded packets faults on ROCm 7.2" % RUNTIME_ENV)
         o = trainer.opts
         if o.gradient_accumulation_steps != 1:
             raise ValueError("GraphedTrainStep: gradient_accumulation_steps == 1")
@@ -89,7 +119,7 @@ class GraphedTrainStep:
             if self.segmented:
                 self._capture_segments(model, batch, task, tape)
                 return
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = _new_graph()
             with torch.cuda.graph(self.graph):
                 with hs.replay(tape):
                     losses = model(batch, task=task, compute_loss=True)
@@ -98,6 +128,7 @@ class GraphedTrainStep:
                     if capture_optimizer:
                         self.norm = opt.step(max_grad_norm=o.grad_norm if o.grad_norm != -1 else None, graph_tabs=self.tabs)
                 self.losses = losses.detach()
+            self.node_types = check_kernel_only([self.graph], "GraphedTrainStep(%s)" % task)
             # the gradient buffers of the capture belong to the graph from here on: an eager step that found them in
             # p.grad would ACCUMULATE into them (train_step clears the gradients at the end of a step, a capture computes
             # nothing)
@@ -125,7 +156,7 @@ class GraphedTrainStep:
         red = self.tr.reducer
         self.graphs, logs = [], []
         hs.CUTS = cuts = []
-        g0 = torch.cuda.CUDAGraph()
+        g0 = _new_graph()
         try:
             with torch.cuda.graph(g0):
                 with hs.replay(tape):
@@ -140,7 +171,7 @@ class GraphedTrainStep:
 
         @contextlib.contextmanager
         def segment(k):
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             with torch.cuda.graph(g, pool=pool):
                 yield
             self.graphs.append(g)
@@ -151,6 +182,7 @@ class GraphedTrainStep:
         finally:
             red.end_capture()
         del cuts, loss
+        self.node_types = check_kernel_only(self.graphs, "GraphedTrainStep(%s, segmented)" % task)
         last = {i: k for k, log in enumerate(logs) for i in log}        # a tied weight is final in its LAST segment
         self.seg_final = [[i for i, kk in last.items() if kk == k] for k in range(len(logs))]
         self.norm = None

@@ -123,7 +123,7 @@ def text_embeddings(model, txt_ids):
     e = model.embeddings
     L = txt_ids.shape[1]
     pos = torch.arange(L, device=txt_ids.device).unsqueeze(0).expand_as(txt_ids)
-    x = e.word_embeddings(txt_ids) + e.position_embeddings(pos) + e.token_type_embeddings.weight[0]
+    x = ag.add_row(e.word_embeddings(txt_ids) + e.position_embeddings(pos), e.token_type_embeddings.weight, 0)
     return _drop(model, ag.layer_norm(x, e.LayerNorm))
 
 
@@ -170,7 +170,8 @@ def forward_panorama(model, view_img_fts, obj_img_fts, loc_fts, nav_types, view_
         x = interleave_view_obj(x, o, view_lens, obj_lens)
         lens = view_lens + obj_lens
     y = ag.layer_norm(ag.linear(loc_fts.float(), ie.loc_linear.weight, ie.loc_linear.bias), ie.loc_layer_norm)
-    x = x + y + ie.nav_type_embedding(nav_types) + model.embeddings.token_type_embeddings.weight[1]
+    x = ag.add_row(x + y + ag.small_embedding(nav_types, ie.nav_type_embedding.weight),
+                   model.embeddings.token_type_embeddings.weight, 1)
     x = _drop(model, ag.layer_norm(x, ie.layer_norm))
     masks = torch.arange(hs.host(lambda: int(lens.max())), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
     if ie.pano_encoder is not None:
@@ -188,7 +189,7 @@ def grid_cells(model, txt_embeds, grid_fts, grid_map, gridmap_pos_fts, grid_memo
     if grid_memory is not None:
         slab, perm, cell_start = grid_memory.slab, grid_memory.perm, grid_memory.cell_start
         if gridmap_pos_fts is None:
-            gridmap_pos_fts = grid_memory.pos_fts.clone()    # the buffer is overwritten by the next step
+            gridmap_pos_fts = ag.kernel_copy(grid_memory.pos_fts)    # the buffer is overwritten by the next step
     else:
         slab, perm, cell_start = hs.host(lambda: pack_reference_lists(grid_fts, grid_map))
     cells, occ = ag.grid_aggregate(text_fts, slab, perm, cell_start)

@@ -1,4 +1,4 @@
-"""(run by tests/test_hip_train_graph.py in a subprocess with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, see train_graph.py)
+"""(run by tests/test_hip_train_graph.py, one subprocess per case, on the runtime's DEFAULT graph settings)
 GPU: the pre-training step as one hipGraph (train_graph.GraphedTrainStep) against the eager step it captures
 (pretrain_loop.PreTrainer.train_step; reference loop pretrain_src/train_r2r.py:231-303): same losses, same gradient norms,
 same parameters after several optimizer steps (warm-up lr schedule and AdamW bias correction advancing per replay),
@@ -137,6 +137,56 @@ def case_dist2():
         assert p.exitcode == 0, p.exitcode
 
 
+def case_alternate_full():
+    """The scenario that used to die with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the default runtime (pre-recorded
+    graph packets): full-size eager steps of one trainer alternating with graph replays of another, no synchronisation in
+    between.  The graphs hold kernel nodes only now (train_graph.py: KERNEL NODES ONLY)."""
+    from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.synthetic import batch_to, make_pretrain_batch
+    from gridmm_amd.train_graph import GraphedTrainStep
+    from gridmm_amd.vilmodel import default_config
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0"
+    dev = torch.device("cuda")
+    cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=list(TASKS), image_prob_size=1000, obj_prob_size=0,
+                         hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    m0 = GlocalTextPathCMTPreTraining(cfg).to(dev)
+    m0.bert.grid_proj.float()
+    batches = {t: batch_to(make_pretrain_batch(np.random.RandomState(i), 32, t, max_steps=5, L=80, vocab=30000,
+                                               image_prob_size=1000, n_pts=(588 * 3, 588 * 5)), dev) for i, t in enumerate(TASKS)}
+    ma, mb = copy.deepcopy(m0), copy.deepcopy(m0)
+    ta, tb = PreTrainer(ma, default_opts(warmup_steps=20)), PreTrainer(mb, default_opts(warmup_steps=20))
+    graphs = {}
+    for t in TASKS:
+        for _ in range(2):
+            ta.train_step(batches[t], t)
+        graphs[t] = GraphedTrainStep(tb, batches[t], t)
+        assert graphs[t].node_types is None or set(graphs[t].node_types) == {"kernel"}, graphs[t].node_types
+    for i in range(12):
+        t = TASKS[i % 3]
+        la, na = ta.train_step(batches[t], t)
+        lb, nb = graphs[t]()
+        assert torch.equal(la, lb) and float(na) == float(nb), (i, t)      # no atomics on the path: bit-identical
+    torch.cuda.synchronize()
+
+
+def case_nonkernel():
+    """A graph with a memcpy node is refused on the default runtime."""
+    from gridmm_amd import autograd as ag
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.train_graph import GraphedTrainStep
+    model, batches = _setup(0.0)
+    tr = PreTrainer(model, default_opts(warmup_steps=10))
+    ag.kernel_copy = lambda x: x.clone()                  # what the aggregation's forward did before round 4
+    try:
+        GraphedTrainStep(tr, batches["sap"], "sap")
+    except RuntimeError as e:
+        assert "non-kernel nodes" in str(e) and "memcpy" in str(e), str(e)
+    else:
+        raise AssertionError("a graph with memcpy nodes was accepted")
+
+
 def case_two_graphs():
     """Two tasks, two graphs, one trainer: building the second graph runs eager steps after the first capture."""
     from gridmm_amd.pretrain_loop import PreTrainer, default_opts
@@ -255,6 +305,10 @@ if __name__ == "__main__":
         case_equals_eager(case.split("_", 1)[1], segments=True, layers=5)
     elif case == "dist2":
         case_dist2()
+    elif case == "alternate_full":
+        case_alternate_full()
+    elif case == "nonkernel":
+        case_nonkernel()
     else:
         case_equals_eager(case)
     print("ok", case)

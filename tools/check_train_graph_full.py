@@ -1,7 +1,6 @@
 """Full-size check of the captured training step against the eager step (dropout off): loss / norm trajectories over
-N steps cycling mlm / mrc / sap, two identically initialised models.  DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is set here."""
+N steps cycling mlm / mrc / sap, two identically initialised models.  Runs on the default runtime settings (kernel-only graphs)."""
 import os, sys, copy
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 sys.path.insert(0, ".")
 import numpy as np, torch
 from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining

@@ -1,5 +1,4 @@
 import os, sys, copy
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import torch
 from train_graph_cases import _setup

@@ -1,7 +1,6 @@
 """Stability soak of the captured training step: N replays cycling the three task graphs at full size (the configuration of
 bench.py's train leg), losses finite and decreasing, no device fault.  usage: soak_train_graph.py [replays=300]"""
 import os, sys, time
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 sys.path.insert(0, ".")
 import numpy as np, torch
 from gridmm_amd.pretrain_cmt import GlocalTextPathCMTPreTraining
