@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -80,6 +80,8 @@ SIGNATURES = {
     "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_multi_grad_sumsq": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "gridmm_multi_adamw_step": [_vp, _vp, _i, _i, _f, _f, _i, _vp, _f, _vp],
+    # host-side helpers of the agent loop (no device work)
+    "gridmm_route_lengths": [_vp, _i, _i, _vp, _vp, _vp, _i, _vp],
 }
 
 _lib = None

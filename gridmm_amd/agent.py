@@ -274,8 +274,11 @@ class GMapNavAgent:
         if self._graphs is not None:
             for g in self._graphs:
                 g.validate()               # weights updated since the graphs were captured (training between evaluations)?
-        for i, ob in enumerate(obs):
-            gmaps[i].observe(ob)
+        if tbatch is not None:
+            tbatch.observe_all(obs)
+        else:
+            for i, ob in enumerate(obs):
+                gmaps[i].observe(ob)
         traj = [{"instr_id": ob["instr_id"], "path": [[ob["viewpoint"]]], "details": {}} for ob in obs]
 
         language_inputs = self._language_variable(obs)
@@ -301,6 +304,8 @@ class GMapNavAgent:
                 # the half of 'navigation' that needs only the instruction and the grid memory starts now: the device works
                 # through it while the host collates the panorama / graph inputs
                 self._graphs[1].begin(txt_embeds, language_inputs["txt_masks"], mem)
+                t0 = self._tick("navigation", t0)      # (profiled rollouts: the early front half counts as navigation)
+            self.collator.keep_inputs = self.trace is not None
             pano_inputs = self.collator.panorama(obs) if fast else self._panorama_feature_variable(obs)
             t0 = self._tick("host: collate panorama inputs", t0)
             pano_embeds, pano_masks = self._model_call("panorama", pano_inputs)
@@ -333,7 +338,14 @@ class GMapNavAgent:
             else:
                 nav_logits, nav_vpids = nav_outs["fused_logits"], nav_inputs["gmap_vpids"]
             nav_probs = torch.softmax(nav_logits, 1)
-            stop_probs = nav_probs[:, 0].detach().cpu().numpy()       # one D2H per step (reference: B .item() calls)
+            if self.feedback == "argmax" and train_ml is None:
+                # inference: the step's ONE device-to-host read -- stop probabilities and the arg-max actions together
+                a_t = nav_logits.max(1)[1].detach()
+                both = torch.stack([nav_probs[:, 0].detach().double(), a_t.double()]).cpu().numpy()
+                stop_probs, a_t_pre = both[0].astype(np.float32), both[1].astype(np.int64)
+            else:
+                a_t_pre = None
+                stop_probs = nav_probs[:, 0].detach().cpu().numpy()   # one D2H per step (reference: B .item() calls)
             for i, gmap in enumerate(gmaps):
                 if not ended[i]:
                     gmap.stop_score[obs[i]["viewpoint"]] = {"stop": float(stop_probs[i])}
@@ -350,7 +362,8 @@ class GMapNavAgent:
             if self.feedback == "teacher":
                 a_t = nav_targets
             elif self.feedback == "argmax":
-                a_t = nav_logits.max(1)[1].detach()
+                if a_t_pre is None:
+                    a_t = nav_logits.max(1)[1].detach()
             elif self.feedback == "sample":
                 c = torch.distributions.Categorical(nav_probs)
                 self.logs["entropy"].append(c.entropy().sum().item())
@@ -370,9 +383,12 @@ class GMapNavAgent:
 
             if self.feedback in ("teacher", "sample"):
                 a_t_stop = [ob["viewpoint"] == ob["gt_path"][-1] for ob in obs]
+                a_t_host = a_t.cpu().numpy()
+            elif a_t_pre is not None:
+                a_t_host, a_t_stop = a_t_pre, a_t_pre == 0
             else:
-                a_t_stop = (a_t == 0).cpu().numpy()
-            a_t_host = a_t.cpu().numpy()
+                a_t_host = a_t.cpu().numpy()
+                a_t_stop = a_t_host == 0
 
             if self.trace is not None:
                 self.trace.append({"t": t, "pano_inputs": pano_inputs, "nav_inputs": nav_inputs, "nav_outs": nav_outs, "a_t": a_t_host.copy(),
@@ -400,9 +416,12 @@ class GMapNavAgent:
             obs = self.env._get_obs()
             t0 = self._tick("env (grid memory step + observation dicts)", t0)
             self._update_scanvp_cands(obs)
-            for i, ob in enumerate(obs):
-                if not ended[i]:
-                    gmaps[i].observe(ob)
+            if tbatch is not None:
+                tbatch.observe_all(obs, ~ended)
+            else:
+                for i, ob in enumerate(obs):
+                    if not ended[i]:
+                        gmaps[i].observe(ob)
             ended[:] = np.logical_or(ended, np.array([x is None for x in cpu_a_t]))
             if ended.all():
                 break

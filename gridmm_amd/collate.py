@@ -20,7 +20,60 @@ restatement on the same observations, key by key.
 import numpy as np
 import torch
 
+from . import _lib
 from .graph_utils import UNREACHABLE, batched_pos_features
+
+
+class _Stager:
+    """Host arrays of one step -> ONE asynchronous host-to-device copy.  put() copies an array into the current slot of a
+    small ring of PINNED buffers and returns the matching view of the slot's device mirror; flush() ships the used bytes.
+    A `torch.from_numpy(a).to(device)` per array (the form this replaces: ~12 per step) is a blocking copy each, i.e. the
+    host waits for everything already queued on the stream -- the early-launched front half of 'navigation' and the
+    'panorama' graph -- before it can go on collating.  Views are valid until the ring comes round (3 flushes later; their
+    consumers were enqueued on the same stream long before).  On a CPU device put() degrades to a plain copy."""
+
+    def __init__(self, device, nbytes=1 << 20, ring=3):
+        self.device, self.cuda = torch.device(device), torch.device(device).type == "cuda"
+        self.ring, self.pos, self.used = [], 0, 0
+        if self.cuda:
+            for _ in range(ring):
+                self.ring.append([torch.empty(nbytes, dtype=torch.uint8).pin_memory(),
+                                  torch.empty(nbytes, dtype=torch.uint8, device=self.device), None])
+
+    def _slot(self):
+        return self.ring[self.pos]
+
+    def put(self, a):
+        a = np.ascontiguousarray(a)
+        if not self.cuda:
+            return torch.from_numpy(a.copy())
+        t = torch.from_numpy(a)
+        n = a.nbytes
+        o = (self.used + 15) // 16 * 16
+        host, dev, ev = self._slot()
+        if o + n > host.numel():
+            self.flush()                              # (a step that outgrows the slot: ship what is there, start the next slot)
+            host, dev, ev = self._slot()
+            if n > host.numel():
+                self.ring[self.pos][0] = host = torch.empty(2 * n, dtype=torch.uint8).pin_memory()
+                self.ring[self.pos][1] = dev = torch.empty(2 * n, dtype=torch.uint8, device=self.device)
+            o = 0
+        if self.used == 0 and ev is not None:
+            ev.synchronize()                          # the copy issued from this slot three flushes ago has completed
+        if n:
+            host[o:o + n].view(t.dtype).view(t.shape).copy_(t)
+        self.used = o + n
+        return dev[o:o + n].view(t.dtype).view(t.shape)
+
+    def flush(self):
+        if not self.cuda or self.used == 0:
+            return
+        host, dev, _ = self._slot()
+        dev[:self.used].copy_(host[:self.used], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.ring[self.pos][2] = ev
+        self.pos, self.used = (self.pos + 1) % len(self.ring), 0
 
 
 class NavCollator:
@@ -33,6 +86,14 @@ class NavCollator:
         self.node_buckets, self.view_buckets = node_buckets, view_buckets
         self.pool = None              # (B, slots, H) running sums; slot 0 stays zero (stop token / padding)
         self.cnt = None               # (B, slots) host counts
+        self.stage = _Stager(self.device)
+        # panorama blocks are pure functions of (scan, viewpoint, view index) -- the reference keeps them in its
+        # buffered_state_dict / ImageFeaturesDB (map_nav_src/r2r/env.py:529-575, utils/data.py) -- so the COLLATED block of
+        # an observation (candidate views first, then the views that face no candidate; image and location features,
+        # types, length, candidate ids) is kept in device tables, one slot per key: a step uploads only the blocks it has
+        # not seen and gathers the batch on the device.  pano_cache=False restores the per-step assembly.
+        self.pano_cache = True
+        self._pano = None
 
     def reset(self, batch_size):
         self.pool = None
@@ -45,37 +106,116 @@ class NavCollator:
                 return int(b)
         return n
 
+    keep_inputs = False     # True: every uploaded array owns its device memory (training rollouts keep the inputs of all
+    #                         steps for backward; traced rollouts keep them for inspection) instead of a view of the ring
+
     def _dev(self, a):
-        return torch.from_numpy(a).to(self.device)
+        if self.keep_inputs or torch.is_grad_enabled():
+            return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        return self.stage.put(a)
 
     # ---- agent.py:51-94 ---------------------------------------------------------------------------
+    @staticmethod
+    def _pano_block(ob, fs):
+        """One observation's collated panorama: (img (n, fs), loc (n, A + 3), types (n,), candidate ids)."""
+        feat = np.asarray(ob["feature"])
+        A = feat.shape[1] - fs
+        pids = [int(cc["pointId"]) for cc in ob["candidate"]]
+        nc = len(pids)
+        rest = np.ones(36, dtype=bool)
+        n = nc + 36 - len(set(pids))
+        img = np.zeros((n, fs), dtype=np.float32)
+        loc = np.zeros((n, A + 3), dtype=np.float32)
+        types = np.zeros(n, dtype=np.int64)
+        if nc:                                          # candidates' views first, then the views that face no candidate
+            rest[pids] = False
+            cf = np.stack([cc["feature"] for cc in ob["candidate"]])
+            img[:nc], loc[:nc, :A] = cf[:, :fs], cf[:, fs:]
+            types[:nc] = 1
+        img[nc:], loc[nc:, :A] = feat[rest, :fs], feat[rest, fs:]
+        loc[:, A:] = 1.0                                # the constant "box" columns of valid rows
+        return img, loc, types, [cc["viewpointId"] for cc in ob["candidate"]]
+
     def panorama(self, obs):
         fs, B = self.args.image_feat_size, len(obs)
-        cands_all = [[cc["viewpointId"] for cc in ob["candidate"]] for ob in obs]
-        pids = [[int(cc["pointId"]) for cc in ob["candidate"]] for ob in obs]
-        n_cand = np.fromiter((len(p) for p in pids), dtype=np.int64, count=B)
-        lens = np.fromiter((len(p) + 36 - len(set(p)) for p in pids), dtype=np.int64, count=B)
+        if self.pano_cache and all("viewIndex" in ob and "scan" in ob for ob in obs):
+            return self._panorama_cached(obs)
+        blocks = [self._pano_block(ob, fs) for ob in obs]
+        lens = np.fromiter((len(b[2]) for b in blocks), dtype=np.int64, count=B)
         self._view_lens = lens
-        W = np.asarray(obs[0]["feature"]).shape[1]
-        A = W - fs                                      # angle columns
         V = self._bucket(int(lens.max()), self.view_buckets)
         img = np.zeros((B, V, fs), dtype=np.float32)
-        loc = np.zeros((B, V, A + 3), dtype=np.float32)
+        loc = np.zeros((B, V, blocks[0][1].shape[1]), dtype=np.float32)
         types = np.zeros((B, V), dtype=np.int64)
-        for i, ob in enumerate(obs):                    # candidates' views first, then the views that face no candidate
-            feat, nc, n = np.asarray(ob["feature"]), int(n_cand[i]), int(lens[i])
-            rest = np.ones(36, dtype=bool)
-            if nc:
-                rest[pids[i]] = False
-                cf = np.stack([cc["feature"] for cc in ob["candidate"]])
-                img[i, :nc], loc[i, :nc, :A] = cf[:, :fs], cf[:, fs:]
-                types[i, :nc] = 1
-            img[i, nc:n], loc[i, nc:n, :A] = feat[rest, :fs], feat[rest, fs:]
-            loc[i, :n, A:] = 1.0                        # the constant "box" columns of valid rows
-        return {
+        for i, (bi, bl, bt, _) in enumerate(blocks):
+            n = len(bt)
+            img[i, :n], loc[i, :n], types[i, :n] = bi, bl, bt
+        out = {
             "view_img_fts": self._dev(img), "loc_fts": self._dev(loc),
             "nav_types": self._dev(types), "view_lens": self._dev(lens),
-            "cand_vpids": cands_all, "obj_img_fts": None, "obj_lens": None,
+            "cand_vpids": [b[3] for b in blocks], "obj_img_fts": None, "obj_lens": None,
+        }
+        self.stage.flush()
+        return out
+
+    def _panorama_cached(self, obs):
+        fs, B = self.args.image_feat_size, len(obs)
+        P = self._pano
+        if P is None:
+            A3 = np.asarray(obs[0]["feature"]).shape[1] - fs + 3
+            P = self._pano = {"slot": {}, "cands": [], "lens": [], "cap": 0, "vmax": 48, "A3": A3, "img": None, "loc": None,
+                              "types": None}
+        keys = [(ob["scan"], ob["viewpoint"], int(ob["viewIndex"])) for ob in obs]
+        miss = {}
+        for k, ob in zip(keys, obs):
+            if k not in P["slot"] and k not in miss:
+                miss[k] = self._pano_block(ob, fs)
+        if miss:
+            need_v = max(len(b[2]) for b in miss.values())
+            n_new = len(P["slot"]) + len(miss)
+            if n_new > P["cap"] or need_v > P["vmax"]:                 # grow the device tables (doubling)
+                cap = max(256, P["cap"])
+                while cap < n_new:
+                    cap *= 2
+                vmax = P["vmax"]
+                while vmax < need_v:
+                    vmax += 16
+                new = {"img": torch.zeros(cap, vmax, fs, dtype=torch.float32, device=self.device),
+                       "loc": torch.zeros(cap, vmax, P["A3"], dtype=torch.float32, device=self.device),
+                       "types": torch.zeros(cap, vmax, dtype=torch.int64, device=self.device)}
+                for name, t in new.items():
+                    if P[name] is not None:
+                        t[:P["cap"], :P["vmax"]] = P[name]
+                    P[name] = t
+                P["cap"], P["vmax"] = cap, vmax
+            m, vmax = len(miss), P["vmax"]
+            img = np.zeros((m, vmax, fs), dtype=np.float32)
+            loc = np.zeros((m, vmax, P["A3"]), dtype=np.float32)
+            types = np.zeros((m, vmax), dtype=np.int64)
+            first = len(P["slot"])
+            for j, (k, (bi, bl, bt, cands)) in enumerate(miss.items()):
+                n = len(bt)
+                img[j, :n], loc[j, :n], types[j, :n] = bi, bl, bt
+                P["slot"][k] = first + j
+                P["cands"].append(cands)
+                P["lens"].append(n)
+            for name, a in (("img", img), ("loc", loc), ("types", types)):
+                P[name][first:first + m].copy_(torch.from_numpy(a))     # (first sight of a viewpoint: a blocking upload)
+        slots = np.fromiter((P["slot"][k] for k in keys), dtype=np.int64, count=B)
+        lens = np.fromiter((P["lens"][sl] for sl in slots), dtype=np.int64, count=B)
+        self._view_lens = lens
+        V = self._bucket(int(lens.max()), self.view_buckets)
+        sd, ld = self._dev(slots), self._dev(lens)
+        self.stage.flush()
+        if V > P["vmax"]:                                               # (a view bucket wider than the table rows)
+            pad = lambda t: torch.nn.functional.pad(t, (0, 0, 0, V - t.shape[1]) if t.dim() == 3 else (0, V - t.shape[1]))   # noqa: E731
+        else:
+            pad = lambda t: t                                           # noqa: E731
+        return {
+            "view_img_fts": pad(torch.index_select(P["img"][:, :V], 0, sd)),
+            "loc_fts": pad(torch.index_select(P["loc"][:, :V], 0, sd)),
+            "nav_types": pad(torch.index_select(P["types"][:, :V], 0, sd)), "view_lens": ld,
+            "cand_vpids": [P["cands"][sl] for sl in slots], "obj_img_fts": None, "obj_lens": None,
         }
 
     # ---- agent.py:300-311 (graph node embeddings) ---------------------------------------------------
@@ -92,15 +232,33 @@ class NavCollator:
             self.pool = pool
 
     def _apply(self, src, sets, adds):
-        for ops, accumulate in ((sets, False), (adds, True)):
-            if len(ops) == 0:
-                continue
-            ix = self._dev(np.asarray(ops, dtype=np.int64).T.copy())
-            vals = src[ix[0], ix[2]]
-            if torch.is_grad_enabled() and (vals.requires_grad or self.pool.requires_grad):
-                self.pool = self.pool.index_put((ix[0], ix[1]), vals, accumulate=accumulate)
-            else:
-                self.pool.index_put_((ix[0], ix[1]), vals, accumulate=accumulate)
+        """sets / adds: rows (episode, node slot, source row): pool[e, slot] = / += src[e, row].  (episode, slot) pairs are
+        unique within one call (the callers split a step whose node repeats)."""
+        if torch.is_grad_enabled() and (src.requires_grad or self.pool.requires_grad):
+            for ops, accumulate in ((sets, False), (adds, True)):       # differentiable rollouts: out of place
+                if len(ops) == 0:
+                    continue
+                ix = self._dev(np.asarray(ops, dtype=np.int64).T.copy())
+                self.stage.flush()
+                self.pool = self.pool.index_put((ix[0], ix[1]), src[ix[0], ix[2]], accumulate=accumulate)
+            return
+        # inference: flat row indices, one upload, index_select / index_copy_ / index_add_ (one kernel each; index_put_
+        # sorts its indices first: ~0.5 ms of host time per call on this stack)
+        S, V1, H = self.pool.shape[1], src.shape[1], src.shape[2]
+        parts = []
+        for ops in (sets, adds):
+            o = np.asarray(ops, dtype=np.int64).reshape(-1, 3)
+            parts += [o[:, 0] * S + o[:, 1], o[:, 0] * V1 + o[:, 2]]
+        ns, na = len(parts[0]), len(parts[2])
+        if ns + na == 0:
+            return
+        ix = self._dev(np.concatenate(parts))
+        self.stage.flush()
+        flat, rows = self.pool.view(-1, H), src.reshape(-1, H)
+        if ns:
+            flat.index_copy_(0, ix[:ns], rows.index_select(0, ix[ns:2 * ns]))
+        if na:
+            flat.index_add_(0, ix[2 * ns:2 * ns + na], rows.index_select(0, ix[2 * ns + na:]))
 
     def update_embeddings(self, obs, gmaps, ended, pano_embeds, pano_masks, cand_vpids):
         """Current node := mean of its panorama (overwrite); every unvisited candidate += its view embedding."""
@@ -211,9 +369,12 @@ class NavCollator:
         graph = np.where(is_cur, 0.0, tb.dist[bi[:, None], cur[:, None], tgt])
         graph = np.where(np.isfinite(graph), graph, float(UNREACHABLE))
         via = tb.via[bi[:, None], cur[:, None], tgt]
-        hops = np.where(is_cur, 0.0, 1.0)
-        for i, j in zip(*np.nonzero((via >= 0) & tm & ~is_cur)):       # routes with more than one leg: unrolled
-            hops[i, j] = len(gmaps[i]._route_ids(int(cur[i]), int(tgt[i, j])))
+        # routes with more than one leg are unrolled along the pivots (FloydGraph.path) -- one native call for the batch
+        # (gridmm_route_lengths; ~350 Python recursions per step before)
+        hops = np.empty((B, T), dtype=np.float64)
+        tgt_c, tm_c = np.ascontiguousarray(tgt, dtype=np.int64), np.ascontiguousarray(tm, dtype=np.uint8)
+        _lib.check(_lib.load().gridmm_route_lengths(tb.via.ctypes.data, B, cap, cur.ctypes.data, tgt_c.ctypes.data,
+                                                    tm_c.ctypes.data, T, hops.ctypes.data), "gridmm_route_lengths")
         bh = np.array([float(ob["heading"]) for ob in obs])
         be = np.array([float(ob["elevation"]) for ob in obs])
         feats = batched_pos_features(delta.reshape(-1, 3), np.repeat(bh, T), np.repeat(be, T), graph.reshape(-1),
@@ -263,16 +424,18 @@ class NavCollator:
         vpids = [[None] + [g.names[k] for k in ids[i, :m[i]]] for i, g in enumerate(gmaps)]
         lens = m + 1
         slot_d, inv_d = self._dev(slot), self._dev(inv)
-        rows = torch.arange(B, device=self.device).unsqueeze(1)
-        gmap_img = self.pool[rows, slot_d] * inv_d.unsqueeze(2)
         out = {
-            "gmap_vpids": vpids, "gmap_img_embeds": gmap_img, "gmap_step_ids": self._dev(steps),
+            "gmap_vpids": vpids, "gmap_img_embeds": None, "gmap_step_ids": self._dev(steps),
             "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited),
             "gmap_pair_dists": self._dev(pair),
             "gmap_masks": self._dev(np.arange(G)[None] < lens[:, None]), "no_vp_left": [bool(v == 0) for v in n_unv],
             "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),
         }
-        return self._vp_part(out, pano_embeds, cand_vpids, view_lens, nav_types, vpos)
+        out = self._vp_part(out, pano_embeds, cand_vpids, view_lens, nav_types, vpos)
+        self.stage.flush()                         # every host array of the step: one asynchronous upload
+        rows = torch.arange(B, device=self.device).unsqueeze(1)
+        out["gmap_img_embeds"] = self.pool[rows, slot_d] * inv_d.unsqueeze(2)
+        return out
 
     def _vp_part(self, out, pano_embeds, cand_vpids, view_lens, nav_types, vpos):
         B, V1 = pano_embeds.shape[0], pano_embeds.shape[1] + 1
@@ -360,13 +523,15 @@ class NavCollator:
             for j in range(n_vis, m):
                 cand_of_node[i, j + 1] = col.get(names[j], -1)
         slot_d, inv_d = self._dev(slot), self._dev(inv)
-        rows = torch.arange(B, device=self.device).unsqueeze(1)
-        gmap_img = self.pool[rows, slot_d] * inv_d.unsqueeze(2)
         out = {
-            "gmap_vpids": vpids, "gmap_img_embeds": gmap_img, "gmap_step_ids": self._dev(steps),
+            "gmap_vpids": vpids, "gmap_img_embeds": None, "gmap_step_ids": self._dev(steps),
             "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited),
             "gmap_pair_dists": self._dev(pair),
             "gmap_masks": self._dev(np.arange(G)[None] < lens[:, None]), "no_vp_left": no_vp_left,
             "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),
         }
-        return self._vp_part(out, pano_embeds, cand_vpids, view_lens, nav_types, vpos)
+        out = self._vp_part(out, pano_embeds, cand_vpids, view_lens, nav_types, vpos)
+        self.stage.flush()                         # every host array of the step: one asynchronous upload
+        rows = torch.arange(B, device=self.device).unsqueeze(1)
+        out["gmap_img_embeds"] = self.pool[rows, slot_d] * inv_d.unsqueeze(2)
+        return out

@@ -283,6 +283,47 @@ class TopoMapBatch:
         for m in self.maps:
             self._attach(m)
 
+    def observe_all(self, obs, active=None):
+        """TopoMap.observe(obs[b]) for every (active) episode, with the all-pairs relaxation of the B maps done as ONE pass
+        over the (B, n, n) arrays: same arithmetic (float64 edge lengths, strict `<` improvements, pivot ids), same result
+        as the per-map calls (tests/test_topo_map.py)."""
+        bs, ks = [], []
+        for b, ob in enumerate(obs):
+            if active is not None and not active[b]:
+                continue
+            m = self.maps[b]
+            k = m.intern(ob["viewpoint"])
+            cs = [m.intern(c["viewpointId"]) for c in ob["candidate"]]      # (may re-point the arrays: intern first)
+            bs.append(b)
+            ks.append(k)
+            pos = self.pos[b]
+            pos[k] = ob["position"]
+            if cs:
+                ci = np.asarray(cs, dtype=np.int64)
+                pos[ci] = np.asarray([c["position"] for c in ob["candidate"]], dtype=np.float64)
+                delta = pos[ci] - pos[k]
+                w = np.sqrt(delta[:, 0] ** 2 + delta[:, 1] ** 2 + delta[:, 2] ** 2)
+                d, v = self.dist[b], self.via[b]
+                for c, wc in zip(cs, w):                    # (a candidate listed twice keeps the first, shorter-or-equal edge)
+                    if wc < d[k, c]:
+                        d[k, c] = d[c, k] = wc
+                        v[k, c] = v[c, k] = -1
+        if not bs:
+            return
+        bs, ks = np.asarray(bs, dtype=np.int64), np.asarray(ks, dtype=np.int64)
+        n = int(self.n[bs].max())
+        ar = np.arange(len(bs))
+        d = self.dist[bs, :n, :n]                            # (nb, n, n) copies; rows / columns past an episode's n are inf
+        through = d[ar, :, ks][:, :, None] + d[ar, ks, :][:, None, :]
+        better = through < d
+        better[:, np.arange(n), np.arange(n)] = False
+        d[better] = through[better]
+        self.dist[bs, :n, :n] = d
+        v = self.via[bs, :n, :n]
+        v[better] = np.broadcast_to(ks[:, None, None].astype(np.int32), better.shape)[better]
+        self.via[bs, :n, :n] = v
+        self.seen[bs, ks] = True
+
     def mark_step(self, b, vp, t):
         """The agent's `gmap.step_id[vp] = t` (agent.py:277-279) mirrored into the batch array."""
         m = self.maps[b]

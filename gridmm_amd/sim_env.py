@@ -268,20 +268,27 @@ class SyntheticNavEnv:
             item = self.batch[i]
             sc = self.scans[s.scan]
             vi = s.view_index
-            # (candidates and the angle-extended view features are pure functions of (viewpoint, view index): kept like
-            # the reference keeps its buffered_state_dict, env.py:529-575; consumers treat them as read-only)
-            feature, cand, full_feature = sc._memo(("obs", s.vp, vi, self.image_feat_size), lambda: self._static_obs(sc, s, vi),
-                                                   limit=4096, store="_obs_store")
-            x, y, z = sc.pos[s.vp]
-            obs.append({
-                "instr_id": item["instr_id"], "scan": s.scan, "viewpoint": s.vp, "viewIndex": vi,
-                "position": (np.float32(x), np.float32(y), np.float32(z)),
-                "heading": np.float32(s.heading), "elevation": np.float32(s.elevation),
-                "feature": full_feature,
-                "candidate": cand, "instruction": item["instruction"],
-                "instr_encoding": [np.int32(t) for t in item["instr_encoding"]],
-                "gt_path": item["path"], "path_id": item["path_id"],
-                "grid_fts": grid_fts[i], "grid_map": grid_map[i], "gridmap_pos_fts": pos_fts[i],
-                "distance": np.float32(self.shortest_distances[s.scan][s.vp][item["path"][-1]]),
-            })
+            # The fields that are pure functions of (viewpoint, view index) -- candidates, the angle-extended view features,
+            # the position -- are kept like the reference keeps its buffered_state_dict (env.py:529-575), the per-episode
+            # constants (instruction, ground truth) are converted once per item; consumers treat them as read-only.
+            static = sc._memo(("obs", s.vp, vi, self.image_feat_size), lambda: self._static_fields(sc, s, vi),
+                              limit=4096, store="_obs_store")
+            ep = item.get("_obs_fields")
+            if ep is None:
+                ep = item["_obs_fields"] = {
+                    "instr_id": item["instr_id"], "instruction": item["instruction"],
+                    "instr_encoding": [np.int32(t) for t in item["instr_encoding"]], "gt_path": item["path"],
+                    "path_id": item["path_id"]}
+            ob = dict(static)
+            ob.update(ep)
+            ob["heading"], ob["elevation"] = np.float32(s.heading), np.float32(s.elevation)
+            ob["grid_fts"], ob["grid_map"], ob["gridmap_pos_fts"] = grid_fts[i], grid_map[i], pos_fts[i]
+            ob["distance"] = np.float32(self.shortest_distances[s.scan][s.vp][item["path"][-1]])
+            obs.append(ob)
         return obs
+
+    def _static_fields(self, sc, s, vi):
+        feature, cand, full_feature = self._static_obs(sc, s, vi)
+        x, y, z = sc.pos[s.vp]
+        return {"scan": s.scan, "viewpoint": s.vp, "viewIndex": vi, "position": (np.float32(x), np.float32(y), np.float32(z)),
+                "feature": full_feature, "candidate": cand}

@@ -511,6 +511,19 @@ int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tens
 int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float beta1,
                             float beta2, int decay_first, const float* sumsq, float max_norm, gridmm_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Host-side helpers of the agent loop's collation (HOST pointers, no device work, no stream)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Number of legs of the route from cur[b] to every target node of episode b's topological map: len(FloydGraph.path(x, y))
+ * (map_nav_src/models/graph_utils.py:75-100: path(x, y) = [y] without a pivot, else path(x, k) + path(k, y)), evaluated on
+ * the current pivot matrix like the reference's recursion; feeds the "hops" column of get_pos_fts
+ * (graph_utils.py:139-151, agent.py:96-147).
+ *   via [B][cap][cap] int32 pivots (-1: direct / unknown); cur [B] int64; tgt [B][T] int64; mask [B][T] uint8 or NULL
+ *   (0: skipped, hops = 1); hops [B][T] float64 out (0 for tgt == cur). */
+int gridmm_route_lengths(const int32_t* via, int B, int cap, const int64_t* cur, const int64_t* tgt, const uint8_t* mask,
+                         int T, double* hops);
+
 #ifdef __cplusplus
 }
 #endif

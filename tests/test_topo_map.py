@@ -89,3 +89,36 @@ def test_topo_map_batch_rows_equal_standalone_maps():
             cur = a.nodes()[-1]
             np.testing.assert_array_equal(m.pos_features(cur, a.nodes(), 0.3, 0.1), a.pos_features(cur, a.nodes(), 0.3, 0.1))
     assert tb.cap > 4
+
+
+def test_observe_all_equals_per_map_observe():
+    """TopoMapBatch.observe_all: the relaxation of all episodes in one pass over the (B, n, n) arrays == TopoMap.observe
+    per episode (inactive rows untouched), including storage growth."""
+    from gridmm_amd.graph_utils import TopoMapBatch
+    g = np.load(GOLD)
+    T = len(g["in_walk"])
+    starts = ["vp%02d" % g["in_walk"][0]] * 4
+    tb = TopoMapBatch(starts, capacity=4)
+    alone = [TopoMap(s, capacity=4) for s in starts]
+    for t in range(T):
+        obs, active = [], []
+        for b in range(4):
+            ob = _obs(g, (t + 2 * b) % T if b else t)
+            if ob["viewpoint"] not in alone[b] and t:
+                ob = _obs(g, t)
+            obs.append(ob)
+            active.append(not (b == 3 and t % 3 == 1))      # row 3 sits out every third step
+        tb.observe_all(obs, active)
+        for b in range(4):
+            if active[b]:
+                alone[b].observe(obs[b])
+        for b in range(4):
+            m, a = tb.maps[b], alone[b]
+            n = a.n
+            assert m.n == n and m.nodes() == a.nodes()
+            assert np.array_equal(m.dist[:n, :n], a.dist[:n, :n]) and np.array_equal(m.via[:n, :n], a.via[:n, :n])
+            assert np.array_equal(m.seen[:n], a.seen[:n]) and np.array_equal(m.pos[:n], a.pos[:n])
+            for x in range(n):
+                for y in range(n):
+                    assert m._route_ids(x, y) == a._route_ids(x, y)
+    assert tb.cap > 4

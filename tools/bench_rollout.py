@@ -15,8 +15,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--slow-too", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the host side of the timed rollouts")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        r = bench.rollout_leg(a, dev)
+        pr.disable()
+        print(json.dumps(r, indent=1))
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(30)
+        return
     r = bench.rollout_leg(a, dev)
     print(json.dumps(r, indent=1))
     if a.slow_too:
