@@ -301,6 +301,47 @@ def rollout_leg(args, dev, rollouts=4):
                         % (agent._graphs[1].captures, agent._graphs[1].replays)}
 
 
+def finetune_leg(args, dev, iters=3):
+    """Config 2 read as what it says, "R2R FINE-TUNE batch=32": one Seq2SeqAgent.train iteration (map_nav_src/r2r/
+    agent_base.py:164-211, agent.py:268-451) -- zero_grad, a teacher-forced rollout of B = 32 episodes over the synthetic
+    environment at the BASELINE observation shape ('language' once, then 'panorama' + fill_gridmap + 'navigation' per step on
+    the DIFFERENTIABLE path, cross-entropy against the teacher action), ONE backward through every step of the rollout,
+    clip_grad_norm 40, AdamW.  value = episodes / s; kernels_ms = summed device time of the iteration's kernels (HIP events
+    around the whole iteration minus nothing: wall with a synchronize, the iteration is device-bound)."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.sim_env import SyntheticNavEnv
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    geom, B, T = S.BASELINE, args.batch, 7
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = GlocalTextPathNavCMT(default_config(grid_feat_size=geom.feat_dim)).to(dev)
+    mem = GridMemoryBatch(B, geom, max_steps=T + 2, device=dev)
+    env = SyntheticNavEnv(B, mem, n_scans=4, n_episodes=4 * B, seed=3, geom=geom, vocab=30000)
+    env.build_device_store(dev)
+    agent = GMapNavAgent(default_args(max_action_len=T, train_alg="imitation", lr=1e-5), env, model, device=dev)
+    agent.train(4)                            # one pass over the episode list: feature memo, weight packs, allocator
+    torch.cuda.synchronize()
+    n0 = agent.nav_steps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    losses = agent.train(iters)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    steps = (agent.nav_steps - n0) / iters
+    del agent, env, mem, model
+    torch.cuda.empty_cache()
+    return {"value": B / dt, "unit": "episodes/s", "s_per_iteration": dt, "device_span_ms": e0.elapsed_time(e1) / iters,
+            "nav_steps_per_iteration": steps, "episode_steps_per_s": B * steps / dt, "batch": B, "max_action_len": T,
+            "finite_losses": bool(np.isfinite(losses).all()),
+            "workload": "GMapNavAgent.train (imitation): teacher-forced rollout of %d episodes x <= %d steps on the "
+                        "differentiable path, one backward through all steps, clip 40 + AdamW; 36x196x512 observations "
+                        "resident in HBM, full-size model" % (B, T)}
+
+
 def producer_leg(args, dev, steps=5):
     """Config 5's shape with the PRODUCER in the timed region: per step the CLIP ViT-B/32 tower encodes the
     12 view images of every episode (B x 12 x 3 x 224 x 224, already normalised and resident), writes the patch tokens
@@ -824,6 +865,11 @@ def main():
             out["rollout"] = rollout_leg(args, dev)
         except Exception as e:      # a secondary key: reported in the line, the headline measurement stands
             out["rollout"] = {"error": repr(e)[:300]}
+    if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1 and not args.no_train_leg:
+        try:
+            out["finetune"] = finetune_leg(args, dev)
+        except Exception as e:      # a secondary key: reported in the line, the headline measurement stands
+            out["finetune"] = {"error": repr(e)[:300]}
     if not args.no_train_leg:
         # config 3's shape: the pre-training step on EVERY rank with the RCCL gradient exchange (whole-job samples/s)
         tl = train_leg_subprocess(args, n_gpus)

@@ -80,6 +80,12 @@ SIGNATURES = {
     "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_multi_grad_sumsq": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "gridmm_multi_adamw_step": [_vp, _vp, _i, _i, _f, _f, _i, _vp, _f, _vp],
+    "gridmm_xattn_layer_train_saved_bytes": [_i, _i, _i, _i],
+    "gridmm_xattn_layer_train_workspace": [_i, _i, _i, _i],
+    "gridmm_xattn_layer_train_fwd": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp,
+                                     ctypes.c_size_t, _i, _i, _i, _i, _vp],
+    "gridmm_xattn_layer_bwd": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, ctypes.c_size_t, _vp, _vp, _vp, _i64, _i,
+                               _vp, _vp, ctypes.c_size_t, _i, _i, _i, _i, _vp],
     # host-side helpers of the agent loop (no device work)
     "gridmm_route_lengths": [_vp, _i, _i, _vp, _vp, _vp, _i, _vp],
 }
@@ -107,6 +113,8 @@ def load():
         fn.restype = ctypes.c_int
     lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
     lib.gridmm_grid_aggregate_workspace.restype = ctypes.c_size_t
+    lib.gridmm_xattn_layer_train_saved_bytes.restype = ctypes.c_size_t
+    lib.gridmm_xattn_layer_train_workspace.restype = ctypes.c_size_t
     lib.gridmm_nav_heads_workspace.argtypes = [_i, _i, _i]
     lib.gridmm_nav_heads_workspace.restype = ctypes.c_size_t
     v = lib.gridmm_abi_version()

@@ -16,6 +16,7 @@ libgridmm_hip.so; torch only records the graph and moves/gathers/concatenates te
 
 There is no CPU / eager fallback: the functions raise on non-GPU tensors (ops._p).
 """
+import ctypes
 import math
 import weakref
 
@@ -686,3 +687,137 @@ def fuse_logits(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_n
     """-> (global, local, grid, fused) logits, -inf where masked."""
     return _FuseLogits.apply(g_raw, l_raw, grid_raw, fuse_raw, gmap_masks, gmap_visited, vp_nav_masks, cand_of_node,
                              cand_visited)
+
+
+# ------------------------------------------------------------------------------------------------
+# one cross-modal layer as ONE autograd node: gridmm_xattn_layer_train_fwd / gridmm_xattn_layer_bwd (csrc/layer_train.hip)
+# ------------------------------------------------------------------------------------------------
+class _CLinearTrain(ctypes.Structure):
+    _fields_ = [("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p), ("Kp", ctypes.c_int),
+                ("wt_hi", ctypes.c_void_p), ("wt_lo", ctypes.c_void_p), ("Np", ctypes.c_int),
+                ("bias", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
+class _CLnTrain(ctypes.Structure):
+    _fields_ = [("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float)]
+
+
+class _CXLayerTrain(ctypes.Structure):
+    _fields_ = [(n, _CLinearTrain) for n in ("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o")] + \
+               [(n, _CLnTrain) for n in ("x_ln", "s_ln", "f_ln")] + \
+               [("p_hidden", ctypes.c_float), ("p_attn", ctypes.c_float), ("seed", ctypes.c_ulonglong * 5),
+                ("seed_dev", ctypes.c_void_p)]
+
+
+class _CXLayerGrads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("xq_w", "xq_b", "xo_w", "xo_b", "sqkv_w", "sqkv_b", "so_w", "so_b", "ffn_i_w",
+                                                "ffn_i_b", "ffn_o_w", "ffn_o_b", "x_ln_g", "x_ln_b", "s_ln_g", "s_ln_b",
+                                                "f_ln_g", "f_ln_b")]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _XLayer(torch.autograd.Function):
+    """y = GraphLXRTXLayer(x | kv) (vilmodel.py:399-414): cross attention over the projected context, self attention, feed
+    forward -- forward and backward each ONE C call.  params: xq.w, xq.b, xo.w, xo.b, q.w, q.b, k.w, k.b, v.w, v.b, so.w, so.b,
+    ffn_i.w, ffn_i.b, ffn_o.w, ffn_o.b, x_ln.w, x_ln.b, s_ln.w, s_ln.b, f_ln.w, f_ln.b (22 tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, kv, ctx_mask, self_mask, k_col, heads, p_hidden, p_attn, eps, *params):
+        lib = _lib.load()
+        H = heads * 64
+        B, Sq = x.shape[:2]
+        Sk = kv.shape[1]
+        x2 = x.float().contiguous()
+        if kv.stride(2) != 1 or kv.dtype != torch.float32:
+            kv = kv.float().contiguous()
+        (xqw, xqb, xow, xob, qw, qb, kw, kb, vw, vb, sow, sob, fiw, fib, fow, fob, xg, xb, sg, sb, fg, fb) = params
+        qkvw = torch.cat([qw, kw, vw], 0)
+        qkvb = torch.cat([qb, kb, vb], 0)
+        I = fiw.shape[0]
+        keep = []                                   # planes / biases / masks the C struct points into
+
+        def lin(w, b):
+            get = WEIGHTS.getter(w)
+            pf, pt = get(False), get(True)
+            bb = b.detach().float().contiguous()
+            keep.extend([pf, pt, bb])
+            return _CLinearTrain(pf.hi.data_ptr(), pf.lo.data_ptr(), pf.Kp, pt.hi.data_ptr(), pt.lo.data_ptr(), pt.Kp,
+                                 bb.data_ptr(), w.shape[0], w.shape[1])
+
+        def lnp(g, b, e):
+            gg, bb = g.detach().float().contiguous(), b.detach().float().contiguous()
+            keep.extend([gg, bb])
+            return _CLnTrain(gg.data_ptr(), bb.data_ptr(), float(e))
+        draw = lambda on: hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item())) if on else 0   # noqa: E731
+        seeds = [draw(p_attn > 0), draw(p_hidden > 0), draw(p_attn > 0), draw(p_hidden > 0), draw(p_hidden > 0)]
+        seed_dev = SEED_DEV if ((p_attn > 0 or p_hidden > 0) and hs.MODE is not None) else None
+        L = _CXLayerTrain(lin(xqw, xqb), lin(xow, xob), lin(qkvw, qkvb), lin(sow, sob), lin(fiw, fib), lin(fow, fob),
+                          lnp(xg, xb, eps[0]), lnp(sg, sb, eps[1]), lnp(fg, fb, eps[2]), float(p_hidden), float(p_attn),
+                          (ctypes.c_ulonglong * 5)(*seeds), _ptr(seed_dev))
+
+        def u8(m):
+            if m is None:
+                return None
+            m = m.contiguous()
+            return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+        cm, sm = u8(ctx_mask), u8(self_mask)
+        saved = torch.empty(int(lib.gridmm_xattn_layer_train_saved_bytes(B, Sq, H, I)), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(int(lib.gridmm_xattn_layer_train_workspace(B, Sq, H, I)), dtype=torch.uint8, device=x.device)
+        y = torch.empty(B, Sq, H, dtype=torch.float32, device=x.device)
+        _lib.check(lib.gridmm_xattn_layer_train_fwd(
+            ctypes.byref(L), _p(x2), _p(kv), kv.stride(0), kv.stride(1), int(k_col), int(k_col) + H, _p(cm),
+            cm.stride(0) if cm is not None else 0, _p(sm), sm.stride(0) if sm is not None else 0, _p(y), _p(saved),
+            saved.numel(), _p(ws), ws.numel(), B, Sq, Sk, heads, _stream()), "gridmm_xattn_layer_train_fwd")
+        ctx.save_for_backward(x2, kv, cm, sm, saved)
+        ctx.L, ctx.keep, ctx.dims = L, keep, (B, Sq, Sk, H, I, heads, int(k_col))
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, kv, cm, sm, saved = ctx.saved_tensors
+        B, Sq, Sk, H, I, heads, k_col = ctx.dims
+        dev = dy.device
+        dy = dy.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = {"xq_w": torch.empty(H, H, **f32), "xq_b": torch.empty(H, **f32), "xo_w": torch.empty(H, H, **f32),
+             "xo_b": torch.empty(H, **f32), "sqkv_w": torch.empty(3 * H, H, **f32), "sqkv_b": torch.empty(3 * H, **f32),
+             "so_w": torch.empty(H, H, **f32), "so_b": torch.empty(H, **f32), "ffn_i_w": torch.empty(I, H, **f32),
+             "ffn_i_b": torch.empty(I, **f32), "ffn_o_w": torch.empty(H, I, **f32), "ffn_o_b": torch.empty(H, **f32)}
+        for n in ("x_ln_g", "x_ln_b", "s_ln_g", "s_ln_b", "f_ln_g", "f_ln_b"):
+            g[n] = torch.empty(H, **f32)
+        G = _CXLayerGrads(*[g[n].data_ptr() for n, _ in _CXLayerGrads._fields_])
+        dx = torch.empty_like(x2)
+        C = kv.shape[-1]
+        covered = (k_col == 0 and C == 2 * H)
+        dkv = (torch.empty if covered else torch.zeros)(B, Sk, C, **f32)    # K / V blocks of other layers: zero gradient here
+        ws = torch.empty(int(lib.gridmm_xattn_layer_train_workspace(B, Sq, H, I)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gridmm_xattn_layer_bwd(
+            ctypes.byref(ctx.L), _p(x2), _p(kv), kv.stride(0), kv.stride(1), k_col, k_col + H, _p(cm),
+            cm.stride(0) if cm is not None else 0, _p(sm), sm.stride(0) if sm is not None else 0, _p(saved), saved.numel(),
+            _p(dy), _p(dx), _p(dkv), Sk * C, C, ctypes.byref(G), _p(ws), ws.numel(), B, Sq, Sk, heads, _stream()),
+            "gridmm_xattn_layer_bwd")
+        qw, kw, vw = g["sqkv_w"].split(H, 0)
+        qb, kb, vb = g["sqkv_b"].split(H, 0)
+        grads = [g["xq_w"], g["xq_b"], g["xo_w"], g["xo_b"], qw, qb, kw, kb, vw, vb, g["so_w"], g["so_b"], g["ffn_i_w"],
+                 g["ffn_i_b"], g["ffn_o_w"], g["ffn_o_b"], g["x_ln_g"], g["x_ln_b"], g["s_ln_g"], g["s_ln_b"], g["f_ln_g"],
+                 g["f_ln_b"]]
+        grads = [gr if ctx.needs_input_grad[9 + i] else None for i, gr in enumerate(grads)]
+        return (dx, dkv, None, None, None, None, None, None, None) + tuple(grads)
+
+
+def x_layer_fused(x, kv, ctx_mask, self_mask, k_col, heads, p_hidden, p_attn, xatt, selfatt, inter, output):
+    """xatt: BertXAttention-like (.att.query, .output.dense, .output.LayerNorm); selfatt: BertAttention-like (.self.query /
+    key / value, .output.dense / LayerNorm); inter / output: BertIntermediate / BertOutput."""
+    s = selfatt.self
+    params = (xatt.att.query.weight, xatt.att.query.bias, xatt.output.dense.weight, xatt.output.dense.bias,
+              s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias,
+              selfatt.output.dense.weight, selfatt.output.dense.bias, inter.dense.weight, inter.dense.bias,
+              output.dense.weight, output.dense.bias, xatt.output.LayerNorm.weight, xatt.output.LayerNorm.bias,
+              selfatt.output.LayerNorm.weight, selfatt.output.LayerNorm.bias, output.LayerNorm.weight, output.LayerNorm.bias)
+    eps = (float(xatt.output.LayerNorm.eps), float(selfatt.output.LayerNorm.eps), float(output.LayerNorm.eps))
+    return _XLayer.apply(x, kv, ctx_mask, self_mask, k_col, heads, float(p_hidden), float(p_attn), eps, *params)

@@ -1,0 +1,237 @@
+// gridmm_xattn_layer_train_fwd / gridmm_xattn_layer_bwd: one GraphLXRTXLayer of the DIFFERENTIABLE path (fine-tune loop
+// map_nav_src/r2r/agent_base.py:164-211 through models/vilmodel.py:399-414; pre-training pretrain_src/model/
+// vilmodel.py:404-415) -- forward that keeps what the backward needs in one caller-provided block, and the whole backward of
+// the layer (3 LayerNorm backwards, 6 Linear backwards = 18 GEMMs + 6 transposing splits, 2 attention backwards, GELU') as
+// ONE C call: SURVEY.md 8b's gridmm_xattn_layer_bwd.  Like gridmm_xattn_layer_fwd these functions own no arithmetic: they
+// sequence the library's kernels on the caller's stream, in exactly the order (and with the same tile choices) as the
+// op-by-op autograd path of gridmm_amd/autograd.py, so outputs and gradients are bit-identical to it
+// (tests/test_hip_layer_train.py).  Hidden-state dropout rides on the LayerNorm kernels, attention-probability dropout
+// inside the attention kernels; the backward regenerates both masks from the seeds.
+#include "common.h"
+
+namespace {
+inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int mp32(int M) { return (M + 31) / 32 * 32; }
+
+// Layout of the saved block (forward writes, backward reads).  T planes: [C][Mp] hi then lo.
+struct Saved {
+  unsigned short *xT, *cT, *a1T, *c2T, *a2T, *gT;   // transposed planes of every Linear input
+  float *q, *c, *lse_x, *h1, *a1, *qkv, *c2, *lse_s, *h2, *a2, *f1, *h3;
+  size_t bytes;
+};
+
+Saved carve_saved(char* base, int B, int Sq, int H, int I, int heads) {
+  const size_t M = (size_t)B * Sq, Mp = mp32((int)M), Sqp = (Sq + 15) / 16 * 16;
+  char* w = base;
+  auto take = [&](size_t bytes) { char* p = w; w += a256(bytes); return p; };
+  Saved s;
+  s.xT = (unsigned short*)take((size_t)H * Mp * 4);
+  s.cT = (unsigned short*)take((size_t)H * Mp * 4);
+  s.a1T = (unsigned short*)take((size_t)H * Mp * 4);
+  s.c2T = (unsigned short*)take((size_t)H * Mp * 4);
+  s.a2T = (unsigned short*)take((size_t)H * Mp * 4);
+  s.gT = (unsigned short*)take((size_t)I * Mp * 4);
+  s.q = (float*)take(M * H * 4);
+  s.c = (float*)take(M * H * 4);
+  s.lse_x = (float*)take((size_t)B * heads * Sqp * 4);
+  s.h1 = (float*)take(M * H * 4);
+  s.a1 = (float*)take(M * H * 4);
+  s.qkv = (float*)take(M * 3 * H * 4);
+  s.c2 = (float*)take(M * H * 4);
+  s.lse_s = (float*)take((size_t)B * heads * Sqp * 4);
+  s.h2 = (float*)take(M * H * 4);
+  s.a2 = (float*)take(M * H * 4);
+  s.f1 = (float*)take(M * (size_t)I * 4);
+  s.h3 = (float*)take(M * H * 4);
+  s.bytes = (size_t)(w - base);
+  return s;
+}
+
+bool shapes_ok(const gridmm_xlayer_train_t* L, int H, int I) {
+  const gridmm_linear_train_t* ls[6] = {&L->xq, &L->xo, &L->sqkv, &L->so, &L->ffn_i, &L->ffn_o};
+  const int N[6] = {H, H, 3 * H, H, I, H}, K[6] = {H, H, H, H, H, I};
+  for (int i = 0; i < 6; ++i)
+    if (ls[i]->N != N[i] || ls[i]->K != K[i] || !ls[i]->w_hi || !ls[i]->w_lo || ls[i]->Kp < K[i]) return false;
+  return H % 32 == 0 && I % 32 == 0;
+}
+
+// y (M, N) fp32 = x W^T + b (+ R): the forward of autograd._Linear -- one pass over x writes its row planes (the GEMM's A
+// operand) and its transposed planes (kept for dW), then the plane GEMM.
+int linear_fwd(const gridmm_linear_train_t& l, const float* x, unsigned short* xT, unsigned short* rows, const float* R,
+               float* y, int M, int act, gridmm_stream_t st) {
+  const int K = l.K, Mp = mp32(M);
+  int rc = gridmm_transpose_split(x, K, xT, xT + (size_t)K * Mp, nullptr, nullptr, rows, rows + (size_t)M * K, K, M, K, Mp, st);
+  if (rc != GRIDMM_OK) return rc;
+  return gridmm_linear_planes(rows, rows + (size_t)M * K, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, nullptr,
+                              nullptr, 0, M, l.N, K, act, st);
+}
+
+// Backward of one Linear (autograd._Linear.backward): dY -> [one pass: row planes, transposed planes, column sums = db],
+// dX = dY W (+ Radd: the gradient arriving over another branch, summed in the GEMM epilogue), dW = dY^T X.
+struct LinWs { unsigned short *rows, *yT; float *cs_ws, *splitk; };
+int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned short* xT, const float* Radd, float* dX,
+               float* dW, float* db, int M, const LinWs& ws, gridmm_stream_t st) {
+  const int N = l.N, K = l.K, Mp = mp32(M);
+  int rc = gridmm_transpose_split(dY, N, ws.yT, ws.yT + (size_t)N * Mp, db, db ? ws.cs_ws : nullptr, dX ? ws.rows : nullptr,
+                                  dX ? ws.rows + (size_t)M * N : nullptr, N, M, N, Mp, st);
+  if (rc != GRIDMM_OK) return rc;
+  if (dX) {
+    if (!l.wt_hi || !l.wt_lo || l.Np < N) return GRIDMM_EINVAL;
+    rc = gridmm_linear_planes(ws.rows, ws.rows + (size_t)M * N, N, l.wt_hi, l.wt_lo, l.Np, nullptr, Radd, Radd ? K : 0, dX, K,
+                              nullptr, nullptr, 0, M, K, N, GRIDMM_ACT_NONE, st);
+    if (rc != GRIDMM_OK) return rc;
+  }
+  if (dW) {
+    // few output tiles, long contraction: split the M rows over enough workgroups to fill the chip (autograd._gemm_tn)
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int splits = 1;
+    if (tiles <= 36) {
+      splits = 288 / tiles;
+      if (splits > 8) splits = 8;
+      if (splits > Mp / 256) splits = Mp / 256;
+      if (splits < 1) splits = 1;
+    }
+    if (splits > 1)
+      rc = gridmm_linear_planes_splitk(ws.yT, ws.yT + (size_t)N * Mp, Mp, xT, xT + (size_t)K * Mp, Mp, dW, ws.splitk, N, K, Mp,
+                                       splits, st);
+    else
+      rc = gridmm_linear_planes(ws.yT, ws.yT + (size_t)N * Mp, Mp, xT, xT + (size_t)K * Mp, Mp, nullptr, nullptr, 0, dW, K,
+                                nullptr, nullptr, 0, N, K, Mp, GRIDMM_ACT_NONE, st);
+  }
+  return rc;
+}
+}  // namespace
+
+extern "C" size_t gridmm_xattn_layer_train_saved_bytes(int B, int Sq, int H, int I) {
+  return carve_saved(nullptr, B, Sq, H, I, H / 64).bytes;
+}
+
+// forward scratch: row planes of the widest Linear input (M x I, hi + lo); backward: see below
+extern "C" size_t gridmm_xattn_layer_train_workspace(int B, int Sq, int H, int I) {
+  const size_t M = (size_t)B * Sq, Mp = mp32((int)M), W = (size_t)(I > 3 * H ? I : 3 * H);
+  const size_t rows = a256(M * W * 4), yT = a256(W * Mp * 4), cs = a256(((Mp + 255) / 256) * W * 4);
+  const size_t splitk = a256((size_t)8 * H * (I > 3 * H ? I : 3 * H) * 4);
+  const size_t lnws = a256((M + 3) / 4 * 2 * H * 4), delta = a256((size_t)B * (H / 64) * ((Sq + 15) / 16 * 16) * 4);
+  // gradients in flight: dh (M,H) x2, da (M,H) x2, dc (M,H), dqkv (M,3H), dg (M,I), df1 (M,I)
+  const size_t grads = a256(M * H * 4) * 5 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) * 2;
+  return rows + yT + cs + splitk + lnws + delta + grads + 4096;
+}
+
+extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, int64_t kv_bs,
+                                            int kv_rs, int k_col, int v_col, const uint8_t* ctx_mask, int ctx_mask_bs,
+                                            const uint8_t* self_mask, int self_mask_bs, float* Y, void* saved,
+                                            size_t saved_bytes, void* workspace, size_t workspace_bytes, int B, int Sq,
+                                            int Sk, int heads, gridmm_stream_t stream) {
+  if (!L || !X || !KV || !Y || !saved || !workspace || B <= 0 || Sq <= 0 || Sk <= 0 || heads <= 0) return GRIDMM_EINVAL;
+  const int H = heads * 64, I = L->ffn_i.N, M = B * Sq, Sqp = (Sq + 15) / 16 * 16;
+  if (!shapes_ok(L, H, I)) return GRIDMM_EINVAL;
+  if (saved_bytes < gridmm_xattn_layer_train_saved_bytes(B, Sq, H, I) ||
+      workspace_bytes < gridmm_xattn_layer_train_workspace(B, Sq, H, I))
+    return GRIDMM_EINVAL;
+  Saved s = carve_saved((char*)saved, B, Sq, H, I, heads);
+  unsigned short* rows = (unsigned short*)workspace;          // row planes of the current Linear input (scratch)
+  float* g = (float*)((char*)workspace + a256((size_t)M * (I > 3 * H ? I : 3 * H) * 4));   // gelu output (M, I)
+  const float scale = 0.125f;
+  const float ph = L->p_hidden, pa = L->p_attn;
+  int rc;
+#define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
+  auto ln = [&](const float* x, const float* r, const gridmm_ln_t& p, unsigned long long seed, float* y) {
+    if (ph > 0.f) return gridmm_layernorm_dropout(x, r, H, p.gamma, p.beta, p.eps, y, ph, seed, L->seed_dev, M, H, stream);
+    return gridmm_layernorm(x, H, r, H, p.gamma, p.beta, p.eps, y, H, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, M, H,
+                            stream);
+  };
+  // ---- cross attention (vilmodel.py:370-379)
+  GRIDMM_TRY(linear_fwd(L->xq, X, s.xT, rows, nullptr, s.q, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(gridmm_attention_train(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs, ctx_mask,
+                                    ctx_mask_bs, s.c, (int64_t)Sq * H, H, s.lse_x, Sqp, B, heads, Sq, Sk, scale, pa,
+                                    L->seed[0], L->seed_dev, stream));
+  GRIDMM_TRY(linear_fwd(L->xo, s.c, s.cT, rows, nullptr, s.h1, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(ln(s.h1, X, L->x_ln, L->seed[1], s.a1));
+  // ---- self attention (vilmodel.py:172-182)
+  GRIDMM_TRY(linear_fwd(L->sqkv, s.a1, s.a1T, rows, nullptr, s.qkv, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(gridmm_attention_train(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H, s.qkv + 2 * H,
+                                    (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2, (int64_t)Sq * H, H, s.lse_s,
+                                    Sqp, B, heads, Sq, Sq, scale, pa, L->seed[2], L->seed_dev, stream));
+  GRIDMM_TRY(linear_fwd(L->so, s.c2, s.c2T, rows, nullptr, s.h2, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(ln(s.h2, s.a1, L->s_ln, L->seed[3], s.a2));
+  // ---- feed forward (vilmodel.py:184-209)
+  GRIDMM_TRY(linear_fwd(L->ffn_i, s.a2, s.a2T, rows, nullptr, s.f1, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(gridmm_activation(s.f1, nullptr, g, (int64_t)M * I, 0, stream));
+  GRIDMM_TRY(linear_fwd(L->ffn_o, g, s.gT, rows, nullptr, s.h3, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(ln(s.h3, s.a2, L->f_ln, L->seed[4], Y));
+#undef GRIDMM_TRY
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, int64_t kv_bs,
+                                      int kv_rs, int k_col, int v_col, const uint8_t* ctx_mask, int ctx_mask_bs,
+                                      const uint8_t* self_mask, int self_mask_bs, const void* saved, size_t saved_bytes,
+                                      const float* dY, float* dX, float* dKV, int64_t dkv_bs, int dkv_rs,
+                                      const gridmm_xlayer_grads_t* G, void* workspace, size_t workspace_bytes, int B, int Sq,
+                                      int Sk, int heads, gridmm_stream_t stream) {
+  if (!L || !X || !KV || !saved || !dY || !dX || !dKV || !G || !workspace || B <= 0 || Sq <= 0 || Sk <= 0 || heads <= 0)
+    return GRIDMM_EINVAL;
+  const int H = heads * 64, I = L->ffn_i.N, M = B * Sq, Mp = mp32(M), Sqp = (Sq + 15) / 16 * 16;
+  if (!shapes_ok(L, H, I)) return GRIDMM_EINVAL;
+  if (saved_bytes < gridmm_xattn_layer_train_saved_bytes(B, Sq, H, I) ||
+      workspace_bytes < gridmm_xattn_layer_train_workspace(B, Sq, H, I))
+    return GRIDMM_EINVAL;
+  Saved s = carve_saved((char*)saved, B, Sq, H, I, heads);
+  const size_t W = (size_t)(I > 3 * H ? I : 3 * H);
+  char* w = (char*)workspace;
+  auto take = [&](size_t bytes) { char* p = w; w += a256(bytes); return p; };
+  LinWs lw;
+  lw.rows = (unsigned short*)take((size_t)M * W * 4);
+  lw.yT = (unsigned short*)take(W * Mp * 4);
+  lw.cs_ws = (float*)take(((Mp + 255) / 256) * W * 4);
+  lw.splitk = (float*)take((size_t)8 * H * W * 4);
+  float* lnws = (float*)take((size_t)(M + 3) / 4 * 2 * H * 4);
+  float* delta = (float*)take((size_t)B * heads * Sqp * 4);
+  float* dh = (float*)take((size_t)M * H * 4);      // gradient of a pre-LayerNorm sum
+  float* dr = (float*)take((size_t)M * H * 4);      // gradient of the LayerNorm's residual input
+  float* da = (float*)take((size_t)M * H * 4);      // gradient of a block output (both branches summed)
+  float* da_b = (float*)take((size_t)M * H * 4);
+  float* dc = (float*)take((size_t)M * H * 4);      // gradient of an attention output
+  float* dqkv = (float*)take((size_t)M * 3 * H * 4);
+  float* dg = (float*)take((size_t)M * I * 4);
+  float* df1 = (float*)take((size_t)M * I * 4);
+  const float scale = 0.125f;
+  const float ph = L->p_hidden, pa = L->p_attn;
+  int rc;
+#define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
+  // LN backward: dx = gradient of the (dropped-out) dense output, dres = gradient of the residual input
+  auto ln_bwd = [&](const float* x, const float* r, const gridmm_ln_t& p, unsigned long long seed, const float* dy, float* dx,
+                    float* dres, float* dgm, float* dbt) {
+    if (ph > 0.f)
+      return gridmm_layernorm_dropout_bwd(x, r, H, p.gamma, p.eps, dy, dx, dres, dgm, dbt, lnws, ph, seed, L->seed_dev, M, H, stream);
+    return gridmm_layernorm_bwd(x, H, r, H, p.gamma, p.eps, dy, H, dx, H, dgm, dbt, lnws, M, H, stream);
+  };
+  // without dropout the residual's gradient IS dx (one buffer)
+  auto res_of = [&](float* dx, float* dres) { return ph > 0.f ? dres : dx; };
+
+  // ---- feed forward
+  GRIDMM_TRY(ln_bwd(s.h3, s.a2, L->f_ln, L->seed[4], dY, dh, dr, G->f_ln_g, G->f_ln_b));
+  GRIDMM_TRY(linear_bwd(L->ffn_o, dh, s.gT, nullptr, dg, G->ffn_o_w, G->ffn_o_b, M, lw, stream));
+  GRIDMM_TRY(gridmm_activation(s.f1, dg, df1, (int64_t)M * I, 1, stream));
+  GRIDMM_TRY(linear_bwd(L->ffn_i, df1, s.a2T, res_of(dh, dr), da, G->ffn_i_w, G->ffn_i_b, M, lw, stream));   // da = d a2
+  // ---- self attention
+  GRIDMM_TRY(ln_bwd(s.h2, s.a1, L->s_ln, L->seed[3], da, dh, dr, G->s_ln_g, G->s_ln_b));
+  GRIDMM_TRY(linear_bwd(L->so, dh, s.c2T, nullptr, dc, G->so_w, G->so_b, M, lw, stream));
+  GRIDMM_TRY(gridmm_attention_bwd(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H, s.qkv + 2 * H,
+                                  (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2, (int64_t)Sq * H, H, dc,
+                                  (int64_t)Sq * H, H, s.lse_s, delta, dqkv, (int64_t)Sq * 3 * H, 3 * H, dqkv + H,
+                                  (int64_t)Sq * 3 * H, 3 * H, dqkv + 2 * H, (int64_t)Sq * 3 * H, 3 * H, B, heads, Sq, Sq, Sqp,
+                                  scale, pa, L->seed[2], L->seed_dev, stream));
+  GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), da_b, G->sqkv_w, G->sqkv_b, M, lw, stream));   // da_b = d a1
+  // ---- cross attention
+  GRIDMM_TRY(ln_bwd(s.h1, X, L->x_ln, L->seed[1], da_b, dh, dr, G->x_ln_g, G->x_ln_b));
+  GRIDMM_TRY(linear_bwd(L->xo, dh, s.cT, nullptr, dc, G->xo_w, G->xo_b, M, lw, stream));
+  float* dq = da;                                   // (M, H) scratch: the gradient of the query projection
+  GRIDMM_TRY(gridmm_attention_bwd(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs, ctx_mask,
+                                  ctx_mask_bs, s.c, (int64_t)Sq * H, H, dc, (int64_t)Sq * H, H, s.lse_x, delta, dq,
+                                  (int64_t)Sq * H, H, dKV + k_col, dkv_bs, dkv_rs, dKV + v_col, dkv_bs, dkv_rs, B, heads, Sq,
+                                  Sk, Sqp, scale, pa, L->seed[0], L->seed_dev, stream));
+  GRIDMM_TRY(linear_bwd(L->xq, dq, s.xT, res_of(dh, dr), dX, G->xq_w, G->xq_b, M, lw, stream));
+#undef GRIDMM_TRY
+  return GRIDMM_OK;
+}

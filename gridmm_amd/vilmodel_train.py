@@ -78,8 +78,18 @@ def bert_layer(model, layer, x, kmask):
     return ffn_block(model, layer.intermediate, layer.output, self_attention_block(model, layer.attention, x, kmask))
 
 
+FUSED_XLAYER = True     # a whole cross-modal layer as ONE autograd node (ag.x_layer_fused: one C call forward, one backward)
+
+
+def _fusable(model, x, inter):
+    return FUSED_XLAYER and x.is_cuda and x.shape[-1] == model.heads * 64 and inter.dense.weight.shape[0] % 32 == 0
+
+
 def x_layer(model, layer, ctx_kv, ctx_mask, visn, visn_mask, kv_col=0):
     """GraphLXRTXLayer.forward, graph_sprels=None (:399-414)."""
+    if _fusable(model, visn, layer.visn_inter):
+        return ag.x_layer_fused(visn, ctx_kv, ctx_mask, visn_mask, kv_col, model.heads, _hidden_p(model), _attn_p(model),
+                                layer.visual_attention, layer.visn_self_att, layer.visn_inter, layer.visn_output)
     a = cross_attention_block(model, layer.visual_attention, visn, ctx_kv, ctx_mask, kv_col)
     a = self_attention_block(model, layer.visn_self_att, a, visn_mask)
     return ffn_block(model, layer.visn_inter, layer.visn_output, a)
@@ -89,6 +99,9 @@ def lang2visn_layer(model, layer, lang, lang_mask, visn, visn_mask):
     """GraphLXRTXLayer.forward_lang2visn (:416-427): text attends to vision, then text self-attention + FFN."""
     xa = layer.visual_attention
     kv = _cat_linear(visn, [xa.att.key, xa.att.value])
+    if _fusable(model, lang, layer.lang_inter):
+        return ag.x_layer_fused(lang, kv, visn_mask, lang_mask, 0, model.heads, _hidden_p(model), _attn_p(model),
+                                xa, layer.lang_self_att, layer.lang_inter, layer.lang_output)
     a = cross_attention_block(model, xa, lang, kv, visn_mask)
     a = self_attention_block(model, layer.lang_self_att, a, lang_mask)
     return ffn_block(model, layer.lang_inter, layer.lang_output, a)

@@ -511,6 +511,49 @@ int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tens
 int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float beta1,
                             float beta2, int decay_first, const float* sumsq, float max_norm, gridmm_stream_t stream);
 
+/* ---- one cross-modal layer of the DIFFERENTIABLE path: forward that keeps what the backward needs + the whole backward
+ * of the layer as ONE call (gridmm_xattn_layer_bwd).  GraphLXRTXLayer.forward with graph_sprels = None
+ * (map_nav_src/models/vilmodel.py:399-414, pretrain_src/model/vilmodel.py:404-415) under torch autograd in the reference
+ * (agent_base.py:199 / train_r2r.py:262).  Exact-fp32 attention (gridmm_attention_train / _bwd), bf16x3 GEMMs; hidden-state
+ * dropout inside the LayerNorm kernels (p_hidden), attention-probability dropout inside the attention kernels (p_attn);
+ * seed[0..4] = cross-attention probabilities, cross LayerNorm, self-attention probabilities, self LayerNorm, FFN LayerNorm
+ * (+ seed_dev, the per-replay word of a captured step).  The kernels, their order and their tile choices are those of the
+ * op-by-op path (gridmm_amd/autograd.py): outputs and gradients are bit-identical to it.
+ *   X   [B*Sq][H] fp32 tokens; KV [B][Sk][.] fp32 context projections (K at k_col, V at v_col; row stride kv_rs, episode
+ *       stride kv_bs, in elements); masks as in gridmm_attention; Y [B*Sq][H] fp32 out.
+ *   saved      caller-provided block (>= gridmm_xattn_layer_train_saved_bytes) the forward fills and the backward reads
+ *   workspace  >= gridmm_xattn_layer_train_workspace bytes (both calls), 256-byte aligned
+ *   backward:  dY [B*Sq][H] -> dX [B*Sq][H], dKV (K / V gradients written at k_col / v_col of a buffer with strides dkv_bs /
+ *              dkv_rs; other columns untouched), and the parameter gradients of gridmm_xlayer_grads_t (dense [N][K] / [N] /
+ *              [H] fp32, overwritten). */
+typedef struct {
+  const void *w_hi, *w_lo; int Kp;      /* planes of W  [N][Kp]  (forward GEMM) */
+  const void *wt_hi, *wt_lo; int Np;    /* planes of W^T [K][Np] (dX GEMM; only the backward reads them) */
+  const float* bias; int N, K;
+} gridmm_linear_train_t;
+typedef struct {
+  gridmm_linear_train_t xq, xo, sqkv, so, ffn_i, ffn_o;
+  gridmm_ln_t x_ln, s_ln, f_ln;
+  float p_hidden, p_attn;
+  unsigned long long seed[5];
+  const unsigned long long* seed_dev;
+} gridmm_xlayer_train_t;
+typedef struct {
+  float *xq_w, *xq_b, *xo_w, *xo_b, *sqkv_w, *sqkv_b, *so_w, *so_b, *ffn_i_w, *ffn_i_b, *ffn_o_w, *ffn_o_b;
+  float *x_ln_g, *x_ln_b, *s_ln_g, *s_ln_b, *f_ln_g, *f_ln_b;
+} gridmm_xlayer_grads_t;
+size_t gridmm_xattn_layer_train_saved_bytes(int B, int Sq, int H, int I);
+size_t gridmm_xattn_layer_train_workspace(int B, int Sq, int H, int I);
+int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, int64_t kv_bs, int kv_rs,
+                                 int k_col, int v_col, const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask,
+                                 int self_mask_bs, float* Y, void* saved, size_t saved_bytes, void* workspace,
+                                 size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream);
+int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, int64_t kv_bs, int kv_rs,
+                           int k_col, int v_col, const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask,
+                           int self_mask_bs, const void* saved, size_t saved_bytes, const float* dY, float* dX, float* dKV,
+                           int64_t dkv_bs, int dkv_rs, const gridmm_xlayer_grads_t* G, void* workspace,
+                           size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Host-side helpers of the agent loop's collation (HOST pointers, no device work, no stream)
  * ---------------------------------------------------------------------------------------- */

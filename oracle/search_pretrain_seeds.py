@@ -1,0 +1,41 @@
+"""(test infrastructure; needs /root/reference) Search for the batch seed of the reduced mrc fixtures of
+oracle/gen_golden.py (pretrain_reduced.npz / pretrain_reduced_obj.npz): RegionClassification holds a ReLU
+(pretrain_src/model/pretrain_cmt.py:15-18) and a pre-activation within ~1e-4 of zero flips its gate between two correct
+implementations, which moves that sample's gradients by percents.  A fixture whose pre-activations all clear the gate by a
+margin lets the mrc gradients be pinned elementwise like every other task's.
+usage: python -m oracle.search_pretrain_seeds [n_seeds]      prints the best seed (largest min |pre-activation|) per fixture"""
+import sys
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import numpy as np
+import torch
+
+from oracle import gen_golden as G, ref_harness as R
+
+
+def gate_margin(model, batch):
+    gaps = []
+    hooks = []
+    for head in (model.image_classifier, getattr(model, "obj_classifier", None)):
+        if head is not None:
+            hooks.append(head.net[1].register_forward_pre_hook(lambda m, x: gaps.append(float(x[0].detach().abs().min()))))
+    with torch.no_grad():
+        model(batch, task="mrc", compute_loss=True)
+    for h in hooks:
+        h.remove()
+    return min(gaps)
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    torch.set_num_threads(4)
+    for with_obj in (False, True):
+        model = R.build_ref_pretrain_model(seed=9, **(dict(G.PRETRAIN_OBJ) if with_obj else {})).train()
+        best = (0.0, None)
+        for seed in range(12, 12 + n):
+            G.PRETRAIN_SEEDS["mrc"] = seed
+            m = gate_margin(model, G.pretrain_batch("mrc", with_obj))
+            if m > best[0]:
+                best = (m, seed)
+                print("with_obj=%s seed %d: min |pre-activation| %.3e" % (with_obj, seed, m), flush=True)
+        print("BEST with_obj=%s: seed %d margin %.3e" % (with_obj, best[1], best[0]), flush=True)

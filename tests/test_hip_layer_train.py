@@ -1,0 +1,134 @@
+"""GPU: gridmm_xattn_layer_train_fwd / gridmm_xattn_layer_bwd (one cross-modal layer of the differentiable
+path, forward and the WHOLE backward as one C call each) against the op-by-op autograd path over the same kernels
+(gridmm_amd/vilmodel_train.py with FUSED_XLAYER off).  Same kernels, same order, same tiles -> outputs and every gradient
+must be bit-identical; the op-by-op path itself is pinned against the reference's gradients in tests/test_hip_pretrain.py.
+Reference layer: map_nav_src/models/vilmodel.py:399-427, pretrain_src/model/vilmodel.py:404-415."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(inter=256, lang2visn=False, seed=0):
+    from gridmm_amd.vilmodel import GraphLXRTXLayer, default_config
+    cfg = default_config(intermediate_size=inter, use_lang2visn_attn=lang2visn)
+    torch.manual_seed(seed)
+    layer = GraphLXRTXLayer(cfg).cuda()
+    for p in layer.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    return layer
+
+
+def _model(p_hidden, p_attn, training=True):
+    cfg = types.SimpleNamespace(hidden_dropout_prob=p_hidden, attention_probs_dropout_prob=p_attn)
+    return types.SimpleNamespace(heads=12, config=cfg, training=training)
+
+
+def _run(fused, layer, model, x, kv_all, kv_col, ctx_mask, self_mask, dy, lang=False, seed=11):
+    from gridmm_amd import vilmodel_train as VT
+    VT.FUSED_XLAYER = fused
+    try:
+        for p in layer.parameters():
+            p.grad = None
+        x = x.clone().requires_grad_()
+        kv_all = kv_all.clone().requires_grad_()
+        torch.manual_seed(seed)                      # the dropout seeds come from torch's CPU generator, in call order
+        if lang:
+            y = VT.lang2visn_layer(model, layer, x, self_mask, kv_all, ctx_mask)      # kv_all = the vision tokens here
+        else:
+            H = x.shape[-1]
+            kv = kv_all if kv_col is None else kv_all
+            y = VT.x_layer(model, layer, kv, ctx_mask, x, self_mask, kv_col=0 if kv_col is None else kv_col)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None}
+        return y.detach().clone(), x.grad.clone(), kv_all.grad.clone(), grads
+    finally:
+        VT.FUSED_XLAYER = True
+
+
+@pytest.mark.parametrize("B,Sq,Sk,kv_cols,kv_col,p", [(3, 57, 120, 2, 0, 0.0), (2, 37, 296, 8, 2 * 768 * 2, 0.0), (4, 20, 64, 2, 0, 0.1),
+                                                       (2, 216, 80, 4, 2 * 768, 0.1)])
+def test_fused_layer_equals_op_by_op_bitwise(B, Sq, Sk, kv_cols, kv_col, p):
+    H = 768
+    layer = _layer()
+    model = _model(p, p)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, Sq, H, device="cuda", generator=g)
+    kv_all = torch.randn(B, Sk, kv_cols * H, device="cuda", generator=g)
+    ctx_mask = torch.arange(Sk, device="cuda")[None] < torch.tensor([Sk - 7 * b for b in range(B)], device="cuda")[:, None]
+    self_mask = torch.arange(Sq, device="cuda")[None] < torch.tensor([Sq - 3 * b for b in range(B)], device="cuda")[:, None]
+    dy = torch.randn(B, Sq, H, device="cuda", generator=g)
+    a = _run(False, layer, model, x, kv_all, kv_col, ctx_mask, self_mask, dy)
+    b = _run(True, layer, model, x, kv_all, kv_col, ctx_mask, self_mask, dy)
+    assert torch.isfinite(b[0]).all()
+    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
+    assert torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
+    assert torch.equal(a[2], b[2]), float((a[2] - b[2]).abs().max())
+    assert set(a[3]) == set(b[3]) and len(a[3]) == 22
+    for n in a[3]:
+        assert torch.equal(a[3][n], b[3][n]), (n, float((a[3][n] - b[3][n]).abs().max()))
+    if p > 0:                                        # another seed -> other masks (the dropout is really applied)
+        c = _run(True, layer, model, x, kv_all, kv_col, ctx_mask, self_mask, dy, seed=12)
+        assert not torch.equal(b[0], c[0])
+
+
+def test_fused_lang2visn_layer_equals_op_by_op_bitwise():
+    """The text-side twin of the pre-training model (forward_lang2visn, vilmodel.py:416-427): the text attends to the vision
+    tokens through the SAME visual_attention weights, then lang_self_att + lang FFN."""
+    H, B, L, S = 768, 3, 40, 77
+    layer = _layer(lang2visn=True)
+    model = _model(0.0, 0.0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    lang = torch.randn(B, L, H, device="cuda", generator=g)
+    visn = torch.randn(B, S, H, device="cuda", generator=g)
+    lang_mask = torch.arange(L, device="cuda")[None] < torch.tensor([L, L - 5, L - 11], device="cuda")[:, None]
+    visn_mask = torch.arange(S, device="cuda")[None] < torch.tensor([S, S - 9, S - 30], device="cuda")[:, None]
+    dy = torch.randn(B, L, H, device="cuda", generator=g)
+    a = _run(False, layer, model, lang, visn, None, visn_mask, lang_mask, dy, lang=True)
+    b = _run(True, layer, model, lang, visn, None, visn_mask, lang_mask, dy, lang=True)
+    for i in range(3):
+        assert torch.equal(a[i], b[i]), (i, float((a[i] - b[i]).abs().max()))
+    assert set(a[3]) == set(b[3])
+    for n in a[3]:
+        assert torch.equal(a[3][n], b[3][n]), (n, float((a[3][n] - b[3][n]).abs().max()))
+
+
+def test_fused_layer_matches_fp64_torch_reference():
+    """Independent of the op-by-op path: the fused layer against a plain fp64 torch restatement of the layer."""
+    import torch.nn.functional as F
+    H, B, Sq, Sk = 768, 2, 30, 50
+    layer = _layer(inter=128)
+    model = _model(0.0, 0.0)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(B, Sq, H, device="cuda", generator=g) * 0.5
+    kv = torch.randn(B, Sk, 2 * H, device="cuda", generator=g) * 0.5
+    cm = torch.arange(Sk, device="cuda")[None] < torch.tensor([Sk, Sk - 13], device="cuda")[:, None]
+    sm = torch.arange(Sq, device="cuda")[None] < torch.tensor([Sq, Sq - 4], device="cuda")[:, None]
+    dy = torch.randn(B, Sq, H, device="cuda", generator=g)
+    y, dx, dkv, grads = _run(True, layer, model, x, kv, 0, cm, sm, dy)
+
+    L64 = _layer(inter=128).double()
+    L64.load_state_dict({k: v.double() for k, v in layer.state_dict().items()})
+    x64, kv64 = x.double().requires_grad_(), kv.double().requires_grad_()
+
+    def attn(q, k, v, mask):
+        sh = lambda t: t.view(t.shape[0], t.shape[1], 12, 64).transpose(1, 2)        # noqa: E731
+        s = sh(q) @ sh(k).transpose(-1, -2) / 8.0
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+        return (torch.softmax(s, -1) @ sh(v)).transpose(1, 2).reshape(q.shape)
+    xa, sa = L64.visual_attention, L64.visn_self_att
+    q = xa.att.query(x64)
+    a1 = xa.output.LayerNorm(xa.output.dense(attn(q, kv64[..., :H], kv64[..., H:], cm)) + x64)
+    s = sa.self
+    a2 = sa.output.LayerNorm(sa.output.dense(attn(s.query(a1), s.key(a1), s.value(a1), sm)) + a1)
+    y64 = L64.visn_output.LayerNorm(L64.visn_output.dense(F.gelu(L64.visn_inter.dense(a2))) + a2)
+    y64.backward(dy.double())
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-12))    # noqa: E731
+    assert rel(y, y64.detach()) < 2e-5
+    assert rel(dx, x64.grad) < 1e-4 and rel(dkv, kv64.grad) < 1e-4
+    for n, p in L64.named_parameters():
+        if p.grad is not None:
+            assert rel(grads[n], p.grad) < 2e-4, n
