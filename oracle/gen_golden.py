@@ -365,7 +365,12 @@ def gen_nav_vlnce(full=False):
     print(name, "ok", tuple(fused.shape))
 
 
-PRETRAIN_SEEDS = {"mlm": 11, "mrc": 12, "sap": 13}
+# mrc: RegionClassification holds a ReLU (pretrain_cmt.py:15-18); the batch seeds below are the ones (of 400 tried,
+# oracle/search_pretrain_seeds.py) whose pre-activations all clear the gate by >= 1.05e-3 (views) / 6.6e-4 (views + objects),
+# so that no gate can flip between two correct implementations and the mrc gradients are pinned elementwise like the rest
+PRETRAIN_SEEDS = {"mlm": 11, "mrc": 371, "sap": 13}
+PRETRAIN_SEEDS_OBJ = {"mrc": 147}
+PRETRAIN_FULL_SEEDS = {"mlm": 211, "mrc": 212, "sap": 213}      # pretrain_full_b2.npz (unchanged since round 2)
 GRAD_SAMPLES = 48
 
 
@@ -375,7 +380,8 @@ PRETRAIN_OBJ = dict(obj_feat_size=768, obj_prob_size=30, pretrain_tasks=["mrc", 
 def pretrain_batch(task, with_obj=False):
     """The batches of pretrain_reduced{,_obj}.npz, regenerated identically by the tests (inputs are not stored)."""
     if with_obj:
-        return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS.get(task, 14) + 100), 3, task, with_obj=True,
+        return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS_OBJ.get(task, PRETRAIN_SEEDS.get(task, 14)) + 100), 3,
+                                     task, with_obj=True,
                                      obj_feat_size=PRETRAIN_OBJ["obj_feat_size"], obj_prob_size=PRETRAIN_OBJ["obj_prob_size"])
     return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS[task]), 3, task)
 
@@ -387,7 +393,7 @@ PRETRAIN_FULL = dict(num_l_layers=9, num_pano_layers=2, num_x_layers=4, intermed
 
 def pretrain_full_batch(task):
     """The batches of pretrain_full_b2.npz (B = 2, L = 40, up to 4 steps, 300-900 grid points), regenerated by the tests."""
-    return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_SEEDS[task] + 200), 2, task, max_steps=4, L=40, vocab=30522,
+    return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_FULL_SEEDS[task]), 2, task, max_steps=4, L=40, vocab=30522,
                                  image_prob_size=1000, n_pts=(300, 900))
 
 

@@ -34,6 +34,7 @@ if __name__ == "__main__":
         best = (0.0, None)
         for seed in range(12, 12 + n):
             G.PRETRAIN_SEEDS["mrc"] = seed
+            G.PRETRAIN_SEEDS_OBJ["mrc"] = seed
             m = gate_margin(model, G.pretrain_batch("mrc", with_obj))
             if m > best[0]:
                 best = (m, seed)

@@ -129,6 +129,8 @@ def test_fused_layer_matches_fp64_torch_reference():
     rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-12))    # noqa: E731
     assert rel(y, y64.detach()) < 2e-5
     assert rel(dx, x64.grad) < 1e-4 and rel(dkv, kv64.grad) < 1e-4
+    scale = max(float(p.grad.abs().max()) for p in L64.parameters() if p.grad is not None)
     for n, p in L64.named_parameters():
-        if p.grad is not None:
-            assert rel(grads[n], p.grad) < 2e-4, n
+        if p.grad is not None:      # (the key bias has an exactly-zero gradient: softmax is shift invariant -- absolute floor)
+            err = float((grads[n].double() - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-4 * scale)
+            assert err < 2e-4, (n, err)

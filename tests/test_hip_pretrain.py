@@ -10,11 +10,11 @@ measured 0.4-1.5 %): the reference takes the instruction-relevance product, grid
 rounding level, which moves a few arg-max routes of the max over tokens, and text_proj is the only parameter whose whole
 gradient flows through that routing.
 
-mrc: RegionClassification holds a ReLU (pretrain_cmt.py:15-18) and one of its 7680 pre-activations in this fixture sits
-within 1e-4 of zero: perturbing the REFERENCE's own weights by 1e-4 relative moves its mrc gradients by 2-8 %
-(image_classifier.net.0.weight 7.8 %, measured with oracle/ref_harness in the build container) while mlm / sap move by
-< 1e-3.  The fp16-vs-fp32 difference above is of that size, so for mrc the elementwise bound is 1e-1 and the binding
-check is the cosine between all sampled gradient entries (> 0.999).
+mrc: RegionClassification holds a ReLU (pretrain_cmt.py:15-18).  In rounds 1-3 one of the 7680 pre-activations of the
+reduced fixture sat within 1e-4 of zero (perturbing the REFERENCE's own weights by 1e-4 relative moved its mrc gradients by
+2-8 %), and mrc was checked at 1e-1 + cosine.  Round 4 regenerated the reduced mrc fixtures from batch seeds whose
+pre-activations all clear the gate by >= 1.05e-3 / 6.6e-4 (oracle/search_pretrain_seeds.py, gen_golden.PRETRAIN_SEEDS): no
+gate can flip, and mrc is pinned elementwise at 5e-3 like every other task (the cosine check stays).
 """
 import json
 
@@ -87,9 +87,8 @@ def test_pretrain_losses_and_gradients_match_reference(task, with_obj):
         en = abs(float(g.norm()) - float(n_ref)) / max(float(n_ref), 1e-3 * scale)
         errs += [(e, k), (en, k + " [norm]")]
     errs.sort(reverse=True)
-    gate_flip = task == "mrc" and not full       # the reduced mrc fixtures: a ReLU pre-activation within 1e-4 of zero (see above)
     for e, k in errs:
-        bound = 1e-1 if gate_flip else (2e-2 if "text_proj" in k else 5e-3)
+        bound = 2e-2 if "text_proj" in k else 5e-3
         assert e < bound, (k, e, errs[:8])
     a, b = np.concatenate(got_all).astype(np.float64), np.concatenate(ref_all).astype(np.float64)
     cos = float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
