@@ -88,6 +88,8 @@ SIGNATURES = {
                                _vp, _vp, ctypes.c_size_t, _i, _i, _i, _i, _vp],
     # host-side helpers of the agent loop (no device work)
     "gridmm_route_lengths": [_vp, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "gridmm_collate_nav_plan": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "gridmm_collate_nav_fill": [_vp] * 15 + [_i] * 8 + [_vp] * 10,
 }
 
 _lib = None

@@ -294,6 +294,14 @@ class NavCollator:
         self._apply(src, sets, adds)
 
     def _cand_ids(self, gmaps, cand_vpids):
+        memo = getattr(self, "_cid_memo", None)
+        if memo is not None and memo[0] is cand_vpids and memo[1] is gmaps[0]:      # update_embeddings and navigation of one step
+            return memo[2]
+        out = self._cand_ids_build(gmaps, cand_vpids)
+        self._cid_memo = (cand_vpids, gmaps[0], out)
+        return out
+
+    def _cand_ids_build(self, gmaps, cand_vpids):
         B = len(gmaps)
         nc = np.fromiter((len(c) for c in cand_vpids), dtype=np.int64, count=B)
         cid = np.zeros((B, max(int(nc.max()) if B else 0, 1)), dtype=np.int64)
@@ -329,7 +337,73 @@ class NavCollator:
             return self._navigation_batched(batch, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types)
         return self._navigation_loop(obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types)
 
+    native = True       # False: the NumPy form below (kept as the readable restatement; tests compare the two)
+
     def _navigation_batched(self, tb, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types):
+        """The step's nav_inputs from the (B, cap, ...) arrays of a graph_utils.TopoMapBatch in two native calls
+        (gridmm_collate_nav_plan / _fill, csrc/hostutil.hip: node order, position features of graph nodes / candidates /
+        start node, pair distances, step ids, masks, embedding slots, fusion maps); what stays in Python: the viewpoint-name
+        lists the caller needs.  ~100 small NumPy calls per step before (`_navigation_batched_numpy`)."""
+        if not self.native:
+            return self._navigation_batched_numpy(tb, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types)
+        lib = _lib.load()
+        a, B, cap = self.args, len(obs), tb.cap
+        cur = np.fromiter((g.index(ob["viewpoint"]) for g, ob in zip(gmaps, obs)), dtype=np.int64, count=B)
+        start = np.fromiter((g.index(g.start_vp) for g in gmaps), dtype=np.int64, count=B)
+        n = np.ascontiguousarray(tb.n, dtype=np.int64)
+        seen = np.ascontiguousarray(tb.seen).view(np.uint8)
+        order = np.empty((B, cap), dtype=np.int64)
+        m, n_vis, n_unv = (np.empty(B, dtype=np.int64) for _ in range(3))
+        seen_eff = np.empty((B, cap), dtype=np.uint8)
+        P = lambda x: x.ctypes.data       # noqa: E731
+        M = lib.gridmm_collate_nav_plan(P(seen), P(n), P(cur), B, cap, int(bool(a.enc_full_graph)), int(bool(a.act_visited_nodes)),
+                                        P(order), P(m), P(n_vis), P(n_unv), P(seen_eff))
+        if M < 0:
+            _lib.check(M, "gridmm_collate_nav_plan")
+        G = self._bucket(1 + M, self.node_buckets)
+        cid, cm = self._cand_ids(gmaps, cand_vpids)
+        nc = cm.sum(1).astype(np.int64)
+        Cw = cid.shape[1]
+        V1 = pano_embeds.shape[1] + 1
+        afs = int(getattr(a, "angle_feat_size", 4))
+        F = afs + 3
+        if self.cnt.shape[1] <= cap:
+            self._grow(cap)
+        bh = np.array([float(ob["heading"]) for ob in obs], dtype=np.float64)
+        be = np.array([float(ob["elevation"]) for ob in obs], dtype=np.float64)
+        gpos = np.empty((B, G, F), dtype=np.float32)
+        vpos = np.empty((B, V1, 2 * F), dtype=np.float32)
+        pair = np.empty((B, G, G), dtype=np.float32)
+        steps, slot = np.empty((B, G), dtype=np.int64), np.empty((B, G), dtype=np.int64)
+        visited, gmask = np.empty((B, G), dtype=np.uint8), np.empty((B, G), dtype=np.uint8)
+        inv = np.empty((B, G), dtype=np.float32)
+        cand_of_node = np.empty((B, G), dtype=np.int32)
+        cand_visited = np.empty((B, V1), dtype=np.uint8)
+        cnt = np.ascontiguousarray(self.cnt, dtype=np.int32)
+        rc = lib.gridmm_collate_nav_fill(P(tb.pos), P(tb.dist), P(tb.via), P(tb.step), P(order), P(m), P(n_vis), P(seen_eff),
+                                         P(cur), P(start), P(cid), P(nc), P(bh), P(be), P(cnt), B, cap, Cw, cnt.shape[1], G, V1,
+                                         afs, int(bool(a.enc_full_graph)), P(gpos), P(vpos), P(pair), P(steps), P(visited),
+                                         P(slot), P(inv), P(gmask), P(cand_of_node), P(cand_visited))
+        if rc > 0:
+            i, j = divmod(rc - 1, G)
+            raise KeyError("graph node without an embedding: %s" % gmaps[i].names[int(order[i, j - 1])])
+        _lib.check(rc, "gridmm_collate_nav_fill")
+        vpids = [[None] + [g.names[k] for k in order[i, :m[i]]] for i, g in enumerate(gmaps)]
+        slot_d, inv_d = self._dev(slot), self._dev(inv)
+        out = {
+            "gmap_vpids": vpids, "gmap_img_embeds": None, "gmap_step_ids": self._dev(steps),
+            "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited.view(np.bool_)),
+            "gmap_pair_dists": self._dev(pair), "gmap_masks": self._dev(gmask.view(np.bool_)),
+            "no_vp_left": [bool(v == 0) for v in n_unv],
+            "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),
+        }
+        out = self._vp_part(out, pano_embeds, cand_vpids, view_lens, nav_types, vpos)
+        self.stage.flush()                         # every host array of the step: one asynchronous upload
+        rows = torch.arange(B, device=self.device).unsqueeze(1)
+        out["gmap_img_embeds"] = self.pool[rows, slot_d] * inv_d.unsqueeze(2)
+        return out
+
+    def _navigation_batched_numpy(self, tb, obs, gmaps, pano_embeds, cand_vpids, view_lens, nav_types):
         """The same dictionary from the (B, cap, ...) arrays of a graph_utils.TopoMapBatch: node order, geometry, pair
         distances, step ids, embedding slots and the fusion maps of all episodes in one pass of whole-array operations
         (the per-episode Python that is left: name lists for the caller, routes with more than one leg)."""

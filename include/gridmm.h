@@ -567,6 +567,23 @@ int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const float* X, const
 int gridmm_route_lengths(const int32_t* via, int B, int cap, const int64_t* cur, const int64_t* tgt, const uint8_t* mask,
                          int T, double* hops);
 
+/* Navigation-input collation of a lock-step batch from the (B, cap, ...) arrays of its topological maps: what
+ * _nav_gmap_variable / _nav_vp_variable (map_nav_src/r2r/agent.py:96-205: node order [visited | unvisited], get_pos_fts of the
+ * graph nodes / candidates / start node, pair distances, step ids, visited and length masks) and the fused-logit loops of
+ * models/vilmodel.py:881-899 compute per episode in Python.  *_plan orders the nodes and returns the longest sequence (the
+ * caller picks the padded node axis G >= 1 + that); *_fill writes every host-built array of the step.  Array shapes: see
+ * csrc/hostutil.hip.  *_fill returns 0, GRIDMM_EINVAL, or 1 + (b * G + row) of the first graph node without an embedding. */
+int gridmm_collate_nav_plan(const uint8_t* seen, const int64_t* n, const int64_t* cur, int B, int cap, int enc_full_graph,
+                            int act_visited_nodes, int64_t* order, int64_t* m, int64_t* n_vis, int64_t* n_unv,
+                            uint8_t* seen_eff);
+int gridmm_collate_nav_fill(const double* pos, const double* dist, const int32_t* via, const int64_t* step,
+                            const int64_t* order, const int64_t* m, const int64_t* n_vis, const uint8_t* seen_eff,
+                            const int64_t* cur, const int64_t* start, const int64_t* cid, const int64_t* nc,
+                            const double* heading, const double* elevation, const int32_t* cnt, int B, int cap, int Cw,
+                            int slots, int G, int V1, int afs, int enc_full_graph, float* gpos, float* vpos, float* pair,
+                            int64_t* steps, uint8_t* visited, int64_t* slot, float* inv, uint8_t* gmask, int32_t* cand_of_node,
+                            uint8_t* cand_visited);
+
 #ifdef __cplusplus
 }
 #endif

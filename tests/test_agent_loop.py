@@ -190,6 +190,41 @@ def test_batched_collation_equals_the_per_episode_restatement(over):
         assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
 
 
+def test_native_navigation_collation_equals_the_numpy_form():
+    """collate.NavCollator._navigation_batched (gridmm_collate_nav_plan / _fill, csrc/hostutil.hip) against its NumPy
+    restatement on every step of a rollout: integer / bool / name entries identical, floats to 2e-7 (libm vs NumPy's own
+    float32 sin / cos may differ in the last bit)."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.sim_env import SyntheticNavEnv
+
+    def run(native, **over):
+        env = SyntheticNavEnv(8, _StubMem(), n_scans=2, n_episodes=16, seed=5, geom=S.NATIVE, vocab=3000)
+        env.device_store = _StubStore()
+        ag = GMapNavAgent(default_args(max_action_len=12, **over), env, _StubModel(), device="cpu")
+        ag.collator.native, ag.trace = native, []
+        with torch.no_grad():
+            traj = ag.rollout()
+        return ag.trace, traj
+    for over in ({}, {"enc_full_graph": False}, {"act_visited_nodes": True}):
+        (a, ta), (b, tb) = run(False, **over), run(True, **over)
+        assert len(a) == len(b) >= 5 and ta == tb
+        for x, y in zip(a, b):
+            assert set(x["nav_inputs"]) == set(y["nav_inputs"])
+            for k, v in x["nav_inputs"].items():
+                w = y["nav_inputs"][k]
+                if k == "fusion_maps":
+                    assert torch.equal(v[0], w[0]) and torch.equal(v[1], w[1])
+                elif torch.is_tensor(v):
+                    assert v.shape == w.shape and v.dtype == w.dtype, k
+                    if v.dtype.is_floating_point:
+                        assert torch.allclose(v, w, atol=2e-7, rtol=2e-7), (k, float((v - w).abs().max()))
+                    else:
+                        assert torch.equal(v, w), k
+                elif k != "grid_memory":
+                    assert v == w, k
+
+
 @pytest.mark.gpu
 def test_rollout_with_graph_replay_equals_the_eager_rollout():
     """GMapNavAgent.enable_graph_replay(): 'panorama' + the shape-dependent half of 'navigation' from hipGraphs keyed by
