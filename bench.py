@@ -291,7 +291,13 @@ def rollout_leg(args, dev, rollouts=4):
         torch.cuda.synchronize()
         prof_steps = agent.nav_steps - n1
     tot = sum(agent.timers.values())
+    x2 = None
+    try:
+        x2 = rollout_interleaved(args, dev, model, geom, T, rollouts)
+    except Exception as e:          # a secondary key of a secondary key
+        x2 = {"error": repr(e)[:200]}
     return {"value": B * steps / dt, "unit": "episode-steps/s", "ms_per_step": 1e3 * dt / steps, "batch": B,
+            "two_interleaved_batches": x2,
             "steps_per_rollout": steps / rollouts, "max_action_len": T,
             "sections_ms_per_step": {k: 1e3 * v / prof_steps for k, v in sorted(agent.timers.items(), key=lambda kv: -kv[1])},
             "host_share": sum(v for k, v in agent.timers.items() if k.startswith("host") or k.startswith("env")) / tot,
@@ -340,6 +346,39 @@ def finetune_leg(args, dev, iters=3):
             "workload": "GMapNavAgent.train (imitation): teacher-forced rollout of %d episodes x <= %d steps on the "
                         "differentiable path, one backward through all steps, clip 40 + AdamW; 36x196x512 observations "
                         "resident in HBM, full-size model" % (B, T)}
+
+
+def rollout_interleaved(args, dev, model, geom, T, rollouts):
+    """Evaluation throughput with TWO mini-batches of B = 32 in flight (GMapNavAgent.interleaved_rollouts): the two rollouts
+    are advanced alternately at their per-step yield points, each on its own stream, so one batch's host collation runs
+    under the other's 'navigation' kernels.  Same model, separate environments / grid memories / graph caches; every
+    trajectory equals the one the batch produces alone (tests/test_agent_loop.py)."""
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.sim_env import SyntheticNavEnv
+    B = args.batch
+    agents = []
+    for k in range(2):
+        mem = GridMemoryBatch(B, geom, max_steps=T + 2, device=dev)
+        env = SyntheticNavEnv(B, mem, n_scans=4, n_episodes=4 * B, seed=3 + 7 * k, geom=geom, vocab=30000)
+        env.build_device_store(dev)
+        a = GMapNavAgent(default_args(max_action_len=T), env, model, device=dev)
+        a.feedback = "argmax"
+        a._set_mode(False)
+        a.enable_graph_replay()
+        agents.append(a)
+    streams = [torch.cuda.Stream() for _ in agents]
+    with torch.no_grad():
+        for _ in range(4):
+            GMapNavAgent.interleaved_rollouts(agents, streams)
+        torch.cuda.synchronize()
+        n0, t0 = sum(a.nav_steps for a in agents), time.perf_counter()
+        for _ in range(rollouts):
+            GMapNavAgent.interleaved_rollouts(agents, streams)
+        torch.cuda.synchronize()
+        dt, steps = time.perf_counter() - t0, sum(a.nav_steps for a in agents) - n0
+    return {"value": B * steps / dt, "unit": "episode-steps/s", "ms_per_step_of_32": 1e3 * dt / steps, "batches_in_flight": 2,
+            "episodes_in_flight": 2 * B}
 
 
 def producer_leg(args, dev, steps=5):

@@ -14,6 +14,7 @@ whole point history every step (agent.py:168).
 `vln_bert` is any callable (mode, batch) -> outputs with the reference's contract
 (gridmm_amd.vilmodel.GlocalTextPathNavCMT on the GPU; tests also drive it with the CPU oracle).
 """
+import contextlib
 import math
 from types import SimpleNamespace
 
@@ -260,6 +261,18 @@ class GMapNavAgent:
     timers = None
 
     def rollout(self, train_ml=None, reset=True):
+        """One rollout of the environment's next mini-batch (agent.py:268-451).  The body is a generator that yields once
+        per navigation step, right after the step's model calls have been ENQUEUED and before their results are read:
+        rollout() simply drives it to the end; interleaved_rollouts() alternates several of them so that one batch's host
+        work runs under another batch's device work."""
+        gen = self._rollout_gen(train_ml, reset)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as e:
+            return e.value
+
+    def _rollout_gen(self, train_ml=None, reset=True):
         t0 = self._tick(None, 0.0)
         obs = self.env.reset() if reset else self.env._get_obs()
         t0 = self._tick("env (grid memory step + observation dicts)", t0)
@@ -338,6 +351,7 @@ class GMapNavAgent:
             else:
                 nav_logits, nav_vpids = nav_outs["fused_logits"], nav_inputs["gmap_vpids"]
             nav_probs = torch.softmax(nav_logits, 1)
+            yield t                                   # (the device works on this step; another rollout may use the host now)
             if self.feedback == "argmax" and train_ml is None:
                 # inference: the step's ONE device-to-host read -- stop probabilities and the arg-max actions together
                 a_t = nav_logits.max(1)[1].detach()
@@ -431,6 +445,26 @@ class GMapNavAgent:
             self.loss = self.loss + ml_loss
             self.logs["IL_loss"].append(float(ml_loss.detach()) if torch.is_tensor(ml_loss) else float(ml_loss))
         return traj
+
+    @staticmethod
+    def interleaved_rollouts(agents, streams=None):
+        """Run one rollout() of every agent, interleaved at their per-step yield points: while agent A's 'navigation' runs on
+        the device, agent B collates its inputs on the host (and vice versa).  The agents share the model but own their
+        environment, grid memory, collator and graph caches; each runs on its own stream.  Results = [a.rollout() for a in
+        agents] (same trajectories: the calls of one agent are never reordered)."""
+        streams = streams or [torch.cuda.Stream() for _ in agents] if torch.cuda.is_available() else [None] * len(agents)
+        gens = [a._rollout_gen() for a in agents]
+        out, live = [None] * len(agents), list(range(len(agents)))
+        while live:
+            for i in list(live):
+                ctx = torch.cuda.stream(streams[i]) if streams[i] is not None else contextlib.nullcontext()
+                with ctx:
+                    try:
+                        next(gens[i])
+                    except StopIteration as e:
+                        out[i] = e.value
+                        live.remove(i)
+        return out
 
     # ---- Seq2SeqAgent.test / .train (agent_base.py:150-211) ---------------------------------------
     def test(self, feedback="argmax", iters=None):

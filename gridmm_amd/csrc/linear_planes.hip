@@ -10,6 +10,8 @@
 // Producers of activations (LayerNorm, attention, GELU epilogue) write the planes directly, see
 // rowops.hip / attention.hip.  K % 32 == 0 and 16-byte aligned rows are required here; everything
 // else goes through gridmm_linear.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -505,6 +507,11 @@ static int pick_cfg(int M, int N, int K) {
     const float t = (float)rounds * c.occ * c.bm * c.bn / c.q;
     if (t < best_t) { best_t = t; best = c.cfg; }
   }
+  // experiment hooks (tools/bench_gemm_cfg_step.sh): deeper LDS rings for the tiles whose operands arrive cold in the step
+  static const int ov_small = getenv("GRIDMM_GEMM_CFG_SMALL") ? atoi(getenv("GRIDMM_GEMM_CFG_SMALL")) : 0;
+  static const int ov_mid = getenv("GRIDMM_GEMM_CFG_MID") ? atoi(getenv("GRIDMM_GEMM_CFG_MID")) : 0;
+  if (best == 43 && ov_small) return ov_small;
+  if (best == 15 && ov_mid) return ov_mid;
   return best;
 }
 
@@ -561,6 +568,11 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     case 42: return launch<128, 128, 32, 32, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
     case 43: return launch<64, 64, 32, 32, 2, 64, 0, 0, 1, true>(GRIDMM_ARGS);
     case 44: return launch<256, 128, 64, 32, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
+    case 45: return launch<64, 64, 32, 32, 3, 64, 0, 0, 1, true>(GRIDMM_ARGS);    // deeper rings (cold operands in the step)
+    case 46: return launch<64, 64, 32, 32, 4, 32, 0, 0, 1, true>(GRIDMM_ARGS);
+    case 47: return launch<64, 64, 32, 32, 3, 32, 0, 0, 1, true>(GRIDMM_ARGS);
+    case 48: return launch<128, 128, 32, 32, 3, 32, 0, 0, 0, true>(GRIDMM_ARGS);
+    case 49: return launch<64, 64, 32, 32, 4, 64, 0, 0, 1, true>(GRIDMM_ARGS);
     // ablations (tools/bench_gemm.py): 1xx = no MFMA (DMA + LDS reads only), 2xx = no DMA after the prologue
     case 108: return launch<64, 64, 32, 32, 2, 64, 1>(GRIDMM_ARGS);
     case 208: return launch<64, 64, 32, 32, 2, 64, 2>(GRIDMM_ARGS);

@@ -190,6 +190,26 @@ def test_batched_collation_equals_the_per_episode_restatement(over):
         assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
 
 
+def test_interleaved_rollouts_equal_sequential_rollouts():
+    """GMapNavAgent.interleaved_rollouts: several rollouts advanced alternately at their per-step yield points give exactly
+    the trajectories of running them one after the other (per agent, the order of calls does not change)."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.sim_env import SyntheticNavEnv
+
+    def agents():
+        out = []
+        for k in range(3):
+            env = SyntheticNavEnv(4, _StubMem(), n_scans=2, n_episodes=8, seed=3 + k, geom=S.NATIVE, vocab=3000)
+            env.device_store = _StubStore()
+            out.append(GMapNavAgent(default_args(max_action_len=6 + 2 * k), env, _StubModel(), device="cpu"))
+        return out
+    with torch.no_grad():
+        want = [a.rollout() for a in agents()]
+        got = GMapNavAgent.interleaved_rollouts(agents())
+    assert got == want and all(len(t) == 4 for t in got)
+
+
 def test_native_navigation_collation_equals_the_numpy_form():
     """collate.NavCollator._navigation_batched (gridmm_collate_nav_plan / _fill, csrc/hostutil.hip) against its NumPy
     restatement on every step of a rollout: integer / bool / name entries identical, floats to 2e-7 (libm vs NumPy's own
