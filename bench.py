@@ -437,8 +437,14 @@ def _init_dist(dev):
     """(dist module or None, rank, world): RCCL ("nccl") process group, or gloo when N ranks share one GPU (test hook)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1:
+    if world == 1 and not os.environ.get("GRIDMM_DIST_FORCE"):
         return None, 0, 1
+    # (GRIDMM_DIST_FORCE=1 with one rank: the multi-rank leg end to end over the real backend -- the only way it can meet
+    # RCCL on a one-GPU box, which refuses two ranks on one device; tests/test_hip_dist.py)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     import torch.distributed as dist
     if os.environ.get("GRIDMM_BENCH_SHARE_GPU"):
         dist.init_process_group("gloo")
@@ -503,6 +509,7 @@ def train_leg(args, dev, steps=None, emit=None):
     from gridmm_amd.train_graph import GraphedTrainStep
     from gridmm_amd.vilmodel import default_config
     dist, rank, world = _init_dist(dev)
+    multi = dist is not None                 # several ranks (or one rank with GRIDMM_DIST_FORCE: the same code over RCCL)
     share = bool(os.environ.get("GRIDMM_BENCH_SHARE_GPU"))
     steps = steps or int(os.environ.get("GRIDMM_BENCH_TRAIN_STEPS", "6"))
     cfg = default_config(use_lang2visn_attn=True, pretrain_tasks=["mlm", "mrc", "sap"], image_prob_size=1000, obj_prob_size=0)
@@ -523,7 +530,7 @@ def train_leg(args, dev, steps=None, emit=None):
         for t in tasks:                      # first sight of each task agrees on its used-set ...
             tr.train_step(batches[t], t)
     except Exception as e:                   # (a collective this RCCL build rejects fails on every rank alike)
-        if world == 1 or tr.reducer.algo == "ring":
+        if not multi or tr.reducer.algo == "ring":
             raise
         fallback = "%s failed (%s): ring all_reduce instead" % (tr.reducer.algo, repr(e)[:200])
         tr.reducer.algo = "ring"
@@ -535,14 +542,14 @@ def train_leg(args, dev, steps=None, emit=None):
 
     def resync():
         """After a timing loop without the exchange the ranks have drifted apart: rank 0's weights and AdamW moments again."""
-        if world > 1:
+        if multi:
             from gridmm_amd.dist import broadcast_parameters
             broadcast_parameters(model.parameters())
             st = [v for p in model.parameters() for k, v in sorted(tr.optimizer.state.get(p, {}).items()) if torch.is_tensor(v)]
             broadcast_parameters(st)
     dt_eager = _timed_loop(lambda i: tr.train_step(batches[tasks[i % 3]], tasks[i % 3]), steps, dist)
     dt_noex = None
-    if world > 1:
+    if multi:
         tr.exchange = False                  # the same step without the exchange (ranks drift apart: timing only)
         dt_noex = _timed_loop(lambda i: tr.train_step(batches[tasks[i % 3]], tasks[i % 3]), steps, dist)
         tr.exchange = True
@@ -550,7 +557,7 @@ def train_leg(args, dev, steps=None, emit=None):
     graphs = {t: GraphedTrainStep(tr, batches[t], t) for t in tasks}
     for t in tasks:
         graphs[t]()
-    n = 4 * steps if world == 1 else 2 * steps
+    n = 4 * steps if not multi else 2 * steps
     last = {}
 
     def gstep(i):
@@ -562,7 +569,7 @@ def train_leg(args, dev, steps=None, emit=None):
         raise SystemExit("bench.py: the captured training step produced non-finite losses")
     res = {"train_samples_per_s": world * args.batch / dt, "ms_per_step": 1e3 * dt, "batch": args.batch, "n_gpus": world,
            "global_batch": world * args.batch,
-           "launch": ("hipGraph replay, one graph per task (train_graph.GraphedTrainStep)" if world == 1 else
+           "launch": ("hipGraph replay, one graph per task (train_graph.GraphedTrainStep)" if not multi else
                       "hipGraph replay: forward graph + %d backward-segment graphs per task, gradient buckets exchanged on a "
                       "side stream between segment launches, eager clip + AdamW" % (len(graphs[tasks[0]].graphs) - 1)),
            "graph": {"train_samples_per_s": world * args.batch / dt, "ms_per_step": 1e3 * dt},
@@ -570,7 +577,7 @@ def train_leg(args, dev, steps=None, emit=None):
            "best_samples_per_s": world * args.batch / min(dt, dt_eager),
            "workload": "pre-training step (mlm/mrc/sap cycling), full-size model, native 12x49x768 grid memory t=3..5, "
                        "fwd + bwd + clip + fused AdamW"}
-    if world > 1:
+    if multi:
         tr.exchange = False
         dt_graph_noex = _timed_loop(gstep, n, dist)
         tr.exchange = True

@@ -5,6 +5,7 @@ on ROCm; "gloo" in CPU tests), every rank advances its own shard of the episode 
 path has NO collective.  The only exchanges are the end-of-split result gather (reference:
 map_nav_src/utils/distributed.py:90-130, main_nav.py:188) and the max-over-ranks timing of bench.py.
 """
+import os
 import pickle
 
 import torch
@@ -12,7 +13,13 @@ import torch.distributed as dist
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when a process group with more than one rank is up.  GRIDMM_DIST_FORCE=1 also counts a ONE-rank group: every
+    multi-rank code path (bucket copies, collectives on the side stream, the segmented captured step) then runs against the
+    real backend -- the only way these paths can meet RCCL on a one-GPU box, which refuses two ranks on one device
+    (tests/test_hip_dist.py::test_rccl_single_rank_runs_every_multi_rank_path)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or bool(os.environ.get("GRIDMM_DIST_FORCE"))
 
 
 def rank_world():
@@ -173,6 +180,9 @@ class GradientReducer:
                 flat.copy_(w)
             return
         keep = b if b is not None else {}
+        for k in ("wire", "shard", "recv"):              # scratch of another payload type (algo / payload were switched)
+            if keep.get(k) is not None and keep[k].dtype != wire_dt:
+                keep[k] = None
         wire = flat
         if wire_dt != torch.float32:
             if keep.get("wire") is None:
@@ -312,6 +322,15 @@ class GradientReducer:
                 b["pending"].discard(i)
                 self._advance(True)
         return hook
+
+    def close(self):
+        """Remove the hooks from the parameters (a second reducer over the same parameters must not find them)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
 
     def expect(self, key, final=True):
         """Announce the code path of the coming backward (any hashable, e.g. the pre-training task; the SAME on every

@@ -173,3 +173,26 @@ def test_bench_train_leg_two_ranks_exchanges_gradients():
     assert set(ex["graph_ms_per_step_by_algo"]) >= {"ring_fp32", "direct_fp32"} and ex["exposed_ms_graph"] >= 0
     # (no timing assertion here: over gloo, with both ranks on one GPU, the exchange costs ~15x the step's compute and its
     # cost moves by more than the backward it could hide under; the RCCL numbers come from the driver's SCALE run)
+
+
+def test_rccl_single_rank_runs_the_multi_rank_training_leg():
+    """bench.py's multi-rank training leg END TO END over RCCL with one rank (GRIDMM_DIST_FORCE: RCCL refuses two ranks on
+    one device, and this box has one): bucket copies, every exchange algorithm as real RCCL calls on the side stream, the
+    segmented captured step next to a live communicator, the per-algorithm timings and the exchange-alone sweep.  With one
+    rank the exchange moves no bytes: `exposed_ms_graph` here is the pure overhead of the multi-rank machinery."""
+    env = dict(os.environ, GRIDMM_DIST_FORCE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), GRIDMM_BENCH_TRAIN_STEPS="2")
+    env.pop("GRIDMM_BENCH_SHARE_GPU", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--train-leg-only", "--batch", "8"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    t = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    print(json.dumps(t))
+    ex = t["exchange"]
+    assert ex["backend"] == "nccl (RCCL)" and ex["world"] == 1 and ex["buckets"] >= 4
+    by = ex["graph_ms_per_step_by_algo"]
+    assert set(by) >= {"ring_fp32", "direct_fp32", "direct_bf16", "rsag_fp32"} and all(isinstance(v, float) for v in by.values()), by
+    assert all(isinstance(v, float) for v in ex["exchange_alone_ms"].values()), ex["exchange_alone_ms"]
+    seg = ex["buckets_launched_after_segment"]
+    assert len(seg) >= 4 and 0 < seg[-2] <= seg[-1], seg
+    assert ex["reducer_stats"]["repairs"] == 0 and ex["reducer_stats"]["launched_early"] > 0

@@ -20,7 +20,7 @@ def _run(case, env_extra):
 
 
 @pytest.mark.parametrize("case", ["mlm", "mrc", "sap", "dropout", "two_graphs", "fp16_grid_proj", "full_size", "trajectory",
-                                  "segments_sap", "segments_mlm", "dist2", "alternate_full", "nonkernel"])
+                                  "segments_sap", "segments_mlm", "dist2", "rccl1", "alternate_full", "nonkernel"])
 def test_graphed_training_step(case):
     r = _run(case, {})
     assert r.returncode == 0 and ("ok " + case) in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -121,6 +121,57 @@ def _dist2_worker(rank, world, port):
     dist.destroy_process_group()
 
 
+def case_rccl1():
+    """The multi-rank code paths against the REAL backend ("nccl" = RCCL) with ONE rank (RCCL refuses two ranks on one
+    device; GRIDMM_DIST_FORCE makes a one-rank group count as distributed): every exchange algorithm and payload as RCCL
+    calls on the side stream, the eager step with buckets launched from the backward hooks, and the segmented captured step
+    (graph capture next to a live RCCL communicator and its watchdog thread).  World size 1 => the mean over ranks is the
+    rank's own gradient: everything must equal the plain single-process training step."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", GRIDMM_DIST_FORCE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from gridmm_amd import dist as D
+    from gridmm_amd.pretrain_loop import PreTrainer, default_opts
+    from gridmm_amd.train_graph import GraphedTrainStep
+    assert D.is_dist()
+    # 1. the exchange itself, every algorithm / payload, on RCCL
+    red = D.GradientReducer([torch.nn.Parameter(torch.zeros(1000, device="cuda"))], bucket_mb=1)
+    for algo in ("ring", "rsag", "direct"):
+        for payload in ("fp32", "bf16"):
+            red.algo, red.payload = algo, payload
+            flat = torch.randn(4096, device="cuda")
+            want = flat.clone() if payload == "fp32" else flat.to(torch.bfloat16).float()
+            if algo == "direct" and payload == "bf16":
+                want = want.to(torch.bfloat16).float()
+            red._exchange(flat, {})
+            torch.cuda.synchronize()
+            assert torch.allclose(flat, want, rtol=1e-2 if payload == "bf16" else 0, atol=0), (algo, payload)
+    # 2. eager overlapped steps and the segmented captured step == each other, step by step
+    model, batches = _setup(0.0, layers=5)
+    for algo in ("ring", "direct"):
+        ma, mb = copy.deepcopy(model), copy.deepcopy(model)     # (a reducer's hooks stay on its parameters: fresh copies)
+        kw = dict(bucket_mb=8, algo=algo)
+        ta, tb = PreTrainer(ma, default_opts(warmup_steps=10), reducer_kw=kw), PreTrainer(mb, default_opts(warmup_steps=10), reducer_kw=kw)
+        assert tb.reducer._host_async() is False and len(tb.reducer.buckets) >= 4
+        task = "sap" if algo == "ring" else "mlm"
+        for _ in range(2):
+            ta.train_step(batches[task], task)
+        g = GraphedTrainStep(tb, batches[task], task)
+        assert g.segmented and len(g.graphs) >= 4 and (g.node_types is None or set(g.node_types) == {"kernel"})
+        for it in range(4):
+            _compare_step(ta, tb, lambda: ta.train_step(batches[task], task), g, (algo, task, it))
+            assert g.launched_after_segment[-2] > 0, g.launched_after_segment
+        assert ta.reducer.stats["launched_early"] > 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def case_dist2():
     import socket
     import torch.multiprocessing as mp
@@ -305,6 +356,8 @@ if __name__ == "__main__":
         case_equals_eager(case.split("_", 1)[1], segments=True, layers=5)
     elif case == "dist2":
         case_dist2()
+    elif case == "rccl1":
+        case_rccl1()
     elif case == "alternate_full":
         case_alternate_full()
     elif case == "nonkernel":
