@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -46,8 +46,14 @@ SIGNATURES = {
     "gridmm_attention_rows_cfg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i,
                                   _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp],
     "gridmm_xattn_layer_workspace": [_i, _i, _i, _i],
-    "gridmm_xattn_layer_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i64, _vp,
-                               ctypes.c_size_t, _i, _i, _i, _i, _vp],
+    "gridmm_xattn_layer_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i,
+                               _vp, _vp, _vp, _i, _i64, _vp, ctypes.c_size_t, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_attention_rows_seg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _i,
+                                  _vp, _i, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
+    "gridmm_linear_planes_ln_workspace": [_i, _i],
+    "gridmm_linear_planes_ln_sync_bytes": [_i],
+    "gridmm_linear_planes_ln": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i64,
+                                _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_linear_planes_map": [_vp, _vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gridmm_linear_planes_grouped": [_vp, _i, _vp],
     "gridmm_layernorm_map": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp],
@@ -114,6 +120,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
+    lib.gridmm_linear_planes_ln_workspace.restype = ctypes.c_size_t
+    lib.gridmm_linear_planes_ln_sync_bytes.restype = ctypes.c_size_t
     lib.gridmm_grid_aggregate_workspace.restype = ctypes.c_size_t
     lib.gridmm_xattn_layer_train_saved_bytes.restype = ctypes.c_size_t
     lib.gridmm_xattn_layer_train_workspace.restype = ctypes.c_size_t

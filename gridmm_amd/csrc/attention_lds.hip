@@ -70,7 +70,8 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
     const unsigned short* __restrict__ Vh, const unsigned short* __restrict__ Vl, int64_t v_bs, int v_rs,
     const uint8_t* __restrict__ kmask, int mask_bs, float* __restrict__ O, int64_t o_bs, int o_rs,
     unsigned short* __restrict__ Ohi, unsigned short* __restrict__ Olo, int64_t p_bs, int p_rs, int Sq, int Sk,
-    float scale) {
+    float scale, const unsigned short* __restrict__ K2h, const unsigned short* __restrict__ K2l,
+    const unsigned short* __restrict__ V2h, const unsigned short* __restrict__ V2l, int64_t kv2_bs, int kv2_rs, int S1) {
   static_assert(KC % 32 == 0 && 2 * 4 * KC * 128 <= 65536, "chunk ring (also the 16-bit ds offset field)");
   constexpr int PLANE = KC * 64;                                  // u16 per plane image
   constexpr int NT = KC / 32;                                     // key tiles per chunk
@@ -100,6 +101,12 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
   const unsigned short* Kbl = Kl + b * k_bs + h * 64;
   const unsigned short* Vbh = Vh + b * v_bs + h * 64;
   const unsigned short* Vbl = Vl + b * v_bs + h * 64;
+  // keys S1 .. Sk-1 live in a SECOND buffer (row key - S1): e.g. the instruction rows of the local encoder's [map | txt]
+  // context, whose K / V projections are constant over an episode and are kept apart from the per-step map rows
+  const unsigned short* K2bh = K2h + b * kv2_bs + h * 64;
+  const unsigned short* K2bl = K2l + b * kv2_bs + h * 64;
+  const unsigned short* V2bh = V2h + b * kv2_bs + h * 64;
+  const unsigned short* V2bl = V2l + b * kv2_bs + h * 64;
 
   // ---- chunk ring: two LDS buffers; wave NW is the LOADER: it copies chunk c+1 (global -> LDS by LDS-DMA) while the
   // NW math waves work on chunk c -- a wave that issues DMA into a busy memory pipe is blocked at issue for ~200
@@ -112,12 +119,14 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
 #pragma unroll
     for (int r0 = 8 * li; r0 < KC; r0 += 8 * NL) {
       const int key = min(key0c + r0 + lrow, Sk - 1);
-      const size_t ko = (size_t)key * k_rs + coff, vo = (size_t)key * v_rs + coff;
+      const bool s2 = key >= S1;
+      const size_t ko = s2 ? (size_t)(key - S1) * kv2_rs + coff : (size_t)key * k_rs + coff;
+      const size_t vo = s2 ? ko : (size_t)key * v_rs + coff;
       unsigned short* d = kvbuf + buf * (4 * PLANE) + r0 * 64;
-      dma16(Kbh + ko, d);
-      dma16(Kbl + ko, d + PLANE);
-      dma16(Vbh + vo, d + 2 * PLANE);
-      dma16(Vbl + vo, d + 3 * PLANE);
+      dma16((s2 ? K2bh : Kbh) + ko, d);
+      dma16((s2 ? K2bl : Kbl) + ko, d + PLANE);
+      dma16((s2 ? V2bh : Vbh) + vo, d + 2 * PLANE);
+      dma16((s2 ? V2bl : Vbl) + vo, d + 3 * PLANE);
     }
   };
 #ifdef GRIDMM_ATT_PROF
@@ -358,12 +367,15 @@ extern "C" int gridmm_debug_att_prof(unsigned long long* out, int reset) {
 #endif
 
 // cfg: 0 = auto; 1..: tuning configurations (tools/bench_attn2.py)
-extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
-                                         const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
-                                         int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
-                                         int64_t o_bs, int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B,
-                                         int heads, int Sq, int Sk, float scale, int cfg, gridmm_stream_t stream) {
+static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                               const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
+                               int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
+                               int64_t o_bs, int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B,
+                               int heads, int Sq, int Sk, float scale, int cfg, const void* K2_hi, const void* K2_lo,
+                               const void* V2_hi, const void* V2_lo, int64_t kv2_bs, int kv2_rs, int S1,
+                               gridmm_stream_t stream) {
   if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || Sk > 2048) return GRIDMM_EINVAL;   // mask words: 64 x 32 keys
+  if (S1 < 0 || S1 > Sk || (S1 < Sk && (!K2_hi || !K2_lo || !V2_hi || !V2_lo || (kv2_rs & 7) || (kv2_bs & 7)))) return GRIDMM_EINVAL;
   if ((q_rs | k_rs | v_rs) & 7 || (q_bs | k_bs | v_bs) & 7) return GRIDMM_EINVAL;      // 16-byte aligned rows
   if ((!O && !O_hi) || (O_hi && (!O_lo || (p_rs & 3) || (p_bs & 3))) || (O && ((o_rs & 3) || (o_bs & 3))))
     return GRIDMM_EINVAL;
@@ -372,7 +384,9 @@ extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int
 #define GRIDMM_ATT_ARGS                                                                                             \
   (const unsigned short*)Q_hi, (const unsigned short*)Q_lo, q_bs, q_rs, (const unsigned short*)K_hi,               \
       (const unsigned short*)K_lo, k_bs, k_rs, (const unsigned short*)V_hi, (const unsigned short*)V_lo, v_bs, v_rs, \
-      kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs, p_rs, Sq, Sk, scale
+      kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs, p_rs, Sq, Sk, scale,        \
+      (const unsigned short*)K2_hi, (const unsigned short*)K2_lo, (const unsigned short*)V2_hi,                      \
+      (const unsigned short*)V2_lo, kv2_bs, kv2_rs, S1
 #define GRIDMM_ATTL(NQ, NW, KC, AB, NL)                                                                                 \
   do {                                                                                                              \
     dim3 grid((nqt + (NQ) * (NW) - 1) / ((NQ) * (NW)), heads, B), block(((NW) + (NL)) * 64);                               \
@@ -405,6 +419,30 @@ extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int
 #undef GRIDMM_ATT_ARGS
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
+}
+
+extern "C" int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                                         const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
+                                         int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
+                                         int64_t o_bs, int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B,
+                                         int heads, int Sq, int Sk, float scale, int cfg, gridmm_stream_t stream) {
+  return attention_rows_impl(Q_hi, Q_lo, q_bs, q_rs, K_hi, K_lo, k_bs, k_rs, V_hi, V_lo, v_bs, v_rs, kmask, mask_bs, O, o_bs,
+                             o_rs, O_hi, O_lo, p_bs, p_rs, B, heads, Sq, Sk, scale, cfg, nullptr, nullptr, nullptr, nullptr, 0,
+                             0, Sk, stream);
+}
+
+// Keys [0, S1) from K / V, keys [S1, Sk) from a second pair of plane buffers (K2 / V2: row key - S1, row stride kv2_rs,
+// episode stride kv2_bs); kmask spans all Sk keys.  Same arithmetic, key by key, as one concatenated buffer.
+extern "C" int gridmm_attention_rows_seg(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                                         const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
+                                         int64_t v_bs, int v_rs, int S1, const void* K2_hi, const void* K2_lo,
+                                         const void* V2_hi, const void* V2_lo, int64_t kv2_bs, int kv2_rs,
+                                         const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs, int o_rs, void* O_hi,
+                                         void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq, int Sk, float scale,
+                                         gridmm_stream_t stream) {
+  return attention_rows_impl(Q_hi, Q_lo, q_bs, q_rs, K_hi, K_lo, k_bs, k_rs, V_hi, V_lo, v_bs, v_rs, kmask, mask_bs, O, o_bs,
+                             o_rs, O_hi, O_lo, p_bs, p_rs, B, heads, Sq, Sk, scale, 0, K2_hi, K2_lo, V2_hi, V2_lo, kv2_bs,
+                             kv2_rs, S1, stream);
 }
 
 extern "C" int gridmm_attention_rows(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,

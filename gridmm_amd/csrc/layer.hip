@@ -3,7 +3,10 @@
 // C call -- the entry point SURVEY.md §8b names for the cross-modal layers.  It owns no arithmetic of its own: it
 // sequences the library's kernels (6 plane GEMMs, 2 attention_rows, 3 LayerNorms) on the caller's stream through a
 // caller-provided workspace, so a C / C++ host (or the Python module, which uses it for its inference path) drives a
-// whole layer without touching intermediate tensors.  Results are bit-identical to issuing the eleven calls one by one.
+// whole layer without touching intermediate tensors.  Results are bit-identical to issuing the eleven calls one by one
+// when sync_words is NULL; with sync_words the three dense + residual + LayerNorm blocks run as ONE launch each
+// (gridmm_linear_planes_ln: eight launches per layer) whenever the shape allows it, with LayerNorm statistics merged
+// from per-tile partials (differences of a few ulp).
 #include "common.h"
 
 namespace {
@@ -14,16 +17,21 @@ extern "C" size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I) {
   const size_t M = (size_t)B * Sq;
   // planes: q (H), attention context (H), x-attn out (H), qkv (3H), self context (H), self out (H), ffn (I): hi + lo
   // fp32 : pre-LN sums (H) x1 (reused), post-LN a (H), post-LN b (H)
-  return a256(M * H * 4) * 6 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) + a256(M * H * 4) * 3 + 4096;
+  return a256(M * H * 4) * 6 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) + a256(M * H * 4) * 3 +
+         a256(gridmm_linear_planes_ln_workspace((int)M, H)) + 4096;
 }
 
 extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
                                       const void* KV_hi, const void* KV_lo, int64_t kv_bs, int kv_rs, int k_col, int v_col,
-                                      const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask, int self_mask_bs,
+                                      int Sk1, const void* KV2_hi, const void* KV2_lo, int64_t kv2_bs, int kv2_rs,
+                                      int k2_col, int v2_col, const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask, int self_mask_bs,
                                       float* Y, void* Y_hi, void* Y_lo, int y_p_rpb, int64_t y_p_bs, void* workspace,
-                                      size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream) {
+                                      size_t workspace_bytes, void* sync_words, int B, int Sq, int Sk, int heads,
+                                      gridmm_stream_t stream) {
   if (!L || !X || !X_hi || !X_lo || !KV_hi || !KV_lo || !workspace || B <= 0 || Sq <= 0 || Sk <= 0 || heads <= 0)
     return GRIDMM_EINVAL;
+  if (!KV2_hi) Sk1 = Sk;                                     // one context buffer
+  if (Sk1 < 0 || Sk1 > Sk || (Sk1 < Sk && !KV2_lo)) return GRIDMM_EINVAL;
   const int H = L->xq.N, I = L->ffn_i.N, M = B * Sq;
   if (H != heads * 64 || L->xq.K != H || L->xo.N != H || L->xo.K != H || L->sqkv.N != 3 * H || L->sqkv.K != H ||
       L->so.N != H || L->so.K != H || L->ffn_i.K != H || L->ffn_o.N != H || L->ffn_o.K != I || (!Y && !Y_hi))
@@ -42,37 +50,46 @@ extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, 
   float* h = (float*)take((size_t)M * H * 4);
   float* a = (float*)take((size_t)M * H * 4);
   float* bb = (float*)take((size_t)M * H * 4);
+  void* ln_ws = take(gridmm_linear_planes_ln_workspace(M, H));
   const float scale = 0.125f;                                // 1 / sqrt(64)
   int rc;
 #define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
   // ---- cross attention over the context (vilmodel.py:370-379): q = query(x); a = LN(dense(attn) + x)
   GRIDMM_TRY(gridmm_linear_planes(X_hi, X_lo, H, L->xq.w_hi, L->xq.w_lo, L->xq.Kp, L->xq.bias, nullptr, 0, nullptr, 0,
                                   q_hi, q_lo, H, M, H, H, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_attention_rows(q_hi, q_lo, (int64_t)Sq * H, H, (const unsigned short*)KV_hi + k_col,
-                                   (const unsigned short*)KV_lo + k_col, kv_bs, kv_rs, (const unsigned short*)KV_hi + v_col,
-                                   (const unsigned short*)KV_lo + v_col, kv_bs, kv_rs, ctx_mask, ctx_mask_bs, nullptr, 0, 0,
-                                   c_hi, c_lo, (int64_t)Sq * H, H, B, heads, Sq, Sk, scale, stream));
-  GRIDMM_TRY(gridmm_linear_planes(c_hi, c_lo, H, L->xo.w_hi, L->xo.w_lo, L->xo.Kp, L->xo.bias, X, H, h, H, nullptr, nullptr,
-                                  0, M, H, H, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_layernorm(h, H, nullptr, 0, L->x_ln.gamma, L->x_ln.beta, L->x_ln.eps, a, H, nullptr, 0, nullptr, nullptr,
-                              a_hi, a_lo, H, M, H, stream));
+  const unsigned short *k2h = (const unsigned short*)KV2_hi, *k2l = (const unsigned short*)KV2_lo;
+  GRIDMM_TRY(gridmm_attention_rows_seg(q_hi, q_lo, (int64_t)Sq * H, H, (const unsigned short*)KV_hi + k_col,
+                                       (const unsigned short*)KV_lo + k_col, kv_bs, kv_rs, (const unsigned short*)KV_hi + v_col,
+                                       (const unsigned short*)KV_lo + v_col, kv_bs, kv_rs, Sk1, k2h ? k2h + k2_col : nullptr,
+                                       k2h ? k2l + k2_col : nullptr, k2h ? k2h + v2_col : nullptr, k2h ? k2l + v2_col : nullptr,
+                                       kv2_bs, kv2_rs, ctx_mask, ctx_mask_bs, nullptr, 0, 0, c_hi, c_lo, (int64_t)Sq * H, H, B,
+                                       heads, Sq, Sk, scale, stream));
+  // dense + residual + LayerNorm: one launch when the fused form takes the shape, else GEMM then LayerNorm
+  auto dense_ln = [&](const gridmm_linear_t& W, const gridmm_ln_t& ln, const void* in_hi, const void* in_lo, int K,
+                      const float* res, float* out, void* out_hi, void* out_lo, int p_rpb, int64_t p_bs) -> int {
+    int r = GRIDMM_EUNSUPPORTED;
+    if (sync_words)
+      r = gridmm_linear_planes_ln(in_hi, in_lo, K, W.w_hi, W.w_lo, W.Kp, W.bias, res, H, nullptr, 0, ln.gamma, ln.beta, ln.eps,
+                                  out, H, out_hi, out_lo, H, p_rpb, p_bs, ln_ws, sync_words, M, H, K, 0, stream);
+    if (r != GRIDMM_EUNSUPPORTED) return r;
+    r = gridmm_linear_planes(in_hi, in_lo, K, W.w_hi, W.w_lo, W.Kp, W.bias, res, H, h, H, nullptr, nullptr, 0, M, H, K,
+                             GRIDMM_ACT_NONE, stream);
+    if (r != GRIDMM_OK) return r;
+    return gridmm_layernorm_map(h, H, nullptr, 0, ln.gamma, ln.beta, ln.eps, out, H, nullptr, 0, nullptr, nullptr, out_hi,
+                                out_lo, H, p_rpb, p_bs, M, H, stream);
+  };
+  GRIDMM_TRY(dense_ln(L->xo, L->x_ln, c_hi, c_lo, H, X, a, a_hi, a_lo, 0, 0));
   // ---- self attention (vilmodel.py:172-182)
   GRIDMM_TRY(gridmm_linear_planes(a_hi, a_lo, H, L->sqkv.w_hi, L->sqkv.w_lo, L->sqkv.Kp, L->sqkv.bias, nullptr, 0, nullptr,
                                   0, qkv_hi, qkv_lo, 3 * H, M, 3 * H, H, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(gridmm_attention_rows(qkv_hi, qkv_lo, (int64_t)Sq * 3 * H, 3 * H, qkv_hi + H, qkv_lo + H, (int64_t)Sq * 3 * H,
                                    3 * H, qkv_hi + 2 * H, qkv_lo + 2 * H, (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs,
                                    nullptr, 0, 0, s_hi, s_lo, (int64_t)Sq * H, H, B, heads, Sq, Sq, scale, stream));
-  GRIDMM_TRY(gridmm_linear_planes(s_hi, s_lo, H, L->so.w_hi, L->so.w_lo, L->so.Kp, L->so.bias, a, H, h, H, nullptr, nullptr,
-                                  0, M, H, H, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_layernorm(h, H, nullptr, 0, L->s_ln.gamma, L->s_ln.beta, L->s_ln.eps, bb, H, nullptr, 0, nullptr, nullptr,
-                              b_hi, b_lo, H, M, H, stream));
+  GRIDMM_TRY(dense_ln(L->so, L->s_ln, s_hi, s_lo, H, a, bb, b_hi, b_lo, 0, 0));
   // ---- feed forward (vilmodel.py:184-209): LN(dense(gelu(dense(b))) + b)
   GRIDMM_TRY(gridmm_linear_planes(b_hi, b_lo, H, L->ffn_i.w_hi, L->ffn_i.w_lo, L->ffn_i.Kp, L->ffn_i.bias, nullptr, 0, nullptr,
                                   0, f_hi, f_lo, I, M, I, H, GRIDMM_ACT_GELU, stream));
-  GRIDMM_TRY(gridmm_linear_planes(f_hi, f_lo, I, L->ffn_o.w_hi, L->ffn_o.w_lo, L->ffn_o.Kp, L->ffn_o.bias, bb, H, h, H, nullptr,
-                                  nullptr, 0, M, H, I, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_layernorm_map(h, H, nullptr, 0, L->f_ln.gamma, L->f_ln.beta, L->f_ln.eps, Y, H, nullptr, 0, nullptr,
-                                  nullptr, Y_hi, Y_lo, H, y_p_rpb, y_p_bs, M, H, stream));
+  GRIDMM_TRY(dense_ln(L->ffn_o, L->f_ln, f_hi, f_lo, I, bb, Y, Y_hi, Y_lo, y_p_rpb, y_p_bs));
 #undef GRIDMM_TRY
   return GRIDMM_OK;
 }

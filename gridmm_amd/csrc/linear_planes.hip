@@ -30,6 +30,65 @@ __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Fused residual + LayerNorm epilogue (LN = 1): the output rows are complete only across the tn column tiles of a row
+// block, so the workgroups of a row block RENDEZVOUS: each publishes its per-row tile statistics (mean and sum of squared
+// deviations over its BN columns, two passes over the register-resident values), bumps the row block's arrival counter
+// and waits for it to reach tn, then merges the tn partials (Chan) and normalises the values it still holds in
+// registers.  The pre-LayerNorm sums never travel through memory and the LayerNorm launch disappears.  Deadlock-free
+// only when the WHOLE grid is resident at once (the host checks the grid against the occupancy of the kernel) and no
+// other rendezvous kernel runs on the device at the same time (single-stream use; GRIDMM_LN_FUSE=0 turns the path off).
+// The counters are self-resetting: the last workgroup to leave a row block zeroes its pair.
+struct LnArgs {
+  const float* gamma; const float* beta; float eps;
+  float* Y; int ldy;              // post-LayerNorm fp32 out (optional)
+  float2* stats;                  // [tn][M] (tile mean, tile M2)
+  unsigned* ctr;                  // [tm][2] arrive / depart, zero between calls
+  int p_rpb; long p_bs;           // batched row map of the plane outputs (gridmm_layernorm_map)
+  int* err;                       // optional: set to 1 when a rendezvous ran into its poll bound
+};
+
+// Statistics and counters travel as agent-scope RELAXED atomics (sc1 accesses: coherent across the XCDs' L2s) ordered by
+// explicit waits -- never by fences: a release / acquire fence here is a write-back / invalidate of the XCD's WHOLE L2,
+// issued while the other workgroups of the launch are still streaming their operands through it (measured: +50 us per
+// launch).
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_stat(float2* p, float mean, float m2) {
+  const unsigned long long bits = (unsigned long long)__float_as_uint(mean) | ((unsigned long long)__float_as_uint(m2) << 32);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_stat(const float2* p) {
+  const unsigned long long bits =
+      __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)bits), __uint_as_float((unsigned)(bits >> 32)));
+}
+
+// Called by every thread of the workgroup (uniformly) after the tile statistics were stored (st_stat) and the storing
+// threads waited for their stores (s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void ln_rendezvous(unsigned* ctr, int tn, int* err) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                    // every storing thread's statistics have been acknowledged
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned polls = 0;
+    while (ld_agent(ctr) < (unsigned)tn) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++polls > (1u << 21)) { if (err) *err = 1; break; }   // (a missing peer must not hang the device)
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void ln_depart(unsigned* ctr, int tn) {
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)tn - 1u) {                   // everyone has read the statistics: the pair is zero again
+      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // BM x BN block tile, WM x WN per wave (16x16x32 MFMA tiles), NS-stage LDS ring filled by LDS-DMA.
 // One raw s_barrier per k-step; the DMA of stage kt+NS-1 is issued right after the barrier that retires
 // stage kt-1, and only a COUNTED s_waitcnt vmcnt keeps the younger stages in flight across barriers.
@@ -44,13 +103,13 @@ __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short
 // lagging group's R2 of step s-1, finished one barrier earlier) and retired (vmcnt(0)) by every wave before the
 // barrier that ends the 4th interval -- one barrier before the leading group's first read of it, two before the
 // lagging group's -- so a full k-step of MFMA time covers the global->LDS latency.
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int LN = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
     const float* __restrict__ bias, const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc,
     unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo, int ldp, int M, int N, int K,
-    int a_rpb, long a_bs) {
+    int a_rpb, long a_bs, LnArgs la) {
   constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int STAGE = (2 * BM + 2 * BN) * BK;          // u16 elements per stage: Ahi|Alo|Whi|Wlo
@@ -62,7 +121,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   constexpr int ER = (NW > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : 64);   // rows per epilogue pass (LDS budget)
   constexpr int EPI = ER * WN;                           // floats per wave in the epilogue transpose
   constexpr int LDS_U16 = (TR || NS * STAGE * 2 > NW * EPI * 4) ? NS * STAGE : NW * EPI * 2;
-  __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_U16];
+  constexpr int LN_F32 = LN ? BM * WAVES_N + 2 * BM : 0;   // row partials per wave column + (mean, rstd) per row
+  __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_U16 + 2 * LN_F32];
+  [[maybe_unused]] float* s_part = reinterpret_cast<float*>(smem + LDS_U16);   // [BM][WAVES_N]
+  [[maybe_unused]] float* s_mr = s_part + BM * WAVES_N;                        // [BM][2]
+  static_assert(!LN || (ACT == 0 && !PP && NW * 64 >= BM), "fused LayerNorm: plain epilogue, one thread per tile row");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -281,6 +344,111 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
         }
     }
   }
+  if constexpr (TR && LN) {
+    // ---- fused residual + LayerNorm from the C^T accumulators: lane (m = lane & 15, g = lane >> 4) holds
+    // x[i][j][0..3] = row wr*WM + 16 i + m, columns wc*WN + 16 j + 4 g .. + 3 of the tile
+    const int mrow = lane & 15, g4 = (lane >> 4) * 4;
+    const int tn = (N + BN - 1) / BN;
+    float xv[TM][TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n0 = bn + wc * WN + j * 16 + g4;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) bv = *reinterpret_cast<const float4*>(bias + n0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = bm + wr * WM + i * 16 + mrow;
+        xv[i][j][0] = acc[i][j][0] + bv.x; xv[i][j][1] = acc[i][j][1] + bv.y;
+        xv[i][j][2] = acc[i][j][2] + bv.z; xv[i][j][3] = acc[i][j][3] + bv.w;
+        if (R && m < M) {
+          const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
+          xv[i][j][0] += r4.x; xv[i][j][1] += r4.y; xv[i][j][2] += r4.z; xv[i][j][3] += r4.w;
+        }
+        if (C && m < M)
+          *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(xv[i][j][0], xv[i][j][1], xv[i][j][2], xv[i][j][3]);
+      }
+    }
+    // pass 1: tile mean of every row (lanes of one row: 4 g groups x WAVES_N waves)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sm += (xv[i][j][0] + xv[i][j][1]) + (xv[i][j][2] + xv[i][j][3]);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      if (lane < 16) s_part[(wr * WM + i * 16 + mrow) * WAVES_N + wc] = sm;
+    }
+    __syncthreads();
+    float tmean[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float sm = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_N; ++w) sm += s_part[(wr * WM + i * 16 + mrow) * WAVES_N + w];
+      tmean[i] = sm * (1.0f / (float)BN);
+    }
+    __syncthreads();
+    // pass 2: sum of squared deviations from the tile mean
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[i][j][e] - tmean[i]; q += d * d; }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lane < 16) s_part[(wr * WM + i * 16 + mrow) * WAVES_N + wc] = q;
+      if (lane < 16 && wc == 0) s_mr[(wr * WM + i * 16 + mrow) * 2] = tmean[i];
+    }
+    __syncthreads();
+    if (tid < BM) {
+      float q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_N; ++w) q += s_part[tid * WAVES_N + w];
+      if (bm + tid < M) st_stat(la.stats + (size_t)tx * M + bm + tid, s_mr[tid * 2], q);
+    }
+    ln_rendezvous(la.ctr + 2 * ty, tn, la.err);
+    if (tid < BM && bm + tid < M) {       // merge the tn tile statistics of row bm + tid (equal counts: Chan)
+      float mu = 0.f;
+      for (int t = 0; t < tn; ++t) mu += ld_stat(la.stats + (size_t)t * M + bm + tid).x;
+      mu /= (float)tn;
+      float m2 = 0.f;
+      for (int t = 0; t < tn; ++t) {
+        const float2 st = ld_stat(la.stats + (size_t)t * M + bm + tid);
+        const float d = st.x - mu;
+        m2 += st.y + (float)BN * d * d;
+      }
+      s_mr[tid * 2] = mu;
+      s_mr[tid * 2 + 1] = rsqrtf(m2 / (float)N + la.eps);
+    }
+    __syncthreads();
+    ln_depart(la.ctr + 2 * ty, tn);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n0 = bn + wc * WN + j * 16 + g4;
+      const float4 gm = *reinterpret_cast<const float4*>(la.gamma + n0), bt = *reinterpret_cast<const float4*>(la.beta + n0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int lr = wr * WM + i * 16 + mrow, m = bm + lr;
+        if (m >= M) continue;
+        const float mu = s_mr[lr * 2], rs = s_mr[lr * 2 + 1];
+        const float y0 = (xv[i][j][0] - mu) * rs * gm.x + bt.x, y1 = (xv[i][j][1] - mu) * rs * gm.y + bt.y;
+        const float y2 = (xv[i][j][2] - mu) * rs * gm.z + bt.z, y3 = (xv[i][j][3] - mu) * rs * gm.w + bt.w;
+        if (la.Y) *reinterpret_cast<float4*>(la.Y + (size_t)m * la.ldy + n0) = make_float4(y0, y1, y2, y3);
+        if (Chi) {
+          size_t poff = (size_t)m * ldp;
+          if (la.p_rpb > 0) { const int eb = m / la.p_rpb; poff = (size_t)eb * la.p_bs + (size_t)(m - eb * la.p_rpb) * ldp; }
+          uint2 hi, lo;
+          split2_bf16(y0, y1, hi.x, lo.x);
+          split2_bf16(y2, y3, hi.y, lo.y);
+          *reinterpret_cast<uint2*>(Chi + poff + n0) = hi;
+          *reinterpret_cast<uint2*>(Clo + poff + n0) = lo;
+        }
+      }
+    }
+    return;
+  }
   if constexpr (TR) {
     // ---- epilogue straight from the accumulators (no LDS pass, no barrier): with the operands swapped the tile is
     // C^T, i.e. lane (m = lane & 15, g = lane >> 4) holds C[m][4g .. 4g+3] of every 16x16 tile.
@@ -334,6 +502,103 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   const int n0 = bn + wc * WN + c4 * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias && n0 < N) bv = *reinterpret_cast<const float4*>(bias + n0);  // N % 4 == 0
+  if constexpr (LN) {
+    // ---- fused residual + LayerNorm (see LnArgs): one LDS transpose pass, then lane (rr, c4) holds columns 4 c4 .. + 3
+    // of rows it * ROWS_PER_IT + rr of its wave's sub-tile
+    static_assert(!LN || WM == ER, "fused LayerNorm: one epilogue pass per wave");
+    constexpr int NIT = ER / ROWS_PER_IT;
+    const int tn = (N + BN - 1) / BN;
+#pragma unroll
+    for (int i = 0; i < ER / 16; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ep[(i * 16 + (lane >> 4) * 4 + r) * WN + j * 16 + (lane & 15)] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    float xv[NIT][4];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * ROWS_PER_IT + rr, m = bm + wr * WM + row;
+      const float4 v = *reinterpret_cast<const float4*>(ep + row * WN + c4 * 4);
+      xv[it][0] = v.x + bv.x; xv[it][1] = v.y + bv.y; xv[it][2] = v.z + bv.z; xv[it][3] = v.w + bv.w;
+      if (R && m < M) {
+        const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
+        xv[it][0] += r4.x; xv[it][1] += r4.y; xv[it][2] += r4.z; xv[it][3] += r4.w;
+      }
+      if (C && m < M) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(xv[it][0], xv[it][1], xv[it][2], xv[it][3]);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      float sm = (xv[it][0] + xv[it][1]) + (xv[it][2] + xv[it][3]);
+#pragma unroll
+      for (int o = 1; o < F4_PER_ROW; o <<= 1) sm += __shfl_xor(sm, o, 64);
+      if (c4 == 0) s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + wc] = sm;
+    }
+    __syncthreads();
+    float tmean[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      float sm = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_N; ++w) sm += s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + w];
+      tmean[it] = sm * (1.0f / (float)BN);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = xv[it][e] - tmean[it]; q += d * d; }
+#pragma unroll
+      for (int o = 1; o < F4_PER_ROW; o <<= 1) q += __shfl_xor(q, o, 64);
+      if (c4 == 0) s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + wc] = q;
+      if (c4 == 0 && wc == 0) s_mr[(wr * WM + it * ROWS_PER_IT + rr) * 2] = tmean[it];
+    }
+    __syncthreads();
+    if (tid < BM) {
+      float q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_N; ++w) q += s_part[tid * WAVES_N + w];
+      if (bm + tid < M) st_stat(la.stats + (size_t)tx * M + bm + tid, s_mr[tid * 2], q);
+    }
+    ln_rendezvous(la.ctr + 2 * ty, tn, la.err);
+    if (tid < BM && bm + tid < M) {
+      float mu = 0.f;
+      for (int t = 0; t < tn; ++t) mu += ld_stat(la.stats + (size_t)t * M + bm + tid).x;
+      mu /= (float)tn;
+      float m2 = 0.f;
+      for (int t = 0; t < tn; ++t) {
+        const float2 st = ld_stat(la.stats + (size_t)t * M + bm + tid);
+        const float d = st.x - mu;
+        m2 += st.y + (float)BN * d * d;
+      }
+      s_mr[tid * 2] = mu;
+      s_mr[tid * 2 + 1] = rsqrtf(m2 / (float)N + la.eps);
+    }
+    __syncthreads();
+    ln_depart(la.ctr + 2 * ty, tn);
+    const float4 gm = *reinterpret_cast<const float4*>(la.gamma + n0), bt = *reinterpret_cast<const float4*>(la.beta + n0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int lr = wr * WM + it * ROWS_PER_IT + rr, m = bm + lr;
+      if (m >= M) continue;
+      const float mu = s_mr[lr * 2], rs = s_mr[lr * 2 + 1];
+      const float y0 = (xv[it][0] - mu) * rs * gm.x + bt.x, y1 = (xv[it][1] - mu) * rs * gm.y + bt.y;
+      const float y2 = (xv[it][2] - mu) * rs * gm.z + bt.z, y3 = (xv[it][3] - mu) * rs * gm.w + bt.w;
+      if (la.Y) *reinterpret_cast<float4*>(la.Y + (size_t)m * la.ldy + n0) = make_float4(y0, y1, y2, y3);
+      if (Chi) {
+        size_t poff = (size_t)m * ldp;
+        if (la.p_rpb > 0) { const int eb = m / la.p_rpb; poff = (size_t)eb * la.p_bs + (size_t)(m - eb * la.p_rpb) * ldp; }
+        uint2 hi, lo;
+        split2_bf16(y0, y1, hi.x, lo.x);
+        split2_bf16(y2, y3, hi.y, lo.y);
+        *reinterpret_cast<uint2*>(Chi + poff + n0) = hi;
+        *reinterpret_cast<uint2*>(Clo + poff + n0) = lo;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < WM / ER; ++h) {
     if (h) __builtin_amdgcn_wave_barrier();
@@ -409,9 +674,10 @@ int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const 
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
            int ksplit = 1, int a_rpb = 0, long a_bs = 0) {
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM), ksplit), block((BM / WM) * (BN / WN) * 64);
+  const LnArgs la{};
 #define GRIDMM_LP(ACT)                                                                                        \
   GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
-                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs)
+                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs, la)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
   else if (act == GRIDMM_ACT_RELU) GRIDMM_LP(GRIDMM_ACT_RELU);
@@ -420,6 +686,35 @@ int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const 
     else return GRIDMM_EINVAL;
   }
 #undef GRIDMM_LP
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+// Fused-LayerNorm launch of one tile configuration: refuses (GRIDMM_EUNSUPPORTED) unless the whole grid is resident at
+// once -- the rendezvous of a row block's column tiles would otherwise wait for workgroups that cannot start.
+template <int BM, int BN, int WM, int WN, int NS, int BK, int TR>
+int launch_ln(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
+              const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
+              unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, const LnArgs& la, bool dry,
+              hipStream_t st) {
+  auto kern = linear_planes_kernel<BM, BN, WM, WN, NS, BK, GRIDMM_ACT_NONE, 0, 0, TR, 1>;
+  constexpr int threads = (BM / WM) * (BN / WN) * 64;
+  static int capacity = -1;                    // resident workgroups of this kernel on the whole device
+  if (capacity < 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, 0) != hipSuccess)
+      capacity = 0;
+    else
+      capacity = cus * per_cu;
+    (void)hipGetLastError();
+  }
+  if (N % BN) return GRIDMM_EUNSUPPORTED;
+  const long wgs = (long)(N / BN) * ((M + BM - 1) / BM);
+  if (wgs > capacity) return GRIDMM_EUNSUPPORTED;
+  if (dry) return GRIDMM_OK;
+  GRIDMM_LAUNCH(kern, dim3((unsigned)wgs), dim3(threads), 0, st, Ahi, Alo, lda, Whi, Wlo, Kp, bias, R, ldr, C, ldc, Chi, Clo,
+                ldp, M, N, K, 0, 0L, la);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -583,6 +878,44 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     default: return GRIDMM_EINVAL;
   }
 #undef GRIDMM_ARGS
+}
+
+// ---- GEMM + residual + LayerNorm in one launch (see LnArgs): Y = LayerNorm(A W^T + bias + residual) gamma + beta.
+// Tile choice follows pick_cfg's two regimes (64x64 direct epilogue for small M * N, 128x128 otherwise); shapes the
+// fused form cannot take (N not a multiple of the tile width, a grid larger than the device holds at once, or
+// GRIDMM_LN_FUSE=0 in the environment) return GRIDMM_EUNSUPPORTED and the caller issues gridmm_linear_planes +
+// gridmm_layernorm instead.
+static int ln_fuse_enabled() {
+  static const int on = getenv("GRIDMM_LN_FUSE") ? atoi(getenv("GRIDMM_LN_FUSE")) : 1;
+  return on;
+}
+
+extern "C" size_t gridmm_linear_planes_ln_workspace(int M, int N) {
+  return (size_t)((N + 63) / 64) * (size_t)M * sizeof(float2);
+}
+extern "C" size_t gridmm_linear_planes_ln_sync_bytes(int M) { return (size_t)((M + 63) / 64) * 2 * sizeof(unsigned); }
+
+extern "C" int gridmm_linear_planes_ln(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int Kp,
+                                       const float* bias, const float* residual, int ldr, float* C_pre, int ldc,
+                                       const float* gamma, const float* beta, float eps, float* Y, int ldy, void* Y_hi,
+                                       void* Y_lo, int ldp, int p_rpb, int64_t p_bs, void* workspace, void* sync_words,
+                                       int M, int N, int K, int dry_run, gridmm_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || !gamma || !beta) return GRIDMM_EINVAL;
+  if ((C_pre && ldc % 4) || (residual && ldr % 4) || (Y && ldy % 4) || (Y_hi && (ldp % 4 || !Y_lo || (p_rpb > 0 && p_bs % 4))) ||
+      (!Y && !Y_hi))
+    return GRIDMM_EINVAL;
+  if (!ln_fuse_enabled()) return GRIDMM_EUNSUPPORTED;
+  if (!dry_run && (!workspace || !sync_words)) return GRIDMM_EINVAL;
+  const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
+  const unsigned short *wh = (const unsigned short*)W_hi, *wl = (const unsigned short*)W_lo;
+  LnArgs la{gamma, beta, eps, Y, ldy, (float2*)workspace, (unsigned*)sync_words, p_rpb, (long)p_bs, nullptr};
+  hipStream_t st = as_stream(stream);
+#define GRIDMM_LN_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C_pre, ldc, (unsigned short*)Y_hi, (unsigned short*)Y_lo, ldp, M, N, K, la, dry_run != 0, st
+  int rc = GRIDMM_EUNSUPPORTED;
+  if (pick_cfg(M, N, K) == 43 && K % 64 == 0) rc = launch_ln<64, 64, 32, 32, 2, 64, 1>(GRIDMM_LN_ARGS);
+  if (rc == GRIDMM_EUNSUPPORTED) rc = launch_ln<128, 128, 32, 32, 2, 32, 0>(GRIDMM_LN_ARGS);
+#undef GRIDMM_LN_ARGS
+  return rc;
 }
 
 extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi,

@@ -69,12 +69,19 @@ def count_graph_nodes(fn):
 
 
 class GraphedNavStep:
-    def __init__(self, model, mem, batch, depth, restore=None, warmup=2, buckets=None, count_nodes=False):
+    def __init__(self, model, mem, batch, depth, restore=None, warmup=2, buckets=None, count_nodes=False,
+                 instruction_cache=False):
         """depth: (B, n_pts) uint16 device tensor of the observation appended by each step.
         restore: optional (n_pts0, bbox0) device tensors copied back before each step, so that every replay
-        appends to the same history prefix (benchmarks at a fixed memory depth t)."""
+        appends to the same history prefix (benchmarks at a fixed memory depth t).
+        instruction_cache: the instruction-side projections (text_proj, the instruction's K / V in the grid / text layer
+        and in the local encoder's layers) are computed ONCE here, as at the start of an episode, and the captured step
+        reads them (GlocalTextPathNavCMT.instruction_cache); False: every step recomputes them like the reference."""
         self.model, self.mem, self.batch, self.depth = model, mem, dict(batch), depth
         self.restore = restore
+        if instruction_cache:
+            with torch.no_grad():
+                self.batch["instruction_cache"] = model.instruction_cache(batch["txt_embeds"], batch["txt_masks"])
         dev = mem.device
         # fused-logit index maps (integer form of the reference's per-call vpid loops, vilmodel.py:881-899): static device
         # buffers read by the graph, refreshed from pinned host buffers by refresh_fusion_maps() before a replay
@@ -227,6 +234,30 @@ class NavigationGraphs:
         if tok != getattr(self, "_tok", None):
             self.graphs.clear()
             self._tok, self._early = tok, None
+            for st in self._ic.values():      # the cached instruction-side projections were made with the old weights
+                st["src"] = None
+
+    # Per-episode instruction-side constants (GlocalTextPathNavCMT.instruction_cache): ONE set of static buffers per
+    # (B, L), shared by every captured graph of that instruction shape and refilled when a call arrives with a new
+    # txt_embeds tensor (a rollout passes the same tensor at every step).  use_instruction_cache = False: every step
+    # recomputes them inside its graph, as the reference does.
+    use_instruction_cache = True
+
+    def _icache(self, txt_embeds, txt_masks):
+        if not self.use_instruction_cache:
+            return None
+        B, L, _ = txt_embeds.shape
+        st = self._ic.get((B, L))
+        if st is None:
+            dev = txt_embeds.device
+            st = {"buf": {k: torch.empty(shp, dtype=dt, device=dev)
+                          for k, (shp, dt) in self.model.instruction_cache_shapes(B, L).items()}, "src": None, "ver": None}
+            self._ic[(B, L)] = st
+        if st["src"] is not txt_embeds or st["ver"] != txt_embeds._version:
+            st["ic"] = self.model.instruction_cache(txt_embeds, txt_masks, out=st["buf"])
+            st["src"], st["ver"] = txt_embeds, txt_embeds._version
+            self.icache_fills += 1
+        return st["ic"]
 
     TENSOR_KEYS = ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_masks", "gmap_visited_masks",
                    "vp_img_embeds", "vp_pos_fts", "vp_masks", "vp_nav_masks", "vp_obj_masks")
@@ -235,7 +266,8 @@ class NavigationGraphs:
         self.model, self.max_graphs = model, max_graphs
         self.graphs = {}            # key -> dict(graph, static inputs, front buffers, outs); insertion order = recency
         self.pool = None
-        self.captures = self.replays = 0
+        self.captures = self.replays = self.icache_fills = 0
+        self._ic = {}               # (B, L) -> static instruction-cache buffers + the tensor they were filled from
 
     def _inputs(self, batch):
         ins = {k: batch[k] for k in self.TENSOR_KEYS if batch.get(k) is not None}
@@ -247,6 +279,8 @@ class NavigationGraphs:
 
     @staticmethod
     def _front_tensors(fr):
+        if getattr(fr, "icache", None) is not None:     # the instruction side is static already (shared cache buffers)
+            return {"proj": fr.proj, "occ": fr.occ, "pos": fr.gridmap_pos_fts}
         return {"txt_f32": fr.txt.f32, "txt_hi": fr.txt.hi, "txt_lo": fr.txt.lo, "txt_m": fr.txt_m, "proj": fr.proj,
                 "occ": fr.occ, "pos": fr.gridmap_pos_fts}
 
@@ -262,9 +296,14 @@ class NavigationGraphs:
         ent = {"ins": {k: v.clone() for k, v in self._inputs(batch).items()},
                "fr": {k: v.clone() for k, v in self._front_tensors(fr).items()}}
         f = ent["fr"]
-        f["txt_hi"], f["txt_lo"] = ops._planes_like(fr.txt.hi.shape, fr.txt.hi.device)   # one allocation: moved by one launch
-        ent["front"] = SimpleNamespace(txt=ops.Act(f["txt_f32"], f["txt_hi"], f["txt_lo"]), txt_m=f["txt_m"], proj=f["proj"],
-                                       occ=f["occ"], gridmap_pos_fts=f["pos"], in_place=False)
+        ic = getattr(fr, "icache", None)
+        if ic is not None:
+            ent["front"] = SimpleNamespace(txt=ic.txt, txt_m=ic.txt_m, proj=f["proj"], occ=f["occ"], gridmap_pos_fts=f["pos"],
+                                           in_place=False, icache=ic, L=ic.L)
+        else:
+            f["txt_hi"], f["txt_lo"] = ops._planes_like(fr.txt.hi.shape, fr.txt.hi.device)   # one allocation: moved by one launch
+            ent["front"] = SimpleNamespace(txt=ops.Act(f["txt_f32"], f["txt_hi"], f["txt_lo"]), txt_m=f["txt_m"], proj=f["proj"],
+                                           occ=f["occ"], gridmap_pos_fts=f["pos"], in_place=False)
         sb = self._static_batch(ent, batch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -290,7 +329,8 @@ class NavigationGraphs:
         environment step, so that the device works through it while the host is still collating the rest of the inputs.
         The next __call__ with the same instruction tensor and grid memory picks the result up."""
         self._early = (txt_embeds, grid_memory, self._mem_state(grid_memory),
-                       self.model.navigation_front({"txt_embeds": txt_embeds, "txt_masks": txt_masks, "grid_memory": grid_memory}))
+                       self.model.navigation_front({"txt_embeds": txt_embeds, "txt_masks": txt_masks, "grid_memory": grid_memory,
+                                                    "instruction_cache": self._icache(txt_embeds, txt_masks)}))
 
     @staticmethod
     def _mem_state(mem):
@@ -307,7 +347,10 @@ class NavigationGraphs:
         if early is not None and early[0] is batch["txt_embeds"] and early[1] is mem and early[2] == self._mem_state(mem):
             fr = early[3]
         else:
-            fr = model.navigation_front(batch)
+            ic = batch.get("instruction_cache")
+            if ic is None and mem is not None:
+                ic = self._icache(batch["txt_embeds"], batch["txt_masks"])
+            fr = model.navigation_front(dict(batch, instruction_cache=ic))
         cmax = mem.cmax_hint() if mem is not None and hasattr(mem, "cmax_hint") else None
         if cmax is None:
             cmax = int(fr.occ.sum(1, dtype=torch.int32).max())
@@ -318,8 +361,8 @@ class NavigationGraphs:
                 raise RuntimeError("NavigationGraphs: cell bucket %d chosen from a tracked count of %d, but this call's "
                                    "memory has %d occupied cells" % (c_pad, cmax, true))
         ins = self._inputs(batch)
-        key = (tuple(fr.txt.f32.shape), batch["gmap_masks"].shape[1], batch["vp_masks"].shape[1], c_pad,
-               tuple(sorted(ins)))
+        key = (tuple(fr.txt.hi.shape), batch["gmap_masks"].shape[1], batch["vp_masks"].shape[1], c_pad,
+               tuple(sorted(ins)), bool(ops.LN_FUSE), getattr(fr, "icache", None) is not None)
         ent = self.graphs.pop(key, None)
         if ent is None:
             ent = self._capture(key, fr, batch, c_pad)

@@ -180,7 +180,7 @@ def split_rows(x, out=None):
     return Act(x, hi, lo)
 
 
-def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_planes=False):
+def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_planes=False, planes_out=None):
     """act(x @ W^T + b) (+ residual) -> Act.  x: Act or fp32 tensor (..., K).
 
     K % 32 == 0 (every hidden-size GEMM): gridmm_linear_planes -- A as bf16 planes (taken from the
@@ -207,7 +207,10 @@ def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_pla
             M, _, lda, rpb, bs = _rows_map(a.hi)
         c = out if out is not None else (torch.empty(oshape, dtype=torch.float32, device=dev) if want_f32 else None)
         hi = lo = None
-        if want_planes:
+        if planes_out is not None:           # (hi, lo): contiguous destination planes of the result's shape
+            hi, lo = planes_out
+            assert tuple(hi.shape) == oshape and hi.is_contiguous() and lo.is_contiguous() and hi.dtype == torch.bfloat16
+        elif want_planes:
             hi, lo = _planes_like(oshape, dev)
         ldc = _rows2d(c)[2] if c is not None else 0
         ldr = _rows2d(residual)[2] if residual is not None else 0
@@ -270,6 +273,69 @@ def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=Non
         copy_rows(out, final, 0)
         out = final
     return Act(out, hi, lo)
+
+
+# ---- GEMM + residual + LayerNorm as one launch (gridmm_linear_planes_ln) ---------------------------------------------
+# Measured on MI355X (tools/bench_linear_ln.py, profiles/r4_linear_ln_fused_experiment.txt): the rendezvous (sc1 round trips
+# for statistics and counters, all outputs written in one burst after it) costs MORE than the LayerNorm launch it removes
+# -- the B = 32 step runs 2.37 ms fused against 2.28 ms with the launches -- so the fused form is OFF unless asked for.
+LN_FUSE = bool(int(os.environ.get("GRIDMM_LN_FUSE", "0")))   # also: never on when several streams run at once (the fused
+                        # launches rendezvous inside their own grid and must not share the device with one another)
+_LN_SYNC = {}           # device index -> zeroed counter block (the library leaves it zeroed)
+
+
+def ln_sync(dev):
+    """The counter block of the fused GEMM + LayerNorm launches on `dev`, or None when the fused form is off (LN_FUSE) or
+    the block would have to be created inside a stream capture (the warm-up pass of every capture creates it)."""
+    if not LN_FUSE:
+        return None
+    t = _LN_SYNC.get(dev.index)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = torch.zeros(1 << 16, dtype=torch.int32, device=dev)     # 2 words per 64 rows: rows up to 2 M
+        _LN_SYNC[dev.index] = t
+    return t
+
+
+def linear_ln(x, pw, gamma, beta, eps, residual=None, want_pre=False, want_f32=True, want_planes=True, planes_out=None):
+    """LayerNorm(x @ W^T + b (+ residual)) * gamma + beta as ONE launch -> (Act of the result, fp32 pre-LayerNorm sums
+    or None), or None when the shape cannot take the fused form (the caller then issues linear + layernorm).
+    x: Act with contiguous planes (M rows)."""
+    lib = _lib.load()
+    a = x if isinstance(x, Act) else Act(x)
+    if a.hi is None or not a.hi.is_contiguous():
+        return None
+    dev = a.hi.device
+    sync = ln_sync(dev)
+    K, N = a.hi.shape[-1], pw.N
+    M = a.hi.numel() // K
+    if sync is None or K != pw.K or K % 32 or N % 4 or (M + 63) // 64 * 2 > sync.numel():
+        return None
+    oshape = tuple(a.hi.shape[:-1]) + (N,)
+    if residual is not None:
+        residual = uniform_rows(residual)
+    ldr = _rows2d(residual)[2] if residual is not None else 0
+    ldp, rpb, bs = N, 0, 0
+    if planes_out is not None:
+        probe = planes_out[0]
+        _, _, ldp, rpb, bs = _rows_map(probe)
+    args = lambda pre, y, hi, lo, ws, dry: lib.gridmm_linear_planes_ln(
+        _p(a.hi), _p(a.lo), K, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual), ldr, _p(pre), N, _p(gamma), _p(beta),
+        float(eps), _p(y), N, _p(hi), _p(lo), ldp, rpb, bs, _p(ws), _p(sync), M, N, K, dry, _stream())
+    dummy = a.hi                                     # dry run: only the shape question (pointers are not dereferenced)
+    if args(None, None, dummy, dummy, None, 1) != 0:
+        return None
+    pre = torch.empty(oshape, dtype=torch.float32, device=dev) if want_pre else None
+    y = torch.empty(oshape, dtype=torch.float32, device=dev) if want_f32 else None
+    hi = lo = None
+    if planes_out is not None:
+        hi, lo = planes_out
+    elif want_planes:
+        hi, lo = _planes_like(oshape, dev)
+    ws = torch.empty(lib.gridmm_linear_planes_ln_workspace(M, N), dtype=torch.uint8, device=dev)
+    _timed("linear", 2.0 * M * N * K, lambda: _lib.check(args(pre, y, hi, lo, ws, 0), "gridmm_linear_planes_ln"))
+    return Act(y, hi, lo), pre
 
 
 def attention(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True):
@@ -335,16 +401,18 @@ def attention_planes(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_
     return Act(out, hi, lo)
 
 
-def attention_rows(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True, cfg=0):
+def attention_rows(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True, cfg=0, k2=None, v2=None):
     """bf16x3 attention straight from row-major planes.  q, k, v: (hi, lo) pairs of bf16 plane views (B,S,H*64) --
     typically column slices of the fused QKV / KV GEMM outputs; K and V rows are staged in LDS by the kernel (no
-    re-tiling pass).  Returns an Act (planes for the output projection by default)."""
+    re-tiling pass).  k2 / v2: (hi, lo) pairs holding the LAST keys of the context in a second buffer (same strides for
+    both; gridmm_attention_rows_seg).  Returns an Act (planes for the output projection by default)."""
     lib = _lib.load()
     qh, ql = q
     kh, kl = k
     vh, vl = v
     B, Sq, HD = qh.shape
-    Sk = kh.shape[1]
+    S1 = kh.shape[1]
+    Sk = S1 + (k2[0].shape[1] if k2 is not None else 0)
     assert HD == heads * 64 and kh.shape[2] == HD and vh.shape == kh.shape
     for t in (qh, ql, kh, kl, vh, vl):
         assert t.dtype == torch.bfloat16 and t.stride(2) == 1
@@ -360,6 +428,16 @@ def attention_rows(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_pl
         if kmask.dtype == torch.bool:
             kmask = kmask.view(torch.uint8)
         assert kmask.shape == (B, Sk) and kmask.stride(1) == 1
+    if k2 is not None:
+        (k2h, k2l), (v2h, v2l) = k2, v2
+        for t in (k2h, k2l, v2h, v2l):
+            assert t.dtype == torch.bfloat16 and t.stride(2) == 1 and t.shape == k2h.shape and t.stride() == k2h.stride()
+        _timed("attention", 4.0 * B * Sq * Sk * HD, lambda: _lib.check(lib.gridmm_attention_rows_seg(
+            _p(qh), _p(ql), qh.stride(0), qh.stride(1), _p(kh), _p(kl), kh.stride(0), kh.stride(1), _p(vh), _p(vl),
+            vh.stride(0), vh.stride(1), S1, _p(k2h), _p(k2l), _p(v2h), _p(v2l), k2h.stride(0), k2h.stride(1), _p(kmask),
+            kmask.stride(0) if kmask is not None else 0, _p(out), Sq * HD, HD, _p(hi), _p(lo), Sq * HD, HD, B, heads, Sq, Sk,
+            float(scale), _stream()), "gridmm_attention_rows_seg"))
+        return Act(out, hi, lo)
     _timed("attention", 4.0 * B * Sq * Sk * HD, lambda: _lib.check(lib.gridmm_attention_rows_cfg(
         _p(qh), _p(ql), qh.stride(0), qh.stride(1), _p(kh), _p(kl), kh.stride(0), kh.stride(1), _p(vh), _p(vl),
         vh.stride(0), vh.stride(1), _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * HD, HD,
@@ -396,14 +474,21 @@ class XLayerWeights:
         self.H, self.I = xq.N, ffn_i.N
 
 
-def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12, planes_out=None):
+def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12, planes_out=None, kv2=None):
     """One GraphLXRTXLayer as ONE C call (gridmm_xattn_layer_fwd): x Act (f32 + planes) (B, Sq, H); kv Act planes
     (B, Sk, n*H) holding the context's K / V projections at columns k_col / v_col.  Returns Act(f32 + planes).
     planes_out = (hi, lo): where the output planes go (views, possibly rows of a longer padded sequence).  The scratch is
     allocated per call (stream-ordered by the caching allocator: safe for eager calls, several graphs and streams)."""
     lib = _lib.load()
     B, Sq, H = x.f32.shape
-    Sk = kv.hi.shape[1]
+    Sk1 = kv.hi.shape[1]
+    Sk = Sk1
+    k2 = (None, None, 0, 0, 0, 0)
+    if kv2 is not None:     # (Act planes (B, S2, .), k column, v column): the last S2 context rows live in a second buffer
+        a2, k2_col, v2_col = kv2
+        assert a2.hi.stride(2) == 1 and a2.hi.stride() == a2.lo.stride() and a2.hi.shape[0] == B
+        Sk = Sk1 + a2.hi.shape[1]
+        k2 = (a2.hi, a2.lo, a2.hi.stride(0), a2.hi.stride(1), int(k2_col), int(v2_col))
     dev = x.f32.device
     assert x.f32.is_contiguous() and x.hi.is_contiguous() and kv.hi.stride(2) == 1 and kv.hi.stride() == kv.lo.stride()
     need = lib.gridmm_xattn_layer_workspace(B, Sq, H, w.I)
@@ -421,9 +506,10 @@ def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12, planes_ou
     sm = self_mask.view(torch.uint8) if self_mask.dtype == torch.bool else self_mask
     assert cm.stride(1) == 1 and sm.stride(1) == 1
     _lib.check(lib.gridmm_xattn_layer_fwd(ctypes.byref(w.c), _p(x.f32), _p(x.hi), _p(x.lo), _p(kv.hi), _p(kv.lo),
-                                          kv.hi.stride(0), kv.hi.stride(1), int(k_col), int(v_col), _p(cm), cm.stride(0),
-                                          _p(sm), sm.stride(0), _p(y), _p(hi), _p(lo), rpb, bs, _p(ws), need, B, Sq, Sk,
-                                          heads, _stream()), "gridmm_xattn_layer_fwd")
+                                          kv.hi.stride(0), kv.hi.stride(1), int(k_col), int(v_col), Sk1, _p(k2[0]), _p(k2[1]),
+                                          k2[2], k2[3], k2[4], k2[5], _p(cm), cm.stride(0),
+                                          _p(sm), sm.stride(0), _p(y), _p(hi), _p(lo), rpb, bs, _p(ws), need, _p(ln_sync(dev)),
+                                          B, Sq, Sk, heads, _stream()), "gridmm_xattn_layer_fwd")
     return Act(y, hi, lo)
 
 
@@ -691,12 +777,13 @@ def grid_sort_ids(cell_id, n_pts, perm, cell_start):
                "gridmm_grid_sort_ids")
 
 
-def text_fragments(text_fts):
+def text_fragments(text_fts, out=None):
     """(B, L, D) fp32 -> MFMA B-fragment planes (fp16 hi|lo)."""
     lib = _lib.load()
     B, L, D = text_fts.shape
     Lt = (L + 15) // 16
-    frag = torch.empty(B, 2, Lt, D // 32, 64, 8, dtype=torch.float16, device=text_fts.device)
+    frag = out if out is not None else torch.empty(B, 2, Lt, D // 32, 64, 8, dtype=torch.float16, device=text_fts.device)
+    assert frag.shape == (B, 2, Lt, D // 32, 64, 8) and frag.is_contiguous() and frag.dtype == torch.float16
     _lib.check(lib.gridmm_text_fragments(_p(text_fts.contiguous()), _p(frag), B, L, D, _stream()),
                "gridmm_text_fragments")
     return frag

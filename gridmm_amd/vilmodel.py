@@ -276,13 +276,15 @@ class GlocalTextPathNavCMT(nn.Module):
     def _ln(self, mod, x, residual=None, **kw):
         return ops.layernorm(x, mod.weight, mod.bias, mod.eps, residual=residual, **kw)
 
-    def _attend(self, q, k, v, kmask):
-        """q/k/v: ops.Act holding bf16 planes (B,S,n*H) + column offsets (act, col0) -> bf16x3 attention."""
+    def _attend(self, q, k, v, kmask, k2=None, v2=None):
+        """q/k/v: ops.Act holding bf16 planes (B,S,n*H) + column offsets (act, col0) -> bf16x3 attention.  k2 / v2: the
+        last keys of the context in a second buffer (instruction rows kept per episode)."""
         def sl(t):
             a, c0 = t
             H = self.config.hidden_size
             return a.hi[..., c0:c0 + H], a.lo[..., c0:c0 + H]
-        return ops.attention_rows(sl(q), sl(k), sl(v), kmask, heads=self.heads)     # -> planes for the out-proj
+        return ops.attention_rows(sl(q), sl(k), sl(v), kmask, heads=self.heads,      # -> planes for the out-proj
+                                  k2=None if k2 is None else sl(k2), v2=None if v2 is None else sl(v2))
 
     def _self_attention(self, att, key, x, kmask):
         """BertAttention (vilmodel.py:172-182): LN(dense(attn(x)) + x).  x: Act(f32 + planes)."""
@@ -292,13 +294,15 @@ class GlocalTextPathNavCMT(nn.Module):
         h = ops.linear(ctx, self._lin(att.output.dense, key + ".o"), residual=x.f32)
         return self._ln(att.output.LayerNorm, h, want_planes=True)
 
-    def _cross_attention(self, xatt, key, x, ctx, ctx_mask, kv=None):
-        """BertXAttention (vilmodel.py:370-379).  kv: optional precomputed (Act planes (B,Sk,n*2H), col0)."""
+    def _cross_attention(self, xatt, key, x, ctx, ctx_mask, kv=None, kv2=None):
+        """BertXAttention (vilmodel.py:370-379).  kv: optional precomputed (Act planes (B,Sk,n*2H), col0); kv2: the same
+        for the last rows of the context when they live in a second buffer."""
         H = x.shape[-1]
         q = ops.linear(x, self._qkv(xatt.att, key, "q"), want_f32=False, want_planes=True)
         if kv is None:
             kv = (ops.linear(ctx, self._qkv(xatt.att, key, "kv"), want_f32=False, want_planes=True), 0)
-        c = self._attend((q, 0), (kv[0], kv[1]), (kv[0], kv[1] + H), ctx_mask)
+        c = self._attend((q, 0), (kv[0], kv[1]), (kv[0], kv[1] + H), ctx_mask,
+                         k2=None if kv2 is None else (kv2[0], kv2[1]), v2=None if kv2 is None else (kv2[0], kv2[1] + H))
         h = ops.linear(c, self._lin(xatt.output.dense, key + ".o"), residual=x.f32)
         return self._ln(xatt.output.LayerNorm, h, want_planes=True)
 
@@ -311,7 +315,7 @@ class GlocalTextPathNavCMT(nn.Module):
         a = self._self_attention(layer.attention, key + ".att", x, kmask)
         return self._ffn(layer.intermediate, layer.output, key, a)
 
-    def _x_layer(self, layer, key, lang, lang_mask, visn, visn_mask, kv=None, planes_out=None):
+    def _x_layer(self, layer, key, lang, lang_mask, visn, visn_mask, kv=None, planes_out=None, kv2=None):
         """GraphLXRTXLayer.forward with graph_sprels=None (vilmodel.py:399-414).  One C call per layer
         (gridmm_xattn_layer_fwd) unless per-kernel timing is on (ops.TIMER: the eleven launches are issued one by one)."""
         if ops.TIMER is None and visn.f32 is not None and visn.hi is not None and visn.f32.is_contiguous():
@@ -330,8 +334,8 @@ class GlocalTextPathNavCMT(nn.Module):
                 ent = (sig, ops.XLayerWeights(*pws, *lns))
                 self._packed[key + ".xlayer"] = ent
             return ops.xattn_layer(ent[1], visn, kv[0], kv[1], kv[1] + H, lang_mask, visn_mask, heads=self.heads,
-                                   planes_out=planes_out)
-        a = self._cross_attention(layer.visual_attention, key + ".x", visn, lang, lang_mask, kv=kv)
+                                   planes_out=planes_out, kv2=None if kv2 is None else (kv2[0], kv2[1], kv2[1] + H))
+        a = self._cross_attention(layer.visual_attention, key + ".x", visn, lang, lang_mask, kv=kv, kv2=kv2)
         a = self._self_attention(layer.visn_self_att, key + ".s", a, visn_mask)
         return self._ffn(layer.visn_inter, layer.visn_output, key, a, planes_out=planes_out)
 
@@ -445,6 +449,7 @@ class GlocalTextPathNavCMT(nn.Module):
         """vilmodel.py:782-918 on HIP kernels.  Same arguments, same output dict.  With grad enabled (fine-tune /
         pre-training) the differentiable path of vilmodel_train.py runs; under torch.no_grad() the inference path."""
         if self._differentiable():
+            kwargs.pop("instruction_cache", None)      # (inference-only shortcut; the training path records every op)
             return vilmodel_train.forward_navigation(self, *args, **kwargs)
         return self._forward_navigation_infer(*args, **kwargs)
 
@@ -453,13 +458,13 @@ class GlocalTextPathNavCMT(nn.Module):
             self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
             gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
             vp_nav_masks, vp_obj_masks, vp_cand_vpids, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None,
-            fusion_maps=None):
+            fusion_maps=None, instruction_cache=None):
         dev = txt_embeds.device
         G, V = gmap_masks.shape[1], vp_masks.shape[1]
         gmap_m = self._u8(gmap_masks)
         gmap_embeds, vp_embeds, map_embeds = self._encode_navigation_infer(
             txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks, vp_img_embeds, vp_pos_fts,
-            vp_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory)
+            vp_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory, icache=instruction_cache)
         return self._heads_infer(gmap_embeds, vp_embeds, map_embeds, gmap_m, gmap_visited_masks, gmap_vpids,
                                  vp_nav_masks, vp_obj_masks, vp_cand_vpids, fusion_maps, G, V, dev)
 
@@ -471,16 +476,65 @@ class GlocalTextPathNavCMT(nn.Module):
     varlen_buckets = None
     DEFAULT_BUCKETS = (64, 80, 96, 112, 128, 144, 160, 176, N_CELLS)   # 16-row steps: a step costs what its occupied cells cost
 
+    # ---- per-episode instruction-side constants of 'navigation' -------------------------------------------------
+    # The reference recomputes, at EVERY step, text_proj(txt_embeds) (vilmodel.py:793), the K / V projections of the
+    # instruction in the grid / text layer (:841, BertXAttention :370-379) and the K / V projections of the 80
+    # instruction rows of the local encoder's [map | txt] context in each of its layers (:846-853) -- from a
+    # txt_embeds that the 'language' call produced once per episode (r2r/agent.py:274-276).  Row-wise projections of
+    # constant rows: computing them once gives the same bits.  `instruction_cache` does that; 'navigation' takes the
+    # result as batch["instruction_cache"] (declared in bench.py's config and DESIGN.md like the grid_proj shortcut).
+    def instruction_cache_shapes(self, B, L):
+        H, D = self.config.hidden_size, self.text_proj.out_features
+        nl = len(self.local_encoder.encoder.x_layers)
+        ng = len(self.grid_txt_encoder.x_layers)
+        return {"txt_hi": ((B, L, H), torch.bfloat16), "txt_lo": ((B, L, H), torch.bfloat16),
+                "frag": ((B, 2, (L + 15) // 16, D // 32, 64, 8), torch.float16),
+                "gt_hi": ((ng, B, L, 2 * H), torch.bfloat16), "gt_lo": ((ng, B, L, 2 * H), torch.bfloat16),
+                "loc_hi": ((B, L, nl * 2 * H), torch.bfloat16), "loc_lo": ((B, L, nl * 2 * H), torch.bfloat16),
+                "txt_m": ((B, L), torch.uint8)}
+
     @torch.no_grad()
-    def _nav_front(self, txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None, txt_planes=None):
+    def instruction_cache(self, txt_embeds, txt_masks, out=None):
+        """-> SimpleNamespace of the instruction-side tensors every navigation step of the episode reuses.  out: dict of
+        preallocated buffers (instruction_cache_shapes; e.g. the static buffers a hipGraph of the step reads)."""
+        B, L, H = txt_embeds.shape
+        dev = txt_embeds.device
+        if out is None:
+            out = {k: torch.empty(shp, dtype=dt, device=dev) for k, (shp, dt) in self.instruction_cache_shapes(B, L).items()}
+        txt = ops.split_rows(txt_embeds.float().contiguous(), out=(out["txt_hi"], out["txt_lo"]))
+        text_fts = ops.linear(txt, self._lin(self.text_proj, "text_proj")).f32
+        frag = ops.text_fragments(text_fts, out=out["frag"])
+        gt = []
+        for i, layer in enumerate(self.grid_txt_encoder.x_layers):
+            ops.linear(txt, self._qkv(layer.visual_attention.att, "grid_txt.%d.x" % i, "kv"), want_f32=False,
+                       planes_out=(out["gt_hi"][i], out["gt_lo"][i]))
+            gt.append(ops.Act(None, out["gt_hi"][i], out["gt_lo"][i]))
+        ops.linear(txt, self._local_kv_pack(), want_f32=False, planes_out=(out["loc_hi"], out["loc_lo"]))
+        out["txt_m"].copy_(self._u8(txt_masks))
+        return SimpleNamespace(txt=ops.Act(None, out["txt_hi"], out["txt_lo"]), txt_m=out["txt_m"], frag=frag, gt_kv=gt,
+                               local_kv=ops.Act(None, out["loc_hi"], out["loc_lo"]), L=L, buffers=out)
+
+    def _local_kv_pack(self):
+        xl = self.local_encoder.encoder.x_layers
+        return self._pack("local.kv_all",
+                          [w for l in xl for w in (l.visual_attention.att.key.weight, l.visual_attention.att.value.weight)],
+                          [b for l in xl for b in (l.visual_attention.att.key.bias, l.visual_attention.att.value.bias)])
+
+    @torch.no_grad()
+    def _nav_front(self, txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory=None, txt_planes=None,
+                   icache=None):
         """vilmodel.py:793-807: text_proj, instruction-relevance aggregation of the grid memory, grid_proj on the 196
         reduced cell vectors.  Independent of how many cells are occupied.  txt_planes = (hi, lo): where the bf16 planes
         of the instruction go (e.g. the tail of the local encoder's context buffer)."""
         B, L, H = txt_embeds.shape
-        txt_embeds = txt_embeds.float().contiguous()
-        txt = ops.split_rows(txt_embeds, out=txt_planes)   # fp32 + planes
-        text_fts = ops.linear(txt, self._lin(self.text_proj, "text_proj")).f32
-        frag = ops.text_fragments(text_fts)
+        if icache is not None:
+            txt, frag, txt_m = icache.txt, icache.frag, icache.txt_m
+        else:
+            txt_embeds = txt_embeds.float().contiguous()
+            txt = ops.split_rows(txt_embeds, out=txt_planes)   # fp32 + planes
+            text_fts = ops.linear(txt, self._lin(self.text_proj, "text_proj")).f32
+            frag = ops.text_fragments(text_fts)
+            txt_m = self._u8(txt_masks).contiguous()
         n_points = None
         if grid_memory is not None:
             slab, perm, cell_start = grid_memory.slab, grid_memory.perm, grid_memory.cell_start
@@ -491,8 +545,8 @@ class GlocalTextPathNavCMT(nn.Module):
             slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
         cells, occ = ops.grid_aggregate(slab, perm, cell_start, frag, L, n_points=n_points)
         proj = ops.linear(cells, self._lin(self.grid_proj, "grid_proj")).f32
-        return SimpleNamespace(txt=txt, txt_m=self._u8(txt_masks).contiguous(), proj=proj, occ=occ,
-                               gridmap_pos_fts=gridmap_pos_fts, in_place=txt_planes is not None)
+        return SimpleNamespace(txt=txt, txt_m=txt_m, proj=proj, occ=occ, gridmap_pos_fts=gridmap_pos_fts,
+                               in_place=txt_planes is not None, icache=icache, L=L)
 
     @torch.no_grad()
     def _nav_back(self, fr, c_pad, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks, vp_img_embeds, vp_pos_fts,
@@ -500,12 +554,15 @@ class GlocalTextPathNavCMT(nn.Module):
         """vilmodel.py:813-856 on a [cells | nodes] sequence padded to c_pad + G rows (c_pad >= the batch's largest
         occupied-cell count): position embeddings, grid encoder, grid/text layer, local encoder."""
         txt, txt_m = fr.txt, fr.txt_m
-        dev = txt.f32.device
-        B, L, H = txt.f32.shape
+        ic = getattr(fr, "icache", None)
+        dev = txt.hi.device
+        B, L, H = txt.hi.shape
         G, V = gmap_masks.shape[1], vp_masks.shape[1]
         S = c_pad + G
         gmap_m, vp_m = (self._u8(m).contiguous() for m in (gmap_masks, vp_masks))
-        if kv is None:
+        if ic is not None:
+            kv = ops.Act(None, *ops._planes_like((B, S, H), dev))    # map rows only: the instruction's K / V are cached
+        elif kv is None:
             kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
             ops.copy_planes(txt, kv, S)                  # (callers that know c_pad up front let _nav_front write in place)
         kv_masks = torch.empty(B, S + L, dtype=torch.uint8, device=dev)
@@ -534,32 +591,30 @@ class GlocalTextPathNavCMT(nn.Module):
         nl = len(self.grid_txt_encoder.x_layers)
         for i, layer in enumerate(self.grid_txt_encoder.x_layers):
             mp = self._x_layer(layer, "grid_txt.%d" % i, txt, txt_m, mp, map_masks,
+                               kv=None if ic is None else (ic.gt_kv[i], 0),
                                planes_out=(kv.hi[:, :S], kv.lo[:, :S]) if i == nl - 1 else None)
         map_embeds = mp.f32
 
         # ---- local encoder over q = [gmap | vp], kv = [map | txt] (vilmodel.py:843-856).  The context is the
         # same for all layers, so the K/V projections of every layer run as ONE GEMM (N = layers * 2H).
         xl = le.encoder.x_layers
-        kv_all = ops.linear(kv, self._pack("local.kv_all",
-                                           [w for l in xl for w in (l.visual_attention.att.key.weight,
-                                                                    l.visual_attention.att.value.weight)],
-                                           [b for l in xl for b in (l.visual_attention.att.key.bias,
-                                                                    l.visual_attention.att.value.bias)]),
-                            want_f32=False, want_planes=True)
+        kv_all = ops.linear(kv, self._local_kv_pack(), want_f32=False, want_planes=True)
         ops.copy_rows(map_embeds[:, c_pad:], q, 0)
         ops.copy_planes(ops.Act(None, kv.hi[:, c_pad:S], kv.lo[:, c_pad:S]), ops.Act(None, qp[0], qp[1]), 0)
         qa = ops.Act(q, qp[0], qp[1])
         for i, layer in enumerate(xl):
-            qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks, kv=(kv_all, 2 * H * i))
+            qa = self._x_layer(layer, "local.%d" % i, None, kv_masks, qa, q_masks, kv=(kv_all, 2 * H * i),
+                               kv2=None if ic is None else (ic.local_kv, 2 * H * i))
         q = qa.f32
-        self._last_acts = (qa, kv, S + L, c_pad)     # planes of the outputs: the heads read them in place
+        self._last_acts = (qa, kv, kv.hi.shape[1], c_pad)     # planes of the outputs: the heads read them in place
         return q[:, :G], q[:, G:], map_embeds
 
     @torch.no_grad()
     def navigation_front(self, batch):
         """First half of forward('navigation', batch) (independent of the occupied-cell count): see _nav_front."""
         return self._nav_front(batch["txt_embeds"], batch["txt_masks"], batch.get("grid_fts"), batch.get("grid_map"),
-                               batch.get("gridmap_pos_fts"), grid_memory=batch.get("grid_memory"))
+                               batch.get("gridmap_pos_fts"), grid_memory=batch.get("grid_memory"),
+                               icache=batch.get("instruction_cache"))
 
     @torch.no_grad()
     def navigation_back(self, fr, c_pad, batch):
@@ -584,7 +639,7 @@ class GlocalTextPathNavCMT(nn.Module):
     @torch.no_grad()
     def _encode_navigation_infer(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
                                  vp_img_embeds, vp_pos_fts, vp_masks, grid_fts, grid_map, gridmap_pos_fts,
-                                 grid_memory=None):
+                                 grid_memory=None, icache=None):
         """vilmodel.py:788-856: aggregation, grid encoder, grid/text layer, local encoder -> (gmap_embeds (B,G,H),
         vp_embeds (B,V,H), map_embeds (B,c_pad+G,H)).  Shared with the VLN-CE twin (gridmap/vilmodel.py:710-776).
 
@@ -597,13 +652,16 @@ class GlocalTextPathNavCMT(nn.Module):
         G = gmap_masks.shape[1]
         back = (gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks, vp_img_embeds, vp_pos_fts, vp_masks)
         if self.varlen_buckets and not torch.cuda.is_current_stream_capturing():
-            fr = self._nav_front(txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory)
+            fr = self._nav_front(txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory, icache=icache)
             # the reference's max_cell_num (a host decision): from the grid memory's pinned word when it tracked the
             # count behind its last step (no stall), else read back from the occupancy bytes of this call
             cmax = grid_memory.cmax_hint() if grid_memory is not None and hasattr(grid_memory, "cmax_hint") else None
             if cmax is None:
                 cmax = int(fr.occ.sum(1, dtype=torch.int32).max())
             return self._nav_back(fr, self.pick_bucket(cmax), *back)
+        if icache is not None:
+            fr = self._nav_front(txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory, icache=icache)
+            return self._nav_back(fr, N_CELLS, *back)
         S = N_CELLS + G
         kv = ops.Act(None, *ops._planes_like((B, S + L, H), dev))
         fr = self._nav_front(txt_embeds, txt_masks, grid_fts, grid_map, gridmap_pos_fts, grid_memory,
@@ -696,5 +754,6 @@ class GlocalTextPathNavCMT(nn.Module):
                 batch["gmap_visited_masks"], batch["gmap_vpids"], batch["vp_img_embeds"], batch["vp_pos_fts"],
                 batch["vp_masks"], batch["vp_nav_masks"], batch.get("vp_obj_masks"), batch["vp_cand_vpids"],
                 batch.get("grid_fts"), batch.get("grid_map"), batch.get("gridmap_pos_fts"),
-                grid_memory=batch.get("grid_memory"), fusion_maps=batch.get("fusion_maps"))
+                grid_memory=batch.get("grid_memory"), fusion_maps=batch.get("fusion_maps"),
+                **({"instruction_cache": batch["instruction_cache"]} if batch.get("instruction_cache") is not None else {}))
         raise NotImplementedError("wrong mode: %s" % mode)

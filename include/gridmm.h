@@ -24,6 +24,7 @@ extern "C" {
 
 #define GRIDMM_OK 0
 #define GRIDMM_EINVAL (-1)   /* bad shape / unsupported size */
+#define GRIDMM_EUNSUPPORTED (-2)   /* a fused form that this shape / device cannot take: issue the unfused calls */
 #define GRIDMM_ELAUNCH (-1000) /* launch failed: status = -1000 - hipError_t */
 
 #define GRIDMM_GRID 14
@@ -205,6 +206,30 @@ int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const 
                              void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act, int cfg,
                              gridmm_stream_t stream);
 
+/* GEMM + residual + LayerNorm in ONE launch (BertSelfOutput / BertOutput / BertOutAttention's output block,
+ * map_nav_src/models/vilmodel.py:156-168, 196-209; the norm that follows an out-projection / linear2 in
+ * transformer.py:170-182):   x = A W^T + bias + residual;   Y = LayerNorm(x) * gamma + beta   over the N columns.
+ * The workgroups of a row block exchange per-tile row statistics through `workspace` and a pair of counters in
+ * `sync_words` and normalise the values they still hold in registers: no pre-LayerNorm round trip through memory and
+ * no LayerNorm launch.  Outputs: C_pre (optional fp32 x, the residual stream of a pre-norm layer), Y (optional fp32),
+ * Y_hi / Y_lo (optional bf16 planes of Y, row stride ldp, through the batched row map p_rpb / p_bs of
+ * gridmm_layernorm_map when p_rpb > 0).
+ *   workspace   >= gridmm_linear_planes_ln_workspace(M, N) bytes of scratch
+ *   sync_words  >= gridmm_linear_planes_ln_sync_bytes(M) bytes, ZEROED ONCE by the caller (hipMemset) before the first
+ *               call; every call leaves them zero.  One buffer per stream: calls that may run concurrently must not
+ *               share it, and two fused launches must not be resident on the device at the same time (they wait for
+ *               workgroups of their own grid: single-stream use).
+ * Returns GRIDMM_EUNSUPPORTED -- and launches nothing -- when the shape cannot take the fused form (N not a multiple
+ * of the tile width, a grid the device cannot hold at once, GRIDMM_LN_FUSE=0): the caller then issues
+ * gridmm_linear_planes + gridmm_layernorm.  dry_run != 0 only answers that question. */
+size_t gridmm_linear_planes_ln_workspace(int M, int N);
+size_t gridmm_linear_planes_ln_sync_bytes(int M);
+int gridmm_linear_planes_ln(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int Kp,
+                            const float* bias, const float* residual, int ldr, float* C_pre, int ldc, const float* gamma,
+                            const float* beta, float eps, float* Y, int ldy, void* Y_hi, void* Y_lo, int ldp, int p_rpb,
+                            int64_t p_bs, void* workspace, void* sync_words, int M, int N, int K, int dry_run,
+                            gridmm_stream_t stream);
+
 /* gridmm_linear_planes with the A rows taken through a batched row map: GEMM row m = row (m % a_rpb) of episode
  * (m / a_rpb) in a buffer whose episodes lie a_bs elements apart (a_rpb <= 0: plain rows, a_bs ignored; a_bs % 8 == 0).
  * A sub-sequence of a longer padded sequence is multiplied in place -- the instruction rows of the local encoder's
@@ -269,6 +294,18 @@ int gridmm_attention_rows_cfg(const void* Q_hi, const void* Q_lo, int64_t q_bs, 
                               int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B, int heads, int Sq,
                               int Sk, float scale, int cfg, gridmm_stream_t stream);
 
+/* gridmm_attention_rows over a context that lives in TWO plane buffers: keys [0, S1) are rows of K / V, keys [S1, Sk)
+ * rows (key - S1) of K2 / V2 (row stride kv2_rs, episode stride kv2_bs, both % 8 == 0); kmask spans all Sk keys.  Key
+ * by key the same arithmetic as one concatenated buffer (bit-identical).  The local encoder's [map | txt] context
+ * (map_nav_src/models/vilmodel.py:846-853): the K / V projections of the instruction rows do not change during an
+ * episode and are kept apart from the per-step projections of the map rows. */
+int gridmm_attention_rows_seg(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                              const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo, int64_t v_bs,
+                              int v_rs, int S1, const void* K2_hi, const void* K2_lo, const void* V2_hi,
+                              const void* V2_lo, int64_t kv2_bs, int kv2_rs, const uint8_t* kmask, int mask_bs, float* O,
+                              int64_t o_bs, int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, int B, int heads,
+                              int Sq, int Sk, float scale, gridmm_stream_t stream);
+
 /* ---- one cross-modal layer as one call -------------------------------------------------------------------------
  * GraphLXRTXLayer.forward with graph_sprels = None (map_nav_src/models/vilmodel.py:399-414; pretrain / VLN-CE twins
  * identical): cross attention of the Sq tokens over a context whose K / V projections the caller has already computed
@@ -287,9 +324,15 @@ typedef struct {
 size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I);
 int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
                            const void* KV_hi, const void* KV_lo, int64_t kv_bs, int kv_rs, int k_col, int v_col,
-                           const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask, int self_mask_bs,
-                           float* Y, void* Y_hi, void* Y_lo, int y_p_rpb, int64_t y_p_bs, void* workspace,
-                           size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream);
+                           int Sk1, const void* KV2_hi, const void* KV2_lo, int64_t kv2_bs, int kv2_rs, int k2_col,
+                           int v2_col, const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask,
+                           int self_mask_bs, float* Y, void* Y_hi, void* Y_lo, int y_p_rpb, int64_t y_p_bs,
+                           void* workspace, size_t workspace_bytes, void* sync_words, int B, int Sq, int Sk, int heads,
+                           gridmm_stream_t stream);
+/* (KV2_hi != NULL: the context rows [Sk1, Sk) come from a second K / V plane buffer, gridmm_attention_rows_seg; NULL: all
+ * Sk rows from KV) */
+/* (sync_words: NULL, or the zeroed counter block of gridmm_linear_planes_ln for B * Sq rows -- the three dense +
+ * residual + LayerNorm blocks then run as one launch each where the shape allows) */
 /* (y_p_rpb > 0: the output PLANES go through the row map of gridmm_layernorm_map -- Sq rows per episode into a buffer
  * whose episodes are y_p_bs elements apart, e.g. the [map | txt] context of the next encoder; 0: plain [M][H]) */
 

@@ -238,12 +238,23 @@ def test_xattn_layer_entry_point_equals_the_eleven_calls(dev):
     cm = (torch.arange(Sk)[None] < torch.tensor([100, 37, 64])[:, None]).to(dev)
     sm = (torch.arange(Sq)[None] < torch.tensor([57, 57, 40])[:, None]).to(dev)
     with torch.no_grad():
-        fused = model._x_layer(layer, "t.1", None, model._u8(cm), x, model._u8(sm), kv=(kv, 2 * H))
-        ops.TIMER = ops.KernelTimer()
+        keep = ops.LN_FUSE
         try:
-            split = model._x_layer(layer, "t.1", None, model._u8(cm), x, model._u8(sm), kv=(kv, 2 * H))
+            ops.LN_FUSE = False              # eleven launches inside the C call
+            fused = model._x_layer(layer, "t.1", None, model._u8(cm), x, model._u8(sm), kv=(kv, 2 * H))
+            ops.TIMER = ops.KernelTimer()
+            try:
+                split = model._x_layer(layer, "t.1", None, model._u8(cm), x, model._u8(sm), kv=(kv, 2 * H))
+            finally:
+                ops.TIMER = None
+            ops.LN_FUSE = True               # opt-in form: dense + residual + LayerNorm as one launch each
+            ln1 = model._x_layer(layer, "t.1", None, model._u8(cm), x, model._u8(sm), kv=(kv, 2 * H))
         finally:
-            ops.TIMER = None
+            ops.LN_FUSE = keep
     torch.cuda.synchronize()
     assert torch.equal(fused.f32, split.f32) and torch.equal(fused.hi, split.hi) and torch.equal(fused.lo, split.lo)
     assert torch.isfinite(fused.f32).all() and float(fused.f32.abs().max()) > 0.1
+    # the eight-launch form (dense + residual + LayerNorm as one launch each): LayerNorm statistics merged from per-tile
+    # partials instead of one two-pass reduction per row
+    assert float((ln1.f32 - split.f32).abs().max()) < 2e-5
+    assert float((ln1.hi.float() + ln1.lo.float() - ln1.f32).abs().max()) < 1e-4
