@@ -720,7 +720,7 @@ def roofline_leg(step, args, geom, L=80):
             relaunch()
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):      # (a process group's watchdog thread may be polling events)
             for _ in range(10):
                 relaunch()
         g.replay()

@@ -19,6 +19,7 @@
 //     Output lane (j, g) holds O[query j][dims 16n+4g .. +3]: the running-max rescale is lane-local (no broadcast)
 //     and the stores are 64/128-bit.
 //   * NQ query tiles per wave share every K / V fragment read; wave NW of the workgroup only loads (see the chunk ring).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -63,7 +64,10 @@ __device__ unsigned long long g_att_prof[8];
 #define GRIDMM_T(i) do { } while (0)
 #endif
 
-template <int NQ, int NW, int KC, int AB = 0, int NL = 1>
+// SEG: 0 = one context buffer; 1 = keys >= S1 in a second buffer, S1 % 8 == 0 (every 8-row DMA piece lies in one buffer: the
+// choice is wave-uniform, scalar selects only -- per-lane selects in the loader's address path cost the step 0.4 ms when
+// they sat in every call); 2 = any S1 (per-lane selects).
+template <int NQ, int NW, int KC, int AB = 0, int NL = 1, int SEG = 0>
 __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
     const unsigned short* __restrict__ Qh, const unsigned short* __restrict__ Ql, int64_t q_bs, int q_rs,
     const unsigned short* __restrict__ Kh, const unsigned short* __restrict__ Kl, int64_t k_bs, int k_rs,
@@ -119,14 +123,30 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
 #pragma unroll
     for (int r0 = 8 * li; r0 < KC; r0 += 8 * NL) {
       const int key = min(key0c + r0 + lrow, Sk - 1);
-      const bool s2 = key >= S1;
-      const size_t ko = s2 ? (size_t)(key - S1) * kv2_rs + coff : (size_t)key * k_rs + coff;
-      const size_t vo = s2 ? ko : (size_t)key * v_rs + coff;
       unsigned short* d = kvbuf + buf * (4 * PLANE) + r0 * 64;
-      dma16((s2 ? K2bh : Kbh) + ko, d);
-      dma16((s2 ? K2bl : Kbl) + ko, d + PLANE);
-      dma16((s2 ? V2bh : Vbh) + vo, d + 2 * PLANE);
-      dma16((s2 ? V2bl : Vbl) + vo, d + 3 * PLANE);
+      if constexpr (SEG == 0) {
+        const size_t ko = (size_t)key * k_rs + coff, vo = (size_t)key * v_rs + coff;
+        dma16(Kbh + ko, d);
+        dma16(Kbl + ko, d + PLANE);
+        dma16(Vbh + vo, d + 2 * PLANE);
+        dma16(Vbl + vo, d + 3 * PLANE);
+      } else if constexpr (SEG == 1) {
+        const bool s2 = key0c + r0 >= S1;               // wave-uniform: the piece's 8 keys lie in one buffer
+        const int kk = s2 ? key - S1 : key;
+        const size_t ko = (size_t)kk * (s2 ? kv2_rs : k_rs) + coff, vo = (size_t)kk * (s2 ? kv2_rs : v_rs) + coff;
+        dma16((s2 ? K2bh : Kbh) + ko, d);
+        dma16((s2 ? K2bl : Kbl) + ko, d + PLANE);
+        dma16((s2 ? V2bh : Vbh) + vo, d + 2 * PLANE);
+        dma16((s2 ? V2bl : Vbl) + vo, d + 3 * PLANE);
+      } else {
+        const bool s2 = key >= S1;
+        const size_t ko = s2 ? (size_t)(key - S1) * kv2_rs + coff : (size_t)key * k_rs + coff;
+        const size_t vo = s2 ? ko : (size_t)key * v_rs + coff;
+        dma16((s2 ? K2bh : Kbh) + ko, d);
+        dma16((s2 ? K2bl : Kbl) + ko, d + PLANE);
+        dma16((s2 ? V2bh : Vbh) + vo, d + 2 * PLANE);
+        dma16((s2 ? V2bl : Vbl) + vo, d + 3 * PLANE);
+      }
     }
   };
 #ifdef GRIDMM_ATT_PROF
@@ -366,6 +386,15 @@ extern "C" int gridmm_debug_att_prof(unsigned long long* out, int reset) {
 }
 #endif
 
+// Tuning hook (tools/sweep_gemm_cfg_step.py): force the launch configuration of the calls with more than / at most four
+// query tiles inside a running process (0 = the heuristic).  Process-global; not used by the product path.
+static int g_att_cfg_big = 0, g_att_cfg_small = 0;
+extern "C" int gridmm_debug_attention_cfg_override(int cfg_big, int cfg_small) {
+  g_att_cfg_big = cfg_big;
+  g_att_cfg_small = cfg_small;
+  return GRIDMM_OK;
+}
+
 // cfg: 0 = auto; 1..: tuning configurations (tools/bench_attn2.py)
 static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
                                const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
@@ -380,17 +409,34 @@ static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs,
   if ((!O && !O_hi) || (O_hi && (!O_lo || (p_rs & 3) || (p_bs & 3))) || (O && ((o_rs & 3) || (o_bs & 3))))
     return GRIDMM_EINVAL;
   const int nqt = (Sq + 15) / 16;
-  if (cfg == 0) cfg = nqt <= 4 ? 5 : 9;   // tools/bench_attn2.py: 57-query calls 7-17 us with (1, 4, 32); 216-query calls 25-38 us with (1, 8, 32)
+  const int seg = S1 >= Sk ? 0 : ((S1 & 7) == 0 ? 1 : 2);
+  // (1, 7, 32) for 5 .. 14 query tiles: the 216-query calls are exactly 2 x 7 tiles -- no idle math wave, as (1, 8, 32)
+  // leaves in its second workgroup (in-step sweep: -19 us per step over the three calls)
+  if (cfg == 0) cfg = nqt <= 4 ? 5 : (nqt <= 14 ? 24 : 9);
+  if (0) cfg = nqt <= 4 ? 5 : 9;   // tools/bench_attn2.py: 57-query calls 7-17 us with (1, 4, 32); 216-query calls 25-38 us with (1, 8, 32)
+  if (nqt > 4 && g_att_cfg_big) cfg = g_att_cfg_big;        // tuning hook (gridmm_debug_attention_cfg_override)
+  if (nqt <= 4 && g_att_cfg_small) cfg = g_att_cfg_small;
 #define GRIDMM_ATT_ARGS                                                                                             \
   (const unsigned short*)Q_hi, (const unsigned short*)Q_lo, q_bs, q_rs, (const unsigned short*)K_hi,               \
       (const unsigned short*)K_lo, k_bs, k_rs, (const unsigned short*)V_hi, (const unsigned short*)V_lo, v_bs, v_rs, \
       kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo, p_bs, p_rs, Sq, Sk, scale,        \
       (const unsigned short*)K2_hi, (const unsigned short*)K2_lo, (const unsigned short*)V2_hi,                      \
       (const unsigned short*)V2_lo, kv2_bs, kv2_rs, S1
-#define GRIDMM_ATTL(NQ, NW, KC, AB, NL)                                                                                 \
+#define GRIDMM_ATTS(NQ, NW, KC, AB, NL, SEG)                                                                            \
   do {                                                                                                              \
     dim3 grid((nqt + (NQ) * (NW) - 1) / ((NQ) * (NW)), heads, B), block(((NW) + (NL)) * 64);                               \
-    GRIDMM_LAUNCH((attention_rows_kernel<NQ, NW, KC, AB, NL>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS); \
+    GRIDMM_LAUNCH((attention_rows_kernel<NQ, NW, KC, AB, NL, SEG>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS); \
+  } while (0)
+#define GRIDMM_ATTL(NQ, NW, KC, AB, NL)                                                                                 \
+  do {                                                                                                              \
+    if (seg) return GRIDMM_EINVAL;      /* two context buffers: only the configurations instantiated for it below */ \
+    GRIDMM_ATTS(NQ, NW, KC, AB, NL, 0);                                                                             \
+  } while (0)
+#define GRIDMM_ATTG(NQ, NW, KC, NL)     /* configurations that also take a second context buffer */                   \
+  do {                                                                                                              \
+    if (seg == 0) GRIDMM_ATTS(NQ, NW, KC, 0, NL, 0);                                                                \
+    else if (seg == 1) GRIDMM_ATTS(NQ, NW, KC, 0, NL, 1);                                                           \
+    else GRIDMM_ATTS(NQ, NW, KC, 0, NL, 2);                                                                         \
   } while (0)
 #define GRIDMM_ATTX(NQ, NW, KC, AB) GRIDMM_ATTL(NQ, NW, KC, AB, 1)
 #define GRIDMM_ATT(NQ, NW, KC) GRIDMM_ATTX(NQ, NW, KC, 0)
@@ -398,13 +444,19 @@ static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs,
     case 1: GRIDMM_ATT(1, 4, 64); break;
     case 2: GRIDMM_ATT(2, 4, 64); break;
     case 3: GRIDMM_ATT(1, 8, 64); break;
-    case 5: GRIDMM_ATT(1, 4, 32); break;
+    case 5: GRIDMM_ATTG(1, 4, 32, 1); break;
     case 6: GRIDMM_ATT(2, 4, 32); break;
     case 7: GRIDMM_ATT(2, 8, 64); break;
     case 8: GRIDMM_ATT(2, 8, 32); break;
-    case 9: GRIDMM_ATT(1, 8, 32); break;
+    case 9: GRIDMM_ATTG(1, 8, 32, 1); break;
+    case 20: GRIDMM_ATT(1, 14, 32); break;         // ONE workgroup per (episode, head) for up to 224 queries: K / V staged once
+    case 21: GRIDMM_ATT(1, 14, 64); break;
+    case 22: GRIDMM_ATTG(1, 14, 32, 2); break;
+    case 23: GRIDMM_ATT(1, 12, 32); break;
+    case 24: GRIDMM_ATTG(1, 7, 32, 1); break;          // two workgroups of 7 query tiles (216 queries = 14 tiles: no idle wave)
+    case 25: GRIDMM_ATT(2, 7, 32); break;          // one workgroup, two query tiles per wave
     case 14: GRIDMM_ATTL(1, 8, 64, 0, 2); break;   // two loader waves
-    case 15: GRIDMM_ATTL(1, 4, 32, 0, 2); break;
+    case 15: GRIDMM_ATTG(1, 4, 32, 2); break;
     case 16: GRIDMM_ATTL(2, 8, 64, 0, 2); break;
     case 17: GRIDMM_ATTL(2, 4, 64, 0, 2); break;
     case 18: GRIDMM_ATTL(1, 4, 64, 0, 2); break;
@@ -416,6 +468,8 @@ static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs,
 #undef GRIDMM_ATT
 #undef GRIDMM_ATTX
 #undef GRIDMM_ATTL
+#undef GRIDMM_ATTG
+#undef GRIDMM_ATTS
 #undef GRIDMM_ATT_ARGS
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;

@@ -24,6 +24,11 @@ import torch
 from . import ops
 
 
+# Captures run in "thread_local" error mode: with a process group alive, RCCL's watchdog thread polls its events while
+# this thread captures; under the default "global" mode that foreign hipEventQuery invalidates the capture ("operation not
+# permitted when stream is capturing") -- every multi-rank bench run and the one-rank RCCL tests hit it at random.
+CAPTURE_MODE = "thread_local"
+
 NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "waitEvent", 7: "eventRecord"}
 
 
@@ -57,7 +62,7 @@ def count_graph_nodes(fn):
     import ctypes
     try:
         g = torch.cuda.CUDAGraph(keep_graph=True)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             fn()
         hip = ctypes.CDLL("libamdhip64.so")
         n = ctypes.c_size_t(0)
@@ -116,7 +121,7 @@ class GraphedNavStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             self.outs = self._device_step()
         self.n_nodes = count_graph_nodes(self._device_step) if count_nodes else None
 
@@ -134,12 +139,12 @@ class GraphedNavStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             self.front = self._device_front()
         self.back, self.back_outs, self.cmax = {}, {}, {}
         for c in self.buckets:                    # same memory pool: the back graphs read the front graph's outputs
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graph.pool()):
+            with torch.cuda.graph(g, pool=self.graph.pool(), capture_error_mode=CAPTURE_MODE):
                 self.back_outs[c] = model.navigation_back(self.front, c, self.batch)
                 self.cmax[c] = model._cells[1]
             self.back[c] = g
@@ -312,7 +317,7 @@ class NavigationGraphs:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool):
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode=CAPTURE_MODE):
             ent["outs"] = model.navigation_back(ent["front"], c_pad, sb)
         if self.pool is None:
             self.pool = g.pool()
@@ -408,7 +413,7 @@ class PanoramaGraphs:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.pool):
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode=CAPTURE_MODE):
                 ent["outs"] = self.model("panorama", sb)
             if self.pool is None:
                 self.pool = g.pool()

@@ -54,6 +54,9 @@ from .optim import _bump_version, get_lr_sched
 RUNTIME_ENV = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 
+from .graph import CAPTURE_MODE   # "thread_local": RCCL's watchdog thread polls events while this thread captures
+
+
 def _new_graph():
     """A CUDAGraph that keeps its hipGraph_t so that the node types can be inspected (older torch: a plain one)."""
     try:
@@ -120,7 +123,7 @@ class GraphedTrainStep:
                 self._capture_segments(model, batch, task, tape)
                 return
             self.graph = _new_graph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
                 with hs.replay(tape):
                     losses = model(batch, task=task, compute_loss=True)
                     losses.mean().backward()
@@ -158,7 +161,7 @@ class GraphedTrainStep:
         hs.CUTS = cuts = []
         g0 = _new_graph()
         try:
-            with torch.cuda.graph(g0):
+            with torch.cuda.graph(g0, capture_error_mode=CAPTURE_MODE):
                 with hs.replay(tape):
                     losses = model(batch, task=task, compute_loss=True)
                     loss = losses.mean()
@@ -172,7 +175,7 @@ class GraphedTrainStep:
         @contextlib.contextmanager
         def segment(k):
             g = _new_graph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=CAPTURE_MODE):
                 yield
             self.graphs.append(g)
             logs.append(red.take_capture_log())

@@ -230,6 +230,13 @@ int gridmm_linear_planes_ln(const void* A_hi, const void* A_lo, int lda, const v
                             int64_t p_bs, void* workspace, void* sync_words, int M, int N, int K, int dry_run,
                             gridmm_stream_t stream);
 
+/* Tuning hook: force tile configuration `cfg` (0 = back to the heuristic) for the problem shape (M, N, K) in this
+ * process (tools/sweep_gemm_cfg_step.py times candidate tiles inside the captured step).  Process-global; not used by
+ * the product path. */
+int gridmm_debug_gemm_cfg_override(int M, int N, int K, int cfg);
+/* The same for gridmm_attention_rows: configuration of the calls with more than / at most four 16-query tiles. */
+int gridmm_debug_attention_cfg_override(int cfg_big, int cfg_small);
+
 /* gridmm_linear_planes with the A rows taken through a batched row map: GEMM row m = row (m % a_rpb) of episode
  * (m / a_rpb) in a buffer whose episodes lie a_bs elements apart (a_rpb <= 0: plain rows, a_bs ignored; a_bs % 8 == 0).
  * A sub-sequence of a longer padded sequence is multiplied in place -- the instruction rows of the local encoder's
