@@ -54,6 +54,8 @@ SIGNATURES = {
     "gridmm_linear_planes_ln_sync_bytes": [_i],
     "gridmm_linear_planes_ln": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i64,
                                 _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_linear_planes_tn": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_split_rows_pad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_debug_gemm_cfg_override": [_i, _i, _i, _i],
     "gridmm_debug_attention_cfg_override": [_i, _i],
     "gridmm_linear_planes_map": [_vp, _vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -130,6 +130,39 @@ def transpose_split(x2d, want_colsum=False, want_rows=False):
     return hi, lo, cs, Mp, rows
 
 
+TN_GEMM = bool(int(__import__('os').environ.get('GRIDMM_TN_GEMM', '1')))   # A/B switch: 0 = transposed planes + NT GEMM (round 1-3)
+
+
+def split_rows_pad(x2d, want_colsum=False):
+    """fp32 (M,C) -> row-major bf16 hi/lo planes (Mp,C) with rows [M,Mp) zero, Mp = roundup(M,32) [, column sums (C,)]: one
+    pass per activation / gradient for both of its GEMM roles (forward / dX: the first M rows; dW: gridmm_linear_planes_tn)."""
+    lib = _lib.load()
+    x2d, M, C, ld = _as2d(x2d)
+    Mp = (M + 31) // 32 * 32
+    hi = torch.empty(Mp, C, dtype=torch.bfloat16, device=x2d.device)
+    lo = torch.empty_like(hi)
+    cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum else None
+    cs_ws = torch.empty((Mp + 255) // 256, C, dtype=torch.float32, device=x2d.device) if want_colsum else None
+    _lib.check(lib.gridmm_split_rows_pad(_p(x2d), ld, _p(hi), _p(lo), C, _p(cs), _p(cs_ws), M, C, Mp, _stream()),
+               "gridmm_split_rows_pad")
+    return hi, lo, cs, Mp, ops.Act(x2d, hi[:M], lo[:M])
+
+
+def _gemm_tn_rows(yp, xp, N, K, Mp):
+    """dW (N,K) = dY^T X from the zero-padded ROW planes yp = (hi, lo) (Mp,N) of dY and xp (Mp,K) of X."""
+    lib = _lib.load()
+    tiles = -(-N // 128) * -(-K // 128)
+    splits = max(1, min(8, 288 // tiles, Mp // 256)) if tiles <= 36 else 1
+    if SPLITK_OFF:
+        splits = 1
+    dev = yp[0].device
+    dw = torch.empty(N, K, dtype=torch.float32, device=dev)
+    ws = torch.empty(splits, N, K, dtype=torch.float32, device=dev) if splits > 1 else None
+    _lib.check(lib.gridmm_linear_planes_tn(_p(yp[0]), _p(yp[1]), N, _p(xp[0]), _p(xp[1]), K, _p(dw), _p(ws), Mp, N, K, splits,
+                                           _stream()), "gridmm_linear_planes_tn")
+    return dw
+
+
 def _gemm_tn(yt, xt, N, K, M, Mp, dy2d):
     """dW (N,K) = dY^T X from the transposed planes yt = (hi, lo) of dY and xt of X (contraction over the M rows)."""
     pw = ops.PackedLinear.__new__(ops.PackedLinear)
@@ -169,7 +202,11 @@ class _Linear(torch.autograd.Function):
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
         xt = None
         a = x2
-        if need_w and K % 8 == 0:
+        ctx.tn = False
+        if need_w and K % 8 == 0 and TN_GEMM and weight.shape[0] % 8 == 0:
+            xh, xl, _, Mp, a = split_rows_pad(x2)           # row planes (Mp rows, zero padded): A of this GEMM, operand of dW
+            xt, ctx.tn = (xh, xl, Mp), True
+        elif need_w and K % 8 == 0:
             xh, xl, _, Mp, rows = transpose_split(x2, want_rows=True)
             xt, a = (xh, xl, Mp), rows
         y = _gemm(a, packs(False), None if bias is None else bias.detach().float(), r2)
@@ -193,11 +230,15 @@ class _Linear(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         dx = dw = db = None
         yh = yl = rows = None
-        if need_w:
+        if need_w and ctx.tn:
+            yh, yl, db, Mp, rows = split_rows_pad(dy2, want_colsum=ctx.has_bias)
+        elif need_w:
             yh, yl, db, Mp, rows = transpose_split(dy2, want_colsum=ctx.has_bias, want_rows=ctx.needs_input_grad[0])
         if ctx.needs_input_grad[0]:
             dx = _gemm(rows if rows is not None else dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
-        if need_w:
+        if need_w and ctx.tn:
+            dw = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, Mp).to(weight.dtype)
+        elif need_w:
             if ctx.saved_t:
                 xt = (ctx.saved_tensors[0], ctx.saved_tensors[1])
             else:

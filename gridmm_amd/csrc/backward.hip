@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
                                                               unsigned short* __restrict__ Tl, float* __restrict__ colpart,
                                                               unsigned short* __restrict__ Rh,
                                                               unsigned short* __restrict__ Rl, int ldp,
-                                                              int M, int C, int Mp) {
+                                                              int M, int C, int Mp, int Rrows) {
   __shared__ float tile[2][64][65];
   const int c0 = blockIdx.x * 64, tid = threadIdx.x;
   const int lc = tid & 63, lr = tid >> 6;                 // load role: column lc, rows lr, lr+4, ...
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
     for (int i = 0; i < 16; ++i) tl[lr + 4 * i][lc] = v[i];
     __syncthreads();                                        // (the other buffer's readers finished one barrier ago)
     if (t + 1 < TS_TILES && m0 + 64 < Mp) load(m0 + 64);    // next tile's global loads fly over the stores below
-    if (Rh && m0 + rr < M) {
+    if (Rh && m0 + rr < Rrows) {                            // Rrows = Mp: rows [M, Mp) are written as zeros (the tile zero-fills
+                                                            // them): the operand of the TN weight-gradient GEMM
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int c8 = c0 + rc + 8 * half;
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(256) void transpose_split_kernel(const float* __res
       for (int e = 0; e < 8; ++e) {
         const float a = tl[r0 + 2 * e][c], b = tl[r0 + 2 * e + 1][c];
         s += a + b;
-        split2_bf16(a, b, hi[e], lo[e]);
+        if (Th) split2_bf16(a, b, hi[e], lo[e]);
       }
-      if (m0 + r0 < Mp) {
+      if (Th && m0 + r0 < Mp) {
         const size_t o = (size_t)(c0 + c) * Mp + m0 + r0;
         uint4* ph = reinterpret_cast<uint4*>(Th + o);
         uint4* pl = reinterpret_cast<uint4*>(Tl + o);
@@ -257,7 +258,26 @@ extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void*
   hipStream_t st = as_stream(stream);
   dim3 grid((C + 63) / 64, (Mp + 64 * TS_TILES - 1) / (64 * TS_TILES)), block(256);
   GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)T_hi, (unsigned short*)T_lo,
-                colsum ? colsum_ws : nullptr, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp);
+                colsum ? colsum_ws : nullptr, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp, M);
+  GRIDMM_CHECK_LAUNCH();
+  if (colsum) {
+    GRIDMM_LAUNCH(colsum_reduce_kernel, dim3((C + 255) / 256), block, 0, st, colsum_ws, colsum, (int)grid.y, C);
+    GRIDMM_CHECK_LAUNCH();
+  }
+  return GRIDMM_OK;
+}
+
+// X fp32 [M][C] -> row-major bf16 hi/lo planes [Mp][ldp] with rows [M, Mp) ZERO (Mp % 32 == 0) [+ colsum]: the one pass an
+// activation / a gradient needs when the weight gradient runs as gridmm_linear_planes_tn -- the same planes are the A
+// operand of the forward / dX GEMM (first M rows) and an operand of dW = dY^T X (all Mp rows); no transposed copy.
+extern "C" int gridmm_split_rows_pad(const float* X, int ldx, void* R_hi, void* R_lo, int ldp, float* colsum,
+                                     float* colsum_ws, int M, int C, int Mp, gridmm_stream_t stream) {
+  if (M <= 0 || C <= 0 || Mp < M || Mp % 32 || !R_hi || !R_lo || ldp < C || ldp % 8) return GRIDMM_EINVAL;
+  if (colsum && !colsum_ws) return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  dim3 grid((C + 63) / 64, (Mp + 64 * TS_TILES - 1) / (64 * TS_TILES)), block(256);
+  GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)nullptr, (unsigned short*)nullptr,
+                colsum ? colsum_ws : nullptr, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp, Mp);
   GRIDMM_CHECK_LAUNCH();
   if (colsum) {
     GRIDMM_LAUNCH(colsum_reduce_kernel, dim3((C + 255) / 256), block, 0, st, colsum_ws, colsum, (int)grid.y, C);

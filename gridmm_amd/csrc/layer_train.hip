@@ -55,30 +55,32 @@ bool shapes_ok(const gridmm_xlayer_train_t* L, int H, int I) {
   return H % 32 == 0 && I % 32 == 0;
 }
 
-// y (M, N) fp32 = x W^T + b (+ R): the forward of autograd._Linear -- one pass over x writes its row planes (the GEMM's A
-// operand) and its transposed planes (kept for dW), then the plane GEMM.
-int linear_fwd(const gridmm_linear_train_t& l, const float* x, unsigned short* xT, unsigned short* rows, const float* R,
+// y (M, N) fp32 = x W^T + b (+ R): the forward of autograd._Linear -- one pass over x writes its row planes, zero padded
+// to Mp rows, into the SAVED block (`xP`: hi [Mp][K] then lo): the A operand of this GEMM and, in the backward, an operand
+// of dW = dY^T X through gridmm_linear_planes_tn (no transposed copy of x).
+int linear_fwd(const gridmm_linear_train_t& l, const float* x, unsigned short* xP, unsigned short* /*rows*/, const float* R,
                float* y, int M, int act, gridmm_stream_t st) {
   const int K = l.K, Mp = mp32(M);
-  int rc = gridmm_transpose_split(x, K, xT, xT + (size_t)K * Mp, nullptr, nullptr, rows, rows + (size_t)M * K, K, M, K, Mp, st);
+  int rc = gridmm_split_rows_pad(x, K, xP, xP + (size_t)K * Mp, K, nullptr, nullptr, M, K, Mp, st);
   if (rc != GRIDMM_OK) return rc;
-  return gridmm_linear_planes(rows, rows + (size_t)M * K, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, nullptr,
+  return gridmm_linear_planes(xP, xP + (size_t)K * Mp, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, nullptr,
                               nullptr, 0, M, l.N, K, act, st);
 }
 
-// Backward of one Linear (autograd._Linear.backward): dY -> [one pass: row planes, transposed planes, column sums = db],
-// dX = dY W (+ Radd: the gradient arriving over another branch, summed in the GEMM epilogue), dW = dY^T X.
+// Backward of one Linear (autograd._Linear.backward): dY -> [one pass: zero-padded row planes + column sums = db],
+// dX = dY W (+ Radd: the gradient arriving over another branch, summed in the GEMM epilogue), dW = dY^T X from the row
+// planes of dY and of the saved x.
 struct LinWs { unsigned short *rows, *yT; float *cs_ws, *splitk; };
-int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned short* xT, const float* Radd, float* dX,
+int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned short* xP, const float* Radd, float* dX,
                float* dW, float* db, int M, const LinWs& ws, gridmm_stream_t st) {
   const int N = l.N, K = l.K, Mp = mp32(M);
-  int rc = gridmm_transpose_split(dY, N, ws.yT, ws.yT + (size_t)N * Mp, db, db ? ws.cs_ws : nullptr, dX ? ws.rows : nullptr,
-                                  dX ? ws.rows + (size_t)M * N : nullptr, N, M, N, Mp, st);
+  unsigned short *yh = ws.yT, *yl = ws.yT + (size_t)N * Mp;
+  int rc = gridmm_split_rows_pad(dY, N, yh, yl, N, db, db ? ws.cs_ws : nullptr, M, N, Mp, st);
   if (rc != GRIDMM_OK) return rc;
   if (dX) {
     if (!l.wt_hi || !l.wt_lo || l.Np < N) return GRIDMM_EINVAL;
-    rc = gridmm_linear_planes(ws.rows, ws.rows + (size_t)M * N, N, l.wt_hi, l.wt_lo, l.Np, nullptr, Radd, Radd ? K : 0, dX, K,
-                              nullptr, nullptr, 0, M, K, N, GRIDMM_ACT_NONE, st);
+    rc = gridmm_linear_planes(yh, yl, N, l.wt_hi, l.wt_lo, l.Np, nullptr, Radd, Radd ? K : 0, dX, K, nullptr, nullptr, 0, M, K, N,
+                              GRIDMM_ACT_NONE, st);
     if (rc != GRIDMM_OK) return rc;
   }
   if (dW) {
@@ -91,12 +93,7 @@ int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned s
       if (splits > Mp / 256) splits = Mp / 256;
       if (splits < 1) splits = 1;
     }
-    if (splits > 1)
-      rc = gridmm_linear_planes_splitk(ws.yT, ws.yT + (size_t)N * Mp, Mp, xT, xT + (size_t)K * Mp, Mp, dW, ws.splitk, N, K, Mp,
-                                       splits, st);
-    else
-      rc = gridmm_linear_planes(ws.yT, ws.yT + (size_t)N * Mp, Mp, xT, xT + (size_t)K * Mp, Mp, nullptr, nullptr, 0, dW, K,
-                                nullptr, nullptr, 0, N, K, Mp, GRIDMM_ACT_NONE, st);
+    rc = gridmm_linear_planes_tn(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, ws.splitk, Mp, N, K, splits, st);
   }
   return rc;
 }

@@ -1,0 +1,232 @@
+// gridmm_linear_planes_tn: C (N x K, fp32) = A^T B with BOTH operands row-major over the contraction,
+//   A = dY planes [Mp][>= N],  B = X planes [Mp][>= K]   (bf16 hi / lo, Mp % 32 == 0, rows >= M zero),
+// i.e. the weight gradient dW = dY^T X of a Linear (pretrain_src/train_r2r.py:262 / map_nav_src/r2r/agent_base.py:199
+// run it as torch's autograd of nn.Linear) WITHOUT transposed copies of dY and X: the tile pipeline stages row-major
+// [32 contraction rows][64 columns] panels in LDS by LDS-DMA and reads the MFMA fragments through the hardware transpose
+// read (ds_read_b64_tr_b16), exactly as attention_rows reads V^T out of its row-major V image:
+//   * panel image: 32 rows x 128 B, 16-byte slot `s` of row r holds chunk s ^ (r & 6) (swizzle applied on the DMA's
+//     SOURCE side; the destination is lane-linear);
+//   * lane (j, g) of a fragment read gets column 16 nb + j of rows 4g .. 4g+3 (first read) and 16+4g .. 16+4g+3 (second):
+//     contraction slot 8g + e <-> row 4g + e (e < 4) / 16 + 4g + (e - 4) -- the SAME permutation for both operands, so
+//     the products pair up row by row;
+//   * 3-term bf16 split as in linear_planes (lo*hi + hi*lo + hi*hi, fp32 accumulate), operands swapped so that a lane
+//     ends with 4 consecutive output columns (direct 128-bit stores, no LDS epilogue).
+// Split-K over blockIdx.y: partial tiles to a workspace, summed in a fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ uint2 lds_tr_b64(unsigned addr) {       // no wait: see tr_fence
+  uint2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint2 lds_tr_b64_2k(unsigned addr) {    // + 16 rows (2048 B)
+  uint2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void tr_fence(uint2 (&a)[N]) {          // s_waitcnt the uses of a[] cannot be moved above
+  static_assert(N == 8, "eight pairs per fence");
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+               :
+               : "memory");
+}
+
+constexpr int PANEL = 32 * 64;   // u16 per panel image (32 rows x 64 columns)
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_kernel(
+    const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
+    const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int ldb, float* __restrict__ C, int ldc,
+    int Mp, int N, int K) {
+  constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int PA = BM / 64, PB = BN / 64;                 // panels per plane
+  constexpr int STAGE = 2 * (PA + PB) * PANEL;              // u16 per stage: A hi | A lo | B hi | B lo
+  constexpr int PIECES = 2 * (PA + PB) * 4;                 // 1-KiB pieces (8 rows x 128 B) per stage
+  static_assert(BM % 64 == 0 && BN % 64 == 0 && PIECES % NW == 0 && TM == 2 && TN == 2, "tile shape");
+  constexpr int PPW = PIECES / NW;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+  const int tn = (K + BN - 1) / BN;
+  const int ty = blockIdx.x / tn, tx = blockIdx.x % tn;
+  const int bm = ty * BM, bn = tx * BN;                     // first output row (column of A) / column (column of B)
+
+  // DMA plan of this wave: piece p = (plane, panel, row group of 8)
+  const int lrow = lane >> 3;
+  const unsigned short* src[PPW];
+  int dst[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave * PPW + i;
+    const int rg = p & 3, pp = p >> 2;                      // pp: A hi panels, A lo panels, B hi panels, B lo panels
+    const bool isA = pp < 2 * PA;
+    const int q = isA ? pp : pp - 2 * PA, P = isA ? PA : PB;
+    const int lo = q / P, panel = q % P;
+    const int ld = isA ? lda : ldb;
+    int col = (isA ? bm : bn) + panel * 64 + (((lane & 7) ^ (lrow & 6)) << 3);
+    col = min(col, ld - 8);                                 // tiles past the matrix edge re-read its last chunk (never stored)
+    const unsigned short* base = isA ? (lo ? Alo : Ahi) : (lo ? Blo : Bhi);
+    src[i] = base + (size_t)(rg * 8 + lrow) * ld + col;
+    dst[i] = pp * PANEL + rg * 8 * 64;
+  }
+  const size_t stepA = (size_t)32 * lda, stepB = (size_t)32 * ldb;
+  const int firstB = (2 * PA * 4 - wave * PPW);             // pieces [firstB, PPW) of this wave belong to B
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  int nk = Mp / 32, k0 = 0;
+  if (gridDim.y > 1) {
+    const int per = (nk + gridDim.y - 1) / gridDim.y;
+    k0 = blockIdx.y * per;
+    nk = max(0, min(per, nk - k0));
+  }
+  auto issue = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      dma16(src[i] + (size_t)(k0 + kt) * (i < firstB ? stepA : stepB), smem + slot * STAGE + dst[i]);
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  // fragment addresses (bytes inside a panel): lane (j, g): row 4g + (j >> 2), 16-column block nb, 4 columns (j & 3) * 4 ..
+  const int j = lane & 15, g = lane >> 4;
+  const int frow = 4 * g + (j >> 2), s2 = (frow >> 1) & 3;
+  unsigned aoff[TM], boff[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int c = wr * WM + i * 16, panel = c >> 6, nb = (c & 63) >> 4;
+    aoff[i] = (unsigned)(panel * PANEL * 2 + frow * 128 + ((nb ^ s2) << 5) + ((j & 3) << 3));
+  }
+#pragma unroll
+  for (int jj = 0; jj < TN; ++jj) {
+    const int c = wc * WN + jj * 16, panel = c >> 6, nb = (c & 63) >> 4;
+    boff[jj] = (unsigned)((2 * PA + panel) * PANEL * 2 + frow * 128 + ((nb ^ s2) << 5) + ((j & 3) << 3));
+  }
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (NS >= 3 && kt + NS - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; buffer (kt-1) % NS is free
+    if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+    const unsigned cur = lds0 + (unsigned)((kt % NS) * STAGE * 2);
+    uint2 ra[8], rb[8];             // [tile][hi/lo][row half]
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ra[i * 4 + 0] = lds_tr_b64(cur + aoff[i]);
+      ra[i * 4 + 1] = lds_tr_b64_2k(cur + aoff[i]);
+      ra[i * 4 + 2] = lds_tr_b64(cur + aoff[i] + PA * PANEL * 2);
+      ra[i * 4 + 3] = lds_tr_b64_2k(cur + aoff[i] + PA * PANEL * 2);
+    }
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+      rb[jj * 4 + 0] = lds_tr_b64(cur + boff[jj]);
+      rb[jj * 4 + 1] = lds_tr_b64_2k(cur + boff[jj]);
+      rb[jj * 4 + 2] = lds_tr_b64(cur + boff[jj] + PB * PANEL * 2);
+      rb[jj * 4 + 3] = lds_tr_b64_2k(cur + boff[jj] + PB * PANEL * 2);
+    }
+    tr_fence(ra);
+    tr_fence(rb);
+    bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ah[i] = __builtin_bit_cast(bf16x8_t, make_uint4(ra[i * 4].x, ra[i * 4].y, ra[i * 4 + 1].x, ra[i * 4 + 1].y));
+      al[i] = __builtin_bit_cast(bf16x8_t, make_uint4(ra[i * 4 + 2].x, ra[i * 4 + 2].y, ra[i * 4 + 3].x, ra[i * 4 + 3].y));
+    }
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+      bh[jj] = __builtin_bit_cast(bf16x8_t, make_uint4(rb[jj * 4].x, rb[jj * 4].y, rb[jj * 4 + 1].x, rb[jj * 4 + 1].y));
+      bl[jj] = __builtin_bit_cast(bf16x8_t, make_uint4(rb[jj * 4 + 2].x, rb[jj * 4 + 2].y, rb[jj * 4 + 3].x, rb[jj * 4 + 3].y));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj) {   // C^T tiles: a lane ends with 4 consecutive COLUMNS (B columns) of one row (A column)
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[jj], al[i], acc[i][jj], 0, 0, 0);
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[jj], ah[i], acc[i][jj], 0, 0, 0);
+        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[jj], ah[i], acc[i][jj], 0, 0, 0);
+      }
+  }
+  // ---- epilogue straight from the accumulators: lane (m = lane & 15, g) holds C[row m][cols 4g .. 4g+3] of every tile
+  const int mrow = lane & 15, g4 = (lane >> 4) * 4;
+  float* out = C + (gridDim.y > 1 ? (size_t)blockIdx.y * N * ldc : 0);
+#pragma unroll
+  for (int jj = 0; jj < TN; ++jj) {
+    const int n0 = bn + wc * WN + jj * 16 + g4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = bm + wr * WM + i * 16 + mrow;
+      if (m < N && n0 < K)
+        *reinterpret_cast<float4*>(out + (size_t)m * ldc + n0) =
+            make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
+    }
+  }
+}
+
+__global__ void sum_splits_tn_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4, int splits) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(ws)[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(ws)[(size_t)s * n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+}
+
+template <int BM, int BN, int NS>
+int launch_tn(const unsigned short* ah, const unsigned short* al, int lda, const unsigned short* bh, const unsigned short* bl,
+              int ldb, float* C, int Mp, int N, int K, int splits, hipStream_t st) {
+  dim3 grid(((N + BM - 1) / BM) * ((K + BN - 1) / BN), splits), block((BM / 32) * (BN / 32) * 64);
+  GRIDMM_LAUNCH((linear_planes_tn_kernel<BM, BN, 32, 32, NS>), grid, block, 0, st, ah, al, lda, bh, bl, ldb, C, K, Mp, N, K);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+}  // namespace
+
+// C (N x K fp32, contiguous) = A^T B over the Mp rows of A (Mp x >= N) and B (Mp x >= K); splits > 1: the contraction is
+// cut into `splits` ranges whose partial results go to `workspace` (splits x N x K floats) and are summed in order.
+extern "C" int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo,
+                                       int ldb, float* C, float* workspace, int Mp, int N, int K, int splits,
+                                       gridmm_stream_t stream) {
+  if (Mp <= 0 || Mp % 32 || N <= 0 || K <= 0 || K % 4 || lda % 8 || ldb % 8 || lda < 8 || ldb < 8 || !C || splits < 1 ||
+      splits > 64 || (splits > 1 && (!workspace || Mp / 32 < splits)))
+    return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
+  const unsigned short *bh = (const unsigned short*)B_hi, *bl = (const unsigned short*)B_lo;
+  float* out = splits > 1 ? workspace : C;
+  const long t128 = (long)((N + 127) / 128) * ((K + 127) / 128) * splits;
+  int rc;
+  if (t128 >= 200) rc = launch_tn<128, 128, 2>(ah, al, lda, bh, bl, ldb, out, Mp, N, K, splits, st);
+  else rc = launch_tn<64, 64, 3>(ah, al, lda, bh, bl, ldb, out, Mp, N, K, splits, st);
+  if (rc != GRIDMM_OK) return rc;
+  if (splits > 1) {
+    const size_t n4 = (size_t)N * K / 4;
+    GRIDMM_LAUNCH(sum_splits_tn_kernel, dim3((unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256)), dim3(256), 0, st,
+                  workspace, C, n4, splits);
+    GRIDMM_CHECK_LAUNCH();
+  }
+  return GRIDMM_OK;
+}

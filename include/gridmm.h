@@ -446,6 +446,18 @@ int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, floa
 /* (R_hi / R_lo, optional: the row-major planes [M][ldp] of the same X from the same pass -- the A operand of the
  * forward / dX GEMM -- so an activation or a gradient is read ONCE for both of its GEMM roles) */
 
+/* Weight gradient WITHOUT transposed copies: C (N x K fp32, contiguous) = A^T B over the Mp rows of the row-major bf16
+ * hi/lo planes A [Mp][lda >= N] (dY) and B [Mp][ldb >= K] (X); Mp % 32 == 0 and rows >= M of both are ZERO
+ * (gridmm_split_rows_pad writes them so).  The kernel stages row-major panels in LDS and reads the MFMA fragments through
+ * the hardware transpose read (ds_read_b64_tr_b16).  splits > 1: contraction cut into `splits` ranges, partials in
+ * `workspace` (splits x N x K floats), summed in order (deterministic).  Backward of nn.Linear as above. */
+int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
+                            float* C, float* workspace, int Mp, int N, int K, int splits, gridmm_stream_t stream);
+/* X fp32 [M][C] -> row-major planes [Mp][ldp] with rows [M, Mp) zero [+ colsum as gridmm_transpose_split]: one pass per
+ * activation / gradient for BOTH of its GEMM roles (forward or dX: first M rows; dW through gridmm_linear_planes_tn). */
+int gridmm_split_rows_pad(const float* X, int ldx, void* R_hi, void* R_lo, int ldp, float* colsum, float* colsum_ws,
+                          int M, int C, int Mp, gridmm_stream_t stream);
+
 /* Backward of y = LayerNorm(X (+ R)) * gamma + beta (BertLayerNorm / nn.LayerNorm, vilmodel.py:33,131,147).
  *   dX [M][H] (same gradient flows to R); dgamma, dbeta [H]; workspace >= ceil(M/4) * 2 * H floats. */
 int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int ldr, const float* gamma, float eps,

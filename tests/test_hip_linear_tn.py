@@ -1,0 +1,71 @@
+"""GPU: gridmm_linear_planes_tn -- the weight gradient dW = dY^T X straight from ROW-major planes (hardware transpose reads,
+no transposed copies; backward of nn.Linear, map_nav_src/r2r/agent_base.py:199 / pretrain_src/train_r2r.py:262) -- against
+fp64, and against the transposed-planes path of rounds 1-3 (same products, same k order inside a 32-row step)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda")
+
+
+@pytest.mark.parametrize("M,N,K", [(1824, 768, 768), (6912, 768, 3072), (100, 768, 768), (2560, 1000, 768), (57, 64, 64),
+                                   (300, 2304, 768), (9472, 1536, 768), (33, 8, 40), (4096, 3072, 768)])
+def test_tn_gemm_matches_fp64(dev, M, N, K):
+    from gridmm_amd import autograd as ag
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    dy = (torch.randn(M, N, generator=g) * 0.1).to(dev)
+    xh, xl, _, Mp, _ = ag.split_rows_pad(x)
+    yh, yl, db, Mp2, rows = ag.split_rows_pad(dy, want_colsum=True)
+    assert Mp == Mp2 == (M + 31) // 32 * 32
+    assert float(xh[M:].float().abs().max() if Mp > M else 0.0) == 0.0          # the pad rows are zero
+    dw = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, Mp)
+    ref = dy.double().t() @ x.double()
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((dw.double() - ref).abs().max()) <= 2e-5 * max(1.0, scale)
+    assert float((db.double() - dy.double().sum(0)).abs().max()) <= 1e-4
+    assert float((rows.hi.float() + rows.lo.float() - dy).abs().max()) < 1e-4
+
+
+def test_tn_gemm_equals_the_transposed_planes_path(dev):
+    """Both paths multiply the same bf16 hi / lo values with fp32 accumulation over the same 32-row k-steps: the results
+    agree to accumulation-order noise (the order of the rows INSIDE a k-step differs)."""
+    from gridmm_amd import autograd as ag
+    M, N, K = 1824, 768, 768
+    g = torch.Generator().manual_seed(5)
+    x, dy = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    xh, xl, _, Mp, _ = ag.split_rows_pad(x)
+    yh, yl, _, _, _ = ag.split_rows_pad(dy)
+    a = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, Mp)
+    th, tl, _, Mp2, _ = ag.transpose_split(x)
+    uh, ul, _, _, _ = ag.transpose_split(dy)
+    b = ag._gemm_tn((uh, ul), (th, tl), N, K, M, Mp2, dy)
+    torch.cuda.synchronize()
+    assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) * 1e-2
+    # run-to-run: fixed summation order
+    a2 = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, Mp)
+    assert torch.equal(a, a2)
+
+
+def test_linear_backward_through_the_tn_path_matches_torch(dev):
+    from gridmm_amd import autograd as ag
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 57, 768, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(1536, 768, generator=g) * 0.05).to(dev).requires_grad_()
+    b = torch.randn(1536, generator=g).to(dev).requires_grad_()
+    assert ag.TN_GEMM
+    y = ag.linear(x, w, b)
+    (y * torch.cos(y)).sum().backward()
+    got = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    yd = torch.nn.functional.linear(xd, wd, bd)
+    (yd * torch.cos(yd)).sum().backward()
+    for a, r in zip(got, (xd.grad, wd.grad, bd.grad)):
+        assert float((a.double() - r).abs().max()) <= 3e-5 * max(1.0, float(r.abs().max()))

@@ -70,6 +70,17 @@ def main():
 
     winners = {}
     for mode in modes:
+        if mode == "agg":        # workgroups per episode of the aggregation launch (ops.grid_aggregate reads the variable per call)
+            line = "aggregation chunks per episode (default 256 / B = 8) |"
+            for c in (4, 6, 8, 10, 12, 16, 24):
+                def on(c=c):
+                    os.environ["GRIDMM_AGG_CHUNKS"] = str(c)
+                def off():
+                    os.environ.pop("GRIDMM_AGG_CHUNKS", None)
+                d, same = ab(on, off)
+                line += " %d:%+.1f%s" % (c, d, "" if same else "(!)")
+            print(line, flush=True)
+            continue
         if mode == "attention":
             for name, cands, setter in (("> 4 query tiles", ATT_BIG, lambda c: lib.gridmm_debug_attention_cfg_override(c, 0)),
                                         ("<= 4 query tiles", ATT_SMALL, lambda c: lib.gridmm_debug_attention_cfg_override(0, c))):
