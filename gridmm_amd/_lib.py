@@ -55,6 +55,7 @@ SIGNATURES = {
     "gridmm_linear_planes_ln": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i64,
                                 _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_linear_planes_tn": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_linear_planes_tn_splits": [_i, _i, _i],
     "gridmm_split_rows_pad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_debug_gemm_cfg_override": [_i, _i, _i, _i],
     "gridmm_debug_attention_cfg_override": [_i, _i],
@@ -73,6 +74,10 @@ SIGNATURES = {
     "gridmm_transpose_split": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_layernorm_bwd": [_vp, _i, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_activation": [_vp, _vp, _vp, _i64, _i, _vp],
+    "gridmm_activation_planes": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "gridmm_attention_train_planes": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i64, _i,
+                                      _vp, _i, _i, _i, _i, _i, _f, _f, ctypes.c_uint64, _vp, _vp],
+    "gridmm_layernorm_dropout_planes": [_vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _f, ctypes.c_uint64, _vp, _i, _i, _vp],
     "gridmm_attention_train": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i,
                                _i, _i, _i, _i, _f, _f, ctypes.c_uint64, _vp, _vp],
     "gridmm_attention_bwd": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i64, _i,

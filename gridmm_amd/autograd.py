@@ -133,6 +133,25 @@ def transpose_split(x2d, want_colsum=False, want_rows=False):
 TN_GEMM = bool(int(__import__('os').environ.get('GRIDMM_TN_GEMM', '1')))   # A/B switch: 0 = transposed planes + NT GEMM (round 1-3)
 
 
+# Producers (LayerNorm, GELU / ReLU, attention) also emit the bf16 planes of their output and hang them on the tensor; the
+# Linear that consumes the tensor takes them as its A operand and keeps them for its weight gradient: no split pass over an
+# activation that a kernel of ours just wrote.  The tag carries the tensor's version: an in-place edit drops it.
+def _tag_planes(y, hi, lo):
+    y._gridmm_planes = (hi, lo, y._version)
+    return y
+
+
+def _take_planes(x, M, K):
+    p = getattr(x, "_gridmm_planes", None)
+    if p is None or p[2] != x._version or not x.is_contiguous() or p[0].numel() != M * K or p[0].shape[-1] != K:
+        return None
+    return p[0].view(M, K), p[1].view(M, K)
+
+
+def _want_planes(width):
+    return TN_GEMM and width % 8 == 0
+
+
 def split_rows_pad(x2d, want_colsum=False):
     """fp32 (M,C) -> row-major bf16 hi/lo planes (Mp,C) with rows [M,Mp) zero, Mp = roundup(M,32) [, column sums (C,)]: one
     pass per activation / gradient for both of its GEMM roles (forward / dX: the first M rows; dW: gridmm_linear_planes_tn)."""
@@ -148,17 +167,14 @@ def split_rows_pad(x2d, want_colsum=False):
     return hi, lo, cs, Mp, ops.Act(x2d, hi[:M], lo[:M])
 
 
-def _gemm_tn_rows(yp, xp, N, K, Mp):
-    """dW (N,K) = dY^T X from the zero-padded ROW planes yp = (hi, lo) (Mp,N) of dY and xp (Mp,K) of X."""
+def _gemm_tn_rows(yp, xp, N, K, M):
+    """dW (N,K) = dY^T X from the ROW planes yp = (hi, lo) (>= M rows, N) of dY and xp (>= M rows, K) of X."""
     lib = _lib.load()
-    tiles = -(-N // 128) * -(-K // 128)
-    splits = max(1, min(8, 288 // tiles, Mp // 256)) if tiles <= 36 else 1
-    if SPLITK_OFF:
-        splits = 1
+    splits = 1 if SPLITK_OFF else lib.gridmm_linear_planes_tn_splits(M, N, K)
     dev = yp[0].device
     dw = torch.empty(N, K, dtype=torch.float32, device=dev)
     ws = torch.empty(splits, N, K, dtype=torch.float32, device=dev) if splits > 1 else None
-    _lib.check(lib.gridmm_linear_planes_tn(_p(yp[0]), _p(yp[1]), N, _p(xp[0]), _p(xp[1]), K, _p(dw), _p(ws), Mp, N, K, splits,
+    _lib.check(lib.gridmm_linear_planes_tn(_p(yp[0]), _p(yp[1]), N, _p(xp[0]), _p(xp[1]), K, _p(dw), _p(ws), M, N, K, splits,
                                            _stream()), "gridmm_linear_planes_tn")
     return dw
 
@@ -204,7 +220,12 @@ class _Linear(torch.autograd.Function):
         a = x2
         ctx.tn = False
         if need_w and K % 8 == 0 and TN_GEMM and weight.shape[0] % 8 == 0:
-            xh, xl, _, Mp, a = split_rows_pad(x2)           # row planes (Mp rows, zero padded): A of this GEMM, operand of dW
+            pl = _take_planes(x, x2.shape[0], K) if x.dtype == torch.float32 else None
+            if pl is not None:                              # the producer of x wrote its planes already
+                xh, xl = pl
+                Mp, a = x2.shape[0], ops.Act(x2, xh, xl)
+            else:
+                xh, xl, _, Mp, a = split_rows_pad(x2)       # row planes: A of this GEMM, operand of dW = dY^T X
             xt, ctx.tn = (xh, xl, Mp), True
         elif need_w and K % 8 == 0:
             xh, xl, _, Mp, rows = transpose_split(x2, want_rows=True)
@@ -237,7 +258,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _gemm(rows if rows is not None else dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
         if need_w and ctx.tn:
-            dw = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, Mp).to(weight.dtype)
+            dw = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, M).to(weight.dtype)
         elif need_w:
             if ctx.saved_t:
                 xt = (ctx.saved_tensors[0], ctx.saved_tensors[1])
@@ -259,10 +280,11 @@ class _LayerNorm(torch.autograd.Function):
         ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         x2 = ops.uniform_rows(x.float())
         r2 = None if residual is None else ops.uniform_rows(residual.float())
-        y = ops.layernorm(x2, gamma.detach(), beta.detach(), eps, residual=r2).f32
+        act = ops.layernorm(x2, gamma.detach(), beta.detach(), eps, residual=r2, want_planes=_want_planes(x2.shape[-1]))
+        y = act.f32
         ctx.save_for_backward(x2, r2, gamma)
         ctx.eps, ctx.has_res = eps, residual is not None
-        return y
+        return _tag_planes(y, act.hi, act.lo) if act.hi is not None else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -297,12 +319,16 @@ class _LayerNormDropout(torch.autograd.Function):
         seed = hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item()))
         seed_dev = SEED_DEV if hs.MODE is not None else None          # captured steps: the per-replay seed word
         y = torch.empty_like(x2)
-        _lib.check(lib.gridmm_layernorm_dropout(_p(x2), _p(r2), _rows2d(r2)[2] if r2 is not None else 0, _p(gamma.detach()),
-                                                _p(beta.detach()), float(eps), _p(y), float(p), seed, _p(seed_dev), M, H,
-                                                _stream()), "gridmm_layernorm_dropout")
+        hi = lo = None
+        if _want_planes(H):
+            hi, lo = ops._planes_like(x2.shape, x2.device)
+        _lib.check(lib.gridmm_layernorm_dropout_planes(_p(x2), _p(r2), _rows2d(r2)[2] if r2 is not None else 0,
+                                                       _p(gamma.detach()), _p(beta.detach()), float(eps), _p(y), _p(hi), _p(lo),
+                                                       float(p), seed, _p(seed_dev), M, H, _stream()),
+                   "gridmm_layernorm_dropout")
         ctx.save_for_backward(x2, r2, gamma)
         ctx.eps, ctx.has_res, ctx.p, ctx.seed, ctx.seed_dev = eps, residual is not None, float(p), seed, seed_dev
-        return y
+        return _tag_planes(y, hi, lo) if hi is not None else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -341,10 +367,14 @@ class _Activation(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         y = torch.empty_like(x)
-        _lib.check(lib.gridmm_activation(_p(x), None, _p(y), x.numel(), mode, _stream()), "gridmm_activation")
+        hi = lo = None
+        if x.dim() >= 2 and _want_planes(x.shape[-1]):
+            hi, lo = ops._planes_like(x.shape, x.device)
+        _lib.check(lib.gridmm_activation_planes(_p(x), None, _p(y), _p(hi), _p(lo), x.numel(), mode, _stream()),
+                   "gridmm_activation")
         ctx.save_for_backward(x)
         ctx.mode = mode
-        return y
+        return _tag_planes(y, hi, lo) if hi is not None else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -401,14 +431,17 @@ class _Attention(torch.autograd.Function):
         # captured steps (train_graph.py): the kernel arguments are frozen in the graph, so the part of the seed that
         # changes from replay to replay is a device word the kernels read (SEED_DEV, bumped before every replay)
         seed_dev = SEED_DEV if (dropout_p > 0 and hs.MODE is not None) else None
-        _lib.check(lib.gridmm_attention_train(
+        hi = lo = None
+        if TN_GEMM:
+            hi, lo = ops._planes_like(out.shape, out.device)     # the output projection's A operand, straight from the kernel
+        _lib.check(lib.gridmm_attention_train_planes(
             _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
-            _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(lse), Sqp, B, heads, Sq, Sk,
-            scale, float(dropout_p), seed, _p(seed_dev), _stream()), "gridmm_attention_train")
+            _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(hi), _p(lo), Sq * H, H, _p(lse), Sqp,
+            B, heads, Sq, Sk, scale, float(dropout_p), seed, _p(seed_dev), _stream()), "gridmm_attention_train")
         ctx.save_for_backward(q_src, kv_src, kmask, out, lse)
         ctx.cols, ctx.heads, ctx.same, ctx.scale = cols, heads, same, scale
         ctx.dropout_p, ctx.seed, ctx.seed_dev = float(dropout_p), seed, seed_dev
-        return out
+        return _tag_planes(out, hi, lo) if hi is not None else out
 
     @staticmethod
     def backward(ctx, dout):

@@ -178,22 +178,35 @@ extern "C" int gridmm_attention(const float* Q, int64_t q_bs, int q_rs, const fl
   return GRIDMM_OK;
 }
 
+// _planes: also the bf16 hi/lo planes of O (row stride p_rs, episode stride p_bs) -- the A operand of the output
+// projection and, in the backward, an operand of its weight gradient (gridmm_linear_planes_tn): no split pass over O.
+extern "C" int gridmm_attention_train_planes(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs,
+                                             int k_rs, const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask,
+                                             int mask_bs, float* O, int64_t o_bs, int o_rs, void* O_hi, void* O_lo,
+                                             int64_t p_bs, int p_rs, float* lse, int Sqp, int B, int heads, int Sq, int Sk,
+                                             float scale, float dropout_p, unsigned long long seed,
+                                             const unsigned long long* seed_dev, gridmm_stream_t stream) {
+  if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || !O || !lse || Sqp < Sq || Sqp % 16) return GRIDMM_EINVAL;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return GRIDMM_EINVAL;
+  if ((q_rs | k_rs | v_rs | o_rs) & 3) return GRIDMM_EINVAL;
+  if ((q_bs | k_bs | v_bs | o_bs) & 3) return GRIDMM_EINVAL;
+  if (O_hi && (!O_lo || (p_rs & 3) || (p_bs & 3))) return GRIDMM_EINVAL;
+  dim3 grid((Sq + 63) / 64, heads, B), block(256);
+  GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
+                     v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)O_hi, (unsigned short*)O_lo,
+                     p_bs, p_rs, Sq, Sk, scale, lse, Sqp, dropout_p, seed, seed_dev);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
 extern "C" int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs,
                                       int k_rs, const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask,
                                       int mask_bs, float* O, int64_t o_bs, int o_rs, float* lse, int Sqp, int B,
                                       int heads, int Sq, int Sk, float scale, float dropout_p,
                                       unsigned long long seed, const unsigned long long* seed_dev,
                                       gridmm_stream_t stream) {
-  if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || !O || !lse || Sqp < Sq || Sqp % 16) return GRIDMM_EINVAL;
-  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return GRIDMM_EINVAL;
-  if ((q_rs | k_rs | v_rs | o_rs) & 3) return GRIDMM_EINVAL;
-  if ((q_bs | k_bs | v_bs | o_bs) & 3) return GRIDMM_EINVAL;
-  dim3 grid((Sq + 63) / 64, heads, B), block(256);
-  GRIDMM_LAUNCH(attention_kernel, grid, block, 0, as_stream(stream), Q, q_bs, q_rs, K, k_bs, k_rs, V,
-                     v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, (unsigned short*)nullptr, (unsigned short*)nullptr,
-                     (int64_t)0, 0, Sq, Sk, scale, lse, Sqp, dropout_p, seed, seed_dev);
-  GRIDMM_CHECK_LAUNCH();
-  return GRIDMM_OK;
+  return gridmm_attention_train_planes(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, kmask, mask_bs, O, o_bs, o_rs, nullptr,
+                                       nullptr, 0, 0, lse, Sqp, B, heads, Sq, Sk, scale, dropout_p, seed, seed_dev, stream);
 }
 
 // ================================================================================================

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
 
 // mode 0: y = gelu_erf(x); mode 1: dx = dy * gelu'(x); mode 2: y = relu(x); mode 3: dx = dy * (x > 0)
 __global__ void act_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ out,
-                           size_t n4, int mode) {
+                           size_t n4, int mode, unsigned short* __restrict__ Ph = nullptr,
+                           unsigned short* __restrict__ Pl = nullptr) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const float4 x = reinterpret_cast<const float4*>(X)[i];
     float4 d = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -244,6 +245,13 @@ __global__ void act_kernel(const float* __restrict__ X, const float* __restrict_
       else o[e] = v > 0.f ? ds[e] : 0.f;
     }
     reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (Ph) {                        // bf16 hi/lo planes of the result (same element order)
+      uint2 hi, lo;
+      split2_bf16(o[0], o[1], hi.x, lo.x);
+      split2_bf16(o[2], o[3], hi.y, lo.y);
+      reinterpret_cast<uint2*>(Ph)[i] = hi;
+      reinterpret_cast<uint2*>(Pl)[i] = lo;
+    }
   }
 }
 
@@ -327,15 +335,22 @@ extern "C" int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int
   return GRIDMM_OK;
 }
 
-extern "C" int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, int mode,
-                                 gridmm_stream_t stream) {
-  if (n <= 0 || n % 4 || mode < 0 || mode > 3 || ((mode & 1) && !dY)) return GRIDMM_EINVAL;
+// _planes: also the bf16 hi/lo planes of the result (the next Linear's A operand; forward modes 0 / 2 only).
+extern "C" int gridmm_activation_planes(const float* X, const float* dY, float* out, void* out_hi, void* out_lo, int64_t n,
+                                        int mode, gridmm_stream_t stream) {
+  if (n <= 0 || n % 4 || mode < 0 || mode > 3 || ((mode & 1) && !dY) || (out_hi && (!out_lo || (mode & 1)))) return GRIDMM_EINVAL;
   const size_t n4 = (size_t)n / 4;
   unsigned grid = (unsigned)((n4 + 255) / 256);
   if (grid > 16384) grid = 16384;
-  GRIDMM_LAUNCH(act_kernel, dim3(grid), dim3(256), 0, as_stream(stream), X, dY, out, n4, mode);
+  GRIDMM_LAUNCH(act_kernel, dim3(grid), dim3(256), 0, as_stream(stream), X, dY, out, n4, mode, (unsigned short*)out_hi,
+                (unsigned short*)out_lo);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
+}
+
+extern "C" int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, int mode,
+                                 gridmm_stream_t stream) {
+  return gridmm_activation_planes(X, dY, out, nullptr, nullptr, n, mode, stream);
 }
 
 // ================================================================================================

@@ -67,6 +67,14 @@ int linear_fwd(const gridmm_linear_train_t& l, const float* x, unsigned short* x
                               nullptr, 0, M, l.N, K, act, st);
 }
 
+// The same when the producer of x (LayerNorm, GELU, attention) already wrote its planes into the saved block.
+int linear_fwd_planes(const gridmm_linear_train_t& l, const unsigned short* xP, const float* R, float* y, int M, int act,
+                      gridmm_stream_t st) {
+  const int K = l.K, Mp = mp32(M);
+  return gridmm_linear_planes(xP, xP + (size_t)K * Mp, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, nullptr,
+                              nullptr, 0, M, l.N, K, act, st);
+}
+
 // Backward of one Linear (autograd._Linear.backward): dY -> [one pass: zero-padded row planes + column sums = db],
 // dX = dY W (+ Radd: the gradient arriving over another branch, summed in the GEMM epilogue), dW = dY^T X from the row
 // planes of dY and of the saved x.
@@ -84,16 +92,8 @@ int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned s
     if (rc != GRIDMM_OK) return rc;
   }
   if (dW) {
-    // few output tiles, long contraction: split the M rows over enough workgroups to fill the chip (autograd._gemm_tn)
-    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    int splits = 1;
-    if (tiles <= 36) {
-      splits = 288 / tiles;
-      if (splits > 8) splits = 8;
-      if (splits > Mp / 256) splits = Mp / 256;
-      if (splits < 1) splits = 1;
-    }
-    rc = gridmm_linear_planes_tn(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, ws.splitk, Mp, N, K, splits, st);
+    const int splits = gridmm_linear_planes_tn_splits(M, N, K);   // <= 8: ws.splitk holds 8 partial tiles
+    rc = gridmm_linear_planes_tn(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, ws.splitk, M, N, K, splits, st);
   }
   return rc;
 }
@@ -132,30 +132,37 @@ extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, cons
   const float ph = L->p_hidden, pa = L->p_attn;
   int rc;
 #define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
-  auto ln = [&](const float* x, const float* r, const gridmm_ln_t& p, unsigned long long seed, float* y) {
-    if (ph > 0.f) return gridmm_layernorm_dropout(x, r, H, p.gamma, p.beta, p.eps, y, ph, seed, L->seed_dev, M, H, stream);
-    return gridmm_layernorm(x, H, r, H, p.gamma, p.beta, p.eps, y, H, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, M, H,
-                            stream);
+  const int Mp = mp32(M);
+  // Every producer (LayerNorm, attention, GELU) also writes the bf16 planes of its output straight into the SAVED block of
+  // the Linear that consumes it: that Linear's A operand now, an operand of its weight gradient in the backward -- one split
+  // pass per layer (over the layer input X) instead of six.
+  auto ln = [&](const float* x, const float* r, const gridmm_ln_t& p, unsigned long long seed, float* y, unsigned short* yP) {
+    unsigned short* yl = yP ? yP + (size_t)H * Mp : nullptr;
+    if (ph > 0.f)
+      return gridmm_layernorm_dropout_planes(x, r, H, p.gamma, p.beta, p.eps, y, yP, yl, ph, seed, L->seed_dev, M, H, stream);
+    return gridmm_layernorm(x, H, r, H, p.gamma, p.beta, p.eps, y, H, nullptr, 0, nullptr, nullptr, yP, yl, H, M, H, stream);
   };
   // ---- cross attention (vilmodel.py:370-379)
   GRIDMM_TRY(linear_fwd(L->xq, X, s.xT, rows, nullptr, s.q, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_attention_train(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs, ctx_mask,
-                                    ctx_mask_bs, s.c, (int64_t)Sq * H, H, s.lse_x, Sqp, B, heads, Sq, Sk, scale, pa,
-                                    L->seed[0], L->seed_dev, stream));
-  GRIDMM_TRY(linear_fwd(L->xo, s.c, s.cT, rows, nullptr, s.h1, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(ln(s.h1, X, L->x_ln, L->seed[1], s.a1));
+  GRIDMM_TRY(gridmm_attention_train_planes(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs,
+                                           ctx_mask, ctx_mask_bs, s.c, (int64_t)Sq * H, H, s.cT, s.cT + (size_t)H * Mp,
+                                           (int64_t)Sq * H, H, s.lse_x, Sqp, B, heads, Sq, Sk, scale, pa, L->seed[0],
+                                           L->seed_dev, stream));
+  GRIDMM_TRY(linear_fwd_planes(L->xo, s.cT, nullptr, s.h1, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(ln(s.h1, X, L->x_ln, L->seed[1], s.a1, s.a1T));
   // ---- self attention (vilmodel.py:172-182)
-  GRIDMM_TRY(linear_fwd(L->sqkv, s.a1, s.a1T, rows, nullptr, s.qkv, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_attention_train(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H, s.qkv + 2 * H,
-                                    (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2, (int64_t)Sq * H, H, s.lse_s,
-                                    Sqp, B, heads, Sq, Sq, scale, pa, L->seed[2], L->seed_dev, stream));
-  GRIDMM_TRY(linear_fwd(L->so, s.c2, s.c2T, rows, nullptr, s.h2, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(ln(s.h2, s.a1, L->s_ln, L->seed[3], s.a2));
+  GRIDMM_TRY(linear_fwd_planes(L->sqkv, s.a1T, nullptr, s.qkv, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(gridmm_attention_train_planes(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H,
+                                           s.qkv + 2 * H, (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2,
+                                           (int64_t)Sq * H, H, s.c2T, s.c2T + (size_t)H * Mp, (int64_t)Sq * H, H, s.lse_s,
+                                           Sqp, B, heads, Sq, Sq, scale, pa, L->seed[2], L->seed_dev, stream));
+  GRIDMM_TRY(linear_fwd_planes(L->so, s.c2T, nullptr, s.h2, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(ln(s.h2, s.a1, L->s_ln, L->seed[3], s.a2, s.a2T));
   // ---- feed forward (vilmodel.py:184-209)
-  GRIDMM_TRY(linear_fwd(L->ffn_i, s.a2, s.a2T, rows, nullptr, s.f1, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_activation(s.f1, nullptr, g, (int64_t)M * I, 0, stream));
-  GRIDMM_TRY(linear_fwd(L->ffn_o, g, s.gT, rows, nullptr, s.h3, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(ln(s.h3, s.a2, L->f_ln, L->seed[4], Y));
+  GRIDMM_TRY(linear_fwd_planes(L->ffn_i, s.a2T, nullptr, s.f1, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(gridmm_activation_planes(s.f1, nullptr, g, s.gT, s.gT + (size_t)I * Mp, (int64_t)M * I, 0, stream));
+  GRIDMM_TRY(linear_fwd_planes(L->ffn_o, s.gT, nullptr, s.h3, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(ln(s.h3, s.a2, L->f_ln, L->seed[4], Y, nullptr));
 #undef GRIDMM_TRY
   return GRIDMM_OK;
 }

@@ -1,5 +1,6 @@
 // gridmm_linear_planes_tn: C (N x K, fp32) = A^T B with BOTH operands row-major over the contraction,
-//   A = dY planes [Mp][>= N],  B = X planes [Mp][>= K]   (bf16 hi / lo, Mp % 32 == 0, rows >= M zero),
+//   A = dY planes [M][>= N],  B = X planes [M][>= K]   (bf16 hi / lo; any M: the last 32-row step re-reads row M-1 for the
+//   missing rows and zeroes A's copies of them in LDS),
 // i.e. the weight gradient dW = dY^T X of a Linear (pretrain_src/train_r2r.py:262 / map_nav_src/r2r/agent_base.py:199
 // run it as torch's autograd of nn.Linear) WITHOUT transposed copies of dY and X: the tile pipeline stages row-major
 // [32 contraction rows][64 columns] panels in LDS by LDS-DMA and reads the MFMA fragments through the hardware transpose
@@ -46,7 +47,7 @@ template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int ldb, float* __restrict__ C, int ldc,
-    int Mp, int N, int K) {
+    int M, int N, int K) {
   constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int PA = BM / 64, PB = BN / 64;                 // panels per plane
@@ -65,8 +66,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
 
   // DMA plan of this wave: piece p = (plane, panel, row group of 8)
   const int lrow = lane >> 3;
-  const unsigned short* src[PPW];
-  int dst[PPW];
+  const unsigned short* src[PPW];    // row (rg * 8 + lrow) of k-step 0
+  const unsigned short* col0[PPW];   // row 0 of the same column (the last, partial k-step clamps its rows to M - 1)
+  int dst[PPW], prow[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int p = wave * PPW + i;
@@ -78,11 +80,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
     int col = (isA ? bm : bn) + panel * 64 + (((lane & 7) ^ (lrow & 6)) << 3);
     col = min(col, ld - 8);                                 // tiles past the matrix edge re-read its last chunk (never stored)
     const unsigned short* base = isA ? (lo ? Alo : Ahi) : (lo ? Blo : Bhi);
-    src[i] = base + (size_t)(rg * 8 + lrow) * ld + col;
+    prow[i] = rg * 8 + lrow;
+    col0[i] = base + col;
+    src[i] = base + (size_t)prow[i] * ld + col;
     dst[i] = pp * PANEL + rg * 8 * 64;
   }
   const size_t stepA = (size_t)32 * lda, stepB = (size_t)32 * ldb;
   const int firstB = (2 * PA * 4 - wave * PPW);             // pieces [firstB, PPW) of this wave belong to B
+  const int nk_all = (M + 31) >> 5, rem = M & 31;           // rem > 0: the last k-step holds only `rem` rows
 
   f32x4_t acc[TM][TN];
 #pragma unroll
@@ -90,13 +95,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  int nk = Mp / 32, k0 = 0;
+  int nk = nk_all, k0 = 0;
   if (gridDim.y > 1) {
     const int per = (nk + gridDim.y - 1) / gridDim.y;
     k0 = blockIdx.y * per;
     nk = max(0, min(per, nk - k0));
   }
   auto issue = [&](int kt, int slot) {
+    if (rem && k0 + kt == nk_all - 1) {                       // partial step: rows past M - 1 re-read row M - 1 (finite data;
+#pragma unroll                                                // A's copies are zeroed in LDS before the fragments are read)
+      for (int i = 0; i < PPW; ++i) {
+        const int r = min((k0 + kt) * 32 + prow[i], M - 1);
+        dma16(col0[i] + (size_t)r * (i < firstB ? lda : ldb), smem + slot * STAGE + dst[i]);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
       dma16(src[i] + (size_t)(k0 + kt) * (i < firstB ? stepA : stepB), smem + slot * STAGE + dst[i]);
@@ -129,6 +142,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
     }
     __builtin_amdgcn_s_barrier();   // stage kt visible to all waves; buffer (kt-1) % NS is free
     if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
+    if (rem && k0 + kt == nk_all - 1) {                       // zero A's rows [rem, 32) of this stage (both planes, all panels)
+      unsigned short* a0 = smem + (kt % NS) * STAGE;
+      const int chunks = 2 * PA * (32 - rem) * 8;             // 16-byte chunks
+      for (int c = tid; c < chunks; c += NW * 64) {
+        const int panel = c / ((32 - rem) * 8), rc = c % ((32 - rem) * 8);
+        *reinterpret_cast<uint4*>(a0 + panel * PANEL + (rem + rc / 8) * 64 + (rc % 8) * 8) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      __syncthreads();
+    }
     const unsigned cur = lds0 + (unsigned)((kt % NS) * STAGE * 2);
     uint2 ra[8], rb[8];             // [tile][hi/lo][row half]
 #pragma unroll
@@ -196,22 +218,32 @@ __global__ void sum_splits_tn_kernel(const float* __restrict__ ws, float* __rest
 
 template <int BM, int BN, int NS>
 int launch_tn(const unsigned short* ah, const unsigned short* al, int lda, const unsigned short* bh, const unsigned short* bl,
-              int ldb, float* C, int Mp, int N, int K, int splits, hipStream_t st) {
+              int ldb, float* C, int M, int N, int K, int splits, hipStream_t st) {
   dim3 grid(((N + BM - 1) / BM) * ((K + BN - 1) / BN), splits), block((BM / 32) * (BN / 32) * 64);
-  GRIDMM_LAUNCH((linear_planes_tn_kernel<BM, BN, 32, 32, NS>), grid, block, 0, st, ah, al, lda, bh, bl, ldb, C, K, Mp, N, K);
+  GRIDMM_LAUNCH((linear_planes_tn_kernel<BM, BN, 32, 32, NS>), grid, block, 0, st, ah, al, lda, bh, bl, ldb, C, K, M, N, K);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
 
 }  // namespace
 
-// C (N x K fp32, contiguous) = A^T B over the Mp rows of A (Mp x >= N) and B (Mp x >= K); splits > 1: the contraction is
+// How many contraction ranges to cut an (N x K) <- M-row weight gradient into: enough 128x128 workgroups to fill the chip
+// (~384: two per CU with slack for the tail), at least 256 rows per range, at most 8 (the partial tiles are fp32 N x K each).
+extern "C" int gridmm_linear_planes_tn_splits(int M, int N, int K) {
+  const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+  long s = (384 + tiles / 2) / tiles;
+  if (s > 8) s = 8;
+  if (s > M / 256) s = M / 256;
+  return s < 1 ? 1 : (int)s;
+}
+
+// C (N x K fp32, contiguous) = A^T B over the M rows of A (M x >= N) and B (M x >= K); splits > 1: the contraction is
 // cut into `splits` ranges whose partial results go to `workspace` (splits x N x K floats) and are summed in order.
 extern "C" int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo,
-                                       int ldb, float* C, float* workspace, int Mp, int N, int K, int splits,
+                                       int ldb, float* C, float* workspace, int M, int N, int K, int splits,
                                        gridmm_stream_t stream) {
-  if (Mp <= 0 || Mp % 32 || N <= 0 || K <= 0 || K % 4 || lda % 8 || ldb % 8 || lda < 8 || ldb < 8 || !C || splits < 1 ||
-      splits > 64 || (splits > 1 && (!workspace || Mp / 32 < splits)))
+  if (M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 8 || ldb % 8 || lda < 8 || ldb < 8 || !C || splits < 1 ||
+      splits > 64 || (splits > 1 && (!workspace || (M + 31) / 32 < splits)))
     return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
   const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
@@ -219,8 +251,8 @@ extern "C" int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int l
   float* out = splits > 1 ? workspace : C;
   const long t128 = (long)((N + 127) / 128) * ((K + 127) / 128) * splits;
   int rc;
-  if (t128 >= 200) rc = launch_tn<128, 128, 2>(ah, al, lda, bh, bl, ldb, out, Mp, N, K, splits, st);
-  else rc = launch_tn<64, 64, 3>(ah, al, lda, bh, bl, ldb, out, Mp, N, K, splits, st);
+  if (t128 >= 100 && N >= 128 && K >= 128) rc = launch_tn<128, 128, 2>(ah, al, lda, bh, bl, ldb, out, M, N, K, splits, st);
+  else rc = launch_tn<64, 64, 3>(ah, al, lda, bh, bl, ldb, out, M, N, K, splits, st);
   if (rc != GRIDMM_OK) return rc;
   if (splits > 1) {
     const size_t n4 = (size_t)N * K / 4;

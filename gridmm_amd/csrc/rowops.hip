@@ -336,24 +336,32 @@ extern "C" int gridmm_layernorm(const float* X, int ldx, const float* R, int ldr
                               stream);
 }
 
-extern "C" int gridmm_layernorm_dropout(const float* X, const float* R, int ldr, const float* gamma, const float* beta,
-                                        float eps, float* Y, float p, unsigned long long seed,
-                                        const unsigned long long* seed_dev, int M, int H, gridmm_stream_t stream) {
+// _planes: also the bf16 hi/lo planes (M, H) of Y -- the next Linear's A operand and, in the backward, an operand of its
+// weight gradient (gridmm_linear_planes_tn): no split pass over Y.
+extern "C" int gridmm_layernorm_dropout_planes(const float* X, const float* R, int ldr, const float* gamma, const float* beta,
+                                               float eps, float* Y, void* Y_hi, void* Y_lo, float p, unsigned long long seed,
+                                               const unsigned long long* seed_dev, int M, int H, gridmm_stream_t stream) {
   if (M <= 0 || H <= 0 || H % 4 || H > MAX_H || !X || !Y || !(p >= 0.f && p < 1.f) || (R && ldr % 4) ||
-      (size_t)M * H >= (1ull << 32))
+      (size_t)M * H >= (1ull << 32) || (Y_hi && !Y_lo))
     return GRIDMM_EINVAL;
   dim3 grid((M + 3) / 4), block(256);
   const int nv = (H / 4 + 63) / 64;
   const bool full = (H % 256) == 0;
 #define GRIDMM_LND(NV, F)                                                                                             \
   GRIDMM_LAUNCH((layernorm_kernel<NV, F, true>), grid, block, 0, as_stream(stream), X, H, R, ldr, gamma, beta, eps, Y, H, \
-                (const float*)nullptr, 0, (const float*)nullptr, (const int64_t*)nullptr, (unsigned short*)nullptr,  \
-                (unsigned short*)nullptr, 0, 0, 0L, M, H, p, seed, seed_dev)
+                (const float*)nullptr, 0, (const float*)nullptr, (const int64_t*)nullptr, (unsigned short*)Y_hi,     \
+                (unsigned short*)Y_lo, H, 0, 0L, M, H, p, seed, seed_dev)
   if (full) { if (nv == 1) GRIDMM_LND(1, true); else if (nv == 2) GRIDMM_LND(2, true); else if (nv == 3) GRIDMM_LND(3, true); else GRIDMM_LND(4, true); }
   else { if (nv == 1) GRIDMM_LND(1, false); else if (nv == 2) GRIDMM_LND(2, false); else if (nv == 3) GRIDMM_LND(3, false); else GRIDMM_LND(4, false); }
 #undef GRIDMM_LND
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
+}
+
+extern "C" int gridmm_layernorm_dropout(const float* X, const float* R, int ldr, const float* gamma, const float* beta,
+                                        float eps, float* Y, float p, unsigned long long seed,
+                                        const unsigned long long* seed_dev, int M, int H, gridmm_stream_t stream) {
+  return gridmm_layernorm_dropout_planes(X, R, ldr, gamma, beta, eps, Y, nullptr, nullptr, p, seed, seed_dev, M, H, stream);
 }
 
 extern "C" int gridmm_ln_dot(const float* X, int ldx, const float* gamma, const float* beta, float eps,

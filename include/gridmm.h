@@ -446,13 +446,15 @@ int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, floa
 /* (R_hi / R_lo, optional: the row-major planes [M][ldp] of the same X from the same pass -- the A operand of the
  * forward / dX GEMM -- so an activation or a gradient is read ONCE for both of its GEMM roles) */
 
-/* Weight gradient WITHOUT transposed copies: C (N x K fp32, contiguous) = A^T B over the Mp rows of the row-major bf16
- * hi/lo planes A [Mp][lda >= N] (dY) and B [Mp][ldb >= K] (X); Mp % 32 == 0 and rows >= M of both are ZERO
- * (gridmm_split_rows_pad writes them so).  The kernel stages row-major panels in LDS and reads the MFMA fragments through
- * the hardware transpose read (ds_read_b64_tr_b16).  splits > 1: contraction cut into `splits` ranges, partials in
- * `workspace` (splits x N x K floats), summed in order (deterministic).  Backward of nn.Linear as above. */
+/* Weight gradient WITHOUT transposed copies: C (N x K fp32, contiguous) = A^T B over the M rows of the row-major bf16
+ * hi/lo planes A [M][lda >= N] (dY) and B [M][ldb >= K] (X), any M (the last 32-row step clamps its row reads to M - 1 and
+ * zeroes A's copies in LDS).  The kernel stages row-major panels in LDS and reads the MFMA fragments through the hardware
+ * transpose read (ds_read_b64_tr_b16).  splits > 1: contraction cut into `splits` ranges, partials in `workspace`
+ * (splits x N x K floats), summed in order (deterministic).  Backward of nn.Linear as above. */
 int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
-                            float* C, float* workspace, int Mp, int N, int K, int splits, gridmm_stream_t stream);
+                            float* C, float* workspace, int M, int N, int K, int splits, gridmm_stream_t stream);
+/* the number of ranges (1 .. 8) that fills the chip for this problem: what the library's own callers pass as `splits` */
+int gridmm_linear_planes_tn_splits(int M, int N, int K);
 /* X fp32 [M][C] -> row-major planes [Mp][ldp] with rows [M, Mp) zero [+ colsum as gridmm_transpose_split]: one pass per
  * activation / gradient for BOTH of its GEMM roles (forward or dX: first M rows; dW through gridmm_linear_planes_tn). */
 int gridmm_split_rows_pad(const float* X, int ldx, void* R_hi, void* R_lo, int ldp, float* colsum, float* colsum_ws,
@@ -472,6 +474,10 @@ int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int ldr, const
 int gridmm_layernorm_dropout(const float* X, const float* R, int ldr, const float* gamma, const float* beta, float eps,
                              float* Y, float p, unsigned long long seed, const unsigned long long* seed_dev, int M, int H,
                              gridmm_stream_t stream);
+/* (_planes: also the bf16 hi/lo planes (M, H) of Y, the next Linear's A operand and an operand of its TN weight gradient) */
+int gridmm_layernorm_dropout_planes(const float* X, const float* R, int ldr, const float* gamma, const float* beta, float eps,
+                                    float* Y, void* Y_hi, void* Y_lo, float p, unsigned long long seed,
+                                    const unsigned long long* seed_dev, int M, int H, gridmm_stream_t stream);
 int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int ldr, const float* gamma, float eps, const float* dY,
                                  float* dX, float* dR, float* dgamma, float* dbeta, float* workspace, float p,
                                  unsigned long long seed, const unsigned long long* seed_dev, int M, int H,
@@ -480,6 +486,9 @@ int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int ldr, const 
 /* Elementwise activations for training.  mode 0: out = gelu(X) (erf form, vilmodel.py:37-43);
  * 1: out = dY * gelu'(X); 2: out = relu(X); 3: out = dY * (X > 0).  n % 4 == 0, contiguous. */
 int gridmm_activation(const float* X, const float* dY, float* out, int64_t n, int mode, gridmm_stream_t stream);
+/* (_planes, forward modes only: also the bf16 hi/lo planes of `out`, same element order) */
+int gridmm_activation_planes(const float* X, const float* dY, float* out, void* out_hi, void* out_lo, int64_t n, int mode,
+                             gridmm_stream_t stream);
 
 /* gridmm_attention that also returns lse [B][heads][Sqp] (Sqp = roundup(Sq,16)): log-sum-exp of the scaled,
  * masked scores per query -- the only statistic the backward needs. */
@@ -488,6 +497,12 @@ int gridmm_attention_train(const float* Q, int64_t q_bs, int q_rs, const float* 
                            int64_t o_bs, int o_rs, float* lse, int Sqp, int B, int heads, int Sq, int Sk,
                            float scale, float dropout_p, unsigned long long seed, const unsigned long long* seed_dev,
                            gridmm_stream_t stream);
+/* (_planes: also the bf16 hi/lo planes of O, row stride p_rs / episode stride p_bs in elements) */
+int gridmm_attention_train_planes(const float* Q, int64_t q_bs, int q_rs, const float* K, int64_t k_bs, int k_rs,
+                                  const float* V, int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, float* O,
+                                  int64_t o_bs, int o_rs, void* O_hi, void* O_lo, int64_t p_bs, int p_rs, float* lse, int Sqp,
+                                  int B, int heads, int Sq, int Sk, float scale, float dropout_p, unsigned long long seed,
+                                  const unsigned long long* seed_dev, gridmm_stream_t stream);
 /* dropout_p > 0: dropout on the attention probabilities (vilmodel.py:143,362; transformer.py MultiheadAttention):
  * element (b,h,q,k) is kept iff a counter-based hash of (seed, ((b*heads+h)*Sq+q)*Sk+k) >= p, survivors scaled by
  * 1/(1-p); the backward regenerates the mask from the same (dropout_p, seed).  seed_dev (device, may be NULL): a

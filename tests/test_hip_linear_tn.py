@@ -24,13 +24,36 @@ def test_tn_gemm_matches_fp64(dev, M, N, K):
     yh, yl, db, Mp2, rows = ag.split_rows_pad(dy, want_colsum=True)
     assert Mp == Mp2 == (M + 31) // 32 * 32
     assert float(xh[M:].float().abs().max() if Mp > M else 0.0) == 0.0          # the pad rows are zero
-    dw = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, Mp)
+    dw = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M)
     ref = dy.double().t() @ x.double()
     torch.cuda.synchronize()
     scale = float(ref.abs().max())
     assert float((dw.double() - ref).abs().max()) <= 2e-5 * max(1.0, scale)
     assert float((db.double() - dy.double().sum(0)).abs().max()) <= 1e-4
     assert float((rows.hi.float() + rows.lo.float() - dy).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("M", [1, 20, 33, 57, 1824 - 5, 300])
+def test_tn_gemm_on_unpadded_planes_of_any_row_count(dev, M):
+    """Planes with EXACTLY M rows (what LayerNorm / GELU / attention emit): the last 32-row step clamps its reads to row M - 1
+    and zeroes the copies on one side; the buffer behind the planes is poisoned to prove nothing past row M - 1 is read."""
+    from gridmm_amd import autograd as ag, ops
+    N, K = 768, 192
+    g = torch.Generator().manual_seed(M)
+    pool = torch.full((4, M + 40, 768), float("nan"), dtype=torch.bfloat16, device=dev)     # NaN everywhere around the planes
+    x, dy = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    xs, ys = ops.split_rows(x), ops.split_rows(dy)
+    xh, xl = pool[0, :M, :K], pool[1, :M, :K]
+    yh, yl = pool[2, :M], pool[3, :M]
+    xh.copy_(xs.hi); xl.copy_(xs.lo); yh.copy_(ys.hi); yl.copy_(ys.lo)
+    lib = ag._lib.load()
+    dw = torch.empty(N, K, device=dev)
+    ag._lib.check(lib.gridmm_linear_planes_tn(ag._p(yh), ag._p(yl), 768, ag._p(xh), ag._p(xl), 768, ag._p(dw), None, M, N, K, 1,
+                                              ag._stream()), "gridmm_linear_planes_tn")
+    ref = dy.double().t() @ x.double()
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all()
+    assert float((dw.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_tn_gemm_equals_the_transposed_planes_path(dev):
@@ -42,14 +65,14 @@ def test_tn_gemm_equals_the_transposed_planes_path(dev):
     x, dy = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
     xh, xl, _, Mp, _ = ag.split_rows_pad(x)
     yh, yl, _, _, _ = ag.split_rows_pad(dy)
-    a = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, Mp)
+    a = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M)
     th, tl, _, Mp2, _ = ag.transpose_split(x)
     uh, ul, _, _, _ = ag.transpose_split(dy)
     b = ag._gemm_tn((uh, ul), (th, tl), N, K, M, Mp2, dy)
     torch.cuda.synchronize()
     assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) * 1e-2
     # run-to-run: fixed summation order
-    a2 = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, Mp)
+    a2 = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M)
     assert torch.equal(a, a2)
 
 
