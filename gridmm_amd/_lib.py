@@ -59,6 +59,7 @@ SIGNATURES = {
     "gridmm_split_rows_pad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_debug_gemm_cfg_override": [_i, _i, _i, _i],
     "gridmm_debug_attention_cfg_override": [_i, _i],
+    "gridmm_debug_gemm_shapes": [_vp, _i, _i],
     "gridmm_linear_planes_map": [_vp, _vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gridmm_linear_planes_grouped": [_vp, _i, _vp],
     "gridmm_layernorm_map": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp],

@@ -801,7 +801,32 @@ extern "C" int gridmm_debug_gemm_cfg_override(int M, int N, int K, int cfg) {
   return GRIDMM_OK;
 }
 
+// ... and the list of problem shapes the heuristic has been asked about (with its answers and call counts), so that a sweep
+// knows what a captured step contains.  `log` = 1 starts / clears the recording, 0 stops it.
+static int g_shape_log[128][5];
+static int g_shape_logged = 0, g_shape_logging = 0;
+extern "C" int gridmm_debug_gemm_shapes(int* out, int max_rows, int log) {
+  int n = 0;
+  if (out)
+    for (; n < g_shape_logged && n < max_rows; ++n)
+      for (int j = 0; j < 5; ++j) out[n * 5 + j] = g_shape_log[n][j];
+  if (log >= 0) { g_shape_logging = log; if (log == 1) g_shape_logged = 0; }
+  return n;
+}
+static int pick_cfg_impl(int M, int N, int K);
 static int pick_cfg(int M, int N, int K) {
+  const int c = pick_cfg_impl(M, N, K);
+  if (g_shape_logging) {
+    int i = 0;
+    for (; i < g_shape_logged; ++i)
+      if (g_shape_log[i][0] == M && g_shape_log[i][1] == N && g_shape_log[i][2] == K) break;
+    if (i == g_shape_logged && g_shape_logged < 128) { int* e = g_shape_log[g_shape_logged++]; e[0] = M; e[1] = N; e[2] = K; e[3] = c; e[4] = 0; }
+    if (i < 128) ++g_shape_log[i][4];
+  }
+  return c;
+}
+
+static int pick_cfg_impl(int M, int N, int K) {
   for (int i = 0; i < g_cfg_overrides; ++i)
     if (g_cfg_override[i][0] == M && g_cfg_override[i][1] == N && g_cfg_override[i][2] == K && g_cfg_override[i][3] > 0)
       return g_cfg_override[i][3];

@@ -234,6 +234,9 @@ int gridmm_linear_planes_ln(const void* A_hi, const void* A_lo, int lda, const v
  * process (tools/sweep_gemm_cfg_step.py times candidate tiles inside the captured step).  Process-global; not used by
  * the product path. */
 int gridmm_debug_gemm_cfg_override(int M, int N, int K, int cfg);
+/* The problem shapes the tile heuristic was asked about since recording started: rows (M, N, K, chosen cfg, calls) into
+ * out[max_rows][5]; returns the number of rows.  log = 1 starts (and clears) the recording, 0 stops it, -1 leaves it. */
+int gridmm_debug_gemm_shapes(int* out, int max_rows, int log);
 /* The same for gridmm_attention_rows: configuration of the calls with more than / at most four 16-query tiles. */
 int gridmm_debug_attention_cfg_override(int cfg_big, int cfg_small);
 
