@@ -57,6 +57,8 @@ SIGNATURES = {
     "gridmm_linear_planes_tn": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_linear_planes_tn_splits": [_i, _i, _i],
     "gridmm_split_rows_pad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "gridmm_linear_planes_lnx_tiles": [_i, _i, _i, _vp],
+    "gridmm_linear_planes_lnx": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "gridmm_debug_gemm_cfg_override": [_i, _i, _i, _i],
     "gridmm_debug_attention_cfg_override": [_i, _i],
     "gridmm_debug_gemm_shapes": [_vp, _i, _i],

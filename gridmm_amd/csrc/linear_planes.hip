@@ -45,7 +45,39 @@ struct LnArgs {
   unsigned* ctr;                  // [tm][2] arrive / depart, zero between calls
   int p_rpb; long p_bs;           // batched row map of the plane outputs (gridmm_layernorm_map)
   int* err;                       // optional: set to 1 when a rendezvous ran into its poll bound
+  // ---- DEFERRED LayerNorm (LN == 2; no rendezvous, nothing waits): a producer GEMM leaves its result h un-normalised
+  // (fp32 + planes) together with per-(row, column tile) statistics; the LayerNorm is applied by whoever reads h:
+  //   as the A operand:  LN(h) W^T + b = rstd (h W'^T - mu sv) + cv,  W' = W * gamma (folded into the weight planes),
+  //                      sv[n] = sum_k W'[n][k],  cv = W beta + b (passed as the bias)
+  //   as the residual :  r = (h - mu) rstd gamma + beta on the fly
+  const float2* a_stats; int a_tn, a_bn; const float* sv; float a_eps;     // statistics of the A operand's rows (or NULL)
+  const float2* r_stats; int r_tn, r_bn; const float* r_gamma; const float* r_beta; float r_eps;   // ... of the residual's
+  float2* out_stats;              // tile statistics of THIS launch's result rows (or NULL)
+  int ln_n;                       // width of the normalised rows (the hidden size)
 };
+
+// The tn (<= LN_MAX_TN) per-tile (mean, M2) partials of row m, ALL loads in flight at once (a loop of dependent round trips
+// here cost the step 0.15 ms), and their merge into (mean, rstd) (equal widths bn: Chan)
+constexpr int LN_MAX_TN = 12;
+template <int MAXT>
+__device__ __forceinline__ void ln_load_partials(float2 (&p)[MAXT], const float2* st, int tn, int M, int m) {
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) p[t] = t < tn ? st[(size_t)t * M + m] : make_float2(0.f, 0.f);
+}
+template <int MAXT>
+__device__ __forceinline__ float2 ln_merge_partials(const float2 (&p)[MAXT], int tn, int bn, int n, float eps) {
+  float mu = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) mu += p[t].x;                      // (absent tiles hold 0)
+  mu /= (float)tn;
+  float m2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const float d = p[t].x - mu;
+    m2 += t < tn ? p[t].y + (float)bn * d * d : 0.f;
+  }
+  return make_float2(mu, rsqrtf(m2 / (float)n + eps));
+}
 
 // Statistics and counters travel as agent-scope RELAXED atomics (sc1 accesses: coherent across the XCDs' L2s) ordered by
 // explicit waits -- never by fences: a release / acquire fence here is a write-back / invalidate of the XCD's WHOLE L2,
@@ -121,11 +153,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   constexpr int ER = (NW > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : 64);   // rows per epilogue pass (LDS budget)
   constexpr int EPI = ER * WN;                           // floats per wave in the epilogue transpose
   constexpr int LDS_U16 = (TR || NS * STAGE * 2 > NW * EPI * 4) ? NS * STAGE : NW * EPI * 2;
-  constexpr int LN_F32 = LN ? BM * WAVES_N + 2 * BM : 0;   // row partials per wave column + (mean, rstd) per row
+  constexpr int LN_F32 = LN ? BM * WAVES_N + 4 * BM : 0;   // row partials per wave column + 2 x (mean, rstd) per row
   __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_U16 + 2 * LN_F32];
   [[maybe_unused]] float* s_part = reinterpret_cast<float*>(smem + LDS_U16);   // [BM][WAVES_N]
   [[maybe_unused]] float* s_mr = s_part + BM * WAVES_N;                        // [BM][2]
-  static_assert(!LN || (ACT == 0 && !PP && NW * 64 >= BM), "fused LayerNorm: plain epilogue, one thread per tile row");
+  static_assert(!LN || ((ACT == 0 || LN == 2) && !PP && NW * 64 >= BM), "fused LayerNorm: plain epilogue, one thread per tile row");
+  static_assert(LN != 2 || !TR, "deferred LayerNorm: LDS epilogue only");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,6 +213,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       src[i] = (plane == 2 ? Whi : Wlo) + (size_t)n * Kp + chunk * 8;
       dst[i] = 2 * BM * BK + (plane - 2) * BN * BK + r0 * BK;
     }
+  }
+
+  // deferred LayerNorm: the statistics this launch READS (of its A operand's rows or of its residual's rows) are fetched
+  // now, under the main loop, by the one thread per tile row that will merge them (tiles with registers to spare)
+  constexpr bool LN_PREFETCH = LN == 2 && BM * BN <= 128 * 128;
+  [[maybe_unused]] float2 ln_p[LN_PREFETCH ? LN_MAX_TN : 1];
+  if constexpr (LN_PREFETCH) {
+    const float2* st = la.a_stats ? la.a_stats : la.r_stats;
+    if (st && tid < BM && bm + tid < M) ln_load_partials(ln_p, st, la.a_stats ? la.a_tn : la.r_tn, M, bm + tid);
   }
 
   f32x4_t acc[TM][TN];
@@ -344,7 +386,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
         }
     }
   }
-  if constexpr (TR && LN) {
+  if constexpr (TR && LN == 1) {
     // ---- fused residual + LayerNorm from the C^T accumulators: lane (m = lane & 15, g = lane >> 4) holds
     // x[i][j][0..3] = row wr*WM + 16 i + m, columns wc*WN + 16 j + 4 g .. + 3 of the tile
     const int mrow = lane & 15, g4 = (lane >> 4) * 4;
@@ -502,10 +544,141 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   const int n0 = bn + wc * WN + c4 * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias && n0 < N) bv = *reinterpret_cast<const float4*>(bias + n0);  // N % 4 == 0
-  if constexpr (LN) {
+  if constexpr (LN == 2) {
+    // ---- deferred LayerNorm (see LnArgs): statistics IN (of the A operand's rows and / or the residual's rows), bias /
+    // activation / residual, statistics OUT (of the result's rows); nothing here waits for another workgroup
+    constexpr int NIT = ER / ROWS_PER_IT;
+    float* s_mr2 = s_mr + 2 * BM;
+    if (la.a_stats || la.r_stats) {
+      if (tid < BM && bm + tid < M) {
+        if constexpr (LN_PREFETCH) {
+          // (one kind of statistics per launch on this path: a consumer GEMM reads its A operand's, a residual form its residual's)
+          const float2 v = la.a_stats ? ln_merge_partials(ln_p, la.a_tn, la.a_bn, la.ln_n, la.a_eps)
+                                      : ln_merge_partials(ln_p, la.r_tn, la.r_bn, la.ln_n, la.r_eps);
+          float* dstp = la.a_stats ? s_mr : s_mr2;
+          dstp[tid * 2] = v.x; dstp[tid * 2 + 1] = v.y;
+        } else {
+          // big tiles (no registers to spare under the main loop): statistics of 128-wide producer tiles, at most 6 per row
+          float2 pp[6];
+          if (la.a_stats) {
+            ln_load_partials(pp, la.a_stats, la.a_tn, M, bm + tid);
+            const float2 v = ln_merge_partials(pp, la.a_tn, la.a_bn, la.ln_n, la.a_eps);
+            s_mr[tid * 2] = v.x; s_mr[tid * 2 + 1] = v.y;
+          }
+          if (la.r_stats) {
+            ln_load_partials(pp, la.r_stats, la.r_tn, M, bm + tid);
+            const float2 v = ln_merge_partials(pp, la.r_tn, la.r_bn, la.ln_n, la.r_eps);
+            s_mr2[tid * 2] = v.x; s_mr2[tid * 2 + 1] = v.y;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    float4 sv4 = make_float4(0.f, 0.f, 0.f, 0.f), rg = sv4, rb = sv4;
+    if (la.a_stats && n0 < N) sv4 = *reinterpret_cast<const float4*>(la.sv + n0);
+    if (la.r_stats && n0 < N) { rg = *reinterpret_cast<const float4*>(la.r_gamma + n0); rb = *reinterpret_cast<const float4*>(la.r_beta + n0); }
+    // every lane's row statistics into registers BEFORE the transpose passes touch the LDS again
+    constexpr int NROW = (WM / ER) * NIT;
+    float amu[NROW], ars[NROW], rmu[NROW], rrs[NROW];
+#pragma unroll
+    for (int q = 0; q < NROW; ++q) {
+      const int lr = wr * WM + (q / NIT) * ER + (q % NIT) * ROWS_PER_IT + rr;
+      amu[q] = la.a_stats ? s_mr[lr * 2] : 0.f;  ars[q] = la.a_stats ? s_mr[lr * 2 + 1] : 1.f;
+      rmu[q] = la.r_stats ? s_mr2[lr * 2] : 0.f; rrs[q] = la.r_stats ? s_mr2[lr * 2 + 1] : 1.f;
+    }
+    float xv[NIT][4];               // the LAST pass's values (statistics out: single-pass tiles only)
+#pragma unroll
+    for (int h = 0; h < WM / ER; ++h) {
+      if (h) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < ER / 16; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            ep[(i * 16 + (lane >> 4) * 4 + r) * WN + j * 16 + (lane & 15)] = acc[h * (ER / 16) + i][j][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int lr = wr * WM + h * ER + it * ROWS_PER_IT + rr, m = bm + lr;
+        const float4 v = *reinterpret_cast<const float4*>(ep + (it * ROWS_PER_IT + rr) * WN + c4 * 4);
+        float x[4] = {v.x, v.y, v.z, v.w};
+        if (la.a_stats) {
+          const float mu = amu[h * NIT + it], rs = ars[h * NIT + it];
+          x[0] = rs * (x[0] - mu * sv4.x); x[1] = rs * (x[1] - mu * sv4.y); x[2] = rs * (x[2] - mu * sv4.z); x[3] = rs * (x[3] - mu * sv4.w);
+        }
+        x[0] += bv.x; x[1] += bv.y; x[2] += bv.z; x[3] += bv.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
+          if (ACT == GRIDMM_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+        }
+        if (R && m < M && n0 < N) {
+          float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
+          if (la.r_stats) {
+            const float mu = rmu[h * NIT + it], rs = rrs[h * NIT + it];
+            r4.x = (r4.x - mu) * rs * rg.x + rb.x; r4.y = (r4.y - mu) * rs * rg.y + rb.y;
+            r4.z = (r4.z - mu) * rs * rg.z + rb.z; r4.w = (r4.w - mu) * rs * rg.w + rb.w;
+          }
+          x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[it][e] = x[e];
+        if (m < M && n0 < N) {
+          if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
+          if (Chi) {
+            uint2 hi, lo;
+            split2_bf16(x[0], x[1], hi.x, lo.x);
+            split2_bf16(x[2], x[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(Chi + (size_t)m * ldp + n0) = hi;
+            *reinterpret_cast<uint2*>(Clo + (size_t)m * ldp + n0) = lo;
+          }
+        }
+      }
+    }
+    if constexpr (WM == ER)
+    if (la.out_stats) {          // N % BN == 0 (host-checked): every column of the tile is a column of the matrix
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        float sm = (xv[it][0] + xv[it][1]) + (xv[it][2] + xv[it][3]);
+#pragma unroll
+        for (int o = 1; o < F4_PER_ROW; o <<= 1) sm += __shfl_xor(sm, o, 64);
+        if (c4 == 0) s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + wc] = sm;
+      }
+      __syncthreads();
+      float tmean[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_N; ++w) sm += s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + w];
+        tmean[it] = sm * (1.0f / (float)BN);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xv[it][e] - tmean[it]; q += d * d; }
+#pragma unroll
+        for (int o = 1; o < F4_PER_ROW; o <<= 1) q += __shfl_xor(q, o, 64);
+        if (c4 == 0) s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + wc] = q;
+        if (c4 == 0 && wc == 0) s_mr[(wr * WM + it * ROWS_PER_IT + rr) * 2] = tmean[it];
+      }
+      __syncthreads();
+      if (tid < BM && bm + tid < M) {
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_N; ++w) q += s_part[tid * WAVES_N + w];
+        la.out_stats[(size_t)tx * M + bm + tid] = make_float2(s_mr[tid * 2], q);
+      }
+    }
+    return;
+  }
+  if constexpr (LN == 1) {
     // ---- fused residual + LayerNorm (see LnArgs): one LDS transpose pass, then lane (rr, c4) holds columns 4 c4 .. + 3
     // of rows it * ROWS_PER_IT + rr of its wave's sub-tile
-    static_assert(!LN || WM == ER, "fused LayerNorm: one epilogue pass per wave");
+    static_assert(LN != 1 || WM == ER, "fused LayerNorm: one epilogue pass per wave");
     constexpr int NIT = ER / ROWS_PER_IT;
     const int tn = (N + BN - 1) / BN;
 #pragma unroll
@@ -979,6 +1152,69 @@ extern "C" int gridmm_linear_planes_ln(const void* A_hi, const void* A_lo, int l
   if (rc == GRIDMM_EUNSUPPORTED) rc = launch_ln<128, 128, 32, 32, 2, 32, 0>(GRIDMM_LN_ARGS);
 #undef GRIDMM_LN_ARGS
   return rc;
+}
+
+// ---- GEMMs around a DEFERRED LayerNorm (LnArgs, LN == 2): no LayerNorm launch and no rendezvous.  The producer of a
+// pre-LayerNorm sum h leaves h (fp32 + planes) and per-tile row statistics (out_stats); consumers normalise on the fly:
+// a GEMM over LN(h) runs on h's planes with gamma folded into its weight (W' = W * gamma) and corrects in the epilogue,
+//   y = rstd (acc - mu sv) + cv,   sv[n] = sum_k W'[n][k],   cv = W beta + b  (handed in as `bias`),
+// a GEMM whose residual is LN(h) normalises the residual as it reads it.  Tile shapes: the heuristic's 128x64 (3-stage) and
+// 128x128 choices; other shapes answer GRIDMM_EUNSUPPORTED (gridmm_linear_planes_lnx_tiles tells in advance).
+template <int BM, int BN, int WM, int WN, int NS, int BK>
+int launch_lnx(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
+               const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
+               unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, const LnArgs& la,
+               hipStream_t st) {
+  if (la.out_stats && N % BN) return GRIDMM_EUNSUPPORTED;
+  constexpr int NWL = (BM / WM) * (BN / WN);
+  constexpr int ERL = (NWL > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : 64);
+  if (la.out_stats && ERL != WM) return GRIDMM_EUNSUPPORTED;      // statistics out: single-pass epilogues only
+  dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM)), block((BM / WM) * (BN / WN) * 64);
+  if (act == GRIDMM_ACT_NONE)
+    GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, GRIDMM_ACT_NONE, 0, 0, 0, 2>), grid, block, 0, st, Ahi, Alo, lda,
+                  Whi, Wlo, Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, 0, 0L, la);
+  else if (act == GRIDMM_ACT_GELU)
+    GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, GRIDMM_ACT_GELU, 0, 0, 0, 2>), grid, block, 0, st, Ahi, Alo, lda,
+                  Whi, Wlo, Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, 0, 0L, la);
+  else return GRIDMM_EINVAL;
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+// Column tiles (and their width) the deferred-LayerNorm form uses for this problem: the layout of out_stats
+// ([tiles][M] (mean, M2) pairs).  0: the shape cannot take the form.
+extern "C" int gridmm_linear_planes_lnx_tiles(int M, int N, int K, int* tile_width) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4) return 0;
+  const int cfg = pick_cfg(M, N, K);
+  const int bn = cfg == 13 ? 64 : (cfg == 15 ? 128 : 0);     // (the 256x256 tiles have no registers to spare for the forms)
+  if (!bn || N % bn) return 0;
+  if (tile_width) *tile_width = bn;
+  return N / bn;
+}
+
+extern "C" int gridmm_linear_planes_lnx(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
+                                        int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
+                                        void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
+                                        const gridmm_lnx_t* x, gridmm_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || !x || x->ln_n <= 0) return GRIDMM_EINVAL;
+  if ((C && ldc % 4) || (residual && ldr % 4) || (C_hi && (ldp % 4 || !C_lo)) || (!C && !C_hi)) return GRIDMM_EINVAL;
+  if ((x->a_stats && (!x->sv || x->a_tn <= 0 || x->a_tn > 12 || x->a_bn <= 0)) ||
+      (x->r_stats && (!residual || !x->r_gamma || !x->r_beta || x->r_tn <= 0 || x->r_tn > 12 || x->r_bn <= 0)) ||
+      (x->a_stats && x->r_stats))          // one kind of statistics in per launch
+    return GRIDMM_EINVAL;
+  LnArgs la{};
+  la.a_stats = (const float2*)x->a_stats; la.a_tn = x->a_tn; la.a_bn = x->a_bn; la.sv = x->sv; la.a_eps = x->a_eps;
+  la.r_stats = (const float2*)x->r_stats; la.r_tn = x->r_tn; la.r_bn = x->r_bn; la.r_gamma = x->r_gamma; la.r_beta = x->r_beta;
+  la.r_eps = x->r_eps; la.out_stats = (float2*)x->out_stats; la.ln_n = x->ln_n;
+  const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
+  const unsigned short *wh = (const unsigned short*)W_hi, *wl = (const unsigned short*)W_lo;
+  hipStream_t st = as_stream(stream);
+  const int cfg = pick_cfg(M, N, K);
+#define GRIDMM_LNX_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, (unsigned short*)C_hi, (unsigned short*)C_lo, ldp, M, N, K, act, la, st
+  if (cfg == 13) return launch_lnx<128, 64, 32, 32, 3, 64>(GRIDMM_LNX_ARGS);
+  if (cfg == 15) return launch_lnx<128, 128, 32, 32, 2, 32>(GRIDMM_LNX_ARGS);
+#undef GRIDMM_LNX_ARGS
+  return GRIDMM_EUNSUPPORTED;
 }
 
 extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi,

@@ -456,15 +456,23 @@ class _CLn(ctypes.Structure):
 
 class _CXLayer(ctypes.Structure):
     _fields_ = [(n, _CLinear) for n in ("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o")] + \
-               [(n, _CLn) for n in ("x_ln", "s_ln", "f_ln")]
+               [(n, _CLn) for n in ("x_ln", "s_ln", "f_ln")] + \
+               [(n, _CLinear) for n in ("sqkv_f", "ffn_i_f")] + [("sqkv_sv", ctypes.c_void_p), ("ffn_i_sv", ctypes.c_void_p)]
 
 
 class XLayerWeights:
     """gridmm_xlayer_t of one cross-modal layer: packed Linears (PackedLinear) and LayerNorm modules; keeps them alive."""
 
-    def __init__(self, xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln):
+    def __init__(self, xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln, folded=None):
+        """folded = ((sqkv with x_ln folded in, its row sums), (ffn_i with s_ln folded in, its row sums)) or None: the
+        deferred-LayerNorm form of the two inner LayerNorms (fold_layernorm)."""
         self.keep = (xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln)
+        self.folded = folded
         c = _CXLayer()
+        if folded is not None:
+            for name, (pw, sv) in zip(("sqkv_f", "ffn_i_f"), folded):
+                setattr(c, name, _CLinear(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.bias.data_ptr(), pw.N, pw.K, pw.Kp))
+                setattr(c, name[:-2] + "_sv", sv.data_ptr())
         for name, pw in zip(("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o"), self.keep[:6]):
             setattr(c, name, _CLinear(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.bias.data_ptr() if pw.bias is not None else None,
                                       pw.N, pw.K, pw.Kp))
@@ -472,6 +480,15 @@ class XLayerWeights:
             setattr(c, name, _CLn(ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps)))
         self.c = c
         self.H, self.I = xq.N, ffn_i.N
+
+
+def fold_layernorm(weight, bias, ln):
+    """nn.Linear over a LayerNorm's output with the LayerNorm folded in: LN(h) W^T + b = rstd (h W'^T - mu sv) + cv with
+    W' = W * gamma, sv = W' 1, cv = W beta + b.  -> (PackedLinear(W', cv), sv fp32 (N,))"""
+    w = weight.detach().float()
+    wf = w * ln.weight.detach().float()[None, :]
+    cv = w @ ln.bias.detach().float() + (bias.detach().float() if bias is not None else 0.0)
+    return PackedLinear(wf.contiguous(), cv.contiguous()), wf.sum(1).contiguous()
 
 
 def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12, planes_out=None, kv2=None):

@@ -230,6 +230,28 @@ int gridmm_linear_planes_ln(const void* A_hi, const void* A_lo, int lda, const v
                             int64_t p_bs, void* workspace, void* sync_words, int M, int N, int K, int dry_run,
                             gridmm_stream_t stream);
 
+/* GEMMs around a DEFERRED LayerNorm: the LayerNorm between a dense block and its consumers is never launched.  The
+ * producer GEMM (x->out_stats != NULL) leaves its pre-LayerNorm result h = A W^T + bias + residual as fp32 (C) and / or
+ * bf16 planes (C_hi / C_lo) together with per-(column tile, row) statistics (mean and sum of squared deviations over the
+ * tile's columns).  Whoever reads h applies the LayerNorm:
+ *   - as the A operand (x->a_stats): this GEMM runs on h's planes with W' = W * gamma as its weight and computes
+ *       y = act( rstd[m] (acc - mu[m] sv[n]) + bias[n] ),  sv[n] = sum_k W'[n][k],  bias = W beta + b  (caller-folded);
+ *   - as the residual (x->r_stats): residual[m][n] is replaced by (residual - mu) rstd r_gamma[n] + r_beta[n] on the fly.
+ * (BertSelfOutput -> BertIntermediate / BertSelfAttention, map_nav_src/models/vilmodel.py:156-209: same values as
+ * dense + LayerNorm + dense, in a different association.)  a_tn / a_bn, r_tn / r_bn: number and width of the column tiles
+ * of the statistics being read = what gridmm_linear_planes_lnx_tiles answered for the launch that wrote them; ln_n: width of
+ * the normalised rows.  Shapes whose tile choice has no deferred form return GRIDMM_EUNSUPPORTED (.._tiles returns 0). */
+typedef struct {
+  const void* a_stats; int a_tn, a_bn; const float* sv; float a_eps;
+  const void* r_stats; int r_tn, r_bn; const float* r_gamma; const float* r_beta; float r_eps;
+  void* out_stats;
+  int ln_n;
+} gridmm_lnx_t;
+int gridmm_linear_planes_lnx_tiles(int M, int N, int K, int* tile_width);
+int gridmm_linear_planes_lnx(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int Kp,
+                             const float* bias, const float* residual, int ldr, float* C, int ldc, void* C_hi, void* C_lo,
+                             int ldp, int M, int N, int K, int act, const gridmm_lnx_t* x, gridmm_stream_t stream);
+
 /* Tuning hook: force tile configuration `cfg` (0 = back to the heuristic) for the problem shape (M, N, K) in this
  * process (tools/sweep_gemm_cfg_step.py times candidate tiles inside the captured step).  Process-global; not used by
  * the product path. */
@@ -330,6 +352,11 @@ typedef struct {
   gridmm_linear_t sqkv, so;      /* visn_self_att.self.{query|key|value} stacked (3H, H), visn_self_att.output.dense */
   gridmm_linear_t ffn_i, ffn_o;  /* visn_inter.dense (H -> I, gelu), visn_output.dense (I -> H) */
   gridmm_ln_t x_ln, s_ln, f_ln;  /* the three output LayerNorms */
+  /* optional (w_hi == NULL: absent): the deferred-LayerNorm form of the two inner LayerNorms (gridmm_linear_planes_lnx) --
+   * sqkv / ffn_i with the preceding LayerNorm's gamma folded into the weight (W * gamma) and beta into the bias (W beta + b),
+   * and the row sums of the folded weights.  With them (and shapes the form takes) a layer is 9 launches instead of 11. */
+  gridmm_linear_t sqkv_f, ffn_i_f;
+  const float *sqkv_sv, *ffn_i_sv;
 } gridmm_xlayer_t;
 size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I);
 int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
