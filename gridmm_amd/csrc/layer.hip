@@ -73,8 +73,9 @@ extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, 
   // add) normalise on the fly.  Taken when the folded weights are there and every GEMM's tile choice has the form.
   // Measured (profiles/r4_layernorm_fusion_experiments.txt): the B = 32 step runs 2.33-2.35 ms this way against 2.23-2.25 ms
   // with the LayerNorm launches -- the statistics passes and barriers in five GEMM epilogues per layer cost more than the two
-  // ~6 us launches they remove -- so the form is OFF unless GRIDMM_LN_DEFER=1 (kept correct by tests/test_hip_linear_lnx.py).
-  static const int defer_on = getenv("GRIDMM_LN_DEFER") ? atoi(getenv("GRIDMM_LN_DEFER")) : 0;
+  // ~6 us launches they remove -- so callers pass the folded weights only on request (Python: GRIDMM_LN_DEFER=1 /
+  // model.defer_layernorm; kept correct by tests/test_hip_linear_lnx.py and test_hip_kernels.py).
+  const int defer_on = 1;
   int bn_h = 0;
   const int tn_h = gridmm_linear_planes_lnx_tiles(M, H, H, &bn_h);
   if (defer_on && L->sqkv_f.w_hi && L->ffn_i_f.w_hi && L->sqkv_sv && L->ffn_i_sv && tn_h > 0 && tn_h <= 12 && bn_h > 0 &&

@@ -486,8 +486,7 @@ class GlocalTextPathNavCMT(nn.Module):
     # The two inner LayerNorms of every cross-modal layer in deferred form (gridmm_linear_planes_lnx: gamma / beta folded into
     # the next GEMM's weight planes, statistics from the producing GEMM's epilogue, residuals normalised on the fly): two
     # launches fewer per layer.  Same function values, different association (differences ~1e-6).  OFF by default: measured
-    # slower than the launches it removes (2.33-2.35 vs 2.23-2.25 ms per step; csrc/layer.hip).  The C side reads the same
-    # variable: both must be on for the form to run.
+    # slower than the launches it removes (2.33-2.35 vs 2.23-2.25 ms per step; csrc/layer.hip).
     defer_layernorm = bool(int(os.environ.get("GRIDMM_LN_DEFER", "0")))
     varlen_buckets = None
     DEFAULT_BUCKETS = (64, 80, 96, 112, 128, 144, 160, 176, N_CELLS)   # 16-row steps: a step costs what its occupied cells cost

@@ -263,8 +263,8 @@ def test_xattn_layer_entry_point_equals_the_eleven_calls(dev):
     # partials instead of one two-pass reduction per row
     assert float((ln1.f32 - split.f32).abs().max()) < 2e-5
     assert float((ln1.hi.float() + ln1.lo.float() - ln1.f32).abs().max()) < 1e-4
-    # the nine-launch form (GRIDMM_LN_DEFER=1 in the environment of the C library too: otherwise this compares the eleven-launch
-    # form with itself): the two inner LayerNorms deferred into their consumers (gridmm_linear_planes_lnx)
+    # the nine-launch form (opt-in: model.defer_layernorm): the two inner LayerNorms deferred into their consumers
+    # (gridmm_linear_planes_lnx)
     for Bd in (3, 32):                       # 171 rows (small tiles: falls back to eleven launches) and 1824 rows (deferred)
         g2 = torch.Generator().manual_seed(Bd)
         xd = ops.split_rows(torch.randn(Bd, Sq, H, generator=g2).to(dev))
