@@ -921,7 +921,7 @@ def main():
         # the memory deepens as an episode proceeds; the headline is t = 1, these are the same step at
         # t = 5 and t = 15 (re-binning and aggregation walk 5x / 15x the points)
         for t in (5, 15):
-            sec = extra_depth_leg(args, dev, dist, t, max(5, args.steps // 2))
+            sec = extra_depth_leg(args, dev, dist, t, max(10, args.steps))    # (10-step timings of these legs moved by 10 % between runs)
             out["t%d" % t] = {"value": n_gpus * args.batch / sec, "unit": "steps/s", "ms_per_step": 1e3 * sec,
                               "mem_steps": t, "points": geom.pts_per_obs * t}
     if not args.no_depth_legs and not args.eager and args.mem_steps == 1 and n_gpus == 1:
