@@ -883,7 +883,13 @@ def main():
             print(json.dumps(res), flush=True)
         return
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GRIDMM_DIST_FORCE"):
+        # (GRIDMM_DIST_FORCE=1 with one rank: the multi-rank code of THIS leg -- captures next to a live communicator, barriers
+        # and the max-over-ranks reduction over RCCL -- on a one-GPU box; tests/test_hip_dist.py)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist  # RCCL ("nccl" backend on ROCm)
         if share:
             dist.init_process_group("gloo")

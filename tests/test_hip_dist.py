@@ -196,3 +196,19 @@ def test_rccl_single_rank_runs_the_multi_rank_training_leg():
     seg = ex["buckets_launched_after_segment"]
     assert len(seg) >= 4 and 0 < seg[-2] <= seg[-1], seg
     assert ex["reducer_stats"]["repairs"] == 0 and ex["reducer_stats"]["launched_early"] > 0
+
+
+def test_rccl_single_rank_runs_the_navigation_leg():
+    """bench.py's headline leg with a live RCCL process group (one rank, GRIDMM_DIST_FORCE): the step is captured next to the
+    communicator's watchdog thread (thread_local capture mode), the timed region is bracketed by RCCL barriers and the time
+    is reduced with max-over-ranks over RCCL -- what every rank of a --gpus N run does."""
+    env = dict(os.environ, GRIDMM_DIST_FORCE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    env.pop("GRIDMM_BENCH_SHARE_GPU", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-train-leg",
+                          "--no-roofline", "--no-cpu-baseline", "--no-torch-gpu-baseline", "--no-producer-leg"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["replay_check"]["bit_identical"] and d["value"] > 1000
+    assert "t5" in d and "t15" in d            # the depth legs ran through the same barriers
