@@ -105,7 +105,7 @@ def _gemm(a2d, pw, bias=None, residual=None):
     """(M,K) fp32 @ packed (N,K)^T -> (M,N) fp32 through ops.linear (planes kernel when shapes allow)."""
     pw.bias = bias
     try:
-        return ops.linear(a2d, pw, residual=residual).f32
+        return ops.linear(a2d, pw, residual=residual, allow_tiled=False).f32
     finally:
         pw.bias = None
 

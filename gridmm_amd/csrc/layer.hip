@@ -13,6 +13,19 @@
 
 namespace {
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// One plane GEMM of the layer: the tiled weight planes when the layer carries them and the shape's tile reads them, else the
+// row-major ones.
+inline int lin(const gridmm_linear_t& W, const void* A_hi, const void* A_lo, int lda, const float* R, int ldr, float* C, int ldc,
+               void* C_hi, void* C_lo, int ldp, int M, int act, gridmm_stream_t stream) {
+  if (W.wt_hi && W.wt_lo) {
+    const int rc = gridmm_linear_planes(A_hi, A_lo, lda, W.wt_hi, W.wt_lo, -W.Kp, W.bias, R, ldr, C, ldc, C_hi, C_lo, ldp, M, W.N,
+                                        W.K, act, stream);
+    if (rc != GRIDMM_EUNSUPPORTED) return rc;
+  }
+  return gridmm_linear_planes(A_hi, A_lo, lda, W.w_hi, W.w_lo, W.Kp, W.bias, R, ldr, C, ldc, C_hi, C_lo, ldp, M, W.N, W.K, act,
+                              stream);
+}
 }
 
 extern "C" size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I) {
@@ -59,8 +72,7 @@ extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, 
   int rc;
 #define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
   // ---- cross attention over the context (vilmodel.py:370-379): q = query(x); a = LN(dense(attn) + x)
-  GRIDMM_TRY(gridmm_linear_planes(X_hi, X_lo, H, L->xq.w_hi, L->xq.w_lo, L->xq.Kp, L->xq.bias, nullptr, 0, nullptr, 0,
-                                  q_hi, q_lo, H, M, H, H, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(lin(L->xq, X_hi, X_lo, H, nullptr, 0, nullptr, 0, q_hi, q_lo, H, M, GRIDMM_ACT_NONE, stream));
   const unsigned short *k2h = (const unsigned short*)KV2_hi, *k2l = (const unsigned short*)KV2_lo;
   GRIDMM_TRY(gridmm_attention_rows_seg(q_hi, q_lo, (int64_t)Sq * H, H, (const unsigned short*)KV_hi + k_col,
                                        (const unsigned short*)KV_lo + k_col, kv_bs, kv_rs, (const unsigned short*)KV_hi + v_col,
@@ -124,23 +136,20 @@ extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, 
       r = gridmm_linear_planes_ln(in_hi, in_lo, K, W.w_hi, W.w_lo, W.Kp, W.bias, res, H, nullptr, 0, ln.gamma, ln.beta, ln.eps,
                                   out, H, out_hi, out_lo, H, p_rpb, p_bs, ln_ws, sync_words, M, H, K, 0, stream);
     if (r != GRIDMM_EUNSUPPORTED) return r;
-    r = gridmm_linear_planes(in_hi, in_lo, K, W.w_hi, W.w_lo, W.Kp, W.bias, res, H, h, H, nullptr, nullptr, 0, M, H, K,
-                             GRIDMM_ACT_NONE, stream);
+    r = lin(W, in_hi, in_lo, K, res, H, h, H, nullptr, nullptr, 0, M, GRIDMM_ACT_NONE, stream);
     if (r != GRIDMM_OK) return r;
     return gridmm_layernorm_map(h, H, nullptr, 0, ln.gamma, ln.beta, ln.eps, out, H, nullptr, 0, nullptr, nullptr, out_hi,
                                 out_lo, H, p_rpb, p_bs, M, H, stream);
   };
   GRIDMM_TRY(dense_ln(L->xo, L->x_ln, c_hi, c_lo, H, X, a, a_hi, a_lo, 0, 0));
   // ---- self attention (vilmodel.py:172-182)
-  GRIDMM_TRY(gridmm_linear_planes(a_hi, a_lo, H, L->sqkv.w_hi, L->sqkv.w_lo, L->sqkv.Kp, L->sqkv.bias, nullptr, 0, nullptr,
-                                  0, qkv_hi, qkv_lo, 3 * H, M, 3 * H, H, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(lin(L->sqkv, a_hi, a_lo, H, nullptr, 0, nullptr, 0, qkv_hi, qkv_lo, 3 * H, M, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(gridmm_attention_rows(qkv_hi, qkv_lo, (int64_t)Sq * 3 * H, 3 * H, qkv_hi + H, qkv_lo + H, (int64_t)Sq * 3 * H,
                                    3 * H, qkv_hi + 2 * H, qkv_lo + 2 * H, (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs,
                                    nullptr, 0, 0, s_hi, s_lo, (int64_t)Sq * H, H, B, heads, Sq, Sq, scale, stream));
   GRIDMM_TRY(dense_ln(L->so, L->s_ln, s_hi, s_lo, H, a, bb, b_hi, b_lo, 0, 0));
   // ---- feed forward (vilmodel.py:184-209): LN(dense(gelu(dense(b))) + b)
-  GRIDMM_TRY(gridmm_linear_planes(b_hi, b_lo, H, L->ffn_i.w_hi, L->ffn_i.w_lo, L->ffn_i.Kp, L->ffn_i.bias, nullptr, 0, nullptr,
-                                  0, f_hi, f_lo, I, M, I, H, GRIDMM_ACT_GELU, stream));
+  GRIDMM_TRY(lin(L->ffn_i, b_hi, b_lo, H, nullptr, 0, nullptr, 0, f_hi, f_lo, I, M, GRIDMM_ACT_GELU, stream));
   GRIDMM_TRY(dense_ln(L->ffn_o, L->f_ln, f_hi, f_lo, I, bb, Y, Y_hi, Y_lo, y_p_rpb, y_p_bs));
 #undef GRIDMM_TRY
   return GRIDMM_OK;

@@ -135,7 +135,10 @@ __device__ __forceinline__ void ln_depart(unsigned* ctr, int tn) {
 // lagging group's R2 of step s-1, finished one barrier earlier) and retired (vmcnt(0)) by every wave before the
 // barrier that ends the 4th interval -- one barrier before the leading group's first read of it, two before the
 // lagging group's -- so a full k-step of MFMA time covers the global->LDS latency.
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int LN = 0>
+// WT = 1: the W planes arrive TILED as [N / 16][Kp / 32][16 rows][32 k] -- every 1-KiB DMA piece (16 rows x 64 B) is one
+// contiguous KiB of memory instead of 16 segments a row pitch apart (tools/l2_to_lds_bw.hip: contiguous pieces stream at
+// 17.8-23.7 TB/s out of the Infinity Cache, strided rows at 12.5).  BK = 32 tiles only.
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int LN = 0, int WT = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
@@ -159,6 +162,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   [[maybe_unused]] float* s_mr = s_part + BM * WAVES_N;                        // [BM][2]
   static_assert(!LN || ((ACT == 0 || LN == 2) && !PP && NW * 64 >= BM), "fused LayerNorm: plain epilogue, one thread per tile row");
   static_assert(LN != 2 || !TR, "deferred LayerNorm: LDS epilogue only");
+  static_assert(!WT || (!PP && !TR), "tiled W planes: the plain main loop");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,8 +194,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   // DMA plan of this wave: piece p covers 16 rows of one plane
   const unsigned short* src[PPW];
   int dst[PPW];
+  [[maybe_unused]] int kstep[PPW];          // elements between consecutive k-steps of a piece (WT: a W block is 512 apart)
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
+    kstep[i] = BK;
     const int p = wave * PPW + i;
     int plane, r0;
     if (p < BM / RPP) { plane = 0; r0 = p * RPP; }
@@ -210,7 +216,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       dst[i] = plane * BM * BK + r0 * BK;
     } else {
       const int n = min(bn + row, N - 1);
-      src[i] = (plane == 2 ? Whi : Wlo) + (size_t)n * Kp + chunk * 8;
+      if constexpr (WT) {
+        static_assert(!WT || BK == 32, "tiled W planes: 16 x 32 blocks");
+        src[i] = (plane == 2 ? Whi : Wlo) + (size_t)(n >> 4) * (Kp >> 5) * 512 + (n & 15) * 32 + chunk * 8;
+        kstep[i] = 512;
+      } else {
+        src[i] = (plane == 2 ? Whi : Wlo) + (size_t)n * Kp + chunk * 8;
+      }
       dst[i] = 2 * BM * BK + (plane - 2) * BN * BK + r0 * BK;
     }
   }
@@ -245,7 +257,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) {
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + s * BK, smem + s * STAGE + dst[i]);
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + s * (WT ? kstep[i] : BK), smem + s * STAGE + dst[i]);
     }
 
   const int frow = lane & 15, fchunk = lane >> 4;
@@ -343,7 +355,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     if (ABLATE != 2 && kt + NS - 1 < nk) {
       unsigned short* nxt = smem + ((kt + NS - 1) % NS) * STAGE;
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * BK, nxt + dst[i]);
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * (WT ? kstep[i] : BK), nxt + dst[i]);
     }
     const unsigned short* cur = smem + (kt % NS) * STAGE;
 #pragma unroll
@@ -841,7 +853,7 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
 }
 
 // QG: also instantiate the QuickGELU epilogue (only the configurations pick_cfg can choose carry it)
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false, int WT = 0>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
@@ -849,7 +861,7 @@ int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const 
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM), ksplit), block((BM / WM) * (BN / WN) * 64);
   const LnArgs la{};
 #define GRIDMM_LP(ACT)                                                                                        \
-  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
+  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR, 0, WT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
                 Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs, la)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
@@ -1042,6 +1054,8 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
                                         const void* W_lo, int Kp, const float* bias, const float* residual,
                                         int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N,
                                         int K, int act, int cfg, int a_rpb, long a_bs, gridmm_stream_t stream) {
+  const bool wt = Kp < 0;                    // tiled W planes (16 x 32 blocks; rows padded to a multiple of 16)
+  if (wt) Kp = -Kp;
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || act < 0 || act > 3)
     return GRIDMM_EINVAL;
   if (K % 64 && (cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 13 || cfg == 108 || cfg == 208 ||
@@ -1054,6 +1068,11 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
   hipStream_t st = as_stream(stream);
   if (cfg == 0) cfg = pick_cfg(M, N, K);
 #define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st, 1, a_rpb, a_bs
+  if (wt) {                                  // only the BK = 32 tiles of the heuristic read tiled planes
+    if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
+    if (cfg == 36) return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
+    return GRIDMM_EUNSUPPORTED;
+  }
   switch (cfg) {
     case 1: return launch<128, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
     case 2: return launch<128, 128, 64, 32, 2, 64, 0, 0, 0, true>(GRIDMM_ARGS);

@@ -105,7 +105,21 @@ def _rows_map(t):
 class PackedLinear:
     """bf16 hi/lo planes of a Linear weight (N, K) zero-padded to Kp = roundup(K, 32), plus fp32 bias."""
 
-    __slots__ = ("hi", "lo", "bias", "N", "K", "Kp")
+    __slots__ = ("hi", "lo", "bias", "N", "K", "Kp", "_tiled")
+
+    def tiled(self):
+        """The planes as [N16 / 16][Kp / 32][16][32] blocks (rows zero-padded to a multiple of 16): every 1-KiB DMA piece of
+        a BK = 32 tile is one contiguous KiB (experiment: GRIDMM_WT=1)."""
+        t = getattr(self, "_tiled", None)
+        if t is None:
+            Np = (self.N + 15) // 16 * 16
+            out = []
+            for p in (self.hi, self.lo):
+                q = torch.zeros(Np, self.Kp, dtype=p.dtype, device=p.device)
+                q[:self.N] = p
+                out.append(q.view(Np // 16, 16, self.Kp // 32, 32).permute(0, 2, 1, 3).contiguous())
+            t = self._tiled = tuple(out)
+        return t
 
     def __init__(self, weight, bias=None):
         lib = _lib.load()
@@ -117,6 +131,7 @@ class PackedLinear:
         _lib.check(lib.gridmm_split_weight(_p(w), _p(self.hi), _p(self.lo), self.N, self.K, self.Kp, _stream()),
                    "gridmm_split_weight")
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        self._tiled = None
 
 
 def _is_uniform(t):
@@ -180,7 +195,7 @@ def split_rows(x, out=None):
     return Act(x, hi, lo)
 
 
-def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_planes=False, planes_out=None):
+def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_planes=False, planes_out=None, allow_tiled=True):
     """act(x @ W^T + b) (+ residual) -> Act.  x: Act or fp32 tensor (..., K).
 
     K % 32 == 0 (every hidden-size GEMM): gridmm_linear_planes -- A as bf16 planes (taken from the
@@ -214,10 +229,19 @@ def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_pla
             hi, lo = _planes_like(oshape, dev)
         ldc = _rows2d(c)[2] if c is not None else 0
         ldr = _rows2d(residual)[2] if residual is not None else 0
-        _timed("linear", 2.0 * M * pw.N * K, lambda: _lib.check(
-            lib.gridmm_linear_planes_map(_p(a.hi), _p(a.lo), lda, rpb, bs, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias),
-                                         _p(residual), ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream()),
-            "gridmm_linear_planes"))
+        def call():
+            if WT and allow_tiled and getattr(pw, "_tiled", False) is not False:   # (inference weights, packed once; the training
+                                                                                   # path re-packs per step and passes allow_tiled=False)
+                th, tl = pw.tiled()
+                rc = lib.gridmm_linear_planes_map(_p(a.hi), _p(a.lo), lda, rpb, bs, _p(th), _p(tl), -pw.Kp, _p(pw.bias),
+                                                  _p(residual), ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream())
+                if rc != -2:
+                    return _lib.check(rc, "gridmm_linear_planes (tiled W)")
+            _lib.check(
+                lib.gridmm_linear_planes_map(_p(a.hi), _p(a.lo), lda, rpb, bs, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias),
+                                             _p(residual), ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream()),
+                "gridmm_linear_planes")
+        _timed("linear", 2.0 * M * pw.N * K, call)
         return Act(c, hi, lo)
     xf = uniform_rows(a.f32)
     M, _, lda = _rows2d(xf)
@@ -273,6 +297,11 @@ def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=Non
         copy_rows(out, final, 0)
         out = final
     return Act(out, hi, lo)
+
+
+# Tiled weight planes for the BK = 32 tiles (PackedLinear.tiled): every 1-KiB DMA piece of W is one contiguous KiB.  Measured
+# in the B = 32 step: -10..-15 us with the Python-issued GEMMs alone (profiles/r4_tiled_weights.txt).  GRIDMM_WT=0: row-major only.
+WT = bool(int(os.environ.get("GRIDMM_WT", "1")))
 
 
 # ---- GEMM + residual + LayerNorm as one launch (gridmm_linear_planes_ln) ---------------------------------------------
@@ -447,7 +476,14 @@ def attention_rows(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_pl
 
 class _CLinear(ctypes.Structure):
     _fields_ = [("w_hi", ctypes.c_void_p), ("w_lo", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("N", ctypes.c_int),
-                ("K", ctypes.c_int), ("Kp", ctypes.c_int)]
+                ("K", ctypes.c_int), ("Kp", ctypes.c_int), ("wt_hi", ctypes.c_void_p), ("wt_lo", ctypes.c_void_p)]
+
+
+def _clinear(pw):
+    """gridmm_linear_t of a PackedLinear (with its tiled planes when WT is on)."""
+    th, tl = pw.tiled() if (WT and pw.Kp % 32 == 0) else (None, None)
+    return _CLinear(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.bias.data_ptr() if pw.bias is not None else None, pw.N, pw.K, pw.Kp,
+                    th.data_ptr() if th is not None else None, tl.data_ptr() if tl is not None else None)
 
 
 class _CLn(ctypes.Structure):
@@ -471,11 +507,10 @@ class XLayerWeights:
         c = _CXLayer()
         if folded is not None:
             for name, (pw, sv) in zip(("sqkv_f", "ffn_i_f"), folded):
-                setattr(c, name, _CLinear(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.bias.data_ptr(), pw.N, pw.K, pw.Kp))
+                setattr(c, name, _clinear(pw))
                 setattr(c, name[:-2] + "_sv", sv.data_ptr())
         for name, pw in zip(("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o"), self.keep[:6]):
-            setattr(c, name, _CLinear(pw.hi.data_ptr(), pw.lo.data_ptr(), pw.bias.data_ptr() if pw.bias is not None else None,
-                                      pw.N, pw.K, pw.Kp))
+            setattr(c, name, _clinear(pw))
         for name, ln in zip(("x_ln", "s_ln", "f_ln"), self.keep[6:]):
             setattr(c, name, _CLn(ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps)))
         self.c = c

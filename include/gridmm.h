@@ -200,6 +200,8 @@ int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void
                          void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
                          gridmm_stream_t stream);
 
+/* (Kp < 0: W_hi / W_lo are TILED planes of row pitch -Kp, see gridmm_linear_t.wt_hi; shapes whose tile choice cannot read
+ * them return GRIDMM_EUNSUPPORTED and the caller passes the row-major planes) */
 /* Same with an explicit tile configuration (tuning / benchmarking; cfg 0 = the heuristic above). */
 int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
                              int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
@@ -345,7 +347,12 @@ int gridmm_attention_rows_seg(const void* Q_hi, const void* Q_lo, int64_t q_bs, 
  * vilmodel.py:843-853), self attention, feed forward; every block = dense + residual + LayerNorm.  Weights arrive as
  * the bf16 hi/lo planes of gridmm_split_weight.  All intermediates live in `workspace` (>= gridmm_xattn_layer_workspace
  * bytes, 256-byte aligned); outputs: Y fp32 (M, H) and/or its bf16 planes.  heads * 64 == H. */
-typedef struct { const void *w_hi, *w_lo; const float* bias; int N, K, Kp; } gridmm_linear_t;   /* nn.Linear(K, N) */
+typedef struct {                 /* nn.Linear(K, N) */
+  const void *w_hi, *w_lo; const float* bias; int N, K, Kp;
+  const void *wt_hi, *wt_lo;     /* optional (NULL: absent): the same planes TILED as [roundup(N,16) / 16][Kp / 32][16][32]
+                                  * blocks, rows past N zero -- what gridmm_linear_planes reads when it is handed a NEGATIVE Kp:
+                                  * every 1-KiB LDS-DMA piece of a BK = 32 tile is then one contiguous KiB of memory */
+} gridmm_linear_t;
 typedef struct { const float *gamma, *beta; float eps; } gridmm_ln_t;
 typedef struct {
   gridmm_linear_t xq, xo;        /* visual_attention.att.query, visual_attention.output.dense */
