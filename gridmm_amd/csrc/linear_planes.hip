@@ -135,9 +135,9 @@ __device__ __forceinline__ void ln_depart(unsigned* ctr, int tn) {
 // lagging group's R2 of step s-1, finished one barrier earlier) and retired (vmcnt(0)) by every wave before the
 // barrier that ends the 4th interval -- one barrier before the leading group's first read of it, two before the
 // lagging group's -- so a full k-step of MFMA time covers the global->LDS latency.
-// WT = 1: the W planes arrive TILED as [N / 16][Kp / 32][16 rows][32 k] -- every 1-KiB DMA piece (16 rows x 64 B) is one
-// contiguous KiB of memory instead of 16 segments a row pitch apart (tools/l2_to_lds_bw.hip: contiguous pieces stream at
-// 17.8-23.7 TB/s out of the Infinity Cache, strided rows at 12.5).  BK = 32 tiles only.
+// WT = 1: the W planes arrive TILED as [N / RPP][Kp / BK][RPP rows][BK k] blocks (used with BK = 32: 16 x 32) -- every 1-KiB DMA
+// piece is one contiguous KiB of memory instead of 16 HALF cache lines a row pitch apart (tools/l2_to_lds_bw.hip: contiguous
+// pieces stream at 17.8-23.7 TB/s out of the Infinity Cache, strided rows at 12.5).
 template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int LN = 0, int WT = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
@@ -217,8 +217,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     } else {
       const int n = min(bn + row, N - 1);
       if constexpr (WT) {
-        static_assert(!WT || BK == 32, "tiled W planes: 16 x 32 blocks");
-        src[i] = (plane == 2 ? Whi : Wlo) + (size_t)(n >> 4) * (Kp >> 5) * 512 + (n & 15) * 32 + chunk * 8;
+        src[i] = (plane == 2 ? Whi : Wlo) + (size_t)(n / RPP) * (Kp / BK) * 512 + (n % RPP) * BK + chunk * 8;
         kstep[i] = 512;
       } else {
         src[i] = (plane == 2 ? Whi : Wlo) + (size_t)n * Kp + chunk * 8;
@@ -1068,7 +1067,8 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
   hipStream_t st = as_stream(stream);
   if (cfg == 0) cfg = pick_cfg(M, N, K);
 #define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st, 1, a_rpb, a_bs
-  if (wt) {                                  // only the BK = 32 tiles of the heuristic read tiled planes
+  if (wt) {     // tiled planes (16 x 32 blocks): the BK = 32 tiles of the heuristic.  An 8 x 64 copy for the BK = 64 tiles was
+                // measured too (their pieces are 8 full 128-B lines already): +-2 us per step, not kept.
     if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
     if (cfg == 36) return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
     return GRIDMM_EUNSUPPORTED;

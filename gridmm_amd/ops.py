@@ -108,8 +108,8 @@ class PackedLinear:
     __slots__ = ("hi", "lo", "bias", "N", "K", "Kp", "_tiled")
 
     def tiled(self):
-        """The planes as [N16 / 16][Kp / 32][16][32] blocks (rows zero-padded to a multiple of 16): every 1-KiB DMA piece of
-        a BK = 32 tile is one contiguous KiB (experiment: GRIDMM_WT=1)."""
+        """The planes as [Np / 16][Kp / 32][16][32] blocks (rows zero-padded to Np = roundup(N, 16)): every 1-KiB DMA piece of
+        a BK = 32 tile is one contiguous KiB instead of 16 half cache lines (GRIDMM_WT=0 turns the tiled planes off)."""
         t = getattr(self, "_tiled", None)
         if t is None:
             Np = (self.N + 15) // 16 * 16
