@@ -38,6 +38,11 @@ __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short
 // only when the WHOLE grid is resident at once (the host checks the grid against the occupancy of the kernel) and no
 // other rendezvous kernel runs on the device at the same time (single-stream use; GRIDMM_LN_FUSE=0 turns the path off).
 // The counters are self-resetting: the last workgroup to leave a row block zeroes its pair.
+// EXPERIMENTAL (off by default, GRIDMM_LN_FUSE=1): slower than GEMM + LayerNorm as two launches
+// (profiles/r4_layernorm_fusion_experiments.txt), and its cross-XCD hand-over rests on relaxed device-coherent stores being
+// visible to a peer that polls AFTERWARDS -- true in every run of tests/test_hip_linear_ln.py, but a last-arriver variant of
+// the same hand-over (no polling delay) read stale partials: a release fence would be needed for a guarantee, and a fence here
+// costs 0.7 ms per step.
 struct LnArgs {
   const float* gamma; const float* beta; float eps;
   float* Y; int ldy;              // post-LayerNorm fp32 out (optional)
