@@ -143,7 +143,9 @@ __device__ __forceinline__ void ln_depart(unsigned* ctr, int tn) {
 // WT = 1: the W planes arrive TILED as [N / RPP][Kp / BK][RPP rows][BK k] blocks (used with BK = 32: 16 x 32) -- every 1-KiB DMA
 // piece is one contiguous KiB of memory instead of 16 HALF cache lines a row pitch apart (tools/l2_to_lds_bw.hip: contiguous
 // pieces stream at 17.8-23.7 TB/s out of the Infinity Cache, strided rows at 12.5).
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int LN = 0, int WT = 0>
+// AT = 1: the same for the A planes ([M / RPP][lda / BK][RPP][BK] blocks; no row map).
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int LN = 0, int WT = 0,
+          int AT = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
@@ -167,7 +169,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   [[maybe_unused]] float* s_mr = s_part + BM * WAVES_N;                        // [BM][2]
   static_assert(!LN || ((ACT == 0 || LN == 2) && !PP && NW * 64 >= BM), "fused LayerNorm: plain epilogue, one thread per tile row");
   static_assert(LN != 2 || !TR, "deferred LayerNorm: LDS epilogue only");
-  static_assert(!WT || (!PP && !TR), "tiled W planes: the plain main loop");
+  static_assert(!(WT || AT) || (!PP && !TR), "tiled planes: the plain main loop");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,6 +219,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       // stride a_bs -- a sequence that lives inside a longer one ([map | txt] contexts) is read in place
       size_t aoff = (size_t)m * lda;
       if (a_rpb > 0) { const int eb = m / a_rpb; aoff = (size_t)eb * a_bs + (size_t)(m - eb * a_rpb) * lda; }
+      if constexpr (AT) {
+        aoff = (size_t)(m / RPP) * (lda / BK) * 512 + (m % RPP) * BK;
+        kstep[i] = 512;
+      }
       src[i] = (plane == 0 ? Ahi : Alo) + aoff + chunk * 8;
       dst[i] = plane * BM * BK + r0 * BK;
     } else {
@@ -261,7 +267,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) {
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + s * (WT ? kstep[i] : BK), smem + s * STAGE + dst[i]);
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + s * ((WT || AT) ? kstep[i] : BK), smem + s * STAGE + dst[i]);
     }
 
   const int frow = lane & 15, fchunk = lane >> 4;
@@ -359,7 +365,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     if (ABLATE != 2 && kt + NS - 1 < nk) {
       unsigned short* nxt = smem + ((kt + NS - 1) % NS) * STAGE;
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * (WT ? kstep[i] : BK), nxt + dst[i]);
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * ((WT || AT) ? kstep[i] : BK), nxt + dst[i]);
     }
     const unsigned short* cur = smem + (kt % NS) * STAGE;
 #pragma unroll
@@ -857,7 +863,8 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
 }
 
 // QG: also instantiate the QuickGELU epilogue (only the configurations pick_cfg can choose carry it)
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false, int WT = 0>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false, int WT = 0,
+          int AT = 0>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
@@ -865,7 +872,7 @@ int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const 
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM), ksplit), block((BM / WM) * (BN / WN) * 64);
   const LnArgs la{};
 #define GRIDMM_LP(ACT)                                                                                        \
-  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR, 0, WT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
+  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR, 0, WT, AT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
                 Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs, la)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
@@ -1060,6 +1067,9 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
                                         int K, int act, int cfg, int a_rpb, long a_bs, gridmm_stream_t stream) {
   const bool wt = Kp < 0;                    // tiled W planes (16 x 32 blocks; rows padded to a multiple of 16)
   if (wt) Kp = -Kp;
+  const bool at = lda < 0;                   // tiled A planes (EXPERIMENT; with tiled W only, no row map)
+  if (at) lda = -lda;
+  if (at && (!wt || a_rpb > 0 || lda % 32)) return GRIDMM_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || act < 0 || act > 3)
     return GRIDMM_EINVAL;
   if (K % 64 && (cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 13 || cfg == 108 || cfg == 208 ||
@@ -1074,6 +1084,11 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
 #define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st, 1, a_rpb, a_bs
   if (wt) {     // tiled planes (16 x 32 blocks): the BK = 32 tiles of the heuristic.  An 8 x 64 copy for the BK = 64 tiles was
                 // measured too (their pieces are 8 full 128-B lines already): +-2 us per step, not kept.
+    if (at) {
+      if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, false, 1, 1>(GRIDMM_ARGS);
+      if (cfg == 36) return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, false, 1, 1>(GRIDMM_ARGS);
+      return GRIDMM_EUNSUPPORTED;
+    }
     if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
     if (cfg == 36) return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
     return GRIDMM_EUNSUPPORTED;
