@@ -1091,6 +1091,12 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     }
     if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
     if (cfg == 36) return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
+    // (other BK = 32 tiles with tiled W: reachable only through the tuning override, tools/sweep_gemm_cfg_step.py)
+    if (cfg == 16) return launch<256, 128, 64, 32, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 14) return launch<128, 128, 64, 32, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 12) return launch<128, 128, 64, 32, 3, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 48) return launch<128, 128, 32, 32, 3, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 3) return launch<256, 128, 64, 64, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
     return GRIDMM_EUNSUPPORTED;
   }
   switch (cfg) {

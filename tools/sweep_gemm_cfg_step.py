@@ -19,6 +19,9 @@ SHAPES = {  # (M, N, K): (what, launches per step)
     (1824, 2304, 768): ("local QKV", 4), (1824, 3072, 768): ("local FFN1", 4), (1824, 768, 3072): ("local FFN2", 4)}
 THIN = [(1824, 768, 768), (1824, 768, 3072), (1824, 2304, 768), (1824, 3072, 768), (2560, 512, 768), (2560, 1536, 768)]
 CANDS_ALL = [43, 8, 4, 6, 9, 13, 21, 15, 14, 1, 2, 12, 16, 3, 36, 42, 44]
+BIG = [(6912, 3072, 768), (6912, 768, 3072), (6912, 768, 768), (6912, 2304, 768), (9472, 6144, 768), (1824, 2304, 768),
+       (1824, 3072, 768), (6272, 768, 512)]
+CANDS_BIG = [15, 36, 16, 14, 12, 48, 3]        # BK = 32 tiles, all with tiled weight planes
 CANDS_THIN = [43, 8, 13, 21, 50, 52, 53, 55, 56, 6, 9, 15]
 ATT_BIG = [9, 3, 20, 21, 22, 23, 24, 25]
 ATT_SMALL = [5, 1, 15, 18]
@@ -94,8 +97,8 @@ def main():
                         torch.cuda.synchronize()
                 print(line, flush=True)
             continue
-        shapes = THIN if mode == "thin" else list(SHAPES)
-        cands = CANDS_THIN if mode == "thin" else CANDS_ALL
+        shapes = THIN if mode == "thin" else (BIG if mode == "big" else list(SHAPES))
+        cands = CANDS_THIN if mode == "thin" else (CANDS_BIG if mode == "big" else CANDS_ALL)
         for (M, N, K) in shapes:
             what, cnt = SHAPES[(M, N, K)]
             line = "%5d x %4d x %4d  %-18s x%2d |" % (M, N, K, what, cnt)
