@@ -25,11 +25,19 @@ import time
 import numpy as np
 import torch
 
+
+def _dist_forced():
+    """GRIDMM_DIST_FORCE as an integer switch (gridmm_amd.dist.dist_forced; restated here: this runs before the package import)."""
+    try:
+        return int(os.environ.get("GRIDMM_DIST_FORCE", "0").strip() or "0") != 0
+    except ValueError:
+        return False
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-METRIC = "nav steps/sec (whole node), R2R batch=32, 36x196x512 grid, 1/2/4/8 MI355X"
+METRIC = "nav steps/sec (whole node), R2R batch=32, 36\u00d7196\u00d7512 grid, 1/2/4/8 MI355X"   # byte-identical to BASELINE.json's "metric"
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
@@ -461,7 +469,7 @@ def _init_dist(dev):
     """(dist module or None, rank, world): RCCL ("nccl") process group, or gloo when N ranks share one GPU (test hook)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1 and not os.environ.get("GRIDMM_DIST_FORCE"):
+    if world == 1 and not _dist_forced():
         return None, 0, 1
     # (GRIDMM_DIST_FORCE=1 with one rank: the multi-rank leg end to end over the real backend -- the only way it can meet
     # RCCL on a one-GPU box, which refuses two ranks on one device; tests/test_hip_dist.py)
@@ -664,7 +672,7 @@ def train_leg(args, dev, steps=None, emit=None):
     return res if rank == 0 else None
 
 
-def train_leg_subprocess(args, world=1):
+def train_leg_subprocess(args, world=1, dist=None):
     """The training leg in its own process (its 200 M-parameter model, graphs and pools are gone when it returns; a failure
     in this secondary leg cannot take the headline line with it).  Default runtime settings: the captured step holds
     kernel nodes only (gridmm_amd/train_graph.py).  With several
@@ -673,7 +681,14 @@ def train_leg_subprocess(args, world=1):
     import subprocess
     env = dict(os.environ)
     if world > 1:
-        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+        # the children's own rendezvous: a port rank 0 PROBED free (not "parent port + 1", which may be taken), agreed on
+        # through the parent's process group
+        port = [_free_port() if int(os.environ.get("RANK", "0")) == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(port, src=0)
+        else:
+            port = [int(os.environ.get("MASTER_PORT", "29500")) + 1]
+        env["MASTER_PORT"] = str(int(port[0]))
         for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
             env.pop(k)        # (TORCHELASTIC_USE_AGENT_STORE would make the children look for the launcher's store on the new port)
     limit = float(os.environ.get("GRIDMM_BENCH_TRAIN_TIMEOUT", "420"))
@@ -883,7 +898,7 @@ def main():
             print(json.dumps(res), flush=True)
         return
     dist = None
-    if world > 1 or os.environ.get("GRIDMM_DIST_FORCE"):
+    if world > 1 or _dist_forced():
         # (GRIDMM_DIST_FORCE=1 with one rank: the multi-rank code of THIS leg -- captures next to a live communicator, barriers
         # and the max-over-ranks reduction over RCCL -- on a one-GPU box; tests/test_hip_dist.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -918,7 +933,13 @@ def main():
                    "global_batch": args.batch * n_gpus, "parallelism": "dp%d (episode sharding, no step-path collective)" % n_gpus,
                    "launch": "eager" if args.eager else "hipGraph replay; per step on the host: pose/heading floats and the fused-logit index maps (H2D into static buffers)",
                    "gemm": "MFMA bf16 16x16x32, 3-term split (hi*hi+lo*hi+hi*lo), fp32 accumulate",
-                   "attention": "MFMA bf16 16x16x32, 3-term split, fp32 softmax", "slab": "fp16, relevance on MFMA f16 (text hi+lo)"},
+                   "attention": "MFMA bf16 16x16x32, 3-term split, fp32 softmax", "slab": "fp16, relevance on MFMA f16 (text hi+lo)",
+                   "grid_proj": "post-reduction shortcut (declared, SURVEY 8d): grid_proj runs on the 196 reduced cell vectors "
+                                "(W sum_j a_j x_j + b, sum_j a_j = 1) instead of on all N points as vilmodel.py:799 writes it -- "
+                                "-5.4 GFLOP per episode-step, difference < 1e-6; the roofline flop count (2MNK of the launched "
+                                "GEMMs) is the post-reduction count",
+                   "instruction_side": "recomputed every step like the reference (the cached form is the secondary key "
+                                       "instruction_cache)"},
     }
     out["replay_check"] = check
     if getattr(step, "graph", None) is not None and step.graph.n_nodes is not None:
@@ -937,11 +958,13 @@ def main():
         out["instruction_cache"] = instruction_cache_leg(args, dev, max(5, args.steps // 2), out["ms_per_step"])
         if args.batch == 32 and args.mem_steps == 1:
             out["larger_batches"] = larger_batch_leg(args, dev, max(5, args.steps // 2))
-    if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1:
+    def _rollout():
         try:
             out["rollout"] = rollout_leg(args, dev)
         except Exception as e:      # a secondary key: reported in the line, the headline measurement stands
             out["rollout"] = {"error": repr(e)[:300]}
+    if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1:
+        _rollout()
     if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus == 1 and not args.no_train_leg:
         try:
             out["finetune"] = finetune_leg(args, dev)
@@ -949,9 +972,15 @@ def main():
             out["finetune"] = {"error": repr(e)[:300]}
     if not args.no_train_leg:
         # config 3's shape: the pre-training step on EVERY rank with the RCCL gradient exchange (whole-job samples/s)
-        tl = train_leg_subprocess(args, n_gpus)
+        tl = train_leg_subprocess(args, n_gpus, dist)
         if rank == 0:
             out["train"] = tl
+    if rank == 0 and not args.no_depth_legs and not args.eager and n_gpus > 1:
+        # N > 1: rank 0's end-to-end rollout (one GPU's worth; the other ranks wait at the final barrier), after the legs
+        # that need every rank
+        _rollout()
+        if isinstance(out.get("rollout"), dict):
+            out["rollout"]["note"] = "rank 0 only (one GPU); the other ranks idle"
     if rank == 0 and n_gpus == 1 and not args.no_producer_leg:
         out["vlnce_with_producer"] = producer_leg(args, dev)
     if rank == 0 and not args.no_roofline:
@@ -962,10 +991,12 @@ def main():
             if k != dom and k in rl:
                 out["roofline_" + k] = rl[k]
         out["kernels"] = rl["kernels"]
-    if rank == 0 and n_gpus == 1:
-        if not args.no_torch_gpu_baseline:
+    if rank == 0:
+        if not args.no_torch_gpu_baseline and n_gpus == 1:
             out["torch_gpu_baseline"] = torch_gpu_baseline(model, batch, mem, args)
         if not args.no_cpu_baseline:
+            # (also in the N > 1 line -- a SCALE line carries roofline AND cpu_baseline; timed on rank 0's host cores after
+            # every timed leg, the other ranks wait at the barrier below)
             out["cpu_baseline"] = cpu_baseline(model, eps, batch, args, geom)
     if dist is not None:
         dist.barrier()

@@ -14,7 +14,11 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
-ABI_VERSION = 19
+# Development build (`make -C gridmm_amd/csrc debug`, -DGRIDMM_DEBUG_HOOKS): the same kernels plus the process-global tuning
+# overrides and the whole experiment table of tile configurations.  Only the sweep tools ask for it (load(debug=True) or
+# GRIDMM_LIB_DEBUG=1 before the first load); the product path and the tests run on the shipping library, which has neither.
+DEBUG_LIB_PATH = os.path.join(_HERE, "libgridmm_hip_dbg.so")
+ABI_VERSION = 20
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -47,22 +51,13 @@ SIGNATURES = {
                                   _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp],
     "gridmm_xattn_layer_workspace": [_i, _i, _i, _i],
     "gridmm_xattn_layer_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i,
-                               _vp, _vp, _vp, _i, _i64, _vp, ctypes.c_size_t, _vp, _i, _i, _i, _i, _vp],
+                               _vp, _vp, _vp, _i, _i64, _vp, ctypes.c_size_t, _i, _i, _i, _i, _vp],
     "gridmm_attention_rows_seg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _i,
                                   _vp, _i, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
-    "gridmm_linear_planes_ln_workspace": [_i, _i],
-    "gridmm_linear_planes_ln_sync_bytes": [_i],
-    "gridmm_linear_planes_ln": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i64,
-                                _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_linear_planes_tn": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_linear_planes_tn_splits": [_i, _i, _i],
     "gridmm_split_rows_pad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
-    "gridmm_linear_planes_lnx_tiles": [_i, _i, _i, _vp],
-    "gridmm_linear_planes_lnx": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "gridmm_debug_gemm_cfg_override": [_i, _i, _i, _i],
-    "gridmm_debug_attention_cfg_override": [_i, _i],
-    "gridmm_debug_gemm_shapes": [_vp, _i, _i],
-    "gridmm_linear_planes_map": [_vp, _vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gridmm_linear_planes_map": [_vp, _vp, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gridmm_linear_planes_grouped": [_vp, _i, _vp],
     "gridmm_layernorm_map": [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp],
     "gridmm_split_rows_map": [_vp, _i, _vp, _vp, _i, _i, _i64, _i, _i, _vp],
@@ -110,30 +105,49 @@ SIGNATURES = {
     "gridmm_collate_nav_fill": [_vp] * 15 + [_i] * 8 + [_vp] * 10,
 }
 
+# development build only (GRIDMM_DEBUG_HOOKS section of include/gridmm.h)
+DEBUG_SIGNATURES = {
+    "gridmm_debug_gemm_cfg_override": [_i, _i, _i, _i],
+    "gridmm_debug_attention_cfg_override": [_i, _i],
+    "gridmm_debug_gemm_shapes": [_vp, _i, _i],
+    "gridmm_debug_linear_planes_map_cfg": [_vp, _vp, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i,
+                                           _i, _i, _i, _vp],
+}
+W_ROWMAJOR, W_TILED = 0, 1
+
 _lib = None
+_lib_is_debug = False
 
 
 class GridmmLibraryError(RuntimeError):
     pass
 
 
-def load():
-    """dlopen the HIP library (no GPU needed for loading) and bind every prototype."""
-    global _lib
+def load(debug=None):
+    """dlopen the HIP library (no GPU needed for loading) and bind every prototype.  debug=True (or GRIDMM_LIB_DEBUG=1 in the
+    environment at the first call) binds the development build instead; one library per process."""
+    global _lib, _lib_is_debug
+    if debug is None:
+        debug = _lib_is_debug if _lib is not None else os.environ.get("GRIDMM_LIB_DEBUG", "0") not in ("", "0")
     if _lib is not None:
+        if debug and not _lib_is_debug:
+            raise GridmmLibraryError("the shipping library is already loaded in this process; set GRIDMM_LIB_DEBUG=1 (or call "
+                                     "load(debug=True)) before the first use to get the development build")
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = DEBUG_LIB_PATH if debug else LIB_PATH
+    if not os.path.exists(path):
         raise GridmmLibraryError(
-            "libgridmm_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; "
-            "g.build()'` (or `make -C gridmm_amd/csrc`). There is no fallback path." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, argtypes in SIGNATURES.items():
+            "%s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C gridmm_amd/csrc%s`). "
+            "There is no fallback path." % (path, " debug" if debug else ""))
+    lib = ctypes.CDLL(path)
+    sigs = dict(SIGNATURES)
+    if debug:
+        sigs.update(DEBUG_SIGNATURES)
+    for name, argtypes in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
-    lib.gridmm_linear_planes_ln_workspace.restype = ctypes.c_size_t
-    lib.gridmm_linear_planes_ln_sync_bytes.restype = ctypes.c_size_t
     lib.gridmm_grid_aggregate_workspace.restype = ctypes.c_size_t
     lib.gridmm_xattn_layer_train_saved_bytes.restype = ctypes.c_size_t
     lib.gridmm_xattn_layer_train_workspace.restype = ctypes.c_size_t
@@ -141,8 +155,8 @@ def load():
     lib.gridmm_nav_heads_workspace.restype = ctypes.c_size_t
     v = lib.gridmm_abi_version()
     if v != ABI_VERSION:
-        raise GridmmLibraryError("libgridmm_hip.so ABI %d != expected %d (stale build?)" % (v, ABI_VERSION))
-    _lib = lib
+        raise GridmmLibraryError("%s ABI %d != expected %d (stale build?)" % (os.path.basename(path), v, ABI_VERSION))
+    _lib, _lib_is_debug = lib, bool(debug)
     return lib
 
 

@@ -456,21 +456,15 @@ class GMapNavAgent:
         streams = streams or [torch.cuda.Stream() for _ in agents] if torch.cuda.is_available() else [None] * len(agents)
         gens = [a._rollout_gen() for a in agents]
         out, live = [None] * len(agents), list(range(len(agents)))
-        # several streams at once: the fused GEMM + LayerNorm launches (which rendezvous inside their own grid and assume
-        # the device to themselves) are off for these rollouts; the graph caches key their entries by this switch
-        fuse, ops.LN_FUSE = ops.LN_FUSE, False
-        try:
-            while live:
-                for i in list(live):
-                    ctx = torch.cuda.stream(streams[i]) if streams[i] is not None else contextlib.nullcontext()
-                    with ctx:
-                        try:
-                            next(gens[i])
-                        except StopIteration as e:
-                            out[i] = e.value
-                            live.remove(i)
-        finally:
-            ops.LN_FUSE = fuse
+        while live:
+            for i in list(live):
+                ctx = torch.cuda.stream(streams[i]) if streams[i] is not None else contextlib.nullcontext()
+                with ctx:
+                    try:
+                        next(gens[i])
+                    except StopIteration as e:
+                        out[i] = e.value
+                        live.remove(i)
         return out
 
     # ---- Seq2SeqAgent.test / .train (agent_base.py:150-211) ---------------------------------------

@@ -92,12 +92,20 @@ class NavCollator:
         # an observation (candidate views first, then the views that face no candidate; image and location features,
         # types, length, candidate ids) is kept in device tables, one slot per key: a step uploads only the blocks it has
         # not seen and gathers the batch on the device.  pano_cache=False restores the per-step assembly.
+        # The tables are BOUNDED: at most `pano_cache_slots` blocks (default 4096: ~0.6 GB at 48 views x 768 fp32), least
+        # recently used blocks are overwritten beyond that -- a full R2R sweep touches tens of thousands of distinct
+        # (viewpoint, view index) states and an unbounded table would grow into several GB.  clear_panorama_cache() drops them.
         self.pano_cache = True
+        self.pano_cache_slots = 4096
         self._pano = None
 
     def reset(self, batch_size):
         self.pool = None
         self.cnt = np.zeros((batch_size, self.node_slots), dtype=np.int32)
+
+    def clear_panorama_cache(self):
+        """Drop the device tables of collated panorama blocks (e.g. between splits); they are rebuilt on demand."""
+        self._pano = None
 
     @staticmethod
     def _bucket(n, buckets):
@@ -163,20 +171,24 @@ class NavCollator:
         P = self._pano
         if P is None:
             A3 = np.asarray(obs[0]["feature"]).shape[1] - fs + 3
-            P = self._pano = {"slot": {}, "cands": [], "lens": [], "cap": 0, "vmax": 48, "A3": A3, "img": None, "loc": None,
-                              "types": None}
+            P = self._pano = {"slot": {}, "key_of": [], "cands": [], "lens": [], "tick": np.zeros(0, dtype=np.int64), "clock": 0,
+                              "cap": 0, "vmax": 48, "A3": A3, "img": None, "loc": None, "types": None}
         keys = [(ob["scan"], ob["viewpoint"], int(ob["viewIndex"])) for ob in obs]
+        P["clock"] += 1
         miss = {}
         for k, ob in zip(keys, obs):
             if k not in P["slot"] and k not in miss:
                 miss[k] = self._pano_block(ob, fs)
         if miss:
+            limit = max(int(self.pano_cache_slots), 2 * B)             # (a batch must fit beside the blocks it replaces)
             need_v = max(len(b[2]) for b in miss.values())
-            n_new = len(P["slot"]) + len(miss)
-            if n_new > P["cap"] or need_v > P["vmax"]:                 # grow the device tables (doubling)
+            used = len(P["key_of"])
+            n_new = min(used + len(miss), limit)
+            if n_new > P["cap"] or need_v > P["vmax"]:                 # grow the device tables (doubling, up to the limit)
                 cap = max(256, P["cap"])
                 while cap < n_new:
                     cap *= 2
+                cap = min(cap, limit)
                 vmax = P["vmax"]
                 while vmax < need_v:
                     vmax += 16
@@ -186,22 +198,42 @@ class NavCollator:
                 for name, t in new.items():
                     if P[name] is not None:
                         t[:P["cap"], :P["vmax"]] = P[name]
-                    P[name] = t
-                P["cap"], P["vmax"] = cap, vmax
+                    P[name] = t                                         # (the old table is released here)
+                tick = np.zeros(cap, dtype=np.int64)
+                tick[:len(P["tick"])] = P["tick"]
+                P["cap"], P["vmax"], P["tick"] = cap, vmax, tick
+            # slots of the new blocks: fresh ones while the table has room, then the least recently used blocks that this
+            # batch does not read (their keys leave the index)
             m, vmax = len(miss), P["vmax"]
+            fresh = list(range(used, min(used + m, P["cap"])))
+            if len(fresh) < m:
+                busy = {P["slot"][k] for k in keys if k in P["slot"]}
+                order = np.argsort(P["tick"][:used], kind="stable")
+                victims = [int(sl) for sl in order if int(sl) not in busy][:m - len(fresh)]
+                for sl in victims:
+                    del P["slot"][P["key_of"][sl]]
+                fresh += victims
             img = np.zeros((m, vmax, fs), dtype=np.float32)
             loc = np.zeros((m, vmax, P["A3"]), dtype=np.float32)
             types = np.zeros((m, vmax), dtype=np.int64)
-            first = len(P["slot"])
             for j, (k, (bi, bl, bt, cands)) in enumerate(miss.items()):
-                n = len(bt)
+                n, sl = len(bt), fresh[j]
                 img[j, :n], loc[j, :n], types[j, :n] = bi, bl, bt
-                P["slot"][k] = first + j
-                P["cands"].append(cands)
-                P["lens"].append(n)
+                P["slot"][k] = sl
+                if sl == len(P["key_of"]):
+                    P["key_of"].append(k); P["cands"].append(cands); P["lens"].append(n)
+                else:
+                    P["key_of"][sl], P["cands"][sl], P["lens"][sl] = k, cands, n
+            contiguous = fresh == list(range(fresh[0], fresh[0] + m))
+            ix = None if contiguous else torch.from_numpy(np.asarray(fresh, dtype=np.int64)).to(self.device)
             for name, a in (("img", img), ("loc", loc), ("types", types)):
-                P[name][first:first + m].copy_(torch.from_numpy(a))     # (first sight of a viewpoint: a blocking upload)
+                src = torch.from_numpy(a).to(self.device)              # (first sight of a viewpoint: a blocking upload)
+                if contiguous:
+                    P[name][fresh[0]:fresh[0] + m].copy_(src)
+                else:
+                    P[name].index_copy_(0, ix, src)
         slots = np.fromiter((P["slot"][k] for k in keys), dtype=np.int64, count=B)
+        P["tick"][slots] = P["clock"]
         lens = np.fromiter((P["lens"][sl] for sl in slots), dtype=np.int64, count=B)
         self._view_lens = lens
         V = self._bucket(int(lens.max()), self.view_buckets)

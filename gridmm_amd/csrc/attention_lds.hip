@@ -386,14 +386,16 @@ extern "C" int gridmm_debug_att_prof(unsigned long long* out, int reset) {
 }
 #endif
 
-// Tuning hook (tools/sweep_gemm_cfg_step.py): force the launch configuration of the calls with more than / at most four
-// query tiles inside a running process (0 = the heuristic).  Process-global; not used by the product path.
+#ifdef GRIDMM_DEBUG_HOOKS
+// Tuning hook of the development build (tools/sweep_gemm_cfg_step.py): force the launch configuration of the calls with more
+// than / at most four query tiles inside a running process (0 = the heuristic).  Not in the shipping library.
 static int g_att_cfg_big = 0, g_att_cfg_small = 0;
 extern "C" int gridmm_debug_attention_cfg_override(int cfg_big, int cfg_small) {
   g_att_cfg_big = cfg_big;
   g_att_cfg_small = cfg_small;
   return GRIDMM_OK;
 }
+#endif
 
 // cfg: 0 = auto; 1..: tuning configurations (tools/bench_attn2.py)
 static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
@@ -413,9 +415,10 @@ static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs,
   // (1, 7, 32) for 5 .. 14 query tiles: the 216-query calls are exactly 2 x 7 tiles -- no idle math wave, as (1, 8, 32)
   // leaves in its second workgroup (in-step sweep: -19 us per step over the three calls)
   if (cfg == 0) cfg = nqt <= 4 ? 5 : (nqt <= 14 ? 24 : 9);
-  if (0) cfg = nqt <= 4 ? 5 : 9;   // tools/bench_attn2.py: 57-query calls 7-17 us with (1, 4, 32); 216-query calls 25-38 us with (1, 8, 32)
-  if (nqt > 4 && g_att_cfg_big) cfg = g_att_cfg_big;        // tuning hook (gridmm_debug_attention_cfg_override)
+#ifdef GRIDMM_DEBUG_HOOKS
+  if (nqt > 4 && g_att_cfg_big) cfg = g_att_cfg_big;
   if (nqt <= 4 && g_att_cfg_small) cfg = g_att_cfg_small;
+#endif
 #define GRIDMM_ATT_ARGS                                                                                             \
   (const unsigned short*)Q_hi, (const unsigned short*)Q_lo, q_bs, q_rs, (const unsigned short*)K_hi,               \
       (const unsigned short*)K_lo, k_bs, k_rs, (const unsigned short*)V_hi, (const unsigned short*)V_lo, v_bs, v_rs, \

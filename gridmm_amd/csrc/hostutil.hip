@@ -160,14 +160,14 @@ extern "C" int gridmm_collate_nav_fill(const double* pos, const double* dist, co
     const int64_t* o = order + (size_t)b * cap;
     const uint8_t* se = seen_eff + (size_t)b * cap;
     const int mb = (int)m[b], c = (int)cur[b], ncb = (int)nc[b];
-    if (mb + 1 > G || ncb > Cw || ncb + 1 > V1 || start[b] < 0 || start[b] >= cap) return GRIDMM_EINVAL;
+    if (mb + 1 > G || ncb > Cw || ncb + 1 > V1 || start[b] < 0 || start[b] >= cap || c < 0 || c >= cap) return GRIDMM_EINVAL;
     float* gp = gpos + (size_t)b * G * F;
     float* vp = vpos + (size_t)b * V1 * 2 * F;
     float* pr = pair + (size_t)b * G * G;
     for (size_t i = 0; i < (size_t)G * F; ++i) gp[i] = 0.f;
     for (size_t i = 0; i < (size_t)V1 * 2 * F; ++i) vp[i] = 0.f;
     for (size_t i = 0; i < (size_t)G * G; ++i) pr[i] = 0.f;
-    gp[1] = 1.f; gp[3] = 1.f;                                            // the stop token: sin 0, cos 0, sin 0, cos 0
+    for (int r = 0; r < afs / 4; ++r) { gp[4 * r + 1] = 1.f; gp[4 * r + 3] = 1.f; }   // the stop token: (sin 0, cos 0, sin 0, cos 0) in every repeat of the quad (get_angle_fts)
     auto feat = [&](int t) {
       double graph = 0.0, hops = 0.0;
       if (t != c) {

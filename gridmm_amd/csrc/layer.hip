@@ -4,9 +4,7 @@
 // sequences the library's kernels (6 plane GEMMs, 2 attention_rows, 3 LayerNorms) on the caller's stream through a
 // caller-provided workspace, so a C / C++ host (or the Python module, which uses it for its inference path) drives a
 // whole layer without touching intermediate tensors.  Results are bit-identical to issuing the eleven calls one by one
-// when sync_words is NULL; with sync_words the three dense + residual + LayerNorm blocks run as ONE launch each
-// (gridmm_linear_planes_ln: eight launches per layer) whenever the shape allows it, with LayerNorm statistics merged
-// from per-tile partials (differences of a few ulp).
+// (pinned by tests/test_hip_kernels.py).
 #include <cstdlib>
 
 #include "common.h"
@@ -19,8 +17,8 @@ inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int lin(const gridmm_linear_t& W, const void* A_hi, const void* A_lo, int lda, const float* R, int ldr, float* C, int ldc,
                void* C_hi, void* C_lo, int ldp, int M, int act, gridmm_stream_t stream) {
   if (W.wt_hi && W.wt_lo) {
-    const int rc = gridmm_linear_planes(A_hi, A_lo, lda, W.wt_hi, W.wt_lo, -W.Kp, W.bias, R, ldr, C, ldc, C_hi, C_lo, ldp, M, W.N,
-                                        W.K, act, stream);
+    const int rc = gridmm_linear_planes_map(A_hi, A_lo, lda, 0, 0, W.wt_hi, W.wt_lo, W.Kp, GRIDMM_W_TILED, W.bias, R, ldr, C, ldc,
+                                            C_hi, C_lo, ldp, M, W.N, W.K, act, stream);
     if (rc != GRIDMM_EUNSUPPORTED) return rc;
   }
   return gridmm_linear_planes(A_hi, A_lo, lda, W.w_hi, W.w_lo, W.Kp, W.bias, R, ldr, C, ldc, C_hi, C_lo, ldp, M, W.N, W.K, act,
@@ -32,8 +30,7 @@ extern "C" size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I) {
   const size_t M = (size_t)B * Sq;
   // planes: q (H), attention context (H), x-attn out (H), qkv (3H), self context (H), self out (H), ffn (I): hi + lo
   // fp32 : pre-LN sums (H) x1 (reused), post-LN a (H), post-LN b (H)
-  return a256(M * H * 4) * 6 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) + a256(M * H * 4) * 3 +
-         a256(gridmm_linear_planes_ln_workspace((int)M, H)) + 2 * a256(12 * M * 8) + 4096;
+  return a256(M * H * 4) * 6 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) + a256(M * H * 4) * 3 + 4096;
 }
 
 extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
@@ -41,7 +38,7 @@ extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, 
                                       int Sk1, const void* KV2_hi, const void* KV2_lo, int64_t kv2_bs, int kv2_rs,
                                       int k2_col, int v2_col, const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask, int self_mask_bs,
                                       float* Y, void* Y_hi, void* Y_lo, int y_p_rpb, int64_t y_p_bs, void* workspace,
-                                      size_t workspace_bytes, void* sync_words, int B, int Sq, int Sk, int heads,
+                                      size_t workspace_bytes, int B, int Sq, int Sk, int heads,
                                       gridmm_stream_t stream) {
   if (!L || !X || !X_hi || !X_lo || !KV_hi || !KV_lo || !workspace || B <= 0 || Sq <= 0 || Sk <= 0 || heads <= 0)
     return GRIDMM_EINVAL;
@@ -65,9 +62,6 @@ extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, 
   float* h = (float*)take((size_t)M * H * 4);
   float* a = (float*)take((size_t)M * H * 4);
   float* bb = (float*)take((size_t)M * H * 4);
-  void* ln_ws = take(gridmm_linear_planes_ln_workspace(M, H));
-  void* st1 = take((size_t)12 * M * 8);                      // per-tile row statistics of the two deferred LayerNorms
-  void* st2 = take((size_t)12 * M * 8);
   const float scale = 0.125f;                                // 1 / sqrt(64)
   int rc;
 #define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
@@ -80,63 +74,12 @@ extern "C" int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, 
                                        k2h ? k2l + k2_col : nullptr, k2h ? k2h + v2_col : nullptr, k2h ? k2l + v2_col : nullptr,
                                        kv2_bs, kv2_rs, ctx_mask, ctx_mask_bs, nullptr, 0, 0, c_hi, c_lo, (int64_t)Sq * H, H, B,
                                        heads, Sq, Sk, scale, stream));
-  // ---- deferred form of the two inner LayerNorms (9 launches): the dense blocks leave their pre-LayerNorm sums with
-  // per-tile row statistics, the consumers (QKV / FFN-in GEMMs with gamma folded into the weight, the next block's residual
-  // add) normalise on the fly.  Taken when the folded weights are there and every GEMM's tile choice has the form.
-  // Measured (profiles/r4_layernorm_fusion_experiments.txt): the B = 32 step runs 2.33-2.35 ms this way against 2.23-2.25 ms
-  // with the LayerNorm launches -- the statistics passes and barriers in five GEMM epilogues per layer cost more than the two
-  // ~6 us launches they remove -- so callers pass the folded weights only on request (Python: GRIDMM_LN_DEFER=1 /
-  // model.defer_layernorm; kept correct by tests/test_hip_linear_lnx.py and test_hip_kernels.py).
-  const int defer_on = 1;
-  int bn_h = 0;
-  const int tn_h = gridmm_linear_planes_lnx_tiles(M, H, H, &bn_h);
-  if (defer_on && L->sqkv_f.w_hi && L->ffn_i_f.w_hi && L->sqkv_sv && L->ffn_i_sv && tn_h > 0 && tn_h <= 12 && bn_h > 0 &&
-      gridmm_linear_planes_lnx_tiles(M, 3 * H, H, nullptr) > 0 && gridmm_linear_planes_lnx_tiles(M, I, H, nullptr) > 0 &&
-      gridmm_linear_planes_lnx_tiles(M, H, I, nullptr) > 0) {
-    gridmm_lnx_t x{};
-    x.ln_n = H;
-    // xo: h1 = dense(attn) + X  -> a (fp32), a planes, statistics st1   (q projection + cross attention: issued above)
-    x.out_stats = st1;
-    GRIDMM_TRY(gridmm_linear_planes_lnx(c_hi, c_lo, H, L->xo.w_hi, L->xo.w_lo, L->xo.Kp, L->xo.bias, X, H, a, H, a_hi, a_lo, H, M, H,
-                                        H, GRIDMM_ACT_NONE, &x, stream));
-    // sqkv over LN_x(h1): folded weight, corrected in the epilogue
-    x = gridmm_lnx_t{};
-    x.ln_n = H; x.a_stats = st1; x.a_tn = tn_h; x.a_bn = bn_h; x.sv = L->sqkv_sv; x.a_eps = L->x_ln.eps;
-    GRIDMM_TRY(gridmm_linear_planes_lnx(a_hi, a_lo, H, L->sqkv_f.w_hi, L->sqkv_f.w_lo, L->sqkv_f.Kp, L->sqkv_f.bias, nullptr, 0,
-                                        nullptr, 0, qkv_hi, qkv_lo, 3 * H, M, 3 * H, H, GRIDMM_ACT_NONE, &x, stream));
-    GRIDMM_TRY(gridmm_attention_rows(qkv_hi, qkv_lo, (int64_t)Sq * 3 * H, 3 * H, qkv_hi + H, qkv_lo + H, (int64_t)Sq * 3 * H,
-                                     3 * H, qkv_hi + 2 * H, qkv_lo + 2 * H, (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs,
-                                     nullptr, 0, 0, s_hi, s_lo, (int64_t)Sq * H, H, B, heads, Sq, Sq, scale, stream));
-    // so: h2 = dense(attn) + LN_x(h1)  -> bb (fp32), b planes, statistics st2
-    x = gridmm_lnx_t{};
-    x.ln_n = H; x.r_stats = st1; x.r_tn = tn_h; x.r_bn = bn_h; x.r_gamma = L->x_ln.gamma; x.r_beta = L->x_ln.beta;
-    x.r_eps = L->x_ln.eps; x.out_stats = st2;
-    GRIDMM_TRY(gridmm_linear_planes_lnx(s_hi, s_lo, H, L->so.w_hi, L->so.w_lo, L->so.Kp, L->so.bias, a, H, bb, H, b_hi, b_lo, H, M, H,
-                                        H, GRIDMM_ACT_NONE, &x, stream));
-    // ffn_i over LN_s(h2), GELU
-    x = gridmm_lnx_t{};
-    x.ln_n = H; x.a_stats = st2; x.a_tn = tn_h; x.a_bn = bn_h; x.sv = L->ffn_i_sv; x.a_eps = L->s_ln.eps;
-    GRIDMM_TRY(gridmm_linear_planes_lnx(b_hi, b_lo, H, L->ffn_i_f.w_hi, L->ffn_i_f.w_lo, L->ffn_i_f.Kp, L->ffn_i_f.bias, nullptr, 0,
-                                        nullptr, 0, f_hi, f_lo, I, M, I, H, GRIDMM_ACT_GELU, &x, stream));
-    // ffn_o: h3 = dense(f) + LN_s(h2)  -> h; then the layer's output LayerNorm (a real launch: its consumers are outside)
-    x = gridmm_lnx_t{};
-    x.ln_n = H; x.r_stats = st2; x.r_tn = tn_h; x.r_bn = bn_h; x.r_gamma = L->s_ln.gamma; x.r_beta = L->s_ln.beta;
-    x.r_eps = L->s_ln.eps;
-    GRIDMM_TRY(gridmm_linear_planes_lnx(f_hi, f_lo, I, L->ffn_o.w_hi, L->ffn_o.w_lo, L->ffn_o.Kp, L->ffn_o.bias, bb, H, h, H, nullptr,
-                                        nullptr, 0, M, H, I, GRIDMM_ACT_NONE, &x, stream));
-    GRIDMM_TRY(gridmm_layernorm_map(h, H, nullptr, 0, L->f_ln.gamma, L->f_ln.beta, L->f_ln.eps, Y, H, nullptr, 0, nullptr, nullptr,
-                                    Y_hi, Y_lo, H, y_p_rpb, y_p_bs, M, H, stream));
-    return GRIDMM_OK;
-  }
-  // dense + residual + LayerNorm: one launch when the fused form takes the shape, else GEMM then LayerNorm
+  // dense + residual + LayerNorm: GEMM (pre-LayerNorm sums in h), then the LayerNorm launch.  (Two fused forms -- a
+  // rendezvous of the row block's column tiles inside the GEMM, and a LayerNorm deferred into its consumers -- were built in
+  // round 4, measured slower than the two launches and removed in round 5: profiles/r4_layernorm_fusion_experiments.txt.)
   auto dense_ln = [&](const gridmm_linear_t& W, const gridmm_ln_t& ln, const void* in_hi, const void* in_lo, int K,
                       const float* res, float* out, void* out_hi, void* out_lo, int p_rpb, int64_t p_bs) -> int {
-    int r = GRIDMM_EUNSUPPORTED;
-    if (sync_words)
-      r = gridmm_linear_planes_ln(in_hi, in_lo, K, W.w_hi, W.w_lo, W.Kp, W.bias, res, H, nullptr, 0, ln.gamma, ln.beta, ln.eps,
-                                  out, H, out_hi, out_lo, H, p_rpb, p_bs, ln_ws, sync_words, M, H, K, 0, stream);
-    if (r != GRIDMM_EUNSUPPORTED) return r;
-    r = lin(W, in_hi, in_lo, K, res, H, h, H, nullptr, nullptr, 0, M, GRIDMM_ACT_NONE, stream);
+    const int r = lin(W, in_hi, in_lo, K, res, H, h, H, nullptr, nullptr, 0, M, GRIDMM_ACT_NONE, stream);
     if (r != GRIDMM_OK) return r;
     return gridmm_layernorm_map(h, H, nullptr, 0, ln.gamma, ln.beta, ln.eps, out, H, nullptr, 0, nullptr, nullptr, out_hi,
                                 out_lo, H, p_rpb, p_bs, M, H, stream);

@@ -30,102 +30,6 @@ __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Fused residual + LayerNorm epilogue (LN = 1): the output rows are complete only across the tn column tiles of a row
-// block, so the workgroups of a row block RENDEZVOUS: each publishes its per-row tile statistics (mean and sum of squared
-// deviations over its BN columns, two passes over the register-resident values), bumps the row block's arrival counter
-// and waits for it to reach tn, then merges the tn partials (Chan) and normalises the values it still holds in
-// registers.  The pre-LayerNorm sums never travel through memory and the LayerNorm launch disappears.  Deadlock-free
-// only when the WHOLE grid is resident at once (the host checks the grid against the occupancy of the kernel) and no
-// other rendezvous kernel runs on the device at the same time (single-stream use; GRIDMM_LN_FUSE=0 turns the path off).
-// The counters are self-resetting: the last workgroup to leave a row block zeroes its pair.
-// EXPERIMENTAL (off by default, GRIDMM_LN_FUSE=1): slower than GEMM + LayerNorm as two launches
-// (profiles/r4_layernorm_fusion_experiments.txt), and its cross-XCD hand-over rests on relaxed device-coherent stores being
-// visible to a peer that polls AFTERWARDS -- true in every run of tests/test_hip_linear_ln.py, but a last-arriver variant of
-// the same hand-over (no polling delay) read stale partials: a release fence would be needed for a guarantee, and a fence here
-// costs 0.7 ms per step.
-struct LnArgs {
-  const float* gamma; const float* beta; float eps;
-  float* Y; int ldy;              // post-LayerNorm fp32 out (optional)
-  float2* stats;                  // [tn][M] (tile mean, tile M2)
-  unsigned* ctr;                  // [tm][2] arrive / depart, zero between calls
-  int p_rpb; long p_bs;           // batched row map of the plane outputs (gridmm_layernorm_map)
-  int* err;                       // optional: set to 1 when a rendezvous ran into its poll bound
-  // ---- DEFERRED LayerNorm (LN == 2; no rendezvous, nothing waits): a producer GEMM leaves its result h un-normalised
-  // (fp32 + planes) together with per-(row, column tile) statistics; the LayerNorm is applied by whoever reads h:
-  //   as the A operand:  LN(h) W^T + b = rstd (h W'^T - mu sv) + cv,  W' = W * gamma (folded into the weight planes),
-  //                      sv[n] = sum_k W'[n][k],  cv = W beta + b (passed as the bias)
-  //   as the residual :  r = (h - mu) rstd gamma + beta on the fly
-  const float2* a_stats; int a_tn, a_bn; const float* sv; float a_eps;     // statistics of the A operand's rows (or NULL)
-  const float2* r_stats; int r_tn, r_bn; const float* r_gamma; const float* r_beta; float r_eps;   // ... of the residual's
-  float2* out_stats;              // tile statistics of THIS launch's result rows (or NULL)
-  int ln_n;                       // width of the normalised rows (the hidden size)
-};
-
-// The tn (<= LN_MAX_TN) per-tile (mean, M2) partials of row m, ALL loads in flight at once (a loop of dependent round trips
-// here cost the step 0.15 ms), and their merge into (mean, rstd) (equal widths bn: Chan)
-constexpr int LN_MAX_TN = 12;
-template <int MAXT>
-__device__ __forceinline__ void ln_load_partials(float2 (&p)[MAXT], const float2* st, int tn, int M, int m) {
-#pragma unroll
-  for (int t = 0; t < MAXT; ++t) p[t] = t < tn ? st[(size_t)t * M + m] : make_float2(0.f, 0.f);
-}
-template <int MAXT>
-__device__ __forceinline__ float2 ln_merge_partials(const float2 (&p)[MAXT], int tn, int bn, int n, float eps) {
-  float mu = 0.f;
-#pragma unroll
-  for (int t = 0; t < MAXT; ++t) mu += p[t].x;                      // (absent tiles hold 0)
-  mu /= (float)tn;
-  float m2 = 0.f;
-#pragma unroll
-  for (int t = 0; t < MAXT; ++t) {
-    const float d = p[t].x - mu;
-    m2 += t < tn ? p[t].y + (float)bn * d * d : 0.f;
-  }
-  return make_float2(mu, rsqrtf(m2 / (float)n + eps));
-}
-
-// Statistics and counters travel as agent-scope RELAXED atomics (sc1 accesses: coherent across the XCDs' L2s) ordered by
-// explicit waits -- never by fences: a release / acquire fence here is a write-back / invalidate of the XCD's WHOLE L2,
-// issued while the other workgroups of the launch are still streaming their operands through it (measured: +50 us per
-// launch).
-__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_stat(float2* p, float mean, float m2) {
-  const unsigned long long bits = (unsigned long long)__float_as_uint(mean) | ((unsigned long long)__float_as_uint(m2) << 32);
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld_stat(const float2* p) {
-  const unsigned long long bits =
-      __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return make_float2(__uint_as_float((unsigned)bits), __uint_as_float((unsigned)(bits >> 32)));
-}
-
-// Called by every thread of the workgroup (uniformly) after the tile statistics were stored (st_stat) and the storing
-// threads waited for their stores (s_waitcnt vmcnt(0)).
-__device__ __forceinline__ void ln_rendezvous(unsigned* ctr, int tn, int* err) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                    // every storing thread's statistics have been acknowledged
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned polls = 0;
-    while (ld_agent(ctr) < (unsigned)tn) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++polls > (1u << 21)) { if (err) *err = 1; break; }   // (a missing peer must not hang the device)
-    }
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ void ln_depart(unsigned* ctr, int tn) {
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == (unsigned)tn - 1u) {                   // everyone has read the statistics: the pair is zero again
-      __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // BM x BN block tile, WM x WN per wave (16x16x32 MFMA tiles), NS-stage LDS ring filled by LDS-DMA.
 // One raw s_barrier per k-step; the DMA of stage kt+NS-1 is issued right after the barrier that retires
 // stage kt-1, and only a COUNTED s_waitcnt vmcnt keeps the younger stages in flight across barriers.
@@ -143,15 +47,13 @@ __device__ __forceinline__ void ln_depart(unsigned* ctr, int tn) {
 // WT = 1: the W planes arrive TILED as [N / RPP][Kp / BK][RPP rows][BK k] blocks (used with BK = 32: 16 x 32) -- every 1-KiB DMA
 // piece is one contiguous KiB of memory instead of 16 HALF cache lines a row pitch apart (tools/l2_to_lds_bw.hip: contiguous
 // pieces stream at 17.8-23.7 TB/s out of the Infinity Cache, strided rows at 12.5).
-// AT = 1: the same for the A planes ([M / RPP][lda / BK][RPP][BK] blocks; no row map).
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int LN = 0, int WT = 0,
-          int AT = 0>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int WT = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
     const float* __restrict__ bias, const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc,
     unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo, int ldp, int M, int N, int K,
-    int a_rpb, long a_bs, LnArgs la) {
+    int a_rpb, long a_bs) {
   constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int STAGE = (2 * BM + 2 * BN) * BK;          // u16 elements per stage: Ahi|Alo|Whi|Wlo
@@ -160,16 +62,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   constexpr int PIECES = (2 * BM + 2 * BN) / RPP;        // 1-KiB DMA pieces per stage
   static_assert(PIECES % NW == 0, "tile must split evenly over the waves");
   constexpr int PPW = PIECES / NW;
-  constexpr int ER = (NW > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : 64);   // rows per epilogue pass (LDS budget)
+  constexpr int ER = (NW > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : (WM % 64 ? 32 : 64));   // rows per epilogue pass (LDS budget)
   constexpr int EPI = ER * WN;                           // floats per wave in the epilogue transpose
   constexpr int LDS_U16 = (TR || NS * STAGE * 2 > NW * EPI * 4) ? NS * STAGE : NW * EPI * 2;
-  constexpr int LN_F32 = LN ? BM * WAVES_N + 4 * BM : 0;   // row partials per wave column + 2 x (mean, rstd) per row
-  __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_U16 + 2 * LN_F32];
-  [[maybe_unused]] float* s_part = reinterpret_cast<float*>(smem + LDS_U16);   // [BM][WAVES_N]
-  [[maybe_unused]] float* s_mr = s_part + BM * WAVES_N;                        // [BM][2]
-  static_assert(!LN || ((ACT == 0 || LN == 2) && !PP && NW * 64 >= BM), "fused LayerNorm: plain epilogue, one thread per tile row");
-  static_assert(LN != 2 || !TR, "deferred LayerNorm: LDS epilogue only");
-  static_assert(!(WT || AT) || (!PP && !TR), "tiled planes: the plain main loop");
+  __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_U16];
+  static_assert(!WT || (!PP && !TR), "tiled planes: the plain main loop");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,10 +116,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       // stride a_bs -- a sequence that lives inside a longer one ([map | txt] contexts) is read in place
       size_t aoff = (size_t)m * lda;
       if (a_rpb > 0) { const int eb = m / a_rpb; aoff = (size_t)eb * a_bs + (size_t)(m - eb * a_rpb) * lda; }
-      if constexpr (AT) {
-        aoff = (size_t)(m / RPP) * (lda / BK) * 512 + (m % RPP) * BK;
-        kstep[i] = 512;
-      }
       src[i] = (plane == 0 ? Ahi : Alo) + aoff + chunk * 8;
       dst[i] = plane * BM * BK + r0 * BK;
     } else {
@@ -235,15 +128,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       }
       dst[i] = 2 * BM * BK + (plane - 2) * BN * BK + r0 * BK;
     }
-  }
-
-  // deferred LayerNorm: the statistics this launch READS (of its A operand's rows or of its residual's rows) are fetched
-  // now, under the main loop, by the one thread per tile row that will merge them (tiles with registers to spare)
-  constexpr bool LN_PREFETCH = LN == 2 && BM * BN <= 128 * 128;
-  [[maybe_unused]] float2 ln_p[LN_PREFETCH ? LN_MAX_TN : 1];
-  if constexpr (LN_PREFETCH) {
-    const float2* st = la.a_stats ? la.a_stats : la.r_stats;
-    if (st && tid < BM && bm + tid < M) ln_load_partials(ln_p, st, la.a_stats ? la.a_tn : la.r_tn, M, bm + tid);
   }
 
   f32x4_t acc[TM][TN];
@@ -267,7 +151,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) {
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + s * ((WT || AT) ? kstep[i] : BK), smem + s * STAGE + dst[i]);
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + s * (WT ? kstep[i] : BK), smem + s * STAGE + dst[i]);
     }
 
   const int frow = lane & 15, fchunk = lane >> 4;
@@ -365,7 +249,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     if (ABLATE != 2 && kt + NS - 1 < nk) {
       unsigned short* nxt = smem + ((kt + NS - 1) % NS) * STAGE;
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * ((WT || AT) ? kstep[i] : BK), nxt + dst[i]);
+      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * (WT ? kstep[i] : BK), nxt + dst[i]);
     }
     const unsigned short* cur = smem + (kt % NS) * STAGE;
 #pragma unroll
@@ -407,111 +291,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
           }
         }
     }
-  }
-  if constexpr (TR && LN == 1) {
-    // ---- fused residual + LayerNorm from the C^T accumulators: lane (m = lane & 15, g = lane >> 4) holds
-    // x[i][j][0..3] = row wr*WM + 16 i + m, columns wc*WN + 16 j + 4 g .. + 3 of the tile
-    const int mrow = lane & 15, g4 = (lane >> 4) * 4;
-    const int tn = (N + BN - 1) / BN;
-    float xv[TM][TN][4];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n0 = bn + wc * WN + j * 16 + g4;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) bv = *reinterpret_cast<const float4*>(bias + n0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = bm + wr * WM + i * 16 + mrow;
-        xv[i][j][0] = acc[i][j][0] + bv.x; xv[i][j][1] = acc[i][j][1] + bv.y;
-        xv[i][j][2] = acc[i][j][2] + bv.z; xv[i][j][3] = acc[i][j][3] + bv.w;
-        if (R && m < M) {
-          const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
-          xv[i][j][0] += r4.x; xv[i][j][1] += r4.y; xv[i][j][2] += r4.z; xv[i][j][3] += r4.w;
-        }
-        if (C && m < M)
-          *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(xv[i][j][0], xv[i][j][1], xv[i][j][2], xv[i][j][3]);
-      }
-    }
-    // pass 1: tile mean of every row (lanes of one row: 4 g groups x WAVES_N waves)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float sm = 0.f;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) sm += (xv[i][j][0] + xv[i][j][1]) + (xv[i][j][2] + xv[i][j][3]);
-      sm += __shfl_xor(sm, 16, 64);
-      sm += __shfl_xor(sm, 32, 64);
-      if (lane < 16) s_part[(wr * WM + i * 16 + mrow) * WAVES_N + wc] = sm;
-    }
-    __syncthreads();
-    float tmean[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float sm = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES_N; ++w) sm += s_part[(wr * WM + i * 16 + mrow) * WAVES_N + w];
-      tmean[i] = sm * (1.0f / (float)BN);
-    }
-    __syncthreads();
-    // pass 2: sum of squared deviations from the tile mean
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float q = 0.f;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = xv[i][j][e] - tmean[i]; q += d * d; }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
-      if (lane < 16) s_part[(wr * WM + i * 16 + mrow) * WAVES_N + wc] = q;
-      if (lane < 16 && wc == 0) s_mr[(wr * WM + i * 16 + mrow) * 2] = tmean[i];
-    }
-    __syncthreads();
-    if (tid < BM) {
-      float q = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES_N; ++w) q += s_part[tid * WAVES_N + w];
-      if (bm + tid < M) st_stat(la.stats + (size_t)tx * M + bm + tid, s_mr[tid * 2], q);
-    }
-    ln_rendezvous(la.ctr + 2 * ty, tn, la.err);
-    if (tid < BM && bm + tid < M) {       // merge the tn tile statistics of row bm + tid (equal counts: Chan)
-      float mu = 0.f;
-      for (int t = 0; t < tn; ++t) mu += ld_stat(la.stats + (size_t)t * M + bm + tid).x;
-      mu /= (float)tn;
-      float m2 = 0.f;
-      for (int t = 0; t < tn; ++t) {
-        const float2 st = ld_stat(la.stats + (size_t)t * M + bm + tid);
-        const float d = st.x - mu;
-        m2 += st.y + (float)BN * d * d;
-      }
-      s_mr[tid * 2] = mu;
-      s_mr[tid * 2 + 1] = rsqrtf(m2 / (float)N + la.eps);
-    }
-    __syncthreads();
-    ln_depart(la.ctr + 2 * ty, tn);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n0 = bn + wc * WN + j * 16 + g4;
-      const float4 gm = *reinterpret_cast<const float4*>(la.gamma + n0), bt = *reinterpret_cast<const float4*>(la.beta + n0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int lr = wr * WM + i * 16 + mrow, m = bm + lr;
-        if (m >= M) continue;
-        const float mu = s_mr[lr * 2], rs = s_mr[lr * 2 + 1];
-        const float y0 = (xv[i][j][0] - mu) * rs * gm.x + bt.x, y1 = (xv[i][j][1] - mu) * rs * gm.y + bt.y;
-        const float y2 = (xv[i][j][2] - mu) * rs * gm.z + bt.z, y3 = (xv[i][j][3] - mu) * rs * gm.w + bt.w;
-        if (la.Y) *reinterpret_cast<float4*>(la.Y + (size_t)m * la.ldy + n0) = make_float4(y0, y1, y2, y3);
-        if (Chi) {
-          size_t poff = (size_t)m * ldp;
-          if (la.p_rpb > 0) { const int eb = m / la.p_rpb; poff = (size_t)eb * la.p_bs + (size_t)(m - eb * la.p_rpb) * ldp; }
-          uint2 hi, lo;
-          split2_bf16(y0, y1, hi.x, lo.x);
-          split2_bf16(y2, y3, hi.y, lo.y);
-          *reinterpret_cast<uint2*>(Chi + poff + n0) = hi;
-          *reinterpret_cast<uint2*>(Clo + poff + n0) = lo;
-        }
-      }
-    }
-    return;
   }
   if constexpr (TR) {
     // ---- epilogue straight from the accumulators (no LDS pass, no barrier): with the operands swapped the tile is
@@ -566,234 +345,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   const int n0 = bn + wc * WN + c4 * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias && n0 < N) bv = *reinterpret_cast<const float4*>(bias + n0);  // N % 4 == 0
-  if constexpr (LN == 2) {
-    // ---- deferred LayerNorm (see LnArgs): statistics IN (of the A operand's rows and / or the residual's rows), bias /
-    // activation / residual, statistics OUT (of the result's rows); nothing here waits for another workgroup
-    constexpr int NIT = ER / ROWS_PER_IT;
-    float* s_mr2 = s_mr + 2 * BM;
-    if (la.a_stats || la.r_stats) {
-      if (tid < BM && bm + tid < M) {
-        if constexpr (LN_PREFETCH) {
-          // (one kind of statistics per launch on this path: a consumer GEMM reads its A operand's, a residual form its residual's)
-          const float2 v = la.a_stats ? ln_merge_partials(ln_p, la.a_tn, la.a_bn, la.ln_n, la.a_eps)
-                                      : ln_merge_partials(ln_p, la.r_tn, la.r_bn, la.ln_n, la.r_eps);
-          float* dstp = la.a_stats ? s_mr : s_mr2;
-          dstp[tid * 2] = v.x; dstp[tid * 2 + 1] = v.y;
-        } else {
-          // big tiles (no registers to spare under the main loop): statistics of 128-wide producer tiles, at most 6 per row
-          float2 pp[6];
-          if (la.a_stats) {
-            ln_load_partials(pp, la.a_stats, la.a_tn, M, bm + tid);
-            const float2 v = ln_merge_partials(pp, la.a_tn, la.a_bn, la.ln_n, la.a_eps);
-            s_mr[tid * 2] = v.x; s_mr[tid * 2 + 1] = v.y;
-          }
-          if (la.r_stats) {
-            ln_load_partials(pp, la.r_stats, la.r_tn, M, bm + tid);
-            const float2 v = ln_merge_partials(pp, la.r_tn, la.r_bn, la.ln_n, la.r_eps);
-            s_mr2[tid * 2] = v.x; s_mr2[tid * 2 + 1] = v.y;
-          }
-        }
-      }
-      __syncthreads();
-    }
-    float4 sv4 = make_float4(0.f, 0.f, 0.f, 0.f), rg = sv4, rb = sv4;
-    if (la.a_stats && n0 < N) sv4 = *reinterpret_cast<const float4*>(la.sv + n0);
-    if (la.r_stats && n0 < N) { rg = *reinterpret_cast<const float4*>(la.r_gamma + n0); rb = *reinterpret_cast<const float4*>(la.r_beta + n0); }
-    // every lane's row statistics into registers BEFORE the transpose passes touch the LDS again
-    constexpr int NROW = (WM / ER) * NIT;
-    float amu[NROW], ars[NROW], rmu[NROW], rrs[NROW];
-#pragma unroll
-    for (int q = 0; q < NROW; ++q) {
-      const int lr = wr * WM + (q / NIT) * ER + (q % NIT) * ROWS_PER_IT + rr;
-      amu[q] = la.a_stats ? s_mr[lr * 2] : 0.f;  ars[q] = la.a_stats ? s_mr[lr * 2 + 1] : 1.f;
-      rmu[q] = la.r_stats ? s_mr2[lr * 2] : 0.f; rrs[q] = la.r_stats ? s_mr2[lr * 2 + 1] : 1.f;
-    }
-    float xv[NIT][4];               // the LAST pass's values (statistics out: single-pass tiles only)
-#pragma unroll
-    for (int h = 0; h < WM / ER; ++h) {
-      if (h) __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < ER / 16; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            ep[(i * 16 + (lane >> 4) * 4 + r) * WN + j * 16 + (lane & 15)] = acc[h * (ER / 16) + i][j][r];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int lr = wr * WM + h * ER + it * ROWS_PER_IT + rr, m = bm + lr;
-        const float4 v = *reinterpret_cast<const float4*>(ep + (it * ROWS_PER_IT + rr) * WN + c4 * 4);
-        float x[4] = {v.x, v.y, v.z, v.w};
-        if (la.a_stats) {
-          const float mu = amu[h * NIT + it], rs = ars[h * NIT + it];
-          x[0] = rs * (x[0] - mu * sv4.x); x[1] = rs * (x[1] - mu * sv4.y); x[2] = rs * (x[2] - mu * sv4.z); x[3] = rs * (x[3] - mu * sv4.w);
-        }
-        x[0] += bv.x; x[1] += bv.y; x[2] += bv.z; x[3] += bv.w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
-          if (ACT == GRIDMM_ACT_RELU) x[e] = fmaxf(x[e], 0.f);
-        }
-        if (R && m < M && n0 < N) {
-          float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
-          if (la.r_stats) {
-            const float mu = rmu[h * NIT + it], rs = rrs[h * NIT + it];
-            r4.x = (r4.x - mu) * rs * rg.x + rb.x; r4.y = (r4.y - mu) * rs * rg.y + rb.y;
-            r4.z = (r4.z - mu) * rs * rg.z + rb.z; r4.w = (r4.w - mu) * rs * rg.w + rb.w;
-          }
-          x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xv[it][e] = x[e];
-        if (m < M && n0 < N) {
-          if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
-          if (Chi) {
-            uint2 hi, lo;
-            split2_bf16(x[0], x[1], hi.x, lo.x);
-            split2_bf16(x[2], x[3], hi.y, lo.y);
-            *reinterpret_cast<uint2*>(Chi + (size_t)m * ldp + n0) = hi;
-            *reinterpret_cast<uint2*>(Clo + (size_t)m * ldp + n0) = lo;
-          }
-        }
-      }
-    }
-    if constexpr (WM == ER)
-    if (la.out_stats) {          // N % BN == 0 (host-checked): every column of the tile is a column of the matrix
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        float sm = (xv[it][0] + xv[it][1]) + (xv[it][2] + xv[it][3]);
-#pragma unroll
-        for (int o = 1; o < F4_PER_ROW; o <<= 1) sm += __shfl_xor(sm, o, 64);
-        if (c4 == 0) s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + wc] = sm;
-      }
-      __syncthreads();
-      float tmean[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        float sm = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES_N; ++w) sm += s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + w];
-        tmean[it] = sm * (1.0f / (float)BN);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = xv[it][e] - tmean[it]; q += d * d; }
-#pragma unroll
-        for (int o = 1; o < F4_PER_ROW; o <<= 1) q += __shfl_xor(q, o, 64);
-        if (c4 == 0) s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + wc] = q;
-        if (c4 == 0 && wc == 0) s_mr[(wr * WM + it * ROWS_PER_IT + rr) * 2] = tmean[it];
-      }
-      __syncthreads();
-      if (tid < BM && bm + tid < M) {
-        float q = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES_N; ++w) q += s_part[tid * WAVES_N + w];
-        la.out_stats[(size_t)tx * M + bm + tid] = make_float2(s_mr[tid * 2], q);
-      }
-    }
-    return;
-  }
-  if constexpr (LN == 1) {
-    // ---- fused residual + LayerNorm (see LnArgs): one LDS transpose pass, then lane (rr, c4) holds columns 4 c4 .. + 3
-    // of rows it * ROWS_PER_IT + rr of its wave's sub-tile
-    static_assert(LN != 1 || WM == ER, "fused LayerNorm: one epilogue pass per wave");
-    constexpr int NIT = ER / ROWS_PER_IT;
-    const int tn = (N + BN - 1) / BN;
-#pragma unroll
-    for (int i = 0; i < ER / 16; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ep[(i * 16 + (lane >> 4) * 4 + r) * WN + j * 16 + (lane & 15)] = acc[i][j][r];
-    __builtin_amdgcn_wave_barrier();
-    float xv[NIT][4];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = it * ROWS_PER_IT + rr, m = bm + wr * WM + row;
-      const float4 v = *reinterpret_cast<const float4*>(ep + row * WN + c4 * 4);
-      xv[it][0] = v.x + bv.x; xv[it][1] = v.y + bv.y; xv[it][2] = v.z + bv.z; xv[it][3] = v.w + bv.w;
-      if (R && m < M) {
-        const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
-        xv[it][0] += r4.x; xv[it][1] += r4.y; xv[it][2] += r4.z; xv[it][3] += r4.w;
-      }
-      if (C && m < M) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(xv[it][0], xv[it][1], xv[it][2], xv[it][3]);
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      float sm = (xv[it][0] + xv[it][1]) + (xv[it][2] + xv[it][3]);
-#pragma unroll
-      for (int o = 1; o < F4_PER_ROW; o <<= 1) sm += __shfl_xor(sm, o, 64);
-      if (c4 == 0) s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + wc] = sm;
-    }
-    __syncthreads();
-    float tmean[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      float sm = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES_N; ++w) sm += s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + w];
-      tmean[it] = sm * (1.0f / (float)BN);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      float q = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = xv[it][e] - tmean[it]; q += d * d; }
-#pragma unroll
-      for (int o = 1; o < F4_PER_ROW; o <<= 1) q += __shfl_xor(q, o, 64);
-      if (c4 == 0) s_part[(wr * WM + it * ROWS_PER_IT + rr) * WAVES_N + wc] = q;
-      if (c4 == 0 && wc == 0) s_mr[(wr * WM + it * ROWS_PER_IT + rr) * 2] = tmean[it];
-    }
-    __syncthreads();
-    if (tid < BM) {
-      float q = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES_N; ++w) q += s_part[tid * WAVES_N + w];
-      if (bm + tid < M) st_stat(la.stats + (size_t)tx * M + bm + tid, s_mr[tid * 2], q);
-    }
-    ln_rendezvous(la.ctr + 2 * ty, tn, la.err);
-    if (tid < BM && bm + tid < M) {
-      float mu = 0.f;
-      for (int t = 0; t < tn; ++t) mu += ld_stat(la.stats + (size_t)t * M + bm + tid).x;
-      mu /= (float)tn;
-      float m2 = 0.f;
-      for (int t = 0; t < tn; ++t) {
-        const float2 st = ld_stat(la.stats + (size_t)t * M + bm + tid);
-        const float d = st.x - mu;
-        m2 += st.y + (float)BN * d * d;
-      }
-      s_mr[tid * 2] = mu;
-      s_mr[tid * 2 + 1] = rsqrtf(m2 / (float)N + la.eps);
-    }
-    __syncthreads();
-    ln_depart(la.ctr + 2 * ty, tn);
-    const float4 gm = *reinterpret_cast<const float4*>(la.gamma + n0), bt = *reinterpret_cast<const float4*>(la.beta + n0);
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int lr = wr * WM + it * ROWS_PER_IT + rr, m = bm + lr;
-      if (m >= M) continue;
-      const float mu = s_mr[lr * 2], rs = s_mr[lr * 2 + 1];
-      const float y0 = (xv[it][0] - mu) * rs * gm.x + bt.x, y1 = (xv[it][1] - mu) * rs * gm.y + bt.y;
-      const float y2 = (xv[it][2] - mu) * rs * gm.z + bt.z, y3 = (xv[it][3] - mu) * rs * gm.w + bt.w;
-      if (la.Y) *reinterpret_cast<float4*>(la.Y + (size_t)m * la.ldy + n0) = make_float4(y0, y1, y2, y3);
-      if (Chi) {
-        size_t poff = (size_t)m * ldp;
-        if (la.p_rpb > 0) { const int eb = m / la.p_rpb; poff = (size_t)eb * la.p_bs + (size_t)(m - eb * la.p_rpb) * ldp; }
-        uint2 hi, lo;
-        split2_bf16(y0, y1, hi.x, lo.x);
-        split2_bf16(y2, y3, hi.y, lo.y);
-        *reinterpret_cast<uint2*>(Chi + poff + n0) = hi;
-        *reinterpret_cast<uint2*>(Clo + poff + n0) = lo;
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int h = 0; h < WM / ER; ++h) {
     if (h) __builtin_amdgcn_wave_barrier();
@@ -863,17 +414,15 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
 }
 
 // QG: also instantiate the QuickGELU epilogue (only the configurations pick_cfg can choose carry it)
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false, int WT = 0,
-          int AT = 0>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false, int WT = 0>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
            int ksplit = 1, int a_rpb = 0, long a_bs = 0) {
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM), ksplit), block((BM / WM) * (BN / WN) * 64);
-  const LnArgs la{};
 #define GRIDMM_LP(ACT)                                                                                        \
-  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR, 0, WT, AT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
-                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs, la)
+  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR, WT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
+                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
   else if (act == GRIDMM_ACT_RELU) GRIDMM_LP(GRIDMM_ACT_RELU);
@@ -882,35 +431,6 @@ int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const 
     else return GRIDMM_EINVAL;
   }
 #undef GRIDMM_LP
-  GRIDMM_CHECK_LAUNCH();
-  return GRIDMM_OK;
-}
-
-// Fused-LayerNorm launch of one tile configuration: refuses (GRIDMM_EUNSUPPORTED) unless the whole grid is resident at
-// once -- the rendezvous of a row block's column tiles would otherwise wait for workgroups that cannot start.
-template <int BM, int BN, int WM, int WN, int NS, int BK, int TR>
-int launch_ln(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
-              const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
-              unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, const LnArgs& la, bool dry,
-              hipStream_t st) {
-  auto kern = linear_planes_kernel<BM, BN, WM, WN, NS, BK, GRIDMM_ACT_NONE, 0, 0, TR, 1>;
-  constexpr int threads = (BM / WM) * (BN / WN) * 64;
-  static int capacity = -1;                    // resident workgroups of this kernel on the whole device
-  if (capacity < 0) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, 0) != hipSuccess)
-      capacity = 0;
-    else
-      capacity = cus * per_cu;
-    (void)hipGetLastError();
-  }
-  if (N % BN) return GRIDMM_EUNSUPPORTED;
-  const long wgs = (long)(N / BN) * ((M + BM - 1) / BM);
-  if (wgs > capacity) return GRIDMM_EUNSUPPORTED;
-  if (dry) return GRIDMM_OK;
-  GRIDMM_LAUNCH(kern, dim3((unsigned)wgs), dim3(threads), 0, st, Ahi, Alo, lda, Whi, Wlo, Kp, bias, R, ldr, C, ldc, Chi, Clo,
-                ldp, M, N, K, 0, 0L, la);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -980,9 +500,12 @@ extern "C" int gridmm_split_rows(const float* X, int ldx, void* hi, void* lo, in
 // each costing BM*BN*occ / quality, with the relative per-tile throughputs measured on MI355X by
 // tools/bench_gemm.py (profiles/gemm_tiles_r1.txt): larger tiles re-use more of each LDS-DMA'd byte, small
 // ones fill the 256 CUs when M*N is small.
-// Tuning hook (tools/sweep_gemm_cfg_step.py): force the tile configuration of one (M, N, K) problem shape inside a
-// running process, to time candidate tiles IN the captured step (operands arrive as the step leaves them: A just written
-// by the previous launch, weights cold) instead of in an isolated loop.  Not used by the product path.
+#ifdef GRIDMM_DEBUG_HOOKS
+// Tuning hooks -- ONLY in the development build (make debug -> libgridmm_hip_dbg.so, -DGRIDMM_DEBUG_HOOKS); the shipping
+// library has no process-global state.  gridmm_debug_gemm_cfg_override forces the tile configuration of one (M, N, K)
+// problem shape inside a running process, so that tools/sweep_gemm_cfg_step.py can time candidate tiles IN the captured
+// step (operands arrive as the step leaves them: A just written by the previous launch, weights cold) instead of in an
+// isolated loop; gridmm_debug_gemm_shapes lists the problem shapes the heuristic has been asked about.
 static int g_cfg_override[32][4];
 static int g_cfg_overrides = 0;
 extern "C" int gridmm_debug_gemm_cfg_override(int M, int N, int K, int cfg) {
@@ -996,9 +519,6 @@ extern "C" int gridmm_debug_gemm_cfg_override(int M, int N, int K, int cfg) {
   e[0] = M; e[1] = N; e[2] = K; e[3] = cfg;
   return GRIDMM_OK;
 }
-
-// ... and the list of problem shapes the heuristic has been asked about (with its answers and call counts), so that a sweep
-// knows what a captured step contains.  `log` = 1 starts / clears the recording, 0 stops it.
 static int g_shape_log[128][5];
 static int g_shape_logged = 0, g_shape_logging = 0;
 extern "C" int gridmm_debug_gemm_shapes(int* out, int max_rows, int log) {
@@ -1009,8 +529,13 @@ extern "C" int gridmm_debug_gemm_shapes(int* out, int max_rows, int log) {
   if (log >= 0) { g_shape_logging = log; if (log == 1) g_shape_logged = 0; }
   return n;
 }
+#endif
 static int pick_cfg_impl(int M, int N, int K);
 static int pick_cfg(int M, int N, int K) {
+#ifdef GRIDMM_DEBUG_HOOKS
+  for (int i = 0; i < g_cfg_overrides; ++i)
+    if (g_cfg_override[i][0] == M && g_cfg_override[i][1] == N && g_cfg_override[i][2] == K && g_cfg_override[i][3] > 0)
+      return g_cfg_override[i][3];
   const int c = pick_cfg_impl(M, N, K);
   if (g_shape_logging) {
     int i = 0;
@@ -1020,12 +545,12 @@ static int pick_cfg(int M, int N, int K) {
     if (i < 128) ++g_shape_log[i][4];
   }
   return c;
+#else
+  return pick_cfg_impl(M, N, K);
+#endif
 }
 
 static int pick_cfg_impl(int M, int N, int K) {
-  for (int i = 0; i < g_cfg_overrides; ++i)
-    if (g_cfg_override[i][0] == M && g_cfg_override[i][1] == N && g_cfg_override[i][2] == K && g_cfg_override[i][3] > 0)
-      return g_cfg_override[i][3];
   struct Cand { int cfg, bm, bn, occ; float q; bool k64; };
   static const Cand cands[] = {
       {36, 256, 256, 1, 1.35f, false}, // 16 waves, 64x64 per wave (4 waves / SIMD): 3-8 % over the 8-wave 128x64 form
@@ -1051,29 +576,21 @@ static int pick_cfg_impl(int M, int N, int K) {
     const long t13 = (long)((M + 127) / 128) * ((N + 63) / 64);
     if (t13 >= 128 && t13 <= 256) best = 13;
   }
-  // experiment hooks (tools/bench_gemm_cfg_step.sh): deeper LDS rings for the tiles whose operands arrive cold in the step
-  static const int ov_small = getenv("GRIDMM_GEMM_CFG_SMALL") ? atoi(getenv("GRIDMM_GEMM_CFG_SMALL")) : 0;
-  static const int ov_mid = getenv("GRIDMM_GEMM_CFG_MID") ? atoi(getenv("GRIDMM_GEMM_CFG_MID")) : 0;
-  if (best == 43 && ov_small) return ov_small;
-  if (best == 15 && ov_mid) return ov_mid;
   return best;
 }
 
-// cfg: 0 = auto; tuning configs 1..6 (tools/bench_gemm.py):
-//   1: 128x128 NS=2   2: 128x128 NS=3   3: 256x128 (8 waves) NS=2   4: 64x64 NS=2   5: 64x64 NS=3   6: 128x64 NS=3
+// cfg: 0 = the heuristic above; the shipping library instantiates the tiles the heuristic can choose (2, 4, 13, 15, 16, 36,
+// 43, 57), the development build (-DGRIDMM_DEBUG_HOOKS) the whole experiment table of tools/bench_gemm.py and the sweeps.
+// w_layout: GRIDMM_W_ROWMAJOR ([N][Kp] planes) or GRIDMM_W_TILED ([ceil(N/16)][Kp/32][16][32] blocks, gridmm_linear_t.wt_hi):
+// tiled planes are read by the BK = 32 tiles; a shape whose tile is not one of them answers GRIDMM_EUNSUPPORTED and the
+// caller passes the row-major planes.
 static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
-                                        const void* W_lo, int Kp, const float* bias, const float* residual,
+                                        const void* W_lo, int Kp, int w_layout, const float* bias, const float* residual,
                                         int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N,
                                         int K, int act, int cfg, int a_rpb, long a_bs, gridmm_stream_t stream) {
-  const bool wt = Kp < 0;                    // tiled W planes (16 x 32 blocks; rows padded to a multiple of 16)
-  if (wt) Kp = -Kp;
-  const bool at = lda < 0;                   // tiled A planes (EXPERIMENT; with tiled W only, no row map)
-  if (at) lda = -lda;
-  if (at && (!wt || a_rpb > 0 || lda % 32)) return GRIDMM_EINVAL;
-  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || act < 0 || act > 3)
-    return GRIDMM_EINVAL;
-  if (K % 64 && (cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 13 || cfg == 108 || cfg == 208 ||
-                 cfg == 43 || cfg == 45 || cfg == 49 || cfg == 50 || cfg == 51 || cfg == 53 || cfg == 54 || cfg == 56 || cfg == 57))
+  if (w_layout != GRIDMM_W_ROWMAJOR && w_layout != GRIDMM_W_TILED) return GRIDMM_EINVAL;
+  const bool wt = w_layout == GRIDMM_W_TILED;
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda <= 0 || lda % 8 || N % 4 || act < 0 || act > 3)
     return GRIDMM_EINVAL;
   if ((C && ldc % 4) || (residual && ldr % 4) || (C_hi && (ldp % 4 || !C_lo)) || (!C && !C_hi)) return GRIDMM_EINVAL;
   const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
@@ -1084,26 +601,41 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
 #define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st, 1, a_rpb, a_bs
   if (wt) {     // tiled planes (16 x 32 blocks): the BK = 32 tiles of the heuristic.  An 8 x 64 copy for the BK = 64 tiles was
                 // measured too (their pieces are 8 full 128-B lines already): +-2 us per step, not kept.
-    if (at) {
-      if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, false, 1, 1>(GRIDMM_ARGS);
-      if (cfg == 36) return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, false, 1, 1>(GRIDMM_ARGS);
-      return GRIDMM_EUNSUPPORTED;
-    }
     if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
     if (cfg == 36) return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
-    // (other BK = 32 tiles with tiled W: reachable only through the tuning override, tools/sweep_gemm_cfg_step.py)
+#ifdef GRIDMM_DEBUG_HOOKS
     if (cfg == 16) return launch<256, 128, 64, 32, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
     if (cfg == 14) return launch<128, 128, 64, 32, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
     if (cfg == 12) return launch<128, 128, 64, 32, 3, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
     if (cfg == 48) return launch<128, 128, 32, 32, 3, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
     if (cfg == 3) return launch<256, 128, 64, 64, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 60) return launch<192, 128, 48, 64, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);   // 192-row tiles (round 5 sweep)
+    if (cfg == 61) return launch<192, 128, 96, 32, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 62) return launch<256, 128, 64, 64, 3, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 63) return launch<128, 128, 64, 64, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 64) return launch<192, 256, 96, 64, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+#endif
     return GRIDMM_EUNSUPPORTED;
   }
+  if (K % 64 && (cfg == 2 || cfg == 13 || cfg == 43 || cfg == 57)) return GRIDMM_EINVAL;
   switch (cfg) {
-    case 1: return launch<128, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
     case 2: return launch<128, 128, 64, 32, 2, 64, 0, 0, 0, true>(GRIDMM_ARGS);
-    case 3: return launch<256, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
     case 4: return launch<64, 64, 32, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
+    case 13: return launch<128, 64, 32, 32, 3, 64, 0, 0, 0, true>(GRIDMM_ARGS);
+    case 15: return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
+    case 16: return launch<256, 128, 64, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
+    case 36: return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);   // 16 waves, lockstep
+    case 43: return launch<64, 64, 32, 32, 2, 64, 0, 0, 1, true>(GRIDMM_ARGS);     // direct epilogue from C^T accumulators
+    case 57: return launch<128, 64, 32, 32, 3, 64, 0, 0, 0, true>(GRIDMM_ARGS);    // = 13
+    default: break;
+  }
+#ifdef GRIDMM_DEBUG_HOOKS
+  if (K % 64 && (cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 108 || cfg == 208 || cfg == 45 || cfg == 49 ||
+                 cfg == 50 || cfg == 51 || cfg == 53 || cfg == 54 || cfg == 56))
+    return GRIDMM_EINVAL;
+  switch (cfg) {   // the experiment table (tools/bench_gemm.py, tools/sweep_gemm_cfg_step.py; profiles/gemm_tiles_r1.txt, r4_gemm_cfg_sweep_*)
+    case 1: return launch<128, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
+    case 3: return launch<256, 128, 64, 64, 2, 32>(GRIDMM_ARGS);
     case 5: return launch<128, 128, 64, 64, 2, 64>(GRIDMM_ARGS);
     case 6: return launch<128, 64, 64, 32, 2, 32>(GRIDMM_ARGS);
     case 7: return launch<256, 256, 128, 64, 2, 32>(GRIDMM_ARGS);
@@ -1112,35 +644,21 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     case 10: return launch<64, 64, 32, 32, 4, 64>(GRIDMM_ARGS);
     case 11: return launch<64, 64, 32, 32, 3, 64>(GRIDMM_ARGS);
     case 12: return launch<128, 128, 64, 32, 3, 32>(GRIDMM_ARGS);
-    case 13: return launch<128, 64, 32, 32, 3, 64, 0, 0, 0, true>(GRIDMM_ARGS);
     case 14: return launch<128, 128, 64, 32, 2, 32>(GRIDMM_ARGS);
-    case 15: return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
-    case 16: return launch<256, 128, 64, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
     case 17: return launch<64, 64, 32, 32, 4, 32>(GRIDMM_ARGS);
     case 18: return launch<64, 64, 32, 32, 3, 32>(GRIDMM_ARGS);
-    case 19: return launch<64, 32, 32, 16, 4, 32>(GRIDMM_ARGS);
-    case 20: return launch<64, 64, 16, 32, 4, 32>(GRIDMM_ARGS);
     case 21: return launch<128, 64, 32, 32, 4, 32>(GRIDMM_ARGS);
     case 22: return launch<256, 128, 64, 64, 3, 32>(GRIDMM_ARGS);
     case 23: return launch<256, 128, 64, 32, 3, 32>(GRIDMM_ARGS);
     case 24: return launch<128, 256, 64, 64, 3, 32>(GRIDMM_ARGS);
     case 30: return launch<256, 256, 128, 64, 2, 32, 0, 1>(GRIDMM_ARGS);   // ping-pong schedules
-    case 31: return launch<256, 128, 64, 64, 2, 32, 0, 1>(GRIDMM_ARGS);
-    case 32: return launch<128, 256, 64, 64, 2, 32, 0, 1>(GRIDMM_ARGS);
     case 33: return launch<128, 128, 64, 32, 2, 32, 0, 1>(GRIDMM_ARGS);
     case 34: return launch<256, 256, 64, 64, 2, 32, 0, 1>(GRIDMM_ARGS);    // 16 waves: 2 + 2 per SIMD
-    case 35: return launch<256, 128, 64, 32, 2, 32, 0, 1>(GRIDMM_ARGS);
-    case 36: return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);   // 16 waves, lockstep (control)
     case 40: return launch<256, 256, 64, 64, 2, 32, 0, 0, 1>(GRIDMM_ARGS);  // TR = direct epilogue from C^T accumulators
-    case 41: return launch<256, 256, 128, 64, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
     case 42: return launch<128, 128, 32, 32, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
-    case 43: return launch<64, 64, 32, 32, 2, 64, 0, 0, 1, true>(GRIDMM_ARGS);
     case 44: return launch<256, 128, 64, 32, 2, 32, 0, 0, 1>(GRIDMM_ARGS);
     case 45: return launch<64, 64, 32, 32, 3, 64, 0, 0, 1, true>(GRIDMM_ARGS);    // deeper rings (cold operands in the step)
-    case 46: return launch<64, 64, 32, 32, 4, 32, 0, 0, 1, true>(GRIDMM_ARGS);
-    case 47: return launch<64, 64, 32, 32, 3, 32, 0, 0, 1, true>(GRIDMM_ARGS);
     case 48: return launch<128, 128, 32, 32, 3, 32, 0, 0, 0, true>(GRIDMM_ARGS);
-    case 49: return launch<64, 64, 32, 32, 4, 64, 0, 0, 1, true>(GRIDMM_ARGS);
     case 50: return launch<128, 64, 32, 32, 3, 64, 0, 0, 1>(GRIDMM_ARGS);          // 128x64 tiles, direct epilogue (thin M, in-step sweep)
     case 51: return launch<128, 64, 32, 32, 2, 64, 0, 0, 1>(GRIDMM_ARGS);
     case 52: return launch<128, 64, 32, 32, 4, 32, 0, 0, 1>(GRIDMM_ARGS);
@@ -1148,7 +666,6 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     case 54: return launch<128, 64, 64, 32, 3, 64, 0, 0, 1>(GRIDMM_ARGS);
     case 55: return launch<128, 64, 32, 32, 3, 32, 0, 0, 1>(GRIDMM_ARGS);
     case 56: return launch<96, 64, 48, 32, 3, 64>(GRIDMM_ARGS);
-    case 57: return launch<128, 64, 32, 32, 3, 64, 0, 0, 0, true>(GRIDMM_ARGS);     // = 13 with the QuickGELU epilogue
     // ablations (tools/bench_gemm.py): 1xx = no MFMA (DMA + LDS reads only), 2xx = no DMA after the prologue
     case 108: return launch<64, 64, 32, 32, 2, 64, 1>(GRIDMM_ARGS);
     case 208: return launch<64, 64, 32, 32, 2, 64, 2>(GRIDMM_ARGS);
@@ -1156,131 +673,44 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     case 215: return launch<128, 128, 32, 32, 2, 32, 2>(GRIDMM_ARGS);
     case 107: return launch<256, 256, 128, 64, 2, 32, 1>(GRIDMM_ARGS);
     case 207: return launch<256, 256, 128, 64, 2, 32, 2>(GRIDMM_ARGS);
-    default: return GRIDMM_EINVAL;
+    default: break;
   }
+#endif
+  return GRIDMM_EINVAL;
 #undef GRIDMM_ARGS
-}
-
-// ---- GEMM + residual + LayerNorm in one launch (see LnArgs): Y = LayerNorm(A W^T + bias + residual) gamma + beta.
-// Tile choice follows pick_cfg's two regimes (64x64 direct epilogue for small M * N, 128x128 otherwise); shapes the
-// fused form cannot take (N not a multiple of the tile width, a grid larger than the device holds at once, or
-// GRIDMM_LN_FUSE=0 in the environment) return GRIDMM_EUNSUPPORTED and the caller issues gridmm_linear_planes +
-// gridmm_layernorm instead.
-static int ln_fuse_enabled() {
-  static const int on = getenv("GRIDMM_LN_FUSE") ? atoi(getenv("GRIDMM_LN_FUSE")) : 1;
-  return on;
-}
-
-extern "C" size_t gridmm_linear_planes_ln_workspace(int M, int N) {
-  return (size_t)((N + 63) / 64) * (size_t)M * sizeof(float2);
-}
-extern "C" size_t gridmm_linear_planes_ln_sync_bytes(int M) { return (size_t)((M + 63) / 64) * 2 * sizeof(unsigned); }
-
-extern "C" int gridmm_linear_planes_ln(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int Kp,
-                                       const float* bias, const float* residual, int ldr, float* C_pre, int ldc,
-                                       const float* gamma, const float* beta, float eps, float* Y, int ldy, void* Y_hi,
-                                       void* Y_lo, int ldp, int p_rpb, int64_t p_bs, void* workspace, void* sync_words,
-                                       int M, int N, int K, int dry_run, gridmm_stream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || !gamma || !beta) return GRIDMM_EINVAL;
-  if ((C_pre && ldc % 4) || (residual && ldr % 4) || (Y && ldy % 4) || (Y_hi && (ldp % 4 || !Y_lo || (p_rpb > 0 && p_bs % 4))) ||
-      (!Y && !Y_hi))
-    return GRIDMM_EINVAL;
-  if (!ln_fuse_enabled()) return GRIDMM_EUNSUPPORTED;
-  if (!dry_run && (!workspace || !sync_words)) return GRIDMM_EINVAL;
-  const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
-  const unsigned short *wh = (const unsigned short*)W_hi, *wl = (const unsigned short*)W_lo;
-  LnArgs la{gamma, beta, eps, Y, ldy, (float2*)workspace, (unsigned*)sync_words, p_rpb, (long)p_bs, nullptr};
-  hipStream_t st = as_stream(stream);
-#define GRIDMM_LN_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C_pre, ldc, (unsigned short*)Y_hi, (unsigned short*)Y_lo, ldp, M, N, K, la, dry_run != 0, st
-  int rc = GRIDMM_EUNSUPPORTED;
-  if (pick_cfg(M, N, K) == 43 && K % 64 == 0) rc = launch_ln<64, 64, 32, 32, 2, 64, 1>(GRIDMM_LN_ARGS);
-  if (rc == GRIDMM_EUNSUPPORTED) rc = launch_ln<128, 128, 32, 32, 2, 32, 0>(GRIDMM_LN_ARGS);
-#undef GRIDMM_LN_ARGS
-  return rc;
-}
-
-// ---- GEMMs around a DEFERRED LayerNorm (LnArgs, LN == 2): no LayerNorm launch and no rendezvous.  The producer of a
-// pre-LayerNorm sum h leaves h (fp32 + planes) and per-tile row statistics (out_stats); consumers normalise on the fly:
-// a GEMM over LN(h) runs on h's planes with gamma folded into its weight (W' = W * gamma) and corrects in the epilogue,
-//   y = rstd (acc - mu sv) + cv,   sv[n] = sum_k W'[n][k],   cv = W beta + b  (handed in as `bias`),
-// a GEMM whose residual is LN(h) normalises the residual as it reads it.  Tile shapes: the heuristic's 128x64 (3-stage) and
-// 128x128 choices; other shapes answer GRIDMM_EUNSUPPORTED (gridmm_linear_planes_lnx_tiles tells in advance).
-template <int BM, int BN, int WM, int WN, int NS, int BK>
-int launch_lnx(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
-               const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
-               unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, const LnArgs& la,
-               hipStream_t st) {
-  if (la.out_stats && N % BN) return GRIDMM_EUNSUPPORTED;
-  constexpr int NWL = (BM / WM) * (BN / WN);
-  constexpr int ERL = (NWL > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : 64);
-  if (la.out_stats && ERL != WM) return GRIDMM_EUNSUPPORTED;      // statistics out: single-pass epilogues only
-  dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM)), block((BM / WM) * (BN / WN) * 64);
-  if (act == GRIDMM_ACT_NONE)
-    GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, GRIDMM_ACT_NONE, 0, 0, 0, 2>), grid, block, 0, st, Ahi, Alo, lda,
-                  Whi, Wlo, Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, 0, 0L, la);
-  else if (act == GRIDMM_ACT_GELU)
-    GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, GRIDMM_ACT_GELU, 0, 0, 0, 2>), grid, block, 0, st, Ahi, Alo, lda,
-                  Whi, Wlo, Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, 0, 0L, la);
-  else return GRIDMM_EINVAL;
-  GRIDMM_CHECK_LAUNCH();
-  return GRIDMM_OK;
-}
-
-// Column tiles (and their width) the deferred-LayerNorm form uses for this problem: the layout of out_stats
-// ([tiles][M] (mean, M2) pairs).  0: the shape cannot take the form.
-extern "C" int gridmm_linear_planes_lnx_tiles(int M, int N, int K, int* tile_width) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4) return 0;
-  const int cfg = pick_cfg(M, N, K);
-  const int bn = cfg == 13 ? 64 : (cfg == 15 ? 128 : 0);     // (the 256x256 tiles have no registers to spare for the forms)
-  if (!bn || N % bn) return 0;
-  if (tile_width) *tile_width = bn;
-  return N / bn;
-}
-
-extern "C" int gridmm_linear_planes_lnx(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
-                                        int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
-                                        void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
-                                        const gridmm_lnx_t* x, gridmm_stream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda % 8 || N % 4 || !x || x->ln_n <= 0) return GRIDMM_EINVAL;
-  if ((C && ldc % 4) || (residual && ldr % 4) || (C_hi && (ldp % 4 || !C_lo)) || (!C && !C_hi)) return GRIDMM_EINVAL;
-  if ((x->a_stats && (!x->sv || x->a_tn <= 0 || x->a_tn > 12 || x->a_bn <= 0)) ||
-      (x->r_stats && (!residual || !x->r_gamma || !x->r_beta || x->r_tn <= 0 || x->r_tn > 12 || x->r_bn <= 0)) ||
-      (x->a_stats && x->r_stats))          // one kind of statistics in per launch
-    return GRIDMM_EINVAL;
-  LnArgs la{};
-  la.a_stats = (const float2*)x->a_stats; la.a_tn = x->a_tn; la.a_bn = x->a_bn; la.sv = x->sv; la.a_eps = x->a_eps;
-  la.r_stats = (const float2*)x->r_stats; la.r_tn = x->r_tn; la.r_bn = x->r_bn; la.r_gamma = x->r_gamma; la.r_beta = x->r_beta;
-  la.r_eps = x->r_eps; la.out_stats = (float2*)x->out_stats; la.ln_n = x->ln_n;
-  const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
-  const unsigned short *wh = (const unsigned short*)W_hi, *wl = (const unsigned short*)W_lo;
-  hipStream_t st = as_stream(stream);
-  const int cfg = pick_cfg(M, N, K);
-#define GRIDMM_LNX_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, (unsigned short*)C_hi, (unsigned short*)C_lo, ldp, M, N, K, act, la, st
-  if (cfg == 13) return launch_lnx<128, 64, 32, 32, 3, 64>(GRIDMM_LNX_ARGS);
-  if (cfg == 15) return launch_lnx<128, 128, 32, 32, 2, 32>(GRIDMM_LNX_ARGS);
-#undef GRIDMM_LNX_ARGS
-  return GRIDMM_EUNSUPPORTED;
 }
 
 extern "C" int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
                                         const void* W_lo, int Kp, const float* bias, const float* residual,
                                         int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N,
                                         int K, int act, int cfg, gridmm_stream_t stream) {
-  return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M, N, K, act,
-                                cfg, 0, 0, stream);
+  return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, GRIDMM_W_ROWMAJOR, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp,
+                                M, N, K, act, cfg, 0, 0, stream);
 }
 
-// A rows through a batched row map: row m of the GEMM = row (m % a_rpb) of episode (m / a_rpb) in a buffer whose
-// episodes are a_bs elements apart (a_rpb <= 0: plain rows).  Lets a GEMM read a sub-sequence of a longer padded
-// sequence in place -- the instruction rows inside the local encoder's [map | txt] context, the map nodes inside [cells | nodes].
+// The general form: A rows through a batched row map -- row m of the GEMM = row (m % a_rpb) of episode (m / a_rpb) in a
+// buffer whose episodes are a_bs elements apart (a_rpb <= 0: plain rows); lets a GEMM read a sub-sequence of a longer padded
+// sequence in place (the instruction rows inside the local encoder's [map | txt] context, the map nodes inside
+// [cells | nodes]) -- and the W planes in either layout (w_layout).
 extern "C" int gridmm_linear_planes_map(const void* A_hi, const void* A_lo, int lda, int a_rpb, int64_t a_bs,
-                                        const void* W_hi, const void* W_lo, int Kp, const float* bias,
+                                        const void* W_hi, const void* W_lo, int Kp, int w_layout, const float* bias,
                                         const float* residual, int ldr, float* C, int ldc, void* C_hi, void* C_lo,
                                         int ldp, int M, int N, int K, int act, gridmm_stream_t stream) {
   if (a_rpb > 0 && (a_bs % 8)) return GRIDMM_EINVAL;
-  return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M, N, K, act,
-                                0, a_rpb, (long)a_bs, stream);
+  return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, w_layout, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M, N, K,
+                                act, 0, a_rpb, (long)a_bs, stream);
 }
+
+#ifdef GRIDMM_DEBUG_HOOKS
+// (development build: the general form with an explicit tile configuration -- tools/bench_gemm_tiled.py)
+extern "C" int gridmm_debug_linear_planes_map_cfg(const void* A_hi, const void* A_lo, int lda, int a_rpb, int64_t a_bs,
+                                                  const void* W_hi, const void* W_lo, int Kp, int w_layout, const float* bias,
+                                                  const float* residual, int ldr, float* C, int ldc, void* C_hi, void* C_lo,
+                                                  int ldp, int M, int N, int K, int act, int cfg, gridmm_stream_t stream) {
+  return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, w_layout, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M, N, K,
+                                act, cfg, a_rpb, (long)a_bs, stream);
+}
+#endif
 
 extern "C" int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
                                     const void* W_lo, int Kp, const float* bias, const float* residual, int ldr,

@@ -19,7 +19,17 @@ def is_dist():
     (tests/test_hip_dist.py::test_rccl_single_rank_runs_every_multi_rank_path)."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size() > 1 or bool(os.environ.get("GRIDMM_DIST_FORCE"))
+    return dist.get_world_size() > 1 or dist_forced()
+
+
+def dist_forced():
+    """GRIDMM_DIST_FORCE as an INTEGER switch ("0", "" and unset are off; ADVICE r4: `bool(str)` made "0" enable it).  Read
+    per call on purpose: the one-rank RCCL tests set it after the package is imported."""
+    v = os.environ.get("GRIDMM_DIST_FORCE", "0").strip()
+    try:
+        return int(v or "0") != 0
+    except ValueError:
+        return False
 
 
 def rank_world():
@@ -74,11 +84,14 @@ def control_group():
     the same point).  Separate from the data group even when that is gloo too: control all-reduces are issued from the main
     thread while a helper thread may be inside a data collective (GradientReducer._launch), and gloo pairs collectives of
     one group by call order."""
-    key = id(dist.group.WORLD)
-    if key not in _CTL:
+    world = dist.group.WORLD
+    ent = _CTL.get("ctl")
+    # keyed on the process-group OBJECT (held here, so its id cannot be recycled by a later group -- ADVICE r4) and dropped
+    # when the default group was destroyed and re-created
+    if ent is None or ent[0] is not world:
         _CTL.clear()
-        _CTL[key] = dist.new_group(backend="gloo")
-    return _CTL[key]
+        _CTL["ctl"] = ent = (world, dist.new_group(backend="gloo"))
+    return ent[1]
 
 
 class GradientReducer:

@@ -367,7 +367,7 @@ class NavigationGraphs:
                                    "memory has %d occupied cells" % (c_pad, cmax, true))
         ins = self._inputs(batch)
         key = (tuple(fr.txt.hi.shape), batch["gmap_masks"].shape[1], batch["vp_masks"].shape[1], c_pad,
-               tuple(sorted(ins)), bool(ops.LN_FUSE), getattr(fr, "icache", None) is not None)
+               tuple(sorted(ins)), getattr(fr, "icache", None) is not None)
         ent = self.graphs.pop(key, None)
         if ent is None:
             ent = self._capture(key, fr, batch, c_pad)

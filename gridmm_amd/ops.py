@@ -233,13 +233,14 @@ def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_pla
             if WT and allow_tiled and getattr(pw, "_tiled", False) is not False:   # (inference weights, packed once; the training
                                                                                    # path re-packs per step and passes allow_tiled=False)
                 th, tl = pw.tiled()
-                rc = lib.gridmm_linear_planes_map(_p(a.hi), _p(a.lo), lda, rpb, bs, _p(th), _p(tl), -pw.Kp, _p(pw.bias),
+                rc = lib.gridmm_linear_planes_map(_p(a.hi), _p(a.lo), lda, rpb, bs, _p(th), _p(tl), pw.Kp, _lib.W_TILED, _p(pw.bias),
                                                   _p(residual), ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream())
                 if rc != -2:
                     return _lib.check(rc, "gridmm_linear_planes (tiled W)")
             _lib.check(
-                lib.gridmm_linear_planes_map(_p(a.hi), _p(a.lo), lda, rpb, bs, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias),
-                                             _p(residual), ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act, _stream()),
+                lib.gridmm_linear_planes_map(_p(a.hi), _p(a.lo), lda, rpb, bs, _p(pw.hi), _p(pw.lo), pw.Kp, _lib.W_ROWMAJOR,
+                                             _p(pw.bias), _p(residual), ldr, _p(c), ldc, _p(hi), _p(lo), pw.N, M, pw.N, K, act,
+                                             _stream()),
                 "gridmm_linear_planes")
         _timed("linear", 2.0 * M * pw.N * K, call)
         return Act(c, hi, lo)
@@ -302,69 +303,6 @@ def layernorm(x, gamma, beta, eps, residual=None, add1=None, table=None, idx=Non
 # Tiled weight planes for the BK = 32 tiles (PackedLinear.tiled): every 1-KiB DMA piece of W is one contiguous KiB.  Measured
 # in the B = 32 step: -10..-15 us with the Python-issued GEMMs alone (profiles/r4_tiled_weights.txt).  GRIDMM_WT=0: row-major only.
 WT = bool(int(os.environ.get("GRIDMM_WT", "1")))
-
-
-# ---- GEMM + residual + LayerNorm as one launch (gridmm_linear_planes_ln) ---------------------------------------------
-# Measured on MI355X (tools/bench_linear_ln.py, profiles/r4_linear_ln_fused_experiment.txt): the rendezvous (sc1 round trips
-# for statistics and counters, all outputs written in one burst after it) costs MORE than the LayerNorm launch it removes
-# -- the B = 32 step runs 2.37 ms fused against 2.28 ms with the launches -- so the fused form is OFF unless asked for.
-LN_FUSE = bool(int(os.environ.get("GRIDMM_LN_FUSE", "0")))   # also: never on when several streams run at once (the fused
-                        # launches rendezvous inside their own grid and must not share the device with one another)
-_LN_SYNC = {}           # device index -> zeroed counter block (the library leaves it zeroed)
-
-
-def ln_sync(dev):
-    """The counter block of the fused GEMM + LayerNorm launches on `dev`, or None when the fused form is off (LN_FUSE) or
-    the block would have to be created inside a stream capture (the warm-up pass of every capture creates it)."""
-    if not LN_FUSE:
-        return None
-    t = _LN_SYNC.get(dev.index)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        t = torch.zeros(1 << 16, dtype=torch.int32, device=dev)     # 2 words per 64 rows: rows up to 2 M
-        _LN_SYNC[dev.index] = t
-    return t
-
-
-def linear_ln(x, pw, gamma, beta, eps, residual=None, want_pre=False, want_f32=True, want_planes=True, planes_out=None):
-    """LayerNorm(x @ W^T + b (+ residual)) * gamma + beta as ONE launch -> (Act of the result, fp32 pre-LayerNorm sums
-    or None), or None when the shape cannot take the fused form (the caller then issues linear + layernorm).
-    x: Act with contiguous planes (M rows)."""
-    lib = _lib.load()
-    a = x if isinstance(x, Act) else Act(x)
-    if a.hi is None or not a.hi.is_contiguous():
-        return None
-    dev = a.hi.device
-    sync = ln_sync(dev)
-    K, N = a.hi.shape[-1], pw.N
-    M = a.hi.numel() // K
-    if sync is None or K != pw.K or K % 32 or N % 4 or (M + 63) // 64 * 2 > sync.numel():
-        return None
-    oshape = tuple(a.hi.shape[:-1]) + (N,)
-    if residual is not None:
-        residual = uniform_rows(residual)
-    ldr = _rows2d(residual)[2] if residual is not None else 0
-    ldp, rpb, bs = N, 0, 0
-    if planes_out is not None:
-        probe = planes_out[0]
-        _, _, ldp, rpb, bs = _rows_map(probe)
-    args = lambda pre, y, hi, lo, ws, dry: lib.gridmm_linear_planes_ln(
-        _p(a.hi), _p(a.lo), K, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual), ldr, _p(pre), N, _p(gamma), _p(beta),
-        float(eps), _p(y), N, _p(hi), _p(lo), ldp, rpb, bs, _p(ws), _p(sync), M, N, K, dry, _stream())
-    dummy = a.hi                                     # dry run: only the shape question (pointers are not dereferenced)
-    if args(None, None, dummy, dummy, None, 1) != 0:
-        return None
-    pre = torch.empty(oshape, dtype=torch.float32, device=dev) if want_pre else None
-    y = torch.empty(oshape, dtype=torch.float32, device=dev) if want_f32 else None
-    hi = lo = None
-    if planes_out is not None:
-        hi, lo = planes_out
-    elif want_planes:
-        hi, lo = _planes_like(oshape, dev)
-    ws = torch.empty(lib.gridmm_linear_planes_ln_workspace(M, N), dtype=torch.uint8, device=dev)
-    _timed("linear", 2.0 * M * N * K, lambda: _lib.check(args(pre, y, hi, lo, ws, 0), "gridmm_linear_planes_ln"))
-    return Act(y, hi, lo), pre
 
 
 def attention(q, k, v, kmask, heads=12, scale=None, want_f32=False, want_planes=True):
@@ -492,38 +430,21 @@ class _CLn(ctypes.Structure):
 
 class _CXLayer(ctypes.Structure):
     _fields_ = [(n, _CLinear) for n in ("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o")] + \
-               [(n, _CLn) for n in ("x_ln", "s_ln", "f_ln")] + \
-               [(n, _CLinear) for n in ("sqkv_f", "ffn_i_f")] + [("sqkv_sv", ctypes.c_void_p), ("ffn_i_sv", ctypes.c_void_p)]
+               [(n, _CLn) for n in ("x_ln", "s_ln", "f_ln")]
 
 
 class XLayerWeights:
     """gridmm_xlayer_t of one cross-modal layer: packed Linears (PackedLinear) and LayerNorm modules; keeps them alive."""
 
-    def __init__(self, xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln, folded=None):
-        """folded = ((sqkv with x_ln folded in, its row sums), (ffn_i with s_ln folded in, its row sums)) or None: the
-        deferred-LayerNorm form of the two inner LayerNorms (fold_layernorm)."""
+    def __init__(self, xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln):
         self.keep = (xq, xo, sqkv, so, ffn_i, ffn_o, x_ln, s_ln, f_ln)
-        self.folded = folded
         c = _CXLayer()
-        if folded is not None:
-            for name, (pw, sv) in zip(("sqkv_f", "ffn_i_f"), folded):
-                setattr(c, name, _clinear(pw))
-                setattr(c, name[:-2] + "_sv", sv.data_ptr())
         for name, pw in zip(("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o"), self.keep[:6]):
             setattr(c, name, _clinear(pw))
         for name, ln in zip(("x_ln", "s_ln", "f_ln"), self.keep[6:]):
             setattr(c, name, _CLn(ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps)))
         self.c = c
         self.H, self.I = xq.N, ffn_i.N
-
-
-def fold_layernorm(weight, bias, ln):
-    """nn.Linear over a LayerNorm's output with the LayerNorm folded in: LN(h) W^T + b = rstd (h W'^T - mu sv) + cv with
-    W' = W * gamma, sv = W' 1, cv = W beta + b.  -> (PackedLinear(W', cv), sv fp32 (N,))"""
-    w = weight.detach().float()
-    wf = w * ln.weight.detach().float()[None, :]
-    cv = w @ ln.bias.detach().float() + (bias.detach().float() if bias is not None else 0.0)
-    return PackedLinear(wf.contiguous(), cv.contiguous()), wf.sum(1).contiguous()
 
 
 def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12, planes_out=None, kv2=None):
@@ -560,7 +481,7 @@ def xattn_layer(w, x, kv, k_col, v_col, ctx_mask, self_mask, heads=12, planes_ou
     _lib.check(lib.gridmm_xattn_layer_fwd(ctypes.byref(w.c), _p(x.f32), _p(x.hi), _p(x.lo), _p(kv.hi), _p(kv.lo),
                                           kv.hi.stride(0), kv.hi.stride(1), int(k_col), int(v_col), Sk1, _p(k2[0]), _p(k2[1]),
                                           k2[2], k2[3], k2[4], k2[5], _p(cm), cm.stride(0),
-                                          _p(sm), sm.stride(0), _p(y), _p(hi), _p(lo), rpb, bs, _p(ws), need, _p(ln_sync(dev)),
+                                          _p(sm), sm.stride(0), _p(y), _p(hi), _p(lo), rpb, bs, _p(ws), need,
                                           B, Sq, Sk, heads, _stream()), "gridmm_xattn_layer_fwd")
     return Act(y, hi, lo)
 

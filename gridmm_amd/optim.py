@@ -54,7 +54,7 @@ class AdamW(torch.optim.Optimizer):
                      ("lr", "<f4"), ("step_size", "<f4"), ("eps", "<f4"), ("wd", "<f4"), ("dtype", "<i4"), ("pad", "<i4")])
     _CHUNK = 16384
 
-    def _tables(self, items, dev, graph_tabs=None, key=None):
+    def _tables(self, items, dev, graph_tabs=None, key=None, ring_min=1):
         """items: list of (p, g, exp_avg, exp_avg_sq, lr, step_size, eps, wd) for contiguous fp32 / fp16 tensors.
         graph_tabs (captured steps): the table lives in a pinned host pool mirrored by a device pool, both allocated
         BEFORE the capture; nothing is copied inside the graph -- refresh_graph_tables() rewrites lr / step_size / eps in
@@ -71,10 +71,15 @@ class AdamW(torch.optim.Optimizer):
             # through pinned memory (a ring: a slot is rewritten only after the copy issued from it has completed), so that
             # the upload is a plain asynchronous DMA and never a staged pageable copy (measured host-synchronous on this
             # ROCm stack, tools/repro_pageable_h2d.py -- correct either way, but it stalls the launching thread)
-            pinned, d = self._pinned_slot(len(blob), dev)
+            # The DEVICE table is allocated per call (stream-ordered by the caching allocator and kept alive by
+            # self._keepalive): step() builds the tables of ALL (betas, decay order) classes before it launches any kernel
+            # -- the clip norm spans every class -- so a device ring shorter than the class count would be overwritten
+            # under kernels that have not run yet; the pinned ring holds at least one slot per class too.
+            pinned = self._pinned_slot(len(blob), ring_min)
             pinned.numpy()[:] = blob
+            d = torch.empty(len(blob), dtype=torch.uint8, device=dev)
             d.copy_(pinned, non_blocking=True)
-            self._ring[self._ring_pos][2].record()
+            self._ring[self._ring_pos][1].record()
         else:
             pinned, d = self._carve(graph_tabs, len(blob))
             pinned.numpy()[:] = blob
@@ -83,22 +88,21 @@ class AdamW(torch.optim.Optimizer):
 
     _RING = 4
 
-    def _pinned_slot(self, nbytes, dev):
-        """(pinned host bytes, device bytes) from a small ring: a slot is reused only after the copy issued from it has
-        completed (the event recorded behind it), so the host never rewrites a table the device has not fetched yet."""
+    def _pinned_slot(self, nbytes, ring_min=1):
+        """Pinned host bytes from a ring of max(_RING, ring_min + 1) slots: a slot is reused only after the copy issued from it
+        has completed (the event recorded behind it), so the host never rewrites a table the device has not fetched yet."""
         ring = self.__dict__.setdefault("_ring", [])
-        if len(ring) < self._RING:
-            ring.append([torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory(),
-                         torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev), torch.cuda.Event()])
+        size = max(self._RING, ring_min + 1)
+        if len(ring) < size:
+            ring.append([torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory(), torch.cuda.Event()])
             self._ring_pos = len(ring) - 1
         else:
-            self._ring_pos = (self._ring_pos + 1) % self._RING
-            ring[self._ring_pos][2].synchronize()
+            self._ring_pos = (self._ring_pos + 1) % len(ring)
+            ring[self._ring_pos][1].synchronize()
         slot = ring[self._ring_pos]
-        if slot[0].numel() < nbytes or slot[1].device != torch.device(dev):
+        if slot[0].numel() < nbytes:
             slot[0] = torch.empty(2 * nbytes, dtype=torch.uint8).pin_memory()
-            slot[1] = torch.empty(2 * nbytes, dtype=torch.uint8, device=dev)
-        return slot[0][:nbytes], slot[1][:nbytes]
+        return slot[0][:nbytes]
 
     @staticmethod
     def _carve(graph_tabs, nbytes):
@@ -165,7 +169,7 @@ class AdamW(torch.optim.Optimizer):
         classes = {}
         for it in multi:
             classes.setdefault(it[8:], []).append(it[:8])
-        tables = {k: self._tables(v, dev, graph_tabs, k) for k, v in classes.items()}
+        tables = {k: self._tables(v, dev, graph_tabs, k, ring_min=len(classes)) for k, v in classes.items()}
         sumsq = None
         if max_grad_norm is not None:
             sumsq = torch.zeros(1, dtype=torch.float32, device=dev)

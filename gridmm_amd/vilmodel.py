@@ -330,18 +330,10 @@ class GlocalTextPathNavCMT(nn.Module):
                    self._qkv(sa.self, key + ".s"), self._lin(sa.output.dense, key + ".s.o"),
                    self._lin(ff.visn_inter.dense, key + ".i"), self._lin(ff.visn_output.dense, key + ".f"))
             lns = (layer.visual_attention.output.LayerNorm, sa.output.LayerNorm, ff.visn_output.LayerNorm)
-            # (versions too: the deferred-LayerNorm form folds gamma / beta of the two inner LayerNorms into weight planes)
-            sig = pws + tuple(v for ln in lns for p in (ln.weight, ln.bias) for v in (p.data_ptr(), p._version)) + \
-                (bool(self.defer_layernorm),)
+            sig = pws + tuple(v for ln in lns for p in (ln.weight, ln.bias) for v in (p.data_ptr(), p._version))
             ent = self._packed.get(key + ".xlayer")
             if ent is None or len(ent[0]) != len(sig) or any(a is not b and a != b for a, b in zip(ent[0], sig)):
-                folded = None
-                if self.defer_layernorm:
-                    qkv_w = torch.cat([m.weight.detach() for m in (sa.self.query, sa.self.key, sa.self.value)], 0)
-                    qkv_b = torch.cat([m.bias.detach() for m in (sa.self.query, sa.self.key, sa.self.value)], 0)
-                    folded = (ops.fold_layernorm(qkv_w, qkv_b, lns[0]),
-                              ops.fold_layernorm(ff.visn_inter.dense.weight, ff.visn_inter.dense.bias, lns[1]))
-                ent = (sig, ops.XLayerWeights(*pws, *lns, folded=folded))
+                ent = (sig, ops.XLayerWeights(*pws, *lns))
                 self._packed[key + ".xlayer"] = ent
             return ops.xattn_layer(ent[1], visn, kv[0], kv[1], kv[1] + H, lang_mask, visn_mask, heads=self.heads,
                                    planes_out=planes_out, kv2=None if kv2 is None else (kv2[0], kv2[1], kv2[1] + H))
@@ -483,11 +475,6 @@ class GlocalTextPathNavCMT(nn.Module):
     # (vilmodel.py:809-823, ops.py:46-68 pad_tensors_wgrad) -- eager calls read the batch's largest occupied-cell count
     # (one small D2H, as the reference's python max() does) and run the encoders on the smallest bucket that holds it;
     # graph.GraphedNavStep keeps one captured back half per bucket and predicts the bucket from the previous step.
-    # The two inner LayerNorms of every cross-modal layer in deferred form (gridmm_linear_planes_lnx: gamma / beta folded into
-    # the next GEMM's weight planes, statistics from the producing GEMM's epilogue, residuals normalised on the fly): two
-    # launches fewer per layer.  Same function values, different association (differences ~1e-6).  OFF by default: measured
-    # slower than the launches it removes (2.33-2.35 vs 2.23-2.25 ms per step; csrc/layer.hip).
-    defer_layernorm = bool(int(os.environ.get("GRIDMM_LN_DEFER", "0")))
     varlen_buckets = None
     DEFAULT_BUCKETS = (64, 80, 96, 112, 128, 144, 160, 176, N_CELLS)   # 16-row steps: a step costs what its occupied cells cost
 

@@ -10,7 +10,8 @@
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
  *   - no allocation inside: outputs / workspaces are caller-provided;
  *   - returns 0 on success, a negative GRIDMM_E* code otherwise (never throws);
- *   - re-entrant, no global state.
+ *   - re-entrant, no global state (tuning overrides and in-kernel profilers exist only in the development build,
+ *     `make debug` -> libgridmm_hip_dbg.so, declared under GRIDMM_DEBUG_HOOKS at the end of this header).
  */
 #ifndef GRIDMM_H
 #define GRIDMM_H
@@ -200,78 +201,26 @@ int gridmm_linear_planes(const void* A_hi, const void* A_lo, int lda, const void
                          void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
                          gridmm_stream_t stream);
 
-/* (Kp < 0: W_hi / W_lo are TILED planes of row pitch -Kp, see gridmm_linear_t.wt_hi; shapes whose tile choice cannot read
- * them return GRIDMM_EUNSUPPORTED and the caller passes the row-major planes) */
-/* Same with an explicit tile configuration (tuning / benchmarking; cfg 0 = the heuristic above). */
+/* Same with an explicit tile configuration (cfg 0 = the heuristic; the shipping library answers the tiles the heuristic can
+ * choose -- 2, 4, 13, 15, 16, 36, 43, 57 -- and GRIDMM_EINVAL for the rest of the development build's experiment table). */
 int gridmm_linear_planes_cfg(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo,
                              int Kp, const float* bias, const float* residual, int ldr, float* C, int ldc,
                              void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act, int cfg,
                              gridmm_stream_t stream);
 
-/* GEMM + residual + LayerNorm in ONE launch (BertSelfOutput / BertOutput / BertOutAttention's output block,
- * map_nav_src/models/vilmodel.py:156-168, 196-209; the norm that follows an out-projection / linear2 in
- * transformer.py:170-182):   x = A W^T + bias + residual;   Y = LayerNorm(x) * gamma + beta   over the N columns.
- * The workgroups of a row block exchange per-tile row statistics through `workspace` and a pair of counters in
- * `sync_words` and normalise the values they still hold in registers: no pre-LayerNorm round trip through memory and
- * no LayerNorm launch.  Outputs: C_pre (optional fp32 x, the residual stream of a pre-norm layer), Y (optional fp32),
- * Y_hi / Y_lo (optional bf16 planes of Y, row stride ldp, through the batched row map p_rpb / p_bs of
- * gridmm_layernorm_map when p_rpb > 0).
- *   workspace   >= gridmm_linear_planes_ln_workspace(M, N) bytes of scratch
- *   sync_words  >= gridmm_linear_planes_ln_sync_bytes(M) bytes, ZEROED ONCE by the caller (hipMemset) before the first
- *               call; every call leaves them zero.  One buffer per stream: calls that may run concurrently must not
- *               share it, and two fused launches must not be resident on the device at the same time (they wait for
- *               workgroups of their own grid: single-stream use).
- * Returns GRIDMM_EUNSUPPORTED -- and launches nothing -- when the shape cannot take the fused form (N not a multiple
- * of the tile width, a grid the device cannot hold at once, GRIDMM_LN_FUSE=0): the caller then issues
- * gridmm_linear_planes + gridmm_layernorm.  dry_run != 0 only answers that question. */
-size_t gridmm_linear_planes_ln_workspace(int M, int N);
-size_t gridmm_linear_planes_ln_sync_bytes(int M);
-int gridmm_linear_planes_ln(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int Kp,
-                            const float* bias, const float* residual, int ldr, float* C_pre, int ldc, const float* gamma,
-                            const float* beta, float eps, float* Y, int ldy, void* Y_hi, void* Y_lo, int ldp, int p_rpb,
-                            int64_t p_bs, void* workspace, void* sync_words, int M, int N, int K, int dry_run,
-                            gridmm_stream_t stream);
-
-/* GEMMs around a DEFERRED LayerNorm: the LayerNorm between a dense block and its consumers is never launched.  The
- * producer GEMM (x->out_stats != NULL) leaves its pre-LayerNorm result h = A W^T + bias + residual as fp32 (C) and / or
- * bf16 planes (C_hi / C_lo) together with per-(column tile, row) statistics (mean and sum of squared deviations over the
- * tile's columns).  Whoever reads h applies the LayerNorm:
- *   - as the A operand (x->a_stats): this GEMM runs on h's planes with W' = W * gamma as its weight and computes
- *       y = act( rstd[m] (acc - mu[m] sv[n]) + bias[n] ),  sv[n] = sum_k W'[n][k],  bias = W beta + b  (caller-folded);
- *   - as the residual (x->r_stats): residual[m][n] is replaced by (residual - mu) rstd r_gamma[n] + r_beta[n] on the fly.
- * (BertSelfOutput -> BertIntermediate / BertSelfAttention, map_nav_src/models/vilmodel.py:156-209: same values as
- * dense + LayerNorm + dense, in a different association.)  a_tn / a_bn, r_tn / r_bn: number and width of the column tiles
- * of the statistics being read = what gridmm_linear_planes_lnx_tiles answered for the launch that wrote them; ln_n: width of
- * the normalised rows.  Shapes whose tile choice has no deferred form return GRIDMM_EUNSUPPORTED (.._tiles returns 0). */
-typedef struct {
-  const void* a_stats; int a_tn, a_bn; const float* sv; float a_eps;
-  const void* r_stats; int r_tn, r_bn; const float* r_gamma; const float* r_beta; float r_eps;
-  void* out_stats;
-  int ln_n;
-} gridmm_lnx_t;
-int gridmm_linear_planes_lnx_tiles(int M, int N, int K, int* tile_width);
-int gridmm_linear_planes_lnx(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int Kp,
-                             const float* bias, const float* residual, int ldr, float* C, int ldc, void* C_hi, void* C_lo,
-                             int ldp, int M, int N, int K, int act, const gridmm_lnx_t* x, gridmm_stream_t stream);
-
-/* Tuning hook: force tile configuration `cfg` (0 = back to the heuristic) for the problem shape (M, N, K) in this
- * process (tools/sweep_gemm_cfg_step.py times candidate tiles inside the captured step).  Process-global; not used by
- * the product path. */
-int gridmm_debug_gemm_cfg_override(int M, int N, int K, int cfg);
-/* The problem shapes the tile heuristic was asked about since recording started: rows (M, N, K, chosen cfg, calls) into
- * out[max_rows][5]; returns the number of rows.  log = 1 starts (and clears) the recording, 0 stops it, -1 leaves it. */
-int gridmm_debug_gemm_shapes(int* out, int max_rows, int log);
-/* The same for gridmm_attention_rows: configuration of the calls with more than / at most four 16-query tiles. */
-int gridmm_debug_attention_cfg_override(int cfg_big, int cfg_small);
-
-/* gridmm_linear_planes with the A rows taken through a batched row map: GEMM row m = row (m % a_rpb) of episode
- * (m / a_rpb) in a buffer whose episodes lie a_bs elements apart (a_rpb <= 0: plain rows, a_bs ignored; a_bs % 8 == 0).
- * A sub-sequence of a longer padded sequence is multiplied in place -- the instruction rows of the local encoder's
- * [map | txt] context (vilmodel.py:846-848), the map-node rows of [cells | nodes] (:843, :872) -- instead of being
- * gathered by torch.cat / slicing first. */
+/* Layout of a pair of weight planes handed to gridmm_linear_planes_map. */
+#define GRIDMM_W_ROWMAJOR 0   /* [N][Kp]: what gridmm_split_weight writes */
+#define GRIDMM_W_TILED 1      /* [roundup(N,16) / 16][Kp / 32][16 rows][32 k] blocks, rows past N zero (gridmm_linear_t.wt_hi):
+                               * every 1-KiB LDS-DMA piece of a BK = 32 tile is one contiguous KiB of memory.  Shapes whose tile
+                               * choice is not a BK = 32 tile return GRIDMM_EUNSUPPORTED: pass the row-major planes then. */
+/* gridmm_linear_planes in its general form.  The A rows are taken through a batched row map: GEMM row m = row (m % a_rpb)
+ * of episode (m / a_rpb) in a buffer whose episodes lie a_bs elements apart (a_rpb <= 0: plain rows, a_bs ignored;
+ * a_bs % 8 == 0).  A sub-sequence of a longer padded sequence is multiplied in place -- the instruction rows of the local
+ * encoder's [map | txt] context (vilmodel.py:846-848), the map-node rows of [cells | nodes] (:843, :872) -- instead of being
+ * copied out first.  The W planes arrive in the layout `w_layout` names (explicit: no sign-encoded arguments). */
 int gridmm_linear_planes_map(const void* A_hi, const void* A_lo, int lda, int a_rpb, int64_t a_bs, const void* W_hi,
-                             const void* W_lo, int Kp, const float* bias, const float* residual, int ldr, float* C,
-                             int ldc, void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
+                             const void* W_lo, int Kp, int w_layout, const float* bias, const float* residual, int ldr,
+                             float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
                              gridmm_stream_t stream);
 
 /* Several small plane GEMMs C_i = act_i(A_i W_i^T + b_i) in ONE launch (64x64 tiles, K % 64 == 0): the ClsPrediction
@@ -350,8 +299,8 @@ int gridmm_attention_rows_seg(const void* Q_hi, const void* Q_lo, int64_t q_bs, 
 typedef struct {                 /* nn.Linear(K, N) */
   const void *w_hi, *w_lo; const float* bias; int N, K, Kp;
   const void *wt_hi, *wt_lo;     /* optional (NULL: absent): the same planes TILED as [roundup(N,16) / 16][Kp / 32][16][32]
-                                  * blocks, rows past N zero -- what gridmm_linear_planes reads when it is handed a NEGATIVE Kp:
-                                  * every 1-KiB LDS-DMA piece of a BK = 32 tile is then one contiguous KiB of memory */
+                                  * blocks, rows past N zero (GRIDMM_W_TILED): every 1-KiB LDS-DMA piece of a BK = 32 tile is then one
+                                  * contiguous KiB of memory */
 } gridmm_linear_t;
 typedef struct { const float *gamma, *beta; float eps; } gridmm_ln_t;
 typedef struct {
@@ -359,11 +308,6 @@ typedef struct {
   gridmm_linear_t sqkv, so;      /* visn_self_att.self.{query|key|value} stacked (3H, H), visn_self_att.output.dense */
   gridmm_linear_t ffn_i, ffn_o;  /* visn_inter.dense (H -> I, gelu), visn_output.dense (I -> H) */
   gridmm_ln_t x_ln, s_ln, f_ln;  /* the three output LayerNorms */
-  /* optional (w_hi == NULL: absent): the deferred-LayerNorm form of the two inner LayerNorms (gridmm_linear_planes_lnx) --
-   * sqkv / ffn_i with the preceding LayerNorm's gamma folded into the weight (W * gamma) and beta into the bias (W beta + b),
-   * and the row sums of the folded weights.  With them (and shapes the form takes) a layer is 9 launches instead of 11. */
-  gridmm_linear_t sqkv_f, ffn_i_f;
-  const float *sqkv_sv, *ffn_i_sv;
 } gridmm_xlayer_t;
 size_t gridmm_xattn_layer_workspace(int B, int Sq, int H, int I);
 int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void* X_hi, const void* X_lo,
@@ -371,12 +315,9 @@ int gridmm_xattn_layer_fwd(const gridmm_xlayer_t* L, const float* X, const void*
                            int Sk1, const void* KV2_hi, const void* KV2_lo, int64_t kv2_bs, int kv2_rs, int k2_col,
                            int v2_col, const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask,
                            int self_mask_bs, float* Y, void* Y_hi, void* Y_lo, int y_p_rpb, int64_t y_p_bs,
-                           void* workspace, size_t workspace_bytes, void* sync_words, int B, int Sq, int Sk, int heads,
-                           gridmm_stream_t stream);
+                           void* workspace, size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream);
 /* (KV2_hi != NULL: the context rows [Sk1, Sk) come from a second K / V plane buffer, gridmm_attention_rows_seg; NULL: all
  * Sk rows from KV) */
-/* (sync_words: NULL, or the zeroed counter block of gridmm_linear_planes_ln for B * Sq rows -- the three dense +
- * residual + LayerNorm blocks then run as one launch each where the shape allows) */
 /* (y_p_rpb > 0: the output PLANES go through the row map of gridmm_layernorm_map -- Sq rows per episode into a buffer
  * whose episodes are y_p_bs elements apart, e.g. the [map | txt] context of the next encoder; 0: plain [M][H]) */
 
@@ -697,6 +638,25 @@ int gridmm_collate_nav_fill(const double* pos, const double* dist, const int32_t
                             int slots, int G, int V1, int afs, int enc_full_graph, float* gpos, float* vpos, float* pair,
                             int64_t* steps, uint8_t* visited, int64_t* slot, float* inv, uint8_t* gmask, int32_t* cand_of_node,
                             uint8_t* cand_visited);
+
+#ifdef GRIDMM_DEBUG_HOOKS
+/* ---- development build only (gridmm_amd/csrc: `make debug` -> libgridmm_hip_dbg.so) -------------------------------
+ * Process-global tuning hooks for tools/sweep_gemm_cfg_step.py / sweep_gemm_cfg_train.py; the shipping library neither
+ * exports them nor holds the state behind them (tests/test_capi_symbols.py asserts that no gridmm_debug_* symbol exists
+ * in libgridmm_hip.so). */
+/* Force tile configuration `cfg` (0 = back to the heuristic) for the problem shape (M, N, K) in this process. */
+int gridmm_debug_gemm_cfg_override(int M, int N, int K, int cfg);
+/* The problem shapes the tile heuristic was asked about since recording started: rows (M, N, K, chosen cfg, calls) into
+ * out[max_rows][5]; returns the number of rows.  log = 1 starts (and clears) the recording, 0 stops it, -1 leaves it. */
+int gridmm_debug_gemm_shapes(int* out, int max_rows, int log);
+/* The same for gridmm_attention_rows: configuration of the calls with more than / at most four 16-query tiles. */
+int gridmm_debug_attention_cfg_override(int cfg_big, int cfg_small);
+/* gridmm_linear_planes_map with an explicit tile configuration out of the whole experiment table. */
+int gridmm_debug_linear_planes_map_cfg(const void* A_hi, const void* A_lo, int lda, int a_rpb, int64_t a_bs, const void* W_hi,
+                                       const void* W_lo, int Kp, int w_layout, const float* bias, const float* residual,
+                                       int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N, int K,
+                                       int act, int cfg, gridmm_stream_t stream);
+#endif
 
 #ifdef __cplusplus
 }

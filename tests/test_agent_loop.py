@@ -342,3 +342,48 @@ def test_device_store_environment_equals_host_assembled_observations():
     for x, y in zip(a, b):
         for k in ("fused_logits", "global_logits", "local_logits", "grid_logits"):
             assert torch.equal(x["nav_outs"][k], y["nav_outs"][k]), (x["t"], k)
+
+
+def test_panorama_cache_is_bounded_lru_and_equals_the_uncached_collation():
+    """the device tables of collated panorama blocks are capped (pano_cache_slots) and recycle their least
+    recently used slots; whatever the eviction history, a step's gathered batch equals the per-step assembly."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from gridmm_amd.collate import NavCollator
+    fs, A, B = 16, 4, 2
+    args = SimpleNamespace(image_feat_size=fs, angle_feat_size=A)
+    rs = np.random.RandomState(0)
+    world = {}
+
+    def ob(vp, view):
+        key = (vp, view)
+        if key not in world:
+            nc = int(rs.randint(0, 5))
+            world[key] = dict(scan="s", viewpoint="v%d" % vp, viewIndex=view,
+                              feature=rs.randn(36, fs + A).astype(np.float32),
+                              candidate=[dict(pointId=int(p), viewpointId="c%d_%d" % (vp, p),
+                                              feature=rs.randn(fs + A).astype(np.float32))
+                                         for p in rs.choice(36, nc, replace=False)])
+        return world[key]
+
+    cached, plain = NavCollator(args, "cpu"), NavCollator(args, "cpu")
+    cached.pano_cache_slots, plain.pano_cache = 5, False
+    seq = [(0, 0), (1, 3), (2, 5), (0, 0), (3, 1), (4, 2), (5, 7), (1, 3), (6, 0), (0, 0), (7, 1), (2, 5)]
+    for t in range(len(seq) - 1):
+        obs = [ob(*seq[t]), ob(*seq[t + 1])]
+        got, want = cached.panorama(obs), plain.panorama(obs)
+        for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens"):
+            g, w = got[k], want[k]
+            n = min(g.shape[1], w.shape[1]) if g.dim() > 1 else None
+            if n is None:
+                assert torch.equal(g, w), (t, k)
+            else:
+                assert torch.equal(g[:, :n], w[:, :n]), (t, k)
+                assert not g[:, n:].any() and not w[:, n:].any()
+        assert got["cand_vpids"] == want["cand_vpids"]
+        P = cached._pano
+        assert P["cap"] <= max(5, 2 * B) and len(P["slot"]) <= P["cap"] and len(P["key_of"]) <= P["cap"]
+    assert len(world) > 5                       # more distinct states than slots: evictions happened
+    cached.clear_panorama_cache()
+    assert cached._pano is None

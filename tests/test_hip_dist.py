@@ -144,6 +144,27 @@ def test_bench_plain_invocation_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["value"] > 0
 
 
+def test_bench_plain_invocation_eight_ranks_dry_run():
+    """`python bench.py --gpus 8 --batch 4` as the driver's SCALE run issues it, all eight ranks on this one GPU (test hook,
+    gloo for the timing collectives): the N = 8 code path end to end -- self-launch under torch.distributed.run, eight
+    captures side by side, barrier + max-over-ranks timing over 8 ranks, ONE line from rank 0 that carries roofline AND
+    cpu_baseline with the whole-job value."""
+    env = dict(os.environ, GRIDMM_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "4",
+           "--no-depth-legs", "--no-train-leg", "--no-producer-leg", "--no-torch-gpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 32 and d["value"] > 0
+    assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["replay_check"]
+
+
 def test_bench_train_leg_two_ranks_exchanges_gradients():
     """The multi-rank training leg of bench.py (config 3's measuring path): both ranks on this GPU (gloo), every rank runs the
     full-size pre-training step, GradientReducer exchanges the gradients (direct reduce-scatter / all-gather form), the

@@ -1,4 +1,6 @@
 """Device time (hipGraph-timed) of gridmm_transpose_v and gridmm_attention_planes per attention shape of the step."""
+import os
+os.environ.setdefault("GRIDMM_LIB_DEBUG", "1")   # development build: tile overrides + the whole experiment table (make -C gridmm_amd/csrc debug)
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

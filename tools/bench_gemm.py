@@ -1,4 +1,6 @@
 """Micro-benchmark of gridmm_linear_planes tile configurations on the step's GEMM shapes (GPU only)."""
+import os
+os.environ.setdefault("GRIDMM_LIB_DEBUG", "1")   # development build: tile overrides + the whole experiment table (make -C gridmm_amd/csrc debug)
 import ctypes
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

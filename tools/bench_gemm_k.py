@@ -1,4 +1,6 @@
 """Fixed cost vs per-k-step cost of gridmm_linear_planes: time over K for a few (M, N, cfg) -- GPU only."""
+import os
+os.environ.setdefault("GRIDMM_LIB_DEBUG", "1")   # development build: tile overrides + the whole experiment table (make -C gridmm_amd/csrc debug)
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,7 @@
 """Is the planes GEMM bound by where its operands come from?  Same launch with the A rows collapsed onto one row
 (lda = 0: the whole A stream is L1/L2-resident) and / or a tiny W (all tiles read the same weight rows) -- GPU only."""
+import os
+os.environ.setdefault("GRIDMM_LIB_DEBUG", "1")   # development build: tile overrides + the whole experiment table (make -C gridmm_amd/csrc debug)
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

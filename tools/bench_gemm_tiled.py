@@ -1,6 +1,8 @@
 """Micro-benchmark: row-major vs tiled W vs tiled W + tiled A planes (16 x 32 blocks) for the BK = 32 tiles, hipGraph of 40 calls
 with rotating cold weights (GPU only).  The A-side experiment: is tiling the ACTIVATION planes worth a change through every
 producer kernel?"""
+import os
+os.environ.setdefault("GRIDMM_LIB_DEBUG", "1")   # development build: tile overrides + the whole experiment table (make -C gridmm_amd/csrc debug)
 import ctypes
 import os
 import sys
@@ -27,7 +29,6 @@ def main():
     for (M, N, K) in SHAPES:
         x = torch.randn(M, K, device=dev)
         a = ops.split_rows(x)
-        ah, al = tile(a.hi), tile(a.lo)
         ncopy = min(64, max(2, int(700e6 // (N * K * 4)) + 1))
         pws = [ops.PackedLinear(torch.randn(N, K, device=dev) * 0.05, torch.randn(N, device=dev)) for _ in range(ncopy)]
         for q in pws:
@@ -35,17 +36,13 @@ def main():
         c = torch.empty(M, N, device=dev)
         res = {}
         outs = {}
-        for mode in ("row-major", "tiled W", "tiled W + A"):
+        for mode in ("row-major", "tiled W"):      # (the tiled-A probe of round 4 -- -5..-7 % per launch, profiles/r4_tiled_weights.txt --
+                                                   # was a kernel flag that round 5 removed with the other experiment residue)
             def call(i):
                 q = pws[i % ncopy]
-                if mode == "row-major":
-                    args = (a.hi, a.lo, K, q.hi, q.lo, q.Kp)
-                elif mode == "tiled W":
-                    args = (a.hi, a.lo, K, q._tiled[0], q._tiled[1], -q.Kp)
-                else:
-                    args = (ah, al, -K, q._tiled[0], q._tiled[1], -q.Kp)
-                rc = lib.gridmm_linear_planes_cfg(args[0].data_ptr(), args[1].data_ptr(), args[2], args[3].data_ptr(), args[4].data_ptr(),
-                                                  args[5], q.bias.data_ptr(), None, 0, c.data_ptr(), N, None, None, 0, M, N, K, 0, 0, st())
+                wh, wl, lay = (q.hi, q.lo, _lib.W_ROWMAJOR) if mode == "row-major" else (q._tiled[0], q._tiled[1], _lib.W_TILED)
+                rc = lib.gridmm_linear_planes_map(a.hi.data_ptr(), a.lo.data_ptr(), K, 0, 0, wh.data_ptr(), wl.data_ptr(), q.Kp, lay,
+                                                  q.bias.data_ptr(), None, 0, c.data_ptr(), N, None, None, 0, M, N, K, 0, st())
                 assert rc == 0, rc
             call(0)
             torch.cuda.synchronize()
@@ -64,7 +61,7 @@ def main():
                 e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) * 1e3 / 40)
             res[mode] = best
-        same = torch.equal(outs["row-major"], outs["tiled W"]) and torch.equal(outs["row-major"], outs["tiled W + A"])
+        same = torch.equal(outs["row-major"], outs["tiled W"])
         print("%5d x %4d x %4d | " % (M, N, K) + " | ".join("%s %6.1f us" % (k, v) for k, v in res.items()) + " | same bits: %s" % same, flush=True)
 
 

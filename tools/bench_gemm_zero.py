@@ -1,4 +1,6 @@
 """Is the planes GEMM power/clock-limited?  Same launches on random vs zero-filled operands (GPU only)."""
+import os
+os.environ.setdefault("GRIDMM_LIB_DEBUG", "1")   # development build: tile overrides + the whole experiment table (make -C gridmm_amd/csrc debug)
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

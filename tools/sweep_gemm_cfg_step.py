@@ -4,6 +4,8 @@ step and time its replays, alternating with the heuristic's choice (A B A B: box
 The isolated micro-benchmark (tools/bench_gemm.py) sees operands that differ from the step's: here A was just written by
 the previous launch and the L2s were flushed at the kernel boundary.
 usage: PYTHONPATH=. python tools/sweep_gemm_cfg_step.py [thin | all | attention] ..."""
+import os
+os.environ.setdefault("GRIDMM_LIB_DEBUG", "1")   # development build: tile overrides + the whole experiment table (make -C gridmm_amd/csrc debug)
 import argparse
 import os
 import sys
@@ -21,7 +23,7 @@ THIN = [(1824, 768, 768), (1824, 768, 3072), (1824, 2304, 768), (1824, 3072, 768
 CANDS_ALL = [43, 8, 4, 6, 9, 13, 21, 15, 14, 1, 2, 12, 16, 3, 36, 42, 44]
 BIG = [(6912, 3072, 768), (6912, 768, 3072), (6912, 768, 768), (6912, 2304, 768), (9472, 6144, 768), (1824, 2304, 768),
        (1824, 3072, 768), (6272, 768, 512)]
-CANDS_BIG = [15, 36, 16, 14, 12, 48, 3]        # BK = 32 tiles, all with tiled weight planes
+CANDS_BIG = [15, 36, 60, 61, 62, 63, 64, 16]        # BK = 32 tiles, all with tiled weight planes
 CANDS_THIN = [43, 8, 13, 21, 50, 52, 53, 55, 56, 6, 9, 15]
 ATT_BIG = [9, 3, 20, 21, 22, 23, 24, 25]
 ATT_SMALL = [5, 1, 15, 18]

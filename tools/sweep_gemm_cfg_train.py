@@ -2,6 +2,8 @@
 (gridmm_debug_gemm_shapes), then for the shapes that carry the most launches forces each candidate configuration,
 re-captures the step and times its replays, alternating with the heuristic (A B A B).
 usage: PYTHONPATH=. python tools/sweep_gemm_cfg_train.py [task] [n_shapes]"""
+import os
+os.environ.setdefault("GRIDMM_LIB_DEBUG", "1")   # development build: tile overrides + the whole experiment table (make -C gridmm_amd/csrc debug)
 import ctypes
 import os
 import sys
