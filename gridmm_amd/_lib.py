@@ -81,6 +81,12 @@ SIGNATURES = {
     "gridmm_attention_bwd": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i64, _i,
                              _vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f,
                              ctypes.c_uint64, _vp, _vp],
+    "gridmm_attention_rows_train": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _vp,
+                                    _i64, _i, _vp, _i, _vp, _i64, _i, _i, _i, _i, _f, _f, ctypes.c_uint64, _vp, _vp],
+    "gridmm_linear_planes_shift": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gridmm_attention_rows_bwd": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i64, _i,
+                                  _vp, _vp, _i64, _vp, ctypes.c_size_t, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f,
+                                  ctypes.c_uint64, _vp, _vp],
     "gridmm_grid_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_grid_aggregate_bwd_routed": [_vp] * 9 + [_i, _i, _i, _i, _vp],
     "gridmm_fuse_logits_bwd": [_vp] * 16 + [_i, _i, _i, _vp],
@@ -95,9 +101,9 @@ SIGNATURES = {
     "gridmm_multi_adamw_step": [_vp, _vp, _i, _i, _f, _f, _i, _vp, _f, _vp],
     "gridmm_xattn_layer_train_saved_bytes": [_i, _i, _i, _i],
     "gridmm_xattn_layer_train_workspace": [_i, _i, _i, _i],
-    "gridmm_xattn_layer_train_fwd": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp,
+    "gridmm_xattn_layer_train_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp,
                                      ctypes.c_size_t, _i, _i, _i, _i, _vp],
-    "gridmm_xattn_layer_bwd": [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, ctypes.c_size_t, _vp, _vp, _vp, _i64, _i,
+    "gridmm_xattn_layer_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, ctypes.c_size_t, _vp, _vp, _vp, _i64, _i,
                                _vp, _vp, ctypes.c_size_t, _i, _i, _i, _i, _vp],
     # host-side helpers of the agent loop (no device work)
     "gridmm_route_lengths": [_vp, _i, _i, _vp, _vp, _vp, _i, _vp],
@@ -148,6 +154,8 @@ def load(debug=None):
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
+    lib.gridmm_attention_rows_bwd_workspace.argtypes = [_i, _i, _i]
+    lib.gridmm_attention_rows_bwd_workspace.restype = ctypes.c_size_t
     lib.gridmm_grid_aggregate_workspace.restype = ctypes.c_size_t
     lib.gridmm_xattn_layer_train_saved_bytes.restype = ctypes.c_size_t
     lib.gridmm_xattn_layer_train_workspace.restype = ctypes.c_size_t

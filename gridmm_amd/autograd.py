@@ -101,11 +101,13 @@ def _as2d(x):
     return x, M, K, ld
 
 
-def _gemm(a2d, pw, bias=None, residual=None):
-    """(M,K) fp32 @ packed (N,K)^T -> (M,N) fp32 through ops.linear (planes kernel when shapes allow)."""
+def _gemm(a2d, pw, bias=None, residual=None, planes=False, plane_shift=None):
+    """(M,K) fp32 @ packed (N,K)^T -> (M,N) fp32 through ops.linear (planes kernel when shapes allow).  planes: also the
+    bf16 hi/lo planes of the result from the same epilogue -> (fp32, hi, lo); plane_shift: see ops.linear."""
     pw.bias = bias
     try:
-        return ops.linear(a2d, pw, residual=residual, allow_tiled=False).f32
+        act = ops.linear(a2d, pw, residual=residual, allow_tiled=False, want_planes=planes, plane_shift=plane_shift)
+        return (act.f32, act.hi, act.lo) if planes else act.f32
     finally:
         pw.bias = None
 
@@ -209,7 +211,7 @@ class _Linear(torch.autograd.Function):
     for dW instead of the fp32 input), the backward's dY pass emits row planes (dX GEMM), dY^T planes (dW GEMM) and db."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, packs):
+    def forward(ctx, x, weight, bias, residual, packs, out_planes=False):
         ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
         K = x.shape[-1]
         ctx.packs = packs
@@ -230,7 +232,26 @@ class _Linear(torch.autograd.Function):
         elif need_w and K % 8 == 0:
             xh, xl, _, Mp, rows = transpose_split(x2, want_rows=True)
             xt, a = (xh, xl, Mp), rows
-        y = _gemm(a, packs(False), None if bias is None else bias.detach().float(), r2)
+        want_out = out_planes is not False and out_planes is not None and weight.shape[0] % 8 == 0 and K % 32 == 0
+        # out_planes = an int c0 (not True): the planes of the columns >= c0 are SHIFTED by row 0 of their episode (k | v
+        # projections; csrc/attention_train.hip "SHIFTED K / V").  The shift table = the projection of row 0 of every episode:
+        # one B-row GEMM over the A planes through the batched row map.
+        shift = None
+        bvec = None if bias is None else bias.detach().float()
+        if want_out and out_planes is not True and x.dim() == 3 and isinstance(a, ops.Act) and a.hi is not None and r2 is None:
+            B_, S_ = x.shape[0], x.shape[1]
+            pwf = packs(False)
+            pwf.bias = bvec
+            try:
+                shift = ops.linear(ops.Act(None, a.hi[:B_ * S_].view(B_, S_, K)[:, :1], a.lo[:B_ * S_].view(B_, S_, K)[:, :1]), pwf,
+                                   allow_tiled=False).f32.view(B_, weight.shape[0])
+            finally:
+                pwf.bias = None
+        y = _gemm(a, packs(False), bvec, r2, planes=want_out,
+                  plane_shift=None if shift is None else (shift, x.shape[1], int(out_planes)))
+        yh = yl = None
+        if want_out:
+            y, yh, yl = y
         if xt is not None:
             ctx.save_for_backward(xt[0], xt[1], weight)
             ctx.Mp, ctx.saved_t = xt[2], True
@@ -238,12 +259,16 @@ class _Linear(torch.autograd.Function):
             ctx.save_for_backward(x2, weight)
             ctx.saved_t = False
         ctx.has_bias, ctx.has_res, ctx.M = bias is not None, residual is not None, x2.shape[0]
-        return y.view(*x.shape[:-1], weight.shape[0])
+        y = y.view(*x.shape[:-1], weight.shape[0])
+        if yh is not None:          # the consumer (the attention kernels on the bf16 matrix pipe) reads the planes, not y
+            _tag_planes(y, yh.view(y.shape), yl.view(y.shape))
+            y._gridmm_shift = shift         # (B, N) fp32 or None: row 0 of every episode (the planes >= c0 are relative to it)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
-            return (None,) * 5
+            return (None,) * 6
         weight = ctx.saved_tensors[-1]
         N, K = weight.shape
         dy2 = dy.contiguous().view(-1, N)
@@ -266,12 +291,15 @@ class _Linear(torch.autograd.Function):
                 xh, xl, _, _, _ = transpose_split(ctx.saved_tensors[0])
                 xt = (xh, xl)
             dw = _gemm_tn((yh, yl), xt, N, K, M, Mp, dy2).to(weight.dtype)
-        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None), None
+        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None), None, None
 
 
-def linear(x, weight, bias=None, residual=None):
-    """x (..., K) @ weight (N, K)^T + bias (+ residual)."""
-    return _Linear.apply(x, weight, bias, residual, WEIGHTS.getter(weight))
+def linear(x, weight, bias=None, residual=None, out_planes=False):
+    """x (..., K) @ weight (N, K)^T + bias (+ residual).  out_planes: the GEMM epilogue also writes the bf16 hi/lo planes of
+    the result and hangs them on the returned tensor (q / k / v projections: the attention kernels take planes).  True: plain
+    planes (a q projection); an int c0: the planes of the columns >= c0 are shifted by row 0 of their episode (H for a fused
+    q | k | v projection, 0 for a k | v projection) and the tensor also carries that row (`_gridmm_shift`)."""
+    return _Linear.apply(x, weight, bias, residual, WEIGHTS.getter(weight), out_planes)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -397,9 +425,46 @@ def relu(x):
     return _Activation.apply(x, 2)
 
 
+BF16_ATTENTION = bool(int(__import__('os').environ.get('GRIDMM_TRAIN_ATTENTION_BF16', '1')))   # A/B switch: 0 = exact-fp32 MFMA kernels
+
+
+def _planes_of(t):
+    """(hi, lo) planes a producer hung on `t` (shape of t, contiguous), or None."""
+    p = getattr(t, "_gridmm_planes", None)
+    if p is None or p[2] != t._version or not t.is_contiguous() or tuple(p[0].shape) != tuple(t.shape):
+        return None
+    return p[0], p[1]
+
+
+def _planes_strided(t):
+    """(hi, lo) plane views with the shape AND strides of `t` (a column block of a tagged projection, see tag_plane_views),
+    or None."""
+    p = getattr(t, "_gridmm_planes", None)
+    if p is None or p[2] != t._version or tuple(p[0].shape) != tuple(t.shape) or p[0].stride() != t.stride() or \
+            p[1].stride() != t.stride():
+        return None
+    return p[0], p[1]
+
+
+def split_with_planes(t, width):
+    """t.split(width, dim=-1) whose pieces carry the matching column blocks of t's planes (the [k | v] blocks the layers of
+    the local encoder read out of ONE shared context projection, map_nav_src/models/vilmodel.py:843-853)."""
+    parts = t.split(width, dim=-1)
+    p = _planes_of(t)
+    if p is not None:
+        sh = getattr(t, "_gridmm_shift", None)
+        shs = sh.split(width, dim=-1) if sh is not None else [None] * len(parts)
+        for part, hi, lo, s_ in zip(parts, p[0].split(width, dim=-1), p[1].split(width, dim=-1), shs):
+            _tag_planes(part, hi, lo)
+            part._gridmm_shift = s_
+    return parts
+
+
 class _Attention(torch.autograd.Function):
     """q_src (B,Sq,nq*H) with q at column q_col; kv_src (B,Sk,nk*H) with k at k_col, v at v_col (fused projection
-    outputs are consumed in place through strides).  Returns (B,Sq,H)."""
+    outputs are consumed in place through strides).  Returns (B,Sq,H).  When the projections carry their bf16 planes
+    (linear(..., out_planes=True)) forward and backward run on the bf16 matrix pipe (gridmm_attention_rows_train / _bwd:
+    3-term split, K / V -- Q / dO in the backward -- staged in LDS); otherwise on the exact-fp32 kernels."""
 
     @staticmethod
     def forward(ctx, q_src, kv_src, kmask, cols, heads, dropout_p=0.0):
@@ -409,15 +474,22 @@ class _Attention(torch.autograd.Function):
         same = kv_src is None
         if same:
             kv_src = q_src
+        def planes(t):     # planes with t's strides (a column block of a shared projection is read in place)
+            p = _planes_strided(t) if BF16_ATTENTION else None
+            ok = p is not None and t.dim() == 3 and t.stride(2) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0
+            return p if ok else None
+        qp = planes(q_src)
+        kp = qp if same else planes(kv_src)
+        fast = qp is not None and kp is not None and kv_src.shape[1] <= 2048
         def usable(t):     # the kernels take batch / row strides: a column block of a wider projection is read in place
             return t.dtype == torch.float32 and t.stride(-1) == 1 and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 \
                 and t.data_ptr() % 16 == 0
-        q_src = q_src if usable(q_src) else q_src.contiguous()
-        kv_src = q_src if same else (kv_src if usable(kv_src) else kv_src.contiguous())
+        if not fast:
+            q_src = q_src if usable(q_src) else q_src.contiguous()
+            kv_src = q_src if same else (kv_src if usable(kv_src) else kv_src.contiguous())
         qc, kc, vc = cols
         B, Sq = q_src.shape[:2]
         Sk = kv_src.shape[1]
-        q, k, v = q_src[..., qc:qc + H], kv_src[..., kc:kc + H], kv_src[..., vc:vc + H]
         if kmask is not None:
             kmask = kmask.contiguous()
             kmask = kmask.view(torch.uint8) if kmask.dtype == torch.bool else kmask.to(torch.uint8)
@@ -434,11 +506,28 @@ class _Attention(torch.autograd.Function):
         hi = lo = None
         if TN_GEMM:
             hi, lo = ops._planes_like(out.shape, out.device)     # the output projection's A operand, straight from the kernel
-        _lib.check(lib.gridmm_attention_train_planes(
-            _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
-            _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(hi), _p(lo), Sq * H, H, _p(lse), Sqp,
-            B, heads, Sq, Sk, scale, float(dropout_p), seed, _p(seed_dev), _stream()), "gridmm_attention_train")
-        ctx.save_for_backward(q_src, kv_src, kmask, out, lse)
+        mbs = kmask.stride(0) if kmask is not None else 0
+        if fast:
+            qs, ks = (q_src.stride(0), q_src.stride(1)), (kv_src.stride(0), kv_src.stride(1))
+            off = lambda t, c: ctypes.c_void_p(t.data_ptr() + 2 * c)      # noqa: E731  (bf16 planes: 2 bytes per element)
+            sh = getattr(kv_src, "_gridmm_shift", None)                  # (B, width) row 0 of every episode: shifted k | v planes
+            assert sh is None or (sh.dim() == 2 and sh.stride(1) == 1 and sh.dtype == torch.float32)
+            vb = ctypes.c_void_p(sh.data_ptr() + 4 * vc) if sh is not None else ctypes.c_void_p(0)
+            vbs = sh.stride(0) if sh is not None else 0
+            _lib.check(lib.gridmm_attention_rows_train(
+                off(qp[0], qc), off(qp[1], qc), qs[0], qs[1], off(kp[0], kc), off(kp[1], kc), ks[0], ks[1], off(kp[0], vc),
+                off(kp[1], vc), ks[0], ks[1], _p(kmask), mbs, _p(out), Sq * H, H, _p(hi), _p(lo), Sq * H, H, _p(lse), Sqp, vb, vbs,
+                B, heads, Sq, Sk, scale, float(dropout_p), seed, _p(seed_dev), _stream()), "gridmm_attention_rows_train")
+            ctx.save_for_backward(qp[0], qp[1], kp[0], kp[1], kmask, out, lse, *([sh] if sh is not None else []))
+            ctx.q_shape, ctx.kv_shape, ctx.strides = tuple(q_src.shape), tuple(kv_src.shape), (qs, ks)
+        else:
+            q, k, v = q_src[..., qc:qc + H], kv_src[..., kc:kc + H], kv_src[..., vc:vc + H]
+            _lib.check(lib.gridmm_attention_train_planes(
+                _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+                _p(kmask), mbs, _p(out), Sq * H, H, _p(hi), _p(lo), Sq * H, H, _p(lse), Sqp,
+                B, heads, Sq, Sk, scale, float(dropout_p), seed, _p(seed_dev), _stream()), "gridmm_attention_train")
+            ctx.save_for_backward(q_src, kv_src, kmask, out, lse)
+        ctx.fast = fast
         ctx.cols, ctx.heads, ctx.same, ctx.scale = cols, heads, same, scale
         ctx.dropout_p, ctx.seed, ctx.seed_dev = float(dropout_p), seed, seed_dev
         return _tag_planes(out, hi, lo) if hi is not None else out
@@ -448,17 +537,45 @@ class _Attention(torch.autograd.Function):
         if dout is None:
             return (None,) * 6
         lib = _lib.load()
-        q_src, kv_src, kmask, out, lse = ctx.saved_tensors
         heads, H = ctx.heads, ctx.heads * 64
         qc, kc, vc = ctx.cols
-        B, Sq = q_src.shape[:2]
-        Sk = kv_src.shape[1]
-        Sqp = lse.shape[2]
         dout = dout.contiguous()
         # the kernels write every row of the q / k / v column blocks; only columns outside them (the K|V blocks of the
         # other layers in a shared context projection) need the zero fill
         def covered(width, blocks):
             return sorted(blocks) == list(range(0, width, H)) and width % H == 0
+        if ctx.fast:
+            qh, ql, kh, kl, kmask, out, lse, *shl = ctx.saved_tensors
+            sh = shl[0] if shl else None
+            vb = ctypes.c_void_p(sh.data_ptr() + 4 * vc) if sh is not None else ctypes.c_void_p(0)
+            vbs = sh.stride(0) if sh is not None else 0
+            q_shape, kv_shape = ctx.q_shape, ctx.kv_shape
+            B, Sq, Wq = q_shape
+            Sk, Wk = kv_shape[1], kv_shape[2]
+            Sqp = lse.shape[2]
+            dev = dout.device
+            mk = lambda shape, full: (torch.empty if full else torch.zeros)(shape, dtype=torch.float32, device=dev)   # noqa: E731
+            if ctx.same:
+                dq_src = mk(q_shape, covered(Wq, [qc, kc, vc]))
+                dkv_src = dq_src
+            else:
+                dq_src = mk(q_shape, covered(Wq, [qc]))
+                dkv_src = mk(kv_shape, covered(Wk, [kc, vc]))
+            need = lib.gridmm_attention_rows_bwd_workspace(B, heads, Sq)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            off = lambda t, c: ctypes.c_void_p(t.data_ptr() + 2 * c)      # noqa: E731
+            foff = lambda t, c: ctypes.c_void_p(t.data_ptr() + 4 * c)     # noqa: E731
+            qs, ks = ctx.strides
+            _lib.check(lib.gridmm_attention_rows_bwd(
+                off(qh, qc), off(ql, qc), qs[0], qs[1], off(kh, kc), off(kl, kc), ks[0], ks[1], off(kh, vc), off(kl, vc), ks[0], ks[1],
+                _p(kmask), kmask.stride(0) if kmask is not None else 0, _p(out), Sq * H, H, _p(dout), Sq * H, H, _p(lse), vb, vbs,
+                _p(ws), need, foff(dq_src, qc), Sq * Wq, Wq, foff(dkv_src, kc), Sk * Wk, Wk, foff(dkv_src, vc), Sk * Wk, Wk, B, heads, Sq, Sk,
+                Sqp, ctx.scale, ctx.dropout_p, ctx.seed, _p(ctx.seed_dev), _stream()), "gridmm_attention_rows_bwd")
+            return dq_src, (None if ctx.same else dkv_src), None, None, None, None
+        q_src, kv_src, kmask, out, lse = ctx.saved_tensors
+        B, Sq = q_src.shape[:2]
+        Sk = kv_src.shape[1]
+        Sqp = lse.shape[2]
         cf = dict(memory_format=torch.contiguous_format)     # (the sources may be strided column blocks: dense gradients)
         if ctx.same:
             dq_src = (torch.empty_like if covered(q_src.shape[-1], [qc, kc, vc]) else torch.zeros_like)(q_src, **cf)
@@ -780,7 +897,7 @@ class _CXLayerTrain(ctypes.Structure):
     _fields_ = [(n, _CLinearTrain) for n in ("xq", "xo", "sqkv", "so", "ffn_i", "ffn_o")] + \
                [(n, _CLnTrain) for n in ("x_ln", "s_ln", "f_ln")] + \
                [("p_hidden", ctypes.c_float), ("p_attn", ctypes.c_float), ("seed", ctypes.c_ulonglong * 5),
-                ("seed_dev", ctypes.c_void_p)]
+                ("seed_dev", ctypes.c_void_p), ("attention_fp32", ctypes.c_int)]
 
 
 class _CXLayerGrads(ctypes.Structure):
@@ -805,8 +922,11 @@ class _XLayer(torch.autograd.Function):
         B, Sq = x.shape[:2]
         Sk = kv.shape[1]
         x2 = x.float().contiguous()
+        kvp = _planes_strided(kv) if BF16_ATTENTION else None     # planes of the context projections (same strides as kv)
+        kvs = getattr(kv, "_gridmm_shift", None) if kvp is not None else None   # (B, width): row 0 of every episode (shifted planes)
         if kv.stride(2) != 1 or kv.dtype != torch.float32:
-            kv = kv.float().contiguous()
+            kv, kvp, kvs = kv.float().contiguous(), None, None
+        assert kvs is None or (kvs.dim() == 2 and kvs.stride(1) == 1 and kvs.shape[1] == kv.shape[2])
         (xqw, xqb, xow, xob, qw, qb, kw, kb, vw, vb, sow, sob, fiw, fib, fow, fob, xg, xb, sg, sb, fg, fb) = params
         qkvw = torch.cat([qw, kw, vw], 0)
         qkvb = torch.cat([qb, kb, vb], 0)
@@ -830,7 +950,7 @@ class _XLayer(torch.autograd.Function):
         seed_dev = SEED_DEV if ((p_attn > 0 or p_hidden > 0) and hs.MODE is not None) else None
         L = _CXLayerTrain(lin(xqw, xqb), lin(xow, xob), lin(qkvw, qkvb), lin(sow, sob), lin(fiw, fib), lin(fow, fob),
                           lnp(xg, xb, eps[0]), lnp(sg, sb, eps[1]), lnp(fg, fb, eps[2]), float(p_hidden), float(p_attn),
-                          (ctypes.c_ulonglong * 5)(*seeds), _ptr(seed_dev))
+                          (ctypes.c_ulonglong * 5)(*seeds), _ptr(seed_dev), 0 if BF16_ATTENTION else 1)
 
         def u8(m):
             if m is None:
@@ -842,10 +962,11 @@ class _XLayer(torch.autograd.Function):
         ws = torch.empty(int(lib.gridmm_xattn_layer_train_workspace(B, Sq, H, I)), dtype=torch.uint8, device=x.device)
         y = torch.empty(B, Sq, H, dtype=torch.float32, device=x.device)
         _lib.check(lib.gridmm_xattn_layer_train_fwd(
-            ctypes.byref(L), _p(x2), _p(kv), kv.stride(0), kv.stride(1), int(k_col), int(k_col) + H, _p(cm),
+            ctypes.byref(L), _p(x2), _p(kv), _p(kvp[0] if kvp else None), _p(kvp[1] if kvp else None), _p(kvs),
+            kvs.stride(0) if kvs is not None else 0, kv.stride(0), kv.stride(1), int(k_col), int(k_col) + H, _p(cm),
             cm.stride(0) if cm is not None else 0, _p(sm), sm.stride(0) if sm is not None else 0, _p(y), _p(saved),
             saved.numel(), _p(ws), ws.numel(), B, Sq, Sk, heads, _stream()), "gridmm_xattn_layer_train_fwd")
-        ctx.save_for_backward(x2, kv, cm, sm, saved)
+        ctx.save_for_backward(x2, kv, cm, sm, saved, *(kvp if kvp else ()), *([kvs] if kvs is not None else []))
         ctx.L, ctx.keep, ctx.dims = L, keep, (B, Sq, Sk, H, I, heads, int(k_col))
         ctx.shapes = [tuple(p.shape) for p in params]
         return y
@@ -853,7 +974,8 @@ class _XLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x2, kv, cm, sm, saved = ctx.saved_tensors
+        x2, kv, cm, sm, saved, *rest = ctx.saved_tensors
+        kvp, kvs = rest[:2], (rest[2] if len(rest) > 2 else None)
         B, Sq, Sk, H, I, heads, k_col = ctx.dims
         dev = dy.device
         dy = dy.contiguous()
@@ -871,7 +993,8 @@ class _XLayer(torch.autograd.Function):
         dkv = (torch.empty if covered else torch.zeros)(B, Sk, C, **f32)    # K / V blocks of other layers: zero gradient here
         ws = torch.empty(int(lib.gridmm_xattn_layer_train_workspace(B, Sq, H, I)), dtype=torch.uint8, device=dev)
         _lib.check(lib.gridmm_xattn_layer_bwd(
-            ctypes.byref(ctx.L), _p(x2), _p(kv), kv.stride(0), kv.stride(1), k_col, k_col + H, _p(cm),
+            ctypes.byref(ctx.L), _p(x2), _p(kv), _p(kvp[0] if kvp else None), _p(kvp[1] if kvp else None), _p(kvs),
+            kvs.stride(0) if kvs is not None else 0, kv.stride(0), kv.stride(1), k_col, k_col + H, _p(cm),
             cm.stride(0) if cm is not None else 0, _p(sm), sm.stride(0) if sm is not None else 0, _p(saved), saved.numel(),
             _p(dy), _p(dx), _p(dkv), Sk * C, C, ctypes.byref(G), _p(ws), ws.numel(), B, Sq, Sk, heads, _stream()),
             "gridmm_xattn_layer_bwd")

@@ -16,7 +16,7 @@ inline int mp32(int M) { return (M + 31) / 32 * 32; }
 // Layout of the saved block (forward writes, backward reads).  T planes: [C][Mp] hi then lo.
 struct Saved {
   unsigned short *xT, *cT, *a1T, *c2T, *a2T, *gT;   // transposed planes of every Linear input
-  float *q, *c, *lse_x, *h1, *a1, *qkv, *c2, *lse_s, *h2, *a2, *f1, *h3;
+  float *q, *c, *lse_x, *h1, *a1, *qkv, *c2, *lse_s, *h2, *a2, *f1, *h3, *qkv_shift;
   size_t bytes;
 };
 
@@ -43,6 +43,7 @@ Saved carve_saved(char* base, int B, int Sq, int H, int I, int heads) {
   s.a2 = (float*)take(M * H * 4);
   s.f1 = (float*)take(M * (size_t)I * 4);
   s.h3 = (float*)take(M * H * 4);
+  s.qkv_shift = (float*)take((size_t)B * 3 * H * 4);   // row 0 of every episode's q | k | v projection (shifted K / V planes)
   s.bytes = (size_t)(w - base);
   return s;
 }
@@ -58,21 +59,30 @@ bool shapes_ok(const gridmm_xlayer_train_t* L, int H, int I) {
 // y (M, N) fp32 = x W^T + b (+ R): the forward of autograd._Linear -- one pass over x writes its row planes, zero padded
 // to Mp rows, into the SAVED block (`xP`: hi [Mp][K] then lo): the A operand of this GEMM and, in the backward, an operand
 // of dW = dY^T X through gridmm_linear_planes_tn (no transposed copy of x).
+// (yP != NULL: the result also -- or, with y == NULL, only -- as bf16 planes hi [M][N] then lo: what the attention kernels on
+// the bf16 matrix pipe read)
 int linear_fwd(const gridmm_linear_train_t& l, const float* x, unsigned short* xP, unsigned short* /*rows*/, const float* R,
-               float* y, int M, int act, gridmm_stream_t st) {
+               float* y, int M, int act, gridmm_stream_t st, unsigned short* yP = nullptr) {
   const int K = l.K, Mp = mp32(M);
   int rc = gridmm_split_rows_pad(x, K, xP, xP + (size_t)K * Mp, K, nullptr, nullptr, M, K, Mp, st);
   if (rc != GRIDMM_OK) return rc;
-  return gridmm_linear_planes(xP, xP + (size_t)K * Mp, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, nullptr,
-                              nullptr, 0, M, l.N, K, act, st);
+  return gridmm_linear_planes(xP, xP + (size_t)K * Mp, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, yP,
+                              yP ? yP + (size_t)M * l.N : nullptr, l.N, M, l.N, K, act, st);
 }
 
 // The same when the producer of x (LayerNorm, GELU, attention) already wrote its planes into the saved block.
 int linear_fwd_planes(const gridmm_linear_train_t& l, const unsigned short* xP, const float* R, float* y, int M, int act,
-                      gridmm_stream_t st) {
+                      gridmm_stream_t st, unsigned short* yP = nullptr) {
   const int K = l.K, Mp = mp32(M);
-  return gridmm_linear_planes(xP, xP + (size_t)K * Mp, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, nullptr,
-                              nullptr, 0, M, l.N, K, act, st);
+  return gridmm_linear_planes(xP, xP + (size_t)K * Mp, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, yP,
+                              yP ? yP + (size_t)M * l.N : nullptr, l.N, M, l.N, K, act, st);
+}
+
+// The cross attention runs on the bf16 matrix pipe (gridmm_attention_rows_train / _bwd) when the caller hands the planes of
+// the context's K / V projections; the self attention always does (its q | k | v planes come from this layer's own GEMM).
+// The fp32 regions `q` / `qkv` of the saved block then hold the PLANES of q / qkv (hi [M][N] then lo: the same bytes).
+bool planes_ok(const void* KV_hi, const void* KV_lo, int64_t kv_bs, int kv_rs, int k_col, int v_col, int Sk) {
+  return KV_hi && KV_lo && Sk <= 2048 && !(kv_bs & 7) && !(kv_rs & 7) && !(k_col & 7) && !(v_col & 7);
 }
 
 // Backward of one Linear (autograd._Linear.backward): dY -> [one pass: zero-padded row planes + column sums = db],
@@ -111,11 +121,13 @@ extern "C" size_t gridmm_xattn_layer_train_workspace(int B, int Sq, int H, int I
   const size_t lnws = a256((M + 3) / 4 * 2 * H * 4), delta = a256((size_t)B * (H / 64) * ((Sq + 15) / 16 * 16) * 4);
   // gradients in flight: dh (M,H) x2, da (M,H) x2, dc (M,H), dqkv (M,3H), dg (M,I), df1 (M,I)
   const size_t grads = a256(M * H * 4) * 5 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) * 2;
-  return rows + yT + cs + splitk + lnws + delta + grads + 4096;
+  return rows + yT + cs + splitk + lnws + delta + grads + a256(gridmm_attention_rows_bwd_workspace(B, H / 64, Sq)) + 4096;
 }
 
-extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, int64_t kv_bs,
-                                            int kv_rs, int k_col, int v_col, const uint8_t* ctx_mask, int ctx_mask_bs,
+extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, const void* KV_hi,
+                                            const void* KV_lo, const float* KV_shift, int64_t kv_shift_bs, int64_t kv_bs,
+                                            int kv_rs, int k_col, int v_col,
+                                            const uint8_t* ctx_mask, int ctx_mask_bs,
                                             const uint8_t* self_mask, int self_mask_bs, float* Y, void* saved,
                                             size_t saved_bytes, void* workspace, size_t workspace_bytes, int B, int Sq,
                                             int Sk, int heads, gridmm_stream_t stream) {
@@ -143,19 +155,47 @@ extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, cons
     return gridmm_layernorm(x, H, r, H, p.gamma, p.beta, p.eps, y, H, nullptr, 0, nullptr, nullptr, yP, yl, H, M, H, stream);
   };
   // ---- cross attention (vilmodel.py:370-379)
-  GRIDMM_TRY(linear_fwd(L->xq, X, s.xT, rows, nullptr, s.q, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_attention_train_planes(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs,
-                                           ctx_mask, ctx_mask_bs, s.c, (int64_t)Sq * H, H, s.cT, s.cT + (size_t)H * Mp,
-                                           (int64_t)Sq * H, H, s.lse_x, Sqp, B, heads, Sq, Sk, scale, pa, L->seed[0],
-                                           L->seed_dev, stream));
+  if (!L->attention_fp32 && planes_ok(KV_hi, KV_lo, kv_bs, kv_rs, k_col, v_col, Sk)) {
+    unsigned short* qP = (unsigned short*)s.q;
+    const unsigned short *kvh = (const unsigned short*)KV_hi, *kvl = (const unsigned short*)KV_lo;
+    GRIDMM_TRY(linear_fwd(L->xq, X, s.xT, rows, nullptr, nullptr, M, GRIDMM_ACT_NONE, stream, qP));
+    GRIDMM_TRY(gridmm_attention_rows_train(qP, qP + (size_t)M * H, (int64_t)Sq * H, H, kvh + k_col, kvl + k_col, kv_bs, kv_rs,
+                                           kvh + v_col, kvl + v_col, kv_bs, kv_rs, ctx_mask, ctx_mask_bs, s.c, (int64_t)Sq * H, H,
+                                           s.cT, s.cT + (size_t)H * Mp, (int64_t)Sq * H, H, s.lse_x, Sqp,
+                                           KV_shift ? KV_shift + v_col : nullptr, kv_shift_bs, B, heads, Sq, Sk, scale, pa,
+                                           L->seed[0], L->seed_dev, stream));
+  } else {
+    GRIDMM_TRY(linear_fwd(L->xq, X, s.xT, rows, nullptr, s.q, M, GRIDMM_ACT_NONE, stream));
+    GRIDMM_TRY(gridmm_attention_train_planes(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs,
+                                             ctx_mask, ctx_mask_bs, s.c, (int64_t)Sq * H, H, s.cT, s.cT + (size_t)H * Mp,
+                                             (int64_t)Sq * H, H, s.lse_x, Sqp, B, heads, Sq, Sk, scale, pa, L->seed[0],
+                                             L->seed_dev, stream));
+  }
   GRIDMM_TRY(linear_fwd_planes(L->xo, s.cT, nullptr, s.h1, M, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(ln(s.h1, X, L->x_ln, L->seed[1], s.a1, s.a1T));
   // ---- self attention (vilmodel.py:172-182)
-  GRIDMM_TRY(linear_fwd_planes(L->sqkv, s.a1T, nullptr, s.qkv, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_attention_train_planes(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H,
-                                           s.qkv + 2 * H, (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2,
-                                           (int64_t)Sq * H, H, s.c2T, s.c2T + (size_t)H * Mp, (int64_t)Sq * H, H, s.lse_s,
-                                           Sqp, B, heads, Sq, Sq, scale, pa, L->seed[2], L->seed_dev, stream));
+  if (L->attention_fp32) {
+    GRIDMM_TRY(linear_fwd_planes(L->sqkv, s.a1T, nullptr, s.qkv, M, GRIDMM_ACT_NONE, stream));
+    GRIDMM_TRY(gridmm_attention_train_planes(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H,
+                                             s.qkv + 2 * H, (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2,
+                                             (int64_t)Sq * H, H, s.c2T, s.c2T + (size_t)H * Mp, (int64_t)Sq * H, H, s.lse_s,
+                                             Sqp, B, heads, Sq, Sq, scale, pa, L->seed[2], L->seed_dev, stream));
+  } else {
+    unsigned short *qh = (unsigned short*)s.qkv, *ql = qh + (size_t)M * 3 * H;
+    const int64_t bs = (int64_t)Sq * 3 * H;
+    // row 0 of every episode through the projection (B rows, read in place through the row map), then the projection itself
+    // with the k | v planes shifted by it (csrc/attention_train.hip "SHIFTED K / V")
+    const unsigned short *ah = s.a1T, *al = s.a1T + (size_t)H * Mp;
+    GRIDMM_TRY(gridmm_linear_planes_map(ah, al, H, 1, (int64_t)Sq * H, L->sqkv.w_hi, L->sqkv.w_lo, L->sqkv.Kp, GRIDMM_W_ROWMAJOR,
+                                        L->sqkv.bias, nullptr, 0, s.qkv_shift, 3 * H, nullptr, nullptr, 0, B, 3 * H, H,
+                                        GRIDMM_ACT_NONE, stream));
+    GRIDMM_TRY(gridmm_linear_planes_shift(ah, al, H, L->sqkv.w_hi, L->sqkv.w_lo, L->sqkv.Kp, L->sqkv.bias, nullptr, 0, nullptr, 0, qh,
+                                          ql, 3 * H, s.qkv_shift, Sq, H, M, 3 * H, H, GRIDMM_ACT_NONE, stream));
+    GRIDMM_TRY(gridmm_attention_rows_train(qh, ql, bs, 3 * H, qh + H, ql + H, bs, 3 * H, qh + 2 * H, ql + 2 * H, bs, 3 * H, self_mask,
+                                           self_mask_bs, s.c2, (int64_t)Sq * H, H, s.c2T, s.c2T + (size_t)H * Mp, (int64_t)Sq * H,
+                                           H, s.lse_s, Sqp, s.qkv_shift + 2 * H, (int64_t)3 * H, B, heads, Sq, Sq, scale, pa,
+                                           L->seed[2], L->seed_dev, stream));
+  }
   GRIDMM_TRY(linear_fwd_planes(L->so, s.c2T, nullptr, s.h2, M, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(ln(s.h2, s.a1, L->s_ln, L->seed[3], s.a2, s.a2T));
   // ---- feed forward (vilmodel.py:184-209)
@@ -167,8 +207,10 @@ extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, cons
   return GRIDMM_OK;
 }
 
-extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, int64_t kv_bs,
-                                      int kv_rs, int k_col, int v_col, const uint8_t* ctx_mask, int ctx_mask_bs,
+extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, const void* KV_hi,
+                                      const void* KV_lo, const float* KV_shift, int64_t kv_shift_bs, int64_t kv_bs, int kv_rs,
+                                      int k_col, int v_col,
+                                      const uint8_t* ctx_mask, int ctx_mask_bs,
                                       const uint8_t* self_mask, int self_mask_bs, const void* saved, size_t saved_bytes,
                                       const float* dY, float* dX, float* dKV, int64_t dkv_bs, int dkv_rs,
                                       const gridmm_xlayer_grads_t* G, void* workspace, size_t workspace_bytes, int B, int Sq,
@@ -199,6 +241,8 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
   float* dqkv = (float*)take((size_t)M * 3 * H * 4);
   float* dg = (float*)take((size_t)M * I * 4);
   float* df1 = (float*)take((size_t)M * I * 4);
+  const size_t att_bytes = gridmm_attention_rows_bwd_workspace(B, heads, Sq);
+  void* att_ws = take(att_bytes);                   // delta + planes of dO of the attention backward on the bf16 matrix pipe
   const float scale = 0.125f;
   const float ph = L->p_hidden, pa = L->p_attn;
   int rc;
@@ -221,20 +265,40 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
   // ---- self attention
   GRIDMM_TRY(ln_bwd(s.h2, s.a1, L->s_ln, L->seed[3], da, dh, dr, G->s_ln_g, G->s_ln_b));
   GRIDMM_TRY(linear_bwd(L->so, dh, s.c2T, nullptr, dc, G->so_w, G->so_b, M, lw, stream));
-  GRIDMM_TRY(gridmm_attention_bwd(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H, s.qkv + 2 * H,
-                                  (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2, (int64_t)Sq * H, H, dc,
-                                  (int64_t)Sq * H, H, s.lse_s, delta, dqkv, (int64_t)Sq * 3 * H, 3 * H, dqkv + H,
-                                  (int64_t)Sq * 3 * H, 3 * H, dqkv + 2 * H, (int64_t)Sq * 3 * H, 3 * H, B, heads, Sq, Sq, Sqp,
-                                  scale, pa, L->seed[2], L->seed_dev, stream));
+  if (L->attention_fp32) {
+    GRIDMM_TRY(gridmm_attention_bwd(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H, s.qkv + 2 * H,
+                                    (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2, (int64_t)Sq * H, H, dc,
+                                    (int64_t)Sq * H, H, s.lse_s, delta, dqkv, (int64_t)Sq * 3 * H, 3 * H, dqkv + H,
+                                    (int64_t)Sq * 3 * H, 3 * H, dqkv + 2 * H, (int64_t)Sq * 3 * H, 3 * H, B, heads, Sq, Sq, Sqp,
+                                    scale, pa, L->seed[2], L->seed_dev, stream));
+  } else {
+    const unsigned short *qh = (const unsigned short*)s.qkv, *ql = qh + (size_t)M * 3 * H;
+    const int64_t bs = (int64_t)Sq * 3 * H;
+    GRIDMM_TRY(gridmm_attention_rows_bwd(qh, ql, bs, 3 * H, qh + H, ql + H, bs, 3 * H, qh + 2 * H, ql + 2 * H, bs, 3 * H, self_mask,
+                                         self_mask_bs, s.c2, (int64_t)Sq * H, H, dc, (int64_t)Sq * H, H, s.lse_s,
+                                         s.qkv_shift + 2 * H, (int64_t)3 * H, att_ws, att_bytes, dqkv, bs, 3 * H, dqkv + H, bs, 3 * H, dqkv + 2 * H, bs, 3 * H, B, heads, Sq, Sq, Sqp, scale,
+                                         pa, L->seed[2], L->seed_dev, stream));
+  }
   GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), da_b, G->sqkv_w, G->sqkv_b, M, lw, stream));   // da_b = d a1
   // ---- cross attention
   GRIDMM_TRY(ln_bwd(s.h1, X, L->x_ln, L->seed[1], da_b, dh, dr, G->x_ln_g, G->x_ln_b));
   GRIDMM_TRY(linear_bwd(L->xo, dh, s.cT, nullptr, dc, G->xo_w, G->xo_b, M, lw, stream));
   float* dq = da;                                   // (M, H) scratch: the gradient of the query projection
-  GRIDMM_TRY(gridmm_attention_bwd(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs, ctx_mask,
-                                  ctx_mask_bs, s.c, (int64_t)Sq * H, H, dc, (int64_t)Sq * H, H, s.lse_x, delta, dq,
-                                  (int64_t)Sq * H, H, dKV + k_col, dkv_bs, dkv_rs, dKV + v_col, dkv_bs, dkv_rs, B, heads, Sq,
-                                  Sk, Sqp, scale, pa, L->seed[0], L->seed_dev, stream));
+  if (!L->attention_fp32 && planes_ok(KV_hi, KV_lo, kv_bs, kv_rs, k_col, v_col, Sk)) {
+    const unsigned short* qP = (const unsigned short*)s.q;
+    const unsigned short *kvh = (const unsigned short*)KV_hi, *kvl = (const unsigned short*)KV_lo;
+    GRIDMM_TRY(gridmm_attention_rows_bwd(qP, qP + (size_t)M * H, (int64_t)Sq * H, H, kvh + k_col, kvl + k_col, kv_bs, kv_rs,
+                                         kvh + v_col, kvl + v_col, kv_bs, kv_rs, ctx_mask, ctx_mask_bs, s.c, (int64_t)Sq * H, H, dc,
+                                         (int64_t)Sq * H, H, s.lse_x, KV_shift ? KV_shift + v_col : nullptr, kv_shift_bs, att_ws,
+                                         att_bytes, dq, (int64_t)Sq * H, H, dKV + k_col, dkv_bs,
+                                         dkv_rs, dKV + v_col, dkv_bs, dkv_rs, B, heads, Sq, Sk, Sqp, scale, pa, L->seed[0],
+                                         L->seed_dev, stream));
+  } else {
+    GRIDMM_TRY(gridmm_attention_bwd(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs, ctx_mask,
+                                    ctx_mask_bs, s.c, (int64_t)Sq * H, H, dc, (int64_t)Sq * H, H, s.lse_x, delta, dq,
+                                    (int64_t)Sq * H, H, dKV + k_col, dkv_bs, dkv_rs, dKV + v_col, dkv_bs, dkv_rs, B, heads, Sq,
+                                    Sk, Sqp, scale, pa, L->seed[0], L->seed_dev, stream));
+  }
   GRIDMM_TRY(linear_bwd(L->xq, dq, s.xT, res_of(dh, dr), dX, G->xq_w, G->xq_b, M, lw, stream));
 #undef GRIDMM_TRY
   return GRIDMM_OK;

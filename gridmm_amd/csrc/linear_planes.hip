@@ -30,6 +30,12 @@ __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Per-episode shift of the PLANE output only (training: the K / V projections of the differentiable path hand the attention
+// kernels planes of K - K[row 0 of the episode], V - V[row 0] -- softmax(Q K^T) is invariant to a shift of K and
+// P V = P (V - v0) + (sum_k P_k) v0 -- so that the bf16 products of the attention carry no large common component; the fp32
+// output C stays the true projection).  Columns >= c0 of row m get tab[(m / rpb) * N + n] subtracted before the hi / lo split.
+struct PShift { const float* tab; int rpb, c0; };
+
 // BM x BN block tile, WM x WN per wave (16x16x32 MFMA tiles), NS-stage LDS ring filled by LDS-DMA.
 // One raw s_barrier per k-step; the DMA of stage kt+NS-1 is issued right after the barrier that retires
 // stage kt-1, and only a COUNTED s_waitcnt vmcnt keeps the younger stages in flight across barriers.
@@ -53,7 +59,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
     const float* __restrict__ bias, const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc,
     unsigned short* __restrict__ Chi, unsigned short* __restrict__ Clo, int ldp, int M, int N, int K,
-    int a_rpb, long a_bs) {
+    int a_rpb, long a_bs, PShift ps) {
   constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int STAGE = (2 * BM + 2 * BN) * BK;          // u16 elements per stage: Ahi|Alo|Whi|Wlo
@@ -324,6 +330,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
           }
           if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
           if (Chi) {
+            if (ps.tab && n0 >= ps.c0) {
+              const float4 s4 = *reinterpret_cast<const float4*>(ps.tab + (size_t)(m / ps.rpb) * N + n0);
+              x[0] -= s4.x; x[1] -= s4.y; x[2] -= s4.z; x[3] -= s4.w;
+            }
             uint2 hi, lo;
             split2_bf16(x[0], x[1], hi.x, lo.x);
             split2_bf16(x[2], x[3], hi.y, lo.y);
@@ -375,6 +385,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
         }
         if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
         if (Chi) {
+          if (ps.tab && n0 >= ps.c0) {
+            const float4 s4 = *reinterpret_cast<const float4*>(ps.tab + (size_t)(m / ps.rpb) * N + n0);
+            x[0] -= s4.x; x[1] -= s4.y; x[2] -= s4.z; x[3] -= s4.w;
+          }
           u16x4_t hi, lo;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -418,11 +432,11 @@ template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
-           int ksplit = 1, int a_rpb = 0, long a_bs = 0) {
+           int ksplit = 1, int a_rpb = 0, long a_bs = 0, PShift ps = PShift{nullptr, 1, 0}) {
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM), ksplit), block((BM / WM) * (BN / WN) * 64);
 #define GRIDMM_LP(ACT)                                                                                        \
   GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR, WT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
-                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs)
+                Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs, ps)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
   else if (act == GRIDMM_ACT_RELU) GRIDMM_LP(GRIDMM_ACT_RELU);
@@ -587,7 +601,9 @@ static int pick_cfg_impl(int M, int N, int K) {
 static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, const void* W_hi,
                                         const void* W_lo, int Kp, int w_layout, const float* bias, const float* residual,
                                         int ldr, float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N,
-                                        int K, int act, int cfg, int a_rpb, long a_bs, gridmm_stream_t stream) {
+                                        int K, int act, int cfg, int a_rpb, long a_bs, gridmm_stream_t stream,
+                                        PShift ps = PShift{nullptr, 1, 0}) {
+  if (ps.tab && (ps.rpb <= 0 || ps.c0 < 0 || ps.c0 % 4 || !C_hi)) return GRIDMM_EINVAL;
   if (w_layout != GRIDMM_W_ROWMAJOR && w_layout != GRIDMM_W_TILED) return GRIDMM_EINVAL;
   const bool wt = w_layout == GRIDMM_W_TILED;
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda <= 0 || lda % 8 || N % 4 || act < 0 || act > 3)
@@ -598,7 +614,7 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
   unsigned short *ch = (unsigned short*)C_hi, *cl = (unsigned short*)C_lo;
   hipStream_t st = as_stream(stream);
   if (cfg == 0) cfg = pick_cfg(M, N, K);
-#define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st, 1, a_rpb, a_bs
+#define GRIDMM_ARGS ah, al, lda, wh, wl, Kp, bias, residual, ldr, C, ldc, ch, cl, ldp, M, N, K, act, st, 1, a_rpb, a_bs, ps
   if (wt) {     // tiled planes (16 x 32 blocks): the BK = 32 tiles of the heuristic.  An 8 x 64 copy for the BK = 64 tiles was
                 // measured too (their pieces are 8 full 128-B lines already): +-2 us per step, not kept.
     if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
@@ -699,6 +715,17 @@ extern "C" int gridmm_linear_planes_map(const void* A_hi, const void* A_lo, int 
   if (a_rpb > 0 && (a_bs % 8)) return GRIDMM_EINVAL;
   return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, w_layout, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M, N, K,
                                 act, 0, a_rpb, (long)a_bs, stream);
+}
+
+// gridmm_linear_planes whose PLANE output is shifted per episode (PShift above): planes[m][n] = split(x[m][n] -
+// shift[(m / shift_rpb) * N + n]) for the columns n >= shift_c0, C = x as always.  The K / V projections of the differentiable
+// path (the attention kernels on the bf16 matrix pipe read the shifted planes, gridmm_attention_rows_train).
+extern "C" int gridmm_linear_planes_shift(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int Kp,
+                                          const float* bias, const float* residual, int ldr, float* C, int ldc, void* C_hi,
+                                          void* C_lo, int ldp, const float* shift, int shift_rpb, int shift_c0, int M, int N, int K,
+                                          int act, gridmm_stream_t stream) {
+  return linear_planes_dispatch(A_hi, A_lo, lda, W_hi, W_lo, Kp, GRIDMM_W_ROWMAJOR, bias, residual, ldr, C, ldc, C_hi, C_lo, ldp, M,
+                                N, K, act, 0, 0, 0, stream, PShift{shift, shift_rpb, shift_c0});
 }
 
 #ifdef GRIDMM_DEBUG_HOOKS

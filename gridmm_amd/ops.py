@@ -195,7 +195,8 @@ def split_rows(x, out=None):
     return Act(x, hi, lo)
 
 
-def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_planes=False, planes_out=None, allow_tiled=True):
+def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_planes=False, planes_out=None, allow_tiled=True,
+           plane_shift=None):
     """act(x @ W^T + b) (+ residual) -> Act.  x: Act or fp32 tensor (..., K).
 
     K % 32 == 0 (every hidden-size GEMM): gridmm_linear_planes -- A as bf16 planes (taken from the
@@ -230,6 +231,12 @@ def linear(x, pw, act=ACT_NONE, residual=None, out=None, want_f32=True, want_pla
         ldc = _rows2d(c)[2] if c is not None else 0
         ldr = _rows2d(residual)[2] if residual is not None else 0
         def call():
+            if plane_shift is not None:      # (tab (E, N) fp32, rows per episode, first shifted column): gridmm_linear_planes_shift
+                tab, rpb_s, c0 = plane_shift
+                assert rpb == 0 and hi is not None and tab.is_contiguous() and tab.shape[-1] == pw.N
+                return _lib.check(lib.gridmm_linear_planes_shift(
+                    _p(a.hi), _p(a.lo), lda, _p(pw.hi), _p(pw.lo), pw.Kp, _p(pw.bias), _p(residual), ldr, _p(c), ldc, _p(hi), _p(lo),
+                    pw.N, _p(tab), int(rpb_s), int(c0), M, pw.N, K, act, _stream()), "gridmm_linear_planes_shift")
             if WT and allow_tiled and getattr(pw, "_tiled", False) is not False:   # (inference weights, packed once; the training
                                                                                    # path re-packs per step and passes allow_tiled=False)
                 th, tl = pw.tiled()

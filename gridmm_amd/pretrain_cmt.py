@@ -135,7 +135,7 @@ class GlocalTextPathCMT(nn.Module):
         map_embeds = VT.pre_ln_encoder(b, b.grid_encoder, map_embeds, map_masks)
         for layer in b.grid_txt_encoder.x_layers:
             xa = layer.visual_attention
-            kv = VT._cat_linear(txt_embeds, [xa.att.key, xa.att.value])
+            kv = VT._cat_linear(txt_embeds, [xa.att.key, xa.att.value], out_planes=0)
             map_embeds = VT.x_layer(b, layer, kv, txt_masks, map_embeds, map_masks)
         map_embeds, vp_input = hs.boundary(VT.CUT_MAP, map_embeds), hs.boundary(VT.CUT_MAP, vp_input)
         return dict(txt_embeds=txt_embeds, txt_masks=txt_masks, map_embeds=map_embeds, map_masks=map_masks,
@@ -155,8 +155,8 @@ class GlocalTextPathCMT(nn.Module):
         q_masks = torch.cat([f["gmap_masks"], f["vp_masks"]], 1)
         xl = b.local_encoder.encoder.x_layers
         kv_all = VT._cat_linear(kv_embeds, [m for l in xl for m in (l.visual_attention.att.key,
-                                                                    l.visual_attention.att.value)])
-        for layer, kv in zip(xl, kv_all.split(2 * H, dim=-1)):       # (split: see vilmodel_train.encode_navigation)
+                                                                    l.visual_attention.att.value)], out_planes=0)
+        for layer, kv in zip(xl, ag.split_with_planes(kv_all, 2 * H)):       # (split: see vilmodel_train.encode_navigation)
             q = VT.x_layer(b, layer, kv, kv_masks, q, q_masks)
         return q[:, :G], q[:, G:], gridmap_embeds, f
 

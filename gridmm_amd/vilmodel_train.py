@@ -43,17 +43,19 @@ def _attn_p(model):
     return float(model.config.attention_probs_dropout_prob) if model.training else 0.0
 
 
-def _cat_linear(x, mods, residual=None):
-    """One GEMM for several Linear modules sharing the input (fused q|k|v projections)."""
+def _cat_linear(x, mods, residual=None, out_planes=False):
+    """One GEMM for several Linear modules sharing the input (fused q|k|v projections).  out_planes: the result also carries
+    its bf16 planes (what the attention kernels of the differentiable path read)."""
     if len(mods) == 1:
-        return ag.linear(x, mods[0].weight, mods[0].bias, residual)
-    return ag.linear(x, torch.cat([m.weight for m in mods], 0), torch.cat([m.bias for m in mods], 0), residual)
+        return ag.linear(x, mods[0].weight, mods[0].bias, residual, out_planes=out_planes)
+    return ag.linear(x, torch.cat([m.weight for m in mods], 0), torch.cat([m.bias for m in mods], 0), residual,
+                     out_planes=out_planes)
 
 
 def self_attention_block(model, att, x, kmask):
     """BertAttention (:172-182): LN(dropout(dense(attn(x))) + x)."""
     s = att.self
-    qkv = _cat_linear(x, [s.query, s.key, s.value])
+    qkv = _cat_linear(x, [s.query, s.key, s.value], out_planes=x.shape[-1])
     ctx = ag.self_attention(qkv, kmask, model.heads, _attn_p(model))
     h = ag.linear(ctx, att.output.dense.weight, att.output.dense.bias)
     return ag.layer_norm(h, att.output.LayerNorm, residual=x, dropout_p=_hidden_p(model))
@@ -61,7 +63,7 @@ def self_attention_block(model, att, x, kmask):
 
 def cross_attention_block(model, xatt, x, ctx_kv, ctx_mask, kv_col=0):
     """BertXAttention (:370-379); ctx_kv = [k | v] projections of the context (possibly several layers wide)."""
-    q = ag.linear(x, xatt.att.query.weight, xatt.att.query.bias)
+    q = ag.linear(x, xatt.att.query.weight, xatt.att.query.bias, out_planes=True)
     c = ag.cross_attention(q, ctx_kv, ctx_mask, model.heads, kv_col=kv_col, dropout_p=_attn_p(model))
     h = ag.linear(c, xatt.output.dense.weight, xatt.output.dense.bias)
     return ag.layer_norm(h, xatt.output.LayerNorm, residual=x, dropout_p=_hidden_p(model))
@@ -98,7 +100,7 @@ def x_layer(model, layer, ctx_kv, ctx_mask, visn, visn_mask, kv_col=0):
 def lang2visn_layer(model, layer, lang, lang_mask, visn, visn_mask):
     """GraphLXRTXLayer.forward_lang2visn (:416-427): text attends to vision, then text self-attention + FFN."""
     xa = layer.visual_attention
-    kv = _cat_linear(visn, [xa.att.key, xa.att.value])
+    kv = _cat_linear(visn, [xa.att.key, xa.att.value], out_planes=0)
     if _fusable(model, lang, layer.lang_inter):
         return ag.x_layer_fused(lang, kv, visn_mask, lang_mask, 0, model.heads, _hidden_p(model), _attn_p(model),
                                 xa, layer.lang_self_att, layer.lang_inter, layer.lang_output)
@@ -112,7 +114,7 @@ def pre_ln_encoder(model, enc, x, kmask):
     p = model.config.hidden_dropout_prob   # create_transformer_encoder passes it as the layer dropout (ops.py:11-16)
     for layer in enc.layers:
         h = ag.layer_norm(x, layer.norm1)
-        qkv = ag.linear(h, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias)
+        qkv = ag.linear(h, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias, out_planes=h.shape[-1])
         ctx = ag.self_attention(qkv, kmask, model.heads, p if model.training else 0.0)   # nn.MultiheadAttention(dropout=p)
         x = x + _drop(model, ag.linear(ctx, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias), p)
         h = ag.layer_norm(x, layer.norm2)
@@ -256,7 +258,7 @@ def encode_navigation(model, txt_embeds, txt_masks, cells, cell_masks, gmap_img_
     map_embeds = pre_ln_encoder(model, model.grid_encoder, map_embeds, map_masks)
     for layer in model.grid_txt_encoder.x_layers:
         xa = layer.visual_attention
-        kv = _cat_linear(txt_embeds, [xa.att.key, xa.att.value])
+        kv = _cat_linear(txt_embeds, [xa.att.key, xa.att.value], out_planes=0)
         map_embeds = x_layer(model, layer, kv, txt_masks, map_embeds, map_masks)
 
     kv_embeds = torch.cat([map_embeds, txt_embeds], 1)
@@ -264,11 +266,12 @@ def encode_navigation(model, txt_embeds, txt_masks, cells, cell_masks, gmap_img_
     q = torch.cat([map_embeds[:, N_CELLS:], vp_embeds], 1)
     q_masks = torch.cat([gmap_masks, vp_masks], 1)
     xl = le.encoder.x_layers
-    kv_all = _cat_linear(kv_embeds, [m for l in xl for m in (l.visual_attention.att.key, l.visual_attention.att.value)])
+    kv_all = _cat_linear(kv_embeds, [m for l in xl for m in (l.visual_attention.att.key, l.visual_attention.att.value)],
+                         out_planes=0)
     # every layer reads ITS [k | v] column block through a split view: the backward of the split is one concatenation of
     # the layers' (B, Sk, 2H) gradients (a shared kv_col form made every layer return a zero-filled full-width tensor,
     # summed three times: 4 fills + 3 adds of the whole 6144-wide context projection per step)
-    for layer, kv in zip(xl, kv_all.split(2 * H, dim=-1)):
+    for layer, kv in zip(xl, ag.split_with_planes(kv_all, 2 * H)):
         q = x_layer(model, layer, kv, kv_masks, q, q_masks)
     return q[:, :G], q[:, G:], map_embeds
 

@@ -223,6 +223,16 @@ int gridmm_linear_planes_map(const void* A_hi, const void* A_lo, int lda, int a_
                              float* C, int ldc, void* C_hi, void* C_lo, int ldp, int M, int N, int K, int act,
                              gridmm_stream_t stream);
 
+/* gridmm_linear_planes whose PLANE output is shifted per episode: planes[m][n] = split(x[m][n] - shift[(m / shift_rpb) * N + n])
+ * for the columns n >= shift_c0 (x = act(A W^T + bias) + residual; the fp32 output C stays x).  For the K / V projections of
+ * the differentiable path: shift = the projection of row 0 of every episode (a B-row gridmm_linear_planes_map call with
+ * a_rpb = 1), the attention kernels on the bf16 matrix pipe read the shifted planes and get V[row 0] as `vbar`
+ * (gridmm_attention_rows_train).  C_hi / C_lo required; shift_c0 % 4 == 0. */
+int gridmm_linear_planes_shift(const void* A_hi, const void* A_lo, int lda, const void* W_hi, const void* W_lo, int Kp,
+                               const float* bias, const float* residual, int ldr, float* C, int ldc, void* C_hi, void* C_lo,
+                               int ldp, const float* shift, int shift_rpb, int shift_c0, int M, int N, int K, int act,
+                               gridmm_stream_t stream);
+
 /* Several small plane GEMMs C_i = act_i(A_i W_i^T + b_i) in ONE launch (64x64 tiles, K % 64 == 0): the ClsPrediction
  * heads at the end of forward('navigation') (vilmodel.py:859-877, 903-905) are 32..1824 rows each.  `problems` is a
  * [host] array of n_problems <= GRIDMM_MAX_GROUPED records; A rows through the row map of gridmm_linear_planes_map;
@@ -497,6 +507,39 @@ int gridmm_attention_bwd(const float* Q, int64_t q_bs, int q_rs, const float* K,
                          float dropout_p, unsigned long long seed, const unsigned long long* seed_dev,
                          gridmm_stream_t stream);
 
+/* ---- the same attention core on the bf16 matrix pipe (round 5; csrc/attention_train.hip) ---------------------------
+ * Forward + backward of softmax(Q K^T scale + key mask) (with dropout on the probabilities) V for operands that arrive as
+ * bf16 hi/lo PLANES (what the QKV / KV GEMMs of the differentiable path emit beside their fp32 result): the 3-term bf16
+ * split of gridmm_attention_rows (K / V -- or Q / dO -- staged once per workgroup in LDS by a loader wave) instead of exact
+ * fp32 on the f32 matrix pipe.  Same reference lines as gridmm_attention_train / gridmm_attention_bwd
+ * (map_nav_src/models/vilmodel.py:95-157, 317-368; transformer.py:176-177), same dropout mask for the same seed.
+ *   lse2 [B][heads][Sqp]: log2 sum_k 2^(s_k scale log2 e) per query (+1e30 for a fully masked row), Sqp = roundup(Sq,16)
+ *   O fp32 and / or its planes (forward); dQ / dK / dV fp32 with their own strides (backward; every row of the three
+ *   column blocks is written, masked keys get zero)
+ *   workspace >= gridmm_attention_rows_bwd_workspace(B, heads, Sq) bytes: delta = <dO, O> (and <dO, vbar>) per query + the
+ *   planes of dO
+ *   vbar (may be NULL) [B][vb_bs]: the K / V planes are SHIFTED per episode -- K - K[row 0], V - V[row 0], what
+ *   gridmm_linear_planes_shift writes -- and vbar + b * vb_bs holds the row V[row 0] of episode b (all heads, 16-byte aligned,
+ *   vb_bs % 4 == 0).  Same function values and gradients (softmax is invariant to a shift of K; P V = P (V - v0) + (sum P) v0),
+ *   without the common component of the rows in the bf16 products: the q / k weight gradients then sit at the error level of
+ *   the exact-fp32 kernels (they were 10-15x above it without the shift, csrc/attention_train.hip).
+ * Strides of the plane operands in elements, % 8 == 0; Sk <= 2048. */
+int gridmm_attention_rows_train(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi, const void* K_lo,
+                                int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo, int64_t v_bs, int v_rs,
+                                const uint8_t* kmask, int mask_bs, float* O, int64_t o_bs, int o_rs, void* O_hi, void* O_lo,
+                                int64_t p_bs, int p_rs, float* lse2, int Sqp, const float* vbar, int64_t vb_bs, int B, int heads,
+                                int Sq, int Sk, float scale, float dropout_p, unsigned long long seed,
+                                const unsigned long long* seed_dev, gridmm_stream_t stream);
+size_t gridmm_attention_rows_bwd_workspace(int B, int heads, int Sq);
+int gridmm_attention_rows_bwd(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi, const void* K_lo,
+                              int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo, int64_t v_bs, int v_rs,
+                              const uint8_t* kmask, int mask_bs, const float* O, int64_t o_bs, int o_rs, const float* dO,
+                              int64_t do_bs, int do_rs, const float* lse2, const float* vbar, int64_t vb_bs, void* workspace,
+                              size_t workspace_bytes, float* dQ,
+                              int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs, int dk_rs, float* dV, int64_t dv_bs, int dv_rs,
+                              int B, int heads, int Sq, int Sk, int Sqp, float scale, float dropout_p, unsigned long long seed,
+                              const unsigned long long* seed_dev, gridmm_stream_t stream);
+
 /* Backward of gridmm_grid_aggregate w.r.t. text = text_proj(txt_embeds) (vilmodel.py:795-807; the gradient
  * reaches text_proj and the language encoder through the max / softmax weights):
  *   relevance [B][cap] as written by the forward (by sorted position), text [B][L][D] f32, dcells [B][196][D] f32 (gradient of the
@@ -569,7 +612,11 @@ int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tens
 /* ---- one cross-modal layer of the DIFFERENTIABLE path: forward that keeps what the backward needs + the whole backward
  * of the layer as ONE call (gridmm_xattn_layer_bwd).  GraphLXRTXLayer.forward with graph_sprels = None
  * (map_nav_src/models/vilmodel.py:399-414, pretrain_src/model/vilmodel.py:404-415) under torch autograd in the reference
- * (agent_base.py:199 / train_r2r.py:262).  Exact-fp32 attention (gridmm_attention_train / _bwd), bf16x3 GEMMs; hidden-state
+ * (agent_base.py:199 / train_r2r.py:262).  Attention on the bf16 matrix pipe (gridmm_attention_rows_train / _bwd: the self
+ * attention always, the cross attention when the planes KV_hi / KV_lo of the context projections are given -- NULL: the exact-
+ * fp32 kernels gridmm_attention_train / _bwd read KV; KV_shift != NULL: the planes are the shifted ones of
+ * gridmm_linear_planes_shift and KV_shift + b * kv_shift_bs is row 0 of episode b's projection, same column layout as KV),
+ * bf16x3 GEMMs; hidden-state
  * dropout inside the LayerNorm kernels (p_hidden), attention-probability dropout inside the attention kernels (p_attn);
  * seed[0..4] = cross-attention probabilities, cross LayerNorm, self-attention probabilities, self LayerNorm, FFN LayerNorm
  * (+ seed_dev, the per-replay word of a captured step).  The kernels, their order and their tile choices are those of the
@@ -592,6 +639,7 @@ typedef struct {
   float p_hidden, p_attn;
   unsigned long long seed[5];
   const unsigned long long* seed_dev;
+  int attention_fp32;            /* != 0: both attentions on the exact-fp32 kernels (A / B against the bf16 matrix-pipe form) */
 } gridmm_xlayer_train_t;
 typedef struct {
   float *xq_w, *xq_b, *xo_w, *xo_b, *sqkv_w, *sqkv_b, *so_w, *so_b, *ffn_i_w, *ffn_i_b, *ffn_o_w, *ffn_o_b;
@@ -599,11 +647,13 @@ typedef struct {
 } gridmm_xlayer_grads_t;
 size_t gridmm_xattn_layer_train_saved_bytes(int B, int Sq, int H, int I);
 size_t gridmm_xattn_layer_train_workspace(int B, int Sq, int H, int I);
-int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, int64_t kv_bs, int kv_rs,
+int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, const void* KV_hi,
+                                 const void* KV_lo, const float* KV_shift, int64_t kv_shift_bs, int64_t kv_bs, int kv_rs,
                                  int k_col, int v_col, const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask,
                                  int self_mask_bs, float* Y, void* saved, size_t saved_bytes, void* workspace,
                                  size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream);
-int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, int64_t kv_bs, int kv_rs,
+int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, const void* KV_hi, const void* KV_lo,
+                           const float* KV_shift, int64_t kv_shift_bs, int64_t kv_bs, int kv_rs,
                            int k_col, int v_col, const uint8_t* ctx_mask, int ctx_mask_bs, const uint8_t* self_mask,
                            int self_mask_bs, const void* saved, size_t saved_bytes, const float* dY, float* dX, float* dKV,
                            int64_t dkv_bs, int dkv_rs, const gridmm_xlayer_grads_t* G, void* workspace,

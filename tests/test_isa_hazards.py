@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-FILES = ["aggregate_pipe.hip", "aggregate_rel.hip", "aggregate_relg.hip", "aggregate.hip", "attention_lds.hip",
+FILES = ["aggregate_pipe.hip", "aggregate_rel.hip", "aggregate_relg.hip", "aggregate.hip", "attention_lds.hip", "attention_train.hip",
          "linear_planes.hip", "grouped.hip", "navfuse.hip"]
 
 
