@@ -88,7 +88,7 @@ SIGNATURES = {
                                   _vp, _vp, _i64, _vp, ctypes.c_size_t, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f,
                                   ctypes.c_uint64, _vp, _vp],
     "gridmm_grid_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "gridmm_grid_aggregate_bwd_routed": [_vp] * 9 + [_i, _i, _i, _i, _vp],
+    "gridmm_grid_aggregate_bwd_routed": [_vp] * 10 + [_i, _i, _i, _i, _vp],
     "gridmm_fuse_logits_bwd": [_vp] * 16 + [_i, _i, _i, _vp],
     "gridmm_cells_compact_bwd": [_vp, _i64, _vp, _vp, _i, _i, _vp],
     "gridmm_dropout": [_vp, _vp, _i64, _f, ctypes.c_uint64, _vp, _vp],
@@ -154,6 +154,8 @@ def load(debug=None):
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.gridmm_xattn_layer_workspace.restype = ctypes.c_size_t
+    lib.gridmm_grid_aggregate_bwd_workspace.argtypes = [_i, _i, _i]
+    lib.gridmm_grid_aggregate_bwd_workspace.restype = ctypes.c_size_t
     lib.gridmm_attention_rows_bwd_workspace.argtypes = [_i, _i, _i]
     lib.gridmm_attention_rows_bwd_workspace.restype = ctypes.c_size_t
     lib.gridmm_grid_aggregate_workspace.restype = ctypes.c_size_t

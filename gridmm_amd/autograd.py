@@ -669,8 +669,9 @@ class _GridAggregate(torch.autograd.Function):
         da = torch.empty(B, cap, dtype=torch.float32, device=slab.device)
         if ctx.amax is not None:
             dw = torch.empty(B, cap, dtype=torch.float32, device=slab.device)
+            part = torch.empty(lib.gridmm_grid_aggregate_bwd_workspace(B, D, L) // 4, dtype=torch.float32, device=slab.device)
             _lib.check(lib.gridmm_grid_aggregate_bwd_routed(_p(slab), _p(perm), _p(cell_start), _p(rel), _p(ctx.amax),
-                                                            _p(dcells), _p(dtext), _p(da), _p(dw), B, cap, D, L,
+                                                            _p(dcells), _p(dtext), _p(da), _p(dw), _p(part), B, cap, D, L,
                                                             _stream()), "gridmm_grid_aggregate_bwd_routed")
             return dtext, None, None, None
         am = torch.empty(B, cap, dtype=torch.int32, device=slab.device)

@@ -606,6 +606,141 @@ __global__ __launch_bounds__(256) void agg_bwd_gather_kernel(
   }
 }
 
+// ---- round 5 forms of the two slab passes (D % 8 == 0).  The first versions above spent their time OUTSIDE the slab reads:
+// the da pass did a 8-step binary search through L2 per point, and the gather pass gave every token its own workgroup that
+// scanned all points -- the routing concentrates on a few tokens, so a handful of workgroups did most of the row reads one
+// dependent load chain at a time (1.4 ms per call at the 36 x 196 x 512 shape, 13 ms of a 128 ms fine-tune iteration).
+//   agg_bwd_da2_kernel     a wave owns 16 consecutive sorted points: ONE search for the first, then the cell advances with
+//                          the position; 16-byte row loads; the dcells row stays in registers while the cell does not change
+//   agg_bwd_gather2_kernel point-balanced: a workgroup owns a contiguous chunk of the sorted order and a 256-column half of
+//                          the rows, each of its two waves a private [L][128] fp32 table in LDS that it updates in point
+//                          order (no atomics, deterministic); the chunk tables go to a workspace
+//   agg_bwd_gsum_kernel    dtext = sum of the chunk tables in chunk order
+constexpr int DA2_P = 16;
+constexpr int GCH = 8;          // chunks per episode of the gather pass
+
+template <int NV8>              // 16-byte row pieces per lane: D <= 512 * NV8
+__global__ __launch_bounds__(256) void agg_bwd_da2_kernel(const _Float16* __restrict__ slab, const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ cell_start, const float* __restrict__ dcells,
+                                                          float* __restrict__ da, int cap, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+  const int valid = cs[GRIDMM_CELLS];
+  const int p0 = (blockIdx.x * 4 + wave) * DA2_P;
+  if (p0 >= valid) return;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+  int lo = 0, hi = GRIDMM_CELLS;                // cell of sorted position p0: largest c with cs[c] <= p0 (wave-uniform)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (cs[mid] <= p0) lo = mid; else hi = mid;
+  }
+  int next = cs[lo + 1], loaded = -1;
+  float dc[NV8][8];
+  const int n = min(DA2_P, valid - p0);
+  const int myperm = lane < n ? perm_b[p0 + lane] : 0;      // the wave's row ids in one load
+  float keep = 0.f;
+  for (int p = 0; p < n; ++p) {
+    const int pos = p0 + p;
+    while (pos >= next && lo < GRIDMM_CELLS - 1) { ++lo; next = cs[lo + 1]; }
+    if (lo != loaded) {                          // (wave-uniform) the gradient row of this cell
+#pragma unroll
+      for (int i = 0; i < NV8; ++i) {
+        const int d0 = 8 * lane + 512 * i;
+        if (d0 < D) {
+          const float4 u = *reinterpret_cast<const float4*>(dcells + ((size_t)b * GRIDMM_CELLS + lo) * D + d0);
+          const float4 v = *reinterpret_cast<const float4*>(dcells + ((size_t)b * GRIDMM_CELLS + lo) * D + d0 + 4);
+          dc[i][0] = u.x; dc[i][1] = u.y; dc[i][2] = u.z; dc[i][3] = u.w; dc[i][4] = v.x; dc[i][5] = v.y; dc[i][6] = v.z; dc[i][7] = v.w;
+        }
+      }
+      loaded = lo;
+    }
+    const int row = __builtin_amdgcn_readlane(myperm, p);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      const int d0 = 8 * lane + 512 * i;
+      if (d0 < D) {
+        const f16x8_t h = *reinterpret_cast<const f16x8_t*>(slab + ((size_t)b * cap + row) * D + d0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)h[e] * dc[i][e];
+      }
+    }
+    s = wave_sum(s);
+    if (lane == p) keep = s;
+  }
+  if (lane < n) da[(size_t)b * cap + p0 + lane] = keep;
+}
+
+__global__ __launch_bounds__(128) void agg_bwd_gather2_kernel(const _Float16* __restrict__ slab, const int32_t* __restrict__ perm,
+                                                              const int32_t* __restrict__ cell_start,
+                                                              const int32_t* __restrict__ amax, const float* __restrict__ dw,
+                                                              float* __restrict__ part, int cap, int D, int L) {
+  extern __shared__ __attribute__((aligned(16))) float2 s_tab[];          // [2 waves][L][64 lanes] (two dims per lane)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int halves = (D + 255) / 256;
+  const int chunk = blockIdx.x / halves, half = blockIdx.x % halves, b = blockIdx.y;
+  const int valid = cell_start[(size_t)b * (GRIDMM_CELLS + 2) + GRIDMM_CELLS];
+  const int per = ((valid + GCH - 1) / GCH + 63) / 64 * 64;               // points per chunk, whole 64-point groups
+  const int beg = chunk * per, end = min(valid, beg + per);
+  const int d0 = half * 256 + wave * 128 + 2 * lane;                       // this lane's two columns
+  const bool col_ok = d0 < D;
+  float2* tab = s_tab + (size_t)wave * L * 64;
+  for (int l = 0; l < L; ++l) tab[l * 64 + lane] = make_float2(0.f, 0.f);
+  const int32_t* am = amax + (size_t)b * cap;
+  const int32_t* perm_b = perm + (size_t)b * cap;
+  const float* dwb = dw + (size_t)b * cap;
+  const _Float16* sb = slab + (size_t)b * cap * D + (col_ok ? d0 : 0);
+  for (int g0 = beg; g0 < end; g0 += 64) {
+    const int p = g0 + lane;
+    const bool ok = p < end;
+    const float gv = ok ? dwb[p] : 0.f;
+    const int lv = ok ? am[p] : 0, rv = ok ? perm_b[p] : 0;
+    const int cnt = min(64, end - g0);
+    for (int i0 = 0; i0 < cnt; i0 += 4) {                                // four rows in flight, then their four updates in order
+      f16x2_t x[4];
+      float gq[4];
+      int lq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u, 63);
+        gq[u] = __shfl(gv, i, 64);
+        lq[u] = __shfl(lv, i, 64);
+        const int r = __shfl(rv, i, 64);
+        x[u] = *reinterpret_cast<const f16x2_t*>(sb + (size_t)r * D);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + u < cnt) {
+          float2 t = tab[lq[u] * 64 + lane];
+          t.x += gq[u] * (float)x[u][0];
+          t.y += gq[u] * (float)x[u][1];
+          tab[lq[u] * 64 + lane] = t;
+        }
+      }
+    }
+  }
+  if (col_ok) {
+    float* out = part + (((size_t)b * GCH + chunk) * L) * D + d0;
+    for (int l = 0; l < L; ++l) *reinterpret_cast<float2*>(out + (size_t)l * D) = tab[l * 64 + lane];
+  }
+}
+
+__global__ void agg_bwd_gsum_kernel(const float* __restrict__ part, float* __restrict__ dtext, size_t per_b4) {
+  const size_t n4 = per_b4 * gridDim.y;
+  (void)n4;
+  const int b = blockIdx.y;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_b4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(part)[((size_t)b * GCH) * per_b4 + i];
+#pragma unroll
+    for (int c = 1; c < GCH; ++c) {
+      const float4 v = reinterpret_cast<const float4*>(part)[((size_t)b * GCH + c) * per_b4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(dtext)[(size_t)b * per_b4 + i] = a;
+  }
+}
+
 }  // namespace
 
 extern "C" int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32_t* cell_start,
@@ -638,12 +773,43 @@ extern "C" int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, 
   return GRIDMM_OK;
 }
 
+extern "C" size_t gridmm_grid_aggregate_bwd_workspace(int B, int D, int L) {
+  return (size_t)B * GCH * L * D * sizeof(float);
+}
+
 extern "C" int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t* perm, const int32_t* cell_start,
                                                 const float* relevance, const int32_t* amax, const float* dcells,
-                                                float* dtext, float* da_ws, float* dw_ws, int B, int cap, int D, int L,
-                                                gridmm_stream_t stream) {
+                                                float* dtext, float* da_ws, float* dw_ws, float* part_ws, int B, int cap, int D,
+                                                int L, gridmm_stream_t stream) {
   if (B <= 0 || cap <= 0 || L <= 0 || D <= 0 || D % 2 || D > 128 * AGG_MAXV) return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
+  const size_t tab_bytes = (size_t)2 * L * 64 * sizeof(float2);
+  if (part_ws && D % 8 == 0 && (D * L) % 4 == 0 && tab_bytes <= 80 * 1024) {      // the point-balanced forms (see above)
+    dim3 gp2((cap + 4 * DA2_P - 1) / (4 * DA2_P), B), gc2(GRIDMM_CELLS, B);
+    if (D <= 512) GRIDMM_LAUNCH((agg_bwd_da2_kernel<1>), gp2, dim3(256), 0, st, (const _Float16*)slab, perm, cell_start, dcells, da_ws, cap, D);
+    else GRIDMM_LAUNCH((agg_bwd_da2_kernel<2>), gp2, dim3(256), 0, st, (const _Float16*)slab, perm, cell_start, dcells, da_ws, cap, D);
+    GRIDMM_CHECK_LAUNCH();
+    GRIDMM_LAUNCH(agg_bwd_dw_kernel, gc2, dim3(256), 0, st, cell_start, relevance, da_ws, dw_ws, cap);
+    GRIDMM_CHECK_LAUNCH();
+    const int halves = (D + 255) / 256;
+    if (tab_bytes > 48 * 1024) {      // more dynamic LDS than the default limit: raise it (idempotent; a property of the kernel)
+      static bool raised = false;
+      if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(agg_bwd_gather2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                80 * 1024) != hipSuccess)
+          return GRIDMM_ELAUNCH;
+        raised = true;
+      }
+    }
+    GRIDMM_LAUNCH(agg_bwd_gather2_kernel, dim3(GCH * halves, B), dim3(128), tab_bytes, st, (const _Float16*)slab, perm, cell_start,
+                  amax, dw_ws, part_ws, cap, D, L);
+    GRIDMM_CHECK_LAUNCH();
+    const size_t per_b4 = (size_t)L * D / 4;
+    GRIDMM_LAUNCH(agg_bwd_gsum_kernel, dim3((unsigned)((per_b4 + 255) / 256 > 64 ? 64 : (per_b4 + 255) / 256), B), dim3(256), 0, st,
+                  (const float*)part_ws, dtext, per_b4);
+    GRIDMM_CHECK_LAUNCH();
+    return GRIDMM_OK;
+  }
   const int nv = (D + 127) / 128;
   dim3 gp((cap + 4 * AGG_P - 1) / (4 * AGG_P), B), gc(GRIDMM_CELLS, B), gl(L, B), block(256);
 #define GRIDMM_AGGR(NV)                                                                                          \

@@ -549,11 +549,15 @@ int gridmm_grid_aggregate_bwd(const void* slab, const int32_t* perm, const int32
                               const float* relevance, const float* text, const float* dcells, float* dtext,
                               float* da_ws, int32_t* amax_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
 
-/* The same gradient from the forward's routing (gridmm_grid_aggregate_train): three streaming passes, no search, no
- * atomics, deterministic.  relevance / amax [B][cap] by sorted position; da_ws, dw_ws [B][cap] f32 workspaces. */
+/* The same gradient from the forward's routing (gridmm_grid_aggregate_train): streaming passes, no search, no atomics,
+ * deterministic.  relevance / amax [B][cap] by sorted position; da_ws, dw_ws [B][cap] f32 workspaces; part_ws (may be NULL:
+ * the per-token form of round 3) >= gridmm_grid_aggregate_bwd_workspace(B, D, L) bytes: the point-balanced gather of round 5
+ * (chunk tables summed in chunk order). */
+size_t gridmm_grid_aggregate_bwd_workspace(int B, int D, int L);
 int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t* perm, const int32_t* cell_start,
                                      const float* relevance, const int32_t* amax, const float* dcells, float* dtext,
-                                     float* da_ws, float* dw_ws, int B, int cap, int D, int L, gridmm_stream_t stream);
+                                     float* da_ws, float* dw_ws, float* part_ws, int B, int cap, int D, int L,
+                                     gridmm_stream_t stream);
 
 /* Backward of gridmm_fuse_logits (vilmodel.py:859-899) -- SURVEY.md 8b's gridmm_fuse_logits_bwd: gradients of the four
  * logit sets (any of them NULL = zero) -> gradients of the three raw head outputs and of the pre-sigmoid fusion weight
