@@ -713,6 +713,32 @@ def train_leg_subprocess(args, world=1, dist=None):
     return json.loads(lines[-1])
 
 
+def hbm_stream_peak(dev, gib=4):
+    """Measured HBM streaming-READ rate (GB/s): gridmm_hbm_read_probe over a window of `gib` GiB (16x the 256 MiB Infinity
+    Cache, so that nothing of a pass survives to the next), best of 5 timed passes after a warm-up."""
+    import ctypes
+    from gridmm_amd import _lib
+    lib = _lib.load()
+    n = int(gib) << 30
+    buf = torch.empty(n, dtype=torch.uint8, device=dev)
+    buf.view(torch.int32).fill_(1)
+    out = torch.zeros(2048, dtype=torch.float32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda: _lib.check(lib.gridmm_hbm_read_probe(ctypes.c_void_p(buf.data_ptr()), n, ctypes.c_void_p(out.data_ptr()), st),   # noqa: E731
+                              "gridmm_hbm_read_probe")
+    call()
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); call(); e1.record()
+        torch.cuda.synchronize()
+        best = max(best, n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del buf
+    torch.cuda.empty_cache()
+    return best
+
+
 def roofline_leg(step, args, geom, L=80):
     """Per-kernel HIP-event timing over a few instrumented steps (events on the launch stream)."""
     from gridmm_amd import ops
@@ -766,6 +792,13 @@ def roofline_leg(step, args, geom, L=80):
                                  "us_per_launch": 1e3 * per_launch_ms,
                                  "timing": "HIP events around hipGraph replays of the launch (aggregation kernel + merge "
                                            "kernel)" if agg_ms is not None else "HIP events around the eager launch"}
+        try:       # the measured streaming-read peak of THIS box next to the specification
+            pk = hbm_stream_peak(torch.device("cuda", torch.cuda.current_device()))
+            out["grid_aggregate"].update(peak_measured=pk, frac_of_measured=gbs / pk,
+                                         peak_measured_how="gridmm_hbm_read_probe: one pass over a 4 GiB window (16x the "
+                                                           "Infinity Cache), 16-byte loads, best of 5")
+        except Exception as e:
+            out["grid_aggregate"]["peak_measured_error"] = repr(e)[:200]
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_traffic.sh:
     # FETCH_SIZE and WRITE_SIZE in separate runs, (2*FETCH + WRITE) * 1024 with the gfx950 read-side correction)
     import glob

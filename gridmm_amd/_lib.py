@@ -25,6 +25,7 @@ _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int6
 # name -> argtypes, exactly the prototypes of include/gridmm.h
 SIGNATURES = {
     "gridmm_abi_version": [],
+    "gridmm_hbm_read_probe": [_vp, ctypes.c_size_t, _vp, _vp],
     "gridmm_grid_project": [_vp, _i, _vp, _vp, _vp, _i] + [_vp] * 9 + [_i, _i, _i, _i, _f, _i, _f, _vp],
     "gridmm_grid_bin": [_vp] * 10 + [_i, _i, _i, _vp],
     "gridmm_grid_bin_sliced": [_vp] * 11 + [_i, _i, _i, _i, _vp],

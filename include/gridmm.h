@@ -36,6 +36,12 @@ typedef void* gridmm_stream_t;
 /* ABI version of this header (bumped on any signature change). */
 int gridmm_abi_version(void);
 
+/* Measurement helper ("a measured stream peak next to the specification"): reads `bytes` (% 16 == 0, 16-byte
+ * aligned) at p exactly once with 16-byte loads from 2048 workgroups; out >= 2048 floats, zeroed by the caller (its content is
+ * a by-product).  bench.py times it over a 4 GiB window -- 16x the Infinity Cache -- and reports the rate as
+ * roofline_grid_aggregate.peak_measured. */
+int gridmm_hbm_read_probe(const void* p, size_t bytes, float* out, gridmm_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Grid memory ("fill_gridmap")
  * ---------------------------------------------------------------------------------------- */
