@@ -281,6 +281,74 @@ def fuzz_attention_bwd(rs, n):
             fail("attn_bwd", case, "run-to-run variation")
 
 
+def fuzz_attention_train(rs, n):
+    """The attention of the differentiable path on the bf16 matrix pipe (round 5): projections that carry planes (q plain, k | v
+    shifted by row 0 of the episode) -> gridmm_attention_rows_train / _bwd, against fp64 autograd of the same expression, on
+    inputs with a LARGE common component in the context rows (what the shift exists for); every case twice (bit equality)."""
+    from gridmm_amd import autograd as ag
+
+    def ref_att(q, k, v, kmask, heads):
+        B, Sq, H = q.shape
+        qh, kh, vh = (t.reshape(B, -1, heads, 64).transpose(1, 2) for t in (q, k, v))
+        s_ = qh @ kh.transpose(-1, -2) / 8.0
+        s_ = s_.masked_fill(~kmask[:, None, None, :], -float("inf"))
+        return (torch.softmax(s_, -1) @ vh).transpose(1, 2).reshape(B, Sq, H)
+    for _ in range(n):
+        B, heads = int(rs.choice([1, 2, 3])), int(rs.choice([2, 12]))
+        Sq = int(rs.choice([1, 17, 57, 80, 216, 300]))
+        Sk = int(rs.choice([3, 45, 80, 216, 296, 350]))
+        same = bool(rs.randint(2))
+        if same:
+            Sk = Sq
+        H = heads * 64
+        g = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+        lens = torch.randint(max(1, Sk // 3), Sk + 1, (B,), generator=g)
+        lens[0] = Sk
+        kmask = torch.arange(Sk)[None] < lens[:, None]
+        common = float(rs.choice([0.0, 3.0, 10.0])) * torch.randn(1, 1, H, generator=g)
+        x0 = torch.randn(B, Sq, H, generator=g) + (common if same else 0.0)
+        c0 = x0 if same else torch.randn(B, Sk, H, generator=g) + common
+        wq0 = torch.randn(3 * H if same else H, H, generator=g) * 0.03
+        wkv0 = torch.randn(2 * H, H, generator=g) * 0.03
+        bkv0 = torch.randn(2 * H, generator=g) * 0.1
+        dy = torch.randn(B, Sq, H, generator=g)
+        runs = []
+        for _rep in range(2):
+            x = x0.to(DEV).requires_grad_()
+            wq, wkv, bkv = (torch.nn.Parameter(t.to(DEV)) for t in (wq0, wkv0, bkv0))
+            if same:
+                qkv = ag.linear(x, wq, None, out_planes=H)
+                y = ag.self_attention(qkv, kmask.to(DEV), heads)
+                outs = [x, wq]
+            else:
+                c = c0.to(DEV).requires_grad_()
+                q = ag.linear(x, wq, None, out_planes=True)
+                kv = ag.linear(c, wkv, bkv, out_planes=0)
+                y = ag.cross_attention(q, kv, kmask.to(DEV), heads, kv_col=0)
+                outs = [x, c, wq, wkv, bkv]
+            y.backward(dy.to(DEV))
+            torch.cuda.synchronize()
+            runs.append([y.detach().clone()] + [t.grad.clone() for t in outs])
+        xd = x0.double().requires_grad_()
+        wqd, wkvd, bkvd = (t.double().requires_grad_() for t in (wq0, wkv0, bkv0))
+        if same:
+            qkvd = xd @ wqd.t()
+            yd = ref_att(qkvd[..., :H], qkvd[..., H:2 * H], qkvd[..., 2 * H:], kmask, heads)
+            exp_in = [xd, wqd]
+        else:
+            cd = c0.double().requires_grad_()
+            kvd = cd @ wkvd.t() + bkvd
+            yd = ref_att(xd @ wqd.t(), kvd[..., :H], kvd[..., H:], kmask, heads)
+            exp_in = [xd, cd, wqd, wkvd, bkvd]
+        yd.backward(dy.double())
+        case = (B, heads, Sq, Sk, same)
+        for i, (a, e) in enumerate(zip(runs[0], [yd] + [t.grad for t in exp_in])):
+            if _rel(a.cpu(), e) > 5e-4:        # (inputs up to |x| ~ 10 through bf16x3 projections AND attention)
+                fail("attn_train", case, "tensor %d rel err %.2e" % (i, _rel(a.cpu(), e)))
+        if not all(torch.equal(a, b2) for a, b2 in zip(runs[0], runs[1])):
+            fail("attn_train", case, "run-to-run variation")
+
+
 def fuzz_aggregate_bwd(rs, n):
     from gridmm_amd import autograd as ag
     for _ in range(n):
@@ -372,12 +440,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,nav,linear_bwd,attn_bwd,agg_bwd,gridmap")
+    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,nav,linear_bwd,attn_bwd,attn_train,agg_bwd,gridmap")
     a = ap.parse_args()
     rs = np.random.RandomState(a.seed)
     table = {"gemm": fuzz_gemm, "attention": fuzz_attention, "layernorm": fuzz_layernorm, "aggregate": fuzz_aggregate,
              "nav": lambda r, n: fuzz_nav(r, max(4, n // 4)), "linear_bwd": fuzz_linear_bwd,
              "attn_bwd": lambda r, n: fuzz_attention_bwd(r, max(4, n // 2)),
+             "attn_train": lambda r, n: fuzz_attention_train(r, max(4, n // 2)),
              "agg_bwd": lambda r, n: fuzz_aggregate_bwd(r, max(4, n // 4)),
              "gridmap": lambda r, n: fuzz_gridmap(r, max(4, n // 4))}
     for name in a.only.split(","):
