@@ -36,6 +36,8 @@ class _WeightCache:
 
     def __init__(self):
         self._ent = {}   # id(param) -> (weakref to param, entry); the weakref's callback drops the entry
+        self._grp = {}   # ids of a group's members -> (weakrefs, entry): fused planes of weights that share their input
+        self._member = {}   # id(param) -> (weakref, group key, first row in the fused planes)
 
     @staticmethod
     def _pack(w, transposed):
@@ -50,8 +52,14 @@ class _WeightCache:
         return ops.PackedLinear(src.t().contiguous() if transposed else src.contiguous(), None)
 
     @staticmethod
-    def _pack_both(w):
+    def _pack_both(w, into=None):
+        """into = (PackedLinear of W, PackedLinear of W^T) of an earlier call: re-pack IN PLACE (the plane buffers of a trained
+        weight keep their addresses for the life of the cache entry: captured training steps and the optimizer's plane
+        records point at them)."""
         src = w.detach()
+        if into is not None:
+            transpose_split(src, want_rows=True, out=(into[1].hi, into[1].lo, into[0].hi, into[0].lo))
+            return into
         hi, lo, _, Np, rows = transpose_split(src, want_rows=True)
         out = []
         for h, l, N, K, Kp in ((rows.hi, rows.lo, src.shape[0], src.shape[1], src.shape[1]),
@@ -61,37 +69,187 @@ class _WeightCache:
             out.append(pw)
         return out
 
-    def getter(self, w):
-        """-> get(transposed) returning the PackedLinear of w or w^T."""
-        if not isinstance(w, torch.nn.Parameter):
-            return lambda transposed: self._pack(w, transposed)
-        ver = (w._version, w.data_ptr(), tuple(w.shape))
-        key = id(w)
-        slot = self._ent.get(key)
-        if slot is None or slot[0]() is not w or slot[1]["ver"] != ver:
-            ent = {"ver": ver}
-            self._ent[key] = (weakref.ref(w, lambda _r, key=key: self._ent.pop(key, None)), ent)
-        else:
-            ent = slot[1]
-
+    def _make_get(self, ent, w):
         def get(transposed, ent=ent, w=w):
             if transposed not in ent:
                 if (w.requires_grad and w.dim() == 2 and w.dtype == torch.float32   # (grad mode is off inside Function.forward)
                         and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0 and w.is_contiguous()):
                     # a trained weight is needed in both orientations every step (forward: W, dX: W^T): one pass over
                     # it writes both pairs of planes instead of a split launch + a transposing launch
-                    ent[False], ent[True] = self._pack_both(w)
+                    ent[False], ent[True] = self._pack_both(w, ent.get("keep"))
+                    ent["keep"] = (ent[False], ent[True])         # persistent plane buffers of this parameter
                 else:
                     ent[transposed] = self._pack(w, transposed)
             return ent[transposed]
         return get
 
+    def _slot_of(self, w):
+        slot = self._ent.get(id(w))
+        return slot if (slot is not None and slot[0]() is w) else None
+
+    def getter(self, w):
+        """-> get(transposed) returning the PackedLinear of w or w^T."""
+        if not isinstance(w, torch.nn.Parameter):
+            return lambda transposed: self._pack(w, transposed)
+        ver = (w._version, w.data_ptr(), tuple(w.shape))
+        key = id(w)
+        slot = self._slot_of(w)
+        if slot is None:
+            ent = {"ver": ver}
+            self._ent[key] = (weakref.ref(w, lambda _r, key=key: self._ent.pop(key, None)), ent)
+        elif slot[1]["ver"] != ver:
+            # the parameter changed behind the cache (load_state_dict, an update that did not write the planes): the entry
+            # keeps its persistent buffers ("keep") and re-packs into them on the next use
+            ent = slot[1]
+            keep = ent.get("keep")
+            ent.clear()
+            ent["ver"] = ver
+            if keep is not None and tuple(keep[0].hi.shape) == tuple(w.shape):
+                ent["keep"] = keep
+        else:
+            ent = slot[1]
+        return self._make_get(ent, w)
+
+    # ---- fused planes of several Parameters that share their input (q | k | v; k | v of one or of all local layers): the
+    # members stay separate Parameters, their planes are row blocks of ONE pair of plane buffers
+    @staticmethod
+    def groupable(ws):
+        if len(ws) < 2 or not all(isinstance(w, torch.nn.Parameter) for w in ws):
+            return False
+        K = ws[0].shape[-1]
+        return all(w.dim() == 2 and w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == K and w.shape[0] % 8 == 0
+                   for w in ws) and K % 32 == 0 and any(w.requires_grad for w in ws)
+
+    def _group_slot(self, key):
+        slot = self._grp.get(key)
+        if slot is not None and any(r() is None for r in slot[0]):
+            self._drop_group(key)
+            return None
+        return slot
+
+    def _drop_group(self, key):
+        self._grp.pop(key, None)
+        for i in key:
+            m = self._member.get(i)
+            if m is not None and m[1] == key:
+                self._member.pop(i, None)
+
+    def group_getter(self, ws):
+        key = tuple(id(w) for w in ws)
+        ver = tuple((w._version, w.data_ptr(), tuple(w.shape)) for w in ws)
+        slot = self._group_slot(key)
+        if slot is None:
+            ent = {"ver": ver}
+            refs = [weakref.ref(w, lambda _r, key=key: self._drop_group(key)) for w in ws]
+            self._grp[key] = (refs, ent)
+            # A weight's planes are written by the optimizer in exactly ONE cache entry -- the first fused group that registered
+            # it.  Any other entry holding the same weight (another grouping of it, its single entry) is never marked current
+            # by an update: it goes stale with the version bump and is re-packed by launches (inside a captured step too), as
+            # in round 4.  (k | v of one local layer for the text->vision direction vs k | v of all four layers: two groups.)
+            row0 = 0
+            for w, r in zip(ws, refs):
+                old = self._member.get(id(w))
+                single = self._slot_of(w)
+                if (old is None or old[0]() is not w or self._group_slot(old[1]) is None) and \
+                        (single is None or single[1].get("keep") is None):
+                    self._member[id(w)] = (r, key, row0)
+                row0 += int(w.shape[0])
+        else:
+            ent = slot[1]
+            if ent["ver"] != ver:
+                keep = ent.get("keep")
+                ent.clear()
+                ent["ver"] = ver
+                if keep is not None:
+                    ent["keep"] = keep
+
+        def get(transposed, ent=ent, ws=ws):
+            if transposed not in ent:
+                cat = torch.cat([w.detach() for w in ws], 0)
+                ent[False], ent[True] = self._pack_both(cat, ent.get("keep"))
+                ent["keep"] = (ent[False], ent[True])
+            return ent[transposed]
+        return get
+
+    def _member_of(self, w):
+        m = self._member.get(id(w))
+        if m is None or m[0]() is not w:
+            return None
+        slot = self._group_slot(m[1])
+        return None if slot is None else (slot, m[1], m[2])
+
+    # ---- optimizer-owned planes (csrc/optim.hip adamw_tiles): the fused AdamW launch writes the updated weight's planes in
+    # both orientations itself, so no pack launch follows an optimizer step
+    def optimizer_planes(self, w):
+        """(hi, lo, thi, tlo, N, K, ldw, ldt) of a trained weight whose planes exist in both orientations, or None."""
+        if not OPT_PLANES or w.dim() != 2 or w.shape[0] % 64 or w.shape[1] % 64 or w.dtype != torch.float32 or not w.is_contiguous():
+            return None
+        mem = self._member_of(w)
+        if mem is not None:
+            (refs, ent), key, row0 = mem
+            keep = ent.get("keep")
+            if keep is not None and row0 % 64 == 0:
+                pf, pt = keep
+                N, K = w.shape
+                if pf.Kp == K and pf.hi.shape[1] == K and pt.hi.shape[0] == K:
+                    return (pf.hi[row0:row0 + N], pf.lo[row0:row0 + N], pt.hi[:, row0:row0 + N], pt.lo[:, row0:row0 + N], N, K, K,
+                            int(pt.hi.shape[1]))
+        slot = self._slot_of(w)
+        if slot is None:
+            return None
+        keep = slot[1].get("keep")
+        if keep is None or w.dim() != 2 or w.shape[0] % 64 or w.shape[1] % 64 or w.dtype != torch.float32 or not w.is_contiguous():
+            return None
+        pf, pt = keep
+        N, K = w.shape
+        if pf.Kp != K or pt.Kp != N or tuple(pf.hi.shape) != (N, K) or tuple(pt.hi.shape) != (K, N):
+            return None
+        return pf.hi, pf.lo, pt.hi, pt.lo, N, K, K, N
+
+    def mark_written(self, w):
+        """The optimizer wrote the planes of `w` for its CURRENT version (after the version bump)."""
+        mem = self._member_of(w)
+        if mem is not None and mem[0][1].get("keep") is not None:
+            (refs, ent), key, row0 = mem
+            i = key.index(id(w))
+            ver = list(ent["ver"])
+            ver[i] = (w._version, w.data_ptr(), tuple(w.shape))
+            ent["ver"] = tuple(ver)
+            ent[False], ent[True] = ent["keep"]
+            return
+        slot = self._slot_of(w)
+        if slot is None or slot[1].get("keep") is None:
+            return
+        ent = slot[1]
+        ent["ver"] = (w._version, w.data_ptr(), tuple(w.shape))
+        ent[False], ent[True] = ent["keep"]
+
+    def ensure_current(self, params):
+        """Before the replay of a captured training step (which holds no pack launches): re-pack, in place, every weight
+        that changed behind the cache (load_state_dict, an eager update without plane records)."""
+        for w in params:
+            mem = self._member_of(w)
+            if mem is not None and mem[0][1].get("keep") is not None and self.optimizer_planes(w) is not None:
+                (refs, ent), key, row0 = mem
+                ws = [r() for r in refs]
+                if ent["ver"] != tuple((x._version, x.data_ptr(), tuple(x.shape)) for x in ws):
+                    self.group_getter(tuple(ws))(False)
+                continue
+            slot = self._slot_of(w)
+            if slot is None or slot[1].get("keep") is None or self.optimizer_planes(w) is None:
+                continue                  # (weights without plane records are re-packed by launches INSIDE the captured step)
+            if slot[1]["ver"] != (w._version, w.data_ptr(), tuple(w.shape)):
+                self.getter(w)(False)
+
     def clear(self):
         self._ent.clear()
+        self._grp.clear()
+        self._member.clear()
 
 
 WEIGHTS = _WeightCache()
 SEED_DEV = None        # device int64[1]: per-replay seed word of a captured training step (set by train_graph.py)
+OPT_PLANES = bool(int(__import__('os').environ.get('GRIDMM_OPT_PLANES', '1')))   # A/B switch: 0 = re-pack every updated weight (round 4)
 SPLITK_OFF = bool(int(__import__('os').environ.get('GRIDMM_SPLITK_OFF', '0')))   # A/B switch for tools/bench_train.py
 
 
@@ -112,20 +270,29 @@ def _gemm(a2d, pw, bias=None, residual=None, planes=False, plane_shift=None):
         pw.bias = None
 
 
-def transpose_split(x2d, want_colsum=False, want_rows=False):
+def transpose_split(x2d, want_colsum=False, want_rows=False, out=None):
     """fp32 (M,C) -> transposed bf16 hi/lo planes (C,Mp), Mp = roundup(M,32) [, column sums (C,)] [, the row-major
-    planes as an ops.Act] -- one pass over x2d."""
+    planes as an ops.Act] -- one pass over x2d.  out = (hi, lo, row_hi, row_lo): write into these buffers (the persistent
+    planes of a trained weight, _WeightCache)."""
     lib = _lib.load()
     x2d, M, C, ld = _as2d(x2d)
     Mp = (M + 31) // 32 * 32
-    hi = torch.empty(C, Mp, dtype=torch.bfloat16, device=x2d.device)
-    lo = torch.empty_like(hi)
+    if out is not None:
+        hi, lo = out[0], out[1]
+        assert tuple(hi.shape) == (C, Mp) and hi.is_contiguous() and lo.is_contiguous()
+    else:
+        hi = torch.empty(C, Mp, dtype=torch.bfloat16, device=x2d.device)
+        lo = torch.empty_like(hi)
     cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum else None
     cs_ws = torch.empty((Mp + 255) // 256, C, dtype=torch.float32, device=x2d.device) if want_colsum else None
     rows = None
     if want_rows and C % 8 == 0:
-        rh = torch.empty(M, C, dtype=torch.bfloat16, device=x2d.device)
-        rows = ops.Act(x2d, rh, torch.empty_like(rh))
+        if out is not None:
+            rows = ops.Act(x2d, out[2], out[3])
+            assert tuple(out[2].shape) == (M, C) and out[2].is_contiguous() and out[3].is_contiguous()
+        else:
+            rh = torch.empty(M, C, dtype=torch.bfloat16, device=x2d.device)
+            rows = ops.Act(x2d, rh, torch.empty_like(rh))
     _lib.check(lib.gridmm_transpose_split(_p(x2d), ld, _p(hi), _p(lo), _p(cs), _p(cs_ws), _p(rows.hi if rows else None),
                                           _p(rows.lo if rows else None), C, M, C, Mp, _stream()),
                "gridmm_transpose_split")
@@ -206,92 +373,143 @@ def _gemm_tn(yt, xt, N, K, M, Mp, dy2d):
     return ops.linear(a, pw).f32
 
 
-class _Linear(torch.autograd.Function):
-    """Each activation / gradient is read once per role pair: the forward's input split also emits X^T planes (saved
-    for dW instead of the fp32 input), the backward's dY pass emits row planes (dX GEMM), dY^T planes (dW GEMM) and db."""
+def _linear_fwd(ctx, x, wshape, w_req, bias, residual, packs, out_planes):
+    """Forward of y = x W^T + b (+ residual) for a weight -- or a row-wise concatenation of weights -- of shape wshape whose
+    planes come from packs(transposed).  Each activation / gradient is read once per role pair: the forward's input split
+    emits the row planes that are also an operand of dW (saved instead of the fp32 input)."""
+    N = wshape[0]
+    K = x.shape[-1]
+    ctx.packs, ctx.wshape = packs, tuple(wshape)
+    x2 = x.float().contiguous().view(-1, K)
+    r2 = None if residual is None else residual.float().contiguous().view(-1, N)
+    need_w = w_req or (bias is not None and bias.requires_grad)
+    xt = None
+    a = x2
+    ctx.tn = False
+    if need_w and K % 8 == 0 and TN_GEMM and N % 8 == 0:
+        pl = _take_planes(x, x2.shape[0], K) if x.dtype == torch.float32 else None
+        if pl is not None:                              # the producer of x wrote its planes already
+            xh, xl = pl
+            Mp, a = x2.shape[0], ops.Act(x2, xh, xl)
+        else:
+            xh, xl, _, Mp, a = split_rows_pad(x2)       # row planes: A of this GEMM, operand of dW = dY^T X
+        xt, ctx.tn = (xh, xl, Mp), True
+    elif need_w and K % 8 == 0:
+        xh, xl, _, Mp, rows = transpose_split(x2, want_rows=True)
+        xt, a = (xh, xl, Mp), rows
+    want_out = out_planes is not False and out_planes is not None and N % 8 == 0 and K % 32 == 0
+    # out_planes = an int c0 (not True): the planes of the columns >= c0 are SHIFTED by row 0 of their episode (k | v
+    # projections; csrc/attention_train.hip "SHIFTED K / V").  The shift table = the projection of row 0 of every episode:
+    # one B-row GEMM over the A planes through the batched row map.
+    shift = None
+    bvec = None if bias is None else bias.detach().float()
+    if want_out and out_planes is not True and x.dim() == 3 and isinstance(a, ops.Act) and a.hi is not None and r2 is None:
+        B_, S_ = x.shape[0], x.shape[1]
+        pwf = packs(False)
+        pwf.bias = bvec
+        try:
+            shift = ops.linear(ops.Act(None, a.hi[:B_ * S_].view(B_, S_, K)[:, :1], a.lo[:B_ * S_].view(B_, S_, K)[:, :1]), pwf,
+                               allow_tiled=False).f32.view(B_, N)
+        finally:
+            pwf.bias = None
+    y = _gemm(a, packs(False), bvec, r2, planes=want_out,
+              plane_shift=None if shift is None else (shift, x.shape[1], int(out_planes)))
+    yh = yl = None
+    if want_out:
+        y, yh, yl = y
+    if xt is not None:
+        ctx.save_for_backward(xt[0], xt[1])
+        ctx.Mp, ctx.saved_t = xt[2], True
+    else:
+        ctx.save_for_backward(x2)
+        ctx.saved_t = False
+    ctx.has_bias, ctx.has_res, ctx.M = bias is not None, residual is not None, x2.shape[0]
+    y = y.view(*x.shape[:-1], N)
+    if yh is not None:          # the consumer (the attention kernels on the bf16 matrix pipe) reads the planes, not y
+        _tag_planes(y, yh.view(y.shape), yl.view(y.shape))
+        y._gridmm_shift = shift         # (B, N) fp32 or None: row 0 of every episode (the planes >= c0 are relative to it)
+    return y
 
+
+def _linear_bwd(ctx, dy, need_x, need_w):
+    """-> dx, dW (fp32, wshape), db: the backward's dY pass emits row planes (dX GEMM, dW GEMM operand) and db."""
+    N, K = ctx.wshape
+    dy2 = dy.contiguous().view(-1, N)
+    M = ctx.M
+    dx = dw = db = None
+    yh = yl = rows = None
+    if need_w and ctx.tn:
+        yh, yl, db, Mp, rows = split_rows_pad(dy2, want_colsum=ctx.has_bias)
+    elif need_w:
+        yh, yl, db, Mp, rows = transpose_split(dy2, want_colsum=ctx.has_bias, want_rows=need_x)
+    if need_x:
+        dx = _gemm(rows if rows is not None else dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
+    if need_w and ctx.tn:
+        dw = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, M)
+    elif need_w:
+        if ctx.saved_t:
+            xt = (ctx.saved_tensors[0], ctx.saved_tensors[1])
+        else:
+            xh, xl, _, _, _ = transpose_split(ctx.saved_tensors[0])
+            xt = (xh, xl)
+        dw = _gemm_tn((yh, yl), xt, N, K, M, Mp, dy2)
+    return dx, dw, db
+
+
+class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, packs, out_planes=False):
         ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
-        K = x.shape[-1]
-        ctx.packs = packs
-        x2 = x.float().contiguous().view(-1, K)
-        r2 = None if residual is None else residual.float().contiguous().view(-1, weight.shape[0])
-        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
-        xt = None
-        a = x2
-        ctx.tn = False
-        if need_w and K % 8 == 0 and TN_GEMM and weight.shape[0] % 8 == 0:
-            pl = _take_planes(x, x2.shape[0], K) if x.dtype == torch.float32 else None
-            if pl is not None:                              # the producer of x wrote its planes already
-                xh, xl = pl
-                Mp, a = x2.shape[0], ops.Act(x2, xh, xl)
-            else:
-                xh, xl, _, Mp, a = split_rows_pad(x2)       # row planes: A of this GEMM, operand of dW = dY^T X
-            xt, ctx.tn = (xh, xl, Mp), True
-        elif need_w and K % 8 == 0:
-            xh, xl, _, Mp, rows = transpose_split(x2, want_rows=True)
-            xt, a = (xh, xl, Mp), rows
-        want_out = out_planes is not False and out_planes is not None and weight.shape[0] % 8 == 0 and K % 32 == 0
-        # out_planes = an int c0 (not True): the planes of the columns >= c0 are SHIFTED by row 0 of their episode (k | v
-        # projections; csrc/attention_train.hip "SHIFTED K / V").  The shift table = the projection of row 0 of every episode:
-        # one B-row GEMM over the A planes through the batched row map.
-        shift = None
-        bvec = None if bias is None else bias.detach().float()
-        if want_out and out_planes is not True and x.dim() == 3 and isinstance(a, ops.Act) and a.hi is not None and r2 is None:
-            B_, S_ = x.shape[0], x.shape[1]
-            pwf = packs(False)
-            pwf.bias = bvec
-            try:
-                shift = ops.linear(ops.Act(None, a.hi[:B_ * S_].view(B_, S_, K)[:, :1], a.lo[:B_ * S_].view(B_, S_, K)[:, :1]), pwf,
-                                   allow_tiled=False).f32.view(B_, weight.shape[0])
-            finally:
-                pwf.bias = None
-        y = _gemm(a, packs(False), bvec, r2, planes=want_out,
-                  plane_shift=None if shift is None else (shift, x.shape[1], int(out_planes)))
-        yh = yl = None
-        if want_out:
-            y, yh, yl = y
-        if xt is not None:
-            ctx.save_for_backward(xt[0], xt[1], weight)
-            ctx.Mp, ctx.saved_t = xt[2], True
-        else:
-            ctx.save_for_backward(x2, weight)
-            ctx.saved_t = False
-        ctx.has_bias, ctx.has_res, ctx.M = bias is not None, residual is not None, x2.shape[0]
-        y = y.view(*x.shape[:-1], weight.shape[0])
-        if yh is not None:          # the consumer (the attention kernels on the bf16 matrix pipe) reads the planes, not y
-            _tag_planes(y, yh.view(y.shape), yl.view(y.shape))
-            y._gridmm_shift = shift         # (B, N) fp32 or None: row 0 of every episode (the planes >= c0 are relative to it)
-        return y
+        ctx.wdtype = weight.dtype
+        return _linear_fwd(ctx, x, weight.shape, weight.requires_grad, bias, residual, packs, out_planes)
 
     @staticmethod
     def backward(ctx, dy):
         if dy is None:
             return (None,) * 6
-        weight = ctx.saved_tensors[-1]
-        N, K = weight.shape
-        dy2 = dy.contiguous().view(-1, N)
-        M = ctx.M
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
-        dx = dw = db = None
-        yh = yl = rows = None
-        if need_w and ctx.tn:
-            yh, yl, db, Mp, rows = split_rows_pad(dy2, want_colsum=ctx.has_bias)
-        elif need_w:
-            yh, yl, db, Mp, rows = transpose_split(dy2, want_colsum=ctx.has_bias, want_rows=ctx.needs_input_grad[0])
-        if ctx.needs_input_grad[0]:
-            dx = _gemm(rows if rows is not None else dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
-        if need_w and ctx.tn:
-            dw = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, M).to(weight.dtype)
-        elif need_w:
-            if ctx.saved_t:
-                xt = (ctx.saved_tensors[0], ctx.saved_tensors[1])
-            else:
-                xh, xl, _, _, _ = transpose_split(ctx.saved_tensors[0])
-                xt = (xh, xl)
-            dw = _gemm_tn((yh, yl), xt, N, K, M, Mp, dy2).to(weight.dtype)
+        dx, dw, db = _linear_bwd(ctx, dy, ctx.needs_input_grad[0], need_w)
+        if dw is not None:
+            dw = dw.to(ctx.wdtype)
         return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None), None, None
+
+
+class _LinearGroup(torch.autograd.Function):
+    """One GEMM for several Linear modules that share their input (fused q | k | v, k | v of one or of all local layers):
+    the weights stay separate Parameters; their planes live row-block by row-block in ONE pair of fused plane buffers
+    (_WeightCache.group_getter) that the optimizer keeps current, so neither a torch.cat of the weights nor a pack launch
+    runs per step; the backward returns the row blocks of the fused dW / db as the members' gradients."""
+
+    @staticmethod
+    def forward(ctx, x, residual, packs, out_planes, nw, *wb):
+        ctx.set_materialize_grads(False)
+        ws, bs = wb[:nw], wb[nw:]
+        ctx.rows = [int(w.shape[0]) for w in ws]
+        ctx.nb = len(bs)
+        bias = torch.cat([b.detach() for b in bs], 0) if bs else None
+        if bias is not None:
+            bias.requires_grad_(any(b.requires_grad for b in bs))
+        return _linear_fwd(ctx, x, (sum(ctx.rows), ws[0].shape[1]), any(w.requires_grad for w in ws), bias, residual, packs,
+                           out_planes)
+
+    @staticmethod
+    def backward(ctx, dy):
+        nw = len(ctx.rows)
+        if dy is None:
+            return (None,) * (5 + nw + ctx.nb)
+        need_w = any(ctx.needs_input_grad[5:5 + nw]) or (ctx.has_bias and any(ctx.needs_input_grad[5 + nw:]))
+        dx, dw, db = _linear_bwd(ctx, dy, ctx.needs_input_grad[0], need_w)
+        dws = list(dw.split(ctx.rows, 0)) if dw is not None else [None] * nw
+        dbs = list(db.split(ctx.rows, 0)) if (db is not None and ctx.nb) else [None] * ctx.nb
+        return (dx, (dy if ctx.has_res else None), None, None, None) + tuple(dws) + tuple(dbs)
+
+
+def linear_group(x, weights, biases, residual=None, out_planes=False):
+    """x @ cat(weights)^T + cat(biases): see _LinearGroup."""
+    ws = tuple(weights)
+    if not WEIGHTS.groupable(ws):
+        return linear(x, torch.cat(list(ws), 0), torch.cat(list(biases), 0) if biases else None, residual, out_planes=out_planes)
+    return _LinearGroup.apply(x, residual, WEIGHTS.group_getter(ws), out_planes, len(ws), *ws, *tuple(biases or ()))
 
 
 def linear(x, weight, bias=None, residual=None, out_planes=False):
@@ -929,7 +1147,6 @@ class _XLayer(torch.autograd.Function):
             kv, kvp, kvs = kv.float().contiguous(), None, None
         assert kvs is None or (kvs.dim() == 2 and kvs.stride(1) == 1 and kvs.shape[1] == kv.shape[2])
         (xqw, xqb, xow, xob, qw, qb, kw, kb, vw, vb, sow, sob, fiw, fib, fow, fob, xg, xb, sg, sb, fg, fb) = params
-        qkvw = torch.cat([qw, kw, vw], 0)
         qkvb = torch.cat([qb, kb, vb], 0)
         I = fiw.shape[0]
         keep = []                                   # planes / biases / masks the C struct points into
@@ -949,7 +1166,17 @@ class _XLayer(torch.autograd.Function):
         draw = lambda on: hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item())) if on else 0   # noqa: E731
         seeds = [draw(p_attn > 0), draw(p_hidden > 0), draw(p_attn > 0), draw(p_hidden > 0), draw(p_hidden > 0)]
         seed_dev = SEED_DEV if ((p_attn > 0 or p_hidden > 0) and hs.MODE is not None) else None
-        L = _CXLayerTrain(lin(xqw, xqb), lin(xow, xob), lin(qkvw, qkvb), lin(sow, sob), lin(fiw, fib), lin(fow, fob),
+        def lin_group(ws, b):           # q | k | v as ONE projection: fused planes of the three Parameters (no torch.cat of weights)
+            if WEIGHTS.groupable(tuple(ws)):
+                get = WEIGHTS.group_getter(tuple(ws))
+            else:
+                get = WEIGHTS.getter(torch.cat(list(ws), 0))
+            pf, pt = get(False), get(True)
+            bb = b.detach().float().contiguous()
+            keep.extend([pf, pt, bb])
+            return _CLinearTrain(pf.hi.data_ptr(), pf.lo.data_ptr(), pf.Kp, pt.hi.data_ptr(), pt.lo.data_ptr(), pt.Kp,
+                                 bb.data_ptr(), sum(int(w.shape[0]) for w in ws), ws[0].shape[1])
+        L = _CXLayerTrain(lin(xqw, xqb), lin(xow, xob), lin_group((qw, kw, vw), qkvb), lin(sow, sob), lin(fiw, fib), lin(fow, fob),
                           lnp(xg, xb, eps[0]), lnp(sg, sb, eps[1]), lnp(fg, fb, eps[2]), float(p_hidden), float(p_attn),
                           (ctypes.c_ulonglong * 5)(*seeds), _ptr(seed_dev), 0 if BF16_ATTENTION else 1)
 

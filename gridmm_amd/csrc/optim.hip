@@ -135,16 +135,91 @@ __device__ __forceinline__ void adamw_range(T* __restrict__ p, const T* __restri
   }
 }
 
+// ---- optimizer-owned weight planes (round 5).  A trained 2-D weight is needed as bf16 hi / lo planes in BOTH orientations every
+// step (forward: W [N][K]; dX: W^T [K][N]); round 4 re-packed every updated weight with a transposing split launch per
+// weight and step (~124 launches, ~1.4 ms of the 161 M-parameter step).  For a tensor with a plane record the update walks
+// 64 x 64 tiles instead of flat 16 K-element chunks (same element arithmetic, bit for bit), writes the row planes straight
+// from the registers and the transposed planes through an LDS tile: the weight's planes are current the moment the optimizer
+// step ends, and no pack launch follows.  N % 64 == 0, K % 64 == 0, fp32; ldw / ldt: row pitches of the two plane pairs (a
+// member of a fused q | k | v projection writes its row block / column block of the shared planes).
+struct PlaneDesc {
+  unsigned short *hi, *lo, *thi, *tlo;   // hi == NULL: no planes for this tensor
+  int N, K, ldw, ldt;
+};
+static_assert(sizeof(PlaneDesc) == 48, "record layout shared with gridmm_amd/optim.py (_PREC)");
+
+__device__ __forceinline__ void adamw_tiles(const TensorDesc& d, const PlaneDesc& pl, int chunk, float scale, float b1, float b2,
+                                            int decay_first) {
+  __shared__ float tile[64][65];          // the updated weights of one 64 x 64 tile (the transposing splitter's layout)
+  float* p = static_cast<float*>(d.p);
+  const float* g = static_cast<const float*>(d.g);
+  float* m = static_cast<float*>(d.m);
+  float* v = static_cast<float*>(d.v);
+  const int tiles_k = pl.K >> 6, ntiles = (pl.N >> 6) * tiles_k;
+  const int tid = threadIdx.x;
+  const int lc = tid & 63, lr = tid >> 6;                 // update role: column lc, rows lr, lr + 4, ... (256-byte row segments)
+  const int rr = tid >> 2, rc = (tid & 3) * 16;           // store roles: row / transposed row rr, 16 elements from rc
+  for (int t = 4 * chunk; t < 4 * chunk + 4 && t < ntiles; ++t) {
+    const int tr = t / tiles_k, tc = t - tr * tiles_k;
+    const size_t base = (size_t)(tr * 64) * pl.K + tc * 64 + lc;
+    float ge[16], pe[16], me[16], ve[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const size_t o = base + (size_t)(lr + 4 * i) * pl.K;
+      ge[i] = g[o]; pe[i] = p[o]; me[i] = m[o]; ve[i] = v[o];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {            // (adamw_range<float>: rnd() is the identity)
+      const size_t o = base + (size_t)(lr + 4 * i) * pl.K;
+      const float gi = ge[i] * scale;
+      float pi = pe[i];
+      const float mi = b1 * me[i] + (1.f - b1) * gi;
+      const float vi = b2 * ve[i] + (1.f - b2) * gi * gi;
+      if (decay_first && d.wd > 0.f) pi = pi - d.lr * d.wd * pi;
+      pi = pi - d.step_size * (mi / (sqrtf(vi) + d.eps));
+      if (!decay_first && d.wd > 0.f) pi = pi - d.lr * d.wd * pi;
+      p[o] = pi; m[o] = mi; v[o] = vi;
+      tile[lr + 4 * i][lc] = pi;
+    }
+    __syncthreads();
+    {   // row planes: row tr * 64 + rr, columns tc * 64 + rc .. + 15
+      unsigned int hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split2_bf16(tile[rr][rc + 2 * e], tile[rr][rc + 2 * e + 1], hi[e], lo[e]);
+      const size_t o = (size_t)(tr * 64 + rr) * pl.ldw + tc * 64 + rc;
+      uint4* ph = reinterpret_cast<uint4*>(pl.hi + o);
+      uint4* pq = reinterpret_cast<uint4*>(pl.lo + o);
+      ph[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); ph[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+      pq[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); pq[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    }
+    {   // transposed planes: row tc * 64 + rr of W^T, columns tr * 64 + rc .. + 15
+      unsigned int hi[8], lo[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split2_bf16(tile[rc + 2 * e][rr], tile[rc + 2 * e + 1][rr], hi[e], lo[e]);
+      const size_t o = (size_t)(tc * 64 + rr) * pl.ldt + tr * 64 + rc;
+      uint4* ph = reinterpret_cast<uint4*>(pl.thi + o);
+      uint4* pq = reinterpret_cast<uint4*>(pl.tlo + o);
+      ph[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]); ph[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+      pq[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]); pq[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void multi_adamw_kernel(const TensorDesc* __restrict__ desc,
                                                           const int* __restrict__ chunk_first, int T, float b1, float b2,
                                                           int decay_first, const float* __restrict__ sumsq,
-                                                          float max_norm) {
+                                                          float max_norm, const PlaneDesc* __restrict__ planes) {
   const int t = find_tensor(chunk_first, T, blockIdx.x);
   const TensorDesc d = desc[t];
   float scale = 1.f;
   if (sumsq) {
     const float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
     scale = c < 1.f ? c : 1.f;
+  }
+  if (planes && planes[t].hi && d.dtype == 0) {       // (workgroup-uniform)
+    adamw_tiles(d, planes[t], blockIdx.x - chunk_first[t], scale, b1, b2, decay_first);
+    return;
   }
   const long long i0 = (long long)(blockIdx.x - chunk_first[t]) * MT_CHUNK;
   const long long i1 = i0 + MT_CHUNK < d.n ? i0 + MT_CHUNK : d.n;
@@ -201,11 +276,11 @@ extern "C" int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first,
 }
 
 extern "C" int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float beta1,
-                                       float beta2, int decay_first, const float* sumsq, float max_norm,
+                                       float beta2, int decay_first, const float* sumsq, float max_norm, const void* planes,
                                        gridmm_stream_t stream) {
   if (n_tensors <= 0 || n_chunks <= 0) return GRIDMM_EINVAL;
   GRIDMM_LAUNCH(multi_adamw_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), (const TensorDesc*)desc,
-                chunk_first, n_tensors, beta1, beta2, decay_first, sumsq, max_norm);
+                chunk_first, n_tensors, beta1, beta2, decay_first, sumsq, max_norm, (const PlaneDesc*)planes);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }

@@ -52,6 +52,8 @@ class AdamW(torch.optim.Optimizer):
     # (gradient tensors are re-allocated by zero_grad) and shipped with ONE small H2D copy
     _REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"),
                      ("lr", "<f4"), ("step_size", "<f4"), ("eps", "<f4"), ("wd", "<f4"), ("dtype", "<i4"), ("pad", "<i4")])
+    _PREC = np.dtype([("hi", "<u8"), ("lo", "<u8"), ("thi", "<u8"), ("tlo", "<u8"), ("N", "<i4"), ("K", "<i4"), ("ldw", "<i4"),
+                      ("ldt", "<i4")])       # csrc/optim.hip PlaneDesc: optimizer-owned weight planes
     _CHUNK = 16384
 
     def _tables(self, items, dev, graph_tabs=None, key=None, ring_min=1):
@@ -60,13 +62,23 @@ class AdamW(torch.optim.Optimizer):
         BEFORE the capture; nothing is copied inside the graph -- refresh_graph_tables() rewrites lr / step_size / eps in
         the pinned copy and uploads the pool on the replay's stream before every replay.  (An H2D copy node inside the
         graph was tried first: replayed, it raced with the kernels reading the table -- wild pointers at full size.)"""
+        from . import autograd as ag
         rec = np.zeros(len(items), self._REC)
         first = np.zeros(len(items) + 1, np.int32)
+        prec = np.zeros(len(items), self._PREC)
+        owned = []
         for i, (p, g, m, v, lr, ss, eps, wd) in enumerate(items):
             rec[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, ss, eps, wd,
                       int(p.dtype == torch.float16), 0)
             first[i + 1] = first[i] + -(-p.numel() // self._CHUNK)
-        blob = np.concatenate([rec.view(np.uint8), first.view(np.uint8)])
+            pl = ag.WEIGHTS.optimizer_planes(p) if g.dtype == torch.float32 else None
+            if pl is not None:      # the update writes this weight's bf16 planes in both orientations itself
+                prec[i] = (pl[0].data_ptr(), pl[1].data_ptr(), pl[2].data_ptr(), pl[3].data_ptr(), pl[4], pl[5], pl[6], pl[7])
+                owned.append(p)
+        pad = (-(rec.nbytes + first.nbytes)) % 16
+        blob = np.concatenate([rec.view(np.uint8), first.view(np.uint8), np.zeros(pad, np.uint8), prec.view(np.uint8)])
+        self._last_planes = (rec.nbytes + first.nbytes + pad) if owned else None       # byte offset of the plane records
+        self._last_owned = owned
         if graph_tabs is None:
             # through pinned memory (a ring: a slot is rewritten only after the copy issued from it has completed), so that
             # the upload is a plain asynchronous DMA and never a staged pageable copy (measured host-synchronous on this
@@ -84,7 +96,8 @@ class AdamW(torch.optim.Optimizer):
             pinned, d = self._carve(graph_tabs, len(blob))
             pinned.numpy()[:] = blob
             graph_tabs["multi"][key] = (pinned, d, rec.nbytes, [it[0] for it in items])
-        return d, rec.nbytes, int(first[-1])
+            graph_tabs.setdefault("owned", []).extend(owned)
+        return d, rec.nbytes, int(first[-1]), self._last_planes, owned
 
     _RING = 4
 
@@ -175,17 +188,23 @@ class AdamW(torch.optim.Optimizer):
             sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
             part = torch.empty(max(t[2] for t in tables.values()), dtype=torch.float32, device=dev)
             tmp = torch.empty(1, dtype=torch.float32, device=dev)
-            for (blob, rec_bytes, n_chunks), items in zip(tables.values(), classes.values()):
+            for (blob, rec_bytes, n_chunks, _po, _ow), items in zip(tables.values(), classes.values()):
                 _lib.check(lib.gridmm_multi_grad_sumsq(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
                                                        n_chunks, _p(part), _p(tmp), _stream()), "gridmm_multi_grad_sumsq")
                 sumsq += tmp
         for (b1, b2, df), items in classes.items():
-            blob, rec_bytes, n_chunks = tables[(b1, b2, df)]
+            blob, rec_bytes, n_chunks, plane_off, owned = tables[(b1, b2, df)]
             _lib.check(lib.gridmm_multi_adamw_step(_p(blob), ctypes.c_void_p(blob.data_ptr() + rec_bytes), len(items),
                                                    n_chunks, b1, b2, df, _p(sumsq) if sumsq is not None else ctypes.c_void_p(0),
-                                                   float(max_grad_norm or 0.0), _stream()), "gridmm_multi_adamw_step")
+                                                   float(max_grad_norm or 0.0),
+                                                   ctypes.c_void_p(blob.data_ptr() + plane_off) if plane_off is not None else ctypes.c_void_p(0),
+                                                   _stream()), "gridmm_multi_adamw_step")
+        from . import autograd as ag
         for it in multi:
             _bump_version(it[0])
+        for _b, _r, _n, _po, owned in tables.values():
+            for p in owned:
+                ag.WEIGHTS.mark_written(p)            # its planes are current for the new version: no pack launch follows
         self._keepalive = (tables, multi)              # device tables / cast gradients must outlive the async launches
         return None if sumsq is None else sumsq.sqrt()
 

@@ -231,6 +231,9 @@ class GraphedTrainStep:
         lr = get_lr_sched(tr.global_step, tr.opts)
         for g in opt.param_groups:
             g["lr"] = lr
+        # the captured step holds no weight-pack launches (the optimizer writes the planes): anything that changed a weight
+        # behind the cache since the last step (load_state_dict, an update without plane records) is re-packed now
+        ag.WEIGHTS.ensure_current(self.params)
         if self.capture_optimizer:
             opt.refresh_graph_tables(self.tabs)
         self.seed_host[0] = int(torch.randint(0, 2 ** 62, (1,)).item())      # torch's CPU generator, as the eager path
@@ -252,4 +255,6 @@ class GraphedTrainStep:
             return self.losses, self.norm                   # (opt.step bumped the parameter versions itself)
         for p in self.params:
             _bump_version(p)
+        for p in self.tabs.get("owned", ()):                # the replayed update wrote these weights' planes
+            ag.WEIGHTS.mark_written(p)
         return self.losses, self.norm

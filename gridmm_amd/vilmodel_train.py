@@ -48,8 +48,7 @@ def _cat_linear(x, mods, residual=None, out_planes=False):
     its bf16 planes (what the attention kernels of the differentiable path read)."""
     if len(mods) == 1:
         return ag.linear(x, mods[0].weight, mods[0].bias, residual, out_planes=out_planes)
-    return ag.linear(x, torch.cat([m.weight for m in mods], 0), torch.cat([m.bias for m in mods], 0), residual,
-                     out_planes=out_planes)
+    return ag.linear_group(x, [m.weight for m in mods], [m.bias for m in mods], residual, out_planes=out_planes)
 
 
 def self_attention_block(model, att, x, kmask):

@@ -616,8 +616,13 @@ int gridmm_linear_planes_splitk(const void* A_hi, const void* A_lo, int lda, con
  * is bit-reproducible), out = the global sum of squares (device scalar). */
 int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float* partial,
                             float* out, gridmm_stream_t stream);
+/* planes (device, may be NULL): n_tensors records {void *hi, *lo, *thi, *tlo; int32 N, K, ldw, ldt} (48 bytes).  A tensor whose
+ * record has hi != NULL is a contiguous fp32 [N][K] weight (N % 64 == 0, K % 64 == 0) whose bf16 hi / lo planes the update
+ * writes itself: row planes [N][ldw] at hi / lo and the planes of W^T [K][ldt] at thi / tlo -- what the forward and dX GEMMs
+ * of the differentiable path read (replaces one gridmm_transpose_split launch per weight and step).  Same update arithmetic. */
 int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float beta1,
-                            float beta2, int decay_first, const float* sumsq, float max_norm, gridmm_stream_t stream);
+                            float beta2, int decay_first, const float* sumsq, float max_norm, const void* planes,
+                            gridmm_stream_t stream);
 
 /* ---- one cross-modal layer of the DIFFERENTIABLE path: forward that keeps what the backward needs + the whole backward
  * of the layer as ONE call (gridmm_xattn_layer_bwd).  GraphLXRTXLayer.forward with graph_sprels = None
