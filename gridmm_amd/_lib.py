@@ -56,6 +56,7 @@ SIGNATURES = {
     "gridmm_attention_rows_seg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _i,
                                   _vp, _i, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "gridmm_linear_planes_tn": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gridmm_linear_planes_tn_db": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     "gridmm_linear_planes_tn_splits": [_i, _i, _i],
     "gridmm_split_rows_pad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_linear_planes_map": [_vp, _vp, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -100,6 +101,7 @@ SIGNATURES = {
     "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_multi_grad_sumsq": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "gridmm_multi_adamw_step": [_vp, _vp, _i, _i, _f, _f, _i, _vp, _f, _vp, _vp],
+    "gridmm_multi_grad_accumulate": [_vp, _vp, _i, _i, _vp],
     "gridmm_xattn_layer_train_saved_bytes": [_i, _i, _i, _i],
     "gridmm_xattn_layer_train_workspace": [_i, _i, _i, _i],
     "gridmm_xattn_layer_train_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp,

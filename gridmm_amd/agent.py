@@ -15,6 +15,7 @@ whole point history every step (agent.py:168).
 (gridmm_amd.vilmodel.GlocalTextPathNavCMT on the GPU; tests also drive it with the CPU oracle).
 """
 import contextlib
+import os
 import math
 from types import SimpleNamespace
 
@@ -252,13 +253,16 @@ class GMapNavAgent:
         if self.timers is None:
             return 0.0
         import time
-        torch.cuda.synchronize()
+        if self.timers_sync:
+            torch.cuda.synchronize()
         t = time.perf_counter()
         if t0:
             self.timers[name] = self.timers.get(name, 0.0) + (t - t0)
         return t
 
     timers = None
+    defer_grads = bool(int(os.environ.get("GRIDMM_DEFER_GRADS", "1")))   # A/B switch (autograd.deferred_param_grads)
+    timers_sync = True      # False: host-side time per section only (the device wait lands in the section that reads results)
 
     def rollout(self, train_ml=None, reset=True):
         """One rollout of the environment's next mini-batch (agent.py:268-451).  The body is a generator that yields once
@@ -565,6 +569,7 @@ class GMapNavAgent:
         self.feedback = feedback
         self._set_mode(True)
         self.losses = []
+        from . import autograd as ag
         for _ in range(n_iters):
             self.vln_bert_optimizer.zero_grad()
             self.loss = 0
@@ -580,7 +585,11 @@ class GMapNavAgent:
             else:
                 raise NotImplementedError("train_alg %r (the A2C branch, train_rl=True, is not used by the released "
                                           "GridMM scripts)" % self.args.train_alg)
-            self.loss.backward()
+            # one backward through every step of the rollout(s): each parameter gets a gradient per step -- kept aside by the
+            # kernels' autograd Functions and summed by ONE launch instead of one add per parameter and step
+            with ag.deferred_param_grads() if self.defer_grads else contextlib.nullcontext():
+                self.loss.backward()
+            ag.flush_param_grads()
             self.grad_reducer.reduce()
             if self.args.optim == "adamW":
                 self.vln_bert_optimizer.step(max_grad_norm=40.0)          # clip_grad_norm_(40) fused into the step

@@ -16,6 +16,7 @@ libgridmm_hip.so; torch only records the graph and moves/gathers/concatenates te
 
 There is no CPU / eager fallback: the functions raise on non-GPU tensors (ops._p).
 """
+import contextlib
 import ctypes
 import math
 import weakref
@@ -299,6 +300,88 @@ def transpose_split(x2d, want_colsum=False, want_rows=False, out=None):
     return hi, lo, cs, Mp, rows
 
 
+# ------------------------------------------------------------------------------------------------
+# deferred parameter gradients: ONE accumulation launch per backward instead of one per parameter and use
+# ------------------------------------------------------------------------------------------------
+class _DeferredGrads:
+    """A fine-tuning iteration backpropagates through every navigation step of a rollout at once (agent_base.py:190-199):
+    each step gives each parameter a gradient and autograd's AccumulateGrad adds them one launch at a time (~2 000
+    launches of ~4 us per iteration at 7 steps).  Inside `deferred_param_grads()` the custom Functions of this module keep
+    the gradients of leaf Parameters aside (hand()) and return None for them; `flush_param_grads()` -- call it right
+    after backward() -- sums them into .grad with one multi-tensor launch (gridmm_multi_grad_accumulate), in the order they
+    were produced: the same sums, bit for bit, as the sequential in-place adds.  Parameters that also receive gradients
+    through plain torch ops keep those (the flush adds to an existing .grad).  Post-accumulate-grad hooks do not fire for
+    deferred gradients; dist.GradientReducer.reduce() picks such gradients up by itself."""
+
+    def __init__(self):
+        self.active = False
+        self.pending = {}            # id(param) -> (param, [gradients in production order])
+
+    def hand(self, param, g):
+        if g is None or not self.active:
+            return g
+        if not (isinstance(param, torch.nn.Parameter) and param.is_leaf and g.is_cuda and g.dtype == torch.float32
+                and param.dtype == torch.float32 and g.shape == param.shape and g.is_contiguous()):
+            return g
+        self.pending.setdefault(id(param), (param, []))[1].append(g)
+        return None
+
+
+DEFERRED = _DeferredGrads()
+_SUM_REC = None
+
+
+@contextlib.contextmanager
+def deferred_param_grads():
+    prev, DEFERRED.active = DEFERRED.active, True
+    try:
+        yield
+    finally:
+        DEFERRED.active = prev
+
+
+def flush_param_grads():
+    """Sum the gradients kept aside since the last flush into their parameters' .grad (see _DeferredGrads)."""
+    global _SUM_REC
+    import numpy as np
+    items = list(DEFERRED.pending.values())
+    DEFERRED.pending.clear()
+    work = []
+    for prm, gs in items:
+        if prm.grad is None:
+            prm.grad, gs = gs[0], gs[1:]            # the first gradient becomes .grad as it is (AccumulateGrad does the same)
+        elif not (prm.grad.dtype == torch.float32 and prm.grad.is_contiguous()):
+            for g in gs:
+                prm.grad.add_(g)
+            continue
+        if gs:
+            work.append((prm.grad, gs))
+    if not work:
+        return
+    if _SUM_REC is None:
+        _SUM_REC = np.dtype([("dst", "<u8"), ("src", "<u8", (7,)), ("n", "<i8"), ("n_src", "<i4"), ("pad", "<i4")])
+        assert _SUM_REC.itemsize == 80
+    lib = _lib.load()
+    dev = work[0][0].device
+    rnd = 0
+    while True:                                      # more than 7 gradients of one parameter: further rounds, in order
+        part = [(dst, gs[7 * rnd:7 * rnd + 7]) for dst, gs in work if len(gs) > 7 * rnd]
+        if not part:
+            break
+        rec = np.zeros(len(part), _SUM_REC)
+        first = np.zeros(len(part) + 1, np.int32)
+        for i, (dst, gs) in enumerate(part):
+            rec["dst"][i], rec["n"][i], rec["n_src"][i] = dst.data_ptr(), dst.numel(), len(gs)
+            for k, g in enumerate(gs):
+                rec["src"][i, k] = g.data_ptr()
+            first[i + 1] = first[i] + (dst.numel() + 16383) // 16384
+        blob = np.concatenate([rec.view(np.uint8).reshape(-1), first.view(np.uint8)])
+        d = torch.from_numpy(blob).pin_memory().to(dev, non_blocking=True)
+        _lib.check(lib.gridmm_multi_grad_accumulate(_p(d), ctypes.c_void_p(d.data_ptr() + rec.nbytes), len(part), int(first[-1]),
+                                                    _stream()), "gridmm_multi_grad_accumulate")
+        rnd += 1
+
+
 TN_GEMM = bool(int(__import__('os').environ.get('GRIDMM_TN_GEMM', '1')))   # A/B switch: 0 = transposed planes + NT GEMM (round 1-3)
 
 
@@ -321,31 +404,39 @@ def _want_planes(width):
     return TN_GEMM and width % 8 == 0
 
 
-def split_rows_pad(x2d, want_colsum=False):
+def split_rows_pad(x2d, want_colsum=False, defer_colsum=False):
     """fp32 (M,C) -> row-major bf16 hi/lo planes (Mp,C) with rows [M,Mp) zero, Mp = roundup(M,32) [, column sums (C,)]: one
-    pass per activation / gradient for both of its GEMM roles (forward / dX: the first M rows; dW: gridmm_linear_planes_tn)."""
+    pass per activation / gradient for both of its GEMM roles (forward / dX: the first M rows; dW: gridmm_linear_planes_tn).
+    defer_colsum: the column sums come back as their per-256-row partials (n_part, C) -- _gemm_tn_rows reduces them in the
+    weight gradient's summing pass instead of a launch of their own."""
     lib = _lib.load()
     x2d, M, C, ld = _as2d(x2d)
     Mp = (M + 31) // 32 * 32
     hi = torch.empty(Mp, C, dtype=torch.bfloat16, device=x2d.device)
     lo = torch.empty_like(hi)
-    cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum else None
+    cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum and not defer_colsum else None
     cs_ws = torch.empty((Mp + 255) // 256, C, dtype=torch.float32, device=x2d.device) if want_colsum else None
     _lib.check(lib.gridmm_split_rows_pad(_p(x2d), ld, _p(hi), _p(lo), C, _p(cs), _p(cs_ws), M, C, Mp, _stream()),
                "gridmm_split_rows_pad")
-    return hi, lo, cs, Mp, ops.Act(x2d, hi[:M], lo[:M])
+    return hi, lo, (cs_ws if want_colsum and defer_colsum else cs), Mp, ops.Act(x2d, hi[:M], lo[:M])
 
 
-def _gemm_tn_rows(yp, xp, N, K, M):
-    """dW (N,K) = dY^T X from the ROW planes yp = (hi, lo) (>= M rows, N) of dY and xp (>= M rows, K) of X."""
+def _gemm_tn_rows(yp, xp, N, K, M, colpart=None):
+    """dW (N,K) = dY^T X from the ROW planes yp = (hi, lo) (>= M rows, N) of dY and xp (>= M rows, K) of X.
+    colpart: the (n_part, N) column-sum partials of dY (split_rows_pad(defer_colsum=True)) -> also returns db (N,)."""
     lib = _lib.load()
     splits = 1 if SPLITK_OFF else lib.gridmm_linear_planes_tn_splits(M, N, K)
     dev = yp[0].device
     dw = torch.empty(N, K, dtype=torch.float32, device=dev)
     ws = torch.empty(splits, N, K, dtype=torch.float32, device=dev) if splits > 1 else None
-    _lib.check(lib.gridmm_linear_planes_tn(_p(yp[0]), _p(yp[1]), N, _p(xp[0]), _p(xp[1]), K, _p(dw), _p(ws), M, N, K, splits,
-                                           _stream()), "gridmm_linear_planes_tn")
-    return dw
+    if colpart is None:
+        _lib.check(lib.gridmm_linear_planes_tn(_p(yp[0]), _p(yp[1]), N, _p(xp[0]), _p(xp[1]), K, _p(dw), _p(ws), M, N, K, splits,
+                                               _stream()), "gridmm_linear_planes_tn")
+        return dw
+    db = torch.empty(N, dtype=torch.float32, device=dev)
+    _lib.check(lib.gridmm_linear_planes_tn_db(_p(yp[0]), _p(yp[1]), N, _p(xp[0]), _p(xp[1]), K, _p(dw), _p(ws), M, N, K, splits,
+                                              _p(colpart), colpart.shape[0], _p(db), _stream()), "gridmm_linear_planes_tn_db")
+    return dw, db
 
 
 def _gemm_tn(yt, xt, N, K, M, Mp, dy2d):
@@ -439,12 +530,14 @@ def _linear_bwd(ctx, dy, need_x, need_w):
     dx = dw = db = None
     yh = yl = rows = None
     if need_w and ctx.tn:
-        yh, yl, db, Mp, rows = split_rows_pad(dy2, want_colsum=ctx.has_bias)
+        yh, yl, db, Mp, rows = split_rows_pad(dy2, want_colsum=ctx.has_bias, defer_colsum=True)
     elif need_w:
         yh, yl, db, Mp, rows = transpose_split(dy2, want_colsum=ctx.has_bias, want_rows=need_x)
     if need_x:
         dx = _gemm(rows if rows is not None else dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
-    if need_w and ctx.tn:
+    if need_w and ctx.tn and ctx.has_bias:      # db: reduced from the split pass's partials by the dW summing pass
+        dw, db = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, M, colpart=db)
+    elif need_w and ctx.tn:
         dw = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, M)
     elif need_w:
         if ctx.saved_t:
@@ -460,7 +553,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, packs, out_planes=False):
         ctx.set_materialize_grads(False)   # a branch the loss does not use passes None: its backward does no work
-        ctx.wdtype = weight.dtype
+        ctx.wdtype, ctx.prm = weight.dtype, (weight, bias)
         return _linear_fwd(ctx, x, weight.shape, weight.requires_grad, bias, residual, packs, out_planes)
 
     @staticmethod
@@ -471,7 +564,8 @@ class _Linear(torch.autograd.Function):
         dx, dw, db = _linear_bwd(ctx, dy, ctx.needs_input_grad[0], need_w)
         if dw is not None:
             dw = dw.to(ctx.wdtype)
-        return dx, dw, (db if ctx.has_bias else None), (dy if ctx.has_res else None), None, None
+        hand = DEFERRED.hand
+        return dx, hand(ctx.prm[0], dw), hand(ctx.prm[1], db if ctx.has_bias else None), (dy if ctx.has_res else None), None, None
 
 
 class _LinearGroup(torch.autograd.Function):
@@ -484,6 +578,7 @@ class _LinearGroup(torch.autograd.Function):
     def forward(ctx, x, residual, packs, out_planes, nw, *wb):
         ctx.set_materialize_grads(False)
         ws, bs = wb[:nw], wb[nw:]
+        ctx.prm = wb
         ctx.rows = [int(w.shape[0]) for w in ws]
         ctx.nb = len(bs)
         bias = torch.cat([b.detach() for b in bs], 0) if bs else None
@@ -501,7 +596,8 @@ class _LinearGroup(torch.autograd.Function):
         dx, dw, db = _linear_bwd(ctx, dy, ctx.needs_input_grad[0], need_w)
         dws = list(dw.split(ctx.rows, 0)) if dw is not None else [None] * nw
         dbs = list(db.split(ctx.rows, 0)) if (db is not None and ctx.nb) else [None] * ctx.nb
-        return (dx, (dy if ctx.has_res else None), None, None, None) + tuple(dws) + tuple(dbs)
+        gr = [DEFERRED.hand(prm, g) for prm, g in zip(ctx.prm, dws + dbs)]
+        return (dx, (dy if ctx.has_res else None), None, None, None) + tuple(gr)
 
 
 def linear_group(x, weights, biases, residual=None, out_planes=False):
@@ -529,7 +625,7 @@ class _LayerNorm(torch.autograd.Function):
         act = ops.layernorm(x2, gamma.detach(), beta.detach(), eps, residual=r2, want_planes=_want_planes(x2.shape[-1]))
         y = act.f32
         ctx.save_for_backward(x2, r2, gamma)
-        ctx.eps, ctx.has_res = eps, residual is not None
+        ctx.eps, ctx.has_res, ctx.prm = eps, residual is not None, (gamma, beta)
         return _tag_planes(y, act.hi, act.lo) if act.hi is not None else y
 
     @staticmethod
@@ -547,7 +643,7 @@ class _LayerNorm(torch.autograd.Function):
         _lib.check(lib.gridmm_layernorm_bwd(_p(x2), ldx, _p(r2), _rows2d(r2)[2] if r2 is not None else 0,
                                             _p(gamma.detach()), float(ctx.eps), _p(dy), H, _p(dx), H, _p(dg), _p(db),
                                             _p(ws), M, H, _stream()), "gridmm_layernorm_bwd")
-        return dx, (dx if ctx.has_res else None), dg, db, None
+        return dx, (dx if ctx.has_res else None), DEFERRED.hand(ctx.prm[0], dg), DEFERRED.hand(ctx.prm[1], db), None
 
 
 class _LayerNormDropout(torch.autograd.Function):
@@ -574,6 +670,7 @@ class _LayerNormDropout(torch.autograd.Function):
                    "gridmm_layernorm_dropout")
         ctx.save_for_backward(x2, r2, gamma)
         ctx.eps, ctx.has_res, ctx.p, ctx.seed, ctx.seed_dev = eps, residual is not None, float(p), seed, seed_dev
+        ctx.prm = (gamma, beta)
         return _tag_planes(y, hi, lo) if hi is not None else y
 
     @staticmethod
@@ -594,7 +691,7 @@ class _LayerNormDropout(torch.autograd.Function):
                                                     _p(gamma.detach()), float(ctx.eps), _p(dy), _p(dx), _p(dr), _p(dg), _p(db),
                                                     _p(ws), ctx.p, ctx.seed, _p(ctx.seed_dev), M, H, _stream()),
                    "gridmm_layernorm_dropout_bwd")
-        return dx, dr, dg, db, None, None
+        return dx, dr, DEFERRED.hand(ctx.prm[0], dg), DEFERRED.hand(ctx.prm[1], db), None, None
 
 
 def layer_norm(x, mod, residual=None, dropout_p=0.0):
@@ -1147,6 +1244,7 @@ class _XLayer(torch.autograd.Function):
             kv, kvp, kvs = kv.float().contiguous(), None, None
         assert kvs is None or (kvs.dim() == 2 and kvs.stride(1) == 1 and kvs.shape[1] == kv.shape[2])
         (xqw, xqb, xow, xob, qw, qb, kw, kb, vw, vb, sow, sob, fiw, fib, fow, fob, xg, xb, sg, sb, fg, fb) = params
+        ctx.prm = params
         qkvb = torch.cat([qb, kb, vb], 0)
         I = fiw.shape[0]
         keep = []                                   # planes / biases / masks the C struct points into
@@ -1231,7 +1329,7 @@ class _XLayer(torch.autograd.Function):
         grads = [g["xq_w"], g["xq_b"], g["xo_w"], g["xo_b"], qw, qb, kw, kb, vw, vb, g["so_w"], g["so_b"], g["ffn_i_w"],
                  g["ffn_i_b"], g["ffn_o_w"], g["ffn_o_b"], g["x_ln_g"], g["x_ln_b"], g["s_ln_g"], g["s_ln_b"], g["f_ln_g"],
                  g["f_ln_b"]]
-        grads = [gr if ctx.needs_input_grad[9 + i] else None for i, gr in enumerate(grads)]
+        grads = [DEFERRED.hand(ctx.prm[i], gr) if ctx.needs_input_grad[9 + i] else None for i, gr in enumerate(grads)]
         return (dx, dkv, None, None, None, None, None, None, None) + tuple(grads)
 
 

@@ -266,7 +266,7 @@ extern "C" int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void*
   hipStream_t st = as_stream(stream);
   dim3 grid((C + 63) / 64, (Mp + 64 * TS_TILES - 1) / (64 * TS_TILES)), block(256);
   GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)T_hi, (unsigned short*)T_lo,
-                colsum ? colsum_ws : nullptr, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp, M);
+                colsum_ws, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp, M);
   GRIDMM_CHECK_LAUNCH();
   if (colsum) {
     GRIDMM_LAUNCH(colsum_reduce_kernel, dim3((C + 255) / 256), block, 0, st, colsum_ws, colsum, (int)grid.y, C);
@@ -285,7 +285,7 @@ extern "C" int gridmm_split_rows_pad(const float* X, int ldx, void* R_hi, void* 
   hipStream_t st = as_stream(stream);
   dim3 grid((C + 63) / 64, (Mp + 64 * TS_TILES - 1) / (64 * TS_TILES)), block(256);
   GRIDMM_LAUNCH(transpose_split_kernel, grid, block, 0, st, X, ldx, (unsigned short*)nullptr, (unsigned short*)nullptr,
-                colsum ? colsum_ws : nullptr, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp, Mp);
+                colsum_ws, (unsigned short*)R_hi, (unsigned short*)R_lo, ldp, M, C, Mp, Mp);
   GRIDMM_CHECK_LAUNCH();
   if (colsum) {
     GRIDMM_LAUNCH(colsum_reduce_kernel, dim3((C + 255) / 256), block, 0, st, colsum_ws, colsum, (int)grid.y, C);

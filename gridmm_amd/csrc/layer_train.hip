@@ -93,7 +93,10 @@ int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned s
                float* dW, float* db, int M, const LinWs& ws, gridmm_stream_t st) {
   const int N = l.N, K = l.K, Mp = mp32(M);
   unsigned short *yh = ws.yT, *yl = ws.yT + (size_t)N * Mp;
-  int rc = gridmm_split_rows_pad(dY, N, yh, yl, N, db, db ? ws.cs_ws : nullptr, M, N, Mp, st);
+  // db: the split pass leaves one column-sum partial per 256 rows; the weight gradient's summing pass reduces them
+  // (gridmm_linear_planes_tn_db) -- no reduction launch of its own unless there is no weight gradient
+  const bool fold = db && dW;
+  int rc = gridmm_split_rows_pad(dY, N, yh, yl, N, fold ? nullptr : db, db ? ws.cs_ws : nullptr, M, N, Mp, st);
   if (rc != GRIDMM_OK) return rc;
   if (dX) {
     if (!l.wt_hi || !l.wt_lo || l.Np < N) return GRIDMM_EINVAL;
@@ -103,7 +106,8 @@ int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned s
   }
   if (dW) {
     const int splits = gridmm_linear_planes_tn_splits(M, N, K);   // <= 8: ws.splitk holds 8 partial tiles
-    rc = gridmm_linear_planes_tn(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, ws.splitk, M, N, K, splits, st);
+    rc = gridmm_linear_planes_tn_db(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, ws.splitk, M, N, K, splits,
+                                    fold ? ws.cs_ws : nullptr, (Mp + 255) / 256, fold ? db : nullptr, st);
   }
   return rc;
 }

@@ -205,8 +205,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
   }
 }
 
-__global__ void sum_splits_tn_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4, int splits) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+// Second stage of a weight gradient: out = the `splits` partial products summed in order; the workgroups past `sum_blocks`
+// reduce, likewise in order, the column-sum partials of dY that the split pass left (gridmm_split_rows_pad /
+// gridmm_transpose_split with colsum = NULL): db[c] = sum_r colpart[r][c] -- the bias gradient without a launch of its own.
+__global__ void sum_splits_tn_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4, int splits,
+                                     int sum_blocks, const float* __restrict__ colpart, float* __restrict__ db, int n_part,
+                                     int C) {
+  if ((int)blockIdx.x >= sum_blocks) {
+    const int c = ((int)blockIdx.x - sum_blocks) * blockDim.x + threadIdx.x;
+    if (c < C) {
+      float s = 0.f;
+      for (int r = 0; r < n_part; ++r) s += colpart[(size_t)r * C + c];
+      db[c] = s;
+    }
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)sum_blocks * blockDim.x) {
     float4 a = reinterpret_cast<const float4*>(ws)[i];
     for (int s = 1; s < splits; ++s) {
       const float4 b = reinterpret_cast<const float4*>(ws)[(size_t)s * n4 + i];
@@ -239,11 +253,13 @@ extern "C" int gridmm_linear_planes_tn_splits(int M, int N, int K) {
 
 // C (N x K fp32, contiguous) = A^T B over the M rows of A (M x >= N) and B (M x >= K); splits > 1: the contraction is
 // cut into `splits` ranges whose partial results go to `workspace` (splits x N x K floats) and are summed in order.
-extern "C" int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo,
-                                       int ldb, float* C, float* workspace, int M, int N, int K, int splits,
-                                       gridmm_stream_t stream) {
+// colsum_ws != NULL: also db (N floats) = the n_part x N column-sum partials of A's fp32 source summed in order (the bias
+// gradient of the Linear whose weight gradient this is), by the summing pass when there is one.
+static int linear_planes_tn_impl(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
+                                 float* C, float* workspace, int M, int N, int K, int splits, const float* colsum_ws,
+                                 int n_part, float* db, gridmm_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 8 || ldb % 8 || lda < 8 || ldb < 8 || !C || splits < 1 ||
-      splits > 64 || (splits > 1 && (!workspace || (M + 31) / 32 < splits)))
+      splits > 64 || (splits > 1 && (!workspace || (M + 31) / 32 < splits)) || (colsum_ws && (!db || n_part < 1)))
     return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
   const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
@@ -254,11 +270,25 @@ extern "C" int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int l
   if (t128 >= 100 && N >= 128 && K >= 128) rc = launch_tn<128, 128, 2>(ah, al, lda, bh, bl, ldb, out, M, N, K, splits, st);
   else rc = launch_tn<64, 64, 3>(ah, al, lda, bh, bl, ldb, out, M, N, K, splits, st);
   if (rc != GRIDMM_OK) return rc;
-  if (splits > 1) {
+  if (splits > 1 || colsum_ws) {
     const size_t n4 = (size_t)N * K / 4;
-    GRIDMM_LAUNCH(sum_splits_tn_kernel, dim3((unsigned)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256)), dim3(256), 0, st,
-                  workspace, C, n4, splits);
+    const int sum_blocks = splits > 1 ? (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256) : 0;
+    const int db_blocks = colsum_ws ? (N + 255) / 256 : 0;
+    GRIDMM_LAUNCH(sum_splits_tn_kernel, dim3((unsigned)(sum_blocks + db_blocks)), dim3(256), 0, st, workspace, C, n4, splits,
+                  sum_blocks, colsum_ws, db, n_part, N);
     GRIDMM_CHECK_LAUNCH();
   }
   return GRIDMM_OK;
+}
+
+extern "C" int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo,
+                                       int ldb, float* C, float* workspace, int M, int N, int K, int splits,
+                                       gridmm_stream_t stream) {
+  return linear_planes_tn_impl(A_hi, A_lo, lda, B_hi, B_lo, ldb, C, workspace, M, N, K, splits, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int gridmm_linear_planes_tn_db(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo,
+                                          int ldb, float* C, float* workspace, int M, int N, int K, int splits,
+                                          const float* colsum_ws, int n_part, float* db, gridmm_stream_t stream) {
+  return linear_planes_tn_impl(A_hi, A_lo, lda, B_hi, B_lo, ldb, C, workspace, M, N, K, splits, colsum_ws, n_part, db, stream);
 }

@@ -238,6 +238,57 @@ inline unsigned grid_for(size_t n, size_t cap = 4096) {
 
 }  // namespace
 
+// ---- gradient accumulation of a multi-step backward in ONE launch.  A fine-tuning iteration backpropagates through the
+// 7 .. 15 navigation steps of a rollout (map_nav_src/r2r/agent.py:268-451, agent_base.py:190-199): every step hands every
+// parameter a gradient, and autograd's AccumulateGrad adds them with one launch per parameter and step (~2 000 launches of
+// ~4 us per iteration).  The custom Functions of gridmm_amd.autograd keep those gradients aside instead
+// (deferred_param_grads) and this kernel sums them at the end of the backward: dst = ((dst + src0) + src1) + ... in
+// list order -- the order and the fp32 roundings of the sequential in-place adds it replaces (bit-identical).
+struct SumDesc {
+  float* dst;
+  const float* src[7];
+  long long n;
+  int n_src, pad;
+};
+static_assert(sizeof(SumDesc) == 80, "record layout shared with gridmm_amd/autograd.py (_SUM_REC)");
+
+__global__ __launch_bounds__(256) void multi_grad_accumulate_kernel(const SumDesc* __restrict__ desc,
+                                                                    const int* __restrict__ chunk_first, int T) {
+  const int t = find_tensor(chunk_first, T, blockIdx.x);
+  const SumDesc d = desc[t];
+  const long long i0 = (long long)(blockIdx.x - chunk_first[t]) * MT_CHUNK;
+  const long long i1 = i0 + MT_CHUNK < d.n ? i0 + MT_CHUNK : d.n;
+  unsigned long long al = (unsigned long long)(size_t)d.dst;
+  for (int k = 0; k < d.n_src; ++k) al |= (unsigned long long)(size_t)d.src[k];
+  long long i = i0;
+  if ((al & 15) == 0) {                                 // MT_CHUNK % 4 == 0: chunk starts keep the alignment
+    const long long v1 = i0 + ((i1 - i0) & ~3LL);
+    for (i = i0 + 4 * threadIdx.x; i < v1; i += 4 * 256) {
+      float4 a = *reinterpret_cast<const float4*>(d.dst + i);
+      for (int k = 0; k < d.n_src; ++k) {
+        const float4 b = *reinterpret_cast<const float4*>(d.src[k] + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      *reinterpret_cast<float4*>(d.dst + i) = a;
+    }
+    i = v1;
+  }
+  for (i += threadIdx.x; i < i1; i += 256) {
+    float a = d.dst[i];
+    for (int k = 0; k < d.n_src; ++k) a += d.src[k][i];
+    d.dst[i] = a;
+  }
+}
+
+extern "C" int gridmm_multi_grad_accumulate(const void* desc, const int* chunk_first, int n_tensors, int n_chunks,
+                                            gridmm_stream_t stream) {
+  if (n_tensors <= 0 || n_chunks <= 0 || !desc || !chunk_first) return GRIDMM_EINVAL;
+  GRIDMM_LAUNCH(multi_grad_accumulate_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), (const SumDesc*)desc,
+                chunk_first, n_tensors);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
 extern "C" int gridmm_grad_sumsq(const void* g, int64_t n, int dtype, float* acc, gridmm_stream_t stream) {
   if (n <= 0 || !acc || (dtype != 0 && dtype != 1)) return GRIDMM_EINVAL;
   hipStream_t st_ = as_stream(stream);

@@ -436,7 +436,8 @@ int gridmm_copy_rows(const float* src, int64_t src_bs, int src_rs, float* dst, i
 int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, float* colsum, float* colsum_ws, void* R_hi,
                            void* R_lo, int ldp, int M, int C, int Mp, gridmm_stream_t stream);
 /* (colsum != NULL needs colsum_ws >= ceil(Mp / 256) * C floats: one partial per 256-row block, summed in a fixed
- * order -- no float atomics, db is bit-reproducible from run to run) */
+ * order -- no float atomics, db is bit-reproducible from run to run.  colsum = NULL with colsum_ws != NULL: the partials
+ * only, for gridmm_linear_planes_tn_db to reduce in the weight gradient's own summing pass) */
 /* (R_hi / R_lo, optional: the row-major planes [M][ldp] of the same X from the same pass -- the A operand of the
  * forward / dX GEMM -- so an activation or a gradient is read ONCE for both of its GEMM roles) */
 
@@ -447,6 +448,13 @@ int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, floa
  * (splits x N x K floats), summed in order (deterministic).  Backward of nn.Linear as above. */
 int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
                             float* C, float* workspace, int M, int N, int K, int splits, gridmm_stream_t stream);
+/* The same, plus the bias gradient of that Linear in the summing pass: colsum_ws = the n_part x N column-sum partials that
+ * gridmm_split_rows_pad / gridmm_transpose_split leave when called with colsum = NULL and a workspace (n_part =
+ * ceil(Mp / 256)); db[n] = their sum over the partials, in order (bit-identical to the split pass's own reduction).
+ * colsum_ws = NULL: exactly gridmm_linear_planes_tn. */
+int gridmm_linear_planes_tn_db(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
+                               float* C, float* workspace, int M, int N, int K, int splits, const float* colsum_ws,
+                               int n_part, float* db, gridmm_stream_t stream);
 /* the number of ranges (1 .. 8) that fills the chip for this problem: what the library's own callers pass as `splits` */
 int gridmm_linear_planes_tn_splits(int M, int N, int K);
 /* X fp32 [M][C] -> row-major planes [Mp][ldp] with rows [M, Mp) zero [+ colsum as gridmm_transpose_split]: one pass per
@@ -623,6 +631,14 @@ int gridmm_multi_grad_sumsq(const void* desc, const int* chunk_first, int n_tens
 int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tensors, int n_chunks, float beta1,
                             float beta2, int decay_first, const float* sumsq, float max_norm, const void* planes,
                             gridmm_stream_t stream);
+
+/* Gradient accumulation of a multi-step backward as ONE launch (fine-tuning: one backward through the 7 .. 15 navigation
+ * steps of a rollout, map_nav_src/r2r/agent_base.py:190-199 -- under torch autograd every step's gradient of every parameter
+ * is added by its own launch).  desc: device array of n_tensors records {float* dst; const float* src[7]; int64 n;
+ * int32 n_src, pad;} (80 bytes); dst[i] = ((dst[i] + src[0][i]) + src[1][i]) + ... over n_src <= 7 sources, fp32, in list
+ * order (bit-identical to the sequential in-place adds).  chunk_first / n_chunks as above. */
+int gridmm_multi_grad_accumulate(const void* desc, const int* chunk_first, int n_tensors, int n_chunks,
+                                 gridmm_stream_t stream);
 
 /* ---- one cross-modal layer of the DIFFERENTIABLE path: forward that keeps what the backward needs + the whole backward
  * of the layer as ONE call (gridmm_xattn_layer_bwd).  GraphLXRTXLayer.forward with graph_sprels = None

@@ -92,3 +92,22 @@ def test_linear_backward_through_the_tn_path_matches_torch(dev):
     (yd * torch.cos(yd)).sum().backward()
     for a, r in zip(got, (xd.grad, wd.grad, bd.grad)):
         assert float((a.double() - r).abs().max()) <= 3e-5 * max(1.0, float(r.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(1824, 768, 768), (6912, 3072, 768), (57, 64, 64), (300, 2304, 768), (33, 8, 40)])
+def test_bias_gradient_from_the_summing_pass_is_bit_identical(dev, M, N, K):
+    """gridmm_linear_planes_tn_db: db reduced from the split pass's per-256-row partials inside the weight gradient's summing
+    pass (or by that pass alone when the contraction is not split) == the split pass's own reduction, bit for bit; dW is
+    untouched by the extra workgroups."""
+    from gridmm_amd import autograd as ag
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    dy = (torch.randn(M, N, generator=g) * 0.1).to(dev)
+    xh, xl, _, _, _ = ag.split_rows_pad(x)
+    yh, yl, db_ref, _, _ = ag.split_rows_pad(dy, want_colsum=True)
+    yh2, yl2, part, _, _ = ag.split_rows_pad(dy, want_colsum=True, defer_colsum=True)
+    assert part.shape == (((M + 31) // 32 * 32 + 255) // 256, N)
+    dw_ref = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M)
+    dw, db = ag._gemm_tn_rows((yh2, yl2), (xh, xl), N, K, M, colpart=part)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)

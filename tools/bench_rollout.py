@@ -16,8 +16,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--slow-too", action="store_true")
     ap.add_argument("--profile", action="store_true", help="cProfile of the host side of the timed rollouts")
+    ap.add_argument("--nosync-sections", action="store_true", help="section timers without device synchronisation: where the HOST spends a step")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.nosync_sections:
+        from gridmm_amd.agent import GMapNavAgent
+        GMapNavAgent.timers_sync = False
     if a.profile:
         import cProfile
         import pstats
