@@ -1,3 +1,7 @@
+"""Diagnostic: is the pre-training step bit-reproducible?  Runs the same two tasks twice (eager / captured, per argv[1]) from
+identical copies of the model and prints whether losses and gradient norms match bit for bit (the property
+tests/test_hip_train_graph.py asserts; this script is the interactive form used to find the atomics that broke it in round 3).
+usage (repo root): python tools/dbg_determinism.py eager|graph"""
 import os, sys, copy
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import torch

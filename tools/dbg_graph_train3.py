@@ -1,3 +1,6 @@
+"""Diagnostic driver of the captured pre-training step (reduced or `full` size; env DROP / TIMING): builds the trainer, captures
+one task graph and replays it -- the workload that tools/train_graph_gaps.sh traces to tell a GPU-bound replay from a
+dispatch-bound one.  usage (repo root): python tools/dbg_graph_train3.py [full]"""
 import sys, copy, time
 sys.path.insert(0, ".")
 import numpy as np, torch, os

@@ -1,5 +1,8 @@
+"""Diagnostic: per-parameter gradient error of the full-size pre-training twin against the reference's fixture
+(tests/golden/pretrain_full_b2.npz), for A/B runs of a kernel change (e.g. GRIDMM_TRAIN_ATTENTION_BF16=0/1: the numbers in
+profiles/r5_attention_train_bench.txt).  usage (repo root): python tools/dbg_pretrain_grad_errors.py mlm|mrc|sap"""
 import os, sys, json
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np, torch
 from conftest import load_golden
 import test_hip_pretrain as T

@@ -1,5 +1,9 @@
+"""Diagnostic: loss and worst gradient errors of the pre-training twin against both reference fixtures (reduced and full
+size), all three tasks -- the table behind the bounds asserted in tests/test_hip_pretrain.py.
+usage (repo root): python tools/grad_errs.py"""
+import os
 import json, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from conftest import load_golden
 from oracle import gen_golden
 import test_hip_pretrain as TP
