@@ -286,7 +286,7 @@ def config_legs(args, dev, steps):
     return res
 
 
-def rollout_leg(args, dev, rollouts=4):
+def rollout_leg(args, dev, rollouts=4, profiler=None):
     """End to end: GMapNavAgent.rollout (map_nav_src/r2r/agent.py:268-451) over the synthetic environment, B = 32
     episodes x up to 15 steps at the BASELINE observation shape -- 'language' once, then per step 'panorama', TopoMap
     update, input collation, fill_gridmap, 'navigation', action selection, env step (argmax feedback, no_grad, varlen map
@@ -313,8 +313,12 @@ def rollout_leg(args, dev, rollouts=4):
             agent.rollout()                   # the weights, captures the graphs of the shapes these rollouts visit
         torch.cuda.synchronize()
         n0, t0 = agent.nav_steps, time.perf_counter()
+        if profiler is not None:              # tools/bench_rollout.py --profile: the host side of the timed rollouts only
+            profiler.enable()
         for _ in range(rollouts):
             agent.rollout()
+        if profiler is not None:
+            profiler.disable()
         torch.cuda.synchronize()
         dt, steps = time.perf_counter() - t0, agent.nav_steps - n0
         agent.timers = {}

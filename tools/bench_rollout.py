@@ -26,9 +26,7 @@ def main():
         import cProfile
         import pstats
         pr = cProfile.Profile()
-        pr.enable()
-        r = bench.rollout_leg(a, dev)
-        pr.disable()
+        r = bench.rollout_leg(a, dev, profiler=pr)
         print(json.dumps(r, indent=1))
         pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
         pstats.Stats(pr).sort_stats("tottime").print_stats(30)
