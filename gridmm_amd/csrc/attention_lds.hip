@@ -67,11 +67,7 @@ __device__ unsigned long long g_att_prof[8];
 // SEG: 0 = one context buffer; 1 = keys >= S1 in a second buffer, S1 % 8 == 0 (every 8-row DMA piece lies in one buffer: the
 // choice is wave-uniform, scalar selects only -- per-lane selects in the loader's address path cost the step 0.4 ms when
 // they sat in every call); 2 = any S1 (per-lane selects).
-// KSPL = 2 (few query tiles, long key lists: the 57-query calls of the local encoder): the workgroup's keys are SPLIT over
-// two groups of NW / 2 math waves -- group kg walks the chunks [kg * half, (kg + 1) * half) with its own loader wave and ring
-// slots -- and the two partial results (m, l, O) of a query tile are combined through LDS at the end: half the dependent
-// chunk steps per wave, twice the waves per SIMD.
-template <int NQ, int NW, int KC, int AB = 0, int NL = 1, int SEG = 0, int KSPL = 1>
+template <int NQ, int NW, int KC, int AB = 0, int NL = 1, int SEG = 0>
 __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
     const unsigned short* __restrict__ Qh, const unsigned short* __restrict__ Ql, int64_t q_bs, int q_rs,
     const unsigned short* __restrict__ Kh, const unsigned short* __restrict__ Kl, int64_t k_bs, int k_rs,
@@ -81,11 +77,9 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
     float scale, const unsigned short* __restrict__ K2h, const unsigned short* __restrict__ K2l,
     const unsigned short* __restrict__ V2h, const unsigned short* __restrict__ V2l, int64_t kv2_bs, int kv2_rs, int S1) {
   static_assert(KC % 32 == 0 && 2 * 4 * KC * 128 <= 65536, "chunk ring (also the 16-bit ds offset field)");
-  static_assert(KSPL == 1 || (KSPL == 2 && NQ == 1 && NL == 2 && NW % 2 == 0 && AB == 0), "key split: one loader per key group");
-  constexpr int NWQ = NW / KSPL;                                  // math waves (= query-tile sets) per key group
   constexpr int PLANE = KC * 64;                                  // u16 per plane image
   constexpr int NT = KC / 32;                                     // key tiles per chunk
-  __shared__ __attribute__((aligned(16))) unsigned short kvbuf[2 * KSPL * 4 * PLANE];   // 2 x KSPL x (K hi | K lo | V hi | V lo)
+  __shared__ __attribute__((aligned(16))) unsigned short kvbuf[2 * 4 * PLANE];   // 2 x (K hi | K lo | V hi | V lo)
   __shared__ unsigned s_mw[64];                                   // key validity, one word per 32 keys (Sk <= 2048)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -125,10 +119,9 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
   auto stage = [&](int key0c, int buf) {   // piece = (plane, 8 key rows); lane -> (row r0 + lane / 8, slot lane % 8)
     if (AB == 1 || AB == 3) return;        // timing ablation: no staging
     const int lrow = lane >> 3, coff = ((lane & 7) ^ (lrow & 6)) << 3;   // r0 % 8 == 0: the slot swizzle is per lane
-    const int li = (NL > 1 && KSPL == 1) ? wave - NW : 0;                // the NL loader waves take every NL-th row group
-    constexpr int RSTEP = KSPL == 1 ? 8 * NL : 8;                        // (key split: a loader stages whole chunks of its group)
+    const int li = NL > 1 ? wave - NW : 0;                               // the NL loader waves take every NL-th row group
 #pragma unroll
-    for (int r0 = 8 * li; r0 < KC; r0 += RSTEP) {
+    for (int r0 = 8 * li; r0 < KC; r0 += 8 * NL) {
       const int key = min(key0c + r0 + lrow, Sk - 1);
       unsigned short* d = kvbuf + buf * (4 * PLANE) + r0 * 64;
       if constexpr (SEG == 0) {
@@ -160,12 +153,8 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = __builtin_readcyclecounter();
 #endif
-  const int nch = (Sk + KC - 1) / KC;                             // chunks in all; a key group walks `half` of them
-  const int half = KSPL == 1 ? nch : (nch + 1) / 2;
   if (wave >= NW) {                        // ---------------- loader wave(s)
-    const int grp = KSPL == 1 ? 0 : wave - NW;                     // key split: loader `grp` feeds key group `grp`
-    const int c0 = grp * half;
-    if (c0 < nch) stage(c0 * KC, grp);
+    stage(0, 0);
     if (wave == NW) {   // validity words from independent byte loads, under the first DMA
       const uint8_t* mrow = kmask ? kmask + (size_t)b * mask_bs : nullptr;
       for (int i = 0; i < ((Sk + 63) >> 6); ++i) {
@@ -175,11 +164,11 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
       }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // chunk 0 (of every group) and the validity words are visible
+    __builtin_amdgcn_s_barrier();          // chunk 0 and the validity words are visible
     int lb = 0;
-    for (int s = 0; s < half; ++s, lb ^= 1) {
-      if (s + 1 < half && c0 + s + 1 < nch) {
-        stage((c0 + s + 1) * KC, (lb ^ 1) * KSPL + grp);
+    for (int key0c = 0; key0c < Sk; key0c += KC, lb ^= 1) {
+      if (key0c + KC < Sk) {
+        stage(key0c + KC, lb ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();        // chunk c+1 landed; the math waves are done with chunk c
@@ -187,8 +176,7 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
     return;
   }
 
-  const int qi = KSPL == 1 ? wave : wave % NWQ, kg = KSPL == 1 ? 0 : wave / NWQ;
-  const int qt0 = (blockIdx.x * NWQ + qi) * NQ;                   // first query tile of this wave
+  const int qt0 = (blockIdx.x * NW + wave) * NQ;                  // first query tile of this wave
   // Q^T as the B operand of S^T = K Q^T: lane (query j, k-chunk g) holds head dims 32 ks + 8g .. +8.  Query tiles past
   // Sq run on a copy of row Sq-1 and are not stored.
   bf16x8_t qh[NQ][2], ql[NQ][2];
@@ -211,20 +199,18 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
   GRIDMM_T(0);                                                    // prologue issue
   __builtin_amdgcn_s_barrier();                                   // chunk 0 and the validity words are visible
   GRIDMM_T(1);
-  for (int s = 0; s < half; ++s, buf ^= 1) {
-    const int key0c = (kg * half + s) * KC;
-    if (s) {
+  for (int key0c = 0; key0c < Sk; key0c += KC, buf ^= 1) {
+    const int rows = min(KC, ((Sk - key0c + 31) >> 5) << 5);      // multiple of 32
+    if (key0c) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's LDS reads of the previous chunk are done
       __builtin_amdgcn_s_barrier();                               // hand-over: next chunk landed, previous buffer free
       GRIDMM_T(2);
     }
     if (AB == 2 || AB == 3) continue;                             // timing ablation: no math (barriers stay)
-    if (KSPL > 1 && key0c >= Sk) continue;                        // (the last group's list is one chunk shorter)
-    const int rows = min(KC, ((Sk - key0c + 31) >> 5) << 5);      // multiple of 32
-    const unsigned short* kv = kvbuf + (buf * KSPL + kg) * (4 * PLANE);
+    const unsigned short* kv = kvbuf + buf * (4 * PLANE);
     unsigned vaddr[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) vaddr[n] = vaddr0[n] + (unsigned)((buf * KSPL + kg) * (4 * PLANE) * 2);
+    for (int n = 0; n < 4; ++n) vaddr[n] = vaddr0[n] + (unsigned)(buf * (4 * PLANE) * 2);
 
     // ---- the chunk's (<= KC / 32) key tiles in three lock-step phases over the wave's NQ query tiles: all score
     // tiles (independent MFMA chains), ONE max / rescale / row-sum exchange per query tile, all P V tiles.
@@ -362,29 +348,6 @@ __global__ __launch_bounds__((NW + NL) * 64) void attention_rows_kernel(
   }
 
   __builtin_amdgcn_s_barrier();                                   // pairs with the loader's last hand-over
-  if constexpr (KSPL == 2) {
-    // ---- combine the two key groups of a query tile: the ring is free (every wave passed the barrier above); group 1
-    // parks (m, l, O) in it, group 0 merges in the log2 domain and stores.  [qi][18 values][lane]
-    float* comb = reinterpret_cast<float*>(kvbuf) + (size_t)qi * 18 * 64 + lane;
-    if (kg == 1) {
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) comb[(n * 4 + e) * 64] = o[0][n][e];
-      comb[16 * 64] = m_run[0];
-      comb[17 * 64] = l_run[0];
-    }
-    __syncthreads();                                              // (the loader waves have ended: math waves only)
-    if (kg == 1) return;
-    const float m1 = comb[16 * 64], l1 = comb[17 * 64];
-    const float m = fmaxf(m_run[0], m1);
-    const float a0 = __builtin_amdgcn_exp2f(m_run[0] - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
-    l_run[0] = l_run[0] * a0 + l1 * a1;
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[0][n][e] = o[0][n][e] * a0 + comb[(n * 4 + e) * 64] * a1;
-  }
   // ---- finish from registers: lane (j, g) holds O[query j][16n + 4g .. +3]
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
@@ -467,13 +430,6 @@ static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs,
     dim3 grid((nqt + (NQ) * (NW) - 1) / ((NQ) * (NW)), heads, B), block(((NW) + (NL)) * 64);                               \
     GRIDMM_LAUNCH((attention_rows_kernel<NQ, NW, KC, AB, NL, SEG>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS); \
   } while (0)
-#define GRIDMM_ATTK(NWQ, KC)            /* keys split over two groups of NWQ math waves (two loaders) */                   \
-  do {                                                                                                              \
-    dim3 grid((nqt + (NWQ) - 1) / (NWQ), heads, B), block((2 * (NWQ) + 2) * 64);                                      \
-    if (seg == 0) GRIDMM_LAUNCH((attention_rows_kernel<1, 2 * (NWQ), KC, 0, 2, 0, 2>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS); \
-    else if (seg == 1) GRIDMM_LAUNCH((attention_rows_kernel<1, 2 * (NWQ), KC, 0, 2, 1, 2>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS); \
-    else GRIDMM_LAUNCH((attention_rows_kernel<1, 2 * (NWQ), KC, 0, 2, 2, 2>), grid, block, 0, as_stream(stream), GRIDMM_ATT_ARGS); \
-  } while (0)
 #define GRIDMM_ATTL(NQ, NW, KC, AB, NL)                                                                                 \
   do {                                                                                                              \
     if (seg) return GRIDMM_EINVAL;      /* two context buffers: only the configurations instantiated for it below */ \
@@ -502,7 +458,6 @@ static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs,
     case 23: GRIDMM_ATT(1, 12, 32); break;
     case 24: GRIDMM_ATTG(1, 7, 32, 1); break;          // two workgroups of 7 query tiles (216 queries = 14 tiles: no idle wave)
     case 25: GRIDMM_ATT(2, 7, 32); break;          // one workgroup, two query tiles per wave
-    case 40: GRIDMM_ATTK(4, 32); break;            // key split: 4 query tiles x 2 key groups
     case 14: GRIDMM_ATTL(1, 8, 64, 0, 2); break;   // two loader waves
     case 15: GRIDMM_ATTG(1, 4, 32, 2); break;
     case 16: GRIDMM_ATTL(2, 8, 64, 0, 2); break;
@@ -518,7 +473,6 @@ static int attention_rows_impl(const void* Q_hi, const void* Q_lo, int64_t q_bs,
 #undef GRIDMM_ATTL
 #undef GRIDMM_ATTG
 #undef GRIDMM_ATTS
-#undef GRIDMM_ATTK
 #undef GRIDMM_ATT_ARGS
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;

@@ -174,7 +174,7 @@ def test_attention_bf16x3_planes_matches_fp32_softmax(dev, B, Sq, Sk):
     assert ((out.hi.float() + out.lo.float()) - o).abs().max() <= 2.0 ** -15 * o.abs().max()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 9, 24, 40])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5, 6, 9, 24])
 @pytest.mark.parametrize("B,Sq,Sk", [(2, 16, 32), (3, 57, 296), (2, 216, 216), (1, 5, 37), (2, 216, 80), (2, 57, 57), (1, 40, 512),
                                      (2, 90, 700), (1, 300, 1100)])   # RxR: 250-300 instruction tokens + map + a long graph
 def test_attention_rows_matches_fp32_softmax(dev, B, Sq, Sk, cfg):

@@ -26,7 +26,7 @@ BIG = [(6912, 3072, 768), (6912, 768, 3072), (6912, 768, 768), (6912, 2304, 768)
 CANDS_BIG = [15, 36, 60, 61, 62, 63, 64, 16]        # BK = 32 tiles, all with tiled weight planes
 CANDS_THIN = [43, 8, 13, 21, 50, 52, 53, 55, 56, 6, 9, 15]
 ATT_BIG = [9, 3, 20, 21, 22, 23, 24, 25]
-ATT_SMALL = [5, 15, 40]
+ATT_SMALL = [5, 1, 15, 18]
 
 
 def main():
