@@ -329,6 +329,8 @@ def rollout_leg(args, dev, rollouts=4, profiler=None):
     tot = sum(agent.timers.values())
     x2 = None
     try:
+        # (B episodes as two half-batches in flight, rollout_interleaved(..., B=B // 2), measured in round 5: 8 250 against
+        # 8 040 for the single batch on the same box -- the host work of a step does not halve with the batch)
         x2 = rollout_interleaved(args, dev, model, geom, T, rollouts)
     except Exception as e:          # a secondary key of a secondary key
         x2 = {"error": repr(e)[:200]}
@@ -384,17 +386,18 @@ def finetune_leg(args, dev, iters=3):
                         "resident in HBM, full-size model" % (B, T)}
 
 
-def rollout_interleaved(args, dev, model, geom, T, rollouts):
-    """Evaluation throughput with TWO mini-batches of B = 32 in flight (GMapNavAgent.interleaved_rollouts): the two rollouts
-    are advanced alternately at their per-step yield points, each on its own stream, so one batch's host collation runs
-    under the other's 'navigation' kernels.  Same model, separate environments / grid memories / graph caches; every
-    trajectory equals the one the batch produces alone (tests/test_agent_loop.py)."""
+def rollout_interleaved(args, dev, model, geom, T, rollouts, B=None, n_agents=2):
+    """Evaluation throughput with SEVERAL mini-batches in flight (GMapNavAgent.interleaved_rollouts): the rollouts are advanced
+    alternately at their per-step yield points, each on its own stream, so one batch's host collation runs under the
+    others' 'navigation' kernels.  Same model, separate environments / grid memories / graph caches; every trajectory
+    equals the one the batch produces alone (tests/test_agent_loop.py).  Default: two batches of B = 32; B = 16 x 2 is the
+    reference's 32 episodes in flight, stepped as two half-batches."""
     from gridmm_amd.agent import GMapNavAgent, default_args
     from gridmm_amd.grid_memory import GridMemoryBatch
     from gridmm_amd.sim_env import SyntheticNavEnv
-    B = args.batch
+    B = B or args.batch
     agents = []
-    for k in range(2):
+    for k in range(n_agents):
         mem = GridMemoryBatch(B, geom, max_steps=T + 2, device=dev)
         env = SyntheticNavEnv(B, mem, n_scans=4, n_episodes=4 * B, seed=3 + 7 * k, geom=geom, vocab=30000)
         env.build_device_store(dev)
@@ -413,8 +416,10 @@ def rollout_interleaved(args, dev, model, geom, T, rollouts):
             GMapNavAgent.interleaved_rollouts(agents, streams)
         torch.cuda.synchronize()
         dt, steps = time.perf_counter() - t0, sum(a.nav_steps for a in agents) - n0
-    return {"value": B * steps / dt, "unit": "episode-steps/s", "ms_per_step_of_32": 1e3 * dt / steps, "batches_in_flight": 2,
-            "episodes_in_flight": 2 * B}
+    del agents
+    torch.cuda.empty_cache()
+    return {"value": B * steps / dt, "unit": "episode-steps/s", "ms_per_step_of_32": 1e3 * dt / (B * steps) * 32,
+            "batches_in_flight": n_agents, "batch": B, "episodes_in_flight": n_agents * B}
 
 
 def producer_leg(args, dev, steps=5):
