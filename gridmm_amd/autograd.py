@@ -1236,13 +1236,16 @@ class _XLayer(torch.autograd.Function):
         lib = _lib.load()
         H = heads * 64
         B, Sq = x.shape[:2]
-        Sk = kv.shape[1]
+        cross = kv is not None                      # kv = None: a BertLayer (self attention + feed forward; bert_layer_fused)
+        Sk = kv.shape[1] if cross else 0
         x2 = x.float().contiguous()
-        kvp = _planes_strided(kv) if BF16_ATTENTION else None     # planes of the context projections (same strides as kv)
-        kvs = getattr(kv, "_gridmm_shift", None) if kvp is not None else None   # (B, width): row 0 of every episode (shifted planes)
-        if kv.stride(2) != 1 or kv.dtype != torch.float32:
-            kv, kvp, kvs = kv.float().contiguous(), None, None
-        assert kvs is None or (kvs.dim() == 2 and kvs.stride(1) == 1 and kvs.shape[1] == kv.shape[2])
+        kvp = kvs = None
+        if cross:
+            kvp = _planes_strided(kv) if BF16_ATTENTION else None     # planes of the context projections (same strides as kv)
+            kvs = getattr(kv, "_gridmm_shift", None) if kvp is not None else None   # (B, width): row 0 of every episode (shifted planes)
+            if kv.stride(2) != 1 or kv.dtype != torch.float32:
+                kv, kvp, kvs = kv.float().contiguous(), None, None
+            assert kvs is None or (kvs.dim() == 2 and kvs.stride(1) == 1 and kvs.shape[1] == kv.shape[2])
         (xqw, xqb, xow, xob, qw, qb, kw, kb, vw, vb, sow, sob, fiw, fib, fow, fob, xg, xb, sg, sb, fg, fb) = params
         ctx.prm = params
         qkvb = torch.cat([qb, kb, vb], 0)
@@ -1250,6 +1253,8 @@ class _XLayer(torch.autograd.Function):
         keep = []                                   # planes / biases / masks the C struct points into
 
         def lin(w, b):
+            if w is None:
+                return _CLinearTrain()
             get = WEIGHTS.getter(w)
             pf, pt = get(False), get(True)
             bb = b.detach().float().contiguous()
@@ -1258,11 +1263,13 @@ class _XLayer(torch.autograd.Function):
                                  bb.data_ptr(), w.shape[0], w.shape[1])
 
         def lnp(g, b, e):
+            if g is None:
+                return _CLnTrain()
             gg, bb = g.detach().float().contiguous(), b.detach().float().contiguous()
             keep.extend([gg, bb])
             return _CLnTrain(gg.data_ptr(), bb.data_ptr(), float(e))
         draw = lambda on: hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item())) if on else 0   # noqa: E731
-        seeds = [draw(p_attn > 0), draw(p_hidden > 0), draw(p_attn > 0), draw(p_hidden > 0), draw(p_hidden > 0)]
+        seeds = [draw(cross and p_attn > 0), draw(cross and p_hidden > 0), draw(p_attn > 0), draw(p_hidden > 0), draw(p_hidden > 0)]
         seed_dev = SEED_DEV if ((p_attn > 0 or p_hidden > 0) and hs.MODE is not None) else None
         def lin_group(ws, b):           # q | k | v as ONE projection: fused planes of the three Parameters (no torch.cat of weights)
             if WEIGHTS.groupable(tuple(ws)):
@@ -1289,12 +1296,13 @@ class _XLayer(torch.autograd.Function):
         y = torch.empty(B, Sq, H, dtype=torch.float32, device=x.device)
         _lib.check(lib.gridmm_xattn_layer_train_fwd(
             ctypes.byref(L), _p(x2), _p(kv), _p(kvp[0] if kvp else None), _p(kvp[1] if kvp else None), _p(kvs),
-            kvs.stride(0) if kvs is not None else 0, kv.stride(0), kv.stride(1), int(k_col), int(k_col) + H, _p(cm),
+            kvs.stride(0) if kvs is not None else 0, kv.stride(0) if cross else 0, kv.stride(1) if cross else 0, int(k_col),
+            int(k_col) + H, _p(cm),
             cm.stride(0) if cm is not None else 0, _p(sm), sm.stride(0) if sm is not None else 0, _p(y), _p(saved),
             saved.numel(), _p(ws), ws.numel(), B, Sq, Sk, heads, _stream()), "gridmm_xattn_layer_train_fwd")
         ctx.save_for_backward(x2, kv, cm, sm, saved, *(kvp if kvp else ()), *([kvs] if kvs is not None else []))
         ctx.L, ctx.keep, ctx.dims = L, keep, (B, Sq, Sk, H, I, heads, int(k_col))
-        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.shapes = [tuple(p.shape) if p is not None else None for p in params]
         return y
 
     @staticmethod
@@ -1306,31 +1314,50 @@ class _XLayer(torch.autograd.Function):
         dev = dy.device
         dy = dy.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
-        g = {"xq_w": torch.empty(H, H, **f32), "xq_b": torch.empty(H, **f32), "xo_w": torch.empty(H, H, **f32),
-             "xo_b": torch.empty(H, **f32), "sqkv_w": torch.empty(3 * H, H, **f32), "sqkv_b": torch.empty(3 * H, **f32),
+        cross = kv is not None
+        g = {"sqkv_w": torch.empty(3 * H, H, **f32), "sqkv_b": torch.empty(3 * H, **f32),
              "so_w": torch.empty(H, H, **f32), "so_b": torch.empty(H, **f32), "ffn_i_w": torch.empty(I, H, **f32),
              "ffn_i_b": torch.empty(I, **f32), "ffn_o_w": torch.empty(H, I, **f32), "ffn_o_b": torch.empty(H, **f32)}
-        for n in ("x_ln_g", "x_ln_b", "s_ln_g", "s_ln_b", "f_ln_g", "f_ln_b"):
+        if cross:
+            g.update({"xq_w": torch.empty(H, H, **f32), "xq_b": torch.empty(H, **f32), "xo_w": torch.empty(H, H, **f32),
+                      "xo_b": torch.empty(H, **f32), "x_ln_g": torch.empty(H, **f32), "x_ln_b": torch.empty(H, **f32)})
+        for n in ("s_ln_g", "s_ln_b", "f_ln_g", "f_ln_b"):
             g[n] = torch.empty(H, **f32)
-        G = _CXLayerGrads(*[g[n].data_ptr() for n, _ in _CXLayerGrads._fields_])
+        G = _CXLayerGrads(*[_ptr(g.get(n)) for n, _ in _CXLayerGrads._fields_])
         dx = torch.empty_like(x2)
-        C = kv.shape[-1]
-        covered = (k_col == 0 and C == 2 * H)
-        dkv = (torch.empty if covered else torch.zeros)(B, Sk, C, **f32)    # K / V blocks of other layers: zero gradient here
+        dkv, C = None, 0
+        if cross:
+            C = kv.shape[-1]
+            covered = (k_col == 0 and C == 2 * H)
+            dkv = (torch.empty if covered else torch.zeros)(B, Sk, C, **f32)    # K / V blocks of other layers: zero gradient here
         ws = torch.empty(int(lib.gridmm_xattn_layer_train_workspace(B, Sq, H, I)), dtype=torch.uint8, device=dev)
         _lib.check(lib.gridmm_xattn_layer_bwd(
             ctypes.byref(ctx.L), _p(x2), _p(kv), _p(kvp[0] if kvp else None), _p(kvp[1] if kvp else None), _p(kvs),
-            kvs.stride(0) if kvs is not None else 0, kv.stride(0), kv.stride(1), k_col, k_col + H, _p(cm),
+            kvs.stride(0) if kvs is not None else 0, kv.stride(0) if cross else 0, kv.stride(1) if cross else 0, k_col,
+            k_col + H, _p(cm),
             cm.stride(0) if cm is not None else 0, _p(sm), sm.stride(0) if sm is not None else 0, _p(saved), saved.numel(),
             _p(dy), _p(dx), _p(dkv), Sk * C, C, ctypes.byref(G), _p(ws), ws.numel(), B, Sq, Sk, heads, _stream()),
             "gridmm_xattn_layer_bwd")
         qw, kw, vw = g["sqkv_w"].split(H, 0)
         qb, kb, vb = g["sqkv_b"].split(H, 0)
-        grads = [g["xq_w"], g["xq_b"], g["xo_w"], g["xo_b"], qw, qb, kw, kb, vw, vb, g["so_w"], g["so_b"], g["ffn_i_w"],
-                 g["ffn_i_b"], g["ffn_o_w"], g["ffn_o_b"], g["x_ln_g"], g["x_ln_b"], g["s_ln_g"], g["s_ln_b"], g["f_ln_g"],
-                 g["f_ln_b"]]
-        grads = [DEFERRED.hand(ctx.prm[i], gr) if ctx.needs_input_grad[9 + i] else None for i, gr in enumerate(grads)]
+        grads = [g.get("xq_w"), g.get("xq_b"), g.get("xo_w"), g.get("xo_b"), qw, qb, kw, kb, vw, vb, g["so_w"], g["so_b"],
+                 g["ffn_i_w"], g["ffn_i_b"], g["ffn_o_w"], g["ffn_o_b"], g.get("x_ln_g"), g.get("x_ln_b"), g["s_ln_g"],
+                 g["s_ln_b"], g["f_ln_g"], g["f_ln_b"]]
+        grads = [DEFERRED.hand(ctx.prm[i], gr) if (gr is not None and ctx.needs_input_grad[9 + i]) else None
+                 for i, gr in enumerate(grads)]
         return (dx, dkv, None, None, None, None, None, None, None) + tuple(grads)
+
+
+def bert_layer_fused(x, self_mask, heads, p_hidden, p_attn, selfatt, inter, output):
+    """BertLayer (vilmodel.py:214-231: BertAttention + BertIntermediate + BertOutput) as ONE autograd node: the layer C calls
+    with no context (KV = NULL).  Same kernels in the same order as vilmodel_train.bert_layer's op-by-op form."""
+    s = selfatt.self
+    params = (None, None, None, None, s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias,
+              selfatt.output.dense.weight, selfatt.output.dense.bias, inter.dense.weight, inter.dense.bias,
+              output.dense.weight, output.dense.bias, None, None,
+              selfatt.output.LayerNorm.weight, selfatt.output.LayerNorm.bias, output.LayerNorm.weight, output.LayerNorm.bias)
+    eps = (0.0, float(selfatt.output.LayerNorm.eps), float(output.LayerNorm.eps))
+    return _XLayer.apply(x, None, None, self_mask, 0, heads, float(p_hidden), float(p_attn), eps, *params)
 
 
 def x_layer_fused(x, kv, ctx_mask, self_mask, k_col, heads, p_hidden, p_attn, xatt, selfatt, inter, output):

@@ -48,10 +48,10 @@ Saved carve_saved(char* base, int B, int Sq, int H, int I, int heads) {
   return s;
 }
 
-bool shapes_ok(const gridmm_xlayer_train_t* L, int H, int I) {
+bool shapes_ok(const gridmm_xlayer_train_t* L, int H, int I, bool cross = true) {
   const gridmm_linear_train_t* ls[6] = {&L->xq, &L->xo, &L->sqkv, &L->so, &L->ffn_i, &L->ffn_o};
   const int N[6] = {H, H, 3 * H, H, I, H}, K[6] = {H, H, H, H, H, I};
-  for (int i = 0; i < 6; ++i)
+  for (int i = cross ? 0 : 2; i < 6; ++i)
     if (ls[i]->N != N[i] || ls[i]->K != K[i] || !ls[i]->w_hi || !ls[i]->w_lo || ls[i]->Kp < K[i]) return false;
   return H % 32 == 0 && I % 32 == 0;
 }
@@ -135,9 +135,12 @@ extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, cons
                                             const uint8_t* self_mask, int self_mask_bs, float* Y, void* saved,
                                             size_t saved_bytes, void* workspace, size_t workspace_bytes, int B, int Sq,
                                             int Sk, int heads, gridmm_stream_t stream) {
-  if (!L || !X || !KV || !Y || !saved || !workspace || B <= 0 || Sq <= 0 || Sk <= 0 || heads <= 0) return GRIDMM_EINVAL;
+  // KV == NULL: a BertLayer (vilmodel.py:214-231: self attention + feed forward, no cross-attention block; the xq / xo / x_ln
+  // members of L are not read)
+  const bool cross = KV != nullptr;
+  if (!L || !X || !Y || !saved || !workspace || B <= 0 || Sq <= 0 || (cross && Sk <= 0) || heads <= 0) return GRIDMM_EINVAL;
   const int H = heads * 64, I = L->ffn_i.N, M = B * Sq, Sqp = (Sq + 15) / 16 * 16;
-  if (!shapes_ok(L, H, I)) return GRIDMM_EINVAL;
+  if (!shapes_ok(L, H, I, cross)) return GRIDMM_EINVAL;
   if (saved_bytes < gridmm_xattn_layer_train_saved_bytes(B, Sq, H, I) ||
       workspace_bytes < gridmm_xattn_layer_train_workspace(B, Sq, H, I))
     return GRIDMM_EINVAL;
@@ -158,6 +161,10 @@ extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, cons
       return gridmm_layernorm_dropout_planes(x, r, H, p.gamma, p.beta, p.eps, y, yP, yl, ph, seed, L->seed_dev, M, H, stream);
     return gridmm_layernorm(x, H, r, H, p.gamma, p.beta, p.eps, y, H, nullptr, 0, nullptr, nullptr, yP, yl, H, M, H, stream);
   };
+  const float* a1 = cross ? s.a1 : X;             // input of the self-attention block (and its LayerNorm's residual)
+  if (!cross) {                                   // the layer input straight into the self-attention block: its planes
+    GRIDMM_TRY(gridmm_split_rows_pad(X, H, s.a1T, s.a1T + (size_t)H * Mp, H, nullptr, nullptr, M, H, Mp, stream));
+  } else {
   // ---- cross attention (vilmodel.py:370-379)
   if (!L->attention_fp32 && planes_ok(KV_hi, KV_lo, kv_bs, kv_rs, k_col, v_col, Sk)) {
     unsigned short* qP = (unsigned short*)s.q;
@@ -177,6 +184,7 @@ extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, cons
   }
   GRIDMM_TRY(linear_fwd_planes(L->xo, s.cT, nullptr, s.h1, M, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(ln(s.h1, X, L->x_ln, L->seed[1], s.a1, s.a1T));
+  }
   // ---- self attention (vilmodel.py:172-182)
   if (L->attention_fp32) {
     GRIDMM_TRY(linear_fwd_planes(L->sqkv, s.a1T, nullptr, s.qkv, M, GRIDMM_ACT_NONE, stream));
@@ -201,7 +209,7 @@ extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, cons
                                            L->seed[2], L->seed_dev, stream));
   }
   GRIDMM_TRY(linear_fwd_planes(L->so, s.c2T, nullptr, s.h2, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(ln(s.h2, s.a1, L->s_ln, L->seed[3], s.a2, s.a2T));
+  GRIDMM_TRY(ln(s.h2, a1, L->s_ln, L->seed[3], s.a2, s.a2T));
   // ---- feed forward (vilmodel.py:184-209)
   GRIDMM_TRY(linear_fwd_planes(L->ffn_i, s.a2T, nullptr, s.f1, M, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(gridmm_activation_planes(s.f1, nullptr, g, s.gT, s.gT + (size_t)I * Mp, (int64_t)M * I, 0, stream));
@@ -219,10 +227,12 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
                                       const float* dY, float* dX, float* dKV, int64_t dkv_bs, int dkv_rs,
                                       const gridmm_xlayer_grads_t* G, void* workspace, size_t workspace_bytes, int B, int Sq,
                                       int Sk, int heads, gridmm_stream_t stream) {
-  if (!L || !X || !KV || !saved || !dY || !dX || !dKV || !G || !workspace || B <= 0 || Sq <= 0 || Sk <= 0 || heads <= 0)
+  const bool cross = KV != nullptr;               // KV == NULL: the BertLayer form (see the forward); dKV is not written
+  if (!L || !X || !saved || !dY || !dX || (cross && !dKV) || !G || !workspace || B <= 0 || Sq <= 0 || (cross && Sk <= 0) ||
+      heads <= 0)
     return GRIDMM_EINVAL;
   const int H = heads * 64, I = L->ffn_i.N, M = B * Sq, Mp = mp32(M), Sqp = (Sq + 15) / 16 * 16;
-  if (!shapes_ok(L, H, I)) return GRIDMM_EINVAL;
+  if (!shapes_ok(L, H, I, cross)) return GRIDMM_EINVAL;
   if (saved_bytes < gridmm_xattn_layer_train_saved_bytes(B, Sq, H, I) ||
       workspace_bytes < gridmm_xattn_layer_train_workspace(B, Sq, H, I))
     return GRIDMM_EINVAL;
@@ -267,7 +277,7 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
   GRIDMM_TRY(gridmm_activation(s.f1, dg, df1, (int64_t)M * I, 1, stream));
   GRIDMM_TRY(linear_bwd(L->ffn_i, df1, s.a2T, res_of(dh, dr), da, G->ffn_i_w, G->ffn_i_b, M, lw, stream));   // da = d a2
   // ---- self attention
-  GRIDMM_TRY(ln_bwd(s.h2, s.a1, L->s_ln, L->seed[3], da, dh, dr, G->s_ln_g, G->s_ln_b));
+  GRIDMM_TRY(ln_bwd(s.h2, cross ? s.a1 : X, L->s_ln, L->seed[3], da, dh, dr, G->s_ln_g, G->s_ln_b));
   GRIDMM_TRY(linear_bwd(L->so, dh, s.c2T, nullptr, dc, G->so_w, G->so_b, M, lw, stream));
   if (L->attention_fp32) {
     GRIDMM_TRY(gridmm_attention_bwd(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H, s.qkv + 2 * H,
@@ -283,7 +293,8 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
                                          s.qkv_shift + 2 * H, (int64_t)3 * H, att_ws, att_bytes, dqkv, bs, 3 * H, dqkv + H, bs, 3 * H, dqkv + 2 * H, bs, 3 * H, B, heads, Sq, Sq, Sqp, scale,
                                          pa, L->seed[2], L->seed_dev, stream));
   }
-  GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), da_b, G->sqkv_w, G->sqkv_b, M, lw, stream));   // da_b = d a1
+  GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), cross ? da_b : dX, G->sqkv_w, G->sqkv_b, M, lw, stream));   // d a1
+  if (!cross) return GRIDMM_OK;
   // ---- cross attention
   GRIDMM_TRY(ln_bwd(s.h1, X, L->x_ln, L->seed[1], da_b, dh, dr, G->x_ln_g, G->x_ln_b));
   GRIDMM_TRY(linear_bwd(L->xo, dh, s.cT, nullptr, dc, G->xo_w, G->xo_b, M, lw, stream));

@@ -12,6 +12,8 @@ dropout1/2/dropout; ClsPrediction has none) through torch's RNG; dropout on the 
 (attention_probs_dropout_prob, vilmodel.py:112,143,334,362; nn.MultiheadAttention(dropout=p), transformer.py:138) inside
 the fused attention kernels from a counter-based hash, so the backward regenerates the forward's mask.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -75,15 +77,20 @@ def ffn_block(model, inter, out, x):
     return ag.layer_norm(o, out.LayerNorm, residual=x, dropout_p=_hidden_p(model))
 
 
-def bert_layer(model, layer, x, kmask):
-    return ffn_block(model, layer.intermediate, layer.output, self_attention_block(model, layer.attention, x, kmask))
-
-
 FUSED_XLAYER = True     # a whole cross-modal layer as ONE autograd node (ag.x_layer_fused: one C call forward, one backward)
+FUSED_BERT_LAYER = bool(int(os.environ.get("GRIDMM_FUSED_BERT_LAYER", "1")))   # the same for BertLayer (text / panorama encoders)
 
 
 def _fusable(model, x, inter):
     return FUSED_XLAYER and x.is_cuda and x.shape[-1] == model.heads * 64 and inter.dense.weight.shape[0] % 32 == 0
+
+
+def bert_layer(model, layer, x, kmask):
+    """BertLayer.forward (:214-231)."""
+    if FUSED_BERT_LAYER and x.dim() == 3 and _fusable(model, x, layer.intermediate):
+        return ag.bert_layer_fused(x, kmask, model.heads, _hidden_p(model), _attn_p(model), layer.attention,
+                                   layer.intermediate, layer.output)
+    return ffn_block(model, layer.intermediate, layer.output, self_attention_block(model, layer.attention, x, kmask))
 
 
 def x_layer(model, layer, ctx_kv, ctx_mask, visn, visn_mask, kv_col=0):

@@ -676,6 +676,9 @@ typedef struct {
   float *xq_w, *xq_b, *xo_w, *xo_b, *sqkv_w, *sqkv_b, *so_w, *so_b, *ffn_i_w, *ffn_i_b, *ffn_o_w, *ffn_o_b;
   float *x_ln_g, *x_ln_b, *s_ln_g, *s_ln_b, *f_ln_g, *f_ln_b;
 } gridmm_xlayer_grads_t;
+/* KV == NULL (forward and backward alike): a BertLayer -- self attention + feed forward only (vilmodel.py:214-231: the layers of
+ * the text and panorama encoders); the xq / xo / x_ln members of L, the context's KV / plane / mask arguments and dKV are
+ * not read / written, Sk is ignored. */
 size_t gridmm_xattn_layer_train_saved_bytes(int B, int Sq, int H, int I);
 size_t gridmm_xattn_layer_train_workspace(int B, int Sq, int H, int I);
 int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, const void* KV_hi,

@@ -134,3 +134,44 @@ def test_fused_layer_matches_fp64_torch_reference():
         if p.grad is not None:      # (the key bias has an exactly-zero gradient: softmax is shift invariant -- absolute floor)
             err = float((grads[n].double() - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-4 * scale)
             assert err < 2e-4, (n, err)
+
+
+@pytest.mark.parametrize("B,S,p", [(3, 57, 0.0), (2, 80, 0.1), (4, 37, 0.1), (1, 216, 0.0)])
+def test_fused_bert_layer_equals_op_by_op_bitwise(B, S, p):
+    """The layer C calls with KV = NULL (a BertLayer: self attention + feed forward; text and panorama encoders,
+    map_nav_src/models/vilmodel.py:214-231) against vilmodel_train.bert_layer's op-by-op form: same kernels in the same
+    order -> output, input gradient and every parameter gradient bit-identical, with and without dropout, ragged masks."""
+    from gridmm_amd import vilmodel_train as VT
+    from gridmm_amd.vilmodel import BertLayer, default_config
+    H = 768
+    torch.manual_seed(5)
+    layer = BertLayer(default_config(intermediate_size=256)).cuda()
+    for q in layer.parameters():
+        torch.nn.init.normal_(q, std=0.05)
+    model = _model(p, p)
+    g = torch.Generator(device="cuda").manual_seed(B + S)
+    x0 = torch.randn(B, S, H, device="cuda", generator=g)
+    dy = torch.randn(B, S, H, device="cuda", generator=g)
+    lens = torch.randint(1, S + 1, (B,), generator=torch.Generator().manual_seed(S))
+    lens[0] = S
+    mask = (torch.arange(S)[None] < lens[:, None]).cuda()
+    outs = []
+    for fused in (True, False):
+        VT.FUSED_BERT_LAYER = fused
+        try:
+            for q in layer.parameters():
+                q.grad = None
+            x = x0.clone().requires_grad_()
+            torch.manual_seed(21)                    # the dropout seeds come from torch's CPU generator, in call order
+            y = VT.bert_layer(model, layer, x, mask)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            outs.append((y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in layer.named_parameters()}))
+        finally:
+            VT.FUSED_BERT_LAYER = True
+    (y1, dx1, g1), (y2, dx2, g2) = outs
+    assert torch.isfinite(y1).all()
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    assert set(g1) == set(g2) and len(g1) == 16
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
