@@ -1348,6 +1348,96 @@ class _XLayer(torch.autograd.Function):
         return (dx, dkv, None, None, None, None, None, None, None) + tuple(grads)
 
 
+class _CPreLNLayer(ctypes.Structure):
+    _fields_ = [(n, _CLinearTrain) for n in ("qkv", "out", "ffn1", "ffn2")] + [(n, _CLnTrain) for n in ("ln1", "ln2")] + \
+               [("p", ctypes.c_float), ("seed", ctypes.c_ulonglong * 4), ("seed_dev", ctypes.c_void_p)]
+
+
+class _CPreLNGrads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("qkv_w", "qkv_b", "out_w", "out_b", "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b",
+                                                "ln1_g", "ln1_b", "ln2_g", "ln2_b")]
+
+
+class _PreLNLayer(torch.autograd.Function):
+    """One pre-LayerNorm transformer layer (transformer.py:170-182) as ONE autograd node: gridmm_preln_layer_train_fwd / _bwd.
+    params: in_proj.w, in_proj.b, out_proj.w, out_proj.b, linear1.w, linear1.b, linear2.w, linear2.b, norm1.w, norm1.b,
+    norm2.w, norm2.b (12 tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, heads, p, eps, *params):
+        lib = _lib.load()
+        H = heads * 64
+        B, S = x.shape[:2]
+        x2 = x.float().contiguous()
+        (qw, qb, ow, ob, w1, b1, w2, b2, g1, be1, g2, be2) = params
+        ctx.prm = params
+        I = w1.shape[0]
+        keep = []
+
+        def lin(w, b):
+            get = WEIGHTS.getter(w)
+            pf, pt = get(False), get(True)
+            bb = b.detach().float().contiguous()
+            keep.extend([pf, pt, bb])
+            return _CLinearTrain(pf.hi.data_ptr(), pf.lo.data_ptr(), pf.Kp, pt.hi.data_ptr(), pt.lo.data_ptr(), pt.Kp,
+                                 bb.data_ptr(), w.shape[0], w.shape[1])
+
+        def lnp(g, b, e):
+            gg, bb = g.detach().float().contiguous(), b.detach().float().contiguous()
+            keep.extend([gg, bb])
+            return _CLnTrain(gg.data_ptr(), bb.data_ptr(), float(e))
+        draw = lambda on: hs.host(lambda: int(torch.randint(0, 2 ** 62, (1,)).item())) if on else 0   # noqa: E731
+        seeds = [draw(p > 0) for _ in range(4)]      # attention, after out_proj, after the activation, after linear2
+        seed_dev = SEED_DEV if (p > 0 and hs.MODE is not None) else None
+        L = _CPreLNLayer(lin(qw, qb), lin(ow, ob), lin(w1, b1), lin(w2, b2), lnp(g1, be1, eps[0]), lnp(g2, be2, eps[1]),
+                         float(p), (ctypes.c_ulonglong * 4)(*seeds), _ptr(seed_dev))
+        m = None
+        if mask is not None:
+            m = mask.contiguous()
+            m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+        saved = torch.empty(int(lib.gridmm_preln_layer_saved_bytes(B, S, H, I)), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(int(lib.gridmm_preln_layer_workspace(B, S, H, I)), dtype=torch.uint8, device=x.device)
+        y = torch.empty(B, S, H, dtype=torch.float32, device=x.device)
+        _lib.check(lib.gridmm_preln_layer_train_fwd(ctypes.byref(L), _p(x2), _p(m), m.stride(0) if m is not None else 0, _p(y),
+                                                    _p(saved), saved.numel(), _p(ws), ws.numel(), B, S, heads, _stream()),
+                   "gridmm_preln_layer_train_fwd")
+        ctx.save_for_backward(x2, m, saved)
+        ctx.L, ctx.keep, ctx.dims = L, keep, (B, S, H, I, heads)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 17
+        lib = _lib.load()
+        x2, m, saved = ctx.saved_tensors
+        B, S, H, I, heads = ctx.dims
+        dev = dy.device
+        dy = dy.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = [torch.empty(3 * H, H, **f32), torch.empty(3 * H, **f32), torch.empty(H, H, **f32), torch.empty(H, **f32),
+             torch.empty(I, H, **f32), torch.empty(I, **f32), torch.empty(H, I, **f32), torch.empty(H, **f32),
+             torch.empty(H, **f32), torch.empty(H, **f32), torch.empty(H, **f32), torch.empty(H, **f32)]
+        G = _CPreLNGrads(*[t.data_ptr() for t in g])
+        dx = torch.empty_like(x2)
+        ws = torch.empty(int(lib.gridmm_preln_layer_workspace(B, S, H, I)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gridmm_preln_layer_bwd(ctypes.byref(ctx.L), _p(x2), _p(m), m.stride(0) if m is not None else 0, _p(saved),
+                                              saved.numel(), _p(dy), _p(dx), ctypes.byref(G), _p(ws), ws.numel(), B, S, heads,
+                                              _stream()), "gridmm_preln_layer_bwd")
+        grads = [DEFERRED.hand(ctx.prm[i], gr) if ctx.needs_input_grad[5 + i] else None for i, gr in enumerate(g)]
+        return (dx, None, None, None, None) + tuple(grads)
+
+
+def pre_ln_layer_fused(x, mask, heads, p, layer):
+    """layer: TransformerEncoderLayer-like (.norm1, .self_attn.in_proj_weight / in_proj_bias / out_proj, .norm2, .linear1,
+    .linear2); p: its dropout probability in train() mode (0 otherwise)."""
+    a = layer.self_attn
+    params = (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, layer.linear1.weight, layer.linear1.bias,
+              layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight,
+              layer.norm2.bias)
+    return _PreLNLayer.apply(x, mask, heads, float(p), (float(layer.norm1.eps), float(layer.norm2.eps)), *params)
+
+
 def bert_layer_fused(x, self_mask, heads, p_hidden, p_attn, selfatt, inter, output):
     """BertLayer (vilmodel.py:214-231: BertAttention + BertIntermediate + BertOutput) as ONE autograd node: the layer C calls
     with no context (KV = NULL).  Same kernels in the same order as vilmodel_train.bert_layer's op-by-op form."""

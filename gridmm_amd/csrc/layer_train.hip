@@ -318,3 +318,181 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
 #undef GRIDMM_TRY
   return GRIDMM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One PRE-LayerNorm transformer layer of the differentiable path (the panorama encoder's and the grid encoder's layers:
+// TransformerEncoderLayer.forward_pre, map_nav_src/models/transformer.py:170-182 through create_transformer_encoder,
+// models/ops.py:11-16): x1 = x + drop(out_proj(attn(qkv(LN1(x)))));  y = x1 + drop(linear2(drop(gelu(linear1(LN2(x1)))))).
+// Forward and whole backward as one C call each; like the calls above they own no arithmetic and issue the kernels of
+// vilmodel_train.pre_ln_encoder's op-by-op form with the same tile choices (bit-identical: tests/test_hip_layer_train.py).
+// The residual sums ride on the dropout pass (gridmm_dropout_add); the activation's dropout writes the planes that
+// linear2 reads (no split pass).
+namespace {
+struct SavedP {
+  unsigned short *h1T, *cT, *h2T, *fT;     // planes of every Linear input (hi [Mp][K] then lo)
+  float *qkv, *c, *lse, *x1, *f1, *qkv_shift;
+  size_t bytes;
+};
+SavedP carve_saved_p(char* base, int B, int S, int H, int I, int heads) {
+  const size_t M = (size_t)B * S, Mp = mp32((int)M), Sp = (S + 15) / 16 * 16;
+  char* w = base;
+  auto take = [&](size_t bytes) { char* p = w; w += a256(bytes); return p; };
+  SavedP s;
+  s.h1T = (unsigned short*)take((size_t)H * Mp * 4);
+  s.cT = (unsigned short*)take((size_t)H * Mp * 4);
+  s.h2T = (unsigned short*)take((size_t)H * Mp * 4);
+  s.fT = (unsigned short*)take((size_t)I * Mp * 4);
+  s.qkv = (float*)take(M * 3 * H * 4);            // the PLANES of q | k | v (hi [M][3H] then lo: the same bytes)
+  s.c = (float*)take(M * H * 4);
+  s.lse = (float*)take((size_t)B * heads * Sp * 4);
+  s.x1 = (float*)take(M * H * 4);
+  s.f1 = (float*)take(M * (size_t)I * 4);
+  s.qkv_shift = (float*)take((size_t)B * 3 * H * 4);
+  s.bytes = (size_t)(w - base);
+  return s;
+}
+bool shapes_ok_p(const gridmm_preln_layer_t* L, int H, int I) {
+  const gridmm_linear_train_t* ls[4] = {&L->qkv, &L->out, &L->ffn1, &L->ffn2};
+  const int N[4] = {3 * H, H, I, H}, K[4] = {H, H, H, I};
+  for (int i = 0; i < 4; ++i)
+    if (ls[i]->N != N[i] || ls[i]->K != K[i] || !ls[i]->w_hi || !ls[i]->w_lo || ls[i]->Kp < K[i]) return false;
+  return H % 32 == 0 && I % 32 == 0 && L->p >= 0.f && L->p < 1.f;
+}
+}  // namespace
+
+extern "C" size_t gridmm_preln_layer_saved_bytes(int B, int S, int H, int I) {
+  return carve_saved_p(nullptr, B, S, H, I, H / 64).bytes;
+}
+
+extern "C" size_t gridmm_preln_layer_workspace(int B, int S, int H, int I) {
+  const size_t M = (size_t)B * S, Mp = mp32((int)M), W = (size_t)(I > 3 * H ? I : 3 * H);
+  const size_t lin = a256(M * W * 4) + a256(W * Mp * 4) + a256(((Mp + 255) / 256) * W * 4) + a256((size_t)8 * H * W * 4);
+  const size_t lnws = a256((M + 3) / 4 * 2 * H * 4);
+  // forward: LayerNorm output, dense output, activation; backward: d_o / dG, dF, dF1, dH, dxln, dx1, dC, dqkv
+  const size_t bufs = a256(M * H * 4) * 5 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) * 3;
+  return lin + lnws + bufs + a256(gridmm_attention_rows_bwd_workspace(B, H / 64, S)) + 4096;
+}
+
+extern "C" int gridmm_preln_layer_train_fwd(const gridmm_preln_layer_t* L, const float* X, const uint8_t* mask, int mask_bs,
+                                            float* Y, void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                            int B, int S, int heads, gridmm_stream_t stream) {
+  if (!L || !X || !Y || !saved || !workspace || B <= 0 || S <= 0 || heads <= 0 || S > 2048) return GRIDMM_EINVAL;
+  const int H = heads * 64, I = L->ffn1.N, M = B * S, Mp = mp32(M), Sp = (S + 15) / 16 * 16;
+  if (!shapes_ok_p(L, H, I)) return GRIDMM_EINVAL;
+  if (saved_bytes < gridmm_preln_layer_saved_bytes(B, S, H, I) || workspace_bytes < gridmm_preln_layer_workspace(B, S, H, I))
+    return GRIDMM_EINVAL;
+  SavedP s = carve_saved_p((char*)saved, B, S, H, I, heads);
+  char* w = (char*)workspace;
+  auto take = [&](size_t bytes) { char* p = w; w += a256(bytes); return p; };
+  float* hbuf = (float*)take((size_t)M * H * 4);          // fp32 output of a LayerNorm (its planes are what is read)
+  float* o = (float*)take((size_t)M * H * 4);             // dense output in front of a residual sum
+  float* g = (float*)take((size_t)M * I * 4);             // activation
+  const float p = L->p, scale = 0.125f;
+  const int64_t nH = (int64_t)M * H, nI = (int64_t)M * I;
+  int rc;
+#define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
+  // ---- self attention block: LN1 -> q | k | v (k | v planes shifted by row 0 of the episode) -> attention -> out_proj
+  GRIDMM_TRY(gridmm_layernorm(X, H, nullptr, 0, L->ln1.gamma, L->ln1.beta, L->ln1.eps, hbuf, H, nullptr, 0, nullptr, nullptr,
+                              s.h1T, s.h1T + (size_t)H * Mp, H, M, H, stream));
+  {
+    unsigned short *qh = (unsigned short*)s.qkv, *ql = qh + (size_t)M * 3 * H;
+    const int64_t bs = (int64_t)S * 3 * H;
+    const unsigned short *ah = s.h1T, *al = s.h1T + (size_t)H * Mp;
+    GRIDMM_TRY(gridmm_linear_planes_map(ah, al, H, 1, (int64_t)S * H, L->qkv.w_hi, L->qkv.w_lo, L->qkv.Kp, GRIDMM_W_ROWMAJOR,
+                                        L->qkv.bias, nullptr, 0, s.qkv_shift, 3 * H, nullptr, nullptr, 0, B, 3 * H, H,
+                                        GRIDMM_ACT_NONE, stream));
+    GRIDMM_TRY(gridmm_linear_planes_shift(ah, al, H, L->qkv.w_hi, L->qkv.w_lo, L->qkv.Kp, L->qkv.bias, nullptr, 0, nullptr, 0, qh,
+                                          ql, 3 * H, s.qkv_shift, S, H, M, 3 * H, H, GRIDMM_ACT_NONE, stream));
+    GRIDMM_TRY(gridmm_attention_rows_train(qh, ql, bs, 3 * H, qh + H, ql + H, bs, 3 * H, qh + 2 * H, ql + 2 * H, bs, 3 * H, mask,
+                                           mask_bs, s.c, (int64_t)S * H, H, s.cT, s.cT + (size_t)H * Mp, (int64_t)S * H, H, s.lse,
+                                           Sp, s.qkv_shift + 2 * H, (int64_t)3 * H, B, heads, S, S, scale, p, L->seed[0],
+                                           L->seed_dev, stream));
+  }
+  GRIDMM_TRY(linear_fwd_planes(L->out, s.cT, nullptr, o, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(gridmm_dropout_add(o, X, s.x1, nullptr, nullptr, nH, p, L->seed[1], L->seed_dev, stream));
+  // ---- feed forward block: LN2 -> linear1 -> gelu -> dropout (writes the planes linear2 reads) -> linear2
+  GRIDMM_TRY(gridmm_layernorm(s.x1, H, nullptr, 0, L->ln2.gamma, L->ln2.beta, L->ln2.eps, hbuf, H, nullptr, 0, nullptr, nullptr,
+                              s.h2T, s.h2T + (size_t)H * Mp, H, M, H, stream));
+  GRIDMM_TRY(linear_fwd_planes(L->ffn1, s.h2T, nullptr, s.f1, M, GRIDMM_ACT_NONE, stream));
+  if (p > 0.f) {
+    GRIDMM_TRY(gridmm_activation(s.f1, nullptr, g, nI, 0, stream));
+    GRIDMM_TRY(gridmm_dropout_add(g, nullptr, nullptr, s.fT, s.fT + (size_t)I * Mp, nI, p, L->seed[2], L->seed_dev, stream));
+  } else {
+    GRIDMM_TRY(gridmm_activation_planes(s.f1, nullptr, g, s.fT, s.fT + (size_t)I * Mp, nI, 0, stream));
+  }
+  GRIDMM_TRY(linear_fwd_planes(L->ffn2, s.fT, nullptr, o, M, GRIDMM_ACT_NONE, stream));
+  GRIDMM_TRY(gridmm_dropout_add(o, s.x1, Y, nullptr, nullptr, nH, p, L->seed[3], L->seed_dev, stream));
+#undef GRIDMM_TRY
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_preln_layer_bwd(const gridmm_preln_layer_t* L, const float* X, const uint8_t* mask, int mask_bs,
+                                      const void* saved, size_t saved_bytes, const float* dY, float* dX,
+                                      const gridmm_preln_grads_t* G, void* workspace, size_t workspace_bytes, int B, int S,
+                                      int heads, gridmm_stream_t stream) {
+  if (!L || !X || !saved || !dY || !dX || !G || !workspace || B <= 0 || S <= 0 || heads <= 0 || S > 2048) return GRIDMM_EINVAL;
+  const int H = heads * 64, I = L->ffn1.N, M = B * S, Mp = mp32(M), Sp = (S + 15) / 16 * 16;
+  if (!shapes_ok_p(L, H, I)) return GRIDMM_EINVAL;
+  if (saved_bytes < gridmm_preln_layer_saved_bytes(B, S, H, I) || workspace_bytes < gridmm_preln_layer_workspace(B, S, H, I))
+    return GRIDMM_EINVAL;
+  SavedP s = carve_saved_p((char*)saved, B, S, H, I, heads);
+  const size_t W = (size_t)(I > 3 * H ? I : 3 * H);
+  char* w = (char*)workspace;
+  auto take = [&](size_t bytes) { char* p = w; w += a256(bytes); return p; };
+  LinWs lw;
+  lw.rows = (unsigned short*)take((size_t)M * W * 4);
+  lw.yT = (unsigned short*)take(W * Mp * 4);
+  lw.cs_ws = (float*)take(((Mp + 255) / 256) * W * 4);
+  lw.splitk = (float*)take((size_t)8 * H * W * 4);
+  float* lnws = (float*)take((size_t)(M + 3) / 4 * 2 * H * 4);
+  float* dd = (float*)take((size_t)M * I * 4);      // a gradient after its dropout (M x H or M x I)
+  float* dF = (float*)take((size_t)M * I * 4);
+  float* dF1 = (float*)take((size_t)M * I * 4);
+  float* dH = (float*)take((size_t)M * H * 4);      // gradient of a LayerNorm output
+  float* dln = (float*)take((size_t)M * H * 4);     // gradient of a LayerNorm input (its own branch)
+  float* dx1 = (float*)take((size_t)M * H * 4);     // gradient of x1 (both branches summed)
+  float* dC = (float*)take((size_t)M * H * 4);
+  float* dqkv = (float*)take((size_t)M * 3 * H * 4);
+  const size_t att_bytes = gridmm_attention_rows_bwd_workspace(B, heads, S);
+  void* att_ws = take(att_bytes);
+  const float p = L->p, scale = 0.125f;
+  const int64_t nH = (int64_t)M * H, nI = (int64_t)M * I;
+  int rc;
+#define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
+  // the gradient of drop(t) from the gradient of its output: the same mask on the gradient (p == 0: the gradient itself)
+  auto undrop = [&](const float* dy, int64_t n, unsigned long long seed, const float** out) {
+    if (p > 0.f) {
+      *out = dd;
+      return gridmm_dropout_add(dy, nullptr, dd, nullptr, nullptr, n, p, seed, L->seed_dev, stream);
+    }
+    *out = dy;
+    return (int)GRIDMM_OK;
+  };
+  const float* t;
+  // ---- feed forward block
+  GRIDMM_TRY(undrop(dY, nH, L->seed[3], &t));
+  GRIDMM_TRY(linear_bwd(L->ffn2, t, s.fT, nullptr, dF, G->ffn2_w, G->ffn2_b, M, lw, stream));
+  GRIDMM_TRY(undrop(dF, nI, L->seed[2], &t));
+  GRIDMM_TRY(gridmm_activation(s.f1, t, dF1, nI, 1, stream));
+  GRIDMM_TRY(linear_bwd(L->ffn1, dF1, s.h2T, nullptr, dH, G->ffn1_w, G->ffn1_b, M, lw, stream));
+  GRIDMM_TRY(gridmm_layernorm_bwd(s.x1, H, nullptr, 0, L->ln2.gamma, L->ln2.eps, dH, H, dln, H, G->ln2_g, G->ln2_b, lnws, M, H,
+                                  stream));
+  GRIDMM_TRY(gridmm_dropout_add(dln, dY, dx1, nullptr, nullptr, nH, 0.f, 0, nullptr, stream));       // x1 feeds LN2 and the sum
+  // ---- self attention block
+  GRIDMM_TRY(undrop(dx1, nH, L->seed[1], &t));
+  GRIDMM_TRY(linear_bwd(L->out, t, s.cT, nullptr, dC, G->out_w, G->out_b, M, lw, stream));
+  {
+    const unsigned short *qh = (const unsigned short*)s.qkv, *ql = qh + (size_t)M * 3 * H;
+    const int64_t bs = (int64_t)S * 3 * H;
+    GRIDMM_TRY(gridmm_attention_rows_bwd(qh, ql, bs, 3 * H, qh + H, ql + H, bs, 3 * H, qh + 2 * H, ql + 2 * H, bs, 3 * H, mask,
+                                         mask_bs, s.c, (int64_t)S * H, H, dC, (int64_t)S * H, H, s.lse, s.qkv_shift + 2 * H,
+                                         (int64_t)3 * H, att_ws, att_bytes, dqkv, bs, 3 * H, dqkv + H, bs, 3 * H, dqkv + 2 * H, bs,
+                                         3 * H, B, heads, S, S, Sp, scale, p, L->seed[0], L->seed_dev, stream));
+  }
+  GRIDMM_TRY(linear_bwd(L->qkv, dqkv, s.h1T, nullptr, dH, G->qkv_w, G->qkv_b, M, lw, stream));
+  GRIDMM_TRY(gridmm_layernorm_bwd(X, H, nullptr, 0, L->ln1.gamma, L->ln1.eps, dH, H, dln, H, G->ln1_g, G->ln1_b, lnws, M, H,
+                                  stream));
+  GRIDMM_TRY(gridmm_dropout_add(dln, dx1, dX, nullptr, nullptr, nH, 0.f, 0, nullptr, stream));        // x feeds LN1 and the sum
+#undef GRIDMM_TRY
+  return GRIDMM_OK;
+}

@@ -114,7 +114,52 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
   }
 }
 
+// y = r + dropout(x) (p == 0: y = r + x; r == NULL: y = dropout(x)) [+ the bf16 hi / lo planes of y]: the residual sums of a
+// pre-LayerNorm transformer layer (transformer.py:176-182: src = src + dropout1(src2)) and the gradient sums of its backward
+// as ONE pass.  Two roundings, product then sum (no FMA contraction): bit-identical to gridmm_dropout followed by an fp32 add.
+__global__ void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ r, float* __restrict__ y, size_t n4,
+                                   float p, unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                   unsigned short* __restrict__ Ph, unsigned short* __restrict__ Pl) {
+  if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
+  const float scale = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 o = reinterpret_cast<const float4*>(x)[i];
+    if (p > 0.f) {
+      const unsigned int e = (unsigned int)(i * 4);
+      o.x = dropout_keep(seed, e, p) ? __fmul_rn(o.x, scale) : 0.f;
+      o.y = dropout_keep(seed, e + 1, p) ? __fmul_rn(o.y, scale) : 0.f;
+      o.z = dropout_keep(seed, e + 2, p) ? __fmul_rn(o.z, scale) : 0.f;
+      o.w = dropout_keep(seed, e + 3, p) ? __fmul_rn(o.w, scale) : 0.f;
+    }
+    if (r) {
+      const float4 b = reinterpret_cast<const float4*>(r)[i];
+      o.x = __fadd_rn(b.x, o.x); o.y = __fadd_rn(b.y, o.y); o.z = __fadd_rn(b.z, o.z); o.w = __fadd_rn(b.w, o.w);
+    }
+    if (y) reinterpret_cast<float4*>(y)[i] = o;
+    if (Ph) {
+      uint2 hi, lo;
+      split2_bf16(o.x, o.y, hi.x, lo.x);
+      split2_bf16(o.z, o.w, hi.y, lo.y);
+      reinterpret_cast<uint2*>(Ph)[i] = hi;
+      reinterpret_cast<uint2*>(Pl)[i] = lo;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int gridmm_dropout_add(const float* x, const float* r, float* y, void* y_hi, void* y_lo, int64_t n, float p,
+                                  unsigned long long seed, const unsigned long long* seed_dev, gridmm_stream_t stream) {
+  if (!x || (!y && !y_hi) || (y_hi && !y_lo) || n <= 0 || (n & 3) || n >= (1ll << 32) || p < 0.f || p >= 1.f)
+    return GRIDMM_EINVAL;
+  const size_t n4 = (size_t)n / 4;
+  unsigned blocks = (unsigned)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  GRIDMM_LAUNCH(dropout_add_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, y, n4, p, seed, seed_dev,
+                (unsigned short*)y_hi, (unsigned short*)y_lo);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
 
 extern "C" int gridmm_fuse_logits_bwd(const float* g_raw, const float* l_raw, const float* fuse_raw,
                                       const uint8_t* gmap_masks, const uint8_t* gmap_visited,

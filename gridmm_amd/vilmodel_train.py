@@ -78,7 +78,8 @@ def ffn_block(model, inter, out, x):
 
 
 FUSED_XLAYER = True     # a whole cross-modal layer as ONE autograd node (ag.x_layer_fused: one C call forward, one backward)
-FUSED_BERT_LAYER = bool(int(os.environ.get("GRIDMM_FUSED_BERT_LAYER", "1")))   # the same for BertLayer (text / panorama encoders)
+FUSED_BERT_LAYER = bool(int(os.environ.get("GRIDMM_FUSED_BERT_LAYER", "1")))   # the same for BertLayer (the text encoder)
+FUSED_PRELN_LAYER = bool(int(os.environ.get("GRIDMM_FUSED_PRELN_LAYER", "1")))  # ... and the pre-LN layers (panorama / grid encoders)
 
 
 def _fusable(model, x, inter):
@@ -119,6 +120,10 @@ def pre_ln_encoder(model, enc, x, kmask):
     """TransformerEncoder with normalize_before=True (transformer.py:170-182) + final LayerNorm."""
     p = model.config.hidden_dropout_prob   # create_transformer_encoder passes it as the layer dropout (ops.py:11-16)
     for layer in enc.layers:
+        if FUSED_PRELN_LAYER and x.dim() == 3 and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == model.heads * 64 \
+                and layer.linear1.weight.shape[0] % 32 == 0 and x.shape[1] <= 2048:
+            x = ag.pre_ln_layer_fused(x, kmask, model.heads, p if model.training else 0.0, layer)   # one autograd node
+            continue
         h = ag.layer_norm(x, layer.norm1)
         qkv = ag.linear(h, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias, out_planes=h.shape[-1])
         ctx = ag.self_attention(qkv, kmask, model.heads, p if model.training else 0.0)   # nn.MultiheadAttention(dropout=p)

@@ -693,6 +693,40 @@ int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const float* X, const
                            int64_t dkv_bs, int dkv_rs, const gridmm_xlayer_grads_t* G, void* workspace,
                            size_t workspace_bytes, int B, int Sq, int Sk, int heads, gridmm_stream_t stream);
 
+/* ---- one PRE-LayerNorm transformer layer of the differentiable path (the panorama encoder's and the grid encoder's layers:
+ * TransformerEncoderLayer.forward_pre, map_nav_src/models/transformer.py:170-182 via models/ops.py:11-16), forward and whole
+ * backward as one C call each:  x1 = x + drop(out_proj(attention(in_proj(LN1(x)))));
+ *                               y  = x1 + drop(linear2(drop(gelu(linear1(LN2(x1)))))).
+ * p: the layer's dropout probability (attention probabilities and the three hidden-state dropouts; 0 = none), seed[0..3] =
+ * attention, after out_proj, after the activation, after linear2 (seed_dev as gridmm_dropout).  X, Y, dY, dX contiguous
+ * (B, S, H); mask [B][mask_bs] (1 = key is valid; NULL = all).  saved / workspace: caller-provided blocks of at least
+ * gridmm_preln_layer_saved_bytes / _workspace bytes (saved: written by the forward, read by the backward).  The same kernels in
+ * the same order as the op-by-op autograd form (gridmm_amd.vilmodel_train.pre_ln_encoder): bit-identical results. */
+typedef struct {
+  gridmm_linear_train_t qkv, out, ffn1, ffn2;
+  gridmm_ln_t ln1, ln2;
+  float p;
+  unsigned long long seed[4];
+  const unsigned long long* seed_dev;
+} gridmm_preln_layer_t;
+typedef struct {
+  float *qkv_w, *qkv_b, *out_w, *out_b, *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+} gridmm_preln_grads_t;
+size_t gridmm_preln_layer_saved_bytes(int B, int S, int H, int I);
+size_t gridmm_preln_layer_workspace(int B, int S, int H, int I);
+int gridmm_preln_layer_train_fwd(const gridmm_preln_layer_t* L, const float* X, const uint8_t* mask, int mask_bs, float* Y,
+                                 void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, int B, int S,
+                                 int heads, gridmm_stream_t stream);
+int gridmm_preln_layer_bwd(const gridmm_preln_layer_t* L, const float* X, const uint8_t* mask, int mask_bs, const void* saved,
+                           size_t saved_bytes, const float* dY, float* dX, const gridmm_preln_grads_t* G, void* workspace,
+                           size_t workspace_bytes, int B, int S, int heads, gridmm_stream_t stream);
+/* y = r + dropout(x) in one pass (p = 0: y = r + x; r = NULL: y = dropout(x); mask as gridmm_dropout); y_hi / y_lo (optional,
+ * then y may be NULL): the bf16 planes of the result.  Two roundings (product, then sum): equal to gridmm_dropout followed
+ * by an fp32 add bit for bit.  n % 4 == 0, n < 2^32. */
+int gridmm_dropout_add(const float* x, const float* r, float* y, void* y_hi, void* y_lo, int64_t n, float p,
+                       unsigned long long seed, const unsigned long long* seed_dev, gridmm_stream_t stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * Host-side helpers of the agent loop's collation (HOST pointers, no device work, no stream)
  * ---------------------------------------------------------------------------------------- */

@@ -175,3 +175,70 @@ def test_fused_bert_layer_equals_op_by_op_bitwise(B, S, p):
     assert set(g1) == set(g2) and len(g1) == 16
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n
+
+
+@pytest.mark.parametrize("B,S,p,layers", [(3, 37, 0.0, 2), (2, 216, 0.1, 1), (4, 57, 0.1, 2), (1, 20, 0.0, 1)])
+def test_fused_pre_ln_layer_equals_op_by_op_bitwise(B, S, p, layers):
+    """gridmm_preln_layer_train_fwd / _bwd (the pre-LayerNorm layers of the panorama and grid encoders,
+    map_nav_src/models/transformer.py:170-182) against vilmodel_train.pre_ln_encoder's op-by-op form: output, input gradient
+    and all parameter gradients bit-identical, with and without dropout (4 masks per layer), ragged key masks."""
+    from gridmm_amd import vilmodel_train as VT
+    from gridmm_amd.vilmodel import PreLNEncoder, default_config
+    H = 768
+    torch.manual_seed(7)
+    enc = PreLNEncoder(default_config(intermediate_size=256), layers).cuda()
+    for q in enc.parameters():
+        torch.nn.init.normal_(q, std=0.05)
+    model = _model(p, p)
+    g = torch.Generator(device="cuda").manual_seed(B * 7 + S)
+    x0 = torch.randn(B, S, H, device="cuda", generator=g)
+    dy = torch.randn(B, S, H, device="cuda", generator=g)
+    lens = torch.randint(1, S + 1, (B,), generator=torch.Generator().manual_seed(S + 1))
+    lens[0] = S
+    mask = (torch.arange(S)[None] < lens[:, None]).cuda()
+    outs = []
+    for fused in (True, False):
+        VT.FUSED_PRELN_LAYER = fused
+        try:
+            for q in enc.parameters():
+                q.grad = None
+            x = x0.clone().requires_grad_()
+            torch.manual_seed(33)                    # the dropout seeds come from torch's CPU generator, in call order
+            y = VT.pre_ln_encoder(model, enc, x, mask)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            outs.append((y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in enc.named_parameters()}))
+        finally:
+            VT.FUSED_PRELN_LAYER = True
+    (y1, dx1, g1), (y2, dx2, g2) = outs
+    assert torch.isfinite(y1).all()
+    assert torch.equal(y1, y2), float((y1 - y2).abs().max())
+    assert torch.equal(dx1, dx2), float((dx1 - dx2).abs().max())
+    assert set(g1) == set(g2) and len(g1) == 12 * layers + 2
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), (n, float((g1[n] - g2[n]).abs().max()))
+
+
+def test_dropout_add_equals_dropout_then_add():
+    """gridmm_dropout_add: r + dropout(x) in one pass == gridmm_dropout followed by an fp32 add, bit for bit; the planes are
+    the split of that sum; p = 0 is a plain add."""
+    from gridmm_amd import autograd as ag, ops
+    lib = ag._lib.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(37, 768, device="cuda", generator=g)
+    r = torch.randn(37, 768, device="cuda", generator=g)
+    for p in (0.0, 0.1, 0.5):
+        y = torch.empty_like(x)
+        hi, lo = ops._planes_like(x.shape, x.device)
+        ag._lib.check(lib.gridmm_dropout_add(ag._p(x), ag._p(r), ag._p(y), ag._p(hi), ag._p(lo), x.numel(), p, 1234, None,
+                                             ag._stream()), "gridmm_dropout_add")
+        d = torch.empty_like(x)
+        if p > 0:
+            ag._lib.check(lib.gridmm_dropout(ag._p(x), ag._p(d), x.numel(), p, 1234, None, ag._stream()), "gridmm_dropout")
+        else:
+            d.copy_(x)
+        want = r + d
+        torch.cuda.synchronize()
+        assert torch.equal(y, want), p
+        ref = ops.split_rows(want)
+        assert torch.equal(hi, ref.hi) and torch.equal(lo, ref.lo)
