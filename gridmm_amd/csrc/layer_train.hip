@@ -89,14 +89,58 @@ bool planes_ok(const void* KV_hi, const void* KV_lo, int64_t kv_bs, int kv_rs, i
 // dX = dY W (+ Radd: the gradient arriving over another branch, summed in the GEMM epilogue), dW = dY^T X from the row
 // planes of dY and of the saved x.
 struct LinWs { unsigned short *rows, *yT; float *cs_ws, *splitk; };
+
+// The weight gradients of a layer's backward, collected and issued as ONE grouped launch at the end of the layer
+// (gridmm_linear_planes_tn_grouped): each Linear keeps the planes of its dY, its column-sum partials and its split-K
+// workspace in a region of its own (bump-allocated from `area`) until then.
+struct TnBatch {
+  gridmm_tn_problem_t p[8];
+  int n = 0;
+  char* area = nullptr;
+  size_t used = 0, cap = 0;
+  char* take(size_t bytes) {
+    char* q = area + used;
+    used += a256(bytes);
+    return used <= cap ? q : nullptr;
+  }
+};
+// bytes of that area for a layer whose Linears have the given (N, K) and M rows
+size_t tn_area_bytes(int M, const int* N, const int* K, int n) {
+  const size_t Mp = mp32(M);
+  size_t b = 0;
+  for (int i = 0; i < n; ++i) {
+    const int splits = gridmm_linear_planes_tn_splits(M, N[i], K[i]);
+    b += a256((size_t)N[i] * Mp * 4) + a256(((Mp + 255) / 256) * (size_t)N[i] * 4);
+    if (splits > 1) b += a256((size_t)splits * N[i] * K[i] * 4);
+  }
+  return b;
+}
+int tn_flush(TnBatch& tb, gridmm_stream_t st) {
+  if (!tb.n) return GRIDMM_OK;
+  const int rc = gridmm_linear_planes_tn_grouped(tb.p, tb.n, st);
+  tb.n = 0;
+  return rc;
+}
+
 int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned short* xP, const float* Radd, float* dX,
-               float* dW, float* db, int M, const LinWs& ws, gridmm_stream_t st) {
+               float* dW, float* db, int M, const LinWs& ws, gridmm_stream_t st, TnBatch* tb = nullptr) {
   const int N = l.N, K = l.K, Mp = mp32(M);
-  unsigned short *yh = ws.yT, *yl = ws.yT + (size_t)N * Mp;
+  const bool defer = tb && dW;
+  const int splits = dW ? gridmm_linear_planes_tn_splits(M, N, K) : 1;   // <= 8: ws.splitk holds 8 partial tiles
+  unsigned short* yh = ws.yT;
+  float *cs_ws = ws.cs_ws, *splitk = ws.splitk;
+  if (defer) {
+    if (tb->n >= 8) return GRIDMM_EINVAL;
+    yh = (unsigned short*)tb->take((size_t)N * Mp * 4);
+    cs_ws = (float*)tb->take(((size_t)(Mp + 255) / 256) * N * 4);
+    splitk = splits > 1 ? (float*)tb->take((size_t)splits * N * K * 4) : nullptr;
+    if (!yh || !cs_ws || (splits > 1 && !splitk)) return GRIDMM_EINVAL;
+  }
+  unsigned short* yl = yh + (size_t)N * Mp;
   // db: the split pass leaves one column-sum partial per 256 rows; the weight gradient's summing pass reduces them
   // (gridmm_linear_planes_tn_db) -- no reduction launch of its own unless there is no weight gradient
   const bool fold = db && dW;
-  int rc = gridmm_split_rows_pad(dY, N, yh, yl, N, fold ? nullptr : db, db ? ws.cs_ws : nullptr, M, N, Mp, st);
+  int rc = gridmm_split_rows_pad(dY, N, yh, yl, N, fold ? nullptr : db, db ? cs_ws : nullptr, M, N, Mp, st);
   if (rc != GRIDMM_OK) return rc;
   if (dX) {
     if (!l.wt_hi || !l.wt_lo || l.Np < N) return GRIDMM_EINVAL;
@@ -104,10 +148,15 @@ int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned s
                               GRIDMM_ACT_NONE, st);
     if (rc != GRIDMM_OK) return rc;
   }
-  if (dW) {
-    const int splits = gridmm_linear_planes_tn_splits(M, N, K);   // <= 8: ws.splitk holds 8 partial tiles
-    rc = gridmm_linear_planes_tn_db(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, ws.splitk, M, N, K, splits,
-                                    fold ? ws.cs_ws : nullptr, (Mp + 255) / 256, fold ? db : nullptr, st);
+  if (defer) {
+    gridmm_tn_problem_t& q = tb->p[tb->n++];
+    q.A_hi = yh; q.A_lo = yl; q.lda = N;
+    q.B_hi = xP; q.B_lo = xP + (size_t)K * Mp; q.ldb = K;
+    q.C = dW; q.workspace = splitk; q.M = M; q.N = N; q.K = K; q.splits = splits;
+    q.colsum_ws = fold ? cs_ws : nullptr; q.n_part = (Mp + 255) / 256; q.db = fold ? db : nullptr;
+  } else if (dW) {
+    rc = gridmm_linear_planes_tn_db(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, splitk, M, N, K, splits,
+                                    fold ? cs_ws : nullptr, (Mp + 255) / 256, fold ? db : nullptr, st);
   }
   return rc;
 }
@@ -125,7 +174,9 @@ extern "C" size_t gridmm_xattn_layer_train_workspace(int B, int Sq, int H, int I
   const size_t lnws = a256((M + 3) / 4 * 2 * H * 4), delta = a256((size_t)B * (H / 64) * ((Sq + 15) / 16 * 16) * 4);
   // gradients in flight: dh (M,H) x2, da (M,H) x2, dc (M,H), dqkv (M,3H), dg (M,I), df1 (M,I)
   const size_t grads = a256(M * H * 4) * 5 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) * 2;
-  return rows + yT + cs + splitk + lnws + delta + grads + a256(gridmm_attention_rows_bwd_workspace(B, H / 64, Sq)) + 4096;
+  const int Ns[6] = {H, H, 3 * H, H, I, H}, Ks[6] = {H, H, H, H, H, I};
+  return rows + yT + cs + splitk + lnws + delta + grads + a256(gridmm_attention_rows_bwd_workspace(B, H / 64, Sq)) +
+         tn_area_bytes((int)M, Ns, Ks, 6) + 4096;
 }
 
 extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, const float* X, const float* KV, const void* KV_hi,
@@ -257,6 +308,12 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
   float* df1 = (float*)take((size_t)M * I * 4);
   const size_t att_bytes = gridmm_attention_rows_bwd_workspace(B, heads, Sq);
   void* att_ws = take(att_bytes);                   // delta + planes of dO of the attention backward on the bf16 matrix pipe
+  TnBatch tb;                                       // the layer's weight gradients: one grouped launch at the end
+  {
+    const int Ns[6] = {H, H, 3 * H, H, I, H}, Ks[6] = {H, H, H, H, H, I};
+    tb.cap = tn_area_bytes(M, Ns, Ks, 6);
+    tb.area = take(tb.cap);
+  }
   const float scale = 0.125f;
   const float ph = L->p_hidden, pa = L->p_attn;
   int rc;
@@ -273,12 +330,12 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
 
   // ---- feed forward
   GRIDMM_TRY(ln_bwd(s.h3, s.a2, L->f_ln, L->seed[4], dY, dh, dr, G->f_ln_g, G->f_ln_b));
-  GRIDMM_TRY(linear_bwd(L->ffn_o, dh, s.gT, nullptr, dg, G->ffn_o_w, G->ffn_o_b, M, lw, stream));
+  GRIDMM_TRY(linear_bwd(L->ffn_o, dh, s.gT, nullptr, dg, G->ffn_o_w, G->ffn_o_b, M, lw, stream, &tb));
   GRIDMM_TRY(gridmm_activation(s.f1, dg, df1, (int64_t)M * I, 1, stream));
-  GRIDMM_TRY(linear_bwd(L->ffn_i, df1, s.a2T, res_of(dh, dr), da, G->ffn_i_w, G->ffn_i_b, M, lw, stream));   // da = d a2
+  GRIDMM_TRY(linear_bwd(L->ffn_i, df1, s.a2T, res_of(dh, dr), da, G->ffn_i_w, G->ffn_i_b, M, lw, stream, &tb));   // da = d a2
   // ---- self attention
   GRIDMM_TRY(ln_bwd(s.h2, cross ? s.a1 : X, L->s_ln, L->seed[3], da, dh, dr, G->s_ln_g, G->s_ln_b));
-  GRIDMM_TRY(linear_bwd(L->so, dh, s.c2T, nullptr, dc, G->so_w, G->so_b, M, lw, stream));
+  GRIDMM_TRY(linear_bwd(L->so, dh, s.c2T, nullptr, dc, G->so_w, G->so_b, M, lw, stream, &tb));
   if (L->attention_fp32) {
     GRIDMM_TRY(gridmm_attention_bwd(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H, s.qkv + 2 * H,
                                     (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2, (int64_t)Sq * H, H, dc,
@@ -293,11 +350,11 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
                                          s.qkv_shift + 2 * H, (int64_t)3 * H, att_ws, att_bytes, dqkv, bs, 3 * H, dqkv + H, bs, 3 * H, dqkv + 2 * H, bs, 3 * H, B, heads, Sq, Sq, Sqp, scale,
                                          pa, L->seed[2], L->seed_dev, stream));
   }
-  GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), cross ? da_b : dX, G->sqkv_w, G->sqkv_b, M, lw, stream));   // d a1
-  if (!cross) return GRIDMM_OK;
+  GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), cross ? da_b : dX, G->sqkv_w, G->sqkv_b, M, lw, stream, &tb));   // d a1
+  if (!cross) return tn_flush(tb, stream);
   // ---- cross attention
   GRIDMM_TRY(ln_bwd(s.h1, X, L->x_ln, L->seed[1], da_b, dh, dr, G->x_ln_g, G->x_ln_b));
-  GRIDMM_TRY(linear_bwd(L->xo, dh, s.cT, nullptr, dc, G->xo_w, G->xo_b, M, lw, stream));
+  GRIDMM_TRY(linear_bwd(L->xo, dh, s.cT, nullptr, dc, G->xo_w, G->xo_b, M, lw, stream, &tb));
   float* dq = da;                                   // (M, H) scratch: the gradient of the query projection
   if (!L->attention_fp32 && planes_ok(KV_hi, KV_lo, kv_bs, kv_rs, k_col, v_col, Sk)) {
     const unsigned short* qP = (const unsigned short*)s.q;
@@ -314,9 +371,9 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
                                     (int64_t)Sq * H, H, dKV + k_col, dkv_bs, dkv_rs, dKV + v_col, dkv_bs, dkv_rs, B, heads, Sq,
                                     Sk, Sqp, scale, pa, L->seed[0], L->seed_dev, stream));
   }
-  GRIDMM_TRY(linear_bwd(L->xq, dq, s.xT, res_of(dh, dr), dX, G->xq_w, G->xq_b, M, lw, stream));
+  GRIDMM_TRY(linear_bwd(L->xq, dq, s.xT, res_of(dh, dr), dX, G->xq_w, G->xq_b, M, lw, stream, &tb));
 #undef GRIDMM_TRY
-  return GRIDMM_OK;
+  return tn_flush(tb, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -370,7 +427,8 @@ extern "C" size_t gridmm_preln_layer_workspace(int B, int S, int H, int I) {
   const size_t lnws = a256((M + 3) / 4 * 2 * H * 4);
   // forward: LayerNorm output, dense output, activation; backward: d_o / dG, dF, dF1, dH, dxln, dx1, dC, dqkv
   const size_t bufs = a256(M * H * 4) * 5 + a256(M * 3 * H * 4) + a256(M * (size_t)I * 4) * 3;
-  return lin + lnws + bufs + a256(gridmm_attention_rows_bwd_workspace(B, H / 64, S)) + 4096;
+  const int Ns[4] = {3 * H, H, I, H}, Ks[4] = {H, H, H, I};
+  return lin + lnws + bufs + a256(gridmm_attention_rows_bwd_workspace(B, H / 64, S)) + tn_area_bytes((int)M, Ns, Ks, 4) + 4096;
 }
 
 extern "C" int gridmm_preln_layer_train_fwd(const gridmm_preln_layer_t* L, const float* X, const uint8_t* mask, int mask_bs,
@@ -455,6 +513,12 @@ extern "C" int gridmm_preln_layer_bwd(const gridmm_preln_layer_t* L, const float
   float* dqkv = (float*)take((size_t)M * 3 * H * 4);
   const size_t att_bytes = gridmm_attention_rows_bwd_workspace(B, heads, S);
   void* att_ws = take(att_bytes);
+  TnBatch tb;                                       // the layer's four weight gradients: one grouped launch at the end
+  {
+    const int Ns[4] = {3 * H, H, I, H}, Ks[4] = {H, H, H, I};
+    tb.cap = tn_area_bytes(M, Ns, Ks, 4);
+    tb.area = take(tb.cap);
+  }
   const float p = L->p, scale = 0.125f;
   const int64_t nH = (int64_t)M * H, nI = (int64_t)M * I;
   int rc;
@@ -471,16 +535,16 @@ extern "C" int gridmm_preln_layer_bwd(const gridmm_preln_layer_t* L, const float
   const float* t;
   // ---- feed forward block
   GRIDMM_TRY(undrop(dY, nH, L->seed[3], &t));
-  GRIDMM_TRY(linear_bwd(L->ffn2, t, s.fT, nullptr, dF, G->ffn2_w, G->ffn2_b, M, lw, stream));
+  GRIDMM_TRY(linear_bwd(L->ffn2, t, s.fT, nullptr, dF, G->ffn2_w, G->ffn2_b, M, lw, stream, &tb));
   GRIDMM_TRY(undrop(dF, nI, L->seed[2], &t));
   GRIDMM_TRY(gridmm_activation(s.f1, t, dF1, nI, 1, stream));
-  GRIDMM_TRY(linear_bwd(L->ffn1, dF1, s.h2T, nullptr, dH, G->ffn1_w, G->ffn1_b, M, lw, stream));
+  GRIDMM_TRY(linear_bwd(L->ffn1, dF1, s.h2T, nullptr, dH, G->ffn1_w, G->ffn1_b, M, lw, stream, &tb));
   GRIDMM_TRY(gridmm_layernorm_bwd(s.x1, H, nullptr, 0, L->ln2.gamma, L->ln2.eps, dH, H, dln, H, G->ln2_g, G->ln2_b, lnws, M, H,
                                   stream));
   GRIDMM_TRY(gridmm_dropout_add(dln, dY, dx1, nullptr, nullptr, nH, 0.f, 0, nullptr, stream));       // x1 feeds LN2 and the sum
   // ---- self attention block
   GRIDMM_TRY(undrop(dx1, nH, L->seed[1], &t));
-  GRIDMM_TRY(linear_bwd(L->out, t, s.cT, nullptr, dC, G->out_w, G->out_b, M, lw, stream));
+  GRIDMM_TRY(linear_bwd(L->out, t, s.cT, nullptr, dC, G->out_w, G->out_b, M, lw, stream, &tb));
   {
     const unsigned short *qh = (const unsigned short*)s.qkv, *ql = qh + (size_t)M * 3 * H;
     const int64_t bs = (int64_t)S * 3 * H;
@@ -489,10 +553,10 @@ extern "C" int gridmm_preln_layer_bwd(const gridmm_preln_layer_t* L, const float
                                          (int64_t)3 * H, att_ws, att_bytes, dqkv, bs, 3 * H, dqkv + H, bs, 3 * H, dqkv + 2 * H, bs,
                                          3 * H, B, heads, S, S, Sp, scale, p, L->seed[0], L->seed_dev, stream));
   }
-  GRIDMM_TRY(linear_bwd(L->qkv, dqkv, s.h1T, nullptr, dH, G->qkv_w, G->qkv_b, M, lw, stream));
+  GRIDMM_TRY(linear_bwd(L->qkv, dqkv, s.h1T, nullptr, dH, G->qkv_w, G->qkv_b, M, lw, stream, &tb));
   GRIDMM_TRY(gridmm_layernorm_bwd(X, H, nullptr, 0, L->ln1.gamma, L->ln1.eps, dH, H, dln, H, G->ln1_g, G->ln1_b, lnws, M, H,
                                   stream));
   GRIDMM_TRY(gridmm_dropout_add(dln, dx1, dX, nullptr, nullptr, nH, 0.f, 0, nullptr, stream));        // x feeds LN1 and the sum
 #undef GRIDMM_TRY
-  return GRIDMM_OK;
+  return tn_flush(tb, stream);
 }

@@ -43,11 +43,13 @@ __device__ __forceinline__ void tr_fence(uint2 (&a)[N]) {          // s_waitcnt 
 
 constexpr int PANEL = 32 * 64;   // u16 per panel image (32 rows x 64 columns)
 
+// One output tile (`tile`) of one contraction range (`split` of `nsplits`) of one problem: the body of the plain kernel
+// (tile = blockIdx.x, split = blockIdx.y) and of the grouped one (several weight gradients per launch).
 template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_kernel(
+__device__ __forceinline__ void linear_planes_tn_tile(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int ldb, float* __restrict__ C, int ldc,
-    int M, int N, int K) {
+    int M, int N, int K, const int tile, const int split, const int nsplits) {
   constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int PA = BM / 64, PB = BN / 64;                 // panels per plane
@@ -61,7 +63,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WAVES_N, wc = wave % WAVES_N;
   const int tn = (K + BN - 1) / BN;
-  const int ty = blockIdx.x / tn, tx = blockIdx.x % tn;
+  const int ty = tile / tn, tx = tile % tn;
   const int bm = ty * BM, bn = tx * BN;                     // first output row (column of A) / column (column of B)
 
   // DMA plan of this wave: piece p = (plane, panel, row group of 8)
@@ -96,9 +98,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   int nk = nk_all, k0 = 0;
-  if (gridDim.y > 1) {
-    const int per = (nk + gridDim.y - 1) / gridDim.y;
-    k0 = blockIdx.y * per;
+  if (nsplits > 1) {
+    const int per = (nk + nsplits - 1) / nsplits;
+    k0 = split * per;
     nk = max(0, min(per, nk - k0));
   }
   auto issue = [&](int kt, int slot) {
@@ -191,7 +193,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
   }
   // ---- epilogue straight from the accumulators: lane (m = lane & 15, g) holds C[row m][cols 4g .. 4g+3] of every tile
   const int mrow = lane & 15, g4 = (lane >> 4) * 4;
-  float* out = C + (gridDim.y > 1 ? (size_t)blockIdx.y * N * ldc : 0);
+  float* out = C + (nsplits > 1 ? (size_t)split * N * ldc : 0);
 #pragma unroll
   for (int jj = 0; jj < TN; ++jj) {
     const int n0 = bn + wc * WN + jj * 16 + g4;
@@ -202,6 +204,73 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_k
         *reinterpret_cast<float4*>(out + (size_t)m * ldc + n0) =
             make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
     }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_kernel(
+    const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
+    const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int ldb, float* __restrict__ C, int ldc,
+    int M, int N, int K) {
+  linear_planes_tn_tile<BM, BN, WM, WN, NS>(Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, M, N, K, (int)blockIdx.x, (int)blockIdx.y,
+                                            (int)gridDim.y);
+}
+
+// Several weight gradients in ONE launch (the six of a cross-modal layer's backward, the four of a BertLayer's): problem p
+// owns the workgroups [first[p], first[p + 1]) = its tiles x its contraction ranges.  Same tile body, same tile / range
+// numbering per problem as the plain launch: bit-identical results.
+constexpr int TN_GROUP_MAX = 8;
+struct TnProb {
+  const unsigned short *Ahi, *Alo, *Bhi, *Blo;
+  float* out;                    // C, or the split-K workspace
+  int lda, ldb, M, N, K, nsplits, tiles;
+};
+struct TnGroup {
+  TnProb p[TN_GROUP_MAX];
+  int first[TN_GROUP_MAX + 1];
+  int n;
+};
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_grouped_kernel(const TnGroup g) {
+  int q = 0;
+  while (q + 1 < g.n && (int)blockIdx.x >= g.first[q + 1]) ++q;
+  const TnProb& pr = g.p[q];
+  const int local = (int)blockIdx.x - g.first[q];
+  linear_planes_tn_tile<BM, BN, WM, WN, NS>(pr.Ahi, pr.Alo, pr.lda, pr.Bhi, pr.Blo, pr.ldb, pr.out, pr.K, pr.M, pr.N, pr.K,
+                                            local % pr.tiles, local / pr.tiles, pr.nsplits);
+}
+
+// Second stages of a group (see sum_splits_tn_kernel): problem p owns the blocks [first[p], first[p + 1]).
+struct SumProb {
+  const float* ws; float* out; size_t n4; const float* colpart; float* db;
+  int splits, sum_blocks, n_part, C;
+};
+struct SumGroup {
+  SumProb p[TN_GROUP_MAX];
+  int first[TN_GROUP_MAX + 1];
+  int n;
+};
+__global__ void sum_splits_tn_grouped_kernel(const SumGroup g) {
+  int q = 0;
+  while (q + 1 < g.n && (int)blockIdx.x >= g.first[q + 1]) ++q;
+  const SumProb& pr = g.p[q];
+  const int blk = (int)blockIdx.x - g.first[q];
+  if (blk >= pr.sum_blocks) {
+    const int c = (blk - pr.sum_blocks) * blockDim.x + threadIdx.x;
+    if (c < pr.C) {
+      float s = 0.f;
+      for (int r = 0; r < pr.n_part; ++r) s += pr.colpart[(size_t)r * pr.C + c];
+      pr.db[c] = s;
+    }
+    return;
+  }
+  for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < pr.n4; i += (size_t)pr.sum_blocks * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(pr.ws)[i];
+    for (int s = 1; s < pr.splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(pr.ws)[(size_t)s * pr.n4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(pr.out)[i] = a;
   }
 }
 
@@ -291,4 +360,55 @@ extern "C" int gridmm_linear_planes_tn_db(const void* A_hi, const void* A_lo, in
                                           int ldb, float* C, float* workspace, int M, int N, int K, int splits,
                                           const float* colsum_ws, int n_part, float* db, gridmm_stream_t stream) {
   return linear_planes_tn_impl(A_hi, A_lo, lda, B_hi, B_lo, ldb, C, workspace, M, N, K, splits, colsum_ws, n_part, db, stream);
+}
+
+// n <= 8 weight gradients (+ their bias gradients) as at most two GEMM launches (one per tile class) and one summing launch:
+// exactly the results of n calls of gridmm_linear_planes_tn_db, problem by problem.
+extern "C" int gridmm_linear_planes_tn_grouped(const gridmm_tn_problem_t* probs, int n, gridmm_stream_t stream) {
+  if (!probs || n < 1 || n > TN_GROUP_MAX) return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  TnGroup big, small;
+  SumGroup sums;
+  big.n = small.n = sums.n = 0;
+  big.first[0] = small.first[0] = sums.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    const gridmm_tn_problem_t& q = probs[i];
+    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || q.K % 4 || q.lda % 8 || q.ldb % 8 || q.lda < 8 || q.ldb < 8 || !q.C || q.splits < 1 ||
+        q.splits > 64 || (q.splits > 1 && (!q.workspace || (q.M + 31) / 32 < q.splits)) || (q.colsum_ws && (!q.db || q.n_part < 1)))
+      return GRIDMM_EINVAL;
+    const long t128 = (long)((q.N + 127) / 128) * ((q.K + 127) / 128) * q.splits;
+    const bool use128 = t128 >= 100 && q.N >= 128 && q.K >= 128;              // the plain entry point's rule
+    const int BT = use128 ? 128 : 64;
+    TnGroup& g = use128 ? big : small;
+    TnProb& t = g.p[g.n];
+    t.Ahi = (const unsigned short*)q.A_hi; t.Alo = (const unsigned short*)q.A_lo;
+    t.Bhi = (const unsigned short*)q.B_hi; t.Blo = (const unsigned short*)q.B_lo;
+    t.out = q.splits > 1 ? q.workspace : q.C;
+    t.lda = q.lda; t.ldb = q.ldb; t.M = q.M; t.N = q.N; t.K = q.K; t.nsplits = q.splits;
+    t.tiles = ((q.N + BT - 1) / BT) * ((q.K + BT - 1) / BT);
+    g.first[g.n + 1] = g.first[g.n] + t.tiles * q.splits;
+    ++g.n;
+    if (q.splits > 1 || q.colsum_ws) {
+      SumProb& sp = sums.p[sums.n];
+      sp.n4 = (size_t)q.N * q.K / 4;
+      sp.ws = q.workspace; sp.out = q.C; sp.splits = q.splits;
+      sp.sum_blocks = q.splits > 1 ? (int)((sp.n4 + 255) / 256 > 2048 ? 2048 : (sp.n4 + 255) / 256) : 0;
+      sp.colpart = q.colsum_ws; sp.db = q.db; sp.n_part = q.n_part; sp.C = q.N;
+      sums.first[sums.n + 1] = sums.first[sums.n] + sp.sum_blocks + (q.colsum_ws ? (q.N + 255) / 256 : 0);
+      ++sums.n;
+    }
+  }
+  if (big.n) {
+    GRIDMM_LAUNCH((linear_planes_tn_grouped_kernel<128, 128, 32, 32, 2>), dim3((unsigned)big.first[big.n]), dim3(16 * 64), 0, st, big);
+    GRIDMM_CHECK_LAUNCH();
+  }
+  if (small.n) {
+    GRIDMM_LAUNCH((linear_planes_tn_grouped_kernel<64, 64, 32, 32, 3>), dim3((unsigned)small.first[small.n]), dim3(4 * 64), 0, st, small);
+    GRIDMM_CHECK_LAUNCH();
+  }
+  if (sums.n) {
+    GRIDMM_LAUNCH(sum_splits_tn_grouped_kernel, dim3((unsigned)sums.first[sums.n]), dim3(256), 0, st, sums);
+    GRIDMM_CHECK_LAUNCH();
+  }
+  return GRIDMM_OK;
 }

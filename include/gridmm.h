@@ -455,6 +455,17 @@ int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const v
 int gridmm_linear_planes_tn_db(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
                                float* C, float* workspace, int M, int N, int K, int splits, const float* colsum_ws,
                                int n_part, float* db, gridmm_stream_t stream);
+/* n <= 8 such weight gradients (with their bias gradients) as at most two GEMM launches (one per tile class) + one summing launch
+ * -- the six of a cross-modal layer's backward, the four of a BertLayer's: each member exactly as gridmm_linear_planes_tn_db
+ * would compute it (same tiles, same ranges, same order of the sums).  probs: HOST array (read during the call). */
+typedef struct {
+  const void *A_hi, *A_lo; int lda;
+  const void *B_hi, *B_lo; int ldb;
+  float *C, *workspace;
+  int M, N, K, splits;
+  const float* colsum_ws; int n_part; float* db;
+} gridmm_tn_problem_t;
+int gridmm_linear_planes_tn_grouped(const gridmm_tn_problem_t* probs, int n, gridmm_stream_t stream);
 /* the number of ranges (1 .. 8) that fills the chip for this problem: what the library's own callers pass as `splits` */
 int gridmm_linear_planes_tn_splits(int M, int N, int K);
 /* X fp32 [M][C] -> row-major planes [Mp][ldp] with rows [M, Mp) zero [+ colsum as gridmm_transpose_split]: one pass per

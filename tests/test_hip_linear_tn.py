@@ -111,3 +111,48 @@ def test_bias_gradient_from_the_summing_pass_is_bit_identical(dev, M, N, K):
     dw, db = ag._gemm_tn_rows((yh2, yl2), (xh, xl), N, K, M, colpart=part)
     torch.cuda.synchronize()
     assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+
+
+def test_grouped_weight_gradients_equal_the_single_launches_bitwise(dev):
+    """gridmm_linear_planes_tn_grouped: the weight (+ bias) gradients of a layer's Linears in one grouped GEMM launch per tile
+    class + one summing launch == gridmm_linear_planes_tn_db problem by problem, bit for bit (both tile classes, split and
+    unsplit contractions, with and without a bias gradient)."""
+    import ctypes
+    from gridmm_amd import autograd as ag
+
+    class Prob(ctypes.Structure):
+        _fields_ = [("A_hi", ctypes.c_void_p), ("A_lo", ctypes.c_void_p), ("lda", ctypes.c_int),
+                    ("B_hi", ctypes.c_void_p), ("B_lo", ctypes.c_void_p), ("ldb", ctypes.c_int),
+                    ("C", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                    ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("splits", ctypes.c_int),
+                    ("colsum_ws", ctypes.c_void_p), ("n_part", ctypes.c_int), ("db", ctypes.c_void_p)]
+    lib = ag._lib.load()
+    M = 1824
+    shapes = [(768, 768, True), (2304, 768, True), (768, 3072, False), (3072, 768, True), (64, 64, True), (8, 40, False)]
+    g = torch.Generator().manual_seed(9)
+    keep, probs, want = [], (Prob * len(shapes))(), []
+    for i, (N, K, bias) in enumerate(shapes):
+        x = torch.randn(M, K, generator=g).to(dev)
+        dy = (torch.randn(M, N, generator=g) * 0.1).to(dev)
+        xh, xl, _, Mp, _ = ag.split_rows_pad(x)
+        yh, yl, part, _, _ = ag.split_rows_pad(dy, want_colsum=True, defer_colsum=True)
+        if bias:
+            dw_ref, db_ref = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M, colpart=part)
+        else:
+            dw_ref, db_ref = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M), None
+        splits = lib.gridmm_linear_planes_tn_splits(M, N, K)
+        dw = torch.full((N, K), float("nan"), device=dev)
+        db = torch.full((N,), float("nan"), device=dev) if bias else None
+        ws = torch.empty(splits, N, K, device=dev) if splits > 1 else None
+        keep += [xh, xl, yh, yl, part, dw, db, ws]
+        probs[i] = Prob(yh.data_ptr(), yl.data_ptr(), N, xh.data_ptr(), xl.data_ptr(), K, dw.data_ptr(),
+                        ws.data_ptr() if ws is not None else None, M, N, K, splits,
+                        part.data_ptr() if bias else None, part.shape[0], db.data_ptr() if bias else None)
+        want.append((dw_ref, db_ref, dw, db))
+    ag._lib.check(lib.gridmm_linear_planes_tn_grouped(ctypes.byref(probs), len(shapes), ag._stream()),
+                  "gridmm_linear_planes_tn_grouped")
+    torch.cuda.synchronize()
+    for dw_ref, db_ref, dw, db in want:
+        assert torch.equal(dw, dw_ref)
+        if db_ref is not None:
+            assert torch.equal(db, db_ref)
