@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
 # overrides and the whole experiment table of tile configurations.  Only the sweep tools ask for it (load(debug=True) or
 # GRIDMM_LIB_DEBUG=1 before the first load); the product path and the tests run on the shipping library, which has neither.
 DEBUG_LIB_PATH = os.path.join(_HERE, "libgridmm_hip_dbg.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 

@@ -72,10 +72,10 @@ int linear_fwd(const gridmm_linear_train_t& l, const float* x, unsigned short* x
 
 // The same when the producer of x (LayerNorm, GELU, attention) already wrote its planes into the saved block.
 int linear_fwd_planes(const gridmm_linear_train_t& l, const unsigned short* xP, const float* R, float* y, int M, int act,
-                      gridmm_stream_t st, unsigned short* yP = nullptr) {
+                      gridmm_stream_t st, unsigned short* yP = nullptr, unsigned short* yPlo = nullptr) {
   const int K = l.K, Mp = mp32(M);
   return gridmm_linear_planes(xP, xP + (size_t)K * Mp, K, l.w_hi, l.w_lo, l.Kp, l.bias, R, R ? l.N : 0, y, l.N, yP,
-                              yP ? yP + (size_t)M * l.N : nullptr, l.N, M, l.N, K, act, st);
+                              yP ? (yPlo ? yPlo : yP + (size_t)M * l.N) : nullptr, l.N, M, l.N, K, act, st);
 }
 
 // The cross attention runs on the bf16 matrix pipe (gridmm_attention_rows_train / _bwd) when the caller hands the planes of
@@ -262,8 +262,9 @@ extern "C" int gridmm_xattn_layer_train_fwd(const gridmm_xlayer_train_t* L, cons
   GRIDMM_TRY(linear_fwd_planes(L->so, s.c2T, nullptr, s.h2, M, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(ln(s.h2, a1, L->s_ln, L->seed[3], s.a2, s.a2T));
   // ---- feed forward (vilmodel.py:184-209)
-  GRIDMM_TRY(linear_fwd_planes(L->ffn_i, s.a2T, nullptr, s.f1, M, GRIDMM_ACT_NONE, stream));
-  GRIDMM_TRY(gridmm_activation_planes(s.f1, nullptr, g, s.gT, s.gT + (size_t)I * Mp, (int64_t)M * I, 0, stream));
+  // linear1 and its GELU as one launch: s.f1 = the pre-activation (for the GELU backward), s.gT = the planes of gelu(s.f1)
+  GRIDMM_TRY(linear_fwd_planes(L->ffn_i, s.a2T, nullptr, s.f1, M, GRIDMM_ACT_GELU_PLANES, stream, s.gT, s.gT + (size_t)I * Mp));
+  (void)g;
   GRIDMM_TRY(linear_fwd_planes(L->ffn_o, s.gT, nullptr, s.h3, M, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(ln(s.h3, s.a2, L->f_ln, L->seed[4], Y, nullptr));
 #undef GRIDMM_TRY
@@ -471,12 +472,12 @@ extern "C" int gridmm_preln_layer_train_fwd(const gridmm_preln_layer_t* L, const
   // ---- feed forward block: LN2 -> linear1 -> gelu -> dropout (writes the planes linear2 reads) -> linear2
   GRIDMM_TRY(gridmm_layernorm(s.x1, H, nullptr, 0, L->ln2.gamma, L->ln2.beta, L->ln2.eps, hbuf, H, nullptr, 0, nullptr, nullptr,
                               s.h2T, s.h2T + (size_t)H * Mp, H, M, H, stream));
-  GRIDMM_TRY(linear_fwd_planes(L->ffn1, s.h2T, nullptr, s.f1, M, GRIDMM_ACT_NONE, stream));
   if (p > 0.f) {
+    GRIDMM_TRY(linear_fwd_planes(L->ffn1, s.h2T, nullptr, s.f1, M, GRIDMM_ACT_NONE, stream));
     GRIDMM_TRY(gridmm_activation(s.f1, nullptr, g, nI, 0, stream));
     GRIDMM_TRY(gridmm_dropout_add(g, nullptr, nullptr, s.fT, s.fT + (size_t)I * Mp, nI, p, L->seed[2], L->seed_dev, stream));
-  } else {
-    GRIDMM_TRY(gridmm_activation_planes(s.f1, nullptr, g, s.fT, s.fT + (size_t)I * Mp, nI, 0, stream));
+  } else {   // no dropout between the activation and linear2: linear1 + GELU as one launch (pre-activation + planes of gelu)
+    GRIDMM_TRY(linear_fwd_planes(L->ffn1, s.h2T, nullptr, s.f1, M, GRIDMM_ACT_GELU_PLANES, stream, s.fT, s.fT + (size_t)I * Mp));
   }
   GRIDMM_TRY(linear_fwd_planes(L->ffn2, s.fT, nullptr, o, M, GRIDMM_ACT_NONE, stream));
   GRIDMM_TRY(gridmm_dropout_add(o, s.x1, Y, nullptr, nullptr, nH, p, L->seed[3], L->seed_dev, stream));

@@ -34,7 +34,7 @@ __device__ __forceinline__ void dma16(const unsigned short* gsrc, unsigned short
 // kernels planes of K - K[row 0 of the episode], V - V[row 0] -- softmax(Q K^T) is invariant to a shift of K and
 // P V = P (V - v0) + (sum_k P_k) v0 -- so that the bf16 products of the attention carry no large common component; the fp32
 // output C stays the true projection).  Columns >= c0 of row m get tab[(m / rpb) * N + n] subtracted before the hi / lo split.
-struct PShift { const float* tab; int rpb, c0; };
+struct PShift { const float* tab; int rpb, c0; int pre_c; };   // pre_c: C receives the PRE-activation (GRIDMM_ACT_GELU_PLANES)
 
 // BM x BN block tile, WM x WN per wave (16x16x32 MFMA tiles), NS-stage LDS ring filled by LDS-DMA.
 // One raw s_barrier per k-step; the DMA of stage kt+NS-1 is issued right after the barrier that retires
@@ -318,6 +318,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
         }
         if (m < M && n0 < N) {
           float x[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+          const float4 pre = make_float4(x[0], x[1], x[2], x[3]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
@@ -328,7 +329,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
             const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
             x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w;
           }
-          if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
+          if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = (ACT != GRIDMM_ACT_NONE && ps.pre_c) ? pre : make_float4(x[0], x[1], x[2], x[3]);
           if (Chi) {
             if (ps.tab && n0 >= ps.c0) {
               const float4 s4 = *reinterpret_cast<const float4*>(ps.tab + (size_t)(m / ps.rpb) * N + n0);
@@ -373,6 +374,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       float4 v = *reinterpret_cast<const float4*>(ep + row * WN + c4 * 4);
       if (m < M && n0 < N) {
         float x[4] = {v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w};
+        const float4 pre = make_float4(x[0], x[1], x[2], x[3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (ACT == GRIDMM_ACT_GELU) x[e] = x[e] * 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
@@ -383,7 +385,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
           const float4 r4 = *reinterpret_cast<const float4*>(R + (size_t)m * ldr + n0);
           x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w;
         }
-        if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(x[0], x[1], x[2], x[3]);
+        if (C) *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = (ACT != GRIDMM_ACT_NONE && ps.pre_c) ? pre : make_float4(x[0], x[1], x[2], x[3]);
         if (Chi) {
           if (ps.tab && n0 >= ps.c0) {
             const float4 s4 = *reinterpret_cast<const float4*>(ps.tab + (size_t)(m / ps.rpb) * N + n0);
@@ -606,6 +608,11 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
   if (ps.tab && (ps.rpb <= 0 || ps.c0 < 0 || ps.c0 % 4 || !C_hi)) return GRIDMM_EINVAL;
   if (w_layout != GRIDMM_W_ROWMAJOR && w_layout != GRIDMM_W_TILED) return GRIDMM_EINVAL;
   const bool wt = w_layout == GRIDMM_W_TILED;
+  if (act == GRIDMM_ACT_GELU_PLANES) {          // C = x W^T + b (what the GELU backward needs), planes = those of gelu(C)
+    if (!C || !C_hi || residual) return GRIDMM_EINVAL;
+    ps.pre_c = 1;
+    act = GRIDMM_ACT_GELU;
+  }
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 || Kp < K || lda <= 0 || lda % 8 || N % 4 || act < 0 || act > 3)
     return GRIDMM_EINVAL;
   if ((C && ldc % 4) || (residual && ldr % 4) || (C_hi && (ldp % 4 || !C_lo)) || (!C && !C_hi)) return GRIDMM_EINVAL;

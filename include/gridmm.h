@@ -166,6 +166,9 @@ int gridmm_split_weight(const float* W, void* hi, void* lo, int N, int K, int Kp
 #define GRIDMM_ACT_GELU 1  /* exact erf gelu (vilmodel.py:47-53, transformer.py:472) */
 #define GRIDMM_ACT_RELU 2
 #define GRIDMM_ACT_QUICKGELU 3  /* x * sigmoid(1.702 x): CLIP's MLP (VLN_CE/.../gridmap/clip.py:26-28); gridmm_linear_planes only */
+#define GRIDMM_ACT_GELU_PLANES 4 /* gridmm_linear_planes family, training: C receives the PRE-activation x W^T + b (what the GELU
+                                  * backward reads), the planes C_hi / C_lo those of gelu(C) (what the next Linear reads): the
+                                  * feed-forward's first Linear and its activation as one launch.  Needs C and the planes, no residual. */
 
 /* C[M][N] = act(A[M][K] * W^T + bias) (+ residual), fp32 in / fp32 out, the contraction on
  * MFMA bf16 16x16x32 tiles as a 3-term split (a_hi w_hi + a_lo w_hi + a_hi w_lo, fp32
