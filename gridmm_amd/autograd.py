@@ -608,11 +608,59 @@ def linear_group(x, weights, biases, residual=None, out_planes=False):
     return _LinearGroup.apply(x, residual, WEIGHTS.group_getter(ws), out_planes, len(ws), *ws, *tuple(biases or ()))
 
 
+SKINNY_LINEAR = bool(int(__import__('os').environ.get('GRIDMM_SKINNY_LINEAR', '1')))   # A/B switch
+
+
+class _LinearSkinny(torch.autograd.Function):
+    """nn.Linear with K <= 16 input features (position / angle embeddings, vilmodel.py:454-470, 538-552, 640-655): fp32 FMA
+    kernels (gridmm_linear_skinny / _bwd) instead of the tile GEMM's fp32-A fallback."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.set_materialize_grads(False)
+        lib = _lib.load()
+        N, K = weight.shape
+        x2 = x.float().contiguous().view(-1, K)
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        M = x2.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _lib.check(lib.gridmm_linear_skinny(_p(x2), K, _p(w), _p(b), _p(y), N, M, N, K, _stream()), "gridmm_linear_skinny")
+        ctx.save_for_backward(x2, w)
+        ctx.prm, ctx.has_bias, ctx.xshape = (weight, bias), bias is not None, tuple(x.shape)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        lib = _lib.load()
+        x2, w = ctx.saved_tensors
+        N, K = w.shape
+        M = x2.shape[0]
+        dy2 = dy.contiguous().view(M, N)
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dw = db = dx = None
+        if need_w:
+            dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+            db = torch.empty(N, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+            ws = torch.empty(int(lib.gridmm_linear_skinny_bwd_workspace(M, N, K)), dtype=torch.uint8, device=dy.device)
+            _lib.check(lib.gridmm_linear_skinny_bwd(_p(dy2), N, _p(x2), K, _p(dw), _p(db), _p(ws), M, N, K, _stream()),
+                       "gridmm_linear_skinny_bwd")
+            dw = dw.to(ctx.prm[0].dtype)
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, w).view(ctx.xshape)       # (features are inputs in every caller: normally not needed)
+        return dx, DEFERRED.hand(ctx.prm[0], dw), DEFERRED.hand(ctx.prm[1], db)
+
+
 def linear(x, weight, bias=None, residual=None, out_planes=False):
     """x (..., K) @ weight (N, K)^T + bias (+ residual).  out_planes: the GEMM epilogue also writes the bf16 hi/lo planes of
     the result and hangs them on the returned tensor (q / k / v projections: the attention kernels take planes).  True: plain
     planes (a q projection); an int c0: the planes of the columns >= c0 are shifted by row 0 of their episode (H for a fused
     q | k | v projection, 0 for a k | v projection) and the tensor also carries that row (`_gridmm_shift`)."""
+    if SKINNY_LINEAR and weight.shape[1] <= 16 and weight.shape[0] % 4 == 0 and residual is None and not out_planes and x.is_cuda \
+            and weight.dtype == torch.float32:
+        return _LinearSkinny.apply(x, weight, bias)
     return _Linear.apply(x, weight, bias, residual, WEIGHTS.getter(weight), out_planes)
 
 

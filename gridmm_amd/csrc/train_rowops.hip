@@ -146,7 +146,113 @@ __global__ void dropout_add_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+// ---- Linear layers with a handful of input features (the position / angle embeddings: K = 7 for loc_fts and the map /
+// viewpoint position features, K = 14 for their concatenation; map_nav_src/models/vilmodel.py:454-470, 538-552, 640-655).  Too
+// narrow for the MFMA tile GEMMs (their fp32-A fallback walks 64-wide tiles over a 7-deep contraction: 35-86 us per call);
+// plain fp32 FMAs over the rows do it at the speed of writing Y / reading dY.
+constexpr int SK_MAX = 16;
+// Y[m][n] = b[n] + sum_k X[m][k] W[n][k].  Thread = 4 consecutive columns (W rows in registers), workgroup = 256 threads
+// over the columns x SK_ROWS rows.
+constexpr int SK_ROWS = 8;
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, float* __restrict__ Y, int ldy,
+                                                            int M, int N, int K) {
+  __shared__ float s_x[SK_ROWS][SK_MAX];
+  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int m0 = blockIdx.y * SK_ROWS;
+  if (threadIdx.x < SK_ROWS * SK_MAX) {
+    const int r = threadIdx.x / SK_MAX, k = threadIdx.x % SK_MAX;
+    s_x[r][k] = (m0 + r < M && k < K) ? X[(size_t)(m0 + r) * ldx + k] : 0.f;
+  }
+  __syncthreads();
+  if (n0 >= N) return;
+  float w[4][SK_MAX];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < SK_MAX; ++k) w[j][k] = (k < K) ? W[(size_t)(n0 + j) * K + k] : 0.f;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) b4 = *reinterpret_cast<const float4*>(bias + n0);
+  for (int r = 0; r < SK_ROWS && m0 + r < M; ++r) {
+    float y[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int k = 0; k < SK_MAX; ++k) {
+      const float x = s_x[r][k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = fmaf(x, w[j][k], y[j]);
+    }
+    *reinterpret_cast<float4*>(Y + (size_t)(m0 + r) * ldy + n0) = make_float4(y[0], y[1], y[2], y[3]);
+  }
+}
+
+// dW[n][k] = sum_m dY[m][n] X[m][k], db[n] = sum_m dY[m][n]: stage 1, one partial per 256-row block and column
+// (part[blk][n][K + 1], the last entry = the bias partial); stage 2 sums the blocks in order (deterministic).
+constexpr int SKB_ROWS = 256;
+__global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
+                                                                int ldx, float* __restrict__ part, int M, int N, int K) {
+  __shared__ float s_x[SKB_ROWS][SK_MAX];
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * SKB_ROWS, rows = min(SKB_ROWS, M - m0);
+  for (int i = threadIdx.x; i < SKB_ROWS * SK_MAX; i += 256) {
+    const int r = i / SK_MAX, k = i % SK_MAX;
+    s_x[r][k] = (r < rows && k < K) ? X[(size_t)(m0 + r) * ldx + k] : 0.f;
+  }
+  __syncthreads();
+  if (n >= N) return;
+  float acc[SK_MAX + 1];
+#pragma unroll
+  for (int k = 0; k <= SK_MAX; ++k) acc[k] = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    const float d = dY[(size_t)(m0 + r) * ldy + n];
+#pragma unroll
+    for (int k = 0; k < SK_MAX; ++k) acc[k] = fmaf(d, s_x[r][k], acc[k]);
+    acc[SK_MAX] += d;
+  }
+  float* p = part + ((size_t)blockIdx.y * N + n) * (K + 1);
+#pragma unroll
+  for (int k = 0; k < SK_MAX; ++k)
+    if (k < K) p[k] = acc[k];
+  p[K] = acc[SK_MAX];
+}
+__global__ void linear_skinny_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, float* __restrict__ db,
+                                                int n_blk, int N, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over N * (K + 1)
+  if (i >= N * (K + 1)) return;
+  float s = 0.f;
+  for (int b = 0; b < n_blk; ++b) s += part[(size_t)b * N * (K + 1) + i];
+  const int n = i / (K + 1), k = i % (K + 1);
+  if (k < K) { if (dW) dW[(size_t)n * K + k] = s; }
+  else if (db) db[n] = s;
+}
+
 }  // namespace
+
+extern "C" int gridmm_linear_skinny(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N,
+                                    int K, gridmm_stream_t stream) {
+  if (!X || !W || !Y || M <= 0 || N <= 0 || N % 4 || K <= 0 || K > SK_MAX || ldx < K || ldy < N || ldy % 4) return GRIDMM_EINVAL;
+  dim3 grid((N / 4 + 255) / 256, (M + SK_ROWS - 1) / SK_ROWS);
+  GRIDMM_LAUNCH(linear_skinny_kernel, grid, dim3(256), 0, as_stream(stream), X, ldx, W, bias, Y, ldy, M, N, K);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" size_t gridmm_linear_skinny_bwd_workspace(int M, int N, int K) {
+  return (size_t)((M + SKB_ROWS - 1) / SKB_ROWS) * N * (K + 1) * sizeof(float);
+}
+
+extern "C" int gridmm_linear_skinny_bwd(const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, float* workspace,
+                                        int M, int N, int K, gridmm_stream_t stream) {
+  if (!dY || !X || !workspace || (!dW && !db) || M <= 0 || N <= 0 || K <= 0 || K > SK_MAX || ldx < K || ldy < N)
+    return GRIDMM_EINVAL;
+  const int n_blk = (M + SKB_ROWS - 1) / SKB_ROWS;
+  hipStream_t st = as_stream(stream);
+  GRIDMM_LAUNCH(linear_skinny_bwd_kernel, dim3((N + 255) / 256, n_blk), dim3(256), 0, st, dY, ldy, X, ldx, workspace, M, N, K);
+  GRIDMM_CHECK_LAUNCH();
+  const int tot = N * (K + 1);
+  GRIDMM_LAUNCH(linear_skinny_bwd_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, workspace, dW, db, n_blk, N, K);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
 
 extern "C" int gridmm_dropout_add(const float* x, const float* r, float* y, void* y_hi, void* y_lo, int64_t n, float p,
                                   unsigned long long seed, const unsigned long long* seed_dev, gridmm_stream_t stream) {

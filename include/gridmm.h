@@ -646,6 +646,17 @@ int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tens
                             float beta2, int decay_first, const float* sumsq, float max_norm, const void* planes,
                             gridmm_stream_t stream);
 
+/* Linear layers with K <= 16 input features on the differentiable path (position / angle embeddings: loc_fts K = 7,
+ * gmap_pos_fts / vp_pos_fts K = 7 / 14; map_nav_src/models/vilmodel.py:454-470, 538-552, 640-655) in plain fp32 FMAs:
+ *   gridmm_linear_skinny      Y [M][N] (row stride ldy) = X [M][K] (row stride ldx) W^T + bias; W fp32 [N][K] contiguous, N % 4 == 0
+ *   gridmm_linear_skinny_bwd  dW [N][K] = dY^T X, db [N] = column sums of dY (either may be NULL); one partial per 256 rows in
+ *                             `workspace` (gridmm_linear_skinny_bwd_workspace bytes), summed in order (deterministic). */
+int gridmm_linear_skinny(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
+                         gridmm_stream_t stream);
+size_t gridmm_linear_skinny_bwd_workspace(int M, int N, int K);
+int gridmm_linear_skinny_bwd(const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, float* workspace, int M,
+                             int N, int K, gridmm_stream_t stream);
+
 /* Gradient accumulation of a multi-step backward as ONE launch (fine-tuning: one backward through the 7 .. 15 navigation
  * steps of a rollout, map_nav_src/r2r/agent_base.py:190-199 -- under torch autograd every step's gradient of every parameter
  * is added by its own launch).  desc: device array of n_tensors records {float* dst; const float* src[7]; int64 n;

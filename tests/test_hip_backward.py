@@ -225,3 +225,31 @@ def test_attention_probability_dropout_forward_and_backward():
     yd.backward(dy.double())
     assert _rel(y, yd) < 1e-5
     assert _rel(qkv.grad, qd.grad) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(6912, 768, 7), (1824, 768, 14), (37, 768, 7), (300, 64, 5), (1, 8, 16)])
+def test_skinny_linear_matches_fp64(M, N, K):
+    """gridmm_linear_skinny / _bwd (the K <= 16 position / angle embedding Linears of the differentiable path,
+    map_nav_src/models/vilmodel.py:454-470, 538-552, 640-655) vs fp64: forward, dW, db; two runs bit-identical."""
+    import torch
+    from gridmm_amd import autograd as ag
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.3).to(dev))
+    b = torch.nn.Parameter(torch.randn(N, generator=g).to(dev))
+    dy = torch.randn(M, N, generator=g).to(dev)
+    outs = []
+    for _ in range(2):
+        w.grad = b.grad = None
+        y = ag.linear(x, w, b)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        outs.append((y.detach().clone(), w.grad.clone(), b.grad.clone()))
+    y, dw, db = outs[0]
+    assert all(torch.equal(a, c) for a, c in zip(outs[0], outs[1]))
+    yr = x.double() @ w.detach().double().t() + b.detach().double()
+    assert float((y.double() - yr).abs().max()) <= 1e-5 * max(1.0, float(yr.abs().max()))
+    dwr, dbr = dy.double().t() @ x.double(), dy.double().sum(0)
+    assert float((dw.double() - dwr).abs().max()) <= 2e-5 * max(1.0, float(dwr.abs().max()))
+    assert float((db.double() - dbr).abs().max()) <= 2e-5 * max(1.0, float(dbr.abs().max()))
