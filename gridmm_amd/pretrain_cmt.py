@@ -27,6 +27,8 @@ from . import autograd as ag, hostsync as hs, vilmodel as V, vilmodel_train as V
 N_CELLS = 196
 
 
+PAD_VOCAB = bool(int(__import__('os').environ.get('GRIDMM_PAD_VOCAB', '1')))   # A/B switch of forward_mlm's decoder call
+
 class GlocalTextPathCMT(nn.Module):
     """The pre-training backbone (pretrain_src/model/vilmodel.py:640-856): parameters under the reference's names and
     its two entry points forward(...) / forward_mlm(...) with the reference's positional signature; the arithmetic runs
@@ -316,7 +318,18 @@ class GlocalTextPathCMTPreTraining(nn.Module):
         p = self.mlm_head.predictions
         h = ag.layer_norm(ag.gelu(ag.linear(hidden, p.transform.dense.weight, p.transform.dense.bias)),
                           p.transform.LayerNorm)
-        scores = ag.linear(h, p.decoder.weight, p.bias)                       # decoder(h) + bias
+        # decoder(h) + bias.  The vocabulary (30 522 rows) is not a multiple of 8, which the plane GEMMs and the row-major weight
+        # gradient need: the tied matrix and its bias are extended by zero rows for the call (one cat each; the gradient of the
+        # cat is the row slice) and the extra logit columns cut off -- instead of the fp32-A fallback kernels (5 calls of ~260 us
+        # per mlm step).
+        Nv = p.decoder.weight.shape[0]
+        pad = (-Nv) % 8
+        if pad and h.is_cuda and PAD_VOCAB:
+            w = torch.cat([p.decoder.weight, p.decoder.weight.new_zeros(pad, p.decoder.weight.shape[1])], 0)
+            b = torch.cat([p.bias, p.bias.new_zeros(pad)], 0)
+            scores = ag.linear(h, w, b)[..., :Nv]
+        else:
+            scores = ag.linear(h, p.decoder.weight, p.bias)
         if compute_loss:
             return F.cross_entropy(scores, hs.select(labels, sel).long(), reduction="none")
         return scores
