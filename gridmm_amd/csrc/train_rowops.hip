@@ -185,9 +185,9 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
   }
 }
 
-// dW[n][k] = sum_m dY[m][n] X[m][k], db[n] = sum_m dY[m][n]: stage 1, one partial per 256-row block and column
+// dW[n][k] = sum_m dY[m][n] X[m][k], db[n] = sum_m dY[m][n]: stage 1, one partial per 64-row block and column
 // (part[blk][n][K + 1], the last entry = the bias partial); stage 2 sums the blocks in order (deterministic).
-constexpr int SKB_ROWS = 256;
+constexpr int SKB_ROWS = 64;
 __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X,
                                                                 int ldx, float* __restrict__ part, int M, int N, int K) {
   __shared__ float s_x[SKB_ROWS][SK_MAX];

@@ -649,7 +649,7 @@ int gridmm_multi_adamw_step(const void* desc, const int* chunk_first, int n_tens
 /* Linear layers with K <= 16 input features on the differentiable path (position / angle embeddings: loc_fts K = 7,
  * gmap_pos_fts / vp_pos_fts K = 7 / 14; map_nav_src/models/vilmodel.py:454-470, 538-552, 640-655) in plain fp32 FMAs:
  *   gridmm_linear_skinny      Y [M][N] (row stride ldy) = X [M][K] (row stride ldx) W^T + bias; W fp32 [N][K] contiguous, N % 4 == 0
- *   gridmm_linear_skinny_bwd  dW [N][K] = dY^T X, db [N] = column sums of dY (either may be NULL); one partial per 256 rows in
+ *   gridmm_linear_skinny_bwd  dW [N][K] = dY^T X, db [N] = column sums of dY (either may be NULL); one partial per 64 rows in
  *                             `workspace` (gridmm_linear_skinny_bwd_workspace bytes), summed in order (deterministic). */
 int gridmm_linear_skinny(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
                          gridmm_stream_t stream);
