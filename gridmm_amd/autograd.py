@@ -336,6 +336,9 @@ def deferred_param_grads():
     prev, DEFERRED.active = DEFERRED.active, True
     try:
         yield
+    except BaseException:
+        DEFERRED.pending.clear()        # a backward that raised half-way: its gradients must not reach the next flush
+        raise
     finally:
         DEFERRED.active = prev
 
