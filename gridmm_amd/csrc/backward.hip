@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void agg_bwd_gather_kernel(
 //                          order (no atomics, deterministic); the chunk tables go to a workspace
 //   agg_bwd_gsum_kernel    dtext = sum of the chunk tables in chunk order
 constexpr int DA2_P = 16;
-constexpr int GCH = 8;          // chunks per episode of the gather pass
+constexpr int GCH = 32;         // chunks per episode of the gather pass, at most (the workspace is sized for it); 8 / 16 / 32 by capacity
 
 template <int NV8>              // 16-byte row pieces per lane: D <= 512 * NV8
 __global__ __launch_bounds__(256) void agg_bwd_da2_kernel(const _Float16* __restrict__ slab, const int32_t* __restrict__ perm,
@@ -675,13 +675,13 @@ __global__ __launch_bounds__(256) void agg_bwd_da2_kernel(const _Float16* __rest
 __global__ __launch_bounds__(128) void agg_bwd_gather2_kernel(const _Float16* __restrict__ slab, const int32_t* __restrict__ perm,
                                                               const int32_t* __restrict__ cell_start,
                                                               const int32_t* __restrict__ amax, const float* __restrict__ dw,
-                                                              float* __restrict__ part, int cap, int D, int L) {
+                                                              float* __restrict__ part, int cap, int D, int L, int gch) {
   extern __shared__ __attribute__((aligned(16))) float2 s_tab[];          // [2 waves][L][64 lanes] (two dims per lane)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int halves = (D + 255) / 256;
   const int chunk = blockIdx.x / halves, half = blockIdx.x % halves, b = blockIdx.y;
   const int valid = cell_start[(size_t)b * (GRIDMM_CELLS + 2) + GRIDMM_CELLS];
-  const int per = ((valid + GCH - 1) / GCH + 63) / 64 * 64;               // points per chunk, whole 64-point groups
+  const int per = ((valid + gch - 1) / gch + 63) / 64 * 64;               // points per chunk, whole 64-point groups
   const int beg = chunk * per, end = min(valid, beg + per);
   const int d0 = half * 256 + wave * 128 + 2 * lane;                       // this lane's two columns
   const bool col_ok = d0 < D;
@@ -721,20 +721,19 @@ __global__ __launch_bounds__(128) void agg_bwd_gather2_kernel(const _Float16* __
     }
   }
   if (col_ok) {
-    float* out = part + (((size_t)b * GCH + chunk) * L) * D + d0;
+    float* out = part + (((size_t)b * gch + chunk) * L) * D + d0;
     for (int l = 0; l < L; ++l) *reinterpret_cast<float2*>(out + (size_t)l * D) = tab[l * 64 + lane];
   }
 }
 
-__global__ void agg_bwd_gsum_kernel(const float* __restrict__ part, float* __restrict__ dtext, size_t per_b4) {
+__global__ void agg_bwd_gsum_kernel(const float* __restrict__ part, float* __restrict__ dtext, size_t per_b4, int gch) {
   const size_t n4 = per_b4 * gridDim.y;
   (void)n4;
   const int b = blockIdx.y;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_b4; i += (size_t)gridDim.x * blockDim.x) {
-    float4 a = reinterpret_cast<const float4*>(part)[((size_t)b * GCH) * per_b4 + i];
-#pragma unroll
-    for (int c = 1; c < GCH; ++c) {
-      const float4 v = reinterpret_cast<const float4*>(part)[((size_t)b * GCH + c) * per_b4 + i];
+    float4 a = reinterpret_cast<const float4*>(part)[((size_t)b * gch) * per_b4 + i];
+    for (int c = 1; c < gch; ++c) {
+      const float4 v = reinterpret_cast<const float4*>(part)[((size_t)b * gch + c) * per_b4 + i];
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     reinterpret_cast<float4*>(dtext)[(size_t)b * per_b4 + i] = a;
@@ -801,12 +800,15 @@ extern "C" int gridmm_grid_aggregate_bwd_routed(const void* slab, const int32_t*
         raised = true;
       }
     }
-    GRIDMM_LAUNCH(agg_bwd_gather2_kernel, dim3(GCH * halves, B), dim3(128), tab_bytes, st, (const _Float16*)slab, perm, cell_start,
-                  amax, dw_ws, part_ws, cap, D, L);
+    // chunks per episode: the pass is a chain of dependent row loads + LDS updates per wave, so deep memories (fine-tune
+    // rollouts: tens of thousands of points per episode) want more, shorter chunks; their tables cost a write + a read each
+    const int gch = cap >= 32768 ? 32 : (cap >= 16384 ? 16 : 8);
+    GRIDMM_LAUNCH(agg_bwd_gather2_kernel, dim3(gch * halves, B), dim3(128), tab_bytes, st, (const _Float16*)slab, perm, cell_start,
+                  amax, dw_ws, part_ws, cap, D, L, gch);
     GRIDMM_CHECK_LAUNCH();
     const size_t per_b4 = (size_t)L * D / 4;
     GRIDMM_LAUNCH(agg_bwd_gsum_kernel, dim3((unsigned)((per_b4 + 255) / 256 > 64 ? 64 : (per_b4 + 255) / 256), B), dim3(256), 0, st,
-                  (const float*)part_ws, dtext, per_b4);
+                  (const float*)part_ws, dtext, per_b4, gch);
     GRIDMM_CHECK_LAUNCH();
     return GRIDMM_OK;
   }
