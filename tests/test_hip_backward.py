@@ -162,7 +162,8 @@ def test_attention_backward_fully_masked_row_batch():
                                           (2, 512, 200, 2), (2, 768, 144, 1),     # L > 128: streamed text fragments
                                           (2, 512, 96, 1), (2, 512, 112, 1), (2, 512, 128, 1), (1, 768, 96, 1),
                                           (2, 768, 128, 1), (2, 256, 70, 1),   # every wave-assignment case (Lt 5..8)
-                                          (2, 512, 80, 12), (1, 768, 64, 5)])    # thousands of points: the chunked gather pass
+                                          (2, 512, 80, 12), (1, 768, 64, 5),     # thousands of points: the chunked gather pass
+                                          (2, 512, 80, 30), (1, 512, 80, 60)])   # deep memories: 16 / 32 chunks per episode
 def test_grid_aggregate_backward(B, D, L, n_obs):
     """d cells / d text_fts against torch autograd of the reference formulation (vilmodel.py:797-807)."""
     from gridmm_amd import autograd as ag, ops
