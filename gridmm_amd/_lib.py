@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
 # overrides and the whole experiment table of tile configurations.  Only the sweep tools ask for it (load(debug=True) or
 # GRIDMM_LIB_DEBUG=1 before the first load); the product path and the tests run on the shipping library, which has neither.
 DEBUG_LIB_PATH = os.path.join(_HERE, "libgridmm_hip_dbg.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -114,6 +114,9 @@ SIGNATURES = {
     "gridmm_preln_layer_train_fwd": [_vp, _vp, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _i, _i, _i, _vp],
     "gridmm_preln_layer_bwd": [_vp, _vp, _vp, _i, _vp, ctypes.c_size_t, _vp, _vp, _vp, _vp, ctypes.c_size_t, _i, _i, _i, _vp],
     "gridmm_dropout_add": [_vp, _vp, _vp, _vp, _vp, _i64, _f, ctypes.c_uint64, _vp, _vp],
+    "gridmm_rowdot": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "gridmm_rowdot_bwd_workspace": [_i, _i],
+    "gridmm_rowdot_bwd": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_linear_skinny": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_linear_skinny_bwd_workspace": [_i, _i, _i],
     "gridmm_linear_skinny_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -176,6 +179,7 @@ def load(debug=None):
     lib.gridmm_preln_layer_saved_bytes.restype = ctypes.c_size_t
     lib.gridmm_preln_layer_workspace.restype = ctypes.c_size_t
     lib.gridmm_linear_skinny_bwd_workspace.restype = ctypes.c_size_t
+    lib.gridmm_rowdot_bwd_workspace.restype = ctypes.c_size_t
     lib.gridmm_nav_heads_workspace.argtypes = [_i, _i, _i]
     lib.gridmm_nav_heads_workspace.restype = ctypes.c_size_t
     v = lib.gridmm_abi_version()

@@ -656,6 +656,44 @@ class _LinearSkinny(torch.autograd.Function):
         return dx, DEFERRED.hand(ctx.prm[0], dw), DEFERRED.hand(ctx.prm[1], db)
 
 
+class _RowDot(torch.autograd.Function):
+    """nn.Linear(K, 1) (the heads' last layer, vilmodel.py:437-446): gridmm_rowdot / gridmm_rowdot_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.set_materialize_grads(False)
+        lib = _lib.load()
+        K = weight.shape[1]
+        x2 = x.float().contiguous().view(-1, K)
+        w = weight.detach().float().contiguous().view(-1)
+        b = None if bias is None else bias.detach().float().contiguous()
+        M = x2.shape[0]
+        y = torch.empty(M, dtype=torch.float32, device=x.device)
+        _lib.check(lib.gridmm_rowdot(_p(x2), K, _p(w), _p(b), _p(y), M, K, _stream()), "gridmm_rowdot")
+        ctx.save_for_backward(x2, w)
+        ctx.prm, ctx.has_bias, ctx.xshape = (weight, bias), bias is not None, tuple(x.shape)
+        return y.view(*x.shape[:-1], 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        lib = _lib.load()
+        x2, w = ctx.saved_tensors
+        M, K = x2.shape
+        dy2 = dy.contiguous().view(M)
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx = torch.empty(M, K, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(1, K, dtype=torch.float32, device=dy.device) if need_w else None
+        db = torch.empty(1, dtype=torch.float32, device=dy.device) if (need_w and ctx.has_bias) else None
+        ws = torch.empty(int(lib.gridmm_rowdot_bwd_workspace(M, K)), dtype=torch.uint8, device=dy.device)
+        _lib.check(lib.gridmm_rowdot_bwd(_p(dy2), _p(x2), K, _p(w), _p(dx), K, _p(dw), _p(db), _p(ws), M, K, _stream()),
+                   "gridmm_rowdot_bwd")
+        if dw is not None:
+            dw = dw.to(ctx.prm[0].dtype)
+        return (None if dx is None else dx.view(ctx.xshape)), DEFERRED.hand(ctx.prm[0], dw), DEFERRED.hand(ctx.prm[1], db)
+
+
 def linear(x, weight, bias=None, residual=None, out_planes=False):
     """x (..., K) @ weight (N, K)^T + bias (+ residual).  out_planes: the GEMM epilogue also writes the bf16 hi/lo planes of
     the result and hangs them on the returned tensor (q / k / v projections: the attention kernels take planes).  True: plain
@@ -664,6 +702,9 @@ def linear(x, weight, bias=None, residual=None, out_planes=False):
     if SKINNY_LINEAR and weight.shape[1] <= 16 and weight.shape[0] % 4 == 0 and residual is None and not out_planes and x.is_cuda \
             and weight.dtype == torch.float32:
         return _LinearSkinny.apply(x, weight, bias)
+    if SKINNY_LINEAR and weight.shape[0] == 1 and weight.shape[1] % 4 == 0 and residual is None and not out_planes and x.is_cuda \
+            and weight.dtype == torch.float32:
+        return _RowDot.apply(x, weight, bias)
     return _Linear.apply(x, weight, bias, residual, WEIGHTS.getter(weight), out_planes)
 
 

@@ -225,7 +225,75 @@ __global__ void linear_skinny_bwd_reduce_kernel(const float* __restrict__ part, 
   else if (db) db[n] = s;
 }
 
+// ---- Linear layers with ONE output feature (the last Linear of the navigation heads' ClsPrediction, H -> 1;
+// map_nav_src/models/vilmodel.py:437-446): a dot product per row.  Forward: a wave per row.  Backward: dX[m][:] = dY[m] w,
+// dw = sum_m dY[m] X[m][:], db = sum_m dY[m] -- a workgroup per 64 rows writes one partial (K + 1 floats, the layout of
+// linear_skinny_bwd_reduce_kernel with N = 1), summed in block order.
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ Y, int M, int K) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float s = 0.f;
+  for (int c = lane * 4; c < K; c += 256) {
+    const float4 x = *reinterpret_cast<const float4*>(X + (size_t)row * ldx + c);
+    const float4 v = *reinterpret_cast<const float4*>(w + c);
+    s += (x.x * v.x + x.y * v.y) + (x.z * v.z + x.w * v.w);
+  }
+  s = wave_sum(s);
+  if (lane == 0) Y[row] = s + (bias ? bias[0] : 0.f);
+}
+constexpr int RD_ROWS = 64;
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ X, int ldx,
+                                                         const float* __restrict__ w, float* __restrict__ dX, int lddx,
+                                                         float* __restrict__ part, int M, int K) {
+  const int m0 = blockIdx.x * RD_ROWS, rows = min(RD_ROWS, M - m0);
+  float* p = part + (size_t)blockIdx.x * (K + 1);
+  for (int c = threadIdx.x * 4; c < K; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(w + c);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < rows; ++r) {
+      const float d = dY[m0 + r];
+      const float4 x = *reinterpret_cast<const float4*>(X + (size_t)(m0 + r) * ldx + c);
+      a.x = fmaf(d, x.x, a.x); a.y = fmaf(d, x.y, a.y); a.z = fmaf(d, x.z, a.z); a.w = fmaf(d, x.w, a.w);
+      if (dX) *reinterpret_cast<float4*>(dX + (size_t)(m0 + r) * lddx + c) = make_float4(d * v.x, d * v.y, d * v.z, d * v.w);
+    }
+    p[c] = a.x; p[c + 1] = a.y; p[c + 2] = a.z; p[c + 3] = a.w;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += dY[m0 + r];
+    p[K] = s;
+  }
+}
+
 }  // namespace
+
+extern "C" int gridmm_rowdot(const float* X, int ldx, const float* w, const float* bias, float* Y, int M, int K,
+                             gridmm_stream_t stream) {
+  if (!X || !w || !Y || M <= 0 || K <= 0 || K % 4 || ldx < K || ldx % 4) return GRIDMM_EINVAL;
+  GRIDMM_LAUNCH(rowdot_kernel, dim3((M + 3) / 4), dim3(256), 0, as_stream(stream), X, ldx, w, bias, Y, M, K);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" size_t gridmm_rowdot_bwd_workspace(int M, int K) {
+  return (size_t)((M + RD_ROWS - 1) / RD_ROWS) * (K + 1) * sizeof(float);
+}
+
+extern "C" int gridmm_rowdot_bwd(const float* dY, const float* X, int ldx, const float* w, float* dX, int lddx, float* dw,
+                                 float* db, float* workspace, int M, int K, gridmm_stream_t stream) {
+  if (!dY || !X || !w || !workspace || M <= 0 || K <= 0 || K % 4 || ldx < K || ldx % 4 || (dX && (lddx < K || lddx % 4)))
+    return GRIDMM_EINVAL;
+  const int n_blk = (M + RD_ROWS - 1) / RD_ROWS;
+  hipStream_t st = as_stream(stream);
+  GRIDMM_LAUNCH(rowdot_bwd_kernel, dim3(n_blk), dim3(256), 0, st, dY, X, ldx, w, dX, lddx, workspace, M, K);
+  GRIDMM_CHECK_LAUNCH();
+  if (dw || db) {
+    GRIDMM_LAUNCH(linear_skinny_bwd_reduce_kernel, dim3((K + 1 + 255) / 256), dim3(256), 0, st, workspace, dw, db, n_blk, 1, K);
+    GRIDMM_CHECK_LAUNCH();
+  }
+  return GRIDMM_OK;
+}
 
 extern "C" int gridmm_linear_skinny(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N,
                                     int K, gridmm_stream_t stream) {

@@ -657,6 +657,15 @@ size_t gridmm_linear_skinny_bwd_workspace(int M, int N, int K);
 int gridmm_linear_skinny_bwd(const float* dY, int ldy, const float* X, int ldx, float* dW, float* db, float* workspace, int M,
                              int N, int K, gridmm_stream_t stream);
 
+/* Linear layers with ONE output feature on the differentiable path (the last Linear of the heads' ClsPrediction, H -> 1;
+ * map_nav_src/models/vilmodel.py:437-446): Y [M] = X [M][K] w + bias[0] (K % 4 == 0), and its backward dX [M][K] = dY[m] w (NULL:
+ * skipped), dw [K] = sum_m dY[m] X[m][:], db [1] = sum_m dY[m] (one partial per 64 rows in `workspace`,
+ * gridmm_rowdot_bwd_workspace bytes, summed in order). */
+int gridmm_rowdot(const float* X, int ldx, const float* w, const float* bias, float* Y, int M, int K, gridmm_stream_t stream);
+size_t gridmm_rowdot_bwd_workspace(int M, int K);
+int gridmm_rowdot_bwd(const float* dY, const float* X, int ldx, const float* w, float* dX, int lddx, float* dw, float* db,
+                      float* workspace, int M, int K, gridmm_stream_t stream);
+
 /* Gradient accumulation of a multi-step backward as ONE launch (fine-tuning: one backward through the 7 .. 15 navigation
  * steps of a rollout, map_nav_src/r2r/agent_base.py:190-199 -- under torch autograd every step's gradient of every parameter
  * is added by its own launch).  desc: device array of n_tensors records {float* dst; const float* src[7]; int64 n;

@@ -254,3 +254,32 @@ def test_skinny_linear_matches_fp64(M, N, K):
     dwr, dbr = dy.double().t() @ x.double(), dy.double().sum(0)
     assert float((dw.double() - dwr).abs().max()) <= 2e-5 * max(1.0, float(dwr.abs().max()))
     assert float((db.double() - dbr).abs().max()) <= 2e-5 * max(1.0, float(dbr.abs().max()))
+
+
+@pytest.mark.parametrize("M,K", [(1824, 768), (57, 768), (1, 64), (130, 256)])
+def test_rowdot_linear_matches_fp64(M, K):
+    """gridmm_rowdot / _bwd (nn.Linear(K, 1): the last layer of the heads' ClsPrediction, vilmodel.py:437-446) vs fp64:
+    forward, dX, dw, db; two runs bit-identical."""
+    import torch
+    from gridmm_amd import autograd as ag
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_()
+    w = torch.nn.Parameter((torch.randn(1, K, generator=g) * 0.3).to(dev))
+    b = torch.nn.Parameter(torch.randn(1, generator=g).to(dev))
+    dy = torch.randn(M, 1, generator=g).to(dev)
+    outs = []
+    for _ in range(2):
+        w.grad = b.grad = x.grad = None
+        y = ag.linear(x, w, b)
+        assert y.shape == (M, 1)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()))
+    assert all(torch.equal(a, c) for a, c in zip(outs[0], outs[1]))
+    y, dx, dw, db = outs[0]
+    xd, wd = x.detach().double(), w.detach().double()
+    assert float((y.double() - (xd @ wd.t() + b.detach().double())).abs().max()) <= 1e-4
+    assert float((dx.double() - dy.double() @ wd).abs().max()) <= 1e-5
+    assert float((dw.double() - dy.double().t() @ xd).abs().max()) <= 2e-5 * max(1.0, float((dy.double().t() @ xd).abs().max()))
+    assert float((db.double() - dy.double().sum()).abs().max()) <= 1e-4
