@@ -56,7 +56,7 @@ SIGNATURES = {
     "gridmm_attention_rows_seg": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _i,
                                   _vp, _i, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f, _vp],
     "gridmm_linear_planes_tn": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
-    "gridmm_linear_planes_tn_db": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp],
+    "gridmm_linear_planes_tn_db": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gridmm_linear_planes_tn_grouped": [_vp, _i, _vp],
     "gridmm_linear_planes_tn_splits": [_i, _i, _i],
     "gridmm_split_rows_pad": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp],

@@ -424,21 +424,22 @@ def split_rows_pad(x2d, want_colsum=False, defer_colsum=False):
     return hi, lo, (cs_ws if want_colsum and defer_colsum else cs), Mp, ops.Act(x2d, hi[:M], lo[:M])
 
 
-def _gemm_tn_rows(yp, xp, N, K, M, colpart=None):
+def _gemm_tn_rows(yp, xp, N, K, M, want_db=False):
     """dW (N,K) = dY^T X from the ROW planes yp = (hi, lo) (>= M rows, N) of dY and xp (>= M rows, K) of X.
-    colpart: the (n_part, N) column-sum partials of dY (split_rows_pad(defer_colsum=True)) -> also returns db (N,)."""
+    want_db: also db (N,) = the column sums of dY, computed by the GEMM itself from the planes (gridmm_linear_planes_tn_db)."""
     lib = _lib.load()
     splits = 1 if SPLITK_OFF else lib.gridmm_linear_planes_tn_splits(M, N, K)
     dev = yp[0].device
     dw = torch.empty(N, K, dtype=torch.float32, device=dev)
     ws = torch.empty(splits, N, K, dtype=torch.float32, device=dev) if splits > 1 else None
-    if colpart is None:
+    if not want_db:
         _lib.check(lib.gridmm_linear_planes_tn(_p(yp[0]), _p(yp[1]), N, _p(xp[0]), _p(xp[1]), K, _p(dw), _p(ws), M, N, K, splits,
                                                _stream()), "gridmm_linear_planes_tn")
         return dw
     db = torch.empty(N, dtype=torch.float32, device=dev)
+    db_ws = torch.empty(splits, N, dtype=torch.float32, device=dev)
     _lib.check(lib.gridmm_linear_planes_tn_db(_p(yp[0]), _p(yp[1]), N, _p(xp[0]), _p(xp[1]), K, _p(dw), _p(ws), M, N, K, splits,
-                                              _p(colpart), colpart.shape[0], _p(db), _stream()), "gridmm_linear_planes_tn_db")
+                                              _p(db_ws), _p(db), _stream()), "gridmm_linear_planes_tn_db")
     return dw, db
 
 
@@ -533,13 +534,13 @@ def _linear_bwd(ctx, dy, need_x, need_w):
     dx = dw = db = None
     yh = yl = rows = None
     if need_w and ctx.tn:
-        yh, yl, db, Mp, rows = split_rows_pad(dy2, want_colsum=ctx.has_bias, defer_colsum=True)
+        yh, yl, db, Mp, rows = split_rows_pad(dy2)          # (db: by the weight-gradient GEMM, from these planes)
     elif need_w:
         yh, yl, db, Mp, rows = transpose_split(dy2, want_colsum=ctx.has_bias, want_rows=need_x)
     if need_x:
         dx = _gemm(rows if rows is not None else dy2, ctx.packs(True)).view(*dy.shape[:-1], K)
     if need_w and ctx.tn and ctx.has_bias:      # db: reduced from the split pass's partials by the dW summing pass
-        dw, db = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, M, colpart=db)
+        dw, db = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, M, want_db=True)
     elif need_w and ctx.tn:
         dw = _gemm_tn_rows((yh, yl), (ctx.saved_tensors[0], ctx.saved_tensors[1]), N, K, M)
     elif need_w:

@@ -110,7 +110,7 @@ size_t tn_area_bytes(int M, const int* N, const int* K, int n) {
   size_t b = 0;
   for (int i = 0; i < n; ++i) {
     const int splits = gridmm_linear_planes_tn_splits(M, N[i], K[i]);
-    b += a256((size_t)N[i] * Mp * 4) + a256(((Mp + 255) / 256) * (size_t)N[i] * 4);
+    b += a256((size_t)N[i] * Mp * 4) + a256((size_t)8 * N[i] * 4);
     if (splits > 1) b += a256((size_t)splits * N[i] * K[i] * 4);
   }
   return b;
@@ -122,25 +122,33 @@ int tn_flush(TnBatch& tb, gridmm_stream_t st) {
   return rc;
 }
 
+// The dY-plane region of the NEXT Linear backward of the layer (hi [Mp][N] then lo), handed out ahead of time so that the
+// kernel that PRODUCES dY (LayerNorm backward, GELU backward, the dropout pass) writes the planes itself and the Linear's
+// own split pass is skipped (pass the pointer back to linear_bwd as yP_ready).
+unsigned short* reserve_y(TnBatch& tb, int N, int M) { return (unsigned short*)tb.take((size_t)N * mp32(M) * 4); }
+
 int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned short* xP, const float* Radd, float* dX,
-               float* dW, float* db, int M, const LinWs& ws, gridmm_stream_t st, TnBatch* tb = nullptr) {
+               float* dW, float* db, int M, const LinWs& ws, gridmm_stream_t st, TnBatch* tb = nullptr,
+               unsigned short* yP_ready = nullptr) {
   const int N = l.N, K = l.K, Mp = mp32(M);
   const bool defer = tb && dW;
   const int splits = dW ? gridmm_linear_planes_tn_splits(M, N, K) : 1;   // <= 8: ws.splitk holds 8 partial tiles
-  unsigned short* yh = ws.yT;
-  float *cs_ws = ws.cs_ws, *splitk = ws.splitk;
+  unsigned short* yh = yP_ready ? yP_ready : ws.yT;
+  float *db_ws = ws.cs_ws, *splitk = ws.splitk;
   if (defer) {
     if (tb->n >= 8) return GRIDMM_EINVAL;
-    yh = (unsigned short*)tb->take((size_t)N * Mp * 4);
-    cs_ws = (float*)tb->take(((size_t)(Mp + 255) / 256) * N * 4);
+    if (!yP_ready) yh = (unsigned short*)tb->take((size_t)N * Mp * 4);
+    db_ws = db ? (float*)tb->take((size_t)splits * N * 4) : nullptr;
     splitk = splits > 1 ? (float*)tb->take((size_t)splits * N * K * 4) : nullptr;
-    if (!yh || !cs_ws || (splits > 1 && !splitk)) return GRIDMM_EINVAL;
+    if (!yh || (db && !db_ws) || (splits > 1 && !splitk)) return GRIDMM_EINVAL;
   }
   unsigned short* yl = yh + (size_t)N * Mp;
-  // db: the split pass leaves one column-sum partial per 256 rows; the weight gradient's summing pass reduces them
-  // (gridmm_linear_planes_tn_db) -- no reduction launch of its own unless there is no weight gradient
+  // db: with a weight gradient the TN GEMM computes the column sums of dY from the planes itself (gridmm_linear_planes_tn_db);
+  // without one the split pass does (its own reduction launch)
   const bool fold = db && dW;
-  int rc = gridmm_split_rows_pad(dY, N, yh, yl, N, fold ? nullptr : db, db ? cs_ws : nullptr, M, N, Mp, st);
+  int rc = GRIDMM_OK;
+  if (!yP_ready) rc = gridmm_split_rows_pad(dY, N, yh, yl, N, fold ? nullptr : db, (db && !fold) ? ws.cs_ws : nullptr, M, N, Mp, st);
+  else if (db && !fold) return GRIDMM_EINVAL;
   if (rc != GRIDMM_OK) return rc;
   if (dX) {
     if (!l.wt_hi || !l.wt_lo || l.Np < N) return GRIDMM_EINVAL;
@@ -153,10 +161,10 @@ int linear_bwd(const gridmm_linear_train_t& l, const float* dY, const unsigned s
     q.A_hi = yh; q.A_lo = yl; q.lda = N;
     q.B_hi = xP; q.B_lo = xP + (size_t)K * Mp; q.ldb = K;
     q.C = dW; q.workspace = splitk; q.M = M; q.N = N; q.K = K; q.splits = splits;
-    q.colsum_ws = fold ? cs_ws : nullptr; q.n_part = (Mp + 255) / 256; q.db = fold ? db : nullptr;
+    q.db_ws = fold ? db_ws : nullptr; q.db = fold ? db : nullptr;
   } else if (dW) {
-    rc = gridmm_linear_planes_tn_db(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, splitk, M, N, K, splits,
-                                    fold ? cs_ws : nullptr, (Mp + 255) / 256, fold ? db : nullptr, st);
+    rc = gridmm_linear_planes_tn_db(yh, yl, N, xP, xP + (size_t)K * Mp, K, dW, splitk, M, N, K, splits, fold ? db_ws : nullptr,
+                                    fold ? db : nullptr, st);
   }
   return rc;
 }

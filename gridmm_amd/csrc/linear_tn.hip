@@ -49,7 +49,7 @@ template <int BM, int BN, int WM, int WN, int NS>
 __device__ __forceinline__ void linear_planes_tn_tile(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int ldb, float* __restrict__ C, int ldc,
-    int M, int N, int K, const int tile, const int split, const int nsplits) {
+    int M, int N, int K, const int tile, const int split, const int nsplits, float* __restrict__ dbw = nullptr) {
   constexpr int WAVES_N = BN / WN, NW = (BM / WM) * WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int PA = BM / 64, PB = BN / 64;                 // panels per plane
@@ -97,6 +97,15 @@ __device__ __forceinline__ void linear_planes_tn_tile(
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  // dbw != NULL: also the column sums of A over this contraction range (the bias gradient of the Linear whose weight gradient
+  // this is: db[n] = sum_m dY[m][n]) -- by the waves of the FIRST tile column that own distinct A columns, as two more MFMAs per
+  // A tile and k-step with an all-ones first operand: every row of that product is sum_m A[m][c]; from the hi and lo planes
+  // (their sum is dY to 2^-17 relative), fp32 accumulate.  One partial row per contraction range, summed by the summing pass.
+  const bool do_db = dbw != nullptr && tx == 0 && wc == 0;
+  f32x4_t accd[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) accd[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
   int nk = nk_all, k0 = 0;
   if (nsplits > 1) {
     const int per = (nk + nsplits - 1) / nsplits;
@@ -190,6 +199,20 @@ __device__ __forceinline__ void linear_planes_tn_tile(
         acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[jj], ah[i], acc[i][jj], 0, 0, 0);
         acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[jj], ah[i], acc[i][jj], 0, 0, 0);
       }
+    if (do_db) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        accd[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, al[i], accd[i], 0, 0, 0);
+        accd[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, ah[i], accd[i], 0, 0, 0);
+      }
+    }
+  }
+  if (do_db && (lane >> 4) == 0) {            // lane c of the first 16 holds (row 0 of) the column sum of A column 16 i + c
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = bm + wr * WM + i * 16 + (lane & 15);
+      if (m < N) dbw[(size_t)split * N + m] = accd[i][0];
+    }
   }
   // ---- epilogue straight from the accumulators: lane (m = lane & 15, g) holds C[row m][cols 4g .. 4g+3] of every tile
   const int mrow = lane & 15, g4 = (lane >> 4) * 4;
@@ -211,9 +234,9 @@ template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo, int ldb, float* __restrict__ C, int ldc,
-    int M, int N, int K) {
+    int M, int N, int K, float* __restrict__ dbw) {
   linear_planes_tn_tile<BM, BN, WM, WN, NS>(Ahi, Alo, lda, Bhi, Blo, ldb, C, ldc, M, N, K, (int)blockIdx.x, (int)blockIdx.y,
-                                            (int)gridDim.y);
+                                            (int)gridDim.y, dbw);
 }
 
 // Several weight gradients in ONE launch (the six of a cross-modal layer's backward, the four of a BertLayer's): problem p
@@ -223,6 +246,7 @@ constexpr int TN_GROUP_MAX = 8;
 struct TnProb {
   const unsigned short *Ahi, *Alo, *Bhi, *Blo;
   float* out;                    // C, or the split-K workspace
+  float* dbw;                    // bias-gradient partials (nsplits x N), or NULL
   int lda, ldb, M, N, K, nsplits, tiles;
 };
 struct TnGroup {
@@ -237,7 +261,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_tn_g
   const TnProb& pr = g.p[q];
   const int local = (int)blockIdx.x - g.first[q];
   linear_planes_tn_tile<BM, BN, WM, WN, NS>(pr.Ahi, pr.Alo, pr.lda, pr.Bhi, pr.Blo, pr.ldb, pr.out, pr.K, pr.M, pr.N, pr.K,
-                                            local % pr.tiles, local / pr.tiles, pr.nsplits);
+                                            local % pr.tiles, local / pr.tiles, pr.nsplits, pr.dbw);
 }
 
 // Second stages of a group (see sum_splits_tn_kernel): problem p owns the blocks [first[p], first[p + 1]).
@@ -301,9 +325,9 @@ __global__ void sum_splits_tn_kernel(const float* __restrict__ ws, float* __rest
 
 template <int BM, int BN, int NS>
 int launch_tn(const unsigned short* ah, const unsigned short* al, int lda, const unsigned short* bh, const unsigned short* bl,
-              int ldb, float* C, int M, int N, int K, int splits, hipStream_t st) {
+              int ldb, float* C, int M, int N, int K, int splits, hipStream_t st, float* dbw = nullptr) {
   dim3 grid(((N + BM - 1) / BM) * ((K + BN - 1) / BN), splits), block((BM / 32) * (BN / 32) * 64);
-  GRIDMM_LAUNCH((linear_planes_tn_kernel<BM, BN, 32, 32, NS>), grid, block, 0, st, ah, al, lda, bh, bl, ldb, C, K, M, N, K);
+  GRIDMM_LAUNCH((linear_planes_tn_kernel<BM, BN, 32, 32, NS>), grid, block, 0, st, ah, al, lda, bh, bl, ldb, C, K, M, N, K, dbw);
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
 }
@@ -322,29 +346,31 @@ extern "C" int gridmm_linear_planes_tn_splits(int M, int N, int K) {
 
 // C (N x K fp32, contiguous) = A^T B over the M rows of A (M x >= N) and B (M x >= K); splits > 1: the contraction is
 // cut into `splits` ranges whose partial results go to `workspace` (splits x N x K floats) and are summed in order.
-// colsum_ws != NULL: also db (N floats) = the n_part x N column-sum partials of A's fp32 source summed in order (the bias
-// gradient of the Linear whose weight gradient this is), by the summing pass when there is one.
+// db != NULL: also db (N floats) = the column sums of A (the bias gradient of the Linear whose weight gradient this is),
+// computed by the GEMM itself from the planes (one partial row per range in db_ws, splits x N floats) and summed, in range
+// order, by the summing pass.
 static int linear_planes_tn_impl(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
-                                 float* C, float* workspace, int M, int N, int K, int splits, const float* colsum_ws,
-                                 int n_part, float* db, gridmm_stream_t stream) {
+                                 float* C, float* workspace, int M, int N, int K, int splits, float* db_ws, float* db,
+                                 gridmm_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 4 || lda % 8 || ldb % 8 || lda < 8 || ldb < 8 || !C || splits < 1 ||
-      splits > 64 || (splits > 1 && (!workspace || (M + 31) / 32 < splits)) || (colsum_ws && (!db || n_part < 1)))
+      splits > 64 || (splits > 1 && (!workspace || (M + 31) / 32 < splits)) || (db && !db_ws))
     return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
   const unsigned short *ah = (const unsigned short*)A_hi, *al = (const unsigned short*)A_lo;
   const unsigned short *bh = (const unsigned short*)B_hi, *bl = (const unsigned short*)B_lo;
   float* out = splits > 1 ? workspace : C;
+  float* dbw = db ? db_ws : nullptr;
   const long t128 = (long)((N + 127) / 128) * ((K + 127) / 128) * splits;
   int rc;
-  if (t128 >= 100 && N >= 128 && K >= 128) rc = launch_tn<128, 128, 2>(ah, al, lda, bh, bl, ldb, out, M, N, K, splits, st);
-  else rc = launch_tn<64, 64, 3>(ah, al, lda, bh, bl, ldb, out, M, N, K, splits, st);
+  if (t128 >= 100 && N >= 128 && K >= 128) rc = launch_tn<128, 128, 2>(ah, al, lda, bh, bl, ldb, out, M, N, K, splits, st, dbw);
+  else rc = launch_tn<64, 64, 3>(ah, al, lda, bh, bl, ldb, out, M, N, K, splits, st, dbw);
   if (rc != GRIDMM_OK) return rc;
-  if (splits > 1 || colsum_ws) {
+  if (splits > 1 || db) {
     const size_t n4 = (size_t)N * K / 4;
     const int sum_blocks = splits > 1 ? (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256) : 0;
-    const int db_blocks = colsum_ws ? (N + 255) / 256 : 0;
+    const int db_blocks = db ? (N + 255) / 256 : 0;
     GRIDMM_LAUNCH(sum_splits_tn_kernel, dim3((unsigned)(sum_blocks + db_blocks)), dim3(256), 0, st, workspace, C, n4, splits,
-                  sum_blocks, colsum_ws, db, n_part, N);
+                  sum_blocks, dbw, db, splits, N);
     GRIDMM_CHECK_LAUNCH();
   }
   return GRIDMM_OK;
@@ -353,13 +379,13 @@ static int linear_planes_tn_impl(const void* A_hi, const void* A_lo, int lda, co
 extern "C" int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo,
                                        int ldb, float* C, float* workspace, int M, int N, int K, int splits,
                                        gridmm_stream_t stream) {
-  return linear_planes_tn_impl(A_hi, A_lo, lda, B_hi, B_lo, ldb, C, workspace, M, N, K, splits, nullptr, 0, nullptr, stream);
+  return linear_planes_tn_impl(A_hi, A_lo, lda, B_hi, B_lo, ldb, C, workspace, M, N, K, splits, nullptr, nullptr, stream);
 }
 
 extern "C" int gridmm_linear_planes_tn_db(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo,
                                           int ldb, float* C, float* workspace, int M, int N, int K, int splits,
-                                          const float* colsum_ws, int n_part, float* db, gridmm_stream_t stream) {
-  return linear_planes_tn_impl(A_hi, A_lo, lda, B_hi, B_lo, ldb, C, workspace, M, N, K, splits, colsum_ws, n_part, db, stream);
+                                          float* db_ws, float* db, gridmm_stream_t stream) {
+  return linear_planes_tn_impl(A_hi, A_lo, lda, B_hi, B_lo, ldb, C, workspace, M, N, K, splits, db_ws, db, stream);
 }
 
 // n <= 8 weight gradients (+ their bias gradients) as at most two GEMM launches (one per tile class) and one summing launch:
@@ -374,7 +400,7 @@ extern "C" int gridmm_linear_planes_tn_grouped(const gridmm_tn_problem_t* probs,
   for (int i = 0; i < n; ++i) {
     const gridmm_tn_problem_t& q = probs[i];
     if (q.M <= 0 || q.N <= 0 || q.K <= 0 || q.K % 4 || q.lda % 8 || q.ldb % 8 || q.lda < 8 || q.ldb < 8 || !q.C || q.splits < 1 ||
-        q.splits > 64 || (q.splits > 1 && (!q.workspace || (q.M + 31) / 32 < q.splits)) || (q.colsum_ws && (!q.db || q.n_part < 1)))
+        q.splits > 64 || (q.splits > 1 && (!q.workspace || (q.M + 31) / 32 < q.splits)) || (q.db && !q.db_ws))
       return GRIDMM_EINVAL;
     const long t128 = (long)((q.N + 127) / 128) * ((q.K + 127) / 128) * q.splits;
     const bool use128 = t128 >= 100 && q.N >= 128 && q.K >= 128;              // the plain entry point's rule
@@ -384,17 +410,18 @@ extern "C" int gridmm_linear_planes_tn_grouped(const gridmm_tn_problem_t* probs,
     t.Ahi = (const unsigned short*)q.A_hi; t.Alo = (const unsigned short*)q.A_lo;
     t.Bhi = (const unsigned short*)q.B_hi; t.Blo = (const unsigned short*)q.B_lo;
     t.out = q.splits > 1 ? q.workspace : q.C;
+    t.dbw = q.db ? q.db_ws : nullptr;
     t.lda = q.lda; t.ldb = q.ldb; t.M = q.M; t.N = q.N; t.K = q.K; t.nsplits = q.splits;
     t.tiles = ((q.N + BT - 1) / BT) * ((q.K + BT - 1) / BT);
     g.first[g.n + 1] = g.first[g.n] + t.tiles * q.splits;
     ++g.n;
-    if (q.splits > 1 || q.colsum_ws) {
+    if (q.splits > 1 || q.db) {
       SumProb& sp = sums.p[sums.n];
       sp.n4 = (size_t)q.N * q.K / 4;
       sp.ws = q.workspace; sp.out = q.C; sp.splits = q.splits;
       sp.sum_blocks = q.splits > 1 ? (int)((sp.n4 + 255) / 256 > 2048 ? 2048 : (sp.n4 + 255) / 256) : 0;
-      sp.colpart = q.colsum_ws; sp.db = q.db; sp.n_part = q.n_part; sp.C = q.N;
-      sums.first[sums.n + 1] = sums.first[sums.n] + sp.sum_blocks + (q.colsum_ws ? (q.N + 255) / 256 : 0);
+      sp.colpart = q.db ? q.db_ws : nullptr; sp.db = q.db; sp.n_part = q.splits; sp.C = q.N;
+      sums.first[sums.n + 1] = sums.first[sums.n] + sp.sum_blocks + (q.db ? (q.N + 255) / 256 : 0);
       ++sums.n;
     }
   }

@@ -451,13 +451,14 @@ int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, floa
  * (splits x N x K floats), summed in order (deterministic).  Backward of nn.Linear as above. */
 int gridmm_linear_planes_tn(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
                             float* C, float* workspace, int M, int N, int K, int splits, gridmm_stream_t stream);
-/* The same, plus the bias gradient of that Linear in the summing pass: colsum_ws = the n_part x N column-sum partials that
- * gridmm_split_rows_pad / gridmm_transpose_split leave when called with colsum = NULL and a workspace (n_part =
- * ceil(Mp / 256)); db[n] = their sum over the partials, in order (bit-identical to the split pass's own reduction).
- * colsum_ws = NULL: exactly gridmm_linear_planes_tn. */
+/* The same, plus the bias gradient of that Linear: db [N] = column sums of A (= of dY), computed by the GEMM itself from the
+ * planes (two more MFMAs per A tile and k-step against an all-ones operand; hi + lo = dY to 2^-17 relative, fp32 accumulate) --
+ * one partial row per contraction range in db_ws (>= splits x N floats), summed in range order by the summing pass
+ * (deterministic).  The split pass of dY need not produce column sums, and a producer that emits the planes of its dX
+ * (LayerNorm / GELU backward, dropout) makes the split pass itself unnecessary.  db = NULL: exactly gridmm_linear_planes_tn. */
 int gridmm_linear_planes_tn_db(const void* A_hi, const void* A_lo, int lda, const void* B_hi, const void* B_lo, int ldb,
-                               float* C, float* workspace, int M, int N, int K, int splits, const float* colsum_ws,
-                               int n_part, float* db, gridmm_stream_t stream);
+                               float* C, float* workspace, int M, int N, int K, int splits, float* db_ws, float* db,
+                               gridmm_stream_t stream);
 /* n <= 8 such weight gradients (with their bias gradients) as at most two GEMM launches (one per tile class) + one summing launch
  * -- the six of a cross-modal layer's backward, the four of a BertLayer's: each member exactly as gridmm_linear_planes_tn_db
  * would compute it (same tiles, same ranges, same order of the sums).  probs: HOST array (read during the call). */
@@ -466,7 +467,7 @@ typedef struct {
   const void *B_hi, *B_lo; int ldb;
   float *C, *workspace;
   int M, N, K, splits;
-  const float* colsum_ws; int n_part; float* db;
+  float *db_ws, *db;
 } gridmm_tn_problem_t;
 int gridmm_linear_planes_tn_grouped(const gridmm_tn_problem_t* probs, int n, gridmm_stream_t stream);
 /* the number of ranges (1 .. 8) that fills the chip for this problem: what the library's own callers pass as `splits` */

@@ -94,23 +94,25 @@ def test_linear_backward_through_the_tn_path_matches_torch(dev):
         assert float((a.double() - r).abs().max()) <= 3e-5 * max(1.0, float(r.abs().max()))
 
 
-@pytest.mark.parametrize("M,N,K", [(1824, 768, 768), (6912, 3072, 768), (57, 64, 64), (300, 2304, 768), (33, 8, 40)])
-def test_bias_gradient_from_the_summing_pass_is_bit_identical(dev, M, N, K):
-    """gridmm_linear_planes_tn_db: db reduced from the split pass's per-256-row partials inside the weight gradient's summing
-    pass (or by that pass alone when the contraction is not split) == the split pass's own reduction, bit for bit; dW is
-    untouched by the extra workgroups."""
+@pytest.mark.parametrize("M,N,K", [(1824, 768, 768), (6912, 3072, 768), (57, 64, 64), (300, 2304, 768), (33, 8, 40),
+                                   (1000, 1000, 768), (100, 768, 3072)])
+def test_bias_gradient_from_the_weight_gradient_gemm(dev, M, N, K):
+    """gridmm_linear_planes_tn_db: db = the column sums of dY computed by the GEMM itself from the planes (all-ones operand, one
+    partial per contraction range, summed in order) vs fp64; dW is untouched by the extra MFMAs (bit-identical to the plain
+    call); two runs bit-identical."""
     from gridmm_amd import autograd as ag
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).to(dev)
-    dy = (torch.randn(M, N, generator=g) * 0.1).to(dev)
+    dy = (torch.randn(M, N, generator=g) * 0.1 + 0.05).to(dev)
     xh, xl, _, _, _ = ag.split_rows_pad(x)
-    yh, yl, db_ref, _, _ = ag.split_rows_pad(dy, want_colsum=True)
-    yh2, yl2, part, _, _ = ag.split_rows_pad(dy, want_colsum=True, defer_colsum=True)
-    assert part.shape == (((M + 31) // 32 * 32 + 255) // 256, N)
+    yh, yl, _, _, _ = ag.split_rows_pad(dy)
     dw_ref = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M)
-    dw, db = ag._gemm_tn_rows((yh2, yl2), (xh, xl), N, K, M, colpart=part)
+    dw, db = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M, want_db=True)
+    dw2, db2 = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M, want_db=True)
     torch.cuda.synchronize()
-    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    assert torch.equal(dw, dw_ref) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    ref = dy.double().sum(0)
+    assert float((db.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_grouped_weight_gradients_equal_the_single_launches_bitwise(dev):
@@ -125,7 +127,7 @@ def test_grouped_weight_gradients_equal_the_single_launches_bitwise(dev):
                     ("B_hi", ctypes.c_void_p), ("B_lo", ctypes.c_void_p), ("ldb", ctypes.c_int),
                     ("C", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
                     ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("splits", ctypes.c_int),
-                    ("colsum_ws", ctypes.c_void_p), ("n_part", ctypes.c_int), ("db", ctypes.c_void_p)]
+                    ("db_ws", ctypes.c_void_p), ("db", ctypes.c_void_p)]
     lib = ag._lib.load()
     M = 1824
     shapes = [(768, 768, True), (2304, 768, True), (768, 3072, False), (3072, 768, True), (64, 64, True), (8, 40, False)]
@@ -135,19 +137,20 @@ def test_grouped_weight_gradients_equal_the_single_launches_bitwise(dev):
         x = torch.randn(M, K, generator=g).to(dev)
         dy = (torch.randn(M, N, generator=g) * 0.1).to(dev)
         xh, xl, _, Mp, _ = ag.split_rows_pad(x)
-        yh, yl, part, _, _ = ag.split_rows_pad(dy, want_colsum=True, defer_colsum=True)
+        yh, yl, _, _, _ = ag.split_rows_pad(dy)
         if bias:
-            dw_ref, db_ref = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M, colpart=part)
+            dw_ref, db_ref = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M, want_db=True)
         else:
             dw_ref, db_ref = ag._gemm_tn_rows((yh, yl), (xh, xl), N, K, M), None
         splits = lib.gridmm_linear_planes_tn_splits(M, N, K)
         dw = torch.full((N, K), float("nan"), device=dev)
         db = torch.full((N,), float("nan"), device=dev) if bias else None
         ws = torch.empty(splits, N, K, device=dev) if splits > 1 else None
-        keep += [xh, xl, yh, yl, part, dw, db, ws]
+        dbw = torch.empty(splits, N, device=dev) if bias else None
+        keep += [xh, xl, yh, yl, dbw, dw, db, ws]
         probs[i] = Prob(yh.data_ptr(), yl.data_ptr(), N, xh.data_ptr(), xl.data_ptr(), K, dw.data_ptr(),
                         ws.data_ptr() if ws is not None else None, M, N, K, splits,
-                        part.data_ptr() if bias else None, part.shape[0], db.data_ptr() if bias else None)
+                        dbw.data_ptr() if bias else None, db.data_ptr() if bias else None)
         want.append((dw_ref, db_ref, dw, db))
     ag._lib.check(lib.gridmm_linear_planes_tn_grouped(ctypes.byref(probs), len(shapes), ag._stream()),
                   "gridmm_linear_planes_tn_grouped")
