@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
 # overrides and the whole experiment table of tile configurations.  Only the sweep tools ask for it (load(debug=True) or
 # GRIDMM_LIB_DEBUG=1 before the first load); the product path and the tests run on the shipping library, which has neither.
 DEBUG_LIB_PATH = os.path.join(_HERE, "libgridmm_hip_dbg.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -74,6 +74,7 @@ SIGNATURES = {
     # training (backward)
     "gridmm_transpose_split": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_layernorm_bwd": [_vp, _i, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "gridmm_layernorm_bwd_planes": [_vp, _i, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "gridmm_activation": [_vp, _vp, _vp, _i64, _i, _vp],
     "gridmm_activation_planes": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
     "gridmm_attention_train_planes": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i64, _i,
@@ -97,6 +98,8 @@ SIGNATURES = {
     "gridmm_dropout": [_vp, _vp, _i64, _f, ctypes.c_uint64, _vp, _vp],
     "gridmm_layernorm_dropout": [_vp, _vp, _i, _vp, _vp, _f, _vp, _f, ctypes.c_uint64, _vp, _i, _i, _vp],
     "gridmm_layernorm_dropout_bwd": [_vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, ctypes.c_uint64, _vp, _i, _i, _vp],
+    "gridmm_layernorm_dropout_bwd_planes": [_vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, ctypes.c_uint64, _vp, _i,
+                                            _i, _vp],
     "gridmm_grad_sumsq": [_vp, _i64, _i, _vp, _vp],
     "gridmm_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _vp, _vp],
     "gridmm_linear_planes_splitk": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ X, int ldx, const float* __restrict__ R, int ldr, const float* __restrict__ gamma,
     float eps, const float* __restrict__ dY, int ldy, float* __restrict__ dX, int lddx, float* __restrict__ part,
     int M, int H, float* __restrict__ dR = nullptr, int lddr = 0, float drop_p = 0.f, unsigned long long seed = 0,
-    const unsigned long long* __restrict__ seed_dev = nullptr) {
+    const unsigned long long* __restrict__ seed_dev = nullptr, unsigned short* __restrict__ Ph = nullptr,
+    unsigned short* __restrict__ Pl = nullptr) {
   __shared__ float s_g[4][MAX_H_BWD];
   __shared__ float s_b[4][MAX_H_BWD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -183,6 +184,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
           o.w = dropout_keep(seed, e + 3, drop_p) ? o.w * scale : 0.f;
         }
         reinterpret_cast<float4*>(dX + (size_t)row * lddx)[c] = o;
+        if (Ph) {          // the bf16 planes of dX (contiguous rows of H): the dY operand of the Linear in front of this LayerNorm
+          uint2 hi, lo;
+          split2_bf16(o.x, o.y, hi.x, lo.x);
+          split2_bf16(o.z, o.w, hi.y, lo.y);
+          reinterpret_cast<uint2*>(Ph + (size_t)row * H)[c] = hi;
+          reinterpret_cast<uint2*>(Pl + (size_t)row * H)[c] = lo;
+        }
       }
       // per-wave contributions to dgamma (dy * xhat) and dbeta (dy)
       reinterpret_cast<float4*>(s_g[wave])[c] = live ? make_float4(dv[i].x * xv[i].x, dv[i].y * xv[i].y, dv[i].z * xv[i].z, dv[i].w * xv[i].w)
@@ -294,12 +302,13 @@ extern "C" int gridmm_split_rows_pad(const float* X, int ldx, void* R_hi, void* 
   return GRIDMM_OK;
 }
 
-extern "C" int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int ldr, const float* gamma, float eps,
-                                            const float* dY, float* dX, float* dR, float* dgamma, float* dbeta,
-                                            float* workspace, float p, unsigned long long seed,
-                                            const unsigned long long* seed_dev, int M, int H, gridmm_stream_t stream) {
+extern "C" int gridmm_layernorm_dropout_bwd_planes(const float* X, const float* R, int ldr, const float* gamma, float eps,
+                                                   const float* dY, float* dX, void* dX_hi, void* dX_lo, float* dR,
+                                                   float* dgamma, float* dbeta, float* workspace, float p,
+                                                   unsigned long long seed, const unsigned long long* seed_dev, int M, int H,
+                                                   gridmm_stream_t stream) {
   if (M <= 0 || H <= 0 || H % 4 || H > MAX_H_BWD || (R && ldr % 4) || !(p >= 0.f && p < 1.f) ||
-      (size_t)M * H >= (1ull << 32))
+      (size_t)M * H >= (1ull << 32) || (dX_hi && !dX_lo))
     return GRIDMM_EINVAL;
   hipStream_t st = as_stream(stream);
   const int nblk = (M + 3) / 4;
@@ -307,9 +316,39 @@ extern "C" int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int 
   const int nv = (H / 4 + 63) / 64;
 #define GRIDMM_LNBD(NV)                                                                                          \
   GRIDMM_LAUNCH((layernorm_bwd_kernel<NV, true>), grid, block, 0, st, X, H, R, ldr, gamma, eps, dY, H, dX, H, workspace, \
-                M, H, dR, H, p, seed, seed_dev)
+                M, H, dR, H, p, seed, seed_dev, (unsigned short*)dX_hi, (unsigned short*)dX_lo)
   if (nv == 1) GRIDMM_LNBD(1); else if (nv == 2) GRIDMM_LNBD(2); else if (nv == 3) GRIDMM_LNBD(3); else GRIDMM_LNBD(4);
 #undef GRIDMM_LNBD
+  GRIDMM_CHECK_LAUNCH();
+  GRIDMM_LAUNCH(ln_param_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, workspace, dgamma, dbeta, nblk, H);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
+extern "C" int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int ldr, const float* gamma, float eps,
+                                            const float* dY, float* dX, float* dR, float* dgamma, float* dbeta,
+                                            float* workspace, float p, unsigned long long seed,
+                                            const unsigned long long* seed_dev, int M, int H, gridmm_stream_t stream) {
+  return gridmm_layernorm_dropout_bwd_planes(X, R, ldr, gamma, eps, dY, dX, nullptr, nullptr, dR, dgamma, dbeta, workspace, p,
+                                             seed, seed_dev, M, H, stream);
+}
+
+extern "C" int gridmm_layernorm_bwd_planes(const float* X, int ldx, const float* R, int ldr, const float* gamma, float eps,
+                                           const float* dY, int ldy, float* dX, int lddx, void* dX_hi, void* dX_lo,
+                                           float* dgamma, float* dbeta, float* workspace, int M, int H,
+                                           gridmm_stream_t stream) {
+  if (M <= 0 || H <= 0 || H % 4 || H > MAX_H_BWD || ldx % 4 || ldy % 4 || lddx % 4 || (R && ldr % 4) || (dX_hi && !dX_lo))
+    return GRIDMM_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nblk = (M + 3) / 4;
+  dim3 grid(nblk), block(256);
+  const int nv = (H / 4 + 63) / 64;
+#define GRIDMM_LNB(NV)                                                                                      \
+  GRIDMM_LAUNCH((layernorm_bwd_kernel<NV>), grid, block, 0, st, X, ldx, R, ldr, gamma, eps, dY, ldy, dX, lddx, \
+                workspace, M, H, (float*)nullptr, 0, 0.f, 0ull, (const unsigned long long*)nullptr, (unsigned short*)dX_hi,  \
+                (unsigned short*)dX_lo)
+  if (nv == 1) GRIDMM_LNB(1); else if (nv == 2) GRIDMM_LNB(2); else if (nv == 3) GRIDMM_LNB(3); else GRIDMM_LNB(4);
+#undef GRIDMM_LNB
   GRIDMM_CHECK_LAUNCH();
   GRIDMM_LAUNCH(ln_param_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, workspace, dgamma, dbeta, nblk, H);
   GRIDMM_CHECK_LAUNCH();
@@ -319,26 +358,15 @@ extern "C" int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int 
 extern "C" int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int ldr, const float* gamma, float eps,
                                     const float* dY, int ldy, float* dX, int lddx, float* dgamma, float* dbeta,
                                     float* workspace, int M, int H, gridmm_stream_t stream) {
-  if (M <= 0 || H <= 0 || H % 4 || H > MAX_H_BWD || ldx % 4 || ldy % 4 || lddx % 4 || (R && ldr % 4)) return GRIDMM_EINVAL;
-  hipStream_t st = as_stream(stream);
-  const int nblk = (M + 3) / 4;
-  dim3 grid(nblk), block(256);
-  const int nv = (H / 4 + 63) / 64;
-#define GRIDMM_LNB(NV)                                                                                      \
-  GRIDMM_LAUNCH((layernorm_bwd_kernel<NV>), grid, block, 0, st, X, ldx, R, ldr, gamma, eps, dY, ldy, dX, lddx, \
-                workspace, M, H)
-  if (nv == 1) GRIDMM_LNB(1); else if (nv == 2) GRIDMM_LNB(2); else if (nv == 3) GRIDMM_LNB(3); else GRIDMM_LNB(4);
-#undef GRIDMM_LNB
-  GRIDMM_CHECK_LAUNCH();
-  GRIDMM_LAUNCH(ln_param_reduce_kernel, dim3((H + 31) / 32), dim3(1024), 0, st, workspace, dgamma, dbeta, nblk, H);
-  GRIDMM_CHECK_LAUNCH();
-  return GRIDMM_OK;
+  return gridmm_layernorm_bwd_planes(X, ldx, R, ldr, gamma, eps, dY, ldy, dX, lddx, nullptr, nullptr, dgamma, dbeta, workspace, M,
+                                     H, stream);
 }
 
-// _planes: also the bf16 hi/lo planes of the result (the next Linear's A operand; forward modes 0 / 2 only).
+// _planes: also the bf16 hi/lo planes of the result (forward: the next Linear's A operand; backward modes 1 / 3: the dY
+// operand of the Linear in front of the activation).
 extern "C" int gridmm_activation_planes(const float* X, const float* dY, float* out, void* out_hi, void* out_lo, int64_t n,
                                         int mode, gridmm_stream_t stream) {
-  if (n <= 0 || n % 4 || mode < 0 || mode > 3 || ((mode & 1) && !dY) || (out_hi && (!out_lo || (mode & 1)))) return GRIDMM_EINVAL;
+  if (n <= 0 || n % 4 || mode < 0 || mode > 3 || ((mode & 1) && !dY) || (out_hi && !out_lo)) return GRIDMM_EINVAL;
   const size_t n4 = (size_t)n / 4;
   unsigned grid = (unsigned)((n4 + 255) / 256);
   if (grid > 16384) grid = 16384;

@@ -328,23 +328,32 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
   int rc;
 #define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
   // LN backward: dx = gradient of the (dropped-out) dense output, dres = gradient of the residual input
+  // (yP: the reserved dY-plane region of the Linear in front of the LayerNorm -- the kernel writes the planes of dx there)
   auto ln_bwd = [&](const float* x, const float* r, const gridmm_ln_t& p, unsigned long long seed, const float* dy, float* dx,
-                    float* dres, float* dgm, float* dbt) {
+                    float* dres, float* dgm, float* dbt, unsigned short* yP) {
+    unsigned short* yl = yP ? yP + (size_t)H * Mp : nullptr;
     if (ph > 0.f)
-      return gridmm_layernorm_dropout_bwd(x, r, H, p.gamma, p.eps, dy, dx, dres, dgm, dbt, lnws, ph, seed, L->seed_dev, M, H, stream);
-    return gridmm_layernorm_bwd(x, H, r, H, p.gamma, p.eps, dy, H, dx, H, dgm, dbt, lnws, M, H, stream);
+      return gridmm_layernorm_dropout_bwd_planes(x, r, H, p.gamma, p.eps, dy, dx, yP, yl, dres, dgm, dbt, lnws, ph, seed,
+                                                 L->seed_dev, M, H, stream);
+    return gridmm_layernorm_bwd_planes(x, H, r, H, p.gamma, p.eps, dy, H, dx, H, yP, yl, dgm, dbt, lnws, M, H, stream);
   };
+  unsigned short* yP;
   // without dropout the residual's gradient IS dx (one buffer)
   auto res_of = [&](float* dx, float* dres) { return ph > 0.f ? dres : dx; };
 
   // ---- feed forward
-  GRIDMM_TRY(ln_bwd(s.h3, s.a2, L->f_ln, L->seed[4], dY, dh, dr, G->f_ln_g, G->f_ln_b));
-  GRIDMM_TRY(linear_bwd(L->ffn_o, dh, s.gT, nullptr, dg, G->ffn_o_w, G->ffn_o_b, M, lw, stream, &tb));
-  GRIDMM_TRY(gridmm_activation(s.f1, dg, df1, (int64_t)M * I, 1, stream));
-  GRIDMM_TRY(linear_bwd(L->ffn_i, df1, s.a2T, res_of(dh, dr), da, G->ffn_i_w, G->ffn_i_b, M, lw, stream, &tb));   // da = d a2
+  // (the producers of a Linear's dY -- LayerNorm backward, GELU backward -- write its planes into that Linear's region of the
+  // batch: no split pass for ffn_o, ffn_i, so, xo; the attention backward leaves fp32 gradients: sqkv and xq still split)
+  if (!(yP = reserve_y(tb, H, M))) return GRIDMM_EINVAL;
+  GRIDMM_TRY(ln_bwd(s.h3, s.a2, L->f_ln, L->seed[4], dY, dh, dr, G->f_ln_g, G->f_ln_b, yP));
+  GRIDMM_TRY(linear_bwd(L->ffn_o, dh, s.gT, nullptr, dg, G->ffn_o_w, G->ffn_o_b, M, lw, stream, &tb, yP));
+  if (!(yP = reserve_y(tb, I, M))) return GRIDMM_EINVAL;
+  GRIDMM_TRY(gridmm_activation_planes(s.f1, dg, df1, yP, yP + (size_t)I * Mp, (int64_t)M * I, 1, stream));
+  GRIDMM_TRY(linear_bwd(L->ffn_i, df1, s.a2T, res_of(dh, dr), da, G->ffn_i_w, G->ffn_i_b, M, lw, stream, &tb, yP));   // da = d a2
   // ---- self attention
-  GRIDMM_TRY(ln_bwd(s.h2, cross ? s.a1 : X, L->s_ln, L->seed[3], da, dh, dr, G->s_ln_g, G->s_ln_b));
-  GRIDMM_TRY(linear_bwd(L->so, dh, s.c2T, nullptr, dc, G->so_w, G->so_b, M, lw, stream, &tb));
+  if (!(yP = reserve_y(tb, H, M))) return GRIDMM_EINVAL;
+  GRIDMM_TRY(ln_bwd(s.h2, cross ? s.a1 : X, L->s_ln, L->seed[3], da, dh, dr, G->s_ln_g, G->s_ln_b, yP));
+  GRIDMM_TRY(linear_bwd(L->so, dh, s.c2T, nullptr, dc, G->so_w, G->so_b, M, lw, stream, &tb, yP));
   if (L->attention_fp32) {
     GRIDMM_TRY(gridmm_attention_bwd(s.qkv, (int64_t)Sq * 3 * H, 3 * H, s.qkv + H, (int64_t)Sq * 3 * H, 3 * H, s.qkv + 2 * H,
                                     (int64_t)Sq * 3 * H, 3 * H, self_mask, self_mask_bs, s.c2, (int64_t)Sq * H, H, dc,
@@ -362,8 +371,9 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
   GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), cross ? da_b : dX, G->sqkv_w, G->sqkv_b, M, lw, stream, &tb));   // d a1
   if (!cross) return tn_flush(tb, stream);
   // ---- cross attention
-  GRIDMM_TRY(ln_bwd(s.h1, X, L->x_ln, L->seed[1], da_b, dh, dr, G->x_ln_g, G->x_ln_b));
-  GRIDMM_TRY(linear_bwd(L->xo, dh, s.cT, nullptr, dc, G->xo_w, G->xo_b, M, lw, stream, &tb));
+  if (!(yP = reserve_y(tb, H, M))) return GRIDMM_EINVAL;
+  GRIDMM_TRY(ln_bwd(s.h1, X, L->x_ln, L->seed[1], da_b, dh, dr, G->x_ln_g, G->x_ln_b, yP));
+  GRIDMM_TRY(linear_bwd(L->xo, dh, s.cT, nullptr, dc, G->xo_w, G->xo_b, M, lw, stream, &tb, yP));
   float* dq = da;                                   // (M, H) scratch: the gradient of the query projection
   if (!L->attention_fp32 && planes_ok(KV_hi, KV_lo, kv_bs, kv_rs, k_col, v_col, Sk)) {
     const unsigned short* qP = (const unsigned short*)s.q;
@@ -533,27 +543,36 @@ extern "C" int gridmm_preln_layer_bwd(const gridmm_preln_layer_t* L, const float
   int rc;
 #define GRIDMM_TRY(call) do { rc = (call); if (rc != GRIDMM_OK) return rc; } while (0)
   // the gradient of drop(t) from the gradient of its output: the same mask on the gradient (p == 0: the gradient itself)
-  auto undrop = [&](const float* dy, int64_t n, unsigned long long seed, const float** out) {
-    if (p > 0.f) {
-      *out = dd;
-      return gridmm_dropout_add(dy, nullptr, dd, nullptr, nullptr, n, p, seed, L->seed_dev, stream);
-    }
-    *out = dy;
-    return (int)GRIDMM_OK;
+  // (yP: the reserved dY-plane region of the Linear whose output was dropped: the pass writes the planes -- with p == 0 it is
+  // run as a plain split, one launch either way)
+  auto undrop = [&](const float* dy, int width, unsigned long long seed, const float** out, unsigned short* yP) {
+    const int64_t n = (int64_t)M * width;
+    unsigned short* yl = yP + (size_t)width * Mp;
+    *out = p > 0.f ? dd : dy;
+    return gridmm_dropout_add(dy, nullptr, p > 0.f ? dd : nullptr, yP, yl, n, p, seed, L->seed_dev, stream);
   };
   const float* t;
+  unsigned short* yP;
   // ---- feed forward block
-  GRIDMM_TRY(undrop(dY, nH, L->seed[3], &t));
-  GRIDMM_TRY(linear_bwd(L->ffn2, t, s.fT, nullptr, dF, G->ffn2_w, G->ffn2_b, M, lw, stream, &tb));
-  GRIDMM_TRY(undrop(dF, nI, L->seed[2], &t));
-  GRIDMM_TRY(gridmm_activation(s.f1, t, dF1, nI, 1, stream));
-  GRIDMM_TRY(linear_bwd(L->ffn1, dF1, s.h2T, nullptr, dH, G->ffn1_w, G->ffn1_b, M, lw, stream, &tb));
+  if (!(yP = reserve_y(tb, H, M))) return GRIDMM_EINVAL;
+  GRIDMM_TRY(undrop(dY, H, L->seed[3], &t, yP));
+  GRIDMM_TRY(linear_bwd(L->ffn2, t, s.fT, nullptr, dF, G->ffn2_w, G->ffn2_b, M, lw, stream, &tb, yP));
+  if (p > 0.f) {
+    GRIDMM_TRY(gridmm_dropout_add(dF, nullptr, dd, nullptr, nullptr, nI, p, L->seed[2], L->seed_dev, stream));
+    t = dd;
+  } else {
+    t = dF;
+  }
+  if (!(yP = reserve_y(tb, I, M))) return GRIDMM_EINVAL;
+  GRIDMM_TRY(gridmm_activation_planes(s.f1, t, dF1, yP, yP + (size_t)I * Mp, nI, 1, stream));
+  GRIDMM_TRY(linear_bwd(L->ffn1, dF1, s.h2T, nullptr, dH, G->ffn1_w, G->ffn1_b, M, lw, stream, &tb, yP));
   GRIDMM_TRY(gridmm_layernorm_bwd(s.x1, H, nullptr, 0, L->ln2.gamma, L->ln2.eps, dH, H, dln, H, G->ln2_g, G->ln2_b, lnws, M, H,
                                   stream));
   GRIDMM_TRY(gridmm_dropout_add(dln, dY, dx1, nullptr, nullptr, nH, 0.f, 0, nullptr, stream));       // x1 feeds LN2 and the sum
   // ---- self attention block
-  GRIDMM_TRY(undrop(dx1, nH, L->seed[1], &t));
-  GRIDMM_TRY(linear_bwd(L->out, t, s.cT, nullptr, dC, G->out_w, G->out_b, M, lw, stream, &tb));
+  if (!(yP = reserve_y(tb, H, M))) return GRIDMM_EINVAL;
+  GRIDMM_TRY(undrop(dx1, H, L->seed[1], &t, yP));
+  GRIDMM_TRY(linear_bwd(L->out, t, s.cT, nullptr, dC, G->out_w, G->out_b, M, lw, stream, &tb, yP));
   {
     const unsigned short *qh = (const unsigned short*)s.qkv, *ql = qh + (size_t)M * 3 * H;
     const int64_t bs = (int64_t)S * 3 * H;

@@ -482,6 +482,11 @@ int gridmm_split_rows_pad(const float* X, int ldx, void* R_hi, void* R_lo, int l
 int gridmm_layernorm_bwd(const float* X, int ldx, const float* R, int ldr, const float* gamma, float eps,
                          const float* dY, int ldy, float* dX, int lddx, float* dgamma, float* dbeta,
                          float* workspace, int M, int H, gridmm_stream_t stream);
+/* (_planes: also the bf16 hi / lo planes of dX, rows of H contiguous -- the dY operand of the Linear in front of this LayerNorm
+ * for its dX GEMM and its weight gradient: that Linear's split pass is skipped) */
+int gridmm_layernorm_bwd_planes(const float* X, int ldx, const float* R, int ldr, const float* gamma, float eps,
+                                const float* dY, int ldy, float* dX, int lddx, void* dX_hi, void* dX_lo, float* dgamma,
+                                float* dbeta, float* workspace, int M, int H, gridmm_stream_t stream);
 
 /* Training: y = LayerNorm(dropout(X) + R) and its backward, with the hidden-state dropout of BertSelfOutput / BertOutput
  * (vilmodel.py:160-170, 199-211: dense -> dropout -> LayerNorm(. + input)) applied inside the LayerNorm kernels:
@@ -499,6 +504,10 @@ int gridmm_layernorm_dropout_bwd(const float* X, const float* R, int ldr, const 
                                  float* dX, float* dR, float* dgamma, float* dbeta, float* workspace, float p,
                                  unsigned long long seed, const unsigned long long* seed_dev, int M, int H,
                                  gridmm_stream_t stream);
+int gridmm_layernorm_dropout_bwd_planes(const float* X, const float* R, int ldr, const float* gamma, float eps, const float* dY,
+                                        float* dX, void* dX_hi, void* dX_lo, float* dR, float* dgamma, float* dbeta,
+                                        float* workspace, float p, unsigned long long seed, const unsigned long long* seed_dev,
+                                        int M, int H, gridmm_stream_t stream);   /* (planes of the masked dX, as above) */
 
 /* Elementwise activations for training.  mode 0: out = gelu(X) (erf form, vilmodel.py:37-43);
  * 1: out = dY * gelu'(X); 2: out = relu(X); 3: out = dY * (X > 0).  n % 4 == 0, contiguous. */
