@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
 # overrides and the whole experiment table of tile configurations.  Only the sweep tools ask for it (load(debug=True) or
 # GRIDMM_LIB_DEBUG=1 before the first load); the product path and the tests run on the shipping library, which has neither.
 DEBUG_LIB_PATH = os.path.join(_HERE, "libgridmm_hip_dbg.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -90,6 +90,9 @@ SIGNATURES = {
     "gridmm_linear_planes_shift": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gridmm_attention_rows_bwd": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i64, _i,
                                   _vp, _vp, _i64, _vp, ctypes.c_size_t, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _i, _f, _f,
+                                  ctypes.c_uint64, _vp, _vp],
+    "gridmm_attention_rows_bwd_planes": [_vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _i64, _i, _vp, _i64, _i,
+                                  _vp, _vp, _i64, _vp, ctypes.c_size_t, _vp, _i64, _i, _vp, _i64, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f,
                                   ctypes.c_uint64, _vp, _vp],
     "gridmm_grid_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gridmm_grid_aggregate_bwd_routed": [_vp] * 10 + [_i, _i, _i, _i, _vp],

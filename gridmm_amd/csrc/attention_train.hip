@@ -355,7 +355,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void attention_rows_bwd_dq_kernel(
     const uint8_t* __restrict__ kmask, int mask_bs, const unsigned short* __restrict__ dOh,
     const unsigned short* __restrict__ dOl, const float* __restrict__ lse2, const float* __restrict__ delta,
     const float* __restrict__ cq, float* __restrict__ dQ, int64_t dq_bs, int dq_rs, int Sq, int Sk, int Sqp, float scale, float drop_p,
-    unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
+    unsigned long long seed, const unsigned long long* __restrict__ seed_dev, unsigned short* __restrict__ dQh,
+    unsigned short* __restrict__ dQl) {
   __shared__ __attribute__((aligned(16))) unsigned short ring[2 * BUF];
   __shared__ unsigned s_mw[64];
   if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
@@ -439,9 +440,18 @@ __global__ __launch_bounds__((NW + 1) * 64) void attention_rows_bwd_dq_kernel(
   __builtin_amdgcn_s_barrier();
   if (q >= Sq) return;
 #pragma unroll
-  for (int n = 0; n < 4; ++n)
-    *reinterpret_cast<float4*>(dQ + b * dq_bs + (size_t)q * dq_rs + h * 64 + 16 * n + 4 * g) =
-        make_float4(acc[n][0] * scale, acc[n][1] * scale, acc[n][2] * scale, acc[n][3] * scale);
+  for (int n = 0; n < 4; ++n) {
+    const float4 o = make_float4(acc[n][0] * scale, acc[n][1] * scale, acc[n][2] * scale, acc[n][3] * scale);
+    const size_t off = b * dq_bs + (size_t)q * dq_rs + h * 64 + 16 * n + 4 * g;
+    *reinterpret_cast<float4*>(dQ + off) = o;
+    if (dQh) {               // the bf16 planes of dQ (same strides): the dY operand of the query projection's backward
+      uint2 hi, lo;
+      split2_bf16(o.x, o.y, hi.x, lo.x);
+      split2_bf16(o.z, o.w, hi.y, lo.y);
+      *reinterpret_cast<uint2*>(dQh + off) = hi;
+      *reinterpret_cast<uint2*>(dQl + off) = lo;
+    }
+  }
 }
 
 // =====================================================================================================================
@@ -454,7 +464,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void attention_rows_bwd_dkv_kernel(
     const uint8_t* __restrict__ kmask, int mask_bs, const unsigned short* __restrict__ dOh,
     const unsigned short* __restrict__ dOl, const float* __restrict__ lse2, const float* __restrict__ delta,
     const float* __restrict__ cq, float* __restrict__ dK, int64_t dk_bs, int dk_rs, float* __restrict__ dV, int64_t dv_bs, int dv_rs, int Sq, int Sk, int Sqp,
-    float scale, float drop_p, unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
+    float scale, float drop_p, unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+    unsigned short* __restrict__ dKh, unsigned short* __restrict__ dKl, unsigned short* __restrict__ dVh,
+    unsigned short* __restrict__ dVl) {
   __shared__ __attribute__((aligned(16))) unsigned short ring[2 * BUF];
   __shared__ __attribute__((aligned(16))) float s_ls[2][KC], s_dl[2][KC], s_cq[2][KC];
   if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
@@ -554,9 +566,22 @@ __global__ __launch_bounds__((NW + 1) * 64) void attention_rows_bwd_dkv_kernel(
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     const int dcol = h * 64 + 16 * n + 4 * g;
-    *reinterpret_cast<float4*>(dK + b * dk_bs + (size_t)key * dk_rs + dcol) =
-        make_float4(ak[n][0] * scale, ak[n][1] * scale, ak[n][2] * scale, ak[n][3] * scale);
-    *reinterpret_cast<float4*>(dV + b * dv_bs + (size_t)key * dv_rs + dcol) = make_float4(av[n][0], av[n][1], av[n][2], av[n][3]);
+    const float4 k4 = make_float4(ak[n][0] * scale, ak[n][1] * scale, ak[n][2] * scale, ak[n][3] * scale);
+    const float4 v4 = make_float4(av[n][0], av[n][1], av[n][2], av[n][3]);
+    const size_t ko = b * dk_bs + (size_t)key * dk_rs + dcol, vo = b * dv_bs + (size_t)key * dv_rs + dcol;
+    *reinterpret_cast<float4*>(dK + ko) = k4;
+    *reinterpret_cast<float4*>(dV + vo) = v4;
+    if (dKh) {               // planes of dK / dV (same strides as the fp32 gradients)
+      uint2 hi, lo;
+      split2_bf16(k4.x, k4.y, hi.x, lo.x);
+      split2_bf16(k4.z, k4.w, hi.y, lo.y);
+      *reinterpret_cast<uint2*>(dKh + ko) = hi;
+      *reinterpret_cast<uint2*>(dKl + ko) = lo;
+      split2_bf16(v4.x, v4.y, hi.x, lo.x);
+      split2_bf16(v4.z, v4.w, hi.y, lo.y);
+      *reinterpret_cast<uint2*>(dVh + vo) = hi;
+      *reinterpret_cast<uint2*>(dVl + vo) = lo;
+    }
   }
 }
 
@@ -610,17 +635,19 @@ extern "C" size_t gridmm_attention_rows_bwd_workspace(int B, int heads, int Sq) 
   return 2 * (((size_t)B * heads * Sqp * 4 + 255) & ~(size_t)255) + (size_t)B * Sq * heads * 64 * 2 * 2 + 256;
 }
 
-extern "C" int gridmm_attention_rows_bwd(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+extern "C" int gridmm_attention_rows_bwd_planes(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
                                          const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
                                          int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, const float* O, int64_t o_bs,
                                          int o_rs, const float* dO, int64_t do_bs, int do_rs, const float* lse2,
                                          const float* vbar, int64_t vb_bs, void* workspace,
                                          size_t workspace_bytes, float* dQ, int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs,
-                                         int dk_rs, float* dV, int64_t dv_bs, int dv_rs, int B, int heads, int Sq, int Sk, int Sqp,
+                                         int dk_rs, float* dV, int64_t dv_bs, int dv_rs, void* dQ_hi, void* dQ_lo, void* dK_hi,
+                                         void* dK_lo, void* dV_hi, void* dV_lo, int B, int heads, int Sq, int Sk, int Sqp,
                                          float scale, float dropout_p, unsigned long long seed,
                                          const unsigned long long* seed_dev, gridmm_stream_t stream) {
   if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0 || Sqp < Sq || Sqp % 16 || !O || !dO || !lse2 || !workspace || !dQ || !dK || !dV)
     return GRIDMM_EINVAL;
+  if ((dQ_hi && !dQ_lo) || (dK_hi && (!dK_lo || !dV_hi || !dV_lo)) || (!dK_hi && dV_hi)) return GRIDMM_EINVAL;
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return GRIDMM_EINVAL;
   if ((q_rs | k_rs | v_rs) & 7 || (q_bs | k_bs | v_bs) & 7) return GRIDMM_EINVAL;
   if ((o_rs | do_rs | dq_rs | dk_rs | dv_rs) & 3 || (o_bs | do_bs | dq_bs | dk_bs | dv_bs) & 3) return GRIDMM_EINVAL;
@@ -642,17 +669,32 @@ extern "C" int gridmm_attention_rows_bwd(const void* Q_hi, const void* Q_lo, int
       (const unsigned short*)dOh, (const unsigned short*)dOl, lse2, (const float*)delta, (const float*)cqv
   const int qt = (Sq + 15) / 16, kt = (Sk + 15) / 16;
   switch (waves_for(qt)) {
-    case 4: launch_dq<4>(qt, heads, B, st, GRIDMM_A, dQ, dq_bs, dq_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev); break;
-    case 7: launch_dq<7>(qt, heads, B, st, GRIDMM_A, dQ, dq_bs, dq_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev); break;
-    default: launch_dq<8>(qt, heads, B, st, GRIDMM_A, dQ, dq_bs, dq_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev); break;
+    case 4: launch_dq<4>(qt, heads, B, st, GRIDMM_A, dQ, dq_bs, dq_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev, (unsigned short*)dQ_hi, (unsigned short*)dQ_lo); break;
+    case 7: launch_dq<7>(qt, heads, B, st, GRIDMM_A, dQ, dq_bs, dq_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev, (unsigned short*)dQ_hi, (unsigned short*)dQ_lo); break;
+    default: launch_dq<8>(qt, heads, B, st, GRIDMM_A, dQ, dq_bs, dq_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev, (unsigned short*)dQ_hi, (unsigned short*)dQ_lo); break;
   }
   GRIDMM_CHECK_LAUNCH();
   switch (waves_for(kt)) {
-    case 4: launch_dkv<4>(kt, heads, B, st, GRIDMM_A, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev); break;
-    case 7: launch_dkv<7>(kt, heads, B, st, GRIDMM_A, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev); break;
-    default: launch_dkv<8>(kt, heads, B, st, GRIDMM_A, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev); break;
+    case 4: launch_dkv<4>(kt, heads, B, st, GRIDMM_A, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev, (unsigned short*)dK_hi, (unsigned short*)dK_lo, (unsigned short*)dV_hi, (unsigned short*)dV_lo); break;
+    case 7: launch_dkv<7>(kt, heads, B, st, GRIDMM_A, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev, (unsigned short*)dK_hi, (unsigned short*)dK_lo, (unsigned short*)dV_hi, (unsigned short*)dV_lo); break;
+    default: launch_dkv<8>(kt, heads, B, st, GRIDMM_A, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev, (unsigned short*)dK_hi, (unsigned short*)dK_lo, (unsigned short*)dV_hi, (unsigned short*)dV_lo); break;
   }
 #undef GRIDMM_A
   GRIDMM_CHECK_LAUNCH();
   return GRIDMM_OK;
+}
+
+extern "C" int gridmm_attention_rows_bwd(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi,
+                                         const void* K_lo, int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo,
+                                         int64_t v_bs, int v_rs, const uint8_t* kmask, int mask_bs, const float* O, int64_t o_bs,
+                                         int o_rs, const float* dO, int64_t do_bs, int do_rs, const float* lse2,
+                                         const float* vbar, int64_t vb_bs, void* workspace,
+                                         size_t workspace_bytes, float* dQ, int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs,
+                                         int dk_rs, float* dV, int64_t dv_bs, int dv_rs, int B, int heads, int Sq, int Sk, int Sqp,
+                                         float scale, float dropout_p, unsigned long long seed,
+                                         const unsigned long long* seed_dev, gridmm_stream_t stream) {
+  return gridmm_attention_rows_bwd_planes(Q_hi, Q_lo, q_bs, q_rs, K_hi, K_lo, k_bs, k_rs, V_hi, V_lo, v_bs, v_rs, kmask, mask_bs, O,
+                                          o_bs, o_rs, dO, do_bs, do_rs, lse2, vbar, vb_bs, workspace, workspace_bytes, dQ, dq_bs,
+                                          dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, B, heads, Sq, Sk, Sqp, scale, dropout_p, seed, seed_dev, stream);
 }

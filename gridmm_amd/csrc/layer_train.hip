@@ -363,34 +363,41 @@ extern "C" int gridmm_xattn_layer_bwd(const gridmm_xlayer_train_t* L, const floa
   } else {
     const unsigned short *qh = (const unsigned short*)s.qkv, *ql = qh + (size_t)M * 3 * H;
     const int64_t bs = (int64_t)Sq * 3 * H;
-    GRIDMM_TRY(gridmm_attention_rows_bwd(qh, ql, bs, 3 * H, qh + H, ql + H, bs, 3 * H, qh + 2 * H, ql + 2 * H, bs, 3 * H, self_mask,
+    // the kernels also write the planes of dq | dk | dv (strides of dqkv): the dY planes of the q | k | v projection
+    if (!(yP = reserve_y(tb, 3 * H, M))) return GRIDMM_EINVAL;
+    unsigned short *gh = yP, *gl = yP + (size_t)3 * H * Mp;
+    GRIDMM_TRY(gridmm_attention_rows_bwd_planes(qh, ql, bs, 3 * H, qh + H, ql + H, bs, 3 * H, qh + 2 * H, ql + 2 * H, bs, 3 * H, self_mask,
                                          self_mask_bs, s.c2, (int64_t)Sq * H, H, dc, (int64_t)Sq * H, H, s.lse_s,
-                                         s.qkv_shift + 2 * H, (int64_t)3 * H, att_ws, att_bytes, dqkv, bs, 3 * H, dqkv + H, bs, 3 * H, dqkv + 2 * H, bs, 3 * H, B, heads, Sq, Sq, Sqp, scale,
+                                         s.qkv_shift + 2 * H, (int64_t)3 * H, att_ws, att_bytes, dqkv, bs, 3 * H, dqkv + H, bs, 3 * H, dqkv + 2 * H, bs, 3 * H,
+                                         gh, gl, gh + H, gl + H, gh + 2 * H, gl + 2 * H, B, heads, Sq, Sq, Sqp, scale,
                                          pa, L->seed[2], L->seed_dev, stream));
   }
-  GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), cross ? da_b : dX, G->sqkv_w, G->sqkv_b, M, lw, stream, &tb));   // d a1
+  GRIDMM_TRY(linear_bwd(L->sqkv, dqkv, s.a1T, res_of(dh, dr), cross ? da_b : dX, G->sqkv_w, G->sqkv_b, M, lw, stream, &tb,
+                        L->attention_fp32 ? nullptr : yP));   // d a1
   if (!cross) return tn_flush(tb, stream);
   // ---- cross attention
   if (!(yP = reserve_y(tb, H, M))) return GRIDMM_EINVAL;
   GRIDMM_TRY(ln_bwd(s.h1, X, L->x_ln, L->seed[1], da_b, dh, dr, G->x_ln_g, G->x_ln_b, yP));
   GRIDMM_TRY(linear_bwd(L->xo, dh, s.cT, nullptr, dc, G->xo_w, G->xo_b, M, lw, stream, &tb, yP));
   float* dq = da;                                   // (M, H) scratch: the gradient of the query projection
+  unsigned short* yqP = nullptr;                    // its planes, when the attention backward on the matrix pipe wrote them
   if (!L->attention_fp32 && planes_ok(KV_hi, KV_lo, kv_bs, kv_rs, k_col, v_col, Sk)) {
     const unsigned short* qP = (const unsigned short*)s.q;
     const unsigned short *kvh = (const unsigned short*)KV_hi, *kvl = (const unsigned short*)KV_lo;
-    GRIDMM_TRY(gridmm_attention_rows_bwd(qP, qP + (size_t)M * H, (int64_t)Sq * H, H, kvh + k_col, kvl + k_col, kv_bs, kv_rs,
+    if (!(yqP = reserve_y(tb, H, M))) return GRIDMM_EINVAL;
+    GRIDMM_TRY(gridmm_attention_rows_bwd_planes(qP, qP + (size_t)M * H, (int64_t)Sq * H, H, kvh + k_col, kvl + k_col, kv_bs, kv_rs,
                                          kvh + v_col, kvl + v_col, kv_bs, kv_rs, ctx_mask, ctx_mask_bs, s.c, (int64_t)Sq * H, H, dc,
                                          (int64_t)Sq * H, H, s.lse_x, KV_shift ? KV_shift + v_col : nullptr, kv_shift_bs, att_ws,
                                          att_bytes, dq, (int64_t)Sq * H, H, dKV + k_col, dkv_bs,
-                                         dkv_rs, dKV + v_col, dkv_bs, dkv_rs, B, heads, Sq, Sk, Sqp, scale, pa, L->seed[0],
-                                         L->seed_dev, stream));
+                                         dkv_rs, dKV + v_col, dkv_bs, dkv_rs, yqP, yqP + (size_t)H * Mp, nullptr, nullptr, nullptr,
+                                         nullptr, B, heads, Sq, Sk, Sqp, scale, pa, L->seed[0], L->seed_dev, stream));
   } else {
     GRIDMM_TRY(gridmm_attention_bwd(s.q, (int64_t)Sq * H, H, KV + k_col, kv_bs, kv_rs, KV + v_col, kv_bs, kv_rs, ctx_mask,
                                     ctx_mask_bs, s.c, (int64_t)Sq * H, H, dc, (int64_t)Sq * H, H, s.lse_x, delta, dq,
                                     (int64_t)Sq * H, H, dKV + k_col, dkv_bs, dkv_rs, dKV + v_col, dkv_bs, dkv_rs, B, heads, Sq,
                                     Sk, Sqp, scale, pa, L->seed[0], L->seed_dev, stream));
   }
-  GRIDMM_TRY(linear_bwd(L->xq, dq, s.xT, res_of(dh, dr), dX, G->xq_w, G->xq_b, M, lw, stream, &tb));
+  GRIDMM_TRY(linear_bwd(L->xq, dq, s.xT, res_of(dh, dr), dX, G->xq_w, G->xq_b, M, lw, stream, &tb, yqP));
 #undef GRIDMM_TRY
   return tn_flush(tb, stream);
 }
@@ -576,12 +583,15 @@ extern "C" int gridmm_preln_layer_bwd(const gridmm_preln_layer_t* L, const float
   {
     const unsigned short *qh = (const unsigned short*)s.qkv, *ql = qh + (size_t)M * 3 * H;
     const int64_t bs = (int64_t)S * 3 * H;
-    GRIDMM_TRY(gridmm_attention_rows_bwd(qh, ql, bs, 3 * H, qh + H, ql + H, bs, 3 * H, qh + 2 * H, ql + 2 * H, bs, 3 * H, mask,
+    if (!(yP = reserve_y(tb, 3 * H, M))) return GRIDMM_EINVAL;
+    unsigned short *gh = yP, *gl = yP + (size_t)3 * H * Mp;
+    GRIDMM_TRY(gridmm_attention_rows_bwd_planes(qh, ql, bs, 3 * H, qh + H, ql + H, bs, 3 * H, qh + 2 * H, ql + 2 * H, bs, 3 * H, mask,
                                          mask_bs, s.c, (int64_t)S * H, H, dC, (int64_t)S * H, H, s.lse, s.qkv_shift + 2 * H,
                                          (int64_t)3 * H, att_ws, att_bytes, dqkv, bs, 3 * H, dqkv + H, bs, 3 * H, dqkv + 2 * H, bs,
-                                         3 * H, B, heads, S, S, Sp, scale, p, L->seed[0], L->seed_dev, stream));
+                                         3 * H, gh, gl, gh + H, gl + H, gh + 2 * H, gl + 2 * H, B, heads, S, S, Sp, scale, p,
+                                         L->seed[0], L->seed_dev, stream));
   }
-  GRIDMM_TRY(linear_bwd(L->qkv, dqkv, s.h1T, nullptr, dH, G->qkv_w, G->qkv_b, M, lw, stream, &tb));
+  GRIDMM_TRY(linear_bwd(L->qkv, dqkv, s.h1T, nullptr, dH, G->qkv_w, G->qkv_b, M, lw, stream, &tb, yP));
   GRIDMM_TRY(gridmm_layernorm_bwd(X, H, nullptr, 0, L->ln1.gamma, L->ln1.eps, dH, H, dln, H, G->ln1_g, G->ln1_b, lnws, M, H,
                                   stream));
   GRIDMM_TRY(gridmm_dropout_add(dln, dx1, dX, nullptr, nullptr, nH, 0.f, 0, nullptr, stream));        // x feeds LN1 and the sum

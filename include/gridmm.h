@@ -577,6 +577,17 @@ int gridmm_attention_rows_bwd(const void* Q_hi, const void* Q_lo, int64_t q_bs, 
                               int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs, int dk_rs, float* dV, int64_t dv_bs, int dv_rs,
                               int B, int heads, int Sq, int Sk, int Sqp, float scale, float dropout_p, unsigned long long seed,
                               const unsigned long long* seed_dev, gridmm_stream_t stream);
+/* (_planes: dQ_hi / dQ_lo and dK_hi / dK_lo / dV_hi / dV_lo, each pair optional -- the bf16 planes of the gradients with the strides
+ * of their fp32 tensors: the dY operand of the q / k / v projection's backward, whose split pass is then skipped) */
+int gridmm_attention_rows_bwd_planes(const void* Q_hi, const void* Q_lo, int64_t q_bs, int q_rs, const void* K_hi, const void* K_lo,
+                                     int64_t k_bs, int k_rs, const void* V_hi, const void* V_lo, int64_t v_bs, int v_rs,
+                                     const uint8_t* kmask, int mask_bs, const float* O, int64_t o_bs, int o_rs, const float* dO,
+                                     int64_t do_bs, int do_rs, const float* lse2, const float* vbar, int64_t vb_bs, void* workspace,
+                                     size_t workspace_bytes, float* dQ, int64_t dq_bs, int dq_rs, float* dK, int64_t dk_bs,
+                                     int dk_rs, float* dV, int64_t dv_bs, int dv_rs, void* dQ_hi, void* dQ_lo, void* dK_hi,
+                                     void* dK_lo, void* dV_hi, void* dV_lo, int B, int heads, int Sq, int Sk, int Sqp, float scale,
+                                     float dropout_p, unsigned long long seed, const unsigned long long* seed_dev,
+                                     gridmm_stream_t stream);
 
 /* Backward of gridmm_grid_aggregate w.r.t. text = text_proj(txt_embeds) (vilmodel.py:795-807; the gradient
  * reaches text_proj and the language encoder through the max / softmax weights):
