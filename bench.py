@@ -821,7 +821,11 @@ def roofline_leg(step, args, geom, L=80):
                 if k in out and k in t["kernels"]:
                     out[k]["traffic"] = t["kernels"][k]["hbm_bytes_per_launch"]
                     out[k]["traffic_source"] = "profiles/" + os.path.basename(tpath)
-    dom = max(("linear", "grid_aggregate", "attention"), key=lambda k: summ.get(k, {"ms": 0})["ms"])
+    # the dominant kernel among those with a roofline entry (at the BASELINE batch the GEMMs are 75 % of the step; with a
+    # few episodes per rank and ranks sharing a device -- the 8-rank dry run of the tests -- the attention launches can
+    # out-time them in the eager events, and they have no entry of their own: that made `roofline` come out without `frac`
+    # once in ~10 runs)
+    dom = max((k for k in ("linear", "grid_aggregate") if k in out), key=lambda k: summ[k]["ms"])
     out["dominant"] = dom
     return out
 
