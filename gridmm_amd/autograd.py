@@ -407,21 +407,20 @@ def _want_planes(width):
     return TN_GEMM and width % 8 == 0
 
 
-def split_rows_pad(x2d, want_colsum=False, defer_colsum=False):
+def split_rows_pad(x2d, want_colsum=False):
     """fp32 (M,C) -> row-major bf16 hi/lo planes (Mp,C) with rows [M,Mp) zero, Mp = roundup(M,32) [, column sums (C,)]: one
     pass per activation / gradient for both of its GEMM roles (forward / dX: the first M rows; dW: gridmm_linear_planes_tn).
-    defer_colsum: the column sums come back as their per-256-row partials (n_part, C) -- _gemm_tn_rows reduces them in the
-    weight gradient's summing pass instead of a launch of their own."""
+    (The bias gradient of a Linear with a weight gradient comes from the weight-gradient GEMM: _gemm_tn_rows(want_db=True).)"""
     lib = _lib.load()
     x2d, M, C, ld = _as2d(x2d)
     Mp = (M + 31) // 32 * 32
     hi = torch.empty(Mp, C, dtype=torch.bfloat16, device=x2d.device)
     lo = torch.empty_like(hi)
-    cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum and not defer_colsum else None
+    cs = torch.empty(C, dtype=torch.float32, device=x2d.device) if want_colsum else None
     cs_ws = torch.empty((Mp + 255) // 256, C, dtype=torch.float32, device=x2d.device) if want_colsum else None
     _lib.check(lib.gridmm_split_rows_pad(_p(x2d), ld, _p(hi), _p(lo), C, _p(cs), _p(cs_ws), M, C, Mp, _stream()),
                "gridmm_split_rows_pad")
-    return hi, lo, (cs_ws if want_colsum and defer_colsum else cs), Mp, ops.Act(x2d, hi[:M], lo[:M])
+    return hi, lo, cs, Mp, ops.Act(x2d, hi[:M], lo[:M])
 
 
 def _gemm_tn_rows(yp, xp, N, K, M, want_db=False):

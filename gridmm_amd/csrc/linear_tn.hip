@@ -299,8 +299,8 @@ __global__ void sum_splits_tn_grouped_kernel(const SumGroup g) {
 }
 
 // Second stage of a weight gradient: out = the `splits` partial products summed in order; the workgroups past `sum_blocks`
-// reduce, likewise in order, the column-sum partials of dY that the split pass left (gridmm_split_rows_pad /
-// gridmm_transpose_split with colsum = NULL): db[c] = sum_r colpart[r][c] -- the bias gradient without a launch of its own.
+// reduce, likewise in order, the bias-gradient partials that the GEMM wrote (one row of column sums of A per contraction range,
+// see linear_planes_tn_tile): db[c] = sum_r colpart[r][c] -- the bias gradient without a launch of its own.
 __global__ void sum_splits_tn_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n4, int splits,
                                      int sum_blocks, const float* __restrict__ colpart, float* __restrict__ db, int n_part,
                                      int C) {

@@ -440,7 +440,7 @@ int gridmm_transpose_split(const float* X, int ldx, void* T_hi, void* T_lo, floa
                            void* R_lo, int ldp, int M, int C, int Mp, gridmm_stream_t stream);
 /* (colsum != NULL needs colsum_ws >= ceil(Mp / 256) * C floats: one partial per 256-row block, summed in a fixed
  * order -- no float atomics, db is bit-reproducible from run to run.  colsum = NULL with colsum_ws != NULL: the partials
- * only, for gridmm_linear_planes_tn_db to reduce in the weight gradient's own summing pass) */
+ * only.  With a weight gradient the bias gradient comes from gridmm_linear_planes_tn_db instead, and no column sums are needed) */
 /* (R_hi / R_lo, optional: the row-major planes [M][ldp] of the same X from the same pass -- the A operand of the
  * forward / dX GEMM -- so an activation or a gradient is read ONCE for both of its GEMM roles) */
 
