@@ -287,27 +287,40 @@ class TopoMapBatch:
         """TopoMap.observe(obs[b]) for every (active) episode, with the all-pairs relaxation of the B maps done as ONE pass
         over the (B, n, n) arrays: same arithmetic (float64 edge lengths, strict `<` improvements, pivot ids), same result
         as the per-map calls (tests/test_topo_map.py)."""
-        bs, ks = [], []
+        bs, ks, kpos = [], [], []
+        eb, ec, epos = [], [], []                    # candidate edges: row of bs, candidate node id, candidate position
         for b, ob in enumerate(obs):
             if active is not None and not active[b]:
                 continue
             m = self.maps[b]
             k = m.intern(ob["viewpoint"])
-            cs = [m.intern(c["viewpointId"]) for c in ob["candidate"]]      # (may re-point the arrays: intern first)
+            cands = ob["candidate"]
+            cs = [m.intern(c["viewpointId"]) for c in cands]                # (may re-point the arrays: intern first)
+            if cs:
+                eb.extend([len(bs)] * len(cs))
+                ec.extend(cs)
+                epos.extend(c["position"] for c in cands)
             bs.append(b)
             ks.append(k)
-            pos = self.pos[b]
-            pos[k] = ob["position"]
-            if cs:
-                ci = np.asarray(cs, dtype=np.int64)
-                pos[ci] = np.asarray([c["position"] for c in ob["candidate"]], dtype=np.float64)
-                delta = pos[ci] - pos[k]
+            kpos.append(ob["position"])
+        if bs:
+            # positions and observed edges of all episodes in whole-array passes (same float64 arithmetic as TopoMap.observe:
+            # edge length from the stored positions, strict `<` improvements; a candidate listed twice keeps the shorter edge)
+            bsa, ksa = np.asarray(bs, dtype=np.int64), np.asarray(ks, dtype=np.int64)
+            self.pos[bsa, ksa] = np.asarray(kpos, dtype=np.float64)
+            if ec:
+                e = np.asarray(eb, dtype=np.int64)
+                bi, ki, ci = bsa[e], ksa[e], np.asarray(ec, dtype=np.int64)
+                self.pos[bi, ci] = np.asarray(epos, dtype=np.float64)
+                delta = self.pos[bi, ci] - self.pos[bi, ki]
                 w = np.sqrt(delta[:, 0] ** 2 + delta[:, 1] ** 2 + delta[:, 2] ** 2)
-                d, v = self.dist[b], self.via[b]
-                for c, wc in zip(cs, w):                    # (a candidate listed twice keeps the first, shorter-or-equal edge)
-                    if wc < d[k, c]:
-                        d[k, c] = d[c, k] = wc
-                        v[k, c] = v[c, k] = -1
+                imp = w < self.dist[bi, ki, ci]
+                if imp.any():
+                    bi, ki, ci, w = bi[imp], ki[imp], ci[imp], w[imp]
+                    np.minimum.at(self.dist, (bi, ki, ci), w)
+                    np.minimum.at(self.dist, (bi, ci, ki), w)
+                    self.via[bi, ki, ci] = -1
+                    self.via[bi, ci, ki] = -1
         if not bs:
             return
         bs, ks = np.asarray(bs, dtype=np.int64), np.asarray(ks, dtype=np.int64)
