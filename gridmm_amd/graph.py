@@ -211,6 +211,24 @@ class GraphedNavStep:
         return self.outs
 
 
+FOREACH_COPY = bool(int(os.environ.get("GRIDMM_FOREACH_COPY", "1")))   # A/B switch
+
+
+def _copy_all(dsts, srcs):
+    """The step's inputs into a graph's static buffers: one multi-tensor copy per (dtype, device) group instead of ~15
+    copy_ launches (7 us of host time each in a rollout step that is bound by the host)."""
+    if not FOREACH_COPY:
+        for d, s in zip(dsts, srcs):
+            d.copy_(s)
+        return
+    same = [(d, s) for d, s in zip(dsts, srcs) if d.dtype == s.dtype and d.device == s.device and d.shape == s.shape]
+    rest = [(d, s) for d, s in zip(dsts, srcs) if not (d.dtype == s.dtype and d.device == s.device and d.shape == s.shape)]
+    if same:
+        torch._foreach_copy_([d for d, _ in same], [s for _, s in same])
+    for d, s in rest:
+        d.copy_(s)
+
+
 class NavigationGraphs:
     """forward('navigation') for callers whose shapes change from step to step (GMapNavAgent.rollout: the topological
     map grows, instructions differ in length between mini-batches): the half of the step that depends on those shapes
@@ -373,10 +391,8 @@ class NavigationGraphs:
             ent = self._capture(key, fr, batch, c_pad)
         else:
             self.graphs[key] = ent                # most recently used
-        for k, v in ins.items():
-            ent["ins"][k].copy_(v)
-        for k, v in self._front_tensors(fr).items():
-            ent["fr"][k].copy_(v)
+        fts = self._front_tensors(fr)
+        _copy_all([ent["ins"][k] for k in ins] + [ent["fr"][k] for k in fts], list(ins.values()) + list(fts.values()))
         ent["graph"].replay()
         self.replays += 1
         return ent["outs"]
@@ -419,7 +435,6 @@ class PanoramaGraphs:
                 self.pool = g.pool()
             ent["graph"] = g
             self.graphs[key] = ent
-        for k in self.KEYS:
-            ent["ins"][k].copy_(batch[k])
+        _copy_all([ent["ins"][k] for k in self.KEYS], [batch[k] for k in self.KEYS])
         ent["graph"].replay()
         return ent["outs"]
