@@ -11,6 +11,7 @@
 // rowops.hip / attention.hip.  K % 32 == 0 and 16-byte aligned rows are required here; everything
 // else goes through gridmm_linear.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -53,7 +54,13 @@ struct PShift { const float* tab; int rpb, c0; int pre_c; };   // pre_c: C recei
 // WT = 1: the W planes arrive TILED as [N / RPP][Kp / BK][RPP rows][BK k] blocks (used with BK = 32: 16 x 32) -- every 1-KiB DMA
 // piece is one contiguous KiB of memory instead of 16 HALF cache lines a row pitch apart (tools/l2_to_lds_bw.hip: contiguous
 // pieces stream at 17.8-23.7 TB/s out of the Infinity Cache, strided rows at 12.5).
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int WT = 0>
+// RP = 1 ("register-pipelined", BK = 64, round 6): the fragments of sub-step t + 1 (32 of k) are read from LDS into a SECOND
+// register set under the MFMAs of sub-step t, so the LDS array works while the matrix pipe does (the plain loop runs them one
+// after the other: a k-step costs LDS time + MFMA time once a CU holds a single workgroup).  The barrier of k-step kt sits in
+// front of its second sub-step: by then every fragment of stage kt is in registers, so the buffer is FREE a k-step earlier than in
+// the plain loop and the ring keeps all NS stages in flight -- the DMA of stage kt + NS is issued right behind that barrier,
+// piece by piece between the MFMAs.
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int WT = 0, int RP = 0>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
@@ -66,8 +73,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   constexpr int RPP = 512 / BK;                          // rows per 1-KiB DMA piece
   constexpr int CPR = BK / 8;                            // 16-B chunks per row
   constexpr int PIECES = (2 * BM + 2 * BN) / RPP;        // 1-KiB DMA pieces per stage
-  static_assert(PIECES % NW == 0, "tile must split evenly over the waves");
-  constexpr int PPW = PIECES / NW;
+  // pieces per wave: an even split takes consecutive pieces; a tile whose piece count is no multiple of the wave count
+  // (192 x 128 with 16 waves: 40 pieces) deals them round-robin, the first NFULL waves carry PPW, the rest PPW - 1 -- every
+  // wave counts its OWN queue, so the counted vmcnt below is per wave class
+  constexpr bool UNEVEN = PIECES % NW != 0;
+  constexpr int PPW = (PIECES + NW - 1) / NW;
+  constexpr int NFULL = UNEVEN ? PIECES - (PPW - 1) * NW : NW;
+  static_assert(!UNEVEN || (!PP && PPW >= 2), "uneven piece split: plain main loop only");
   constexpr int ER = (NW > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : (WM % 64 ? 32 : 64));   // rows per epilogue pass (LDS budget)
   constexpr int EPI = ER * WN;                           // floats per wave in the epilogue transpose
   constexpr int LDS_U16 = (TR || NS * STAGE * 2 > NW * EPI * 4) ? NS * STAGE : NW * EPI * 2;
@@ -99,16 +111,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       tx = nfs * W + r % w;
     }
   }
+  if (ABLATE == 4) { ty = 0; tx = 0; }          // every workgroup streams the SAME tile (all L2 hits): the L2 -> LDS path alone
+  if (ABLATE == 5) { ty = ty & 7; tx = 0; }     // 8 distinct row tiles, one column tile
   const int bm = ty * BM, bn = tx * BN;
 
   // DMA plan of this wave: piece p covers 16 rows of one plane
   const unsigned short* src[PPW];
+  [[maybe_unused]] const unsigned short* sbase[PPW];   // RP: wave-uniform plane base (SGPRs) + a 32-bit per-lane element offset --
+  [[maybe_unused]] unsigned voff[PPW];                 // half the address registers of the 64-bit per-lane pointers
   int dst[PPW];
   [[maybe_unused]] int kstep[PPW];          // elements between consecutive k-steps of a piece (WT: a W block is 512 apart)
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     kstep[i] = BK;
-    const int p = wave * PPW + i;
+    const int p = UNEVEN ? min(i * NW + wave, PIECES - 1) : wave * PPW + i;
     int plane, r0;
     if (p < BM / RPP) { plane = 0; r0 = p * RPP; }
     else if (p < 2 * BM / RPP) { plane = 1; r0 = (p - BM / RPP) * RPP; }
@@ -123,6 +139,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       size_t aoff = (size_t)m * lda;
       if (a_rpb > 0) { const int eb = m / a_rpb; aoff = (size_t)eb * a_bs + (size_t)(m - eb * a_rpb) * lda; }
       src[i] = (plane == 0 ? Ahi : Alo) + aoff + chunk * 8;
+      sbase[i] = plane == 0 ? Ahi : Alo;
+      voff[i] = (unsigned)(aoff + chunk * 8);
       dst[i] = plane * BM * BK + r0 * BK;
     } else {
       const int n = min(bn + row, N - 1);
@@ -132,6 +150,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
       } else {
         src[i] = (plane == 2 ? Whi : Wlo) + (size_t)n * Kp + chunk * 8;
       }
+      sbase[i] = plane == 2 ? Whi : Wlo;
+      voff[i] = (unsigned)((size_t)n * Kp + chunk * 8);
       dst[i] = 2 * BM * BK + (plane - 2) * BN * BK + r0 * BK;
     }
   }
@@ -151,16 +171,99 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     const int per = (nk + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per;
     nk = max(0, min(per, nk - k0));
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) src[i] += (size_t)k0 * BK;
+    for (int i = 0; i < PPW; ++i) { src[i] += (size_t)k0 * BK; voff[i] += (unsigned)(k0 * BK); }
   }
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
+  for (int s = 0; s < (RP ? NS : NS - 1); ++s)
     if (s < nk) {
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + s * (WT ? kstep[i] : BK), smem + s * STAGE + dst[i]);
+      for (int i = 0; i < PPW; ++i)
+        if (!UNEVEN || i < PPW - 1 || wave < NFULL) {
+          if constexpr (RP) dma16(sbase[i] + (voff[i] + (unsigned)(s * BK)), smem + s * STAGE + dst[i]);
+          else dma16(src[i] + s * (WT ? kstep[i] : BK), smem + s * STAGE + dst[i]);
+        }
     }
 
   const int frow = lane & 15, fchunk = lane >> 4;
+  if constexpr (RP) {
+    static_assert(BK == 64 && !PP && !UNEVEN && !ABLATE && !WT, "register-pipelined loop: BK = 64, even piece split, row-major W");
+    bf16x8_t ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    // fragment addresses: the swizzle term (row >> 1) & 7 does not depend on the 16-row block (16 i and wr * WM are multiples of
+    // 16), so ONE lane offset per (operand, sub-step) + compile-time block offsets (the ds_read offset field) address everything
+    static_assert(WM % 16 == 0 && WN % 16 == 0, "");
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ra = wr * WM + frow, rb = wc * WN + frow;
+      a_off[ks] = ra * BK + ((ks * 4 + fchunk) ^ swz<BK>(ra)) * 8;
+      b_off[ks] = 2 * BM * BK + rb * BK + ((ks * 4 + fchunk) ^ swz<BK>(rb)) * 8;
+    }
+    auto rd = [&](auto setc, const unsigned short* cur, auto ksc) {
+      constexpr int set = decltype(setc)::value, ks = decltype(ksc)::value;
+      const unsigned short* pa = cur + a_off[ks];
+      const unsigned short* pb = cur + b_off[ks];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[set][i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 16 * BK);
+        al[set][i] = *reinterpret_cast<const bf16x8_t*>(pa + BM * BK + i * 16 * BK);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[set][j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 16 * BK);
+        bl[set][j] = *reinterpret_cast<const bf16x8_t*>(pb + BN * BK + j * 16 * BK);
+      }
+    };
+    // the MFMAs of one sub-step; `stage` >= 0: the DMA pieces of that stage go out between them (one per accumulator tile)
+    auto mma = [&](auto setc, int stage) {
+      constexpr int set = decltype(setc)::value;
+      unsigned short* nxt = smem + (stage >= 0 ? stage % NS : 0) * STAGE;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (TR) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[set][j], al[set][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[set][j], ah[set][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[set][j], ah[set][i], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[set][i], bh[set][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[set][i], bl[set][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[set][i], bh[set][j], acc[i][j], 0, 0, 0);
+          }
+          if (i * TN + j < PPW && stage >= 0)
+            dma16(sbase[i * TN + j] + (voff[i * TN + j] + (unsigned)(stage * BK)), nxt + dst[i * TN + j]);
+        }
+      if constexpr (PPW > TM * TN) {
+        if (stage >= 0) {
+#pragma unroll
+          for (int q = TM * TN; q < PPW; ++q) dma16(sbase[q] + (voff[q] + (unsigned)(stage * BK)), nxt + dst[q]);
+        }
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // stage 0 landed (the younger NS - 1 stay in flight) and visible
+    if (nk >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rd(S0{}, smem, S0{});
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned short* cur = smem + (kt % NS) * STAGE;
+      rd(S1{}, cur, S1{});
+      mma(S0{}, -1);
+      int refill = -1;
+      if (kt + 1 < nk) {
+        // stage kt + 1 landed: of the stages issued so far (up to kt + NS - 1) the NS - 2 youngest may stay in flight
+        if (NS >= 3 && kt + NS - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's last reads of stage kt are in registers
+        __builtin_amdgcn_s_barrier();                        // stage kt + 1 visible to all; buffer kt % NS is free
+        rd(S0{}, smem + ((kt + 1) % NS) * STAGE, S0{});
+        if (kt + NS < nk) refill = kt + NS;
+      }
+      mma(S1{}, refill);
+    }
+  } else
   if constexpr (PP) {
     static_assert(!PP || (NS == 2 && BK == 32 && (NW == 8 || NW == 16) && TM % 2 == 0), "ping-pong schedule: 8 / 16 waves, 2 stages, BK 32");
     constexpr int HM = TM / 2;
@@ -247,7 +350,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   for (int kt = 0; kt < nk; ++kt) {
     // retire stage kt: everything except the (NS-2) younger stages must have landed
     if (NS >= 3 && kt + NS - 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+      if (UNEVEN && wave >= NFULL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (PPW - 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -255,9 +359,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
     if (ABLATE != 2 && kt + NS - 1 < nk) {
       unsigned short* nxt = smem + ((kt + NS - 1) % NS) * STAGE;
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) dma16(src[i] + (kt + NS - 1) * (WT ? kstep[i] : BK), nxt + dst[i]);
+      for (int i = 0; i < PPW; ++i)
+        if (!UNEVEN || i < PPW - 1 || wave < NFULL) dma16(src[i] + (kt + NS - 1) * (WT ? kstep[i] : BK), nxt + dst[i]);
     }
     const unsigned short* cur = smem + (kt % NS) * STAGE;
+    if (ABLATE >= 3) continue;      // the operand stream alone: DMA + waits + barriers
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
@@ -430,14 +536,14 @@ __global__ void split_rows_kernel(const float* __restrict__ X, int ldx, unsigned
 }
 
 // QG: also instantiate the QuickGELU epilogue (only the configurations pick_cfg can choose carry it)
-template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false, int WT = 0>
+template <int BM, int BN, int WM, int WN, int NS, int BK, int ABLATE = 0, int PP = 0, int TR = 0, bool QG = false, int WT = 0, int RP = 0>
 int launch(const unsigned short* Ahi, const unsigned short* Alo, int lda, const unsigned short* Whi,
            const unsigned short* Wlo, int Kp, const float* bias, const float* R, int ldr, float* C, int ldc,
            unsigned short* Chi, unsigned short* Clo, int ldp, int M, int N, int K, int act, hipStream_t st,
            int ksplit = 1, int a_rpb = 0, long a_bs = 0, PShift ps = PShift{nullptr, 1, 0}) {
   dim3 grid(((N + BN - 1) / BN) * ((M + BM - 1) / BM), ksplit), block((BM / WM) * (BN / WN) * 64);
 #define GRIDMM_LP(ACT)                                                                                        \
-  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR, WT>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
+  GRIDMM_LAUNCH((linear_planes_kernel<BM, BN, WM, WN, NS, BK, ACT, ABLATE, PP, TR, WT, RP>), grid, block, 0, st, Ahi, Alo, lda, Whi, Wlo, \
                 Kp, bias, R, ldr, C, ldc, Chi, Clo, ldp, M, N, K, a_rpb, a_bs, ps)
   if (act == GRIDMM_ACT_NONE) GRIDMM_LP(GRIDMM_ACT_NONE);
   else if (act == GRIDMM_ACT_GELU) GRIDMM_LP(GRIDMM_ACT_GELU);
@@ -590,7 +696,19 @@ static int pick_cfg_impl(int M, int N, int K) {
   // prefers -- half the tile rows' re-reads of W with the ring deep enough to cover operands that arrive cold.
   if (best == 43 && K % 64 == 0) {
     const long t13 = (long)((M + 127) / 128) * ((N + 63) / 64);
-    if (t13 >= 128 && t13 <= 256) best = 13;
+    // round 6: the same tile with the register-pipelined main loop (RP: fragments of sub-step t + 1 read under the MFMAs of t,
+    // the whole ring in flight); long contractions also take the direct C^T epilogue (in-step A/B: 1824x768x3072 -20 us per
+    // step over 4 launches, 1824x768x768 -4 us over 12; profiles/r6_gemm_cfg_sweep_in_step.txt)
+    if (t13 >= 128 && t13 <= 256) best = K >= 1536 ? 75 : 71;
+  }
+  // Mid-size problems whose 128x128 tiling leaves the second slot of most CUs empty (6912 x 768: 324 tiles on 512 slots): ONE
+  // 16-wave workgroup per CU with a 192x128 tile and 80-KB stages of full 128-B lines (BK = 64) moves 17 % fewer operand bytes
+  // per flop and keeps one whole stage in flight per CU.  In-step A/B: 6912x768x3072 -43 us per step (2 launches), 6912x768x768
+  // -8..-21 us (5 launches).  The operand stream of these launches runs at ~12 TB/s whatever the ring depth
+  // (profiles/r6_gemm_ablation.txt: DMA-only 71 us of a 93-us launch), so bytes per flop is the lever.
+  if (best == 15 && K % 64 == 0) {
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t192 = (long)((M + 191) / 192) * ((N + 127) / 128);
+    if (t128 > 256 && t192 >= 160 && t192 <= 256) best = 66;
   }
   return best;
 }
@@ -637,10 +755,13 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     if (cfg == 62) return launch<256, 128, 64, 64, 3, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
     if (cfg == 63) return launch<128, 128, 64, 64, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
     if (cfg == 64) return launch<192, 256, 96, 64, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
+    if (cfg == 65) return launch<192, 128, 48, 32, 3, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);   // round 6: ONE 16-wave workgroup per CU, 80 KB in flight
+    if (cfg == 67) return launch<192, 128, 48, 32, 4, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);   //          4-stage ring (160 KB)
+    if (cfg == 68) return launch<256, 128, 64, 32, 3, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
 #endif
     return GRIDMM_EUNSUPPORTED;
   }
-  if (K % 64 && (cfg == 2 || cfg == 13 || cfg == 43 || cfg == 57)) return GRIDMM_EINVAL;
+  if (K % 64 && (cfg == 2 || cfg == 13 || cfg == 43 || cfg == 57 || cfg == 66 || cfg == 71 || cfg == 75)) return GRIDMM_EINVAL;
   switch (cfg) {
     case 2: return launch<128, 128, 64, 32, 2, 64, 0, 0, 0, true>(GRIDMM_ARGS);
     case 4: return launch<64, 64, 32, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);
@@ -650,9 +771,14 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     case 36: return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);   // 16 waves, lockstep
     case 43: return launch<64, 64, 32, 32, 2, 64, 0, 0, 1, true>(GRIDMM_ARGS);     // direct epilogue from C^T accumulators
     case 57: return launch<128, 64, 32, 32, 3, 64, 0, 0, 0, true>(GRIDMM_ARGS);    // = 13
+    case 66: return launch<192, 128, 48, 32, 2, 64, 0, 0, 0, true>(GRIDMM_ARGS);   // one 16-wave workgroup per CU, BK = 64
+    case 71: return launch<128, 64, 32, 32, 3, 64, 0, 0, 0, true, 0, 1>(GRIDMM_ARGS);   // cfg 13, register-pipelined
+    case 75: return launch<128, 64, 32, 32, 3, 64, 0, 0, 1, true, 0, 1>(GRIDMM_ARGS);   // ... with the direct C^T epilogue
     default: break;
   }
 #ifdef GRIDMM_DEBUG_HOOKS
+  if (K % 64 && (cfg == 66 || (cfg >= 70 && cfg <= 79) || cfg % 100 == 66 || cfg % 100 == 13)) return GRIDMM_EINVAL;
+  if (cfg >= 400 && cfg < 600) { /* same-tile ablations write garbage: fine */ }
   if (K % 64 && (cfg == 5 || cfg == 8 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 108 || cfg == 208 || cfg == 45 || cfg == 49 ||
                  cfg == 50 || cfg == 51 || cfg == 53 || cfg == 54 || cfg == 56))
     return GRIDMM_EINVAL;
@@ -689,9 +815,35 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     case 54: return launch<128, 64, 64, 32, 3, 64, 0, 0, 1>(GRIDMM_ARGS);
     case 55: return launch<128, 64, 32, 32, 3, 32, 0, 0, 1>(GRIDMM_ARGS);
     case 56: return launch<96, 64, 48, 32, 3, 64>(GRIDMM_ARGS);
+    case 65: return launch<192, 128, 48, 32, 3, 32>(GRIDMM_ARGS);
+    case 67: return launch<192, 128, 48, 32, 4, 32>(GRIDMM_ARGS);
+    case 68: return launch<256, 128, 64, 32, 3, 32>(GRIDMM_ARGS);
+    case 69: return launch<96, 64, 48, 32, 3, 64, 0, 0, 1>(GRIDMM_ARGS);
+    // register-pipelined main loops (RP = 1)
+    case 70: return launch<192, 128, 48, 32, 2, 64, 0, 0, 0, false, 0, 1>(GRIDMM_ARGS);
+    case 72: return launch<128, 128, 32, 32, 2, 64, 0, 0, 0, false, 0, 1>(GRIDMM_ARGS);    // 16 waves, one workgroup per CU
+   // 96 x 64 thin tiles (228 workgroups at M = 1824), direct epilogue
     // ablations (tools/bench_gemm.py): 1xx = no MFMA (DMA + LDS reads only), 2xx = no DMA after the prologue
     case 108: return launch<64, 64, 32, 32, 2, 64, 1>(GRIDMM_ARGS);
     case 208: return launch<64, 64, 32, 32, 2, 64, 2>(GRIDMM_ARGS);
+    case 466: return launch<192, 128, 48, 32, 2, 64, 4>(GRIDMM_ARGS);
+    case 566: return launch<192, 128, 48, 32, 2, 64, 5>(GRIDMM_ARGS);
+    case 467: return launch<192, 128, 48, 32, 4, 32, 4>(GRIDMM_ARGS);
+    case 365: return launch<192, 128, 48, 32, 3, 32, 3>(GRIDMM_ARGS);
+    case 367: return launch<192, 128, 48, 32, 4, 32, 3>(GRIDMM_ARGS);
+    case 165: return launch<192, 128, 48, 32, 3, 32, 1>(GRIDMM_ARGS);
+    case 167: return launch<192, 128, 48, 32, 4, 32, 1>(GRIDMM_ARGS);
+    case 265: return launch<192, 128, 48, 32, 3, 32, 2>(GRIDMM_ARGS);
+    case 166: return launch<192, 128, 48, 32, 2, 64, 1>(GRIDMM_ARGS);
+    case 266: return launch<192, 128, 48, 32, 2, 64, 2>(GRIDMM_ARGS);
+    case 366: return launch<192, 128, 48, 32, 2, 64, 3>(GRIDMM_ARGS);
+    case 315: return launch<128, 128, 32, 32, 2, 32, 3>(GRIDMM_ARGS);
+    case 336: return launch<256, 256, 64, 64, 2, 32, 3>(GRIDMM_ARGS);
+    case 136: return launch<256, 256, 64, 64, 2, 32, 1>(GRIDMM_ARGS);
+    case 236: return launch<256, 256, 64, 64, 2, 32, 2>(GRIDMM_ARGS);
+    case 313: return launch<128, 64, 32, 32, 3, 64, 3>(GRIDMM_ARGS);
+    case 113: return launch<128, 64, 32, 32, 3, 64, 1>(GRIDMM_ARGS);
+    case 213: return launch<128, 64, 32, 32, 3, 64, 2>(GRIDMM_ARGS);
     case 115: return launch<128, 128, 32, 32, 2, 32, 1>(GRIDMM_ARGS);
     case 215: return launch<128, 128, 32, 32, 2, 32, 2>(GRIDMM_ARGS);
     case 107: return launch<256, 256, 128, 64, 2, 32, 1>(GRIDMM_ARGS);

@@ -105,3 +105,115 @@ def test_ops_refuse_cpu_tensors_loudly():
         ops.PackedLinear(torch.zeros(8, 8))           # CPU weight -> no silent fallback
     with pytest.raises(_lib.GridmmLibraryError):
         ops.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 1e-5)
+
+
+# ---- header <-> ctypes contract ------------------------------------------------------------------------------------
+def _prototypes(debug=False):
+    """Every `int|size_t gridmm_*( ... );` prototype of include/gridmm.h as (name, return C type, [argument C types])."""
+    txt = _header(debug)
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", " ", txt)
+    out = []
+    for m in re.finditer(r"^\s*(int|size_t)\s+(gridmm_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.M | re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        ctypes_args = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                assert "(" not in a and "[" not in a, "unparsed declarator in %s: %r" % (name, a)
+                if "*" in a:
+                    ctypes_args.append("ptr")
+                    continue
+                toks = [t for t in a.split() if t not in ("const", "volatile")]
+                assert len(toks) >= 2, "argument without a name in %s: %r" % (name, a)
+                ctypes_args.append(" ".join(toks[:-1]))
+        out.append((name, ret, ctypes_args))
+    return out
+
+
+def _ctype_of(c_type):
+    import ctypes
+    table = {"ptr": ctypes.c_void_p, "gridmm_stream_t": ctypes.c_void_p, "int": ctypes.c_int, "int32_t": ctypes.c_int,
+             "float": ctypes.c_float, "int64_t": ctypes.c_int64, "long long": ctypes.c_int64, "size_t": ctypes.c_size_t,
+             "uint64_t": ctypes.c_uint64, "unsigned": ctypes.c_uint, "unsigned int": ctypes.c_uint, "uint32_t": ctypes.c_uint,
+             "double": ctypes.c_double}
+    assert c_type in table, "no ctypes mapping for C type %r" % c_type
+    return table[c_type]
+
+
+def _assert_binding_matches(protos, lib):
+    import ctypes
+    mismatches = []
+    for name, ret, args in protos:
+        fn = getattr(lib, name)
+        want = [_ctype_of(a) for a in args]
+        got = list(fn.argtypes) if fn.argtypes is not None else None
+        if got is None:
+            mismatches.append("%s: no argtypes bound" % name)
+        elif len(got) != len(want):
+            mismatches.append("%s: header has %d arguments, ctypes binds %d" % (name, len(want), len(got)))
+        else:
+            for i, (w, g) in enumerate(zip(want, got)):
+                if w is not g:
+                    mismatches.append("%s: argument %d is %s in the header, %s in _lib" % (name, i, args[i], g.__name__))
+        want_ret = ctypes.c_size_t if ret == "size_t" else ctypes.c_int
+        if fn.restype is not want_ret:
+            mismatches.append("%s: returns %s in the header, restype is %s" % (name, ret, getattr(fn.restype, "__name__", fn.restype)))
+    return mismatches
+
+
+def test_ctypes_prototypes_equal_the_header_argument_by_argument():
+    """include/gridmm.h is the contract; _lib.SIGNATURES (+ the explicit restype / argtypes lines of _lib.load) is a
+    hand-written copy of it.  Parse every prototype, map the C types to ctypes and compare position by position, so an
+    `int` that becomes `int64_t` (or an argument added on one side only) fails here instead of corrupting a call."""
+    from gridmm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.load()
+    protos = _prototypes()
+    assert sorted(p[0] for p in protos) == _declared(), "the prototype parser and the name scan disagree"
+    assert len(protos) >= 89
+    assert not _assert_binding_matches(protos, lib)
+    # every table entry is a declared prototype (no stale binding survives a removed entry point)
+    assert set(_lib.SIGNATURES) <= set(p[0] for p in protos), set(_lib.SIGNATURES) - set(p[0] for p in protos)
+    dbg = _prototypes(debug=True)
+    assert sorted(p[0] for p in dbg) == sorted(_lib.DEBUG_SIGNATURES)
+    for name, ret, args in dbg:
+        assert ret == "int" and [_ctype_of(a) for a in args] == list(_lib.DEBUG_SIGNATURES[name]), name
+
+
+def test_contract_test_sees_a_changed_argument_type(tmp_path, monkeypatch):
+    """The check above must fail when ONE `int` of a prototype becomes `int64_t` in the header."""
+    from gridmm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.load()
+    real = open(os.path.join(ROOT, "include", "gridmm.h")).read()
+    needle = "int M, int N, int K, int act, gridmm_stream_t stream);"
+    assert needle in real
+    mutated = real.replace(needle, "int M, int64_t N, int K, int act, gridmm_stream_t stream);", 1)
+    import builtins
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if str(path).endswith(os.path.join("include", "gridmm.h")):
+            import io
+            return io.StringIO(mutated)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    bad = _assert_binding_matches(_prototypes(), lib)
+    assert len(bad) == 1 and "int64_t in the header" in bad[0], bad
+    # ... and a dropped argument
+    monkeypatch.setattr(builtins, "open", real_open)
+    mutated2 = real.replace(needle, "int M, int N, int K, gridmm_stream_t stream);", 1)
+
+    def fake_open2(path, *a, **k):
+        if str(path).endswith(os.path.join("include", "gridmm.h")):
+            import io
+            return io.StringIO(mutated2)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open2)
+    bad = _assert_binding_matches(_prototypes(), lib)
+    assert len(bad) == 1 and "arguments" in bad[0], bad

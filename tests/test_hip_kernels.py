@@ -52,6 +52,68 @@ def test_linear_bf16x3_matches_fp32(dev, M, N, K, act):
         assert (rec - y).abs().max().item() <= 2.0 ** -15 * max(1e-3, y.abs().max().item())
 
 
+@pytest.mark.parametrize("cfg", [66, 71, 75])
+@pytest.mark.parametrize("M,N,K", [(6912, 768, 3072), (1824, 768, 768), (191, 200, 64), (193, 132, 128), (1000, 764, 1536),
+                                   (6912, 768, 768), (50, 4, 192)])
+def test_round6_tiles_match_fp64_and_the_reference_tile_bit_for_bit(dev, cfg, M, N, K):
+    """The tiles pick_cfg gained in round 6 -- 192x128 with one 16-wave workgroup per CU (66) and the register-pipelined
+    128x64 loops (71, 75: fragments of sub-step t + 1 read under the MFMAs of t, DMA pieces issued between the MFMAs) --
+    forced through gridmm_linear_planes_cfg: ragged M / N, one k-step, long contractions, with bias + residual + plane output.
+    Same products in the same order as every other tile, so the result must EQUAL the 64x64 tile's (cfg 4) bit for bit; run
+    repeatedly, because a misplaced wait in a DMA ring shows up as a rare wrong tile, not as a constant error."""
+    import ctypes
+    from gridmm_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 5 * K + cfg)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    b = (torch.randn(N, generator=g) * 0.1).to(dev)
+    r = torch.randn(M, N, generator=g).to(dev)
+    pw = ops.PackedLinear(w, b)
+    a = ops.split_rows(x)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(c):
+        y = torch.full((M, N), float("nan"), device=dev)
+        hi = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        lo = torch.zeros_like(hi)
+        rc = lib.gridmm_linear_planes_cfg(a.hi.data_ptr(), a.lo.data_ptr(), K, pw.hi.data_ptr(), pw.lo.data_ptr(), pw.Kp,
+                                          b.data_ptr(), r.data_ptr(), N, y.data_ptr(), N, hi.data_ptr(), lo.data_ptr(), N,
+                                          M, N, K, 1, c, st)
+        assert rc == 0, rc
+        return y, hi, lo
+    y0, h0, l0 = run(4)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = ref * 0.5 * (1 + torch.erf(ref / math.sqrt(2))) + r.double()
+    scale = (x.double().abs() @ w.double().abs().t()).max().item()
+    assert (y0.double() - ref).abs().max().item() <= 4e-5 * scale + 1e-6
+    for _ in range(12):
+        y, h, l = run(cfg)
+        assert torch.equal(y, y0) and torch.equal(h, h0) and torch.equal(l, l0)
+
+
+def test_round6_heuristic_picks_the_new_tiles_for_the_step_shapes(dev):
+    """pick_cfg is internal; what can be observed is that the heuristic's result equals the forced tile's for the shapes the
+    rule is meant for -- and that results do not depend on the tile at all (bit-identical by construction)."""
+    import ctypes
+    from gridmm_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    for (M, N, K) in [(6912, 768, 3072), (6912, 768, 768), (1824, 768, 3072), (1824, 768, 768)]:
+        x = torch.randn(M, K, device=dev)
+        pw = ops.PackedLinear(torch.randn(N, K, device=dev) * 0.05, torch.randn(N, device=dev))
+        a = ops.split_rows(x)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        outs = []
+        for c in (0, 15):
+            y = torch.empty(M, N, device=dev)
+            assert lib.gridmm_linear_planes_cfg(a.hi.data_ptr(), a.lo.data_ptr(), K, pw.hi.data_ptr(), pw.lo.data_ptr(), pw.Kp,
+                                                pw.bias.data_ptr(), None, 0, y.data_ptr(), N, None, None, 0, M, N, K, 0, c, st) == 0
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_linear_strided_input_and_output(dev):
     ops = _ops()
     x = torch.randn(4, 50, 1024, device=dev)[..., :768]        # row stride 1024

@@ -7,10 +7,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gridmm_amd import _lib, ops
 
-SHAPES = [(6912, 2304, 768), (6912, 768, 768), (6912, 3072, 768), (6912, 768, 3072), (9472, 6144, 768),
+SHAPES = [(int(v) for v in os.environ['GEMM_SHAPE'].split('x'))] if os.environ.get('GEMM_SHAPE') else [(6912, 2304, 768), (6912, 768, 768), (6912, 3072, 768), (6912, 768, 3072), (9472, 6144, 768),
           (2560, 1536, 768), (1824, 768, 768), (1824, 2304, 768), (1824, 3072, 768), (1824, 768, 3072),
           (2560, 512, 768), (6272, 768, 512)]
-CFGS = {8: "64x64 BK64", 43: "TR 64x64 BK64", 14: "128x128 8w", 15: "128x128 16w", 36: "256x256 16w", 7: "256x256 8w", 16: "256x128 16w"}
+CFGS = {8: "64x64 BK64", 43: "TR 64x64 BK64", 14: "128x128 8w", 15: "128x128 16w", 36: "256x256 16w", 7: "256x256 8w", 16: "256x128 16w",
+        65: "192x128 16w NS3", 66: "192x128 16w BK64", 67: "192x128 16w NS4", 68: "256x128 16w NS3", 56: "96x64 NS3 BK64", 69: "96x64 TR",
+        70: "192x128 BK64 RP", 71: "128x64 NS3 RP", 72: "128x128 BK64 RP", 75: "128x64 NS3 RP TR", 13: "128x64 NS3",
+        466: "192x128 BK64 DMAonly same tile", 566: "192x128 BK64 DMAonly 8 row tiles", 467: "192x128 NS4 DMAonly same tile", 365: "192x128 NS3 DMAonly", 367: "192x128 NS4 DMAonly", 165: "192x128 NS3 noMFMA", 167: "192x128 NS4 noMFMA", 265: "192x128 NS3 noDMA", 166: "192x128 BK64 noMFMA", 266: "192x128 BK64 noDMA", 366: "192x128 BK64 DMAonly", 115: "128x128 noMFMA", 215: "128x128 noDMA", 315: "128x128 DMAonly",
+        136: "256x256 noMFMA", 236: "256x256 noDMA", 336: "256x256 DMAonly", 113: "128x64 noMFMA", 213: "128x64 noDMA", 313: "128x64 DMAonly"}
 
 
 def run(cfgs=None):
@@ -61,7 +65,7 @@ def run(cfgs=None):
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / n
-            line += "\n      %-20s %6.1fus %5.0fTF%s" % (name, us, 2.0 * M * N * K / us / 1e6, "" if (err < 1e-4 or 100 <= cfg < 300) else " ERR %.1e" % err)
+            line += "\n      %-20s %6.1fus %5.0fTF%s" % (name, us, 2.0 * M * N * K / us / 1e6, "" if (err < 1e-4 or 100 <= cfg < 600) else " ERR %.1e" % err)
         print(line, flush=True)
 
 

@@ -25,6 +25,8 @@ BIG = [(6912, 3072, 768), (6912, 768, 3072), (6912, 768, 768), (6912, 2304, 768)
        (1824, 3072, 768), (6272, 768, 512)]
 CANDS_BIG = [15, 36, 60, 61, 62, 63, 64, 16]        # BK = 32 tiles, all with tiled weight planes
 CANDS_THIN = [43, 8, 13, 21, 50, 52, 53, 55, 56, 6, 9, 15]
+MID = [(6912, 768, 768), (6912, 768, 3072), (6912, 3072, 768), (6272, 768, 512), (2560, 1536, 768)]
+CANDS_MID = [65, 66, 70]                        # round 6: one fat workgroup per CU, deeper rings (80-120 KB in flight)
 ATT_BIG = [9, 3, 20, 21, 22, 23, 24, 25]
 ATT_SMALL = [5, 1, 15, 18]
 
@@ -99,8 +101,10 @@ def main():
                         torch.cuda.synchronize()
                 print(line, flush=True)
             continue
-        shapes = THIN if mode == "thin" else (BIG if mode == "big" else list(SHAPES))
-        cands = CANDS_THIN if mode == "thin" else (CANDS_BIG if mode == "big" else CANDS_ALL)
+        shapes = THIN if mode == "thin" else (BIG if mode == "big" else (MID if mode == "mid" else list(SHAPES)))
+        cands = CANDS_THIN if mode == "thin" else (CANDS_BIG if mode == "big" else (CANDS_MID if mode == "mid" else CANDS_ALL))
+        if mode == "thin6":
+            shapes, cands = [(1824, 768, 768), (1824, 768, 3072), (2560, 512, 768)], [71, 75]
         for (M, N, K) in shapes:
             what, cnt = SHAPES[(M, N, K)]
             line = "%5d x %4d x %4d  %-18s x%2d |" % (M, N, K, what, cnt)
