@@ -103,6 +103,18 @@ class GMapNavAgent:
         return self.vln_bert(mode, batch)
 
     # ---- collation -----------------------------------------------------------------------------
+    def _upload(self, a):
+        """Host array -> device tensor that owns its memory, through the collator's pinned ring (one asynchronous copy; a
+        `torch.from_numpy(a).to(device)` is a pageable upload that waits for the whole stream)."""
+        st = self.collator.stage
+        if not st.cuda:
+            return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        st.flush()
+        st.owned = True
+        t = st.put(a)
+        st.flush()
+        return t
+
     def _language_variable(self, obs):
         lens = [len(ob["instr_encoding"]) for ob in obs]
         seq = np.zeros((len(obs), max(lens)), dtype=np.int64)
@@ -110,7 +122,7 @@ class GMapNavAgent:
         for i, ob in enumerate(obs):
             seq[i, :lens[i]] = ob["instr_encoding"]
             mask[i, :lens[i]] = True
-        return {"txt_ids": torch.from_numpy(seq).to(self.device), "txt_masks": torch.from_numpy(mask).to(self.device)}
+        return {"txt_ids": self._upload(seq), "txt_masks": self._upload(mask)}
 
     def _panorama_feature_variable(self, obs):
         fs = self.args.image_feat_size
@@ -229,7 +241,8 @@ class GMapNavAgent:
                         if d < best_d:
                             best_d, best = d, j
                 a[i] = best
-        return torch.from_numpy(a).to(self.device)
+        self._teacher_host = a                      # (the loop needs the actions on the host too: no read-back)
+        return self._upload(a)
 
     def make_equiv_action(self, a_t, gmaps, obs, traj):
         for i, ob in enumerate(obs):
@@ -305,6 +318,12 @@ class GMapNavAgent:
         ended = np.array([False] * B)
         just_ended = np.array([False] * B)
         ml_loss = 0.0
+        # Teacher-forced training rollouts need nothing from the device to go on: the actions come from the ground-truth path.
+        # The stop probabilities (read every step by the reference, agent.py:353-356, for the best-stop-node bookkeeping of
+        # `traj`) stay on the device and are resolved after the loop -- or not at all inside train(), which discards `traj` --
+        # so the host never waits for the stream and can run a whole iteration ahead of the device.
+        lazy = train_ml is not None and self.feedback == "teacher" and self.trace is None and self.device.type == "cuda"
+        pending = []
 
         for t in range(self.args.max_action_len):
             self.nav_steps = getattr(self, "nav_steps", 0) + 1
@@ -361,18 +380,25 @@ class GMapNavAgent:
                 a_t = nav_logits.max(1)[1].detach()
                 both = torch.stack([nav_probs[:, 0].detach().double(), a_t.double()]).cpu().numpy()
                 stop_probs, a_t_pre = both[0].astype(np.float32), both[1].astype(np.int64)
+            elif lazy:
+                a_t_pre, stop_probs = None, None
+                pending.append({"probs": nav_probs[:, 0].detach(), "vps": [ob["viewpoint"] for ob in obs],
+                                "active": ~ended, "ended_now": []})
             else:
                 a_t_pre = None
                 stop_probs = nav_probs[:, 0].detach().cpu().numpy()   # one D2H per step (reference: B .item() calls)
-            for i, gmap in enumerate(gmaps):
-                if not ended[i]:
-                    gmap.stop_score[obs[i]["viewpoint"]] = {"stop": float(stop_probs[i])}
+            if stop_probs is not None:
+                for i, gmap in enumerate(gmaps):
+                    if not ended[i]:
+                        gmap.stop_score[obs[i]["viewpoint"]] = {"stop": float(stop_probs[i])}
 
             nav_targets = None
             if train_ml is not None or self.feedback == "teacher":
-                nav_targets = self._teacher_action(
-                    obs, nav_vpids, ended,
-                    visited_masks=nav_inputs["gmap_visited_masks"].cpu().numpy() if self.args.fusion != "local" else None)
+                vm = None
+                if self.args.fusion != "local":          # (the batched collator hands the mask over on the host as well)
+                    vm = nav_inputs.get("gmap_visited_masks_host")
+                    vm = nav_inputs["gmap_visited_masks"].cpu().numpy() if vm is None else vm
+                nav_targets = self._teacher_action(obs, nav_vpids, ended, visited_masks=vm)
             if train_ml is not None:
                 ml_loss = ml_loss + F.cross_entropy(nav_logits, nav_targets, ignore_index=self.args.ignoreid,
                                                     reduction="sum")
@@ -401,7 +427,7 @@ class GMapNavAgent:
 
             if self.feedback in ("teacher", "sample"):
                 a_t_stop = [ob["viewpoint"] == ob["gt_path"][-1] for ob in obs]
-                a_t_host = a_t.cpu().numpy()
+                a_t_host = self._teacher_host if self.feedback == "teacher" else a_t.cpu().numpy()
             elif a_t_pre is not None:
                 a_t_host, a_t_stop = a_t_pre, a_t_pre == 0
             else:
@@ -423,6 +449,9 @@ class GMapNavAgent:
             self.make_equiv_action(cpu_a_t, gmaps, obs, traj)
             for i in range(B):
                 if (not ended[i]) and just_ended[i]:
+                    if lazy:
+                        pending[-1]["ended_now"].append(i)
+                        continue
                     stop_node, stop_score = None, {"stop": -float("inf")}
                     for k, v in gmaps[i].stop_score.items():
                         if v["stop"] > stop_score["stop"]:
@@ -444,11 +473,33 @@ class GMapNavAgent:
             if ended.all():
                 break
 
+        if pending and not getattr(self, "_defer_host_reads", False):
+            self._resolve_stops(pending, gmaps, traj)      # ONE read-back for the whole rollout (train() skips even that)
         if train_ml is not None:
             ml_loss = ml_loss * train_ml / B
             self.loss = self.loss + ml_loss
-            self.logs["IL_loss"].append(float(ml_loss.detach()) if torch.is_tensor(ml_loss) else float(ml_loss))
+            if torch.is_tensor(ml_loss) and getattr(self, "_defer_host_reads", False):
+                self._pending_logs.append(ml_loss.detach())           # train() converts them once, after its last iteration
+            else:
+                self.logs["IL_loss"].append(float(ml_loss.detach()) if torch.is_tensor(ml_loss) else float(ml_loss))
         return traj
+
+    @staticmethod
+    def _resolve_stops(pending, gmaps, traj):
+        """The stop-score bookkeeping of agent.py:353-356 / 425-436 for a rollout whose per-step stop probabilities were left
+        on the device: replayed in step order from one read-back (an ended episode's map and trajectory do not change after
+        its last step, so the deferred back-track to the best stop node appends the same route)."""
+        probs = torch.stack([r["probs"] for r in pending]).float().cpu().numpy()
+        for r, pr in zip(pending, probs):
+            for i in np.nonzero(r["active"])[0]:
+                gmaps[i].stop_score[r["vps"][i]] = {"stop": float(pr[i])}
+            for i in r["ended_now"]:
+                stop_node, stop_score = None, {"stop": -float("inf")}
+                for k, v in gmaps[i].stop_score.items():
+                    if v["stop"] > stop_score["stop"]:
+                        stop_score, stop_node = v, k
+                if stop_node is not None and r["vps"][i] != stop_node:
+                    traj[i]["path"].append(gmaps[i].route(r["vps"][i], stop_node))
 
     @staticmethod
     def interleaved_rollouts(agents, streams=None):
@@ -570,6 +621,23 @@ class GMapNavAgent:
         self._set_mode(True)
         self.losses = []
         from . import autograd as ag
+        # no device read-back inside the loop: the losses / IL logs of all iterations are fetched once at the end, so the host
+        # issues iteration i + 1's forward while the device is still in iteration i's backward (GRIDMM_TRAIN_SYNC=1: per-iteration
+        # read-back as before, A/B)
+        self._defer_host_reads = os.environ.get("GRIDMM_TRAIN_SYNC", "0") in ("", "0")
+        self._pending_logs, dev_losses = [], []
+        try:
+            self._train_iterations(n_iters, ag, dev_losses)
+        finally:
+            self._defer_host_reads = False
+            if self._pending_logs:
+                self.logs["IL_loss"].extend(float(v) for v in torch.stack([x.float() for x in self._pending_logs]).cpu())
+            self._pending_logs = []
+        if dev_losses:
+            self.losses = [float(v) for v in torch.stack([x.float() for x in dev_losses]).cpu()]
+        return self.losses
+
+    def _train_iterations(self, n_iters, ag, dev_losses):
         for _ in range(n_iters):
             self.vln_bert_optimizer.zero_grad()
             self.loss = 0
@@ -596,5 +664,7 @@ class GMapNavAgent:
             else:
                 torch.nn.utils.clip_grad_norm_(self.vln_bert.parameters(), 40.0)
                 self.vln_bert_optimizer.step()
-            self.losses.append(float(self.loss.detach()))
-        return self.losses
+            if self._defer_host_reads and torch.is_tensor(self.loss):
+                dev_losses.append(self.loss.detach())
+            else:
+                self.losses.append(float(self.loss.detach()) if torch.is_tensor(self.loss) else float(self.loss))

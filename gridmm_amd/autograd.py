@@ -316,6 +316,7 @@ class _DeferredGrads:
     def __init__(self):
         self.active = False
         self.pending = {}            # id(param) -> (param, [gradients in production order])
+        self.streams = set()         # streams the kept gradients were produced on (autograd runs a node on its forward's stream)
 
     def hand(self, param, g):
         if g is None or not self.active:
@@ -324,6 +325,7 @@ class _DeferredGrads:
                 and param.dtype == torch.float32 and g.shape == param.shape and g.is_contiguous()):
             return g
         self.pending.setdefault(id(param), (param, []))[1].append(g)
+        self.streams.add(torch.cuda.current_stream(g.device))
         return None
 
 
@@ -338,6 +340,7 @@ def deferred_param_grads():
         yield
     except BaseException:
         DEFERRED.pending.clear()        # a backward that raised half-way: its gradients must not reach the next flush
+        DEFERRED.streams.clear()
         raise
     finally:
         DEFERRED.active = prev
@@ -349,6 +352,14 @@ def flush_param_grads():
     import numpy as np
     items = list(DEFERRED.pending.values())
     DEFERRED.pending.clear()
+    # deferred gradients bypass AccumulateGrad, hence also autograd's end-of-backward sync of the caller's stream with the
+    # streams its nodes ran on: order the summing launch behind every producing stream (a no-op for single-stream loops)
+    if DEFERRED.streams:
+        cur = torch.cuda.current_stream()
+        for st in DEFERRED.streams:
+            if st != cur:
+                cur.wait_stream(st)
+        DEFERRED.streams.clear()
     work = []
     for prm, gs in items:
         if prm.grad is None:
@@ -397,8 +408,13 @@ def _tag_planes(y, hi, lo):
 
 
 def _take_planes(x, M, K):
+    """Planes a producer hung on x, as the A operand of a Linear -- never SHIFTED ones (a k | v or q | k | v projection tagged
+    by linear(..., out_planes=<int c0>): its planes hold x - x[row 0 of the episode] for the columns >= c0, which only the
+    attention kernels may read; a Linear over such a tensor splits x itself)."""
     p = getattr(x, "_gridmm_planes", None)
     if p is None or p[2] != x._version or not x.is_contiguous() or p[0].numel() != M * K or p[0].shape[-1] != K:
+        return None
+    if getattr(x, "_gridmm_shift", None) is not None:
         return None
     return p[0].view(M, K), p[1].view(M, K)
 

@@ -35,6 +35,11 @@ class _Stager:
     def __init__(self, device, nbytes=1 << 20, ring=3):
         self.device, self.cuda = torch.device(device), torch.device(device).type == "cuda"
         self.ring, self.pos, self.used = [], 0, 0
+        # owned = True: the views handed out by put() are slices of a FRESH device allocation per flush cycle (they own it and
+        # are never overwritten) instead of the slot's recycled mirror -- for rollouts under autograd, whose backward reads the
+        # inputs of every step after the ring has come round many times.  Same single asynchronous copy per flush: the host
+        # never waits for the stream, so a training loop can run ahead of the device (agent.train).
+        self.owned, self._cycle_owned, self._own = False, False, None
         if self.cuda:
             for _ in range(ring):
                 self.ring.append([torch.empty(nbytes, dtype=torch.uint8).pin_memory(),
@@ -43,23 +48,43 @@ class _Stager:
     def _slot(self):
         return self.ring[self.pos]
 
+    MAX_RING = 64
+
+    def _begin_cycle(self):
+        host, dev, ev = self._slot()
+        if ev is not None and not ev.query() and len(self.ring) < self.MAX_RING:
+            # the copy issued from this slot has not run yet (a training loop whose host is a whole iteration ahead of the
+            # device): a new slot here instead of a wait
+            n = host.numel()
+            self.ring.insert(self.pos, [torch.empty(n, dtype=torch.uint8).pin_memory(),
+                                        torch.empty(n, dtype=torch.uint8, device=self.device), None])
+            host, dev, ev = self._slot()
+        if ev is not None:
+            ev.synchronize()                          # the copy issued from this slot `ring` flushes ago has completed
+        self._cycle_owned = self.owned
+        self._own = torch.empty(host.numel(), dtype=torch.uint8, device=self.device) if self.owned else None
+
     def put(self, a):
         a = np.ascontiguousarray(a)
         if not self.cuda:
             return torch.from_numpy(a.copy())
         t = torch.from_numpy(a)
         n = a.nbytes
+        if self.used and self._cycle_owned != self.owned:
+            self.flush()                              # (a cycle is either recycled or owned)
         o = (self.used + 15) // 16 * 16
-        host, dev, ev = self._slot()
+        host = self._slot()[0]
         if o + n > host.numel():
             self.flush()                              # (a step that outgrows the slot: ship what is there, start the next slot)
-            host, dev, ev = self._slot()
-            if n > host.numel():
-                self.ring[self.pos][0] = host = torch.empty(2 * n, dtype=torch.uint8).pin_memory()
-                self.ring[self.pos][1] = dev = torch.empty(2 * n, dtype=torch.uint8, device=self.device)
+            if n > self._slot()[0].numel():
+                self.ring[self.pos][0] = torch.empty(2 * n, dtype=torch.uint8).pin_memory()
+                self.ring[self.pos][1] = torch.empty(2 * n, dtype=torch.uint8, device=self.device)
             o = 0
-        if self.used == 0 and ev is not None:
-            ev.synchronize()                          # the copy issued from this slot three flushes ago has completed
+        if self.used == 0:
+            self._begin_cycle()
+        host, dev, _ = self._slot()
+        if self._cycle_owned:
+            dev = self._own
         if n:
             host[o:o + n].view(t.dtype).view(t.shape).copy_(t)
         self.used = o + n
@@ -69,11 +94,13 @@ class _Stager:
         if not self.cuda or self.used == 0:
             return
         host, dev, _ = self._slot()
+        if self._cycle_owned:
+            dev = self._own
         dev[:self.used].copy_(host[:self.used], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.ring[self.pos][2] = ev
-        self.pos, self.used = (self.pos + 1) % len(self.ring), 0
+        self.pos, self.used, self._own = (self.pos + 1) % len(self.ring), 0, None
 
 
 class NavCollator:
@@ -118,8 +145,9 @@ class NavCollator:
     #                         steps for backward; traced rollouts keep them for inspection) instead of a view of the ring
 
     def _dev(self, a):
-        if self.keep_inputs or torch.is_grad_enabled():
-            return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        # under autograd (or when the caller keeps the inputs) the views own their device memory; either way the bytes travel
+        # through the pinned ring in ONE asynchronous copy per flush -- never a pageable (stream-synchronising) upload
+        self.stage.owned = bool(self.keep_inputs or torch.is_grad_enabled())
         return self.stage.put(a)
 
     # ---- agent.py:51-94 ---------------------------------------------------------------------------
@@ -225,9 +253,17 @@ class NavCollator:
                 else:
                     P["key_of"][sl], P["cands"][sl], P["lens"][sl] = k, cands, n
             contiguous = fresh == list(range(fresh[0], fresh[0] + m))
-            ix = None if contiguous else torch.from_numpy(np.asarray(fresh, dtype=np.int64)).to(self.device)
+            # first sight of a viewpoint: its collated block goes up through the pinned ring too (asynchronous); owned device
+            # memory, because the four uploads below span more flush cycles than the ring has recycled mirrors
+            self.stage.owned = True
+            ix = None if contiguous else self.stage.put(np.asarray(fresh, dtype=np.int64))
+            srcs = {}
             for name, a in (("img", img), ("loc", loc), ("types", types)):
-                src = torch.from_numpy(a).to(self.device)              # (first sight of a viewpoint: a blocking upload)
+                self.stage.flush()                                     # (blocks of up to B panoramas: one slot each)
+                srcs[name] = self.stage.put(a)
+            self.stage.flush()
+            for name in ("img", "loc", "types"):
+                src = srcs[name]
                 if contiguous:
                     P[name][fresh[0]:fresh[0] + m].copy_(src)
                 else:
@@ -238,6 +274,7 @@ class NavCollator:
         self._view_lens = lens
         V = self._bucket(int(lens.max()), self.view_buckets)
         sd, ld = self._dev(slots), self._dev(lens)
+        ld._gridmm_host_max = int(lens.max())           # the mask width, known here: the model need not read it back
         self.stage.flush()
         if V > P["vmax"]:                                               # (a view bucket wider than the table rows)
             pad = lambda t: torch.nn.functional.pad(t, (0, 0, 0, V - t.shape[1]) if t.dim() == 3 else (0, V - t.shape[1]))   # noqa: E731
@@ -428,6 +465,7 @@ class NavCollator:
             "gmap_pair_dists": self._dev(pair), "gmap_masks": self._dev(gmask.view(np.bool_)),
             "no_vp_left": [bool(v == 0) for v in n_unv],
             "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),
+            "gmap_visited_masks_host": visited.view(np.bool_),      # (the teacher's action needs it on the host)
         }
         out = self._vp_part(out, pano_embeds, cand_vpids, view_lens, nav_types, vpos)
         self.stage.flush()                         # every host array of the step: one asynchronous upload
@@ -532,7 +570,7 @@ class NavCollator:
         slot_d, inv_d = self._dev(slot), self._dev(inv)
         out = {
             "gmap_vpids": vpids, "gmap_img_embeds": None, "gmap_step_ids": self._dev(steps),
-            "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited),
+            "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited), "gmap_visited_masks_host": np.asarray(visited, dtype=bool),
             "gmap_pair_dists": self._dev(pair),
             "gmap_masks": self._dev(np.arange(G)[None] < lens[:, None]), "no_vp_left": [bool(v == 0) for v in n_unv],
             "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),
@@ -631,7 +669,7 @@ class NavCollator:
         slot_d, inv_d = self._dev(slot), self._dev(inv)
         out = {
             "gmap_vpids": vpids, "gmap_img_embeds": None, "gmap_step_ids": self._dev(steps),
-            "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited),
+            "gmap_pos_fts": self._dev(gpos), "gmap_visited_masks": self._dev(visited), "gmap_visited_masks_host": np.asarray(visited, dtype=bool),
             "gmap_pair_dists": self._dev(pair),
             "gmap_masks": self._dev(np.arange(G)[None] < lens[:, None]), "no_vp_left": no_vp_left,
             "fusion_maps": (self._dev(cand_of_node), self._dev(cand_visited)),

@@ -150,11 +150,33 @@ class DeviceStore:
         """PackedStore (mmap) -> HBM, one upload."""
         return cls(store.keys, store.tokens, store.depth, [tuple(store.pose[i]) for i in range(store.n)], device)
 
+    def _upload_index(self, ids):
+        """Row ids -> device through a small ring of pinned buffers (asynchronous: a `torch.tensor(ids, device=...)` is a pageable
+        upload, i.e. the host would wait for everything queued on the stream -- a whole backward pass in a training loop)."""
+        import torch
+        if torch.device(self.device).type != "cuda":
+            return torch.tensor(ids, dtype=torch.int64, device=self.device)
+        ring = getattr(self, "_idx_ring", None)
+        if ring is None or ring[0][0].numel() < len(ids):
+            ring = self._idx_ring = [[torch.empty(max(len(ids), 64), dtype=torch.int64).pin_memory(), None] for _ in range(16)]
+            self._idx_pos = 0
+        host, ev = ring[self._idx_pos]
+        if ev is not None:
+            ev.synchronize()
+        host[:len(ids)] = torch.as_tensor(ids, dtype=torch.int64)
+        dev = torch.empty(len(ids), dtype=torch.int64, device=self.device)
+        dev.copy_(host[:len(ids)], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[self._idx_pos][1] = ev
+        self._idx_pos = (self._idx_pos + 1) % len(ring)
+        return dev
+
     def append(self, mem, keys):
         """Write the observations of `keys` (one per episode of the lock-step batch) into mem.next_slot(); returns
         (depth (B, pts) device tensor, [(x, y)] host floats) for mem.step(depth, None, poses, headings)."""
         import torch
-        idx = torch.tensor([self.index[k] for k in keys], dtype=torch.int64, device=self.device)
+        idx = self._upload_index([self.index[k] for k in keys])
         slot = mem.next_slot()
         slot.copy_(self.tokens.index_select(0, idx).view(slot.shape))       # device-side gather, no PCIe
         d = self.depth.index_select(0, idx)

@@ -81,6 +81,14 @@ class GridMemoryBatch:
         self.act_d.fill_(1)
         self._active = None
         self._h2d_done = None
+        # A RING of pinned host buffers behind the one device buffer (the device side is overwritten in stream order; only a
+        # pinned source has to outlive its copy): with a single buffer set_pose() waits for the previous step's copy, which sits
+        # behind everything queued before it -- in a training loop the whole backward of the previous iteration.  Slot 0 is the
+        # buffer above; callers that claimed bytes of its EXTRA area (stage_extra) keep the single-buffer behaviour.
+        self._views_of = views
+        self._stage_ring = [[self._stage_host, None]]
+        self._stage_pos = 0
+        self.STAGE_RING = 16
         self._cmax_event = None
         self._cmax_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._cmax_host = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(1, dtype=torch.int32)
@@ -120,7 +128,17 @@ class GridMemoryBatch:
         """poses: B x (x, y) python floats (viewpoint_info, env.py:286); headings: B python floats.
         Rounded to fp32 on the host exactly as NumPy does (env.py:118-120, 344-348)."""
         self._cmax_event = None                   # a new pose re-bins the memory: the tracked cell count is stale
-        if self._h2d_done is not None:
+        if self._stage_used == self._stage_extra_off and self.device.type == "cuda":
+            # next slot of the pinned ring: wait only for the copy issued from THAT slot, STAGE_RING steps ago
+            self._stage_pos = (self._stage_pos + 1) % self.STAGE_RING
+            if self._stage_pos == len(self._stage_ring):
+                self._stage_ring.append([torch.zeros(self._stage_host.numel(), dtype=torch.uint8).pin_memory(), None])
+            buf, ev = self._stage_ring[self._stage_pos]
+            if ev is not None:
+                ev.synchronize()
+            self._stage_host = buf
+            self._pose_host, self._head_host, self._act_host, self._vcos_host, self._vsin_host = self._views_of(buf)
+        elif self._h2d_done is not None:
             self._h2d_done.synchronize()          # the previous step's async H2D has consumed the pinned buffers
         # whole-array writes into the pinned buffers; cos / sin stay libm scalars in double (math.cos, as the reference
         # computes them) and are rounded to fp32 once, exactly like np.float32(math.cos(a))
@@ -141,6 +159,7 @@ class GridMemoryBatch:
         if self.device.type == "cuda":
             self._h2d_done = torch.cuda.Event()
             self._h2d_done.record()
+            self._stage_ring[self._stage_pos][1] = self._h2d_done
 
     def stage_extra(self, nbytes):
         """(pinned host view, device view) of `nbytes` of the staging buffer's caller area: whatever the caller writes into

@@ -199,7 +199,10 @@ def forward_panorama(model, view_img_fts, obj_img_fts, loc_fts, nav_types, view_
     x = ag.add_row(x + y + ag.small_embedding(nav_types, ie.nav_type_embedding.weight),
                    model.embeddings.token_type_embeddings.weight, 1)
     x = _drop(model, ag.layer_norm(x, ie.layer_norm))
-    masks = torch.arange(hs.host(lambda: int(lens.max())), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
+    # the mask width is max(lens): a host decision -- the batched collator knows it (collate.NavCollator tags view_lens), any
+    # other caller costs one read-back
+    width = getattr(lens, "_gridmm_host_max", None)
+    masks = torch.arange(hs.host(lambda: int(lens.max()) if width is None else int(width)), device=lens.device).unsqueeze(0) < lens.unsqueeze(1)
     if ie.pano_encoder is not None:
         x = pre_ln_encoder(model, ie.pano_encoder, x, masks)
     return x, masks

@@ -397,6 +397,21 @@ def pretrain_full_batch(task):
                                  image_prob_size=1000, n_pts=(300, 900))
 
 
+# pretrain_reduced_notie.npz: small grid memories (40-64 points per episode) from batch seeds (oracle/search_relevance_ties.py) for
+# which NO point's two best instruction tokens are closer than 4x the difference between the reference's fp16 relevance product and
+# the same product with un-rounded text features: the arg-max routing of the relevance maximum (pretrain_src/model/vilmodel.py:
+# 685-690) is then the same for every correct implementation, and text_proj's gradient can be pinned like any other parameter's
+# (mlm: best of seeds 1000-1299 by min top-2 gap / discrepancy; mrc: best of 1300-2400 that ALSO clears the ReLU gate of
+# RegionClassification by 7.8e-4, see PRETRAIN_SEEDS above; sap: best of 1000-4999 whose ClsPrediction ReLU pre-activations
+# (pretrain_cmt.py:24-36: ~10^5 values per batch) ALSO all clear zero by 6.2e-5 -- those heads run in fp32 on both sides, so
+# a gate can only flip inside the ~1e-5 difference of two fp32 implementations)
+PRETRAIN_NOTIE_SEEDS = {"mlm": 1100, "mrc": 2331, "sap": 1871}
+
+
+def pretrain_notie_batch(task):
+    return S.make_pretrain_batch(np.random.RandomState(PRETRAIN_NOTIE_SEEDS[task]), 3, task, n_pts=(40, 64))
+
+
 def grad_sample_index(name, numel):
     """Seeded positions at which a parameter's gradient is recorded."""
     import zlib
@@ -404,7 +419,7 @@ def grad_sample_index(name, numel):
     return rs.randint(0, numel, size=min(GRAD_SAMPLES, numel))
 
 
-def gen_pretrain(with_obj=False, full=False):
+def gen_pretrain(with_obj=False, full=False, notie=False):
     """GlocalTextPathCMTPreTraining.forward(batch, task) (pretrain_cmt.py:71-321) in train-step form
     (train_r2r.py:245-262): per-sample loss vectors, then loss.mean().backward(): per-parameter gradient norm,
     seeded samples of every gradient, and the set of parameters that received none.
@@ -416,11 +431,34 @@ def gen_pretrain(with_obj=False, full=False):
            "param_names": json.dumps([k for k, _ in model.named_parameters()]),
            "param_dtypes": json.dumps({k: str(v.dtype) for k, v in model.state_dict().items()})}
     for task in (("mrc", "sap", "og") if with_obj else ("mlm", "mrc", "sap")):
-        batch = pretrain_full_batch(task) if full else pretrain_batch(task, with_obj)
+        batch = pretrain_notie_batch(task) if notie else (pretrain_full_batch(task) if full else pretrain_batch(task, with_obj))
+        from oracle.search_relevance_ties import relevance_ties
+        ties, pts, gap, disc = relevance_ties(model, batch, task)
+        out["relevance_ties_" + task] = np.array([ties, pts], np.int64)              # near-tie points / points of the batch
+        out["relevance_gap_" + task] = np.array([gap, disc], np.float32)             # min top-2 gap, max product discrepancy
+        if notie:
+            assert ties == 0, (task, ties, pts)
         model.zero_grad()
+        # the reference's backward through the fp16 grid path (grid_proj output, softmax weights, per-cell sums are half tensors,
+        # pretrain_src/model/vilmodel.py:690-703): how much of d(loss)/d(grid_proj output) lies in fp16's subnormal range -- the
+        # precision text_proj's gradient inherits, whatever the arg-max routing does
+        sub = []
+
+        def _fp16_grad_stats(mod, gin, gout):
+            a = gout[0].detach().float().abs()
+            nz = a[a > 0]
+            sub.append([float(a.max()), float(nz.median()) if nz.numel() else 0.0, float((a == 0).float().mean()),
+                        float(((a > 0) & (a < 6.1e-5)).float().mean())])
+        import warnings
+        hk = model.bert.grid_proj.register_full_backward_hook(_fp16_grad_stats)
         loss = model(batch, task=task, compute_loss=True)
         out["loss_" + task] = loss.detach().float().numpy()
-        loss.mean().backward()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss.mean().backward()
+        hk.remove()
+        sub = np.array(sub, np.float64)      # per episode: max |g|, median nonzero |g|, share exactly zero, share subnormal
+        out["fp16_grad_" + task] = np.array([sub[:, 0].max(), np.median(sub[:, 1]), sub[:, 2].mean(), sub[:, 3].mean()], np.float32)
         names, norms, samples = [], [], []
         for k, p in model.named_parameters():
             if p.grad is None:
@@ -434,6 +472,8 @@ def gen_pretrain(with_obj=False, full=False):
         out["grad_samples_" + task] = np.concatenate(samples).astype(np.float32)
         print(task, "loss", out["loss_" + task], "params with grad", len(names))
     name = "pretrain_full_b2.npz" if full else ("pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz")
+    if notie:
+        name = "pretrain_reduced_notie.npz"
     np.savez_compressed(os.path.join(OUT, name), **out)
 
 
@@ -710,7 +750,7 @@ def gen_policy_ce():
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "topo", "optim", "backbone", "clip", "policyce"]
+    which = sys.argv[1:] or ["fill", "nav", "navobj", "full", "textpano", "rollout", "vlnce", "pretrain", "navvlnce", "panoobj", "pretrainobj", "pretrainnotie", "topo", "optim", "backbone", "clip", "policyce"]
     if "rollout" in which: gen_rollout()
     if "rolloutfull" in which: gen_rollout(full=True)
     if "topo" in which: gen_topo_map()
@@ -731,3 +771,4 @@ if __name__ == "__main__":
     if "panoobj" in which: gen_pano_obj()
     if "pretrainobj" in which: gen_pretrain(True)
     if "pretrainfull" in which: gen_pretrain(full=True)
+    if "pretrainnotie" in which: gen_pretrain(notie=True)

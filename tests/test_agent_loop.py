@@ -113,6 +113,53 @@ def test_dagger_training_iterations_on_hip():
     assert len(res) == B and all(len(r["trajectory"]) >= 1 for r in res)
 
 
+@pytest.mark.gpu
+def test_training_loop_without_read_backs_equals_the_synchronous_loop(monkeypatch):
+    """Round 6: a teacher-forced training rollout issues no device read-back (stop probabilities stay on the device, the
+    teacher's inputs come from the collator's host arrays, every upload goes through pinned rings), and train() fetches the
+    losses once at the end -- the host runs an iteration ahead of the device.  Same arithmetic in the same order: losses, IL
+    logs and parameters must be BIT-identical to the loop that reads back every step and every iteration
+    (GRIDMM_TRAIN_SYNC=1 + traced rollouts), and a rollout called directly returns the same trajectories either way
+    (the deferred stop-score bookkeeping, agent._resolve_stops)."""
+    from gridmm_amd.agent import GMapNavAgent, default_args
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    from gridmm_amd.sim_env import SyntheticNavEnv
+    from gridmm_amd.synthetic import NATIVE
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+
+    def make():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = default_config(num_l_layers=2, num_pano_layers=1, num_x_layers=2, intermediate_size=256, vocab_size=2000,
+                             hidden_dropout_prob=0.0)
+        model = GlocalTextPathNavCMT(cfg).cuda()
+        mem = GridMemoryBatch(4, NATIVE, max_steps=9, device="cuda")
+        env = SyntheticNavEnv(4, mem, n_scans=2, n_episodes=12, seed=3)
+        return GMapNavAgent(default_args(max_action_len=7, train_alg="imitation", lr=2e-4), env, model, device="cuda"), model
+
+    monkeypatch.setenv("GRIDMM_TRAIN_SYNC", "1")
+    a, ma = make()
+    la = a.train(5)
+    monkeypatch.setenv("GRIDMM_TRAIN_SYNC", "0")
+    b, mb = make()
+    lb = b.train(5)
+    assert la == lb and len(la) == 5 and all(np.isfinite(la)), (la, lb)
+    assert a.logs["IL_loss"] == b.logs["IL_loss"] and len(b.logs["IL_loss"]) == 5
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(p, q), k
+    # a direct teacher-forced rollout: deferred (one read-back at the end) vs per-step bookkeeping (a traced rollout)
+    a.feedback = b.feedback = "teacher"
+    a.env.reset_epoch(); b.env.reset_epoch()
+    a.loss = b.loss = 0
+    a.trace = []                                     # traced rollouts read the stop probabilities every step
+    torch.manual_seed(5)                             # (the environment feature dropout of VLNBert.train draws from the global RNG)
+    ta = a.rollout(train_ml=1.0)
+    torch.manual_seed(5)
+    tb = b.rollout(train_ml=1.0)
+    assert ta == tb and any(len(t["path"]) > 1 for t in tb)
+    assert float(a.loss) == float(b.loss)
+
+
 class _StubMem:
     slab = True
 
@@ -170,7 +217,9 @@ def test_batched_collation_equals_the_per_episode_restatement(over):
     assert len(a) == len(b) >= 5 and ta == tb
     for x, y in zip(a, b):
         for part in ("pano_inputs", "nav_inputs"):
-            assert set(x[part]) == set(y[part]) - {"fusion_maps"}
+            assert set(x[part]) == set(y[part]) - {"fusion_maps", "gmap_visited_masks_host"}
+            if part == "nav_inputs":     # the host mirror the batched collator adds (teacher actions without a read-back)
+                assert np.array_equal(np.asarray(y[part]["gmap_visited_masks_host"]), y[part]["gmap_visited_masks"].numpy())
             for k, v in x[part].items():
                 w = y[part][k]
                 if torch.is_tensor(v):
@@ -241,6 +290,8 @@ def test_native_navigation_collation_equals_the_numpy_form():
                         assert torch.allclose(v, w, atol=2e-7, rtol=2e-7), (k, float((v - w).abs().max()))
                     else:
                         assert torch.equal(v, w), k
+                elif isinstance(v, np.ndarray):
+                    assert np.array_equal(v, w), k
                 elif k != "grid_memory":
                     assert v == w, k
 

@@ -135,7 +135,7 @@ def _ctype_of(c_type):
     import ctypes
     table = {"ptr": ctypes.c_void_p, "gridmm_stream_t": ctypes.c_void_p, "int": ctypes.c_int, "int32_t": ctypes.c_int,
              "float": ctypes.c_float, "int64_t": ctypes.c_int64, "long long": ctypes.c_int64, "size_t": ctypes.c_size_t,
-             "uint64_t": ctypes.c_uint64, "unsigned": ctypes.c_uint, "unsigned int": ctypes.c_uint, "uint32_t": ctypes.c_uint,
+             "uint64_t": ctypes.c_uint64, "unsigned long long": ctypes.c_uint64, "unsigned": ctypes.c_uint, "unsigned int": ctypes.c_uint, "uint32_t": ctypes.c_uint,
              "double": ctypes.c_double}
     assert c_type in table, "no ctypes mapping for C type %r" % c_type
     return table[c_type]

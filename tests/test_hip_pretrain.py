@@ -15,6 +15,20 @@ reduced fixture sat within 1e-4 of zero (perturbing the REFERENCE's own weights 
 2-8 %), and mrc was checked at 1e-1 + cosine.  Round 4 regenerated the reduced mrc fixtures from batch seeds whose
 pre-activations all clear the gate by >= 1.05e-3 / 6.6e-4 (oracle/search_pretrain_seeds.py, gen_golden.PRETRAIN_SEEDS): no
 gate can flip, and mrc is pinned elementwise at 5e-3 like every other task (the cosine check stays).
+
+text_proj, round 6 -- two causes, separated.  (i) Arg-max near-ties: the fixtures carry the number of grid points whose two
+best instruction tokens are closer than 4x the difference between the reference's half x half relevance product and the same
+product with un-rounded text features (`relevance_ties_<task>` = [near-tie points, points], oracle/search_relevance_ties.py):
+14-29 of 1 000-1 500 points in the reduced fixtures, HALF of the points at the released size (9-layer text encoder: the token
+features are nearly parallel).  pretrain_reduced_notie.npz (40-64 points per episode, batch seeds searched for ZERO near-ties,
+min top-2 gap 5.8 .. 12.4x the discrepancy; sap / mrc seeds also clear every ReLU gate) removes that cause: text_proj.weight
+comes out at 5.4e-3 (mlm), < 5e-3 (mrc) -- and still 1.1e-2 for sap.  (ii) The reference's backward through the grid path runs
+in fp16 (grid_proj output, softmax weights and per-cell sums are half tensors, pretrain_src/model/vilmodel.py:690-703), and
+d(loss)/d(grid_proj output) lies largely in fp16's SUBNORMAL range: `fp16_grad_<task>` = [max, median of the non-zero entries,
+share exactly zero, share below 6.1e-5] -- 15-60 % of the non-zero entries are subnormal (a few significant bits), median 7e-6
+.. 4e-4.  text_proj's gradient is a sum of exactly those quantised values; this build carries them in fp32.  So the bound for
+text_proj stays 2e-2 wherever near-ties exist or the task is sap, 7e-3 for the tie-free mlm / mrc batches; every other
+parameter 5e-3 everywhere.
 """
 import json
 
@@ -51,16 +65,33 @@ def _model(fx):
 
 @pytest.mark.parametrize("task,with_obj", [("mlm", False), ("mrc", False), ("sap", False),
                                            ("mrc", True), ("sap", True), ("og", True),
-                                           ("mlm", "full"), ("mrc", "full"), ("sap", "full")])
+                                           ("mlm", "full"), ("mrc", "full"), ("sap", "full"),
+                                           ("mlm", "notie"), ("mrc", "notie")])
 def test_pretrain_losses_and_gradients_match_reference(task, with_obj):
     """with_obj == "full": the released full-size configuration (9 / 2 / 4 layers, 3072-wide FFN, 30 522-word vocabulary,
-    161 M parameters), B = 2 -- tests/golden/pretrain_full_b2.npz from the imported reference."""
+    161 M parameters), B = 2 -- tests/golden/pretrain_full_b2.npz from the imported reference.
+    with_obj == "notie": pretrain_reduced_notie.npz -- no arg-max near-tie in the relevance product: text_proj at 7e-3 (mlm,
+    mrc).  The fixture also holds the sap task; it is not asserted: without any near-tie its text_proj gradient is 1.1e-2 from
+    the reference (the fp16 backward, module docstring) and the ReLU heads of sap leave one LayerNorm bias at 7.5e-3."""
     from gridmm_amd.synthetic import batch_to
     full = with_obj == "full"
+    notie = with_obj == "notie"
     with_obj = with_obj is True
-    fx = load_golden("pretrain_full_b2.npz" if full else ("pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz"))
+    fx = load_golden("pretrain_reduced_notie.npz" if notie else
+                     ("pretrain_full_b2.npz" if full else ("pretrain_reduced_obj.npz" if with_obj else "pretrain_reduced.npz")))
+    ties = fx["relevance_ties_" + task] if ("relevance_ties_" + task) in fx.files else None
+    if notie:
+        assert ties is not None and int(ties[0]) == 0 and int(ties[1]) >= 120
+        gap, disc = fx["relevance_gap_" + task]
+        assert gap >= 4.0 * disc          # (the search's criterion, per episode; 5.8 .. 12.4 on the three batches)
+    if ("fp16_grad_" + task) in fx.files:     # the reference's own precision on this path (see the module docstring)
+        assert float(fx["fp16_grad_" + task][3]) > 0.10, "share of fp16-subnormal gradient entries in the reference's grid path"
+    elif ties is not None:
+        assert int(ties[0]) >= 10, "the tie-prone fixture is expected to hold near-ties (that is why its bound is 2e-2)"
+        print("near-tie points: %d of %d" % (int(ties[0]), int(ties[1])))
     model = _model(fx)
-    batch = batch_to(gen_golden.pretrain_full_batch(task) if full else gen_golden.pretrain_batch(task, with_obj), "cuda")
+    batch = batch_to(gen_golden.pretrain_notie_batch(task) if notie else
+                     (gen_golden.pretrain_full_batch(task) if full else gen_golden.pretrain_batch(task, with_obj)), "cuda")
     loss = model(batch, task=task, compute_loss=True)
     want = fx["loss_" + task]
     got = loss.detach().cpu().numpy()
@@ -88,7 +119,9 @@ def test_pretrain_losses_and_gradients_match_reference(task, with_obj):
         errs += [(e, k), (en, k + " [norm]")]
     errs.sort(reverse=True)
     for e, k in errs:
-        bound = 2e-2 if "text_proj" in k else 5e-3
+        # text_proj: 7e-3 on the tie-free mlm / mrc batches (measured 5.4e-3 / < 5e-3), 2e-2 with near-ties and for sap (1.1e-2
+        # WITHOUT any near-tie: the reference's fp16 backward, see the module docstring)
+        bound = (7e-3 if (notie and task != "sap") else 2e-2) if "text_proj" in k else 5e-3
         assert e < bound, (k, e, errs[:8])
     a, b = np.concatenate(got_all).astype(np.float64), np.concatenate(ref_all).astype(np.float64)
     cos = float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
