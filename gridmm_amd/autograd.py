@@ -71,7 +71,14 @@ class _WeightCache:
         return out
 
     def _make_get(self, ent, w):
+        made = ent.get("ver")
+
         def get(transposed, ent=ent, w=w):
+            if ent.get("ver") != made:
+                # a getter outlives its forward inside an autograd node (dX reads W^T in backward): the entry now belongs to a
+                # NEWER version of the parameter (optimizer step / load_state_dict rewrote the persistent planes in place)
+                raise RuntimeError("a weight was modified in place between a Linear's forward and its backward; its planes are "
+                                   "persistent buffers shared across steps -- run backward before updating the weights")
             if transposed not in ent:
                 if (w.requires_grad and w.dim() == 2 and w.dtype == torch.float32   # (grad mode is off inside Function.forward)
                         and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0 and w.is_contiguous()):
@@ -298,6 +305,22 @@ def transpose_split(x2d, want_colsum=False, want_rows=False, out=None):
                                           _p(rows.lo if rows else None), C, M, C, Mp, _stream()),
                "gridmm_transpose_split")
     return hi, lo, cs, Mp, rows
+
+
+def _param_versions(params):
+    """What torch's saved-tensor check would remember of these parameters: the weight planes the layer C calls point at are
+    persistent buffers that the optimizer (or a re-pack after load_state_dict) rewrites IN PLACE, so a backward that runs after
+    such a rewrite would silently differentiate against the new weights."""
+    return tuple((p._version if torch.is_tensor(p) else None) for p in params)
+
+
+def _check_param_versions(ctx_versions, params, what):
+    now = _param_versions(params)
+    if now != ctx_versions:
+        bad = [i for i, (a, b) in enumerate(zip(ctx_versions, now)) if a != b]
+        raise RuntimeError("%s: parameter(s) %s were modified in place between this node's forward and its backward (an optimizer "
+                           "step or load_state_dict under a retained graph); the weight planes the backward reads are shared, "
+                           "persistent buffers -- run backward before updating the weights" % (what, bad))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1411,11 +1434,13 @@ class _XLayer(torch.autograd.Function):
         ctx.save_for_backward(x2, kv, cm, sm, saved, *(kvp if kvp else ()), *([kvs] if kvs is not None else []))
         ctx.L, ctx.keep, ctx.dims = L, keep, (B, Sq, Sk, H, I, heads, int(k_col))
         ctx.shapes = [tuple(p.shape) if p is not None else None for p in params]
+        ctx.versions = _param_versions(params)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
+        _check_param_versions(ctx.versions, ctx.prm, "x-layer backward")
         x2, kv, cm, sm, saved, *rest = ctx.saved_tensors
         kvp, kvs = rest[:2], (rest[2] if len(rest) > 2 else None)
         B, Sq, Sk, H, I, heads, k_col = ctx.dims
@@ -1511,6 +1536,7 @@ class _PreLNLayer(torch.autograd.Function):
                    "gridmm_preln_layer_train_fwd")
         ctx.save_for_backward(x2, m, saved)
         ctx.L, ctx.keep, ctx.dims = L, keep, (B, S, H, I, heads)
+        ctx.versions = _param_versions(ctx.prm)
         return y
 
     @staticmethod
@@ -1518,6 +1544,7 @@ class _PreLNLayer(torch.autograd.Function):
         if dy is None:
             return (None,) * 17
         lib = _lib.load()
+        _check_param_versions(ctx.versions, ctx.prm, "pre-LN layer backward")
         x2, m, saved = ctx.saved_tensors
         B, S, H, I, heads = ctx.dims
         dev = dy.device

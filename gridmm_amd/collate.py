@@ -52,9 +52,10 @@ class _Stager:
 
     def _begin_cycle(self):
         host, dev, ev = self._slot()
-        if ev is not None and not ev.query() and len(self.ring) < self.MAX_RING:
+        if self.owned and ev is not None and not ev.query() and len(self.ring) < self.MAX_RING:
             # the copy issued from this slot has not run yet (a training loop whose host is a whole iteration ahead of the
-            # device): a new slot here instead of a wait
+            # device): a new slot here instead of a wait.  Inference rollouts read the action back every step, so their ring
+            # of three never waits long and never grows (a pinned allocation costs milliseconds)
             n = host.numel()
             self.ring.insert(self.pos, [torch.empty(n, dtype=torch.uint8).pin_memory(),
                                         torch.empty(n, dtype=torch.uint8, device=self.device), None])

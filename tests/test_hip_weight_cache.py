@@ -104,3 +104,27 @@ def test_a_weight_in_two_groupings_is_owned_by_the_first():
     sf = ag.WEIGHTS.group_getter((k0, v0))(False)
     cs, _ = _fresh(torch.cat([k0.detach(), v0.detach()], 0))
     assert _planes_equal(sf, cs)
+
+
+def test_backward_after_a_weight_update_fails_loudly():
+    """the planes a Linear's backward reads (W^T for dX) are persistent buffers that the optimizer rewrites in place,
+    and the weight itself is not a saved tensor of the custom Function -- torch's version check cannot see an update that lands
+    between forward and backward (retain_graph, delayed backward).  The weight cache's getter and the fused layer nodes remember
+    the parameter versions of their forward and refuse a backward against newer weights."""
+    from gridmm_amd import autograd as ag
+    from gridmm_amd.optim import AdamW
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    ag.WEIGHTS.clear()
+    w = torch.nn.Parameter(torch.randn(128, 128, device=dev) * 0.05)
+    x = torch.randn(2, 9, 128, device=dev, requires_grad=True)
+    opt = AdamW([w], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decay_first=True)
+    y = ag.linear(x, w).sum()
+    y.backward(retain_graph=True)                # fine: same weights
+    opt.step(max_grad_norm=1.0)                  # rewrites w and its planes in place
+    with pytest.raises(RuntimeError, match="modified in place"):
+        y.backward()
+    # a fresh forward after the update works
+    x.grad = None
+    ag.linear(x, w).sum().backward()
+    assert torch.isfinite(x.grad).all()
