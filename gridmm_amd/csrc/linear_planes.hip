@@ -61,7 +61,7 @@ struct PShift { const float* tab; int rpb, c0; int pre_c; };   // pre_c: C recei
 // the plain loop and the ring keeps all NS stages in flight -- the DMA of stage kt + NS is issued right behind that barrier,
 // piece by piece between the MFMAs.
 template <int BM, int BN, int WM, int WN, int NS, int BK, int ACT, int ABLATE = 0, int PP = 0, int TR = 0, int WT = 0, int RP = 0>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kernel(
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM == 192 && NS == 2 && BK == 32 && WM == 48 && WN == 32) ? 8 : 1) void linear_planes_kernel(
     const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo, int lda,
     const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo, int Kp,
     const float* __restrict__ bias, const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc,
@@ -80,7 +80,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void linear_planes_kern
   constexpr int PPW = (PIECES + NW - 1) / NW;
   constexpr int NFULL = UNEVEN ? PIECES - (PPW - 1) * NW : NW;
   static_assert(!UNEVEN || (!PP && PPW >= 2), "uneven piece split: plain main loop only");
-  constexpr int ER = (NW > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : (WM % 64 ? 32 : 64));   // rows per epilogue pass (LDS budget)
+  // rows per epilogue pass (LDS budget); the two-per-CU 192x128 form (80-KB ring) takes 16-row passes so that the epilogue fits the ring
+  constexpr int ER = (BM == 192 && NS == 2 && BK == 32 && WM == 48 && WN == 32) ? 16 : (NW > 8 && WM * WN >= 4096) ? 32 : (WM < 64 ? WM : (WM % 64 ? 32 : 64));
   constexpr int EPI = ER * WN;                           // floats per wave in the epilogue transpose
   constexpr int LDS_U16 = (TR || NS * STAGE * 2 > NW * EPI * 4) ? NS * STAGE : NW * EPI * 2;
   __shared__ __attribute__((aligned(16))) unsigned short smem[LDS_U16];
@@ -710,6 +711,15 @@ static int pick_cfg_impl(int M, int N, int K) {
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t192 = (long)((M + 191) / 192) * ((N + 127) / 128);
     if (t128 > 256 && t192 >= 160 && t192 <= 256) best = 66;
   }
+  // Multi-round problems of the 128x128 class (FFN1 of the grid layers: 1 296 tiles = 2.5 rounds at two per CU): the same
+  // 192x128 tile as TWO 16-wave workgroups per CU -- BK 32, 2 stages = 80 KB, 61 VGPRs, 16-row epilogue passes so that the
+  // epilogue fits the ring, tiled weight planes -- keeps the epilogue of one workgroup under the main loop of the other (the
+  // one-per-CU form loses 25 us per launch here) with 17 % fewer operand bytes per flop: 864 tiles = 1.7 rounds.  In-step A/B:
+  // -9 .. -40 us per step over the two launches (four alternations; same-tile noise +-1), isolated 101.5 vs 121 us.
+  if (best == 15) {
+    const long t192 = (long)((M + 191) / 192) * ((N + 127) / 128);
+    if (t192 > 512) best = 76;
+  }
   return best;
 }
 
@@ -744,6 +754,7 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
                 // measured too (their pieces are 8 full 128-B lines already): +-2 us per step, not kept.
     if (cfg == 15) return launch<128, 128, 32, 32, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
     if (cfg == 36) return launch<256, 256, 64, 64, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);
+    if (cfg == 76) return launch<192, 128, 48, 32, 2, 32, 0, 0, 0, true, 1>(GRIDMM_ARGS);   // two 16-wave workgroups per CU (80 KB, 61 VGPRs)
 #ifdef GRIDMM_DEBUG_HOOKS
     if (cfg == 16) return launch<256, 128, 64, 32, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
     if (cfg == 14) return launch<128, 128, 64, 32, 2, 32, 0, 0, 0, false, 1>(GRIDMM_ARGS);
@@ -772,6 +783,7 @@ static int linear_planes_dispatch(const void* A_hi, const void* A_lo, int lda, c
     case 43: return launch<64, 64, 32, 32, 2, 64, 0, 0, 1, true>(GRIDMM_ARGS);     // direct epilogue from C^T accumulators
     case 57: return launch<128, 64, 32, 32, 3, 64, 0, 0, 0, true>(GRIDMM_ARGS);    // = 13
     case 66: return launch<192, 128, 48, 32, 2, 64, 0, 0, 0, true>(GRIDMM_ARGS);   // one 16-wave workgroup per CU, BK = 64
+    case 76: return launch<192, 128, 48, 32, 2, 32, 0, 0, 0, true>(GRIDMM_ARGS);   // two 16-wave workgroups per CU, BK = 32
     case 71: return launch<128, 64, 32, 32, 3, 64, 0, 0, 0, true, 0, 1>(GRIDMM_ARGS);   // cfg 13, register-pipelined
     case 75: return launch<128, 64, 32, 32, 3, 64, 0, 0, 1, true, 0, 1>(GRIDMM_ARGS);   // ... with the direct C^T epilogue
     default: break;

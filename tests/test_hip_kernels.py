@@ -52,13 +52,13 @@ def test_linear_bf16x3_matches_fp32(dev, M, N, K, act):
         assert (rec - y).abs().max().item() <= 2.0 ** -15 * max(1e-3, y.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg", [66, 71, 75])
+@pytest.mark.parametrize("cfg", [66, 71, 75, 76])
 @pytest.mark.parametrize("M,N,K", [(6912, 768, 3072), (1824, 768, 768), (191, 200, 64), (193, 132, 128), (1000, 764, 1536),
-                                   (6912, 768, 768), (50, 4, 192)])
+                                   (6912, 768, 768), (50, 4, 192), (6912, 3072, 768)])
 def test_round6_tiles_match_fp64_and_the_reference_tile_bit_for_bit(dev, cfg, M, N, K):
     """The tiles pick_cfg gained in round 6 -- 192x128 with one 16-wave workgroup per CU (66) and the register-pipelined
     128x64 loops (71, 75: fragments of sub-step t + 1 read under the MFMAs of t, DMA pieces issued between the MFMAs) --
-    forced through gridmm_linear_planes_cfg: ragged M / N, one k-step, long contractions, with bias + residual + plane output.
+    and the two-per-CU 192x128 form (76: uneven DMA piece split, 16-row epilogue passes) -- forced through gridmm_linear_planes_cfg: ragged M / N, one k-step, long contractions, with bias + residual + plane output.
     Same products in the same order as every other tile, so the result must EQUAL the 64x64 tile's (cfg 4) bit for bit; run
     repeatedly, because a misplaced wait in a DMA ring shows up as a rare wrong tile, not as a constant error."""
     import ctypes

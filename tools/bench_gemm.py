@@ -12,7 +12,7 @@ SHAPES = [(int(v) for v in os.environ['GEMM_SHAPE'].split('x'))] if os.environ.g
           (2560, 512, 768), (6272, 768, 512)]
 CFGS = {8: "64x64 BK64", 43: "TR 64x64 BK64", 14: "128x128 8w", 15: "128x128 16w", 36: "256x256 16w", 7: "256x256 8w", 16: "256x128 16w",
         65: "192x128 16w NS3", 66: "192x128 16w BK64", 67: "192x128 16w NS4", 68: "256x128 16w NS3", 56: "96x64 NS3 BK64", 69: "96x64 TR",
-        70: "192x128 BK64 RP", 71: "128x64 NS3 RP", 72: "128x128 BK64 RP", 75: "128x64 NS3 RP TR", 13: "128x64 NS3",
+        76: "192x128 BK32 two per CU", 70: "192x128 BK64 RP", 71: "128x64 NS3 RP", 72: "128x128 BK64 RP", 75: "128x64 NS3 RP TR", 13: "128x64 NS3",
         466: "192x128 BK64 DMAonly same tile", 566: "192x128 BK64 DMAonly 8 row tiles", 467: "192x128 NS4 DMAonly same tile", 365: "192x128 NS3 DMAonly", 367: "192x128 NS4 DMAonly", 165: "192x128 NS3 noMFMA", 167: "192x128 NS4 noMFMA", 265: "192x128 NS3 noDMA", 166: "192x128 BK64 noMFMA", 266: "192x128 BK64 noDMA", 366: "192x128 BK64 DMAonly", 115: "128x128 noMFMA", 215: "128x128 noDMA", 315: "128x128 DMAonly",
         136: "256x256 noMFMA", 236: "256x256 noDMA", 336: "256x256 DMAonly", 113: "128x64 noMFMA", 213: "128x64 noDMA", 313: "128x64 DMAonly"}
 

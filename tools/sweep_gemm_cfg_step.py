@@ -103,6 +103,10 @@ def main():
             continue
         shapes = THIN if mode == "thin" else (BIG if mode == "big" else (MID if mode == "mid" else list(SHAPES)))
         cands = CANDS_THIN if mode == "thin" else (CANDS_BIG if mode == "big" else (CANDS_MID if mode == "mid" else CANDS_ALL))
+        if mode == "ffn1":
+            shapes, cands = [(6912, 3072, 768), (6912, 2304, 768), (9472, 6144, 768)], [76, 15, 36]
+        if mode == "ffn1x":
+            shapes, cands = [(6912, 3072, 768), (1824, 3072, 768), (1824, 2304, 768)], [76, 76, 76, 15]
         if mode == "thin6":
             shapes, cands = [(1824, 768, 768), (1824, 768, 3072), (2560, 512, 768)], [71, 75]
         for (M, N, K) in shapes:
