@@ -322,6 +322,9 @@ def rollout_leg(args, dev, rollouts=4, profiler=None):
         torch.cuda.synchronize()
         dt, steps = time.perf_counter() - t0, agent.nav_steps - n0
         agent.timers = {}
+        agent.rollout()                       # (the synchronised mode frees its temporaries at other moments than the timed mode:
+        torch.cuda.synchronize()              #  its first rollout pays one-off device allocations, 60-80 ms -- not a section's cost)
+        agent.timers = {}
         n1 = agent.nav_steps
         agent.rollout()
         torch.cuda.synchronize()

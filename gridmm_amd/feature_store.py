@@ -157,19 +157,15 @@ class DeviceStore:
         if torch.device(self.device).type != "cuda":
             return torch.tensor(ids, dtype=torch.int64, device=self.device)
         ring = getattr(self, "_idx_ring", None)
-        if ring is None or ring[0][0].numel() < len(ids):
-            ring = self._idx_ring = [[torch.empty(max(len(ids), 64), dtype=torch.int64).pin_memory(), None] for _ in range(16)]
-            self._idx_pos = 0
-        host, ev = ring[self._idx_pos]
-        if ev is not None:
-            ev.synchronize()
+        if ring is None or ring.numel < len(ids):
+            from .pinned import PinnedRing
+            ring = self._idx_ring = PinnedRing(max(len(ids), 64), dtype=torch.int64, max_slots=16)
+        k = ring.acquire()
+        host = ring.host(k)
         host[:len(ids)] = torch.as_tensor(ids, dtype=torch.int64)
         dev = torch.empty(len(ids), dtype=torch.int64, device=self.device)
         dev.copy_(host[:len(ids)], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        ring[self._idx_pos][1] = ev
-        self._idx_pos = (self._idx_pos + 1) % len(ring)
+        ring.record(k)
         return dev
 
     def append(self, mem, keys):

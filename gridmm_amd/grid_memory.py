@@ -86,8 +86,8 @@ class GridMemoryBatch:
         # behind everything queued before it -- in a training loop the whole backward of the previous iteration.  Slot 0 is the
         # buffer above; callers that claimed bytes of its EXTRA area (stage_extra) keep the single-buffer behaviour.
         self._views_of = views
-        self._stage_ring = [[self._stage_host, None]]
-        self._stage_pos = 0
+        self._stage_ring = None            # pinned.PinnedRing, created with the first step on a CUDA device (slot 0 = the buffer above)
+        self._stage_slot = 0
         self.STAGE_RING = 16
         self._cmax_event = None
         self._cmax_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -129,15 +129,18 @@ class GridMemoryBatch:
         Rounded to fp32 on the host exactly as NumPy does (env.py:118-120, 344-348)."""
         self._cmax_event = None                   # a new pose re-bins the memory: the tracked cell count is stale
         if self._stage_used == self._stage_extra_off and self.device.type == "cuda":
-            # next slot of the pinned ring: wait only for the copy issued from THAT slot, STAGE_RING steps ago
-            self._stage_pos = (self._stage_pos + 1) % self.STAGE_RING
-            if self._stage_pos == len(self._stage_ring):
-                self._stage_ring.append([torch.zeros(self._stage_host.numel(), dtype=torch.uint8).pin_memory(), None])
-            buf, ev = self._stage_ring[self._stage_pos]
-            if ev is not None:
-                ev.synchronize()
-            self._stage_host = buf
-            self._pose_host, self._head_host, self._act_host, self._vcos_host, self._vsin_host = self._views_of(buf)
+            # a slot of the pinned ring whose copy has completed (a loop that reads results back every step keeps using one or two
+            # slots; a training loop running ahead of the device grows the ring up to STAGE_RING -- pinned allocations cost
+            # milliseconds, so never eagerly)
+            if self._stage_ring is None:
+                from .pinned import PinnedRing
+                self._stage_ring = PinnedRing(self._stage_host.numel(), max_slots=self.STAGE_RING, first=self._stage_host)
+                if self._h2d_done is not None:
+                    self._stage_ring.record(0, self._h2d_done)
+            k = self._stage_ring.acquire()
+            if k != self._stage_slot or self._stage_ring.host(k) is not self._stage_host:
+                self._stage_slot, self._stage_host = k, self._stage_ring.host(k)
+                self._pose_host, self._head_host, self._act_host, self._vcos_host, self._vsin_host = self._views_of(self._stage_host)
         elif self._h2d_done is not None:
             self._h2d_done.synchronize()          # the previous step's async H2D has consumed the pinned buffers
         # whole-array writes into the pinned buffers; cos / sin stay libm scalars in double (math.cos, as the reference
@@ -159,7 +162,8 @@ class GridMemoryBatch:
         if self.device.type == "cuda":
             self._h2d_done = torch.cuda.Event()
             self._h2d_done.record()
-            self._stage_ring[self._stage_pos][1] = self._h2d_done
+            if self._stage_ring is not None:
+                self._stage_ring.record(self._stage_slot, self._h2d_done)
 
     def stage_extra(self, nbytes):
         """(pinned host view, device view) of `nbytes` of the staging buffer's caller area: whatever the caller writes into
