@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--train-leg-only", action="store_true", help="(internal) run the training leg and print its JSON")
     ap.add_argument("--no-producer-leg", action="store_true", help="skip the VLN-CE step with the CLIP tower in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-relevance-cache", action="store_true",
+                    help="two-pass aggregation shapes (--shape native: D = 768): recompute the relevance of every point at every "
+                         "step like the reference instead of keeping it next to the device-resident slab")
     return ap.parse_args()
 
 
@@ -85,6 +88,9 @@ def build_workload(args, dev, mem_steps=None, device_feats=False, depth_mode="un
     # what a caller has on the host each step for the fused-logit index maps (vilmodel.py:881-899)
     fusion_src = (host_batch["gmap_vpids"], host_batch["gmap_visited_masks"].numpy(), host_batch["vp_cand_vpids"])
     mem = GridMemoryBatch(B, geom, max_steps=t, device=dev)
+    # two-pass aggregation shapes only (D = 768): the relevance of the points of earlier steps stays next to the slab; inside
+    # the captured step too (every replay restores the same history prefix and appends the same observation)
+    mem.relevance_cache_enabled = mem.relevance_cache_in_graphs = not getattr(args, "no_relevance_cache", False)
     okw = dict(depth_mode=depth_mode, inner_frac=0.004) if depth_mode != "uniform" else {}
     eps = [S.make_observations(rs, geom, t, with_feats=not device_feats, **okw) for _ in range(B)]
     n_new = geom.pts_per_obs
@@ -988,7 +994,15 @@ def main():
                                 "-5.4 GFLOP per episode-step, difference < 1e-6; the roofline flop count (2MNK of the launched "
                                 "GEMMs) is the post-reduction count",
                    "instruction_side": "recomputed every step like the reference (the cached form is the secondary key "
-                                       "instruction_cache)"},
+                                       "instruction_cache)",
+                   "relevance": ("one pass over the slab (relevance + per-cell softmax sums in one kernel)"
+                                 if geom.feat_dim != 768 else
+                                 "D = 768: relevance pass + accumulation pass; the relevance of the points appended at earlier "
+                                 "steps is %s" % ("recomputed every step like the reference (--no-relevance-cache)"
+                                                  if args.no_relevance_cache else
+                                                  "kept next to the device-resident slab (it depends on the slab row and the "
+                                                  "instruction only; bit-identical), so a step computes the new observation's "
+                                                  "values and reads the slab once -- --no-relevance-cache recomputes all"))},
     }
     out["replay_check"] = check
     if getattr(step, "graph", None) is not None and step.graph.n_nodes is not None:

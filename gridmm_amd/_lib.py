@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
 # overrides and the whole experiment table of tile configurations.  Only the sweep tools ask for it (load(debug=True) or
 # GRIDMM_LIB_DEBUG=1 before the first load); the product path and the tests run on the shipping library, which has neither.
 DEBUG_LIB_PATH = os.path.join(_HERE, "libgridmm_hip_dbg.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -34,6 +34,8 @@ SIGNATURES = {
     "gridmm_grid_aggregate_workspace": [_i, _i, _i],
     "gridmm_grid_aggregate": [_vp] * 8 + [_i, _i, _i, _i, _i, _vp],
     "gridmm_grid_aggregate_train": [_vp] * 9 + [_i, _i, _i, _i, _i, _vp],
+    "gridmm_grid_aggregate_incremental_scratch": [_i, _i],
+    "gridmm_grid_aggregate_incremental": [_vp] * 6 + [_i] + [_vp] * 7 + [_i, _i, _i, _i, _i, _i, _vp],
     "gridmm_cells_compact": [_vp] * 7 + [_i, _i, _i, _vp],
     "gridmm_split_weight": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "gridmm_linear": [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
@@ -180,6 +182,7 @@ def load(debug=None):
     lib.gridmm_attention_rows_bwd_workspace.argtypes = [_i, _i, _i]
     lib.gridmm_attention_rows_bwd_workspace.restype = ctypes.c_size_t
     lib.gridmm_grid_aggregate_workspace.restype = ctypes.c_size_t
+    lib.gridmm_grid_aggregate_incremental_scratch.restype = ctypes.c_size_t
     lib.gridmm_xattn_layer_train_saved_bytes.restype = ctypes.c_size_t
     lib.gridmm_xattn_layer_train_workspace.restype = ctypes.c_size_t
     lib.gridmm_preln_layer_saved_bytes.restype = ctypes.c_size_t

@@ -54,6 +54,7 @@ class GridMemoryBatch:
         self._bin_ws = torch.empty(B, self.MAX_BIN_SLICES * 17, 197, dtype=torch.int32, device=dev)
         self.n_pts_host = np.zeros(B, np.int64)
         self.keep_for_backward = False
+        self._rel = None                   # per-point relevance kept across the steps of an episode (relevance_cache)
         # static per-step inputs (pinned host -> device): the only bytes that cross PCIe each step.  ONE staging buffer
         # (pose | cos/sin(-heading) | active flags | per-episode view tables (VLN-CE) | EXTRA bytes for the caller, e.g.
         # graph.GraphedNavStep's fused-logit index maps) and ONE async copy per step: every H2D is a ~4 us copy kernel on
@@ -122,6 +123,37 @@ class GridMemoryBatch:
         self.n_pts_host[:] = 0
         self.cell_id.fill_(-1)
         self._cmax_event = None
+        if self._rel is not None:                         # the rows are recycled: no point has a relevance value any more
+            self._rel["valid"].zero_()
+            self._rel["slab"] = self.slab
+
+    # ---- per-point relevance kept across the steps of an episode (two-pass aggregation shapes: D = 768, long instructions)
+    relevance_cache_enabled = True
+    relevance_cache_in_graphs = False     # whole-step hipGraphs (graph.GraphedNavStep) bake the host-side key check in: opt-in
+
+    def relevance_cache(self, key, keep_alive=None):
+        """State of gridmm_grid_aggregate_incremental for this memory: w_j = max_l <x_j, text_l> (vilmodel.py:797-798) depends
+        only on a point's slab row and on the instruction, so the values of the points appended at earlier steps are kept
+        ('hist', by history index; 'valid' = leading points per episode that have one) and a step computes the new
+        observation's only.  `key` identifies the instruction side (the text tensor + the text_proj parameters, their
+        versions): a different key, reset() or a replaced slab clears 'valid' -- a stream-ordered memset, the launch path
+        itself decides everything on the device.  Rows of the slab must not be rewritten once a step has used them (the
+        rows a step appends are recomputed whatever 'valid' says)."""
+        st = self._rel
+        if st is None:
+            from . import _lib
+            B, cap, dev = self.B, self.cap, self.device
+            n = int(_lib.load().gridmm_grid_aggregate_incremental_scratch(B, cap))
+            st = self._rel = {"hist": torch.zeros(B, cap, dtype=torch.float32, device=dev),
+                              "valid": torch.zeros(B, dtype=torch.int32, device=dev),
+                              "rel": torch.zeros(B, cap, dtype=torch.float32, device=dev),
+                              "scratch": torch.empty(n, dtype=torch.uint8, device=dev), "key": None, "slab": self.slab,
+                              "alive": None, "clears": 0}
+        if st["key"] != key or st["slab"] is not self.slab:
+            st["valid"].zero_()
+            st["key"], st["slab"], st["alive"] = key, self.slab, keep_alive
+            st["clears"] += 1
+        return st
 
     # ---- host half of a step: a few floats per episode into static (pinned -> device) buffers
     def set_pose(self, poses, headings, active=None):

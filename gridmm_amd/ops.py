@@ -781,6 +781,49 @@ def text_fragments(text_fts, out=None):
     return frag
 
 
+def two_pass_aggregation(D, L):
+    """Shapes whose aggregation is a relevance pass + an accumulation pass (every other shape reads the slab once already)."""
+    return D == 768 or not 33 <= L <= 96
+
+
+def grid_aggregate_incremental(slab, perm, cell_start, text_frag, L, n_pts, active, n_new, state, n_chunks=None, full=False):
+    """grid_aggregate for a device-resident memory on the two-pass shapes, with the relevance pass restricted to the points
+    that have no value yet (gridmm_grid_aggregate_incremental: normally the observation just appended) -> (cells, occ), or
+    None when the shape is outside the two-pass kernels' range (nothing was launched that matters: call grid_aggregate).
+    state: dict owned by the memory with 'hist' (B, cap) f32, 'valid' (B,) int32, 'scratch' uint8, 'rel' (B, cap) f32
+    (GridMemoryBatch.relevance_cache).  full: no point has a value yet (first step of an episode): the plain passes + one
+    launch that keeps their values (always correct, only cheaper than the general sequence on a cold memory)."""
+    lib = _lib.load()
+    B, cap, D = slab.shape
+    assert slab.dtype == torch.float16 and slab.is_contiguous()
+    if n_chunks is None:
+        n_chunks = max(1, min(N_CELLS, -(-256 // B)))
+        if os.environ.get("GRIDMM_AGG_CHUNKS"):
+            n_chunks = int(os.environ["GRIDMM_AGG_CHUNKS"])
+    dev = slab.device
+    cells = torch.empty(B, N_CELLS, D, dtype=torch.float32, device=dev)
+    occ = torch.empty(B, N_CELLS, dtype=torch.uint8, device=dev)
+    chunks = torch.empty(int(lib.gridmm_grid_aggregate_workspace(B, D, n_chunks)), dtype=torch.uint8, device=dev)
+    status = []
+
+    def launch():
+        rc = lib.gridmm_grid_aggregate_incremental(_p(slab), _p(perm), _p(cell_start), _p(text_frag), _p(n_pts), _p(active),
+                                                   int(n_new), _p(state["hist"]), _p(state["valid"]), _p(state["scratch"]),
+                                                   _p(cells), _p(occ), _p(state["rel"]), _p(chunks), B, cap, D, L, n_chunks,
+                                                   int(bool(full)), _stream())
+        status.append(rc)
+        if rc != -1:                 # GRIDMM_EINVAL: shape outside the range, the caller falls back
+            _lib.check(rc, "gridmm_grid_aggregate_incremental")
+    if TIMER is not None:
+        TIMER.last_aggregate = launch        # (a re-launch recomputes the last observation's values again: idempotent)
+    _timed("grid_aggregate", 0.0, launch)
+    if status[-1] != 0:
+        return None
+    global LAST_AGGREGATE_RC
+    LAST_AGGREGATE_RC = 2            # the incremental two-pass path
+    return cells, occ
+
+
 def grid_aggregate(slab, perm, cell_start, text_frag, L, n_chunks=None, want_relevance=False, n_points=None,
                    want_amax=False):
     """slab (B,cap,D) fp16 -> cells (B,196,D) fp32, occ (B,196) uint8 [, relevance (B,cap) fp32: w of the point at

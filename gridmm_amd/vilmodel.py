@@ -529,6 +529,7 @@ class GlocalTextPathNavCMT(nn.Module):
         reduced cell vectors.  Independent of how many cells are occupied.  txt_planes = (hi, lo): where the bf16 planes
         of the instruction go (e.g. the tail of the local encoder's context buffer)."""
         B, L, H = txt_embeds.shape
+        txt_src = txt_embeds                                   # the caller's tensor: identity of the instruction side
         if icache is not None:
             txt, frag, txt_m = icache.txt, icache.frag, icache.txt_m
         else:
@@ -545,7 +546,21 @@ class GlocalTextPathNavCMT(nn.Module):
                 gridmap_pos_fts = grid_memory.pos_fts
         else:
             slab, perm, cell_start = pack_reference_lists(grid_fts, grid_map)
-        cells, occ = ops.grid_aggregate(slab, perm, cell_start, frag, L, n_points=n_points)
+        res = None
+        if (grid_memory is not None and getattr(grid_memory, "relevance_cache_enabled", False)
+                and ops.two_pass_aggregation(slab.shape[2], L)
+                and (grid_memory.relevance_cache_in_graphs or not torch.cuda.is_current_stream_capturing())):
+            # device-resident memory on a two-pass shape: the relevance of the points of earlier steps is kept (it depends on
+            # the slab row and the instruction only), this step computes the new observation's and reads the slab once
+            tp = self.text_proj
+            key = (id(txt_src), txt_src._version, txt_src.data_ptr(), tp.weight.data_ptr(), tp.weight._version,
+                   tp.bias._version)
+            st = grid_memory.relevance_cache(key, keep_alive=txt_src)       # (holding the tensor keeps its id unique)
+            res = ops.grid_aggregate_incremental(slab, perm, cell_start, frag, L, grid_memory.n_pts,
+                                                 None if grid_memory._active is None else grid_memory.act_d,
+                                                 grid_memory.n_new, st,
+                                                 full=bool((grid_memory.n_pts_host <= grid_memory.n_new).all()))
+        cells, occ = res if res is not None else ops.grid_aggregate(slab, perm, cell_start, frag, L, n_points=n_points)
         proj = ops.linear(cells, self._lin(self.grid_proj, "grid_proj")).f32
         return SimpleNamespace(txt=txt, txt_m=txt_m, proj=proj, occ=occ, gridmap_pos_fts=gridmap_pos_fts,
                                in_place=txt_planes is not None, icache=icache, L=L)

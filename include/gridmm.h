@@ -144,6 +144,31 @@ int gridmm_grid_aggregate_train(const void* slab, const int32_t* perm, const int
                                 const void* text_frag, float* cells, uint8_t* occ, float* relevance, int32_t* amax,
                                 void* workspace, int B, int cap, int D, int L, int n_chunks, gridmm_stream_t stream);
 
+/* The two-pass aggregation (D = 768; instructions outside 33..96 tokens at D <= 512) for a memory that stays on the device:
+ * the relevance w_j = max_l <x_j, text_l> of a point depends only on its slab row and on the instruction, both constant over
+ * an episode, while the reference recomputes all of them at every step (vilmodel.py:797-798 inside the per-step forward).
+ * Here they are kept in history order and only the points without a value are computed (normally the observation just
+ * appended); the accumulation pass then reads the slab ONCE.  Same cells / occ / relevance as gridmm_grid_aggregate, bit for bit.
+ *   n_pts      [B] int32 device: points per episode AFTER this step's append (the grid memory's counter)
+ *   active     [B] uint8 device or NULL (all): episodes that appended n_new rows in this step -- those rows are recomputed
+ *              whatever rel_valid says (a rewound memory may have re-written them)
+ *   rel_hist   [B][cap] f32 in/out: relevance by HISTORY index;  rel_valid [B] int32 in/out: leading points of the episode
+ *              that have a value.  The caller clears rel_valid when the instruction (text_frag) changes or rows are recycled.
+ *   scratch    gridmm_grid_aggregate_incremental_scratch(B, cap) bytes;  workspace / n_chunks as for gridmm_grid_aggregate
+ *   relevance  [B][cap] f32 out (by sorted position, as gridmm_grid_aggregate writes it): required
+ *   full       != 0: the caller knows that no point has a value yet (first step of an episode): the plain relevance pass over
+ *              all points, its values filed into rel_hist (one launch more than gridmm_grid_aggregate, two fewer than the
+ *              general sequence); always correct, whatever rel_valid holds.  Points without a cell (id -1: no depth,
+ *              env.py:283-285) get no value from this form: whether a point has depth must not change over its lifetime
+ * Returns GRIDMM_EINVAL (nothing computed) for the one-pass shapes and for shapes outside the two-pass kernels' range: use
+ * gridmm_grid_aggregate there.  Device-side decisions only: replayable from a hipGraph. */
+size_t gridmm_grid_aggregate_incremental_scratch(int B, int cap);
+int gridmm_grid_aggregate_incremental(const void* slab, const int32_t* perm, const int32_t* cell_start,
+                                      const void* text_frag, const int32_t* n_pts, const uint8_t* active, int n_new,
+                                      float* rel_hist, int32_t* rel_valid, void* scratch, float* cells, uint8_t* occ,
+                                      float* relevance, void* workspace, int B, int cap, int D, int L, int n_chunks,
+                                      int full, gridmm_stream_t stream);
+
 /* Compact non-empty cells to the front (cell order), add the position embedding, build the
  * key mask exactly as vilmodel.py:813-823 does (including its in-place view quirk).
  *   proj [B][196][H] f32 = grid_proj(cells)+bias; pos_emb [B][196][H] f32
