@@ -86,10 +86,10 @@ class GMapNavAgent:
         hipGraphs keyed by shape (graph.NavigationGraphs / PanoramaGraphs); the collator pads the node and view axes to
         buckets so that a rollout touches a handful of keys.  Same logits on the real rows (masked padding)."""
         from .collate import NavCollator
-        from .graph import NavigationGraphs, PanoramaGraphs
+        from .graph import LanguageGraphs, NavigationGraphs, PanoramaGraphs
         model = model if model is not None else getattr(self.vln_bert, "vln_bert", self.vln_bert)
         self.collator = NavCollator(self.args, self.device, node_buckets=self.NODE_BUCKETS, view_buckets=self.VIEW_BUCKETS)
-        self._graphs = (PanoramaGraphs(model), NavigationGraphs(model))
+        self._graphs = (PanoramaGraphs(model), NavigationGraphs(model), LanguageGraphs(model))
         self.fast_collate = True
 
     def _model_call(self, mode, batch):
@@ -100,6 +100,8 @@ class GMapNavAgent:
             if mode == "navigation":
                 out = self._graphs[1](batch)
                 return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()} if self.trace is not None else out
+            if mode == "language" and batch["txt_ids"].is_cuda:
+                return self._graphs[2](batch)
         return self.vln_bert(mode, batch)
 
     # ---- collation -----------------------------------------------------------------------------
@@ -302,8 +304,9 @@ class GMapNavAgent:
             tbatch, gmaps = None, [TopoMap(ob["viewpoint"]) for ob in obs]
         self.collator.reset(B)
         if self._graphs is not None:
+            tok = self._graphs[1].weights_token(self._graphs[1].model)
             for g in self._graphs:
-                g.validate()               # weights updated since the graphs were captured (training between evaluations)?
+                g.validate(tok)            # weights updated since the graphs were captured (training between evaluations)?
         if tbatch is not None:
             tbatch.observe_all(obs)
         else:
@@ -312,7 +315,7 @@ class GMapNavAgent:
         traj = [{"instr_id": ob["instr_id"], "path": [[ob["viewpoint"]]], "details": {}} for ob in obs]
 
         language_inputs = self._language_variable(obs)
-        txt_embeds = self.vln_bert("language", language_inputs)
+        txt_embeds = self._model_call("language", language_inputs)
         t0 = self._tick("language", t0)
 
         ended = np.array([False] * B)

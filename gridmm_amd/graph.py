@@ -252,8 +252,8 @@ class NavigationGraphs:
         hold the packed weight planes of the capture, so they must be dropped then (`validate`)."""
         return hash(tuple((p.data_ptr(), p._version) for p in model.parameters()))
 
-    def validate(self):
-        tok = self.weights_token(self.model)
+    def validate(self, tok=None):
+        tok = self.weights_token(self.model) if tok is None else tok    # (a caller with several graph sets computes it once)
         if tok != getattr(self, "_tok", None):
             self.graphs.clear()
             self._tok, self._early = tok, None
@@ -407,8 +407,8 @@ class PanoramaGraphs:
     def __init__(self, model):
         self.model, self.graphs, self.pool = model, {}, None
 
-    def validate(self):
-        tok = NavigationGraphs.weights_token(self.model)
+    def validate(self, tok=None):
+        tok = NavigationGraphs.weights_token(self.model) if tok is None else tok
         if tok != getattr(self, "_tok", None):
             self.graphs.clear()
             self._tok = tok
@@ -438,3 +438,50 @@ class PanoramaGraphs:
         _copy_all([ent["ins"][k] for k in self.KEYS], [batch[k] for k in self.KEYS])
         ent["graph"].replay()
         return ent["outs"]
+
+
+class LanguageGraphs:
+    """forward('language') (the 9-layer instruction encoder, vilmodel.py:730-734: ~100 launches, once per rollout) replayed
+    from one hipGraph per (B, L).  L is the batch's longest instruction exactly as the caller padded it: the relevance maximum
+    runs over padded columns too (vilmodel.py:798), so the axis is never re-padded here.  Returns a FRESH tensor per call (one
+    copy out of the static buffer): the per-episode caches downstream (NavigationGraphs' instruction cache, the grid memory's
+    kept relevance) recognise a new instruction by the identity of this tensor."""
+
+    def __init__(self, model, max_graphs=16):
+        self.model, self.graphs, self.pool, self.max_graphs = model, {}, None, max_graphs
+        self.captures = self.replays = 0
+
+    def validate(self, tok=None):
+        tok = NavigationGraphs.weights_token(self.model) if tok is None else tok
+        if tok != getattr(self, "_tok", None):
+            self.graphs.clear()
+            self._tok = tok
+
+    @torch.no_grad()
+    def __call__(self, batch):
+        ids, masks = batch["txt_ids"], batch["txt_masks"]
+        key = tuple(ids.shape)
+        ent = self.graphs.pop(key, None)
+        if ent is None:
+            ent = {"ids": ids.clone(), "masks": masks.clone()}
+            sb = {"txt_ids": ent["ids"], "txt_masks": ent["masks"]}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.model("language", sb)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode=CAPTURE_MODE):
+                ent["out"] = self.model("language", sb)
+            if self.pool is None:
+                self.pool = g.pool()
+            ent["graph"] = g
+            self.captures += 1
+            while len(self.graphs) >= self.max_graphs:
+                self.graphs.pop(next(iter(self.graphs)))
+        self.graphs[key] = ent                    # most recently used
+        _copy_all([ent["ids"], ent["masks"]], [ids, masks])
+        ent["graph"].replay()
+        self.replays += 1
+        return ent["out"].clone()

@@ -339,6 +339,12 @@ def test_rollout_with_graph_replay_equals_the_eager_rollout():
         assert not torch.isfinite(y["nav_outs"]["fused_logits"][:, x["nav_outs"]["fused_logits"].shape[1]:]).any()
     g = ga._graphs[1]
     assert g.replays == len(ga.trace) and g.captures < g.replays
+    lg = ga._graphs[2]                                    # forward('language') once per rollout, from a graph per (B, L)
+    assert lg.replays == 2 and 1 <= lg.captures <= 2
+    # D = 768 memory: the relevance of earlier observations is kept across the steps of an episode (cleared once per
+    # rollout: a new instruction tensor), in the eager run and under the graphs alike
+    for a in (ea, ga):
+        assert a.env.grid_memory._rel is not None and a.env.grid_memory._rel["clears"] == 2
     # an in-place weight update (an optimizer step between two evaluations): the captured graphs hold the packed weight
     # planes of their capture, so the next rollout must drop and re-capture them
     with torch.no_grad():
