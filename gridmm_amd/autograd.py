@@ -25,6 +25,7 @@ import torch
 
 from . import _lib, hostsync as hs, ops
 from .ops import _p, _rows2d, _stream
+from .pinned import upload_blob
 
 
 # ------------------------------------------------------------------------------------------------
@@ -413,7 +414,7 @@ def flush_param_grads():
                 rec["src"][i, k] = g.data_ptr()
             first[i + 1] = first[i] + (dst.numel() + 16383) // 16384
         blob = np.concatenate([rec.view(np.uint8).reshape(-1), first.view(np.uint8)])
-        d = torch.from_numpy(blob).pin_memory().to(dev, non_blocking=True)
+        d = upload_blob(blob, dev)                   # (pinned ring: no pinned allocation per call)
         _lib.check(lib.gridmm_multi_grad_accumulate(_p(d), ctypes.c_void_p(d.data_ptr() + rec.nbytes), len(part), int(first[-1]),
                                                     _stream()), "gridmm_multi_grad_accumulate")
         rnd += 1

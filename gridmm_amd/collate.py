@@ -49,6 +49,8 @@ class _Stager:
         return self.ring[self.pos]
 
     MAX_RING = 64
+    GROW = 8
+    _spare = ()
 
     def _begin_cycle(self):
         host, dev, ev = self._slot()
@@ -57,8 +59,11 @@ class _Stager:
             # device): a new slot here instead of a wait.  Inference rollouts read the action back every step, so their ring
             # of three never waits long and never grows (a pinned allocation costs milliseconds)
             n = host.numel()
-            self.ring.insert(self.pos, [torch.empty(n, dtype=torch.uint8).pin_memory(),
-                                        torch.empty(n, dtype=torch.uint8, device=self.device), None])
+            if not self._spare or self._spare[-1].numel() != n:
+                from .pinned import pinned_slots
+                self._spare = pinned_slots(n, min(self.GROW, self.MAX_RING - len(self.ring)))   # one pinned allocation for several slots
+            # (owned cycles never use the slot's device mirror: an empty placeholder until a recycled cycle needs it)
+            self.ring.insert(self.pos, [self._spare.pop(), None, None])
             host, dev, ev = self._slot()
         if ev is not None:
             ev.synchronize()                          # the copy issued from this slot `ring` flushes ago has completed
@@ -86,6 +91,8 @@ class _Stager:
         host, dev, _ = self._slot()
         if self._cycle_owned:
             dev = self._own
+        elif dev is None:                             # a slot added by an owned cycle: its mirror is made on first recycled use
+            dev = self.ring[self.pos][1] = torch.empty(host.numel(), dtype=torch.uint8, device=self.device)
         if n:
             host[o:o + n].view(t.dtype).view(t.shape).copy_(t)
         self.used = o + n
