@@ -374,7 +374,8 @@ def finetune_leg(args, dev, iters=3):
     env = SyntheticNavEnv(B, mem, n_scans=4, n_episodes=4 * B, seed=3, geom=geom, vocab=30000)
     env.build_device_store(dev)
     agent = GMapNavAgent(default_args(max_action_len=T, train_alg="imitation", lr=1e-5), env, model, device=dev)
-    agent.train(4)                            # one pass over the episode list: feature memo, weight packs, allocator
+    agent.train(8)                            # two passes over the episode list: feature memo, weight packs, allocator, and the
+    #                                           pinned upload rings at the size a loop that runs ahead of the device needs
     torch.cuda.synchronize()
     n0 = agent.nav_steps
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
