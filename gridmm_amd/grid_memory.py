@@ -153,6 +153,13 @@ class GridMemoryBatch:
             st["valid"].zero_()
             st["key"], st["slab"], st["alive"] = key, self.slab, keep_alive
             st["clears"] += 1
+            st["streak"] = st.get("streak", 0) + 1
+            if st["streak"] >= 4:
+                # a caller that hands over a NEW instruction tensor at every call (e.g. it re-runs forward('language') per
+                # step) gets nothing from keeping values and pays the two bookkeeping launches: back to the plain passes
+                self.relevance_cache_enabled = False
+        else:
+            st["streak"] = 0
         return st
 
     # ---- host half of a step: a few floats per episode into static (pinned -> device) buffers

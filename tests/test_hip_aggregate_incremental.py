@@ -148,3 +148,27 @@ def test_navigation_with_kept_relevance_equals_recompute_over_an_episode():
                 assert torch.equal(f, torch.isfinite(b)) and torch.equal(a[f], b[f]), (episode, t, k)
         assert mem_a._rel["clears"] == episode + 1 and mem_b._rel is None
         assert torch.equal(mem_a._rel["valid"], mem_a.n_pts)
+
+
+def test_a_caller_with_a_new_instruction_tensor_per_call_falls_back_to_the_plain_passes():
+    """Keeping values pays only when the instruction tensor persists over the steps of an episode: four calls in a row that each
+    bring a new tensor switch the memory back to gridmm_grid_aggregate (same results either way)."""
+    from gridmm_amd import synthetic as S
+    from gridmm_amd.grid_memory import GridMemoryBatch
+    model, batch = _native_model()
+    B = 3
+    rs = np.random.RandomState(3)
+    mem = GridMemoryBatch(B, S.NATIVE, max_steps=6)
+    ref = GridMemoryBatch(B, S.NATIVE, max_steps=6)
+    ref.relevance_cache_enabled = False
+    for t in range(6):
+        eps = [S.make_observations(rs, S.NATIVE, 1, feat_scale=0.35)[0] for _ in range(B)]
+        for m in (mem, ref):
+            m.step(np.stack([e["depth"].reshape(-1) for e in eps]), np.stack([e["feats"] for e in eps]),
+                   [(e["x"], e["y"]) for e in eps], [e["heading"] for e in eps])
+        txt = batch["txt_embeds"].clone()                       # same values, new tensor: the key cannot match
+        a, b = (model("navigation", dict(batch, txt_embeds=txt, grid_fts=None, grid_map=None, gridmap_pos_fts=None,
+                                         grid_memory=m)) for m in (mem, ref))
+        f = torch.isfinite(a["fused_logits"])
+        assert torch.equal(a["fused_logits"][f], b["fused_logits"][f])
+    assert mem.relevance_cache_enabled is False and mem._rel["clears"] == 4

@@ -150,6 +150,49 @@ def fuzz_aggregate(rs, n):
                 fail("aggregate", case, "episode %d max abs err %.3e (rc %d)" % (b, err, ops.LAST_AGGREGATE_RC))
 
 
+def fuzz_aggregate_incremental(rs, n):
+    """gridmm_grid_aggregate_incremental over random episodes: every step appends an observation to a random subset of the
+    episodes, re-draws every cell, and must equal gridmm_grid_aggregate on the same state bit for bit (cells, occupancy,
+    relevance by sorted position); sometimes the instruction changes (the caller clears `valid`) or a step takes the full form."""
+    import test_hip_aggregate_incremental as T
+    for _ in range(n):
+        D = int(rs.choice([256, 512, 768]))
+        L = int(rs.choice([5, 16, 20, 32, 80, 97, 120, 200, 300])) if D != 768 else int(rs.choice([5, 16, 40, 80, 96, 120, 200]))
+        if not ops.two_pass_aggregation(D, L):
+            continue
+        B = int(rs.choice([1, 2, 4]))
+        n_new = int(rs.choice([31, 64, 200, 588, 1000, 2100]))
+        steps = int(rs.choice([2, 3, 5]))
+        n_chunks = rs.choice([None, 1, 4, 8, 24])
+        n_chunks = None if n_chunks is None else int(n_chunks)
+        seed = int(rs.randint(1 << 30))
+        rng, g = np.random.default_rng(seed), torch.Generator().manual_seed(seed)
+        case = (D, L, B, n_new, steps, n_chunks, seed)
+        cap = n_new * steps
+        slab = torch.zeros(B, cap, D, dtype=torch.float16, device=DEV)
+        frag = ops.text_fragments((torch.randn(B, L, D, generator=g) * 0.3).to(DEV))
+        st = T._state(B, cap)
+        n_host = np.zeros(B, np.int64)
+        n_pts = torch.zeros(B, dtype=torch.int32, device=DEV)
+        invalid = rng.random((B, cap)) < 0.1
+        try:
+            for t in range(steps):
+                act = rng.random(B) < 0.8 if t else np.ones(B, bool)
+                for b in np.nonzero(act)[0]:
+                    slab[b, n_host[b]:n_host[b] + n_new] = (torch.randn(n_new, D, generator=g) * 0.5).half().to(DEV)
+                    n_host[b] += n_new
+                n_pts.copy_(torch.from_numpy(n_host.astype(np.int32)))
+                ids = rng.integers(0, 196, size=(B, cap))
+                ids[invalid] = -1
+                if rng.random() < 0.2:
+                    frag = ops.text_fragments((torch.randn(B, L, D, generator=g) * 0.3).to(DEV))
+                    st["valid"].zero_()
+                T._check(slab, torch.from_numpy(ids.astype(np.int16)).to(DEV), n_pts, frag, L, st,
+                         torch.from_numpy(act.astype(np.uint8)).to(DEV), n_new, n_chunks, full=bool(rng.random() < 0.15))
+        except AssertionError as e:
+            fail("agg_inc", case, "differs from gridmm_grid_aggregate at step %d: %r" % (t, e))
+
+
 def fuzz_nav(rs, n):
     """Whole forward('navigation') on a reduced model against the CPU oracle, random batch / graph / view / instruction
     sizes, list-form grid inputs, with and without varlen buckets."""
@@ -440,7 +483,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,nav,linear_bwd,attn_bwd,attn_train,agg_bwd,gridmap")
+    ap.add_argument("--only", default="gemm,attention,layernorm,aggregate,agg_inc,nav,linear_bwd,attn_bwd,attn_train,agg_bwd,gridmap")
     a = ap.parse_args()
     rs = np.random.RandomState(a.seed)
     table = {"gemm": fuzz_gemm, "attention": fuzz_attention, "layernorm": fuzz_layernorm, "aggregate": fuzz_aggregate,
@@ -448,7 +491,8 @@ def main():
              "attn_bwd": lambda r, n: fuzz_attention_bwd(r, max(4, n // 2)),
              "attn_train": lambda r, n: fuzz_attention_train(r, max(4, n // 2)),
              "agg_bwd": lambda r, n: fuzz_aggregate_bwd(r, max(4, n // 4)),
-             "gridmap": lambda r, n: fuzz_gridmap(r, max(4, n // 4))}
+             "gridmap": lambda r, n: fuzz_gridmap(r, max(4, n // 4)),
+             "agg_inc": lambda r, n: fuzz_aggregate_incremental(r, max(4, n // 2))}
     for name in a.only.split(","):
         before = len(FAILS)
         table[name](rs, a.cases)
