@@ -53,6 +53,32 @@ def test_graph_replay_equals_eager_at_bench_config(dev, t):
     assert chk["replay_vs_eager_max_abs"] <= 1e-6
 
 
+@pytest.mark.parametrize("t", [1, 4])
+def test_native_shape_replay_with_kept_relevance_equals_the_recompute(dev, t):
+    """bench.py --shape native (the reference's 12 x 49 x 768 observations, two-pass aggregation): the captured step with the
+    relevance of earlier observations kept beside the slab (gridmm_grid_aggregate_incremental inside the graph, every replay
+    restoring the same history prefix) gives the logits of the step that recomputes every point -- bit for bit -- and of its own
+    eager launches."""
+    import bench
+    outs = {}
+    for keep in (True, False):
+        a = _args(shape="native", mem_steps=t, batch=8, no_relevance_cache=not keep)
+        model, batch, mem, eps, step, eager_step, geom = bench.build_workload(a, dev)
+        assert mem.relevance_cache_enabled is keep and mem.relevance_cache_in_graphs is keep
+        for _ in range(3):
+            got = {k: v.clone() for k, v in step().items() if k in KEYS}
+        torch.cuda.synchronize()
+        assert (mem._rel is not None) is keep
+        chk = bench.check_replay(step, eager_step)
+        assert chk["bit_identical"]
+        outs[keep] = got
+        del model, batch, mem, step, eager_step
+        torch.cuda.empty_cache()
+    for k in KEYS:
+        f = torch.isfinite(outs[True][k])
+        assert torch.equal(f, torch.isfinite(outs[False][k])) and torch.equal(outs[True][k][f], outs[False][k][f]), k
+
+
 def test_graph_replay_matches_oracle_all_32_episodes(dev):
     """t = 1 (the headline depth), host-generated features: every episode's cell ids exact vs the NumPy oracle, all four
     logit sets within 1e-3 of oracle.forward_navigation on the same weights."""
