@@ -110,3 +110,37 @@ def test_navigation_graphs_fill_the_cache_once_per_instruction_tensor(dev):
         assert not torch.equal(ra["fused_logits"], outs[0][0]["fused_logits"])
     finally:
         model.varlen_buckets = None
+
+
+def test_language_graphs_equal_the_eager_encoder_and_return_fresh_tensors(dev):
+    """graph.LanguageGraphs (forward('language') of a rollout from a hipGraph per (B, L)): the same bits as the eager call for
+    every shape, a FRESH tensor per call (the per-episode caches downstream recognise a new instruction by the tensor's
+    identity), least-recently-used eviction beyond `max_graphs`, re-capture after an in-place weight update."""
+    from gridmm_amd.graph import LanguageGraphs
+    from gridmm_amd.vilmodel import GlocalTextPathNavCMT, default_config
+    torch.manual_seed(0)
+    model = GlocalTextPathNavCMT(default_config(num_l_layers=2, num_pano_layers=1, num_x_layers=1, intermediate_size=256,
+                                                vocab_size=500)).eval().to(dev)
+    lg = LanguageGraphs(model, max_graphs=2)
+    g = torch.Generator().manual_seed(1)
+    seen = []
+    for B, L in ((3, 17), (3, 40), (3, 17), (5, 17), (3, 40), (3, 17)):
+        ids = torch.randint(1, 500, (B, L), generator=g).to(dev)
+        lens = torch.randint(1, L + 1, (B,), generator=g)
+        lens[0] = L
+        masks = (torch.arange(L)[None] < lens[:, None]).to(dev)
+        lg.validate()
+        got = lg({"txt_ids": ids, "txt_masks": masks})
+        with torch.no_grad():
+            want = model("language", {"txt_ids": ids, "txt_masks": masks})
+        assert torch.equal(got, want), (B, L)
+        assert all(got.data_ptr() != t.data_ptr() for t in seen)
+        seen.append(got)
+    assert len(lg.graphs) == 2 and lg.replays == 6 and lg.captures == 5      # (3,17) hit once; evicted and re-captured later
+    with torch.no_grad():
+        model.embeddings.word_embeddings.weight.mul_(1.5)
+    lg.validate()
+    assert len(lg.graphs) == 0
+    got = lg({"txt_ids": ids, "txt_masks": masks})
+    with torch.no_grad():
+        assert torch.equal(got, model("language", {"txt_ids": ids, "txt_masks": masks}))
