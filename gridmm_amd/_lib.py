@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libgridmm_hip.so")
 # overrides and the whole experiment table of tile configurations.  Only the sweep tools ask for it (load(debug=True) or
 # GRIDMM_LIB_DEBUG=1 before the first load); the product path and the tests run on the shipping library, which has neither.
 DEBUG_LIB_PATH = os.path.join(_HERE, "libgridmm_hip_dbg.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 
@@ -30,6 +30,7 @@ SIGNATURES = {
     "gridmm_grid_bin": [_vp] * 10 + [_i, _i, _i, _vp],
     "gridmm_grid_bin_sliced": [_vp] * 11 + [_i, _i, _i, _i, _vp],
     "gridmm_grid_sort_ids": [_vp] * 4 + [_i, _i, _vp],
+    "gridmm_grid_cell_count_max": [_vp, _vp, _i, _vp],
     "gridmm_text_fragments": [_vp, _vp, _i, _i, _i, _vp],
     "gridmm_grid_aggregate_workspace": [_i, _i, _i],
     "gridmm_grid_aggregate": [_vp] * 8 + [_i, _i, _i, _i, _i, _vp],

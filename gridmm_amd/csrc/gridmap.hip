@@ -403,6 +403,28 @@ extern "C" int gridmm_grid_bin(const float* hist_x, const float* hist_y, const u
   return GRIDMM_OK;
 }
 
+namespace {
+// cmax[0] = max over the episodes of the number of non-empty cells (one workgroup: B x 196 comparisons, no atomics)
+__global__ __launch_bounds__(256) void cell_count_max_kernel(const int32_t* __restrict__ cell_start, int32_t* __restrict__ cmax,
+                                                             int B) {
+  int best = 0;
+  for (int b = 0; b < B; ++b) {
+    const int32_t* cs = cell_start + (size_t)b * (GRIDMM_CELLS + 2);
+    const int c = threadIdx.x;
+    const int n = __syncthreads_count(c < GRIDMM_CELLS && cs[c + 1] > cs[c]);
+    best = max(best, n);
+  }
+  if (threadIdx.x == 0) cmax[0] = best;
+}
+}  // namespace
+
+extern "C" int gridmm_grid_cell_count_max(const int32_t* cell_start, int32_t* cmax, int B, gridmm_stream_t stream) {
+  if (B <= 0 || !cell_start || !cmax) return GRIDMM_EINVAL;
+  GRIDMM_LAUNCH(cell_count_max_kernel, dim3(1), dim3(256), 0, as_stream(stream), cell_start, cmax, B);
+  GRIDMM_CHECK_LAUNCH();
+  return GRIDMM_OK;
+}
+
 extern "C" int gridmm_grid_sort_ids(const int16_t* cell_id, const int32_t* n_pts, int32_t* perm,
                                     int32_t* cell_start, int B, int cap, gridmm_stream_t stream) {
   if (B <= 0 || cap <= 0) return GRIDMM_EINVAL;

@@ -268,8 +268,7 @@ class GridMemoryBatch:
             # the batch's largest occupied-cell count (the reference's max_cell_num, vilmodel.py:809-823) goes to a pinned
             # word behind the binning kernels: by the time the caller has collated the navigation inputs it is on the host,
             # and the varlen path picks its sequence bucket without stalling the stream (cmax_hint)
-            cs = self.cell_start[:, :197]                 # 196 cell ranges (+ the invalid-point bin behind them)
-            self._cmax_dev.copy_((cs[:, 1:] > cs[:, :-1]).sum(1, dtype=torch.int32).max())
+            ops.grid_cell_count_max(self.cell_start, self._cmax_dev)      # one launch (was five torch ops per step)
             self._cmax_host.copy_(self._cmax_dev, non_blocking=True)
             self._cmax_event = torch.cuda.Event()
             self._cmax_event.record()

@@ -769,6 +769,15 @@ def grid_sort_ids(cell_id, n_pts, perm, cell_start):
                "gridmm_grid_sort_ids")
 
 
+def grid_cell_count_max(cell_start, out):
+    """out[0] = max over the batch of the number of non-empty cells (cell_start (B, 198) int32 as the binning wrote it)."""
+    lib = _lib.load()
+    assert cell_start.dtype == torch.int32 and cell_start.is_contiguous() and cell_start.shape[1] == N_CELLS + 2
+    _lib.check(lib.gridmm_grid_cell_count_max(_p(cell_start), _p(out), cell_start.shape[0], _stream()),
+               "gridmm_grid_cell_count_max")
+    return out
+
+
 def text_fragments(text_fts, out=None):
     """(B, L, D) fp32 -> MFMA B-fragment planes (fp16 hi|lo)."""
     lib = _lib.load()

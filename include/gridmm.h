@@ -93,6 +93,11 @@ int gridmm_grid_bin(const float* hist_x, const float* hist_y, const uint8_t* his
                     int B, int cap, int flags, gridmm_stream_t stream);
 /* (flags bit 0 = GRIDMM_FLAG_VLNCE: head_cs = cos/sin(-heading + pi) and map_x = -(tx cos + ty sin)) */
 
+/* cmax[0] = the batch's largest occupied-cell count after a binning call: the reference's max_cell_num
+ * (map_nav_src/models/vilmodel.py:809-823, a python max() over the batch), on the device in one launch so that a caller can
+ * fetch it with one small asynchronous copy behind the binning kernels.   cell_start [B][198] as gridmm_grid_bin wrote it. */
+int gridmm_grid_cell_count_max(const int32_t* cell_start, int32_t* cmax, int B, gridmm_stream_t stream);
+
 /* Same counting sort for caller-provided cell ids (the reference's `grid_map` list form,
  * map_nav_src/r2r/agent.py:168): ids are int16 in {-1, 0..195}. */
 int gridmm_grid_sort_ids(const int16_t* cell_id, const int32_t* n_pts, int32_t* perm,

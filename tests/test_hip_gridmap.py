@@ -188,3 +188,19 @@ def test_stage_extra_hands_out_disjoint_regions():
     assert h1.data_ptr() % 16 == 0
     with pytest.raises(ValueError):
         mem.stage_extra(mem.STAGE_EXTRA)
+
+
+def test_cell_count_max_equals_the_host_expression():
+    """gridmm_grid_cell_count_max: the batch's largest occupied-cell count (the reference's max_cell_num,
+    map_nav_src/models/vilmodel.py:809-823) from the binning's cell table in one launch."""
+    import torch
+    from gridmm_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for B in (1, 5, 32):
+        sizes = torch.randint(0, 4, (B, 197), generator=g) * (torch.rand(B, 197, generator=g) < 0.6)
+        cs = torch.zeros(B, 198, dtype=torch.int32)
+        cs[:, 1:] = torch.cumsum(sizes, 1).to(torch.int32)
+        want = int((cs[:, 1:197] > cs[:, :196]).sum(1).max())
+        out = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+        ops.grid_cell_count_max(cs.cuda().contiguous(), out)
+        assert int(out[0]) == want
