@@ -18,6 +18,7 @@ from types import SimpleNamespace
 
 import os
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -425,21 +426,28 @@ class GlocalTextPathNavCMT(nn.Module):
         """Integer form of the vpid-keyed python loops (vilmodel.py:884-899); host side."""
         B = len(gmap_vpids)
         vis = gmap_visited_masks.detach().cpu().numpy() if torch.is_tensor(gmap_visited_masks) else gmap_visited_masks
-        cand_of_node = torch.full((B, G), -2, dtype=torch.int32)
-        cand_visited = torch.zeros(B, V, dtype=torch.uint8)
+        vis = np.asarray(vis).tolist()
+        # rows as python lists, ONE array conversion at the end: an element-wise store into a torch tensor costs microseconds,
+        # and this runs on the host in front of every forward('navigation') that brings vpid lists (2 ms -> 0.1 ms at B = 32)
+        con = [[-2] * G for _ in range(B)]
+        cvis = [[0] * V for _ in range(B)]
         for i in range(B):
-            visited = set(vp for vp, m in zip(gmap_vpids[i], vis[i]) if m)
+            gv = gmap_vpids[i]
+            visited = set(vp for vp, m in zip(gv, vis[i]) if m)
             tmp = {}
+            row = cvis[i]
             for j, cv in enumerate(vp_cand_vpids[i]):
                 if j > 0:
                     if cv in visited:
-                        cand_visited[i, j] = 1
+                        row[j] = 1
                     else:
                         tmp[cv] = j
-            for j, vp in enumerate(gmap_vpids[i]):
+            row = con[i]
+            for j, vp in enumerate(gv):
                 if j > 0 and vp not in visited:
-                    cand_of_node[i, j] = tmp.get(vp, -1)
-        return cand_of_node, cand_visited
+                    row[j] = tmp.get(vp, -1)
+        return (torch.from_numpy(np.asarray(con, dtype=np.int32).reshape(B, G)),
+                torch.from_numpy(np.asarray(cvis, dtype=np.uint8).reshape(B, V)))
 
     def fusion_maps(self, batch, device):
         """Device tensors for batch['fusion_maps'] (integer form of the vpid-keyed fusion loops)."""
